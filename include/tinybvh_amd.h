@@ -1,0 +1,221 @@
+/*
+ * tinybvh_amd.h — C ABI of the MI355X (gfx950) batched ray-traversal engine.
+ *
+ * This is the drop-in boundary for the ONE hot path of jbikker/tinybvh that this
+ * repository accelerates: batched Intersect / IsOccluded over packed 64-byte rays on
+ * the GPU layouts that tiny_bvh.h builds on the host (BVH_GPU, BVH4_GPU, BVH8_CWBVH)
+ * and the TLAS wrapper around them.  Every entry point cites the reference interface
+ * it replaces (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - plain pointers and 64-bit sizes only; no C++/torch types; all sizes are element
+ *     counts unless the name says "bytes".
+ *   - every function returns 0 on success, a negative TBVH_E_* code on failure, and
+ *     never calls exit() (the reference's BVH_FATAL_ERROR_IF, tiny_bvh.h:1611-1620,
+ *     and tinyocl's FatalError, tiny_ocl.h:409-507, terminate the process; a library
+ *     behind an FFI must not).  tbvh_last_error() returns the message for the calling
+ *     thread's most recent failure.
+ *   - "blocks16" means units of 16 bytes (one bvhvec4), which is how the reference
+ *     counts BVH4_GPU::usedBlocks and BVH8_CWBVH::usedBlocks.
+ *   - a ray record is the first 64 bytes of tinybvh::Ray (tiny_bvh.h:689-709), equal to
+ *     the device struct Ray of traverse.cl:11-17:
+ *         off  0  O.xyz     12  mask(u32)
+ *         off 16  D.xyz     28  instIdx(u32)
+ *         off 32  rD.xyz    44  hit.inst (when INST_IDX_BITS==32) or pad
+ *         off 48  hit.t  52 hit.u  56 hit.v  60 hit.prim(u32)
+ *     Intersect reads O, D, rD and hit.t (= tmax) and writes bytes 48..63 only, and only
+ *     for rays that hit (a miss leaves the record untouched, like BVH::Intersect,
+ *     tiny_bvh.h:3247-3304 / 8524-8529).  TLAS queries also write hit.inst at byte 44.
+ *   - one tbvh_context per HIP device; contexts and the scenes created from them are
+ *     not thread-safe, different contexts are independent (the reference has a single
+ *     process-global OpenCL device, tiny_ocl.h:362-364).
+ */
+#ifndef TINYBVH_AMD_H_
+#define TINYBVH_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TBVH_ABI_VERSION 1
+
+/* error codes */
+#define TBVH_OK            0
+#define TBVH_E_INVALID    -1   /* bad argument (null pointer, bad stride, bad layout)   */
+#define TBVH_E_NODEVICE   -2   /* no usable HIP device / device index out of range      */
+#define TBVH_E_HIP        -3   /* a HIP runtime call failed; see tbvh_last_error()      */
+#define TBVH_E_NOMEM      -4   /* host or device allocation failed                      */
+#define TBVH_E_FORMAT     -5   /* blob failed validation (e.g. CWBVH root is a leaf)    */
+
+/* layouts; values follow BVHBase::BVHType (tiny_bvh.h:773-791) where one exists */
+#define TBVH_LAYOUT_BVH2_WALD  1  /* LAYOUT_BVH       32-byte nodes (host/oracle only)   */
+#define TBVH_LAYOUT_BVH_GPU    4  /* LAYOUT_BVH_GPU   Aila-Laine 64-byte nodes           */
+#define TBVH_LAYOUT_BVH4_GPU   6  /* LAYOUT_BVH4_GPU  quantized 4-wide + inline tris     */
+#define TBVH_LAYOUT_CWBVH      9  /* LAYOUT_CWBVH     compressed wide BVH8               */
+
+typedef struct tbvh_context tbvh_context;  /* one HIP device + stream + scratch          */
+typedef struct tbvh_scene   tbvh_scene;    /* one uploaded layout (BLAS or TLAS)         */
+typedef struct tbvh_hostbvh tbvh_hostbvh;  /* host-built blobs (see "host builder")      */
+
+/* ------------------------------------------------------------------------------------
+ * context — replaces tinyocl::Kernel::InitCL (tiny_ocl.h:945-1139)
+ * ---------------------------------------------------------------------------------- */
+int         tbvh_abi_version(void);
+const char* tbvh_last_error(void);
+int         tbvh_device_count(void);                     /* >=0, or TBVH_E_HIP           */
+int         tbvh_init(int device, tbvh_context** out);   /* explicit context per device  */
+void        tbvh_shutdown(tbvh_context* ctx);            /* frees scenes' device memory   */
+int         tbvh_synchronize(tbvh_context* ctx);
+/* Make subsequent launches of this context go to an external hipStream_t (e.g. the
+ * current torch stream); NULL restores the context's own stream. */
+int         tbvh_set_stream(tbvh_context* ctx, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------
+ * uploads — replace tinyocl::Buffer(bytes, hostPtr) + CopyToDevice()
+ * (tiny_ocl.h:571-691) as used by tiny_bvh_speedtest.cpp:1102-1108, 1153-1155,
+ * 1200-1206 and tiny_bvh_minimal_gpu.cpp:55-70.  Blobs are consumed verbatim in the
+ * reference's formats; the library may keep a re-laid-out copy internally.
+ * ---------------------------------------------------------------------------------- */
+
+/* BVH_GPU (Aila-Laine).  nodes64 = BVH_GPU::bvhNode (tiny_bvh.h:1095-1105), n_nodes =
+ * usedNodes; prim_idx = BVH_GPU::bvh.primIdx, n_idx = bvh.idxCount; verts = the caller's
+ * bvhvec4 vertex array (3 per triangle), n_tris = triCount. */
+int tbvh_upload_bvh_gpu(tbvh_context* ctx, const void* nodes64, uint64_t n_nodes,
+                        const uint32_t* prim_idx, uint64_t n_idx,
+                        const void* verts16, uint64_t n_tris, tbvh_scene** out);
+
+/* BVH4_GPU.  blocks16 = BVH4_GPU::bvh4Data, n_blocks = usedBlocks (tiny_bvh.h:1284-1286). */
+int tbvh_upload_bvh4_gpu(tbvh_context* ctx, const void* blocks16, uint64_t n_blocks,
+                         tbvh_scene** out);
+
+/* BVH8_CWBVH.  nodes16 = bvh8Data, n_node_blocks = usedBlocks (5 per node);
+ * tris16 = bvh8Tris, n_tri_blocks = 3 * idxCount (tiny_bvh.h:1356-1359;
+ * tiny_bvh_speedtest.cpp:1200-1204). */
+int tbvh_upload_cwbvh(tbvh_context* ctx, const void* nodes16, uint64_t n_node_blocks,
+                      const void* tris16, uint64_t n_tri_blocks, tbvh_scene** out);
+
+/* TLAS in BVH_GPU format over BLASInstance records (tiny_bvh.h:1443-1457, 192 bytes
+ * each) — replaces the uploads of tiny_bvh_gpu2.cpp:122-130.  blas[i] is the scene for
+ * BLASInstance::blasIdx == i.  tlas_idx = tlas.bvh.primIdx (instance indices). */
+int tbvh_upload_tlas(tbvh_context* ctx, const void* tlas_nodes64, uint64_t n_nodes,
+                     const uint32_t* tlas_idx, uint64_t n_idx,
+                     const void* instances192, uint64_t n_instances,
+                     tbvh_scene* const* blas, uint64_t n_blas, tbvh_scene** out);
+/* Per-frame TLAS refresh (same blobs, rebuilt on the host; tiny_bvh_gpu2.cpp:122-130). */
+int tbvh_update_tlas(tbvh_scene* tlas, const void* tlas_nodes64, uint64_t n_nodes,
+                     const uint32_t* tlas_idx, uint64_t n_idx,
+                     const void* instances192, uint64_t n_instances);
+
+void     tbvh_free_scene(tbvh_scene* scene);
+int      tbvh_scene_layout(const tbvh_scene* scene);
+uint64_t tbvh_scene_device_bytes(const tbvh_scene* scene);
+
+/* ------------------------------------------------------------------------------------
+ * queries — replace Kernel::SetArguments + Kernel::Run(count, 64) on batch_ailalaine /
+ * batch_gpu4way / batch_cwbvh (traverse_bvh2.cl:209-219, traverse_bvh4.cl:277-286,
+ * traverse_cwbvh.cl:554-570; tiny_bvh_speedtest.cpp:1117-1133) and the per-ray host API
+ * X::Intersect(Ray&) / X::IsOccluded(const Ray&).
+ * ---------------------------------------------------------------------------------- */
+
+/* Host ray arrays.  stride_bytes is 64 (packed) or 128 (a tinybvh::Ray[] passed in
+ * place); the first 64 bytes of each record are uploaded, traversed, and bytes 44..63
+ * copied back. */
+int tbvh_intersect(tbvh_scene* scene, void* rays, uint64_t n_rays, uint32_t stride_bytes);
+/* occluded[i] = 1 if anything lies in [0, hit.t] along ray i, else 0
+ * (BVH::IsOccluded, tiny_bvh.h:3382-3453; isoccluded_* in the .cl files). */
+int tbvh_occluded(tbvh_scene* scene, const void* rays, uint64_t n_rays,
+                  uint32_t stride_bytes, uint8_t* occluded);
+
+/* Device-resident packed rays (64-byte stride, 16-byte aligned).  Asynchronous on the
+ * context's stream; no host copies.  This is the timed path. */
+int tbvh_intersect_device(tbvh_scene* scene, void* d_rays64, uint64_t n_rays);
+int tbvh_occluded_device(tbvh_scene* scene, const void* d_rays64, uint64_t n_rays,
+                         uint8_t* d_occluded);
+
+/* HIP-event time of the most recent query kernel on this context, in milliseconds
+ * (mirrors the CL_PROFILING_COMMAND_START/END read of tiny_bvh_speedtest.cpp:1126-1131).
+ * Synchronizes the stream. */
+float tbvh_time_last_ms(tbvh_context* ctx);
+
+/* Kernel variant selection for experiments (0 = default).  Returns TBVH_E_INVALID for an
+ * unknown variant of the scene's layout. */
+int tbvh_set_variant(tbvh_scene* scene, int variant);
+
+/* ------------------------------------------------------------------------------------
+ * wavefront path-tracing helpers (device) — the ray generators of
+ * wavefront.cl:52-287 ("Generate" / "Shade" bounce) reduced to what the benchmark
+ * configurations need: primary rays from a pinhole camera in the speedtest's 4x4-tile
+ * order (tiny_bvh_speedtest.cpp:517-551), and diffuse-bounce / shadow rays derived from
+ * the hit records of a previous Intersect.
+ * ---------------------------------------------------------------------------------- */
+typedef struct tbvh_camera {
+    float eye[3];  float p1[3]; float p2[3]; float p3[3];  /* view pyramid corners      */
+    uint32_t width, height, spp_x, spp_y;                 /* pixels and samples/pixel   */
+} tbvh_camera;
+int tbvh_generate_primary_device(tbvh_context* ctx, const tbvh_camera* cam,
+                                 void* d_rays64, uint64_t first, uint64_t n_rays);
+/* For every ray i: if it hit (hit.t < 1e30), spawn a uniform random bounce in the hemisphere
+ * about the geometric normal of hit.prim (tiny_bvh_speedtest.cpp:567-586; RNG = xorshift32
+ * seeded by WangHash, tools.cl:9-11), origin I + 1e-3*R; missed rays spawn from O + 20*D.
+ * d_verts16 = device copy of the original vertex array (3 x 16 bytes per triangle).
+ * d_out may alias d_in. */
+int tbvh_generate_bounce_device(tbvh_context* ctx, const void* d_verts16,
+                                const void* d_in_rays64, void* d_out_rays64,
+                                uint64_t n_rays, uint32_t seed);
+/* Shadow rays from hit points toward light_pos with origin offset eps and
+ * tmax = dist - eps (tiny_bvh_speedtest.cpp:851-865). */
+int tbvh_generate_shadow_device(tbvh_context* ctx, const void* d_in_rays64,
+                                void* d_out_rays64, uint64_t n_rays,
+                                const float light_pos[3], float eps);
+
+/* ------------------------------------------------------------------------------------
+ * device buffers — replace tinyocl::Buffer for callers that keep rays resident
+ * (tiny_ocl.h:130-154, 571-708).  64-bit sizes (tinyocl::Buffer::size is 32-bit,
+ * tiny_ocl.h:152: 64 M rays x 64 B wraps to 0 there).
+ * ---------------------------------------------------------------------------------- */
+int tbvh_device_malloc(tbvh_context* ctx, uint64_t bytes, void** d_out);
+int tbvh_device_free(tbvh_context* ctx, void* d_ptr);
+int tbvh_copy_to_device(tbvh_context* ctx, void* d_dst, const void* src, uint64_t bytes);
+int tbvh_copy_from_device(tbvh_context* ctx, void* dst, const void* d_src, uint64_t bytes);
+
+/* ------------------------------------------------------------------------------------
+ * host builder — the blobs above normally come from the caller's own tiny_bvh.h
+ * (BVH_GPU::Build, BVH4_GPU::Build, BVH8_CWBVH::Build, tiny_bvh.h:4551-4560,
+ * 5059-5070, 5822-5835).  For callers without it (benchmarks on a box that only has
+ * this library) the same blob formats are produced by an independent binned-SAH
+ * builder + wide-BVH collapse + encoders.
+ * ---------------------------------------------------------------------------------- */
+typedef struct tbvh_build_params {
+    uint32_t bins;          /* SAH bins per axis; 0 = default (8, BVHBINS)               */
+    uint32_t max_leaf_tris; /* 0 = layout default (CWBVH 3, others 4)                   */
+    uint32_t threads;       /* 0 = hardware concurrency                                  */
+    uint32_t flags;         /* reserved, 0                                               */
+} tbvh_build_params;
+
+int tbvh_host_build(const void* verts16, uint64_t n_tris, int layout,
+                    const tbvh_build_params* params, tbvh_hostbvh** out);
+/* TLAS over instances192 (BLASInstance records whose transform[] and blasIdx are set);
+ * fills invTransform / aabbMin / aabbMax like BLASInstance::Update (tiny_bvh.h:8386-8427)
+ * from blas_bounds (6 floats per BLAS: min.xyz, max.xyz) and builds a BVH_GPU TLAS. */
+int tbvh_host_build_tlas(void* instances192, uint64_t n_instances,
+                         const float* blas_bounds6, uint64_t n_blas, tbvh_hostbvh** out);
+void     tbvh_host_free(tbvh_hostbvh* h);
+int      tbvh_host_layout(const tbvh_hostbvh* h);
+/* blob accessors; which = 0 nodes, 1 prim indices / triangles (layout dependent):
+ *   BVH2_WALD: 0 = 32-byte nodes, 1 = primIdx (u32)
+ *   BVH_GPU  : 0 = 64-byte nodes, 1 = primIdx (u32)
+ *   BVH4_GPU : 0 = 16-byte blocks
+ *   CWBVH    : 0 = node blocks (16 B, 5 per node), 1 = triangle blocks (16 B, 3 per tri) */
+const void* tbvh_host_blob(const tbvh_hostbvh* h, int which);
+uint64_t    tbvh_host_blob_count(const tbvh_hostbvh* h, int which); /* elements, see above */
+/* Convenience: upload a host-built BVH (verts16 needed for BVH_GPU only). */
+int tbvh_upload_host(tbvh_context* ctx, const tbvh_hostbvh* h, const void* verts16,
+                     uint64_t n_tris, tbvh_scene** out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYBVH_AMD_H_ */

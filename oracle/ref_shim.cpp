@@ -1,0 +1,251 @@
+// ref_shim.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// A thin extern "C" wrapper around the REAL reference (jbikker/tinybvh, tiny_bvh.h),
+// compiled from the sources where they lie (-I$(REFERENCE), default /root/reference) into
+// oracle/_ref/libtinybvh_ref.so by oracle/Makefile.  No reference source is copied into
+// this repository; this file only calls the reference's public API.  It is used to
+//   (1) pin the C restatement in tbvh_oracle.c against BVH::Intersect / IsOccluded,
+//   (2) hand reference-BUILT blobs (BVH_GPU / BVH4_GPU / BVH8_CWBVH, Build and BuildHQ) to
+//       the HIP kernels, which is the real drop-in situation,
+//   (3) time the reference's BVH8_CPU (AVX2) path as bench.py's cpu_baseline ("reference").
+// The .so travels to the GPU box inside the repo snapshot; /root/reference does not.
+#define TINYBVH_IMPLEMENTATION
+#include "tiny_bvh.h"
+
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+using namespace tinybvh;
+
+static_assert(sizeof(Ray) == 128, "host Ray is 128 bytes (SURVEY.md §2a)");
+static_assert(sizeof(BLASInstance) == 192, "BLASInstance is 192 bytes");
+static_assert(INST_IDX_BITS == 32, "shim assumes the default INST_IDX_BITS");
+
+namespace {
+
+struct RefScene {
+    bvhvec4* verts = nullptr;  // owned copy, 64-byte aligned
+    uint32_t triCount = 0;
+    bool hq = false;
+    BVH bvh;                   // the oracle tree (Build or BuildHQ)
+    BVH_GPU* gpu2 = nullptr;
+    BVH4_GPU* gpu4 = nullptr;
+    BVH8_CWBVH* cw = nullptr;
+    BVH8_CPU* cpu8 = nullptr;
+};
+
+struct RefTlas {
+    std::vector<BLASInstance> inst;
+    std::vector<BVHBase*> blas;
+    BVH tlas;
+    BVH_GPU* tlasGpu = nullptr;
+};
+
+// device ray (64 B) -> host Ray: the first 64 bytes of tinybvh::Ray are the device record
+// (offsets checked in SURVEY.md §2a [probe] and by the static_asserts in ref_selfcheck()).
+inline void load(Ray& r, const char* src) { std::memset((void*)&r, 0, sizeof(Ray)); std::memcpy((void*)&r, src, 64); }
+inline void store(char* dst, const Ray& r) { std::memcpy(dst + 44, (const char*)&r + 44, 20); }
+
+template <class F> void forRays(void* rays, uint64_t n, uint32_t stride, F f) {
+    char* p = (char*)rays;
+    for (uint64_t i = 0; i < n; i++, p += stride) { Ray r; load(r, p); f(r); store(p, r); }
+}
+
+}  // namespace
+
+extern "C" {
+
+int ref_selfcheck() {
+    Ray r;
+    const char* b = (const char*)&r;
+    if ((const char*)&r.O != b || (const char*)&r.mask != b + 12) return 1;
+    if ((const char*)&r.D != b + 16 || (const char*)&r.instIdx != b + 28) return 2;
+    if ((const char*)&r.rD != b + 32 || (const char*)&r.hit.inst != b + 44) return 3;
+    if ((const char*)&r.hit.t != b + 48 || (const char*)&r.hit.prim != b + 60) return 4;
+    return 0;
+}
+
+const char* ref_version() {
+    static char v[64];
+    snprintf(v, sizeof v, "tinybvh %d.%d.%d", TINY_BVH_VERSION_MAJOR, TINY_BVH_VERSION_MINOR, TINY_BVH_VERSION_SUB);
+    return v;
+}
+
+// Build the oracle BVH (BVH::Build, tiny_bvh.h:2124; or BVH::BuildHQ, 2623).
+// threaded = 0 forces single-threaded builds for byte-stable output.
+void* ref_build(const void* verts16, uint32_t triCount, int hq, int threaded) {
+    RefScene* s = new RefScene;
+    s->triCount = triCount; s->hq = hq != 0;
+    s->verts = (bvhvec4*)malloc64((size_t)triCount * 48);
+    std::memcpy((void*)s->verts, verts16, (size_t)triCount * 48);
+    s->bvh.threadedBuild = threaded != 0;
+    if (hq) s->bvh.BuildHQ(s->verts, triCount); else s->bvh.Build(s->verts, triCount);
+    return s;
+}
+void ref_free(void* h) {
+    RefScene* s = (RefScene*)h;
+    delete s->gpu2; delete s->gpu4; delete s->cw; delete s->cpu8;
+    free64(s->verts);
+    delete s;
+}
+
+// Convert to a GPU layout with the reference's own converter.  Each layout object builds
+// its own tree with the same builder (Build/BuildHQ) the way tiny_bvh_speedtest.cpp does
+// (:1098-1099, 1149-1150, 1196-1197).
+static void ensureLayout(RefScene* s, int layout) {
+    if (layout == 4 && !s->gpu2) { s->gpu2 = new BVH_GPU(); if (s->hq) s->gpu2->BuildHQ(s->verts, s->triCount); else s->gpu2->Build(s->verts, s->triCount); }
+    if (layout == 6 && !s->gpu4) { s->gpu4 = new BVH4_GPU(); if (s->hq) s->gpu4->BuildHQ(s->verts, s->triCount); else s->gpu4->Build(s->verts, s->triCount); }
+    if (layout == 9 && !s->cw) { s->cw = new BVH8_CWBVH(); if (s->hq) s->cw->BuildHQ(s->verts, s->triCount); else s->cw->Build(s->verts, s->triCount); }
+    if (layout == 8 && !s->cpu8) { s->cpu8 = new BVH8_CPU(); if (s->hq) s->cpu8->BuildHQ(s->verts, s->triCount); else s->cpu8->Build(s->verts, s->triCount); }
+}
+
+// Blob access.  layout: 1 = BVH (Wald), 4 = BVH_GPU, 6 = BVH4_GPU, 9 = CWBVH.
+// which: 0 = nodes / blocks, 1 = primIdx (layouts 1, 4) or triangle blocks (layout 9).
+// Returns element count; *out receives the pointer (owned by the scene).
+uint64_t ref_blob(void* h, int layout, int which, const void** out) {
+    RefScene* s = (RefScene*)h;
+    ensureLayout(s, layout);
+    switch (layout) {
+    case 1:
+        if (which == 0) { *out = s->bvh.bvhNode; return s->bvh.usedNodes; }
+        *out = s->bvh.primIdx; return s->bvh.idxCount;
+    case 4:
+        if (which == 0) { *out = s->gpu2->bvhNode; return s->gpu2->usedNodes; }
+        *out = s->gpu2->bvh.primIdx; return s->gpu2->bvh.idxCount;
+    case 6:
+        *out = s->gpu4->bvh4Data; return s->gpu4->usedBlocks;
+    case 9:
+        if (which == 0) { *out = s->cw->bvh8Data; return s->cw->usedBlocks; }
+        *out = s->cw->bvh8Tris; return (uint64_t)s->cw->bvh8.idxCount * 3;
+    }
+    *out = nullptr; return 0;
+}
+const void* ref_verts(void* h) { return ((RefScene*)h)->verts; }
+
+// Per-ray queries through the reference's own traversal code.
+// layout 1: BVH::Intersect (THE oracle, tiny_bvh.h:3222); 4/6/9: the CPU mirrors of the GPU
+// layouts (4657 / 5252 / 7046); 8: BVH8_CPU::Intersect (7188).
+int ref_intersect(void* h, int layout, void* rays, uint64_t n, uint32_t stride) {
+    RefScene* s = (RefScene*)h;
+    ensureLayout(s, layout);
+    switch (layout) {
+    case 1: forRays(rays, n, stride, [&](Ray& r) { s->bvh.Intersect(r); }); return 0;
+    case 4: forRays(rays, n, stride, [&](Ray& r) { s->gpu2->Intersect(r); }); return 0;
+    case 6: forRays(rays, n, stride, [&](Ray& r) { s->gpu4->Intersect(r); }); return 0;
+    case 9: forRays(rays, n, stride, [&](Ray& r) { s->cw->Intersect(r); }); return 0;
+    case 8: forRays(rays, n, stride, [&](Ray& r) { s->cpu8->Intersect(r); }); return 0;
+    }
+    return -1;
+}
+int ref_occluded(void* h, int layout, const void* rays, uint64_t n, uint32_t stride, uint8_t* out) {
+    RefScene* s = (RefScene*)h;
+    ensureLayout(s, layout);
+    const char* p = (const char*)rays;
+    for (uint64_t i = 0; i < n; i++, p += stride) {
+        Ray r; load(r, p);
+        bool o;
+        if (layout == 1) o = s->bvh.IsOccluded(r);
+        else if (layout == 8) o = s->cpu8->IsOccluded(r);
+        else return -1;
+        out[i] = o ? 1 : 0;
+    }
+    return 0;
+}
+
+// Node / triangle visit counts from the reference CPU mirrors: c_trav = 1024, c_int = 1
+// (SURVEY.md §5 trick).  layouts 1, 4, 6 only (the CWBVH mirror returns 0).
+int ref_counts(void* h, int layout, const void* rays, uint64_t n, uint32_t stride, uint64_t* steps, uint64_t* tris) {
+    RefScene* s = (RefScene*)h;
+    ensureLayout(s, layout);
+    BVHBase* b = layout == 1 ? (BVHBase*)&s->bvh : layout == 4 ? (BVHBase*)s->gpu2 : layout == 6 ? (BVHBase*)s->gpu4 : nullptr;
+    if (!b) return -1;
+    const float ct = b->c_trav, ci = b->c_int;
+    b->c_trav = 65536.0f; b->c_int = 1.0f;
+    uint64_t S = 0, T = 0;
+    const char* p = (const char*)rays;
+    for (uint64_t i = 0; i < n; i++, p += stride) {
+        Ray r; load(r, p);
+        int32_t c = layout == 1 ? s->bvh.Intersect(r) : layout == 4 ? s->gpu2->Intersect(r) : s->gpu4->Intersect(r);
+        S += (uint32_t)c >> 16; T += (uint32_t)c & 65535;
+    }
+    b->c_trav = ct; b->c_int = ci;
+    *steps = S; *tris = T;
+    return 0;
+}
+
+// Timed multi-threaded baseline with the speedtest's dynamic batch scheme: 10 000-ray
+// batches handed out through an atomic counter (tiny_bvh_speedtest.cpp:392-401,
+// 1077-1083).  layout 8 = BVH8_CPU (AVX2), 1 = BVH::Intersect.  shadow != 0 times
+// IsOccluded.  Rays are 64-byte records; each thread expands them to host Rays in
+// batches *outside* nothing — the expansion is part of what a caller holding packed rays
+// would pay, but it is small (64-byte copy) next to traversal.  Returns seconds.
+double ref_time_mt(void* h, int layout, const void* rays, uint64_t n, uint32_t stride, int threads, int shadow, uint64_t* hits) {
+    RefScene* s = (RefScene*)h;
+    ensureLayout(s, layout);
+    if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+    // expand once, untimed (the speedtest times traversal over pre-built Ray arrays)
+    Ray* R = (Ray*)malloc64(n * sizeof(Ray));
+    const char* p = (const char*)rays;
+    for (uint64_t i = 0; i < n; i++, p += stride) load(R[i], p);
+    std::atomic<uint64_t> next{0}, hitCount{0};
+    auto work = [&]() {
+        uint64_t local = 0;
+        for (;;) {
+            const uint64_t b = next.fetch_add(10000);
+            if (b >= n) break;
+            const uint64_t e = b + 10000 < n ? b + 10000 : n;
+            if (shadow) {
+                if (layout == 8) for (uint64_t i = b; i < e; i++) local += s->cpu8->IsOccluded(R[i]);
+                else for (uint64_t i = b; i < e; i++) local += s->bvh.IsOccluded(R[i]);
+            } else {
+                if (layout == 8) for (uint64_t i = b; i < e; i++) s->cpu8->Intersect(R[i]);
+                else for (uint64_t i = b; i < e; i++) s->bvh.Intersect(R[i]);
+                for (uint64_t i = b; i < e; i++) local += R[i].hit.t < BVH_FAR;
+            }
+        }
+        hitCount += local;
+    };
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; t++) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+    const double sec = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    if (hits) *hits = hitCount.load();
+    free64(R);
+    return sec;
+}
+
+// ---- TLAS (BVH::Build(BLASInstance*...), tiny_bvh.h:2221-2259; IntersectTLAS 3306-3380) ----
+// instances192: BLASInstance records with transform[] and blasIdx set; blasScenes[i] are
+// RefScene handles (their BVH::bvh is the BLAS, LAYOUT_BVH as the CPU TLAS requires).
+void* ref_tlas_build(void* instances192, uint32_t nInst, void** blasScenes, uint32_t nBlas) {
+    RefTlas* t = new RefTlas;
+    t->inst.resize(nInst);
+    std::memcpy((void*)t->inst.data(), instances192, (size_t)nInst * 192);
+    for (uint32_t i = 0; i < nBlas; i++) t->blas.push_back(&((RefScene*)blasScenes[i])->bvh);
+    t->tlas.Build(t->inst.data(), nInst, t->blas.data(), nBlas);
+    std::memcpy(instances192, (void*)t->inst.data(), (size_t)nInst * 192);  // hand back updated records
+    return t;
+}
+void ref_tlas_free(void* h) { RefTlas* t = (RefTlas*)h; delete t->tlasGpu; delete t; }
+int ref_tlas_intersect(void* h, void* rays, uint64_t n, uint32_t stride) {
+    RefTlas* t = (RefTlas*)h;
+    forRays(rays, n, stride, [&](Ray& r) { t->tlas.Intersect(r); });
+    return 0;
+}
+// TLAS blobs in BVH_GPU format (BVH_GPU::Build(BLASInstance*...), tiny_bvh.h:4575-4581).
+uint64_t ref_tlas_blob(void* h, int which, const void** out) {
+    RefTlas* t = (RefTlas*)h;
+    if (!t->tlasGpu) { t->tlasGpu = new BVH_GPU(); t->tlasGpu->ConvertFrom(t->tlas, false); }
+    if (which == 0) { *out = t->tlasGpu->bvhNode; return t->tlasGpu->usedNodes; }
+    if (which == 1) { *out = t->tlas.primIdx; return t->tlas.idxCount; }
+    if (which == 2) { *out = t->tlas.bvhNode; return t->tlas.usedNodes; }
+    *out = nullptr; return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+"""pytest configuration: the `gpu` marker, and shared fixtures for the checkers."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_available() -> bool:
+    try:
+        import tinybvh_amd as tb
+        return tb.device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _gpu_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle_lib import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def reference():
+    from oracle_lib import Reference, have_reference
+    if not have_reference():
+        pytest.skip("oracle/_ref/libtinybvh_ref.so not built (needs the reference checkout at build time)")
+    return Reference()
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    import tinybvh_amd as tb
+    c = tb.Context(0)
+    yield c
+    c.close()

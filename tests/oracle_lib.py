@@ -1,0 +1,186 @@
+"""Loaders for the CHECKERS under oracle/ (test infrastructure): the plain-C restatement
+(oracle/liborc.so) and, when present, the real reference behind its C shim
+(oracle/_ref/libtinybvh_ref.so).  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORC_PATH = os.path.join(ROOT, "oracle", "liborc.so")
+REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libtinybvh_ref.so")
+
+_vp, _u64, _u32 = C.c_void_p, C.c_uint64, C.c_uint32
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else C.c_void_p(0)
+
+
+def build_oracle():
+    if not os.path.exists(ORC_PATH) or os.path.getmtime(ORC_PATH) < os.path.getmtime(os.path.join(ROOT, "oracle", "tbvh_oracle.c")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "liborc.so"], stdout=subprocess.DEVNULL)
+
+
+class Oracle:
+    """The C restatement.  All functions take/return numpy arrays of RAY_DTYPE records."""
+
+    def __init__(self):
+        build_oracle()
+        self.lib = C.CDLL(ORC_PATH)
+        L = self.lib
+        L.orc_bvh2_intersect.argtypes = [_vp, _vp, _vp, _vp, _u64, _u32, _vp]
+        L.orc_bvh2_occluded.argtypes = [_vp, _vp, _vp, _vp, _u64, _u32, _vp]
+        L.orc_bvhgpu_intersect.argtypes = [_vp, _vp, _vp, _vp, _u64, _u32, _vp]
+        L.orc_bvh4_intersect.argtypes = [_vp, _vp, _u64, _u32, _vp]
+        L.orc_cwbvh_intersect.argtypes = [_vp, _vp, _vp, _u64, _u32, _vp]
+        L.orc_tlas_intersect.argtypes = [_vp, _vp, _vp, _vp, _vp, _u64, _u32]
+        for f in (L.orc_bvh2_intersect, L.orc_bvh2_occluded, L.orc_bvhgpu_intersect, L.orc_bvh4_intersect, L.orc_cwbvh_intersect, L.orc_tlas_intersect):
+            f.restype = None
+
+    @staticmethod
+    def _prep(rays):
+        r = np.ascontiguousarray(rays).copy()
+        return r
+
+    def bvh2_intersect(self, nodes32, prim_idx, verts, rays, counts=False):
+        r = self._prep(rays)
+        c = np.zeros(2, np.uint64) if counts else None
+        self.lib.orc_bvh2_intersect(_p(nodes32), _p(prim_idx), _p(verts), _p(r), r.shape[0], r.strides[0], _p(c))
+        return (r, c) if counts else r
+
+    def bvh2_occluded(self, nodes32, prim_idx, verts, rays):
+        r = np.ascontiguousarray(rays)
+        out = np.zeros(r.shape[0], np.uint8)
+        self.lib.orc_bvh2_occluded(_p(nodes32), _p(prim_idx), _p(verts), _p(r), r.shape[0], r.strides[0], _p(out))
+        return out
+
+    def bvhgpu_intersect(self, nodes64, prim_idx, verts, rays, counts=False):
+        r = self._prep(rays)
+        c = np.zeros(2, np.uint64) if counts else None
+        self.lib.orc_bvhgpu_intersect(_p(nodes64), _p(prim_idx), _p(verts), _p(r), r.shape[0], r.strides[0], _p(c))
+        return (r, c) if counts else r
+
+    def bvh4_intersect(self, blocks16, rays, counts=False):
+        r = self._prep(rays)
+        c = np.zeros(2, np.uint64) if counts else None
+        self.lib.orc_bvh4_intersect(_p(blocks16), _p(r), r.shape[0], r.strides[0], _p(c))
+        return (r, c) if counts else r
+
+    def cwbvh_intersect(self, nodes16, tris16, rays, counts=False):
+        r = self._prep(rays)
+        c = np.zeros(2, np.uint64) if counts else None
+        self.lib.orc_cwbvh_intersect(_p(nodes16), _p(tris16), _p(r), r.shape[0], r.strides[0], _p(c))
+        return (r, c) if counts else r
+
+
+def have_reference() -> bool:
+    return os.path.exists(REF_PATH)
+
+
+class Reference:
+    """The real tiny_bvh.h behind oracle/ref_shim.cpp."""
+
+    def __init__(self):
+        self.lib = C.CDLL(REF_PATH)
+        L = self.lib
+        L.ref_selfcheck.restype = C.c_int
+        L.ref_version.restype = C.c_char_p
+        L.ref_build.restype = _vp; L.ref_build.argtypes = [_vp, _u32, C.c_int, C.c_int]
+        L.ref_free.argtypes = [_vp]; L.ref_free.restype = None
+        L.ref_blob.restype = _u64; L.ref_blob.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(_vp)]
+        L.ref_verts.restype = _vp; L.ref_verts.argtypes = [_vp]
+        L.ref_intersect.restype = C.c_int; L.ref_intersect.argtypes = [_vp, C.c_int, _vp, _u64, _u32]
+        L.ref_occluded.restype = C.c_int; L.ref_occluded.argtypes = [_vp, C.c_int, _vp, _u64, _u32, _vp]
+        L.ref_counts.restype = C.c_int; L.ref_counts.argtypes = [_vp, C.c_int, _vp, _u64, _u32, C.POINTER(_u64), C.POINTER(_u64)]
+        L.ref_time_mt.restype = C.c_double; L.ref_time_mt.argtypes = [_vp, C.c_int, _vp, _u64, _u32, C.c_int, C.c_int, C.POINTER(_u64)]
+        L.ref_tlas_build.restype = _vp; L.ref_tlas_build.argtypes = [_vp, _u32, C.POINTER(_vp), _u32]
+        L.ref_tlas_free.argtypes = [_vp]; L.ref_tlas_free.restype = None
+        L.ref_tlas_intersect.restype = C.c_int; L.ref_tlas_intersect.argtypes = [_vp, _vp, _u64, _u32]
+        L.ref_tlas_blob.restype = _u64; L.ref_tlas_blob.argtypes = [_vp, C.c_int, C.POINTER(_vp)]
+        assert L.ref_selfcheck() == 0, "tinybvh::Ray layout differs from the 64-byte record"
+
+    def build(self, verts, hq=False, threaded=False):
+        return RefScene(self, verts, hq, threaded)
+
+
+class RefScene:
+    def __init__(self, ref: Reference, verts, hq, threaded):
+        self.ref = ref
+        self.verts = np.ascontiguousarray(verts, np.float32).reshape(-1, 4)
+        self.h = ref.lib.ref_build(_p(self.verts), self.verts.shape[0] // 3, int(hq), int(threaded))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ref.lib.ref_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def blob(self, layout, which, dtype, width):
+        p = _vp()
+        n = self.ref.lib.ref_blob(self.h, layout, which, C.byref(p))
+        nbytes = n * np.dtype(dtype).itemsize * width
+        if not p.value or not n:
+            return np.zeros((0, width), dtype)
+        return np.frombuffer((C.c_char * nbytes).from_address(p.value), dtype=dtype).reshape(n, width).copy()
+
+    def intersect(self, layout, rays):
+        r = np.ascontiguousarray(rays).copy()
+        assert self.ref.lib.ref_intersect(self.h, layout, _p(r), r.shape[0], r.strides[0]) == 0
+        return r
+
+    def occluded(self, layout, rays):
+        r = np.ascontiguousarray(rays)
+        out = np.zeros(r.shape[0], np.uint8)
+        assert self.ref.lib.ref_occluded(self.h, layout, _p(r), r.shape[0], r.strides[0], _p(out)) == 0
+        return out
+
+    def counts(self, layout, rays):
+        r = np.ascontiguousarray(rays)
+        s, t = _u64(), _u64()
+        assert self.ref.lib.ref_counts(self.h, layout, _p(r), r.shape[0], r.strides[0], C.byref(s), C.byref(t)) == 0
+        return s.value, t.value
+
+    def time_mt(self, layout, rays, threads=0, shadow=False):
+        r = np.ascontiguousarray(rays)
+        hits = _u64()
+        sec = self.ref.lib.ref_time_mt(self.h, layout, _p(r), r.shape[0], r.strides[0], threads, int(shadow), C.byref(hits))
+        return sec, hits.value
+
+
+# ---- comparison with the parity contract -----------------------------------------------------------
+
+def compare_hits(got: np.ndarray, want: np.ndarray, rtol: float = 1e-5):
+    """Per-ray comparison of hit records under the contract of BASELINE.json: hit/miss and
+    prim exact, t/u/v within rtol (relative for t, absolute-on-[0,1] for u,v).  Returns a dict
+    of counts.  'tie' = prim differs while t agrees to rtol (exact-distance ties resolve by
+    visit order in the reference itself, SURVEY.md §7 "Bit-exact prim")."""
+    far = np.float32(1e30)
+    gh, wh = got["t"] < far, want["t"] < far
+    # a ray that came in with a finite tmax and missed keeps it; compare on "record changed"
+    res = {"n": int(got.shape[0]), "hits": int(wh.sum())}
+    res["hitmiss"] = int((gh != wh).sum())
+    both = gh & wh
+    dt = np.abs(got["t"][both].astype(np.float64) - want["t"][both].astype(np.float64))
+    rel = dt / np.maximum(np.abs(want["t"][both].astype(np.float64)), 1e-30)
+    same_prim = got["prim"][both] == want["prim"][both]
+    close_t = rel <= rtol
+    res["prim_mismatch"] = int((~same_prim).sum())
+    res["tie"] = int((~same_prim & close_t).sum())
+    res["prim_real"] = int((~same_prim & ~close_t).sum())
+    res["t_bad"] = int((same_prim & ~close_t).sum())
+    sp = same_prim
+    du = np.abs(got["u"][both][sp].astype(np.float64) - want["u"][both][sp].astype(np.float64))
+    dv = np.abs(got["v"][both][sp].astype(np.float64) - want["v"][both][sp].astype(np.float64))
+    res["max_rel_t"] = float(rel[same_prim].max()) if same_prim.any() else 0.0
+    res["max_abs_uv"] = float(max(du.max(), dv.max())) if sp.any() else 0.0
+    res["uv_bad"] = int(((du > 1e-5 * 10) | (dv > 1e-5 * 10)).sum()) if sp.any() else 0
+    res["bit_identical"] = int((got["t"][both].view(np.uint32) == want["t"][both].view(np.uint32)).sum())
+    return res

@@ -1,0 +1,162 @@
+"""Parity of the HIP kernels (through the C ABI) with the oracle, ray by ray.
+
+Contract (BASELINE.json north_star): hit/miss and triIdx exact, t/u/v within 1e-5 relative.
+The kernels share the oracle's triangle arithmetic bit for bit, so we assert the stronger
+statement: t, u, v bit-identical wherever prim agrees, and prim may differ only on exact-t
+ties (equal float t from two triangles, resolved by visit order — the reference's own layouts
+have this floor).
+"""
+import numpy as np
+import pytest
+
+import tinybvh_amd as tb
+from tinybvh_amd import rays as R
+from tinybvh_amd import scenes
+from oracle_lib import compare_hits, have_reference
+
+pytestmark = pytest.mark.gpu
+
+LAYOUTS = [tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU, tb.LAYOUT_CWBVH]
+
+
+def upload(ctx, layout, verts):
+    return tb.LAYOUT_CLASSES[layout](ctx).Build(verts)
+
+
+def oracle_hits(oracle, scene, verts, rays):
+    h = scene.host
+    return oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
+
+
+def assert_parity(got, want, allow_ties=True):
+    c = compare_hits(got, want, rtol=1e-5)
+    assert c["hitmiss"] == 0, c
+    assert c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
+    if not allow_ties:
+        assert c["prim_mismatch"] == 0, c
+    # exact-tie prim swaps must stay at the noise floor
+    assert c["tie"] <= max(2, c["hits"] // 20000), c
+    # same triangle => bit-identical t,u,v (same arithmetic as the oracle)
+    both = (got["t"] < 1e30) & (want["t"] < 1e30) & (got["prim"] == want["prim"])
+    for f in ("t", "u", "v"):
+        assert np.array_equal(got[f][both].view(np.uint32), want[f][both].view(np.uint32)), f
+    # misses leave the record untouched
+    miss = want["t"] >= 1e30
+    for f in ("t", "u", "v", "prim"):
+        assert np.array_equal(got[f][miss], want[f][miss]), f
+    return c
+
+
+@pytest.fixture(scope="module")
+def soup():
+    return scenes.soup(8192, seed=7)
+
+
+@pytest.fixture(scope="module")
+def atrium_small():
+    return scenes.atrium(60_000, seed=1)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_soup_random_rays(ctx, oracle, soup, layout):
+    sc = upload(ctx, layout, soup)
+    rays = R.random_rays(20_000, (-2, -2, -2), (12, 12, 12), seed=3)
+    want = oracle_hits(oracle, sc, soup, rays)
+    got = sc.Intersect(rays.copy())
+    c = assert_parity(got, want)
+    assert c["hits"] > 1000
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_atrium_primary_and_bounce(ctx, oracle, atrium_small, layout):
+    verts = atrium_small
+    sc = upload(ctx, layout, verts)
+    eye, view = scenes.SPONZA_CAMERAS[0]
+    cam = R.camera(eye, view, 160, 96, 2, 2)
+    rays = R.primary(cam)
+    want = oracle_hits(oracle, sc, verts, rays)
+    got = sc.Intersect(rays.copy())
+    c = assert_parity(got, want)
+    assert c["hits"] > 0.9 * rays.shape[0]
+    b = R.bounce(want, verts, seed=5)
+    want_b = oracle_hits(oracle, sc, verts, b)
+    got_b = sc.Intersect(b.copy())
+    assert_parity(got_b, want_b)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_occluded(ctx, oracle, atrium_small, layout):
+    verts = atrium_small
+    sc = upload(ctx, layout, verts)
+    eye, view = scenes.SPONZA_CAMERAS[1]
+    rays = R.primary(R.camera(eye, view, 128, 64, 2, 2))
+    prim = oracle_hits(oracle, sc, verts, rays)
+    ext = float((verts[:, :3].max(0) - verts[:, :3].min(0)).max())
+    sh = R.shadow(prim, (0.0, 25.0, 0.0), ext * 5e-7)
+    h = sc.host
+    want = oracle.bvh2_occluded(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, sh)
+    got = sc.IsOccluded(sh)
+    assert 0 < want.sum() < want.size
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_edge_cases(ctx, oracle, soup, layout):
+    sc = upload(ctx, layout, soup)
+    # empty batch
+    empty = np.zeros(0, dtype=tb.RAY_DTYPE)
+    assert sc.Intersect(empty).shape[0] == 0
+    assert sc.IsOccluded(empty).shape[0] == 0
+    # ragged size (not a multiple of the wave), 1 ray, 63, 65
+    for n in (1, 63, 65, 1000):
+        rays = R.random_rays(n, (0, 0, 0), (10, 10, 10), seed=n)
+        assert_parity(sc.Intersect(rays.copy()), oracle_hits(oracle, sc, soup, rays))
+    # finite tmax: hits beyond it are misses and leave the record untouched
+    rays = R.random_rays(5000, (0, 0, 0), (10, 10, 10), seed=9, tmax=np.float32(1.5))
+    rays["u"] = 7.0; rays["prim"] = 12345
+    want = oracle_hits(oracle, sc, soup, rays)
+    got = sc.Intersect(rays.copy())
+    c = compare_hits(got, want)
+    changed = want["prim"] != 12345
+    assert np.array_equal(got["prim"], want["prim"]) or c["tie"] > 0
+    assert np.array_equal(got["t"][~changed], rays["t"][~changed])
+    assert np.array_equal(got["u"][~changed], rays["u"][~changed])
+    # axis-aligned directions: rD = +-1e30 (tinybvh_safercp)
+    O = np.tile(np.array([[5, 5, -3]], np.float32), (6, 1))
+    D = np.array([[0, 0, 1], [0, 0, -1], [1, 0, 0], [0, 1, 0], [0, -1, 0], [-1, 0, 0]], np.float32)
+    rays = tb.make_rays(O, D)
+    assert_parity(sc.Intersect(rays.copy()), oracle_hits(oracle, sc, soup, rays))
+    # host Ray[] with 128-byte stride passed in place
+    rays = R.random_rays(777, (0, 0, 0), (10, 10, 10), seed=21)
+    wide = np.zeros((777, 2), dtype=tb.RAY_DTYPE)
+    wide[:, 0] = rays
+    wide[:, 1]["t"] = 99.0  # user area must stay untouched
+    flat = wide.reshape(-1)
+    view128 = np.lib.stride_tricks.as_strided(flat, shape=(777,), strides=(128,))
+    from tinybvh_amd import _capi
+    import ctypes as C
+    _capi.check(_capi.lib.tbvh_intersect(sc._h, C.c_void_p(flat.ctypes.data), 777, 128), "tbvh_intersect")
+    assert_parity(np.ascontiguousarray(view128), oracle_hits(oracle, sc, soup, rays))
+    assert np.all(wide[:, 1]["t"] == 99.0)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("hq", [False, True])
+def test_reference_built_blobs(ctx, oracle, reference, atrium_small, layout, hq):
+    """The real drop-in situation: blobs produced by tiny_bvh.h's own Build / BuildHQ."""
+    verts = atrium_small
+    rs = reference.build(verts, hq=hq)
+    cls = tb.LAYOUT_CLASSES[layout]
+    if layout == tb.LAYOUT_BVH_GPU:
+        sc = cls(ctx).Upload(rs.blob(4, 0, np.uint32, 16), rs.blob(4, 1, np.uint32, 1), verts)
+    elif layout == tb.LAYOUT_BVH4_GPU:
+        sc = cls(ctx).Upload(rs.blob(6, 0, np.uint32, 4))
+    else:
+        sc = cls(ctx).Upload(rs.blob(9, 0, np.uint32, 4), rs.blob(9, 1, np.uint32, 4))
+    eye, view = scenes.SPONZA_CAMERAS[2]
+    rays = R.primary(R.camera(eye, view, 160, 96, 2, 2))
+    want = rs.intersect(1, rays)  # BVH::Intersect of the reference itself
+    got = sc.Intersect(rays.copy())
+    assert_parity(got, want)
+    rnd = R.random_rays(30_000, verts[:, :3].min(0), verts[:, :3].max(0), seed=4)
+    assert_parity(sc.Intersect(rnd.copy()), rs.intersect(1, rnd))

@@ -1,0 +1,264 @@
+"""tinybvh_amd — MI355X-native batched ray traversal behind tinybvh's GPU-layout API.
+
+Thin Python mirror of the reference's host interface for this one path (class and method
+names follow tiny_bvh.h: ``BVH_GPU`` / ``BVH4_GPU`` / ``BVH8_CWBVH`` with ``Build``,
+``Intersect``, ``IsOccluded``), over the C ABI in ``include/tinybvh_amd.h``.  All compute
+is in the HIP library; this package holds no traversal code and no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _capi
+from ._capi import BuildParams, Camera, TbvhError, check, lib
+
+LAYOUT_BVH2_WALD = 1
+LAYOUT_BVH_GPU = 4
+LAYOUT_BVH4_GPU = 6
+LAYOUT_CWBVH = 9
+
+BVH_FAR = np.float32(1e30)
+
+# first 64 bytes of tinybvh::Ray (tiny_bvh.h:689-709) == device struct Ray (traverse.cl:11-17)
+RAY_DTYPE = np.dtype([
+    ("O", "<f4", 3), ("mask", "<u4"),
+    ("D", "<f4", 3), ("instIdx", "<u4"),
+    ("rD", "<f4", 3), ("inst", "<u4"),
+    ("t", "<f4"), ("u", "<f4"), ("v", "<f4"), ("prim", "<u4"),
+])
+assert RAY_DTYPE.itemsize == 64
+
+
+def safercp(x: np.ndarray) -> np.ndarray:
+    """tinybvh_safercp (tiny_bvh.h:442): 1/x, or +-1e30 when |x| <= 1e-12."""
+    x = np.asarray(x, dtype=np.float32)
+    big = np.abs(x) > np.float32(1e-12)
+    with np.errstate(divide="ignore"):
+        r = np.where(big, np.float32(1.0) / np.where(big, x, np.float32(1.0)), np.where(x >= 0, BVH_FAR, -BVH_FAR))
+    return r.astype(np.float32)
+
+
+def make_rays(O: np.ndarray, D: np.ndarray, tmax=BVH_FAR, normalize: bool = True) -> np.ndarray:
+    """Build ray records the way the tinybvh::Ray constructor does (tiny_bvh.h:695-703)."""
+    O = np.ascontiguousarray(O, dtype=np.float32).reshape(-1, 3)
+    D = np.ascontiguousarray(D, dtype=np.float32).reshape(-1, 3)
+    if normalize:
+        l = np.sqrt((D * D).sum(axis=1, dtype=np.float32)).astype(np.float32)
+        rl = np.where(l == 0, np.float32(0), np.float32(1) / np.where(l == 0, np.float32(1), l)).astype(np.float32)
+        D = (D * rl[:, None]).astype(np.float32)
+    rays = np.zeros(O.shape[0], dtype=RAY_DTYPE)
+    rays["O"] = O
+    rays["D"] = D
+    rays["rD"] = safercp(D)
+    rays["mask"] = 0xFFFF
+    rays["t"] = tmax
+    return rays
+
+
+def _ptr(a: np.ndarray) -> C.c_void_p:
+    return C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """One HIP device (replaces tinyocl's process-global InitCL, tiny_ocl.h:945-1139)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        check(lib.tbvh_init(device, C.byref(h)), "tbvh_init")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib.tbvh_shutdown(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(lib.tbvh_synchronize(self._h), "tbvh_synchronize")
+
+    def set_stream(self, hip_stream: Optional[int]):
+        check(lib.tbvh_set_stream(self._h, C.c_void_p(hip_stream or 0)), "tbvh_set_stream")
+
+    def time_last_ms(self) -> float:
+        return float(lib.tbvh_time_last_ms(self._h))
+
+    # device buffers (replace tinyocl::Buffer for resident rays)
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        check(lib.tbvh_device_malloc(self._h, nbytes, C.byref(p)), "tbvh_device_malloc")
+        return p.value
+
+    def free(self, dptr: int):
+        check(lib.tbvh_device_free(self._h, C.c_void_p(dptr)), "tbvh_device_free")
+
+    def to_device(self, dptr: int, a: np.ndarray):
+        a = np.ascontiguousarray(a)
+        check(lib.tbvh_copy_to_device(self._h, C.c_void_p(dptr), _ptr(a), a.nbytes), "tbvh_copy_to_device")
+
+    def from_device(self, a: np.ndarray, dptr: int):
+        assert a.flags["C_CONTIGUOUS"]
+        check(lib.tbvh_copy_from_device(self._h, _ptr(a), C.c_void_p(dptr), a.nbytes), "tbvh_copy_from_device")
+
+    # ray generators
+    def generate_primary(self, cam: Camera, d_rays: int, first: int, n: int):
+        check(lib.tbvh_generate_primary_device(self._h, C.byref(cam), C.c_void_p(d_rays), first, n), "tbvh_generate_primary_device")
+
+    def generate_bounce(self, d_verts: int, d_in: int, d_out: int, n: int, seed: int):
+        check(lib.tbvh_generate_bounce_device(self._h, C.c_void_p(d_verts), C.c_void_p(d_in), C.c_void_p(d_out), n, seed), "tbvh_generate_bounce_device")
+
+    def generate_shadow(self, d_in: int, d_out: int, n: int, light, eps: float):
+        l = (C.c_float * 3)(*[float(x) for x in light])
+        check(lib.tbvh_generate_shadow_device(self._h, C.c_void_p(d_in), C.c_void_p(d_out), n, l, float(eps)), "tbvh_generate_shadow_device")
+
+
+class HostBVH:
+    """Blobs built on the host by the library's own builder (tbvh_host_build)."""
+
+    def __init__(self, verts: np.ndarray, layout: int, bins: int = 0, max_leaf_tris: int = 0, threads: int = 0):
+        verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 4)
+        assert verts.shape[0] % 3 == 0
+        self.verts = verts
+        self.n_tris = verts.shape[0] // 3
+        self.layout = layout
+        bp = BuildParams(bins, max_leaf_tris, threads, 0)
+        h = C.c_void_p()
+        check(lib.tbvh_host_build(_ptr(verts), self.n_tris, layout, C.byref(bp), C.byref(h)), "tbvh_host_build")
+        self._h = h
+
+    def blob(self, which: int, dtype, width: int) -> np.ndarray:
+        """Zero-copy numpy view of blob `which` (valid while this object lives)."""
+        p = lib.tbvh_host_blob(self._h, which)
+        n = lib.tbvh_host_blob_count(self._h, which)
+        if not p or n == 0:
+            return np.zeros((0, width), dtype=dtype)
+        nbytes = n * np.dtype(dtype).itemsize * width
+        buf = (C.c_char * nbytes).from_address(p)
+        a = np.frombuffer(buf, dtype=dtype).reshape(n, width)
+        a.flags.writeable = False
+        return a
+
+    # the Wald BVH2 every layout was encoded from (for the oracle)
+    def bvh2_nodes(self) -> np.ndarray:
+        return self.blob(0 if self.layout == LAYOUT_BVH2_WALD else 2, np.uint32, 8)
+
+    def bvh2_prim_idx(self) -> np.ndarray:
+        return self.blob(1 if self.layout in (LAYOUT_BVH2_WALD, LAYOUT_BVH_GPU) else 3, np.uint32, 1).reshape(-1)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib.tbvh_host_free(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class _Scene:
+    """An uploaded layout.  Intersect / IsOccluded mirror X::Intersect(Ray&) /
+    X::IsOccluded(const Ray&) of the reference, but over whole ray arrays."""
+
+    layout = 0
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+
+    def free(self):
+        if self._h and self.ctx._h:
+            lib.tbvh_free_scene(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    @property
+    def device_bytes(self) -> int:
+        return int(lib.tbvh_scene_device_bytes(self._h))
+
+    def set_variant(self, v: int):
+        check(lib.tbvh_set_variant(self._h, v), "tbvh_set_variant")
+
+    def Intersect(self, rays: np.ndarray) -> np.ndarray:
+        """rays: structured RAY_DTYPE array (64-byte records) or a (n, 128)-byte host Ray[] view;
+        updated in place (bytes 44..63 of records that hit) and returned."""
+        assert rays.flags["C_CONTIGUOUS"] and rays.flags["WRITEABLE"]
+        stride = rays.strides[0]
+        check(lib.tbvh_intersect(self._h, _ptr(rays), rays.shape[0], stride), "tbvh_intersect")
+        return rays
+
+    def IsOccluded(self, rays: np.ndarray) -> np.ndarray:
+        assert rays.flags["C_CONTIGUOUS"]
+        out = np.zeros(rays.shape[0], dtype=np.uint8)
+        check(lib.tbvh_occluded(self._h, _ptr(rays), rays.shape[0], rays.strides[0], _ptr(out)), "tbvh_occluded")
+        return out
+
+    # device-resident, asynchronous
+    def intersect_device(self, d_rays: int, n: int):
+        check(lib.tbvh_intersect_device(self._h, C.c_void_p(d_rays), n), "tbvh_intersect_device")
+
+    def occluded_device(self, d_rays: int, n: int, d_out: int):
+        check(lib.tbvh_occluded_device(self._h, C.c_void_p(d_rays), n, C.c_void_p(d_out)), "tbvh_occluded_device")
+
+
+class BVH_GPU(_Scene):
+    """Aila-Laine 2-wide layout (tiny_bvh.h:1092-1127)."""
+    layout = LAYOUT_BVH_GPU
+
+    def Build(self, verts: np.ndarray, **kw) -> "BVH_GPU":
+        self.host = HostBVH(verts, LAYOUT_BVH_GPU, **kw)
+        return self.Upload(self.host.blob(0, np.uint32, 16), self.host.blob(1, np.uint32, 1), self.host.verts)
+
+    def Upload(self, nodes64: np.ndarray, prim_idx: np.ndarray, verts: np.ndarray) -> "BVH_GPU":
+        nodes64 = np.ascontiguousarray(nodes64); prim_idx = np.ascontiguousarray(prim_idx, dtype=np.uint32)
+        verts = np.ascontiguousarray(verts, dtype=np.float32)
+        check(lib.tbvh_upload_bvh_gpu(self.ctx._h, _ptr(nodes64), nodes64.nbytes // 64, _ptr(prim_idx), prim_idx.size,
+                                      _ptr(verts), verts.size // 12, C.byref(self._h)), "tbvh_upload_bvh_gpu")
+        return self
+
+
+class BVH4_GPU(_Scene):
+    """Quantized 4-wide layout with inline triangles (tiny_bvh.h:1245-1289)."""
+    layout = LAYOUT_BVH4_GPU
+
+    def Build(self, verts: np.ndarray, **kw) -> "BVH4_GPU":
+        self.host = HostBVH(verts, LAYOUT_BVH4_GPU, **kw)
+        return self.Upload(self.host.blob(0, np.uint32, 4))
+
+    def Upload(self, blocks16: np.ndarray) -> "BVH4_GPU":
+        blocks16 = np.ascontiguousarray(blocks16)
+        check(lib.tbvh_upload_bvh4_gpu(self.ctx._h, _ptr(blocks16), blocks16.nbytes // 16, C.byref(self._h)), "tbvh_upload_bvh4_gpu")
+        return self
+
+
+class BVH8_CWBVH(_Scene):
+    """Compressed wide BVH (tiny_bvh.h:1334-1362)."""
+    layout = LAYOUT_CWBVH
+
+    def Build(self, verts: np.ndarray, **kw) -> "BVH8_CWBVH":
+        self.host = HostBVH(verts, LAYOUT_CWBVH, **kw)
+        return self.Upload(self.host.blob(0, np.uint32, 4), self.host.blob(1, np.uint32, 4))
+
+    def Upload(self, nodes16: np.ndarray, tris16: np.ndarray) -> "BVH8_CWBVH":
+        nodes16 = np.ascontiguousarray(nodes16); tris16 = np.ascontiguousarray(tris16)
+        check(lib.tbvh_upload_cwbvh(self.ctx._h, _ptr(nodes16), nodes16.nbytes // 16, _ptr(tris16), tris16.nbytes // 16,
+                                    C.byref(self._h)), "tbvh_upload_cwbvh")
+        return self
+
+
+LAYOUT_CLASSES = {LAYOUT_BVH_GPU: BVH_GPU, LAYOUT_BVH4_GPU: BVH4_GPU, LAYOUT_CWBVH: BVH8_CWBVH}
+
+
+def device_count() -> int:
+    return int(lib.tbvh_device_count())

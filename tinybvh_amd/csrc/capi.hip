@@ -1,0 +1,514 @@
+// capi.hip — implementation of include/tinybvh_amd.h: contexts, uploads, query launches,
+// HIP-event timing, host builder entry points.  No torch, no exit(): every failure is a
+// status code + tbvh_last_error().
+#include "../../include/tinybvh_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "host_builder.h"
+#include "kernels.h"
+
+using namespace tbvh;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(TBVH_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+struct tbvh_context {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int numCUs = 0;
+    uint32_t blocks = 0;          // persistent grid size (64-thread workgroups)
+    uint32_t* spill = nullptr;    // stack spill area
+    uint32_t spillEntries = 0;    // 32-bit entries per lane
+    unsigned long long* counter = nullptr;  // ray-fetch counter (+ status word after it)
+    uint32_t* status = nullptr;
+    RayRec* stageRays = nullptr;  // staging for host-array queries
+    uint64_t stageCap = 0;
+    uint8_t* stageOcc = nullptr;
+    uint64_t stageOccCap = 0;
+    std::vector<tbvh_scene*> scenes;
+};
+
+struct tbvh_scene {
+    tbvh_context* ctx = nullptr;
+    int layout = 0;
+    int variant = 0;
+    float4* nodes = nullptr;   // BVH_GPU nodes / BVH4 stream / CWBVH nodes
+    float4* tris = nullptr;    // BVH_GPU gathered tris / CWBVH tris
+    uint64_t nNodeBlocks = 0, nTriBlocks = 0;
+    uint64_t bytes = 0;
+    // TLAS
+    bool isTlas = false;
+};
+
+struct tbvh_hostbvh {
+    int layout = 0;
+    BVH2 bvh2;
+    std::vector<NodeAL> al;
+    std::vector<Vec4> blocksA, blocksB;
+};
+
+namespace {
+
+int setDevice(tbvh_context* c) {
+    HIP_TRY(hipSetDevice(c->device));
+    return 0;
+}
+
+int ensureStage(tbvh_context* c, uint64_t n) {
+    if (c->stageCap >= n) return 0;
+    if (c->stageRays) hipFree(c->stageRays);
+    c->stageRays = nullptr; c->stageCap = 0;
+    HIP_TRY(hipMalloc((void**)&c->stageRays, n * sizeof(RayRec)));
+    c->stageCap = n;
+    return 0;
+}
+int ensureStageOcc(tbvh_context* c, uint64_t n) {
+    if (c->stageOccCap >= n) return 0;
+    if (c->stageOcc) hipFree(c->stageOcc);
+    c->stageOcc = nullptr; c->stageOccCap = 0;
+    HIP_TRY(hipMalloc((void**)&c->stageOcc, n));
+    c->stageOccCap = n;
+    return 0;
+}
+
+int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ) {
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    if (n == 0) return 0;
+    const bool any = d_occ != nullptr;
+    HIP_TRY(hipMemsetAsync(c->counter, 0, 16, c->stream));
+    QueryArgs q;
+    q.rays = d_rays; q.nRays = n; q.occluded = d_occ;
+    q.spill = c->spill; q.counter = (uint32_t*)c->counter;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    switch (s->layout) {
+    case TBVH_LAYOUT_BVH_GPU:
+        q.spillStride = c->spillEntries;
+        launch_bvh2(any, s->nodes, s->tris, q, c->status, c->blocks, c->stream);
+        break;
+    case TBVH_LAYOUT_BVH4_GPU:
+        q.spillStride = c->spillEntries;
+        launch_bvh4(any, s->nodes, q, c->status, c->blocks, c->stream);
+        break;
+    case TBVH_LAYOUT_CWBVH:
+        q.spillStride = c->spillEntries / 2;  // 8-byte entries
+        launch_cwbvh(any, s->nodes, s->tris, q, c->status, c->blocks, c->stream);
+        break;
+    default:
+        return fail(TBVH_E_INVALID, "scene layout %d has no query kernel", s->layout);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return 0;
+}
+
+int checkStatus(tbvh_context* c) {
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, c->status, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (st & 1u) {
+        hipMemsetAsync(c->status, 0, 4, c->stream);
+        return fail(TBVH_E_FORMAT, "traversal stack overflow (tree deeper than the spill area allows)");
+    }
+    return 0;
+}
+
+tbvh_scene* newScene(tbvh_context* c, int layout) {
+    tbvh_scene* s = new (std::nothrow) tbvh_scene;
+    if (!s) return nullptr;
+    s->ctx = c; s->layout = layout;
+    c->scenes.push_back(s);
+    return s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tbvh_abi_version(void) { return TBVH_ABI_VERSION; }
+const char* tbvh_last_error(void) { return g_err; }
+
+int tbvh_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { fail(TBVH_E_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e)); return e == hipErrorNoDevice ? 0 : TBVH_E_HIP; }
+    return n;
+}
+
+int tbvh_init(int device, tbvh_context** out) {
+    if (!out) return fail(TBVH_E_INVALID, "tbvh_init: out is null");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(TBVH_E_NODEVICE, "no HIP device available");
+    if (device < 0 || device >= n) return fail(TBVH_E_NODEVICE, "device %d out of range (0..%d)", device, n - 1);
+    tbvh_context* c = new (std::nothrow) tbvh_context;
+    if (!c) return fail(TBVH_E_NOMEM, "out of host memory");
+    c->device = device;
+    hipDeviceProp_t prop;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) { delete c; return fail(TBVH_E_HIP, "context setup failed: %s", hipGetErrorString(e)); }
+    c->stream = c->ownStream;
+    c->numCUs = prop.multiProcessorCount;
+    // persistent grid: one-wave workgroups, enough to fill every SIMD several times over
+    c->blocks = (uint32_t)c->numCUs * 16u;
+    c->spillEntries = 232;  // 32-bit entries per lane beyond the LDS part of the stack
+    const size_t spillBytes = (size_t)c->blocks * 64 * c->spillEntries * 4;
+    e = hipMalloc((void**)&c->spill, spillBytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->counter, 64);
+    if (e != hipSuccess) { tbvh_shutdown(c); return fail(TBVH_E_NOMEM, "device allocation failed: %s", hipGetErrorString(e)); }
+    c->status = (uint32_t*)(c->counter + 4);
+    hipMemset(c->counter, 0, 64);
+    *out = c;
+    return 0;
+}
+
+void tbvh_shutdown(tbvh_context* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->ownStream) hipStreamSynchronize(c->ownStream);
+    while (!c->scenes.empty()) tbvh_free_scene(c->scenes.back());
+    if (c->spill) hipFree(c->spill);
+    if (c->counter) hipFree(c->counter);
+    if (c->stageRays) hipFree(c->stageRays);
+    if (c->stageOcc) hipFree(c->stageOcc);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ownStream) hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+int tbvh_synchronize(tbvh_context* c) {
+    if (!c) return fail(TBVH_E_INVALID, "null context");
+    if (int r = setDevice(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tbvh_set_stream(tbvh_context* c, void* s) {
+    if (!c) return fail(TBVH_E_INVALID, "null context");
+    c->stream = s ? (hipStream_t)s : c->ownStream;
+    return 0;
+}
+
+// ---- uploads ---------------------------------------------------------------------------
+
+int tbvh_upload_bvh_gpu(tbvh_context* c, const void* nodes64, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx,
+                        const void* verts16, uint64_t nTris, tbvh_scene** out) {
+    if (!c || !nodes64 || !primIdx || !verts16 || !out || nNodes == 0) return fail(TBVH_E_INVALID, "tbvh_upload_bvh_gpu: null/empty argument");
+    if (int r = setDevice(c)) return r;
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    uint32_t* dIdx = nullptr; float4* dVerts = nullptr;
+    hipError_t e = hipMalloc((void**)&s->nodes, nNodes * 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->tris, (nIdx ? nIdx : 1) * 48);
+    if (e == hipSuccess) e = hipMalloc((void**)&dIdx, (nIdx ? nIdx : 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dVerts, (nTris ? nTris : 1) * 48);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, nodes64, nNodes * 64, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dIdx, primIdx, nIdx * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dVerts, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nIdx) { launch_gather_tris(dIdx, dVerts, s->tris, nIdx, nTris, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (dIdx) hipFree(dIdx);
+    if (dVerts) hipFree(dVerts);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH_GPU upload failed: %s", hipGetErrorString(e)); }
+    s->nNodeBlocks = nNodes * 4; s->nTriBlocks = nIdx * 3;
+    s->bytes = nNodes * 64 + nIdx * 48;
+    *out = s;
+    return 0;
+}
+
+int tbvh_upload_bvh4_gpu(tbvh_context* c, const void* blocks16, uint64_t nBlocks, tbvh_scene** out) {
+    if (!c || !blocks16 || !out || nBlocks < 4) return fail(TBVH_E_INVALID, "tbvh_upload_bvh4_gpu: null/empty argument");
+    if (int r = setDevice(c)) return r;
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH4_GPU);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    hipError_t e = hipMalloc((void**)&s->nodes, nBlocks * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, blocks16, nBlocks * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH4_GPU upload failed: %s", hipGetErrorString(e)); }
+    s->nNodeBlocks = nBlocks; s->bytes = nBlocks * 16;
+    *out = s;
+    return 0;
+}
+
+int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks, const void* tris16, uint64_t nTriBlocks,
+                      tbvh_scene** out) {
+    if (!c || !nodes16 || !out || nNodeBlocks < 5 || (nTriBlocks && !tris16)) return fail(TBVH_E_INVALID, "tbvh_upload_cwbvh: null/empty argument");
+    if (nNodeBlocks % 5) return fail(TBVH_E_FORMAT, "CWBVH node blocks (%llu) not a multiple of 5", (unsigned long long)nNodeBlocks);
+    if (int r = setDevice(c)) return r;
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_CWBVH);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    hipError_t e = hipMalloc((void**)&s->nodes, nNodeBlocks * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->tris, (nTriBlocks ? nTriBlocks : 1) * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, nodes16, nNodeBlocks * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nTriBlocks) e = hipMemcpyAsync(s->tris, tris16, nTriBlocks * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "CWBVH upload failed: %s", hipGetErrorString(e)); }
+    s->nNodeBlocks = nNodeBlocks; s->nTriBlocks = nTriBlocks;
+    s->bytes = (nNodeBlocks + nTriBlocks) * 16;
+    *out = s;
+    return 0;
+}
+
+int tbvh_upload_tlas(tbvh_context*, const void*, uint64_t, const uint32_t*, uint64_t, const void*, uint64_t,
+                     tbvh_scene* const*, uint64_t, tbvh_scene**) {
+    return fail(TBVH_E_INVALID, "TLAS queries are not implemented yet");
+}
+int tbvh_update_tlas(tbvh_scene*, const void*, uint64_t, const uint32_t*, uint64_t, const void*, uint64_t) {
+    return fail(TBVH_E_INVALID, "TLAS queries are not implemented yet");
+}
+
+void tbvh_free_scene(tbvh_scene* s) {
+    if (!s) return;
+    tbvh_context* c = s->ctx;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (s->nodes) hipFree(s->nodes);
+    if (s->tris) hipFree(s->tris);
+    for (size_t i = 0; i < c->scenes.size(); i++)
+        if (c->scenes[i] == s) { c->scenes.erase(c->scenes.begin() + i); break; }
+    delete s;
+}
+int tbvh_scene_layout(const tbvh_scene* s) { return s ? s->layout : TBVH_E_INVALID; }
+uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0; }
+
+int tbvh_set_variant(tbvh_scene* s, int v) {
+    if (!s) return fail(TBVH_E_INVALID, "null scene");
+    if (v != 0) return fail(TBVH_E_INVALID, "unknown variant %d", v);
+    s->variant = v;
+    return 0;
+}
+
+// ---- queries ---------------------------------------------------------------------------
+
+int tbvh_intersect_device(tbvh_scene* s, void* dRays, uint64_t n) {
+    if (!s || (!dRays && n)) return fail(TBVH_E_INVALID, "tbvh_intersect_device: null argument");
+    if (((uintptr_t)dRays) & 15) return fail(TBVH_E_INVALID, "ray array must be 16-byte aligned");
+    return launchQuery(s, (RayRec*)dRays, n, nullptr);
+}
+
+int tbvh_occluded_device(tbvh_scene* s, const void* dRays, uint64_t n, uint8_t* dOcc) {
+    if (!s || ((!dRays || !dOcc) && n)) return fail(TBVH_E_INVALID, "tbvh_occluded_device: null argument");
+    if (((uintptr_t)dRays) & 15) return fail(TBVH_E_INVALID, "ray array must be 16-byte aligned");
+    return launchQuery(s, (RayRec*)dRays, n, dOcc);
+}
+
+int tbvh_intersect(tbvh_scene* s, void* rays, uint64_t n, uint32_t stride) {
+    if (!s || (!rays && n)) return fail(TBVH_E_INVALID, "tbvh_intersect: null argument");
+    if (stride < 64 || (stride & 3)) return fail(TBVH_E_INVALID, "stride must be >= 64 and a multiple of 4 (got %u)", stride);
+    if (n == 0) return 0;
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    if (int r = ensureStage(c, n)) return r;
+    HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
+    if (int r = launchQuery(s, c->stageRays, n, nullptr)) return r;
+    // copy back bytes 44..63 of every record (hit.inst + hit)
+    HIP_TRY(hipMemcpy2DAsync((char*)rays + 44, stride, (char*)c->stageRays + 44, 64, 20, n, hipMemcpyDeviceToHost, c->stream));
+    return checkStatus(c);
+}
+
+int tbvh_occluded(tbvh_scene* s, const void* rays, uint64_t n, uint32_t stride, uint8_t* occ) {
+    if (!s || ((!rays || !occ) && n)) return fail(TBVH_E_INVALID, "tbvh_occluded: null argument");
+    if (stride < 64 || (stride & 3)) return fail(TBVH_E_INVALID, "stride must be >= 64 and a multiple of 4 (got %u)", stride);
+    if (n == 0) return 0;
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    if (int r = ensureStage(c, n)) return r;
+    if (int r = ensureStageOcc(c, n)) return r;
+    HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
+    if (int r = launchQuery(s, c->stageRays, n, c->stageOcc)) return r;
+    HIP_TRY(hipMemcpyAsync(occ, c->stageOcc, n, hipMemcpyDeviceToHost, c->stream));
+    return checkStatus(c);
+}
+
+float tbvh_time_last_ms(tbvh_context* c) {
+    if (!c || !c->timed) return -1.0f;
+    hipSetDevice(c->device);
+    if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0f;
+    return ms;
+}
+
+// ---- ray generators ----------------------------------------------------------------------
+
+int tbvh_generate_primary_device(tbvh_context* c, const tbvh_camera* cam, void* dRays, uint64_t first, uint64_t n) {
+    if (!c || !cam || (!dRays && n)) return fail(TBVH_E_INVALID, "tbvh_generate_primary_device: null argument");
+    if (cam->width % 4 || cam->height % 4 || !cam->spp_x || !cam->spp_y) return fail(TBVH_E_INVALID, "camera: width/height must be multiples of 4, spp > 0");
+    if (int r = setDevice(c)) return r;
+    if (!n) return 0;
+    CameraArgs a;
+    memcpy(a.eye, cam->eye, 12); memcpy(a.p1, cam->p1, 12); memcpy(a.p2, cam->p2, 12); memcpy(a.p3, cam->p3, 12);
+    a.width = cam->width; a.height = cam->height; a.sppX = cam->spp_x; a.sppY = cam->spp_y;
+    launch_gen_primary(a, (RayRec*)dRays, first, n, c->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int tbvh_generate_bounce_device(tbvh_context* c, const void* dVerts, const void* dIn, void* dOut, uint64_t n, uint32_t seed) {
+    if (!c || ((!dVerts || !dIn || !dOut) && n)) return fail(TBVH_E_INVALID, "tbvh_generate_bounce_device: null argument");
+    if (int r = setDevice(c)) return r;
+    if (!n) return 0;
+    TriSource src; src.mode = 0; src.verts = (const float4*)dVerts;
+    launch_gen_bounce(src, (const RayRec*)dIn, (RayRec*)dOut, n, seed, c->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int tbvh_generate_shadow_device(tbvh_context* c, const void* dIn, void* dOut, uint64_t n, const float light[3], float eps) {
+    if (!c || !light || ((!dIn || !dOut) && n)) return fail(TBVH_E_INVALID, "tbvh_generate_shadow_device: null argument");
+    if (int r = setDevice(c)) return r;
+    if (!n) return 0;
+    launch_gen_shadow((const RayRec*)dIn, (RayRec*)dOut, n, light[0], light[1], light[2], eps, c->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- device buffers ------------------------------------------------------------------------
+
+int tbvh_device_malloc(tbvh_context* c, uint64_t bytes, void** out) {
+    if (!c || !out) return fail(TBVH_E_INVALID, "tbvh_device_malloc: null argument");
+    if (int r = setDevice(c)) return r;
+    hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(TBVH_E_NOMEM, "hipMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return 0;
+}
+int tbvh_device_free(tbvh_context* c, void* p) {
+    if (!c) return fail(TBVH_E_INVALID, "null context");
+    if (int r = setDevice(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(p));
+    return 0;
+}
+int tbvh_copy_to_device(tbvh_context* c, void* d, const void* src, uint64_t bytes) {
+    if (!c || ((!d || !src) && bytes)) return fail(TBVH_E_INVALID, "tbvh_copy_to_device: null argument");
+    if (int r = setDevice(c)) return r;
+    HIP_TRY(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int tbvh_copy_from_device(tbvh_context* c, void* dst, const void* d, uint64_t bytes) {
+    if (!c || ((!d || !dst) && bytes)) return fail(TBVH_E_INVALID, "tbvh_copy_from_device: null argument");
+    if (int r = setDevice(c)) return r;
+    HIP_TRY(hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ---- host builder ------------------------------------------------------------------------
+
+int tbvh_host_build(const void* verts16, uint64_t nTris, int layout, const tbvh_build_params* p, tbvh_hostbvh** out) {
+    if (!verts16 || !out || nTris == 0) return fail(TBVH_E_INVALID, "tbvh_host_build: null/empty argument");
+    if (nTris > 0x3fffffffull) return fail(TBVH_E_INVALID, "too many triangles");
+    if (layout != TBVH_LAYOUT_BVH2_WALD && layout != TBVH_LAYOUT_BVH_GPU && layout != TBVH_LAYOUT_BVH4_GPU && layout != TBVH_LAYOUT_CWBVH)
+        return fail(TBVH_E_INVALID, "unknown layout %d", layout);
+    tbvh_hostbvh* h = new (std::nothrow) tbvh_hostbvh;
+    if (!h) return fail(TBVH_E_NOMEM, "out of host memory");
+    h->layout = layout;
+    BuildParams bp;
+    if (p) { bp.bins = p->bins ? p->bins : 8; bp.threads = p->threads; bp.maxLeafTris = p->max_leaf_tris; }
+    if (!bp.maxLeafTris) bp.maxLeafTris = layout == TBVH_LAYOUT_CWBVH ? 3 : 4;
+    if (layout == TBVH_LAYOUT_CWBVH && bp.maxLeafTris > 3) bp.maxLeafTris = 3;
+    try {
+        const Vec4* v = (const Vec4*)verts16;
+        build_bvh2(v, (uint32_t)nTris, bp, h->bvh2);
+        if (layout == TBVH_LAYOUT_BVH_GPU) encode_bvh_gpu(h->bvh2, h->al);
+        else if (layout == TBVH_LAYOUT_BVH4_GPU) encode_bvh4_gpu(h->bvh2, v, h->blocksA);
+        else if (layout == TBVH_LAYOUT_CWBVH) encode_cwbvh(h->bvh2, v, h->blocksA, h->blocksB);
+    } catch (const std::bad_alloc&) {
+        delete h;
+        return fail(TBVH_E_NOMEM, "out of host memory while building");
+    }
+    *out = h;
+    return 0;
+}
+
+int tbvh_host_build_tlas(void* instances192, uint64_t nInst, const float* blasBounds6, uint64_t nBlas, tbvh_hostbvh** out) {
+    if (!instances192 || !blasBounds6 || !out || nInst == 0 || nBlas == 0) return fail(TBVH_E_INVALID, "tbvh_host_build_tlas: null/empty argument");
+    Instance192* inst = (Instance192*)instances192;
+    std::vector<float> boxes(nInst * 6);
+    for (uint64_t i = 0; i < nInst; i++) {
+        if (inst[i].blasIdx >= nBlas) return fail(TBVH_E_INVALID, "instance %llu: blasIdx %u out of range", (unsigned long long)i, inst[i].blasIdx);
+        update_instance(inst[i], blasBounds6 + 6 * (size_t)inst[i].blasIdx);
+        for (int a = 0; a < 3; a++) boxes[i * 6 + a] = inst[i].aabbMin[a], boxes[i * 6 + 3 + a] = inst[i].aabbMax[a];
+    }
+    tbvh_hostbvh* h = new (std::nothrow) tbvh_hostbvh;
+    if (!h) return fail(TBVH_E_NOMEM, "out of host memory");
+    h->layout = TBVH_LAYOUT_BVH_GPU;
+    BuildParams bp; bp.maxLeafTris = 1; bp.threads = 1;
+    build_bvh2_boxes(boxes.data(), (uint32_t)nInst, bp, h->bvh2);
+    encode_bvh_gpu(h->bvh2, h->al);
+    *out = h;
+    return 0;
+}
+
+void tbvh_host_free(tbvh_hostbvh* h) { delete h; }
+int tbvh_host_layout(const tbvh_hostbvh* h) { return h ? h->layout : TBVH_E_INVALID; }
+
+const void* tbvh_host_blob(const tbvh_hostbvh* h, int which) {
+    if (!h) return nullptr;
+    switch (h->layout) {
+    case TBVH_LAYOUT_BVH2_WALD: return which == 0 ? (const void*)h->bvh2.nodes.data() : which == 1 ? (const void*)h->bvh2.primIdx.data() : nullptr;
+    case TBVH_LAYOUT_BVH_GPU: return which == 0 ? (const void*)h->al.data() : which == 1 ? (const void*)h->bvh2.primIdx.data() : which == 2 ? (const void*)h->bvh2.nodes.data() : nullptr;
+    case TBVH_LAYOUT_BVH4_GPU: return which == 0 ? (const void*)h->blocksA.data() : which == 2 ? (const void*)h->bvh2.nodes.data() : which == 3 ? (const void*)h->bvh2.primIdx.data() : nullptr;
+    case TBVH_LAYOUT_CWBVH: return which == 0 ? (const void*)h->blocksA.data() : which == 1 ? (const void*)h->blocksB.data() : which == 2 ? (const void*)h->bvh2.nodes.data() : which == 3 ? (const void*)h->bvh2.primIdx.data() : nullptr;
+    }
+    return nullptr;
+}
+uint64_t tbvh_host_blob_count(const tbvh_hostbvh* h, int which) {
+    if (!h) return 0;
+    switch (h->layout) {
+    case TBVH_LAYOUT_BVH2_WALD: return which == 0 ? h->bvh2.nodes.size() : which == 1 ? h->bvh2.primIdx.size() : 0;
+    case TBVH_LAYOUT_BVH_GPU: return which == 0 ? h->al.size() : which == 1 ? h->bvh2.primIdx.size() : which == 2 ? h->bvh2.nodes.size() : 0;
+    case TBVH_LAYOUT_BVH4_GPU: return which == 0 ? h->blocksA.size() : which == 2 ? h->bvh2.nodes.size() : which == 3 ? h->bvh2.primIdx.size() : 0;
+    case TBVH_LAYOUT_CWBVH: return which == 0 ? h->blocksA.size() : which == 1 ? h->blocksB.size() : which == 2 ? h->bvh2.nodes.size() : which == 3 ? h->bvh2.primIdx.size() : 0;
+    }
+    return 0;
+}
+
+int tbvh_upload_host(tbvh_context* c, const tbvh_hostbvh* h, const void* verts16, uint64_t nTris, tbvh_scene** out) {
+    if (!c || !h || !out) return fail(TBVH_E_INVALID, "tbvh_upload_host: null argument");
+    switch (h->layout) {
+    case TBVH_LAYOUT_BVH_GPU:
+        return tbvh_upload_bvh_gpu(c, h->al.data(), h->al.size(), h->bvh2.primIdx.data(), h->bvh2.primIdx.size(), verts16, nTris, out);
+    case TBVH_LAYOUT_BVH4_GPU:
+        return tbvh_upload_bvh4_gpu(c, h->blocksA.data(), h->blocksA.size(), out);
+    case TBVH_LAYOUT_CWBVH:
+        return tbvh_upload_cwbvh(c, h->blocksA.data(), h->blocksA.size(), h->blocksB.data(), h->blocksB.size(), out);
+    }
+    return fail(TBVH_E_INVALID, "layout %d cannot be uploaded", h->layout);
+}
+
+}  // extern "C"

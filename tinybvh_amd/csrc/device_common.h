@@ -1,0 +1,85 @@
+// device_common.h — shared device-side definitions for the gfx950 traversal kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tbvh {
+
+constexpr float kFar = 1e30f;  // BVH_FAR, tiny_bvh.h:144
+
+// 64-byte ray record == first 64 bytes of tinybvh::Ray (tiny_bvh.h:689-709) == device
+// struct Ray (traverse.cl:11-17).  Read as four 16-byte loads per lane.
+struct __attribute__((aligned(16))) RayRec {
+    float4 O;   // xyz, w = mask (u32)
+    float4 D;   // xyz, w = instIdx (u32)
+    float4 rD;  // xyz, w = hit.inst (u32) / pad
+    float4 hit; // t, u, v, prim (u32)
+};
+static_assert(sizeof(RayRec) == 64, "ray record is 64 bytes");
+
+__device__ __forceinline__ uint32_t as_u32(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float as_f32(uint32_t u) { return __uint_as_float(u); }
+
+// Ray/triangle test with the arithmetic of MOLLER_TRUMBORE_TEST (tiny_bvh.h:1644-1656) and
+// the explicit FMA contraction pattern shared with oracle/tbvh_oracle.c (orc_tri), which is
+// the pattern g++ 11.4 -O3 -mfma picks for the reference build:
+//   h = crossA(D,e2); a = dot_zxy(e1,h); u = f*dot_zxy(s,h); q = crossB(s,e1);
+//   v = f*dot_zyx(D,q); t = f*dot_zxy(e2,q)
+// The kernels are compiled with -ffp-contract=off so nothing else in here is fused, and
+// 1/a is the correctly rounded IEEE division (hipcc default).  t,u,v are therefore
+// bit-identical to the oracle, and to BVH::Intersect as built by oracle/Makefile.
+struct TriHit { float t, u, v; };
+
+__device__ __forceinline__ float3 crossA(float3 a, float3 b) {  // first product fused
+    float3 r;
+    r.x = __builtin_fmaf(a.y, b.z, -(a.z * b.y));
+    r.y = __builtin_fmaf(a.z, b.x, -(a.x * b.z));
+    r.z = __builtin_fmaf(a.x, b.y, -(a.y * b.x));
+    return r;
+}
+__device__ __forceinline__ float3 crossB(float3 a, float3 b) {  // second product fused
+    float3 r;
+    r.x = __builtin_fmaf(-a.z, b.y, a.y * b.z);
+    r.y = __builtin_fmaf(-a.x, b.z, a.z * b.x);
+    r.z = __builtin_fmaf(-a.y, b.x, a.x * b.y);
+    return r;
+}
+__device__ __forceinline__ float dot_zxy(float3 a, float3 b) {
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.x, b.x, a.y * b.y));
+}
+__device__ __forceinline__ float dot_zyx(float3 a, float3 b) {
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
+}
+
+// Returns true when the triangle {v0, e1, e2} is hit within [0, tmax] (both ends
+// inclusive, like the reference: rejects only t < 0 || t > tmax).
+__device__ __forceinline__ bool tri_test(float3 O, float3 D, float3 v0, float3 e1, float3 e2,
+                                         float tmax, TriHit& h) {
+    const float3 hh = crossA(D, e2);
+    const float a = dot_zxy(e1, hh);
+    if (__builtin_fabsf(a) < 0.000001f) return false;
+    const float f = 1.0f / a;
+    const float3 s = make_float3(O.x - v0.x, O.y - v0.y, O.z - v0.z);
+    const float u = f * dot_zxy(s, hh);
+    const float3 q = crossB(s, e1);
+    const float v = f * dot_zyx(D, q);
+    if (u < 0 || v < 0 || u + v > 1) return false;
+    const float t = f * dot_zxy(e2, q);
+    if (t < 0 || t > tmax) return false;
+    h.t = t; h.u = u; h.v = v;
+    return true;
+}
+
+__device__ __forceinline__ float3 xyz(float4 v) { return make_float3(v.x, v.y, v.z); }
+
+// Kernel launch parameters common to the query kernels.
+struct QueryArgs {
+    RayRec* rays;          // device, 64-byte stride
+    uint64_t nRays;
+    uint8_t* occluded;     // any-hit output (1 byte per ray) or nullptr
+    uint32_t* spill;       // global overflow area for traversal stacks
+    uint32_t spillStride;  // entries per lane in `spill`
+    uint32_t* counter;     // dynamic ray-fetch counter (persistent kernels)
+};
+
+}  // namespace tbvh

@@ -1,0 +1,539 @@
+// host_builder.cpp — see host_builder.h.
+//
+// What the reference does for the same job (for parity of the *formats*, not the code):
+//   BVH::Build binned SAH, 8 bins           tiny_bvh.h:2124-2461
+//   BVH::SplitLeafs (<=3 tris for CWBVH)    tiny_bvh.h:1988-2017
+//   MBVH<M>::ConvertFrom (wide collapse)    tiny_bvh.h:4975-5048
+//   BVH_GPU::ConvertFrom                    tiny_bvh.h:4612-4655
+//   BVH4_GPU::ConvertFrom                   tiny_bvh.h:5115-5244
+//   BVH8_CWBVH::ConvertFrom                 tiny_bvh.h:5884-6018
+// The encoders here emit byte-compatible blobs (same field meaning, same quantisation
+// rules: conservative floor/ceil) but the tree that goes in is built by this file.
+#include "host_builder.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cassert>
+#include <cmath>
+#include <cstring>
+#include <thread>
+
+namespace tbvh {
+
+namespace {
+
+constexpr float kFar = 1e30f;
+
+struct Box {
+    float mn[3], mx[3];
+    void reset() { mn[0] = mn[1] = mn[2] = kFar; mx[0] = mx[1] = mx[2] = -kFar; }
+    void grow(const float* p) {
+        for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], p[a]); mx[a] = std::max(mx[a], p[a]); }
+    }
+    void grow(const Box& b) {
+        for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], b.mn[a]); mx[a] = std::max(mx[a], b.mx[a]); }
+    }
+    float halfArea() const {
+        const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+        return ex * ey + ey * ez + ez * ex;
+    }
+};
+
+// One primitive as the builder sees it: bounds + centroid.
+struct Prim {
+    Box box;
+    float c[3];
+};
+
+struct Builder {
+    const Prim* prims;
+    uint32_t* idx;  // global permutation, partitioned in place
+    uint32_t bins;
+    uint32_t maxLeaf;
+
+    static constexpr uint32_t kMaxBins = 32;
+
+    // Returns true and the split position if [first, first+count) was partitioned.
+    bool split(const Box& nodeBox, uint32_t first, uint32_t count, uint32_t& mid) const {
+        Box cb; cb.reset();
+        for (uint32_t i = 0; i < count; i++) cb.grow(prims[idx[first + i]].c);
+        float bestCost = kFar; int bestAxis = -1; uint32_t bestPos = 0;
+        float bestScale = 0, bestMin = 0;
+        for (int a = 0; a < 3; a++) {
+            const float ext = cb.mx[a] - cb.mn[a];
+            if (!(ext > 0)) continue;
+            Box bb[kMaxBins]; uint32_t bc[kMaxBins];
+            for (uint32_t b = 0; b < bins; b++) { bb[b].reset(); bc[b] = 0; }
+            const float scale = (float)bins / ext;
+            for (uint32_t i = 0; i < count; i++) {
+                const Prim& p = prims[idx[first + i]];
+                uint32_t b = (uint32_t)std::min((float)(bins - 1), (p.c[a] - cb.mn[a]) * scale);
+                bb[b].grow(p.box); bc[b]++;
+            }
+            // sweep: right-to-left accumulates, then left-to-right evaluates
+            float rArea[kMaxBins]; uint32_t rCnt[kMaxBins];
+            Box acc; acc.reset(); uint32_t n = 0;
+            for (uint32_t b = bins - 1; b >= 1; b--) {
+                if (bc[b]) acc.grow(bb[b]);
+                n += bc[b]; rCnt[b] = n; rArea[b] = n ? acc.halfArea() : 0.f;
+            }
+            acc.reset(); n = 0;
+            for (uint32_t b = 0; b + 1 < bins; b++) {
+                if (bc[b]) acc.grow(bb[b]);
+                n += bc[b];
+                if (n == 0 || rCnt[b + 1] == 0) continue;
+                const float cost = acc.halfArea() * (float)n + rArea[b + 1] * (float)rCnt[b + 1];
+                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestPos = b + 1; bestScale = scale; bestMin = cb.mn[a]; }
+            }
+        }
+        const float leafCost = nodeBox.halfArea() * (float)count;
+        const bool mustSplit = count > maxLeaf;
+        if (bestAxis < 0) {
+            // all centroids coincide: nothing to gain from a spatial split
+            if (!mustSplit) return false;
+            mid = first + count / 2;
+            return true;
+        }
+        // SAH termination (C_TRAV = C_INT = 1, tiny_bvh.h:125-130)
+        if (!mustSplit && bestCost + nodeBox.halfArea() >= leafCost) return false;
+        uint32_t i = first, j = first + count;
+        while (i < j) {
+            const Prim& p = prims[idx[i]];
+            uint32_t b = (uint32_t)std::min((float)(bins - 1), (p.c[bestAxis] - bestMin) * bestScale);
+            if (b < bestPos) i++; else std::swap(idx[i], idx[--j]);
+        }
+        if (i == first || i == first + count) i = first + count / 2;  // numerical corner
+        mid = i;
+        return true;
+    }
+
+    Box bounds(uint32_t first, uint32_t count) const {
+        Box b; b.reset();
+        for (uint32_t i = 0; i < count; i++) b.grow(prims[idx[first + i]].box);
+        return b;
+    }
+
+    static void setNode(Node2& n, const Box& b, uint32_t leftFirst, uint32_t triCount) {
+        for (int a = 0; a < 3; a++) n.mn[a] = b.mn[a], n.mx[a] = b.mx[a];
+        n.leftFirst = leftFirst; n.triCount = triCount;
+    }
+
+    // Build the subtree for [first, first+count) into `nodes`, root at nodes[rootIdx]
+    // (already allocated).  Depth-first with an explicit stack; children are appended as
+    // adjacent pairs.
+    void buildSubtree(std::vector<Node2>& nodes, uint32_t rootIdx, uint32_t first, uint32_t count) const {
+        struct Item { uint32_t node, first, count; };
+        std::vector<Item> stack;
+        stack.push_back({rootIdx, first, count});
+        while (!stack.empty()) {
+            const Item it = stack.back(); stack.pop_back();
+            const Box b = bounds(it.first, it.count);
+            uint32_t mid;
+            if (it.count == 1 || !split(b, it.first, it.count, mid)) {
+                setNode(nodes[it.node], b, it.first, it.count);
+                continue;
+            }
+            const uint32_t l = (uint32_t)nodes.size();
+            nodes.push_back(Node2{}); nodes.push_back(Node2{});
+            setNode(nodes[it.node], b, l, 0);
+            stack.push_back({l + 1, mid, it.first + it.count - mid});
+            stack.push_back({l, it.first, mid - it.first});
+        }
+    }
+};
+
+void buildFromPrims(const std::vector<Prim>& prims, const BuildParams& p, BVH2& out) {
+    const uint32_t n = (uint32_t)prims.size();
+    out.triCount = n;
+    out.primIdx.resize(n);
+    for (uint32_t i = 0; i < n; i++) out.primIdx[i] = i;
+    out.nodes.clear();
+    if (n == 0) { out.nodes.push_back(Node2{}); return; }
+
+    Builder B;
+    B.prims = prims.data(); B.idx = out.primIdx.data();
+    B.bins = std::min<uint32_t>(std::max<uint32_t>(p.bins ? p.bins : 8, 2), Builder::kMaxBins);
+    B.maxLeaf = std::max<uint32_t>(p.maxLeafTris ? p.maxLeafTris : 4, 1);
+    uint32_t threads = p.threads ? p.threads : std::max(1u, std::thread::hardware_concurrency());
+    if (n < 65536) threads = 1;
+
+    out.nodes.reserve((size_t)n * 2);
+    out.nodes.push_back(Node2{});
+    if (threads == 1) { B.buildSubtree(out.nodes, 0, 0, n); return; }
+
+    // Phase A: expand the top of the tree serially (breadth-first) until there are enough
+    // open subtrees to keep every thread busy.  Phase B: open subtrees are built
+    // concurrently into private vectors.  Phase C: stitched back in a fixed order, so the
+    // result does not depend on thread timing (the reference's threaded builder is
+    // numbering-nondeterministic, tiny_bvh.h:2427; this one is not).
+    struct Open { uint32_t node, first, count; };
+    std::vector<Open> open{{0, 0, n}}, done;
+    const uint32_t target = threads * 8;
+    const uint32_t grain = std::max<uint32_t>(n / (threads * 16), 4096);
+    while (!open.empty() && open.size() + done.size() < target) {
+        // expand the largest open range
+        size_t big = 0;
+        for (size_t i = 1; i < open.size(); i++) if (open[i].count > open[big].count) big = i;
+        Open o = open[big];
+        if (o.count <= grain) break;
+        open.erase(open.begin() + big);
+        const Box b = B.bounds(o.first, o.count);
+        uint32_t mid;
+        if (!B.split(b, o.first, o.count, mid)) { done.push_back(o); continue; }
+        const uint32_t l = (uint32_t)out.nodes.size();
+        out.nodes.push_back(Node2{}); out.nodes.push_back(Node2{});
+        Builder::setNode(out.nodes[o.node], b, l, 0);
+        open.push_back({l, o.first, mid - o.first});
+        open.push_back({l + 1, mid, o.first + o.count - mid});
+    }
+    for (auto& o : done) open.push_back(o);
+    std::vector<std::vector<Node2>> local(open.size());
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= open.size()) break;
+            local[i].reserve((size_t)open[i].count * 2);
+            local[i].push_back(Node2{});
+            B.buildSubtree(local[i], 0, open[i].first, open[i].count);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < threads; t++) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    for (size_t i = 0; i < open.size(); i++) {
+        const std::vector<Node2>& L = local[i];
+        const uint32_t base = (uint32_t)out.nodes.size();  // local index k>=1 -> base + k - 1
+        Node2 r = L[0];
+        if (!r.leaf()) r.leftFirst += base - 1;
+        out.nodes[open[i].node] = r;
+        for (size_t k = 1; k < L.size(); k++) {
+            Node2 c = L[k];
+            if (!c.leaf()) c.leftFirst += base - 1;
+            out.nodes.push_back(c);
+        }
+    }
+}
+
+// ---- wide collapse --------------------------------------------------------------------
+
+template <int M> struct WideNode {
+    Box box;
+    uint32_t child[M];   // index into the wide node array; 0 = empty slot
+    uint32_t childCount;
+    uint32_t firstTri, triCount;  // leaf when triCount > 0
+};
+
+// Collapse a BVH2 into an M-wide tree: starting from a node's two children, repeatedly
+// open the interior child with the largest surface area until M children are reached.
+// Wide node 0 is the root and is always interior (a single-leaf BVH2 gets an extra level,
+// like tiny_bvh.h:5036-5044, because CWBVH and BVH4_GPU need an interior root).
+template <int M> void collapse(const BVH2& bvh, std::vector<WideNode<M>>& W) {
+    W.clear();
+    W.reserve(bvh.nodes.size());
+    auto boxOf = [&](uint32_t n2) { Box b; for (int a = 0; a < 3; a++) b.mn[a] = bvh.nodes[n2].mn[a], b.mx[a] = bvh.nodes[n2].mx[a]; return b; };
+    auto makeLeaf = [&](uint32_t n2) {
+        WideNode<M> w{}; w.box = boxOf(n2); w.firstTri = bvh.nodes[n2].leftFirst; w.triCount = bvh.nodes[n2].triCount;
+        W.push_back(w); return (uint32_t)W.size() - 1;
+    };
+    struct Item { uint32_t wide, n2; };
+    std::vector<Item> stack;
+    {
+        WideNode<M> root{}; root.box = boxOf(0); W.push_back(root);
+        if (bvh.nodes[0].leaf()) {
+            const uint32_t l = makeLeaf(0);
+            W[0].child[0] = l; W[0].childCount = 1;
+            return;
+        }
+        stack.push_back({0, 0});
+    }
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        uint32_t kids[M]; uint32_t nk = 2;
+        kids[0] = bvh.nodes[it.n2].leftFirst; kids[1] = kids[0] + 1;
+        while (nk < (uint32_t)M) {
+            int best = -1; float bestSA = -1.f;
+            for (uint32_t i = 0; i < nk; i++) {
+                const Node2& c = bvh.nodes[kids[i]];
+                if (c.leaf()) continue;
+                const float sa = boxOf(kids[i]).halfArea();
+                if (sa > bestSA) bestSA = sa, best = (int)i;
+            }
+            if (best < 0) break;
+            const uint32_t l = bvh.nodes[kids[best]].leftFirst;
+            kids[best] = l; kids[nk++] = l + 1;
+        }
+        // allocate children contiguously
+        uint32_t slots[M];
+        for (uint32_t i = 0; i < nk; i++) {
+            if (bvh.nodes[kids[i]].leaf()) slots[i] = makeLeaf(kids[i]);
+            else {
+                WideNode<M> w{}; w.box = boxOf(kids[i]); W.push_back(w);
+                slots[i] = (uint32_t)W.size() - 1;
+            }
+        }
+        for (uint32_t i = 0; i < nk; i++) W[it.wide].child[i] = slots[i];
+        W[it.wide].childCount = nk;
+        for (uint32_t i = nk; i-- > 0;)
+            if (!bvh.nodes[kids[i]].leaf()) stack.push_back({slots[i], kids[i]});
+    }
+}
+
+inline uint32_t asU32(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float asF32(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+}  // namespace
+
+// ---- public: builders -------------------------------------------------------------------
+
+void build_bvh2(const Vec4* verts, uint32_t triCount, const BuildParams& p, BVH2& out) {
+    std::vector<Prim> prims(triCount);
+    for (uint32_t i = 0; i < triCount; i++) {
+        Prim& pr = prims[i];
+        pr.box.reset();
+        for (int k = 0; k < 3; k++) pr.box.grow(&verts[3 * (size_t)i + k].x);
+        for (int a = 0; a < 3; a++) pr.c[a] = 0.5f * (pr.box.mn[a] + pr.box.mx[a]);
+    }
+    buildFromPrims(prims, p, out);
+}
+
+void build_bvh2_boxes(const float* boxes6, uint32_t count, const BuildParams& p, BVH2& out) {
+    std::vector<Prim> prims(count);
+    for (uint32_t i = 0; i < count; i++) {
+        Prim& pr = prims[i];
+        for (int a = 0; a < 3; a++) {
+            pr.box.mn[a] = boxes6[6 * (size_t)i + a];
+            pr.box.mx[a] = boxes6[6 * (size_t)i + 3 + a];
+            pr.c[a] = 0.5f * (pr.box.mn[a] + pr.box.mx[a]);
+        }
+    }
+    buildFromPrims(prims, p, out);
+}
+
+// ---- public: encoders -------------------------------------------------------------------
+
+// Aila-Laine layout (format: tiny_bvh.h:1095-1105): depth-first pre-order, the left child
+// of node k is node k+1, interior nodes carry both children's boxes, leaves are all-zero
+// except triCount / firstTri.
+void encode_bvh_gpu(const BVH2& bvh, std::vector<NodeAL>& out) {
+    out.assign(bvh.nodes.size(), NodeAL{});
+    constexpr uint32_t kNone = 0xffffffffu;
+    struct Item { uint32_t src, parent; };  // a deferred right child and the node to patch
+    std::vector<Item> stack{{0, kNone}};
+    uint32_t next = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        uint32_t src = it.src, dst = next++;
+        if (it.parent != kNone) out[it.parent].right = dst;
+        for (;;) {  // walk down the left spine; numbers are consecutive along it
+            const Node2& s = bvh.nodes[src];
+            NodeAL& d = out[dst];
+            if (s.leaf()) { d.triCount = s.triCount; d.firstTri = s.leftFirst; break; }
+            const Node2& l = bvh.nodes[s.leftFirst];
+            const Node2& r = bvh.nodes[s.leftFirst + 1];
+            for (int a = 0; a < 3; a++) d.lmin[a] = l.mn[a], d.lmax[a] = l.mx[a], d.rmin[a] = r.mn[a], d.rmax[a] = r.mx[a];
+            d.left = next;
+            stack.push_back({s.leftFirst + 1, dst});  // numbered after the whole left subtree
+            src = s.leftFirst; dst = next++;
+        }
+    }
+    out.resize(next);
+}
+
+// BVH4_GPU stream (format: tiny_bvh.h:1248-1266, 5120-5127).
+void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& blocks) {
+    std::vector<WideNode<4>> W;
+    collapse<4>(bvh, W);
+    blocks.clear();
+    blocks.reserve(W.size() * 4 + (size_t)bvh.triCount * 3);
+    struct Item { uint32_t wide; uint32_t patchWord; };  // patchWord: u32 index to receive the node's block offset
+    std::vector<Item> stack{{0, 0xffffffffu}};
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        const WideNode<4>& n = W[it.wide];
+        const uint32_t base = (uint32_t)blocks.size();
+        if (it.patchWord != 0xffffffffu) reinterpret_cast<uint32_t*>(blocks.data())[it.patchWord] = base;
+        blocks.resize(blocks.size() + 4, Vec4{0, 0, 0, 0});
+        uint32_t info[4] = {0, 0, 0, 0};
+        uint8_t q[6][4] = {};  // xmin, xmax, ymin, ymax, zmin, zmax per child
+        const float ext[3] = {n.box.mx[0] - n.box.mn[0], n.box.mx[1] - n.box.mn[1], n.box.mx[2] - n.box.mn[2]};
+        float scale[3];
+        for (int a = 0; a < 3; a++) scale[a] = ext[a] > 1e-10f ? 254.999f / ext[a] : 0.f;
+        for (uint32_t i = 0; i < n.childCount; i++) {
+            const WideNode<4>& c = W[n.child[i]];
+            for (int a = 0; a < 3; a++) {
+                q[2 * a][i] = (uint8_t)std::floor((c.box.mn[a] - n.box.mn[a]) * scale[a]);
+                q[2 * a + 1][i] = (uint8_t)std::ceil((c.box.mx[a] - n.box.mn[a]) * scale[a]);
+            }
+            if (c.triCount) {
+                const uint32_t rel = (uint32_t)blocks.size() - base;
+                assert(rel < 65536 && c.triCount < 32768);
+                info[i] = 0x80000000u | (c.triCount << 16) | rel;
+                for (uint32_t j = 0; j < c.triCount; j++) {
+                    const uint32_t prim = bvh.primIdx[c.firstTri + j];
+                    const Vec4 v0 = verts[3 * (size_t)prim], v1 = verts[3 * (size_t)prim + 1], v2 = verts[3 * (size_t)prim + 2];
+                    blocks.push_back(Vec4{v0.x, v0.y, v0.z, asF32(prim)});
+                    blocks.push_back(Vec4{v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v1.w - v0.w});
+                    blocks.push_back(Vec4{v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, v2.w - v0.w});
+                }
+            }
+        }
+        // interior children: offsets are patched in when each child is emitted
+        for (uint32_t i = n.childCount; i-- > 0;) {
+            if (W[n.child[i]].triCount) continue;
+            stack.push_back({n.child[i], (base + 3) * 4 + i});
+        }
+        Vec4* nb = blocks.data() + base;
+        uint32_t w0, w1, w2[4];
+        std::memcpy(&w0, q[0], 4); std::memcpy(&w1, q[1], 4);
+        std::memcpy(&w2[0], q[2], 4); std::memcpy(&w2[1], q[3], 4); std::memcpy(&w2[2], q[4], 4); std::memcpy(&w2[3], q[5], 4);
+        nb[0] = Vec4{n.box.mn[0], n.box.mn[1], n.box.mn[2], asF32(w0)};
+        nb[1] = Vec4{ext[0] * (1.0f / 255.0f), ext[1] * (1.0f / 255.0f), ext[2] * (1.0f / 255.0f), asF32(w1)};
+        nb[2] = Vec4{asF32(w2[0]), asF32(w2[1]), asF32(w2[2]), asF32(w2[3])};
+        nb[3] = Vec4{asF32(info[0]), asF32(info[1]), asF32(info[2]), asF32(info[3])};
+    }
+}
+
+// CWBVH (format: Ylitie et al. 2017 as laid out by tiny_bvh.h:5884-6018).
+void encode_cwbvh(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& nodeBlocks,
+                  std::vector<Vec4>& triBlocks) {
+    std::vector<WideNode<8>> W;
+    collapse<8>(bvh, W);
+    nodeBlocks.clear(); triBlocks.clear();
+    nodeBlocks.reserve(W.size() * 5);
+    triBlocks.reserve((size_t)bvh.triCount * 3);
+    struct Item { uint32_t wide; uint32_t addr; };  // addr = node index in the output
+    std::vector<Item> stack{{0, 0}};
+    nodeBlocks.resize(5, Vec4{0, 0, 0, 0});
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        const WideNode<8>& n = W[it.wide];
+        // --- slot assignment: children go to the octant slot their centroid offset points
+        // at (slot bit 2 = -x, bit 1 = -y, bit 0 = -z side), solved greedily on the
+        // cost matrix cost[s][i] = dot(centroid_i - centroid_node, dir_s).
+        float cost[8][8];
+        int slotOf[8], childIn[8];
+        for (int s = 0; s < 8; s++) childIn[s] = -1;
+        for (int i = 0; i < 8; i++) slotOf[i] = -1;
+        float nc[3];
+        for (int a = 0; a < 3; a++) nc[a] = 0.5f * (n.box.mn[a] + n.box.mx[a]);
+        for (uint32_t i = 0; i < n.childCount; i++) {
+            const Box& cb = W[n.child[i]].box;
+            float d[3];
+            for (int a = 0; a < 3; a++) d[a] = 0.5f * (cb.mn[a] + cb.mx[a]) - nc[a];
+            for (int s = 0; s < 8; s++)
+                cost[s][i] = ((s & 4) ? -d[0] : d[0]) + ((s & 2) ? -d[1] : d[1]) + ((s & 1) ? -d[2] : d[2]);
+        }
+        for (uint32_t k = 0; k < n.childCount; k++) {
+            float best = kFar; int bs = -1, bi = -1;
+            for (int s = 0; s < 8; s++) if (childIn[s] < 0)
+                for (uint32_t i = 0; i < n.childCount; i++) if (slotOf[i] < 0 && cost[s][i] < best)
+                    best = cost[s][i], bs = s, bi = (int)i;
+            slotOf[bi] = bs; childIn[bs] = bi;
+        }
+        // --- per-axis exponent: smallest e with extent / 2^e <= 255
+        int e[3];
+        float inv[3];
+        for (int a = 0; a < 3; a++) {
+            const float ext = n.box.mx[a] - n.box.mn[a];
+            int ea = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0f)) : -126;
+            ea = std::max(ea, -126);
+            // guard the ceil() of every child against 255 overflow from rounding
+            for (;;) {
+                const float s = std::ldexp(1.0f, -ea);
+                bool ok = true;
+                for (uint32_t i = 0; i < n.childCount; i++)
+                    if (std::ceil((W[n.child[i]].box.mx[a] - n.box.mn[a]) * s) > 255.f) ok = false;
+                if (ok) break;
+                ea++;
+            }
+            e[a] = ea; inv[a] = std::ldexp(1.0f, -ea);
+        }
+        uint8_t meta[8] = {}, q[6][8] = {};
+        uint32_t imask = 0, childBase = 0, triBase = 0, nInner = 0, nTris = 0;
+        for (int s = 0; s < 8; s++) {
+            if (childIn[s] < 0) continue;
+            const uint32_t ci = n.child[childIn[s]];
+            const WideNode<8>& c = W[ci];
+            for (int a = 0; a < 3; a++) {
+                q[a][s] = (uint8_t)std::floor((c.box.mn[a] - n.box.mn[a]) * inv[a]);
+                q[3 + a][s] = (uint8_t)std::ceil((c.box.mx[a] - n.box.mn[a]) * inv[a]);
+            }
+            if (!c.triCount) {
+                const uint32_t addr = (uint32_t)(nodeBlocks.size() / 5);
+                nodeBlocks.resize(nodeBlocks.size() + 5, Vec4{0, 0, 0, 0});
+                if (nInner++ == 0) childBase = addr;
+                imask |= 1u << s;
+                meta[s] = (uint8_t)((1u << 5) | (24 + s));
+                stack.push_back({ci, addr});
+            } else {
+                assert(c.triCount <= 3);
+                if (nTris == 0) triBase = (uint32_t)triBlocks.size();
+                const uint32_t unary = c.triCount == 1 ? 1u : c.triCount == 2 ? 3u : 7u;
+                meta[s] = (uint8_t)((unary << 5) | nTris);
+                nTris += c.triCount;
+                for (uint32_t j = 0; j < c.triCount; j++) {
+                    const uint32_t prim = bvh.primIdx[c.firstTri + j];
+                    const Vec4 v0 = verts[3 * (size_t)prim], v1 = verts[3 * (size_t)prim + 1], v2 = verts[3 * (size_t)prim + 2];
+                    triBlocks.push_back(Vec4{v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, v2.w - v0.w});
+                    triBlocks.push_back(Vec4{v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v1.w - v0.w});
+                    triBlocks.push_back(Vec4{v0.x, v0.y, v0.z, asF32(prim)});
+                }
+            }
+        }
+        assert(nTris <= 24);
+        Vec4* nb = nodeBlocks.data() + (size_t)it.addr * 5;
+        const uint32_t eim = ((uint32_t)(uint8_t)(int8_t)e[0]) | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) |
+                             ((uint32_t)(uint8_t)(int8_t)e[2] << 16) | (imask << 24);
+        uint32_t m0, m1; std::memcpy(&m0, meta, 4); std::memcpy(&m1, meta + 4, 4);
+        nb[0] = Vec4{n.box.mn[0], n.box.mn[1], n.box.mn[2], asF32(eim)};
+        nb[1] = Vec4{asF32(childBase), asF32(triBase), asF32(m0), asF32(m1)};
+        uint32_t w[12];
+        std::memcpy(w, q, 48);  // qlo_x[8] qlo_y[8] qlo_z[8] qhi_x[8] qhi_y[8] qhi_z[8]
+        nb[2] = Vec4{asF32(w[0]), asF32(w[1]), asF32(w[2]), asF32(w[3])};
+        nb[3] = Vec4{asF32(w[4]), asF32(w[5]), asF32(w[6]), asF32(w[7])};
+        nb[4] = Vec4{asF32(w[8]), asF32(w[9]), asF32(w[10]), asF32(w[11])};
+    }
+}
+
+// ---- instances ---------------------------------------------------------------------------
+
+static bool invert4x4(const float* m, float* out) {
+    // Gauss-Jordan with partial pivoting in double precision.
+    double a[4][8];
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) a[r][c] = m[r * 4 + c], a[r][4 + c] = r == c;
+    for (int c = 0; c < 4; c++) {
+        int piv = c;
+        for (int r = c + 1; r < 4; r++) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0) return false;
+        if (piv != c) for (int k = 0; k < 8; k++) std::swap(a[piv][k], a[c][k]);
+        const double d = 1.0 / a[c][c];
+        for (int k = 0; k < 8; k++) a[c][k] *= d;
+        for (int r = 0; r < 4; r++) if (r != c) {
+            const double f = a[r][c];
+            if (f != 0) for (int k = 0; k < 8; k++) a[r][k] -= f * a[c][k];
+        }
+    }
+    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) out[r * 4 + c] = (float)a[r][4 + c];
+    return true;
+}
+
+// Same job as BLASInstance::Update (tiny_bvh.h:8386-8400): invert the transform, then take
+// the world-space box of the 8 transformed corners of the BLAS root box.
+void update_instance(Instance192& inst, const float* bb) {
+    if (!invert4x4(inst.transform, inst.invTransform)) std::memcpy(inst.invTransform, inst.transform, 64);
+    Box w; w.reset();
+    const float* T = inst.transform;
+    for (int j = 0; j < 8; j++) {
+        const float p[3] = {(j & 1) ? bb[3] : bb[0], (j & 2) ? bb[4] : bb[1], (j & 4) ? bb[5] : bb[2]};
+        float t[3];
+        for (int r = 0; r < 3; r++) t[r] = T[r * 4] * p[0] + T[r * 4 + 1] * p[1] + T[r * 4 + 2] * p[2] + T[r * 4 + 3];
+        const float ww = T[12] * p[0] + T[13] * p[1] + T[14] * p[2] + T[15];
+        if (ww != 1.0f) { const float r = 1.0f / ww; t[0] *= r; t[1] *= r; t[2] *= r; }
+        w.grow(t);
+    }
+    for (int a = 0; a < 3; a++) inst.aabbMin[a] = w.mn[a], inst.aabbMax[a] = w.mx[a];
+}
+
+}  // namespace tbvh

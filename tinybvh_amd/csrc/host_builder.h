@@ -1,0 +1,70 @@
+// host_builder.h — host-side BVH construction and encoding into the blob formats the
+// traversal kernels consume (formats: SURVEY.md Appendix A; reference writers cited per
+// function in host_builder.cpp).  Independent implementation: binned SAH BVH2 builder with
+// deterministic task-parallel subtree construction, surface-area-greedy wide collapse, and
+// encoders for BVH_GPU (Aila-Laine), BVH4_GPU and BVH8_CWBVH.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace tbvh {
+
+struct Vec4 { float x, y, z, w; };
+
+// 32-byte node, same field order as tinybvh::BVH::BVHNode (tiny_bvh.h:857-866):
+// interior: leftFirst = index of left child, right child = leftFirst + 1, triCount = 0;
+// leaf: leftFirst = first entry in primIdx, triCount > 0.
+struct Node2 {
+    float mn[3]; uint32_t leftFirst;
+    float mx[3]; uint32_t triCount;
+    bool leaf() const { return triCount > 0; }
+};
+static_assert(sizeof(Node2) == 32, "Wald node is 32 bytes");
+
+// 64-byte Aila-Laine node (tiny_bvh.h:1095-1105).
+struct NodeAL {
+    float lmin[3]; uint32_t left;
+    float lmax[3]; uint32_t right;
+    float rmin[3]; uint32_t triCount;
+    float rmax[3]; uint32_t firstTri;
+};
+static_assert(sizeof(NodeAL) == 64, "Aila-Laine node is 64 bytes");
+
+struct BuildParams {
+    uint32_t bins = 8;
+    uint32_t maxLeafTris = 4;
+    uint32_t threads = 0;
+};
+
+struct BVH2 {
+    std::vector<Node2> nodes;       // root = 0, siblings adjacent
+    std::vector<uint32_t> primIdx;  // permutation of [0, triCount)
+    uint32_t triCount = 0;
+};
+
+// Build a BVH2 over triangles given as 3 x Vec4 per triangle.
+void build_bvh2(const Vec4* verts, uint32_t triCount, const BuildParams& p, BVH2& out);
+
+// Build a BVH2 over arbitrary boxes (used for the TLAS): box i = {mn[3], mx[3]}.
+void build_bvh2_boxes(const float* boxes6, uint32_t count, const BuildParams& p, BVH2& out);
+
+// Encoders.
+void encode_bvh_gpu(const BVH2& bvh, std::vector<NodeAL>& out);
+void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& blocks);
+void encode_cwbvh(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& nodeBlocks,
+                  std::vector<Vec4>& triBlocks);
+
+// BLASInstance record, 192 bytes (tiny_bvh.h:1443-1457).
+struct Instance192 {
+    float transform[16];
+    float invTransform[16];
+    float aabbMin[3]; uint32_t blasIdx;
+    float aabbMax[3]; uint32_t mask;
+    uint32_t pad[8];
+};
+static_assert(sizeof(Instance192) == 192, "BLASInstance is 192 bytes");
+
+// Fill invTransform and world-space bounds of one instance from the bounds of its BLAS.
+void update_instance(Instance192& inst, const float* blasBounds6);
+
+}  // namespace tbvh

@@ -1,0 +1,29 @@
+// kernels.h — host-visible launchers of the device kernels (defined in kernels_*.hip).
+#pragma once
+#include "device_common.h"
+
+namespace tbvh {
+
+void launch_bvh2(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
+                 uint32_t blocks, hipStream_t s);
+void launch_bvh4(bool anyhit, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
+void launch_cwbvh(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
+                  uint32_t blocks, hipStream_t s);
+void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris,
+                        hipStream_t s);
+
+// ray generators (kernels_raygen.hip)
+struct CameraArgs {
+    float eye[3], p1[3], p2[3], p3[3];
+    uint32_t width, height, sppX, sppY;
+};
+void launch_gen_primary(const CameraArgs& cam, RayRec* rays, uint64_t first, uint64_t n, hipStream_t s);
+// triangle fetch mode for the bounce generator: how to find the geometric normal of prim p
+struct TriSource {
+    int mode;              // 0: verts (3 float4 per prim, original order); 1: none
+    const float4* verts;
+};
+void launch_gen_bounce(const TriSource& src, const RayRec* in, RayRec* out, uint64_t n, uint32_t seed, hipStream_t s);
+void launch_gen_shadow(const RayRec* in, RayRec* out, uint64_t n, float lx, float ly, float lz, float eps, hipStream_t s);
+
+}  // namespace tbvh

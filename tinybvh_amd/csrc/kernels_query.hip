@@ -1,0 +1,332 @@
+// kernels_query.hip — batched Intersect / IsOccluded kernels for gfx950 (MI355X).
+//
+// Replaces (from scratch, not a port) the reference's OpenCL entry points
+//   batch_ailalaine / isoccluded_ailalaine   traverse_bvh2.cl:80-219
+//   batch_gpu4way   / isoccluded_gpu4way     traverse_bvh4.cl:74-286
+//   batch_cwbvh     / isoccluded_cwbvh       traverse_cwbvh.cl:124-570
+// Result semantics follow the CPU oracle BVH::Intersect / IsOccluded (tiny_bvh.h:3247-3304,
+// 3408-3453, 1644-1656), not the .cl files (which use strict comparisons and
+// native_recip): a candidate is rejected only if t < 0 || t > tmax, |det| < 1e-6 misses,
+// nodes whose entry distance equals the current hit distance are still visited.
+//
+// Structure common to all kernels: persistent waves (one wave = one 64-thread workgroup)
+// pull batches of rays from a global counter; one lane owns one ray; the traversal stack
+// is per lane, top in LDS, bottom spilled to global (lane_stack.h).
+#include "device_common.h"
+#include "lane_stack.h"
+#include "kernels.h"
+
+namespace tbvh {
+
+constexpr int WG = 64;
+
+__device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+__device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+// Wave-level batch fetch: lane 0 takes `WG` consecutive ray indices.
+__device__ __forceinline__ uint64_t fetch_batch(unsigned long long* counter) {
+    unsigned long long base = 0;
+    if (threadIdx.x == 0) base = atomicAdd(counter, (unsigned long long)WG);
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
+    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// ---------------------------------------------------------------------------------------
+// BVH_GPU (Aila-Laine 2-wide).  nodes: 4 x float4 per node, verbatim BVH_GPU::bvhNode.
+// tris: 3 x float4 per primIdx entry {v0.xyz|prim, e1, e2}, gathered at upload so a leaf
+// reads one contiguous run instead of primIdx -> verts (two dependent gathers).
+// ---------------------------------------------------------------------------------------
+template <bool ANYHIT>
+__global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes,
+                                             const float4* __restrict__ tris, QueryArgs q,
+                                             uint32_t* __restrict__ status) {
+    constexpr int LDS_N = 24;
+    __shared__ uint32_t stk[LDS_N][WG];
+    const uint32_t glane = blockIdx.x * WG + threadIdx.x;
+    LaneStack<uint32_t, LDS_N, WG> st;
+    st.init(&stk[0][threadIdx.x], q.spill + glane, gridDim.x * WG, q.spillStride);
+    for (;;) {
+        const uint64_t base = fetch_batch((unsigned long long*)q.counter);
+        if (base >= q.nRays) break;
+        const uint64_t ri = base + threadIdx.x;
+        if (ri >= q.nRays) continue;
+        RayRec* rp = q.rays + ri;
+        const float3 O = xyz(rp->O), D = xyz(rp->D), rD = xyz(rp->rD);
+        float4 hit = rp->hit;
+        const float3 ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z);
+        bool found = false;
+        st.reset();
+        uint32_t node = 0;
+        for (;;) {
+            const float4 n0 = nodes[node * 4], n1 = nodes[node * 4 + 1], n2 = nodes[node * 4 + 2], n3 = nodes[node * 4 + 3];
+            const uint32_t triCount = as_u32(n2.w);
+            if (triCount) {
+                uint32_t ta = as_u32(n3.w) * 3;
+                for (uint32_t i = 0; i < triCount; i++, ta += 3) {
+                    const float4 v0 = tris[ta], e1 = tris[ta + 1], e2 = tris[ta + 2];
+                    TriHit h;
+                    if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                        found = true;
+                        if (ANYHIT) break;
+                        hit = make_float4(h.t, h.u, h.v, v0.w);
+                    }
+                }
+                if (ANYHIT && found) break;
+                if (st.empty()) break;
+                node = st.pop();
+                continue;
+            }
+            // slab test of both children, oracle form: t = plane * rD - O*rD, inclusive
+            // visit rule tmax >= tmin (SLAB_TEST_TWO_NODES, tiny_bvh.h:3202-3220)
+            const float lx1 = __builtin_fmaf(n0.x, rD.x, -ro.x), lx2 = __builtin_fmaf(n1.x, rD.x, -ro.x);
+            const float ly1 = __builtin_fmaf(n0.y, rD.y, -ro.y), ly2 = __builtin_fmaf(n1.y, rD.y, -ro.y);
+            const float lz1 = __builtin_fmaf(n0.z, rD.z, -ro.z), lz2 = __builtin_fmaf(n1.z, rD.z, -ro.z);
+            const float rx1 = __builtin_fmaf(n2.x, rD.x, -ro.x), rx2 = __builtin_fmaf(n3.x, rD.x, -ro.x);
+            const float ry1 = __builtin_fmaf(n2.y, rD.y, -ro.y), ry2 = __builtin_fmaf(n3.y, rD.y, -ro.y);
+            const float rz1 = __builtin_fmaf(n2.z, rD.z, -ro.z), rz2 = __builtin_fmaf(n3.z, rD.z, -ro.z);
+            const float tminL = __builtin_fmaxf(fmax3(__builtin_fminf(lx1, lx2), __builtin_fminf(ly1, ly2), __builtin_fminf(lz1, lz2)), 0.0f);
+            const float tmaxL = __builtin_fminf(fmin3(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2), __builtin_fmaxf(lz1, lz2)), hit.x);
+            const float tminR = __builtin_fmaxf(fmax3(__builtin_fminf(rx1, rx2), __builtin_fminf(ry1, ry2), __builtin_fminf(rz1, rz2)), 0.0f);
+            const float tmaxR = __builtin_fminf(fmin3(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2), __builtin_fmaxf(rz1, rz2)), hit.x);
+            const bool hL = tmaxL >= tminL, hR = tmaxR >= tminR;
+            uint32_t l = as_u32(n0.w), r = as_u32(n1.w);
+            if (hL && hR) {
+                if (tminL > tminR) { const uint32_t t = l; l = r; r = t; }
+                st.push(r);
+                node = l;
+            } else if (hL) node = l;
+            else if (hR) node = r;
+            else {
+                if (st.empty()) break;
+                node = st.pop();
+            }
+        }
+        if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+        else if (found) rp->hit = hit;
+    }
+    if (st.overflow) atomicOr(status, 1u);
+}
+
+// ---------------------------------------------------------------------------------------
+// BVH4_GPU.  One float4 stream, verbatim BVH4_GPU::bvh4Data.
+// Traversal order follows the CPU mirror (tiny_bvh.h:5252-5343): children sorted far to
+// near, interior children pushed far first (nearest on top), hit leaves processed in the
+// same sorted order.
+// ---------------------------------------------------------------------------------------
+template <bool ANYHIT>
+__global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, QueryArgs q,
+                                             uint32_t* __restrict__ status) {
+    constexpr int LDS_N = 24;
+    __shared__ uint32_t stk[LDS_N][WG];
+    const uint32_t glane = blockIdx.x * WG + threadIdx.x;
+    LaneStack<uint32_t, LDS_N, WG> st;
+    st.init(&stk[0][threadIdx.x], q.spill + glane, gridDim.x * WG, q.spillStride);
+    for (;;) {
+        const uint64_t base = fetch_batch((unsigned long long*)q.counter);
+        if (base >= q.nRays) break;
+        const uint64_t ri = base + threadIdx.x;
+        if (ri >= q.nRays) continue;
+        RayRec* rp = q.rays + ri;
+        const float3 O = xyz(rp->O), D = xyz(rp->D), rD = xyz(rp->rD);
+        float4 hit = rp->hit;
+        bool found = false;
+        st.reset();
+        uint32_t offset = 0;
+        for (;;) {
+            const float4 d0 = data[offset], d1 = data[offset + 1], d2 = data[offset + 2], d3 = data[offset + 3];
+            // per-axis: t(q) = (bmin + ext*q - O) * rD = q * (ext*rD) + (bmin - O)*rD
+            const float sx = d1.x * rD.x, sy = d1.y * rD.y, sz = d1.z * rD.z;
+            const float bx = (d0.x - O.x) * rD.x, by = (d0.y - O.y) * rD.y, bz = (d0.z - O.z) * rD.z;
+            const uint32_t qx0 = as_u32(d0.w), qx1 = as_u32(d1.w);
+            const uint32_t qy0 = as_u32(d2.x), qy1 = as_u32(d2.y), qz0 = as_u32(d2.z), qz1 = as_u32(d2.w);
+            float dist[4];
+            uint32_t info[4] = { as_u32(d3.x), as_u32(d3.y), as_u32(d3.z), as_u32(d3.w) };
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int sh = 8 * i;
+                const float x1 = __builtin_fmaf((float)((qx0 >> sh) & 255), sx, bx), x2 = __builtin_fmaf((float)((qx1 >> sh) & 255), sx, bx);
+                const float y1 = __builtin_fmaf((float)((qy0 >> sh) & 255), sy, by), y2 = __builtin_fmaf((float)((qy1 >> sh) & 255), sy, by);
+                const float z1 = __builtin_fmaf((float)((qz0 >> sh) & 255), sz, bz), z2 = __builtin_fmaf((float)((qz1 >> sh) & 255), sz, bz);
+                const float tmin = __builtin_fmaxf(fmax3(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2), __builtin_fminf(z1, z2)), 0.0f);
+                const float tmax = __builtin_fminf(fmin3(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2), __builtin_fmaxf(z1, z2)), hit.x);
+                dist[i] = (tmin > tmax || info[i] == 0) ? kFar : tmin;
+            }
+            // 5-comparator network, descending (farthest first)
+#define TBVH_CSWAP(a, b) if (dist[a] < dist[b]) { const float tf = dist[a]; dist[a] = dist[b]; dist[b] = tf; const uint32_t tu = info[a]; info[a] = info[b]; info[b] = tu; }
+            TBVH_CSWAP(0, 2) TBVH_CSWAP(1, 3) TBVH_CSWAP(0, 1) TBVH_CSWAP(2, 3) TBVH_CSWAP(1, 2)
+#undef TBVH_CSWAP
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (dist[i] < kFar && !(info[i] & 0x80000000u)) st.push(info[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                if (!(dist[i] < kFar) || !(info[i] & 0x80000000u)) continue;
+                const uint32_t N = (info[i] >> 16) & 0x7fff;
+                uint32_t ta = offset + (info[i] & 0xffff);
+                for (uint32_t j = 0; j < N; j++, ta += 3) {
+                    const float4 v0 = data[ta], e1 = data[ta + 1], e2 = data[ta + 2];
+                    TriHit h;
+                    if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                        found = true;
+                        if (ANYHIT) break;
+                        hit = make_float4(h.t, h.u, h.v, v0.w);
+                    }
+                }
+                if (ANYHIT && found) break;
+            }
+            if (ANYHIT && found) break;
+            if (st.empty()) break;
+            offset = st.pop();
+        }
+        if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+        else if (found) rp->hit = hit;
+    }
+    if (st.overflow) atomicOr(status, 1u);
+}
+
+// ---------------------------------------------------------------------------------------
+// BVH8_CWBVH.  nodes: 5 x float4 per node, tris: 3 x float4 {e2, e1, v0|prim}; both
+// verbatim.  State machine after Ylitie et al. 2017 as restated by the CPU
+// mirror tiny_bvh.h:7046-7154: ngroup = {child base, hits<<24 | imask}, tgroup =
+// {tri base, tri bits}; highest set bit first = front-to-back through octinv.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sext_s8x4(uint32_t i) {
+    // every byte with its top bit set becomes 0xff, others 0x00
+    return ((i >> 7) & 0x01010101u) * 0xffu;
+}
+
+template <bool ANYHIT>
+__global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes,
+                                              const float4* __restrict__ tris, QueryArgs q,
+                                              uint32_t* __restrict__ status) {
+    constexpr int LDS_N = 16;
+    __shared__ uint2 stk[LDS_N][WG];
+    const uint32_t glane = blockIdx.x * WG + threadIdx.x;
+    LaneStack<uint2, LDS_N, WG> st;
+    st.init(&stk[0][threadIdx.x], (uint2*)q.spill + glane, gridDim.x * WG, q.spillStride);
+    for (;;) {
+        const uint64_t base = fetch_batch((unsigned long long*)q.counter);
+        if (base >= q.nRays) break;
+        const uint64_t ri = base + threadIdx.x;
+        if (ri >= q.nRays) continue;
+        RayRec* rp = q.rays + ri;
+        const float3 O = xyz(rp->O), D = xyz(rp->D), rD = xyz(rp->rD);
+        float4 hit = rp->hit;
+        bool found = false;
+        st.reset();
+        const uint32_t oct = 7u - ((D.x < 0 ? 4u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 1u : 0u));
+        const uint32_t octinv4 = oct * 0x01010101u;
+        uint2 ng = make_uint2(0u, 0x80000000u), tg = make_uint2(0u, 0u);
+        for (;;) {
+            if (ng.y > 0x00FFFFFFu) {
+                const uint32_t imask = ng.y;
+                const uint32_t bit = 31u - (uint32_t)__clz(ng.y);
+                const uint32_t cbase = ng.x;
+                ng.y &= ~(1u << bit);
+                if (ng.y > 0x00FFFFFFu) st.push(ng);
+                const uint32_t slot = (bit - 24u) ^ oct;
+                const uint32_t rel = __popc(imask & ~(0xFFFFFFFFu << slot));
+                const uint32_t ci = (cbase + rel) * 5u;
+                const float4 n0 = nodes[ci], n1 = nodes[ci + 1], n2 = nodes[ci + 2], n3 = nodes[ci + 3], n4 = nodes[ci + 4];
+                const uint32_t ew = as_u32(n0.w);
+                const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
+                const float ox = (n0.x - O.x) * rD.x, oy = (n0.y - O.y) * rD.y, oz = (n0.z - O.z) * rD.z;
+                ng.x = as_u32(n1.x); tg.x = as_u32(n1.y);
+                uint32_t hitmask = 0;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const uint32_t meta4 = half ? as_u32(n1.w) : as_u32(n1.z);
+                    const uint32_t inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+                    const uint32_t imask4 = sext_s8x4(inner4 << 3);
+                    const uint32_t bitidx4 = (meta4 ^ (octinv4 & imask4)) & 0x1F1F1F1Fu;
+                    const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;
+                    const uint32_t qlx = half ? as_u32(n2.y) : as_u32(n2.x), qhx = half ? as_u32(n3.w) : as_u32(n3.z);
+                    const uint32_t qly = half ? as_u32(n2.w) : as_u32(n2.z), qhy = half ? as_u32(n4.y) : as_u32(n4.x);
+                    const uint32_t qlz = half ? as_u32(n3.y) : as_u32(n3.x), qhz = half ? as_u32(n4.w) : as_u32(n4.z);
+                    const uint32_t lox = rD.x < 0 ? qhx : qlx, hix = rD.x < 0 ? qlx : qhx;
+                    const uint32_t loy = rD.y < 0 ? qhy : qly, hiy = rD.y < 0 ? qly : qhy;
+                    const uint32_t loz = rD.z < 0 ? qhz : qlz, hiz = rD.z < 0 ? qlz : qhz;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int sh = 8 * i;
+                        const float tnx = __builtin_fmaf((float)((lox >> sh) & 255), ax, ox), tfx = __builtin_fmaf((float)((hix >> sh) & 255), ax, ox);
+                        const float tny = __builtin_fmaf((float)((loy >> sh) & 255), ay, oy), tfy = __builtin_fmaf((float)((hiy >> sh) & 255), ay, oy);
+                        const float tnz = __builtin_fmaf((float)((loz >> sh) & 255), az, oz), tfz = __builtin_fmaf((float)((hiz >> sh) & 255), az, oz);
+                        const float cmin = __builtin_fmaxf(fmax3(tnx, tny, tnz), 0.0f);
+                        const float cmax = __builtin_fminf(fmin3(tfx, tfy, tfz), hit.x);
+                        if (cmin <= cmax) hitmask |= ((bits4 >> sh) & 255u) << ((bitidx4 >> sh) & 255u);
+                    }
+                }
+                ng.y = (hitmask & 0xFF000000u) | (ew >> 24);
+                tg.y = hitmask & 0x00FFFFFFu;
+            } else {
+                tg = ng;
+                ng = make_uint2(0u, 0u);
+            }
+            while (tg.y != 0) {
+                const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
+                tg.y &= ~(1u << ti);
+                const uint32_t ta = tg.x + ti * 3u;
+                const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
+                TriHit h;
+                if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                    found = true;
+                    if (ANYHIT) break;
+                    hit = make_float4(h.t, h.u, h.v, v0.w);
+                }
+            }
+            if (ANYHIT && found) break;
+            if (ng.y > 0x00FFFFFFu) continue;
+            if (st.empty()) break;
+            ng = st.pop();
+        }
+        if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+        else if (found) rp->hit = hit;
+    }
+    if (st.overflow) atomicOr(status, 1u);
+}
+
+// ---------------------------------------------------------------------------------------
+// upload helper: gather {v0|prim, e1, e2} per primIdx entry for the BVH_GPU layout.
+// e1 = v1 - v0, e2 = v2 - v0 are the same single IEEE subtractions IntersectTri performs
+// per test (tiny_bvh.h:8510-8511), so pre-computing them changes no result bit.
+// ---------------------------------------------------------------------------------------
+__global__ void k_gather_tris(const uint32_t* __restrict__ primIdx, const float4* __restrict__ verts,
+                              float4* __restrict__ out, uint64_t nIdx, uint64_t nTris) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nIdx) return;
+    const uint32_t p = primIdx[i];
+    if (p >= nTris) {  // slack entries of SBVH primIdx arrays (idxCount = 1.5 * triCount)
+        out[i * 3] = make_float4(0, 0, 0, 0); out[i * 3 + 1] = make_float4(0, 0, 0, 0); out[i * 3 + 2] = make_float4(0, 0, 0, 0);
+        return;
+    }
+    const float4 a = verts[(uint64_t)p * 3], b = verts[(uint64_t)p * 3 + 1], c = verts[(uint64_t)p * 3 + 2];
+    out[i * 3] = make_float4(a.x, a.y, a.z, as_f32(p));
+    out[i * 3 + 1] = make_float4(b.x - a.x, b.y - a.y, b.z - a.z, 0.f);
+    out[i * 3 + 2] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, 0.f);
+}
+
+// ---- launchers (called from capi.hip) ----------------------------------------------------
+
+void launch_bvh2(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
+                 uint32_t blocks, hipStream_t s) {
+    if (anyhit) hipLaunchKernelGGL(k_bvh2<true>, dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    else hipLaunchKernelGGL(k_bvh2<false>, dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+}
+void launch_bvh4(bool anyhit, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
+    if (anyhit) hipLaunchKernelGGL(k_bvh4<true>, dim3(blocks), dim3(WG), 0, s, data, q, status);
+    else hipLaunchKernelGGL(k_bvh4<false>, dim3(blocks), dim3(WG), 0, s, data, q, status);
+}
+void launch_cwbvh(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
+                  uint32_t blocks, hipStream_t s) {
+    if (anyhit) hipLaunchKernelGGL(k_cwbvh<true>, dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    else hipLaunchKernelGGL(k_cwbvh<false>, dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+}
+void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris, hipStream_t s) {
+    const uint32_t bs = 256;
+    hipLaunchKernelGGL(k_gather_tris, dim3((uint32_t)((nIdx + bs - 1) / bs)), dim3(bs), 0, s, primIdx, verts, out, nIdx, nTris);
+}
+
+}  // namespace tbvh

@@ -1,0 +1,108 @@
+// kernels_raygen.hip — device-side ray generators for the benchmark configurations, so
+// that rays are produced and consumed in HBM without host round trips.
+//   primary : pinhole camera, 4x4-pixel tiles x spp samples, the speedtest's order
+//             (tiny_bvh_speedtest.cpp:517-551)
+//   bounce  : one diffuse bounce from the hit points of a traced batch
+//             (tiny_bvh_speedtest.cpp:561-587; RNG = WangHash + xorshift32, tools.cl:9-11)
+//   shadow  : rays from hit points toward a point light (tiny_bvh_speedtest.cpp:851-865)
+// Every generated record is what the tinybvh::Ray constructor would build
+// (tiny_bvh.h:695-703): D normalised, rD = tinybvh_safercp(D), mask 0xFFFF, hit.t = tmax.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace tbvh {
+
+__device__ __forceinline__ float safercp(float x) {  // tiny_bvh.h:442
+    if (x > 1e-12f || x < -1e-12f) return 1.0f / x;
+    return x >= 0 ? kFar : -kFar;
+}
+__device__ __forceinline__ float3 normalize3(float3 a) {  // tiny_bvh.h:506-510
+    const float l = sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    const float rl = l == 0 ? 0.f : 1.0f / l;
+    return make_float3(a.x * rl, a.y * rl, a.z * rl);
+}
+__device__ __forceinline__ void write_ray(RayRec* r, float3 O, float3 dir, float tmax) {
+    const float3 D = normalize3(dir);
+    r->O = make_float4(O.x, O.y, O.z, as_f32(0xFFFFu));
+    r->D = make_float4(D.x, D.y, D.z, 0.f);
+    r->rD = make_float4(safercp(D.x), safercp(D.y), safercp(D.z), 0.f);
+    r->hit = make_float4(tmax, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ uint32_t wang_hash(uint32_t s) {
+    s = (s ^ 61u) ^ (s >> 16); s *= 9u; s = s ^ (s >> 4); s *= 0x27d4eb2du; return s ^ (s >> 15);
+}
+__device__ __forceinline__ float rand_float(uint32_t& seed) {
+    seed ^= seed << 13; seed ^= seed >> 17; seed ^= seed << 5;
+    return (float)seed * 2.3283064365387e-10f;
+}
+
+__global__ void k_gen_primary(CameraArgs cam, RayRec* __restrict__ rays, uint64_t first, uint64_t n) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t i = first + k;
+    const uint32_t spp = cam.sppX * cam.sppY;
+    const uint32_t s = (uint32_t)(i % spp);
+    const uint64_t pix = i / spp;
+    const uint32_t inTile = (uint32_t)(pix & 15);
+    const uint64_t tile = pix >> 4;
+    const uint32_t tilesX = cam.width / 4;
+    const uint32_t tx = (uint32_t)(tile % tilesX), ty = (uint32_t)(tile / tilesX);
+    const uint32_t px = tx * 4 + (inTile & 3), py = ty * 4 + (inTile >> 2);
+    const float u = (float)(px * cam.sppX + (s % cam.sppX)) / (float)(cam.width * cam.sppX);
+    const float v = (float)(py * cam.sppY + (s / cam.sppX)) / (float)(cam.height * cam.sppY);
+    const float3 eye = make_float3(cam.eye[0], cam.eye[1], cam.eye[2]);
+    const float3 P = make_float3(cam.p1[0] + u * (cam.p2[0] - cam.p1[0]) + v * (cam.p3[0] - cam.p1[0]),
+                                 cam.p1[1] + u * (cam.p2[1] - cam.p1[1]) + v * (cam.p3[1] - cam.p1[1]),
+                                 cam.p1[2] + u * (cam.p2[2] - cam.p1[2]) + v * (cam.p3[2] - cam.p1[2]));
+    write_ray(rays + k, eye, make_float3(P.x - eye.x, P.y - eye.y, P.z - eye.z), kFar);
+}
+
+__global__ void k_gen_bounce(TriSource src, const RayRec* __restrict__ in, RayRec* __restrict__ out, uint64_t n, uint32_t seed) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float3 O = xyz(in[i].O), D = xyz(in[i].D);
+    const float4 hit = in[i].hit;
+    uint32_t rs = wang_hash(seed + (uint32_t)i * 747796405u + (uint32_t)(i >> 32));
+    if (rs == 0) rs = 1;
+    float3 R = normalize3(make_float3(rand_float(rs) - 0.5f, rand_float(rs) - 0.5f, rand_float(rs) - 0.5f));
+    float3 I;
+    if (hit.x < kFar) {
+        I = make_float3(O.x + hit.x * D.x, O.y + hit.x * D.y, O.z + hit.x * D.z);
+        const uint32_t prim = as_u32(hit.w);
+        const float4 a = src.verts[(uint64_t)prim * 3], b = src.verts[(uint64_t)prim * 3 + 1], c = src.verts[(uint64_t)prim * 3 + 2];
+        const float3 e1 = make_float3(b.x - a.x, b.y - a.y, b.z - a.z), e2 = make_float3(c.x - a.x, c.y - a.y, c.z - a.z);
+        float3 N = normalize3(make_float3(e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x));
+        if (N.x * D.x + N.y * D.y + N.z * D.z > 0) N = make_float3(-N.x, -N.y, -N.z);
+        if (N.x * R.x + N.y * R.y + N.z * R.z < 0) R = make_float3(-R.x, -R.y, -R.z);
+    } else {
+        I = make_float3(O.x + 20.0f * D.x, O.y + 20.0f * D.y, O.z + 20.0f * D.z);
+    }
+    write_ray(out + i, make_float3(I.x + 0.001f * R.x, I.y + 0.001f * R.y, I.z + 0.001f * R.z), R, kFar);
+}
+
+__global__ void k_gen_shadow(const RayRec* __restrict__ in, RayRec* __restrict__ out, uint64_t n, float lx, float ly, float lz, float eps) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float3 O = xyz(in[i].O), D = xyz(in[i].D);
+    const float t = fminf(1000.0f, in[i].hit.x);
+    const float3 I = make_float3(O.x + t * D.x, O.y + t * D.y, O.z + t * D.z);
+    const float3 L = make_float3(lx - I.x, ly - I.y, lz - I.z);
+    const float dist = sqrtf(L.x * L.x + L.y * L.y + L.z * L.z);
+    const float3 Ld = normalize3(L);
+    write_ray(out + i, make_float3(I.x + Ld.x * eps, I.y + Ld.y * eps, I.z + Ld.z * eps), Ld, dist - eps);
+}
+
+void launch_gen_primary(const CameraArgs& cam, RayRec* rays, uint64_t first, uint64_t n, hipStream_t s) {
+    const uint32_t bs = 256;
+    hipLaunchKernelGGL(k_gen_primary, dim3((uint32_t)((n + bs - 1) / bs)), dim3(bs), 0, s, cam, rays, first, n);
+}
+void launch_gen_bounce(const TriSource& src, const RayRec* in, RayRec* out, uint64_t n, uint32_t seed, hipStream_t s) {
+    const uint32_t bs = 256;
+    hipLaunchKernelGGL(k_gen_bounce, dim3((uint32_t)((n + bs - 1) / bs)), dim3(bs), 0, s, src, in, out, n, seed);
+}
+void launch_gen_shadow(const RayRec* in, RayRec* out, uint64_t n, float lx, float ly, float lz, float eps, hipStream_t s) {
+    const uint32_t bs = 256;
+    hipLaunchKernelGGL(k_gen_shadow, dim3((uint32_t)((n + bs - 1) / bs)), dim3(bs), 0, s, in, out, n, lx, ly, lz, eps);
+}
+
+}  // namespace tbvh

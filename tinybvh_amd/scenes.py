@@ -1,0 +1,264 @@
+"""Procedural stand-in scenes and the reference's `.bin` mesh format.
+
+The benchmark scenes BASELINE.json names (Crytek Sponza, Bistro exterior, Dragon) are stripped
+from the reference checkout (`.MISSING_LARGE_BLOBS`) and there is no network, so the
+benchmark uses seeded procedural stand-ins of the same triangle counts and the same
+*character* (an atrium of large walls + columns + cloth for Sponza; a street of facades,
+thin street furniture and a lot of small foliage triangles for Bistro; a dense closed
+surface for Dragon).  If the real `.bin` files are present (TBVH_SCENE_DIR or
+./testdata) they are used instead and the name says so.
+
+Mesh format (`tiny_bvh_speedtest.cpp:490-495`): int32 triCount, then triCount x 3 x float4.
+All generators return float32 arrays of shape (3 * n_tris, 4), w = 0.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+
+def load_bin(path: str) -> np.ndarray:
+    with open(path, "rb") as f:
+        n = int(np.fromfile(f, dtype="<i4", count=1)[0])
+        v = np.fromfile(f, dtype="<f4", count=n * 12)
+    return v.reshape(n * 3, 4)
+
+
+def save_bin(path: str, verts: np.ndarray) -> None:
+    verts = np.ascontiguousarray(verts, dtype="<f4").reshape(-1, 4)
+    with open(path, "wb") as f:
+        np.array([verts.shape[0] // 3], dtype="<i4").tofile(f)
+        verts.tofile(f)
+
+
+def find_real(name: str):
+    for d in (os.environ.get("TBVH_SCENE_DIR", ""), "testdata", "/root/reference/testdata"):
+        if d and os.path.exists(os.path.join(d, name)):
+            return os.path.join(d, name)
+    return None
+
+
+# ---- primitive generators: each returns (n, 3, 3) float32 ------------------------------------
+
+def _grid(p0, du, dv, nu, nv, disp=None):
+    """(nu x nv) quad grid spanning p0 + s*du + t*dv, s,t in [0,1]; 2*nu*nv triangles."""
+    s = np.linspace(0, 1, nu + 1, dtype=np.float32)
+    t = np.linspace(0, 1, nv + 1, dtype=np.float32)
+    S, T = np.meshgrid(s, t, indexing="ij")
+    P = (np.asarray(p0, np.float32)[None, None, :] + S[..., None] * np.asarray(du, np.float32) + T[..., None] * np.asarray(dv, np.float32))
+    if disp is not None:
+        P = P + disp(S, T).astype(np.float32)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    t1 = np.stack([a, b, c], axis=2).reshape(-1, 3, 3)
+    t2 = np.stack([a, c, d], axis=2).reshape(-1, 3, 3)
+    return np.concatenate([t1, t2]).astype(np.float32)
+
+
+def _box(lo, hi, n=1):
+    lo = np.asarray(lo, np.float32); hi = np.asarray(hi, np.float32)
+    e = hi - lo
+    ex, ey, ez = [np.array(v, np.float32) for v in ((e[0], 0, 0), (0, e[1], 0), (0, 0, e[2]))]
+    faces = [(lo, ex, ey), (lo + ez, ex, ey), (lo, ey, ez), (lo + ex, ey, ez), (lo, ez, ex), (lo + ey, ez, ex)]
+    return np.concatenate([_grid(p, u, v, n, n) for p, u, v in faces])
+
+
+def _cylinder(c, r, h, nseg, nrings, axis=1, bulge=0.0):
+    th = np.linspace(0, 2 * np.pi, nseg + 1, dtype=np.float32)
+    y = np.linspace(0, 1, nrings + 1, dtype=np.float32)
+    TH, Y = np.meshgrid(th, y, indexing="ij")
+    rr = r * (1 + bulge * np.sin(Y * np.pi * 6))
+    P = np.zeros(TH.shape + (3,), np.float32)
+    a0, a1 = [(1, 2), (2, 0), (0, 1)][axis]
+    P[..., a0] = np.cos(TH) * rr; P[..., a1] = np.sin(TH) * rr; P[..., axis] = Y * h
+    P += np.asarray(c, np.float32)
+    a, b, cc, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    return np.concatenate([np.stack([a, b, cc], 2).reshape(-1, 3, 3), np.stack([a, cc, d], 2).reshape(-1, 3, 3)])
+
+
+def _sphere(c, r, nu, nv, noise=None):
+    th = np.linspace(0, 2 * np.pi, nu + 1, dtype=np.float32)
+    ph = np.linspace(0, np.pi, nv + 1, dtype=np.float32)
+    TH, PH = np.meshgrid(th, ph, indexing="ij")
+    rr = r if noise is None else r * (1 + noise(TH, PH))
+    P = np.stack([np.cos(TH) * np.sin(PH) * rr, np.cos(PH) * rr, np.sin(TH) * np.sin(PH) * rr], -1).astype(np.float32)
+    P += np.asarray(c, np.float32)
+    a, b, cc, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    return np.concatenate([np.stack([a, b, cc], 2).reshape(-1, 3, 3), np.stack([a, cc, d], 2).reshape(-1, 3, 3)])
+
+
+def _leaves(rng, centers, radius, n_per, size):
+    """Small randomly oriented triangles scattered in ellipsoids around `centers`."""
+    k = centers.shape[0]
+    p = rng.normal(size=(k, n_per, 3)).astype(np.float32)
+    p /= np.maximum(np.linalg.norm(p, axis=-1, keepdims=True), 1e-6)
+    p *= (rng.random((k, n_per, 1), dtype=np.float32) ** (1 / 3)) * np.asarray(radius, np.float32)
+    p += centers[:, None, :]
+    p = p.reshape(-1, 3)
+    d1 = rng.normal(size=p.shape).astype(np.float32) * np.float32(size)
+    d2 = rng.normal(size=p.shape).astype(np.float32) * np.float32(size)
+    return np.stack([p, p + d1, p + d2], axis=1).astype(np.float32)
+
+
+def _pack(tris) -> np.ndarray:
+    t = np.concatenate(tris).astype(np.float32)
+    v = np.zeros((t.shape[0] * 3, 4), np.float32)
+    v[:, :3] = t.reshape(-1, 3)
+    return v
+
+
+# ---- scenes ------------------------------------------------------------------------------------
+
+def atrium(target_tris: int = 262_267, seed: int = 1) -> np.ndarray:
+    """Sponza stand-in: a 74 x 30 x 32 hall (x -38..36, y 0..30, z -16..16) with two arcade
+    floors of columns, arches, floor tiles, wall relief and hanging cloth.  The speedtest's
+    three cameras (tiny_bvh_speedtest.cpp:499-508) are inside it."""
+    rng = np.random.default_rng(seed)
+    tris = []
+    relief = lambda amp, f: (lambda S, T: np.stack([np.zeros_like(S), np.zeros_like(S), amp * np.sin(S * f) * np.sin(T * f * 0.7)], -1))
+    tris.append(_grid((-38, 0, -16), (74, 0, 0), (0, 0, 32), 96, 48, lambda S, T: np.stack([np.zeros_like(S), 0.05 * np.sin(S * 301) * np.sin(T * 173), np.zeros_like(S)], -1)))
+    tris.append(_grid((-38, 30, -16), (74, 0, 0), (0, 0, 32), 24, 12))
+    tris.append(_grid((-38, 0, -16), (74, 0, 0), (0, 30, 0), 120, 60, relief(0.15, 90)))
+    tris.append(_grid((-38, 0, 16), (74, 0, 0), (0, 30, 0), 120, 60, relief(-0.15, 90)))
+    for x in (-38, 36):
+        tris.append(_grid((x, 0, -16), (0, 0, 32), (0, 30, 0), 48, 48, lambda S, T: np.stack([0.1 * np.sin(S * 60) * np.sin(T * 45), np.zeros_like(S), np.zeros_like(S)], -1)))
+    for floor_y, h in ((0.0, 9.0), (10.0, 8.0), (19.0, 7.0)):
+        for z in (-9.0, 9.0):
+            tris.append(_box((-38, floor_y + h, z - 1.2 if z < 0 else z - 1.2), (36, floor_y + h + 1.0, z + 1.2), 6))
+            for i, x in enumerate(np.linspace(-34, 32, 12)):
+                tris.append(_cylinder((x, floor_y, z), 0.7, h, 28, 22, bulge=0.04))
+                tris.append(_box((x - 1.0, floor_y, z - 1.0), (x + 1.0, floor_y + 0.5, z + 1.0), 2))
+                if i:  # arch between columns: half torus segment approximated by a bent strip
+                    x0 = x - 3.0
+                    arch = lambda S, T, x0=x0, fy=floor_y + h - 2.5, zz=z: np.stack(
+                        [x0 + 2.6 * np.cos(np.pi * S) - (x0 - 3 + 6 * S), fy + 2.4 * np.sin(np.pi * S) - fy, np.zeros_like(S)], -1)
+                    tris.append(_grid((x0 - 3, floor_y + h - 2.5, z - 0.6), (6, 0, 0), (0, 0, 1.2), 24, 3, arch))
+    for k in range(10):  # hanging cloth
+        x = -30 + k * 6.5
+        ph = rng.random() * 6
+        cloth = lambda S, T, ph=ph: np.stack([0.35 * np.sin(T * 9 + ph) * S, np.zeros_like(S), 0.6 * np.sin(S * 7 + ph) * np.sin(T * 5)], -1)
+        tris.append(_grid((x, 24, -2), (0, -9, 0), (0, 0, 4), 56, 40, cloth))
+    for k in range(14):  # vases / plants
+        c = (rng.uniform(-34, 32), 0.0, rng.choice([-4.0, 4.0]))
+        tris.append(_sphere((c[0], 1.0, c[2]), 0.9, 28, 18, lambda TH, PH: 0.08 * np.sin(TH * 5)))
+        tris.append(_leaves(rng, np.array([[c[0], 2.6, c[2]]], np.float32), (0.9, 1.1, 0.9), 380, 0.18))
+    have = sum(t.shape[0] for t in tris)
+    if have < target_tris:  # pad with detailed wall ornaments
+        n = target_tris - have
+        centers = np.stack([rng.uniform(-36, 34, 64), rng.uniform(2, 28, 64), rng.choice([-15.6, 15.6], 64)], -1).astype(np.float32)
+        tris.append(_leaves(rng, centers, (1.2, 1.2, 0.25), -(-n // 64), 0.12)[:n])
+    v = _pack(tris)
+    return v[: target_tris * 3] if v.shape[0] // 3 > target_tris else v
+
+
+def street(target_tris: int = 2_832_120, seed: int = 2) -> np.ndarray:
+    """Bistro-exterior stand-in: a 160 x 60 m street with tessellated ground, two rows of
+    facades with window recesses and balconies, awnings, street furniture (thin cylinders),
+    and trees whose foliage is ~45% of all triangles (small, randomly oriented)."""
+    rng = np.random.default_rng(seed)
+    tris = []
+    cobble = lambda S, T: np.stack([np.zeros_like(S), 0.03 * np.sin(S * 911) * np.sin(T * 577), np.zeros_like(S)], -1)
+    tris.append(_grid((-80, 0, -30), (160, 0, 0), (0, 0, 60), 400, 150, cobble))
+    for side, z0 in ((-1, -14.0), (1, 14.0)):
+        x = -78.0
+        while x < 76:
+            w = float(rng.uniform(8, 16)); h = float(rng.uniform(12, 24)); d = 12.0
+            zf = z0; zb = z0 + side * d
+            lo = (x, 0, min(zf, zb)); hi = (x + w, h, max(zf, zb))
+            tris.append(_box(lo, hi, 8))
+            nwx = max(2, int(w / 2.2)); nwy = max(2, int(h / 3.2))
+            for ix in range(nwx):
+                for iy in range(nwy):
+                    wx = x + (ix + 0.5) * w / nwx; wy = 1.8 + iy * (h - 2.5) / nwy
+                    zr = zf - side * 0.02
+                    tris.append(_box((wx - 0.55, wy, min(zr, zr + side * 0.35)), (wx + 0.55, wy + 1.5, max(zr, zr + side * 0.35)), 2))
+                    if iy and (ix + iy) % 3 == 0:  # balcony with railing bars
+                        zb0 = zf - side * 0.9
+                        tris.append(_box((wx - 0.9, wy - 0.15, min(zf, zb0)), (wx + 0.9, wy, max(zf, zb0)), 2))
+                        for b in np.linspace(-0.85, 0.85, 9):
+                            tris.append(_cylinder((wx + b, wy, zb0), 0.02, 1.0, 6, 1))
+            if rng.random() < 0.7:  # awning
+                wave = lambda S, T: np.stack([np.zeros_like(S), 0.08 * np.sin(S * 40), np.zeros_like(S)], -1)
+                tris.append(_grid((x + 0.5, 3.4, zf), (w - 1, 0, 0), (0, -0.7, -side * 2.2), 48, 10, wave))
+            x += w + float(rng.uniform(0.0, 0.6))
+    for k in range(36):  # lamp posts, bollards, chairs/tables
+        px = -76 + k * 4.3; pz = float(rng.choice([-9.5, 9.5]))
+        tris.append(_cylinder((px, 0, pz), 0.08, 5.0, 14, 12))
+        tris.append(_sphere((px, 5.2, pz), 0.35, 20, 12))
+        for j in range(3):
+            cx = px + 1.2 + j * 0.9; cz = pz + float(rng.uniform(-1.5, 1.5))
+            tris.append(_cylinder((cx, 0, cz), 0.03, 0.75, 8, 1))
+            tris.append(_cylinder((cx, 0.75, cz), 0.45, 0.04, 24, 1))
+    # trees: trunk + branches + foliage
+    n_trees = 44
+    tree_x = np.linspace(-74, 74, n_trees // 2)
+    base = sum(t.shape[0] for t in tris)
+    foliage_budget = max(target_tris - base - n_trees * 4000, 0)
+    per_tree = foliage_budget // n_trees
+    for i in range(n_trees):
+        tx = float(tree_x[i // 2]) + float(rng.uniform(-0.8, 0.8)); tz = -6.5 if i % 2 else 6.5
+        tris.append(_cylinder((tx, 0, tz), 0.28, 4.5, 18, 14, bulge=0.05))
+        nb = 40
+        bc = np.stack([tx + rng.normal(0, 1.6, nb), 4.5 + rng.random(nb) * 4.0, tz + rng.normal(0, 1.6, nb)], -1).astype(np.float32)
+        for b in bc[:12]:
+            tris.append(_cylinder((b[0], b[1] - 1.2, b[2]), 0.05, 1.6, 8, 3))
+        tris.append(_leaves(rng, bc, (1.1, 0.9, 1.1), max(per_tree // nb, 1), 0.07))
+    v = _pack(tris)
+    nt = v.shape[0] // 3
+    if nt > target_tris:
+        v = v[: target_tris * 3]
+    elif nt < target_tris:
+        n = target_tris - nt
+        centers = np.stack([rng.uniform(-76, 76, 256), rng.uniform(0.1, 0.5, 256), rng.uniform(-12, 12, 256)], -1).astype(np.float32)
+        v = np.concatenate([v, _pack([_leaves(rng, centers, (0.8, 0.3, 0.8), -(-n // 256), 0.05)[:n]])])
+    return v
+
+
+def blob(target_tris: int = 100_000, seed: int = 3) -> np.ndarray:
+    """Dragon stand-in for instancing: a closed, bumpy, finely tessellated surface in
+    roughly the unit cube around the origin."""
+    nu = int(np.sqrt(target_tris / 2) * 1.41); nv = max(target_tris // (2 * nu), 4)
+    rng = np.random.default_rng(seed)
+    ph = rng.random(4) * 6
+    noise = lambda TH, PH: 0.18 * np.sin(TH * 3 + ph[0]) * np.sin(PH * 5 + ph[1]) + 0.07 * np.sin(TH * 11 + ph[2]) * np.sin(PH * 9 + ph[3])
+    return _pack([_sphere((0, 0, 0), 0.8, nu, nv, noise)])
+
+
+def soup(n_tris: int, seed: int = 7, extent: float = 10.0, size: float = 0.6) -> np.ndarray:
+    """Random triangle soup (the shape of tiny_bvh_minimal_gpu.cpp's 8192 random tris)."""
+    rng = np.random.default_rng(seed)
+    p = rng.random((n_tris, 3), dtype=np.float32) * np.float32(extent)
+    d1 = (rng.random((n_tris, 3), dtype=np.float32) - 0.5) * np.float32(size * 2)
+    d2 = (rng.random((n_tris, 3), dtype=np.float32) - 0.5) * np.float32(size * 2)
+    return _pack([np.stack([p, p + d1, p + d2], 1)])
+
+
+def get(name: str):
+    """Returns (verts, label).  Real files win when present."""
+    real = {"sponza": "cryteksponza.bin", "dragon": "dragon.bin"}
+    if name in real and find_real(real[name]):
+        return load_bin(find_real(real[name])), real[name]
+    if name == "bistro" and find_real("bistro_ext_part1.bin") and find_real("bistro_ext_part2.bin"):
+        return np.concatenate([load_bin(find_real("bistro_ext_part1.bin")), load_bin(find_real("bistro_ext_part2.bin"))]), "bistro_ext_part1+2.bin"
+    if name == "sponza":
+        return atrium(), "procedural atrium (Sponza stand-in, 262k tris, seed 1)"
+    if name == "bistro":
+        return street(), "procedural street (Bistro-exterior stand-in, 2.83M tris, seed 2)"
+    if name == "dragon":
+        return blob(), "procedural blob (Dragon stand-in, 100k tris, seed 3)"
+    raise KeyError(name)
+
+
+# view pyramids: (eye, view direction) -> corners p1 (top-left), p2 (top-right), p3 (bottom-left),
+# the construction of tiny_bvh_speedtest.cpp:509-511
+def view_pyramid(eye, view, aspect_up: float = 0.8):
+    eye = np.asarray(eye, np.float32); view = np.asarray(view, np.float32)
+    view = view / np.linalg.norm(view)
+    right = np.cross(np.array([0, 1, 0], np.float32), view); right /= np.linalg.norm(right)
+    up = np.float32(aspect_up) * np.cross(view, right)
+    Cc = eye + 2 * view
+    return eye, Cc - right + up, Cc + right + up, Cc - right - up
+
+
+SPONZA_CAMERAS = [((-15.24, 21.5, 2.54), (0.826, -0.438, -0.356)), ((-34, 5, 11.26), (0.9427, 0.0292, -0.3324)), ((-1.3, 4.96, 12.28), (-0.9886, 0.0507, -0.1419))]
+STREET_CAMERAS = [((-70.0, 1.7, 0.5), (0.995, 0.02, -0.03)), ((10.0, 14.0, -5.0), (0.8, -0.45, 0.4)), ((40.0, 2.0, 2.0), (-0.97, 0.12, 0.05))]
