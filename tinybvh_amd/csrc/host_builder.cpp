@@ -358,13 +358,30 @@ void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& bloc
         uint32_t info[4] = {0, 0, 0, 0};
         uint8_t q[6][4] = {};  // xmin, xmax, ymin, ymax, zmin, zmax per child
         const float ext[3] = {n.box.mx[0] - n.box.mn[0], n.box.mx[1] - n.box.mn[1], n.box.mx[2] - n.box.mn[2]};
-        float scale[3];
-        for (int a = 0; a < 3; a++) scale[a] = ext[a] > 1e-10f ? 254.999f / ext[a] : 0.f;
+        float scale[3], e255[3];
+        for (int a = 0; a < 3; a++) {
+            scale[a] = ext[a] > 1e-10f ? 254.999f / ext[a] : 0.f;
+            e255[a] = ext[a] * (1.0f / 255.0f);
+            const float guard = 4e-7f * std::max(std::max(std::fabs(n.box.mn[a]), std::fabs(n.box.mx[a])), ext[a]);
+            while (ext[a] > 0 && n.box.mn[a] + e255[a] * 255.0f < n.box.mx[a] + guard) e255[a] = std::nextafter(e255[a], kFar);
+        }
         for (uint32_t i = 0; i < n.childCount; i++) {
             const WideNode<4>& c = W[n.child[i]];
             for (int a = 0; a < 3; a++) {
-                q[2 * a][i] = (uint8_t)std::floor((c.box.mn[a] - n.box.mn[a]) * scale[a]);
-                q[2 * a + 1][i] = (uint8_t)std::ceil((c.box.mx[a] - n.box.mn[a]) * scale[a]);
+                // The reference quantises with floor/ceil(rel * 254.999 / extent)
+                // (tiny_bvh.h:5196-5231) and decodes with bmin + (extent/255) * q; the 254.999
+                // makes the decoded maximum fall short of the true one by up to 4e-6 * rel, so a
+                // reference-encoded BVH4_GPU can cull a box a ray grazes.  Same format here, but
+                // the quantised box is verified against the decode and widened until it really
+                // contains the child (with a few-ulp guard for decoder rounding).
+                const float guard = 4e-7f * std::max(std::max(std::fabs(n.box.mn[a]), std::fabs(n.box.mx[a])), ext[a]);
+                int lo = (int)std::floor((c.box.mn[a] - n.box.mn[a]) * scale[a]);
+                int hi = (int)std::ceil((c.box.mx[a] - n.box.mn[a]) * scale[a]);
+                lo = std::min(std::max(lo, 0), 255); hi = std::min(std::max(hi, 0), 255);
+                while (lo > 0 && n.box.mn[a] + e255[a] * (float)lo > c.box.mn[a] - guard) lo--;
+                while (hi < 255 && n.box.mn[a] + e255[a] * (float)hi < c.box.mx[a] + guard) hi++;
+                q[2 * a][i] = (uint8_t)lo;
+                q[2 * a + 1][i] = (uint8_t)hi;
             }
             if (c.triCount) {
                 const uint32_t rel = (uint32_t)blocks.size() - base;
@@ -389,7 +406,7 @@ void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& bloc
         std::memcpy(&w0, q[0], 4); std::memcpy(&w1, q[1], 4);
         std::memcpy(&w2[0], q[2], 4); std::memcpy(&w2[1], q[3], 4); std::memcpy(&w2[2], q[4], 4); std::memcpy(&w2[3], q[5], 4);
         nb[0] = Vec4{n.box.mn[0], n.box.mn[1], n.box.mn[2], asF32(w0)};
-        nb[1] = Vec4{ext[0] * (1.0f / 255.0f), ext[1] * (1.0f / 255.0f), ext[2] * (1.0f / 255.0f), asF32(w1)};
+        nb[1] = Vec4{e255[0], e255[1], e255[2], asF32(w1)};
         nb[2] = Vec4{asF32(w2[0]), asF32(w2[1]), asF32(w2[2]), asF32(w2[3])};
         nb[3] = Vec4{asF32(info[0]), asF32(info[1]), asF32(info[2]), asF32(info[3])};
     }
@@ -445,6 +462,7 @@ void encode_cwbvh(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& nodeBlo
                 bool ok = true;
                 for (uint32_t i = 0; i < n.childCount; i++)
                     if (std::ceil((W[n.child[i]].box.mx[a] - n.box.mn[a]) * s) > 255.f) ok = false;
+                if (n.box.mn[a] + std::ldexp(255.0f, ea) < n.box.mx[a]) ok = false;
                 if (ok) break;
                 ea++;
             }
@@ -457,8 +475,16 @@ void encode_cwbvh(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& nodeBlo
             const uint32_t ci = n.child[childIn[s]];
             const WideNode<8>& c = W[ci];
             for (int a = 0; a < 3; a++) {
-                q[a][s] = (uint8_t)std::floor((c.box.mn[a] - n.box.mn[a]) * inv[a]);
-                q[3 + a][s] = (uint8_t)std::ceil((c.box.mx[a] - n.box.mn[a]) * inv[a]);
+                // floor / ceil in units of 2^e (tiny_bvh.h:5952-5957), then checked against the
+                // decode lo + q * 2^e so float rounding of the subtraction cannot shrink the box
+                const float sc = std::ldexp(1.0f, e[a]);
+                int lo = (int)std::floor((c.box.mn[a] - n.box.mn[a]) * inv[a]);
+                int hi = (int)std::ceil((c.box.mx[a] - n.box.mn[a]) * inv[a]);
+                lo = std::min(std::max(lo, 0), 255); hi = std::min(std::max(hi, 0), 255);
+                while (lo > 0 && n.box.mn[a] + sc * (float)lo > c.box.mn[a]) lo--;
+                while (hi < 255 && n.box.mn[a] + sc * (float)hi < c.box.mx[a]) hi++;
+                q[a][s] = (uint8_t)lo;
+                q[3 + a][s] = (uint8_t)hi;
             }
             if (!c.triCount) {
                 const uint32_t addr = (uint32_t)(nodeBlocks.size() / 5);
