@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""bench.py — the contract benchmark (one JSON line on rank 0).
+
+Metric (BASELINE.json): MRays/s (primary + diffuse) on Bistro CWBVH; achieved HBM GB/s.
+
+Workload (config.workload): BASELINE.json configs[2]+[3] on one GPU — Bistro-exterior
+(real `bistro_ext_part{1,2}.bin` if present, else the labelled 2.83 M-triangle procedural
+stand-in), BVH8_CWBVH layout, per GPU and per step:
+    16 M primary rays   Intersect   (4096 x 4096 pinhole, speedtest tile order)
+    16 M diffuse rays   Intersect   (incoherent: bounce depths 1, 2 and 3 in equal thirds)
+    16 M shadow rays    IsOccluded  (from the primary hit points toward a point light)
+`value` = (primary + diffuse rays of ALL ranks) / wall time of the K timed steps, where a step
+runs the three traversals plus the two 16-byte-per-ray hit re-arm kernels that make every
+step start from tmax again.  Rays are generated on the device before the timed region and
+are resident in HBM.  N > 1: the BVH is replicated, every rank traces its own batch
+(different camera / RNG seed), no data-path collective: weak scaling.
+
+One process per GPU; launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+torch is used for the barrier / max-reduce over ranks only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="bistro")
+    ap.add_argument("--side", type=int, default=4096, help="primary rays per GPU = side^2")
+    ap.add_argument("--layout", type=int, default=9)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    import tinybvh_amd as tb
+    from tinybvh_amd import rays as R
+    from tinybvh_amd import scenes
+
+    def sync_all():
+        if world > 1:
+            import torch
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.synchronize()
+
+    # ---- scene + layout (host build, untimed) ------------------------------------------------
+    t0 = time.time()
+    verts, label = scenes.get(a.scene)
+    n_tris = verts.shape[0] // 3
+    ctx = tb.Context(local_rank)
+    sc = tb.LAYOUT_CLASSES[a.layout](ctx).Build(verts)
+    if a.variant:
+        sc.set_variant(a.variant)
+    if rank == 0:
+        log(f"[bench] scene: {label}; {n_tris} tris; layout {a.layout}; host build+upload {time.time() - t0:.1f}s; device bytes {sc.device_bytes / 1e6:.0f} MB")
+
+    # ---- ray batches on the device (untimed) -----------------------------------------------------
+    n = a.side * a.side
+    cams = scenes.STREET_CAMERAS if a.scene == "bistro" else scenes.SPONZA_CAMERAS
+    eye, view = cams[rank % len(cams)]
+    cam = R.camera(eye, view, a.side, a.side, 1, 1)
+    d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
+    d_prim, d_diff, d_shad, d_tmp = (ctx.malloc(n * 64) for _ in range(4))
+    d_occ = ctx.malloc(n)
+    ext = float((verts[:, :3].max(0) - verts[:, :3].min(0)).max())
+    light = (0.0, 0.9 * float(verts[:, 1].max()), 0.0)
+    third = n // 3
+    ctx.generate_primary(cam, d_prim, 0, n)
+    sc.intersect_device(d_prim, n)
+    ctx.generate_shadow(d_prim, d_shad, n, light, ext * 5e-7)
+    # diffuse batch: thirds of depth 1 / 2 / 3 (wavefront.cl's 3-bounce loop, wavefront.cl:225)
+    seed = 1000 * (rank + 1)
+    ctx.generate_bounce(d_verts, d_prim, d_tmp, n, seed + 1)          # depth 1 for all
+    # the first third stays at depth 1; the rest is traced and bounced again, in place
+    sc.intersect_device(d_tmp + third * 64, n - third)
+    ctx.generate_bounce(d_verts, d_tmp + third * 64, d_tmp + third * 64, n - third, seed + 2)   # depth 2
+    sc.intersect_device(d_tmp + 2 * third * 64, n - 2 * third)
+    ctx.generate_bounce(d_verts, d_tmp + 2 * third * 64, d_tmp + 2 * third * 64, n - 2 * third, seed + 3)  # depth 3
+    d_diff, d_tmp = d_tmp, d_diff
+    ctx.reset_hits(d_prim, n)
+    ctx.synchronize()
+
+    kern_ms = {"primary": [], "diffuse": [], "shadow": []}
+
+    def step(record: bool):
+        ctx.reset_hits(d_prim, n)
+        sc.intersect_device(d_prim, n)
+        if record:
+            kern_ms["primary"].append(ctx.time_last_ms())
+        ctx.reset_hits(d_diff, n)
+        sc.intersect_device(d_diff, n)
+        if record:
+            kern_ms["diffuse"].append(ctx.time_last_ms())
+        sc.occluded_device(d_shad, n, d_occ)
+        if record:
+            kern_ms["shadow"].append(ctx.time_last_ms())
+
+    for _ in range(a.warmup):
+        step(False)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- results (rank 0) ---------------------------------------------------------------------------
+    if rank == 0:
+        ms_per_step = elapsed / a.steps * 1e3
+        rays_per_step = 2 * n * world  # primary + diffuse (the metric); shadow reported in detail
+        value = rays_per_step / (elapsed / a.steps) / 1e6
+        mean = {k: float(np.mean(v)) for k, v in kern_ms.items()}
+        detail = {k + "_mrays": n / (mean[k] * 1e-3) / 1e6 for k in mean}
+        detail["kernel_ms"] = mean
+        detail["primary_plus_diffuse_kernel_mrays"] = 2 * n / ((mean["primary"] + mean["diffuse"]) * 1e-3) / 1e6
+
+        # roofline of the dominant kernel (CWBVH Intersect on the diffuse batch): algorithmic
+        # bytes per ray = 64 (ray in) + 16 (hit out) + node_bytes*S + tri_bytes*T, SURVEY.md
+        # §8(d), with S,T counted by the oracle's mirror of this layout on a sample of the same rays.
+        roof = None
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_lib import Oracle
+            orc = Oracle()
+            ns = 65536
+            sample = np.zeros(ns, dtype=tb.RAY_DTYPE)
+            stride = max(n // ns, 1)
+            # strided sample of the diffuse batch, re-armed
+            full = np.zeros(n, dtype=tb.RAY_DTYPE) if n * 64 <= (2 << 30) else None
+            if full is not None:
+                ctx.from_device(full, d_diff)
+                sample = full[::stride][:ns].copy()
+                del full
+            sample["t"] = 1e30
+            h = sc.host
+            if a.layout == tb.LAYOUT_CWBVH:
+                _, cnt = orc.cwbvh_intersect(h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4), sample, counts=True)
+                nb, tbytes = 80, 48
+            elif a.layout == tb.LAYOUT_BVH4_GPU:
+                _, cnt = orc.bvh4_intersect(h.blob(0, np.uint32, 4), sample, counts=True)
+                nb, tbytes = 64, 48
+            else:
+                _, cnt = orc.bvhgpu_intersect(h.blob(0, np.uint32, 16), h.blob(1, np.uint32, 1), verts, sample, counts=True)
+                nb, tbytes = 64, 52
+            S, T = float(cnt[0]) / sample.shape[0], float(cnt[1]) / sample.shape[0]
+            bytes_per_ray = 64 + 16 + nb * S + tbytes * T
+            achieved = bytes_per_ray * n / (mean["diffuse"] * 1e-3) / 1e9
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("diffuse_kernel_hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roof = {"bound": "hbm", "kernel": "k_cwbvh<false> (diffuse batch)" if a.layout == 9 else "intersect (diffuse batch)",
+                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                    "traffic": traffic, "algorithmic_bytes_per_ray": bytes_per_ray, "nodes_per_ray": S, "tris_per_ray": T,
+                    "avg_launch_ms": mean["diffuse"]}
+        except Exception as e:  # the checker is optional for the number itself
+            log(f"[bench] roofline sample failed: {e!r}")
+
+        cpu = None
+        if not a.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(tb, ctx, verts, d_prim, d_diff, n)
+            except Exception as e:
+                log(f"[bench] cpu baseline failed: {e!r}")
+
+        out = {
+            "metric": "MRays/s (primary + diffuse) on Bistro CWBVH", "value": value, "unit": "MRays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{label}; BVH8_CWBVH; per GPU per step {n} primary + {n} diffuse (depth 1-3) Intersect + {n} shadow IsOccluded",
+                       "scene_tris": n_tris, "layout": {4: "BVH_GPU", 6: "BVH4_GPU", 9: "BVH8_CWBVH"}[a.layout],
+                       "rays_per_gpu_per_step": 3 * n, "sharding": f"rays x{world}, BVH replicated, no collective"},
+            "detail": detail, "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    sync_all()
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def cpu_baseline(tb, ctx, verts, d_prim, d_diff, n):
+    """Reference BVH8_CPU (AVX2) on all host cores over a bounded sample of the same rays
+    (oracle/_ref, kind 'reference'); falls back to the single-threaded C oracle ('port')."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle, Reference, have_reference
+    ns = 1 << 21  # 2 M primary + 2 M diffuse
+    ns = min(ns, n)
+    buf = np.zeros(ns, dtype=tb.RAY_DTYPE)
+    batches = []
+    for d in (d_prim, d_diff):
+        ctx.from_device(buf, d + ((n - ns) // 2) * 64)
+        b = buf.copy(); b["t"] = 1e30
+        batches.append(b)
+    cores = os.cpu_count() or 1
+    if have_reference():
+        ref = Reference()
+        t0 = time.time()
+        rs = ref.build(verts, hq=False, threaded=True)
+        rs.time_mt(8, batches[0][:1024], threads=1)  # builds BVH8_CPU
+        log(f"[bench] reference BVH + BVH8_CPU build {time.time() - t0:.1f}s")
+        sec = sum(rs.time_mt(8, b, threads=cores)[0] for b in batches)
+        return {"value": 2 * ns / sec / 1e6, "unit": "MRays/s", "cores": cores, "kind": "reference",
+                "sample": f"tinybvh BVH8_CPU::Intersect (AVX2), {cores} threads, {ns} primary + {ns} diffuse rays of the GPU batches"}
+    orc = Oracle()
+    h = tb.HostBVH(verts, tb.LAYOUT_BVH2_WALD)
+    ns2 = 100_000
+    t0 = time.time()
+    for b in batches:
+        orc.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, b[:ns2])
+    sec = time.time() - t0
+    return {"value": 2 * ns2 / sec / 1e6, "unit": "MRays/s", "cores": 1, "kind": "port",
+            "sample": f"C restatement of BVH::Intersect, 1 thread, {ns2} primary + {ns2} diffuse rays"}
+
+
+if __name__ == "__main__":
+    main()

@@ -135,6 +135,10 @@ int tbvh_intersect_device(tbvh_scene* scene, void* d_rays64, uint64_t n_rays);
 int tbvh_occluded_device(tbvh_scene* scene, const void* d_rays64, uint64_t n_rays,
                          uint8_t* d_occluded);
 
+/* Re-arm a device ray batch for another Intersect: hit = {tmax, 0, 0, 0} for every record
+ * (what re-running the tinybvh::Ray constructor's hit.t = t would do, tiny_bvh.h:700). */
+int tbvh_reset_hits_device(tbvh_context* ctx, void* d_rays64, uint64_t n_rays, float tmax);
+
 /* HIP-event time of the most recent query kernel on this context, in milliseconds
  * (mirrors the CL_PROFILING_COMMAND_START/END read of tiny_bvh_speedtest.cpp:1126-1131).
  * Synchronizes the stream. */

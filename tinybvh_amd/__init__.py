@@ -108,6 +108,9 @@ class Context:
         assert a.flags["C_CONTIGUOUS"]
         check(lib.tbvh_copy_from_device(self._h, _ptr(a), C.c_void_p(dptr), a.nbytes), "tbvh_copy_from_device")
 
+    def reset_hits(self, d_rays: int, n: int, tmax: float = 1e30):
+        check(lib.tbvh_reset_hits_device(self._h, C.c_void_p(d_rays), n, float(tmax)), "tbvh_reset_hits_device")
+
     # ray generators
     def generate_primary(self, cam: Camera, d_rays: int, first: int, n: int):
         check(lib.tbvh_generate_primary_device(self._h, C.byref(cam), C.c_void_p(d_rays), first, n), "tbvh_generate_primary_device")

@@ -396,6 +396,15 @@ int tbvh_generate_shadow_device(tbvh_context* c, const void* dIn, void* dOut, ui
     return 0;
 }
 
+int tbvh_reset_hits_device(tbvh_context* c, void* dRays, uint64_t n, float tmax) {
+    if (!c || (!dRays && n)) return fail(TBVH_E_INVALID, "tbvh_reset_hits_device: null argument");
+    if (int r = setDevice(c)) return r;
+    if (!n) return 0;
+    launch_reset_hits((RayRec*)dRays, n, tmax, c->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // ---- device buffers ------------------------------------------------------------------------
 
 int tbvh_device_malloc(tbvh_context* c, uint64_t bytes, void** out) {

@@ -24,6 +24,7 @@ struct TriSource {
     const float4* verts;
 };
 void launch_gen_bounce(const TriSource& src, const RayRec* in, RayRec* out, uint64_t n, uint32_t seed, hipStream_t s);
+void launch_reset_hits(RayRec* rays, uint64_t n, float tmax, hipStream_t s);
 void launch_gen_shadow(const RayRec* in, RayRec* out, uint64_t n, float lx, float ly, float lz, float eps, hipStream_t s);
 
 }  // namespace tbvh

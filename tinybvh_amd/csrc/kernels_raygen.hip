@@ -92,6 +92,15 @@ __global__ void k_gen_shadow(const RayRec* __restrict__ in, RayRec* __restrict__
     write_ray(out + i, make_float3(I.x + Ld.x * eps, I.y + Ld.y * eps, I.z + Ld.z * eps), Ld, dist - eps);
 }
 
+__global__ void k_reset_hits(RayRec* __restrict__ rays, uint64_t n, float tmax) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rays[i].hit = make_float4(tmax, 0.f, 0.f, 0.f);
+}
+void launch_reset_hits(RayRec* rays, uint64_t n, float tmax, hipStream_t s) {
+    const uint32_t bs = 256;
+    hipLaunchKernelGGL(k_reset_hits, dim3((uint32_t)((n + bs - 1) / bs)), dim3(bs), 0, s, rays, n, tmax);
+}
+
 void launch_gen_primary(const CameraArgs& cam, RayRec* rays, uint64_t first, uint64_t n, hipStream_t s) {
     const uint32_t bs = 256;
     hipLaunchKernelGGL(k_gen_primary, dim3((uint32_t)((n + bs - 1) / bs)), dim3(bs), 0, s, cam, rays, first, n);
