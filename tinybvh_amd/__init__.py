@@ -197,14 +197,15 @@ class _Scene:
         """rays: structured RAY_DTYPE array (64-byte records) or a (n, 128)-byte host Ray[] view;
         updated in place (bytes 44..63 of records that hit) and returned."""
         assert rays.flags["C_CONTIGUOUS"] and rays.flags["WRITEABLE"]
-        stride = rays.strides[0]
+        stride = rays.strides[0] if rays.shape[0] else max(rays.dtype.itemsize, 64)
         check(lib.tbvh_intersect(self._h, _ptr(rays), rays.shape[0], stride), "tbvh_intersect")
         return rays
 
     def IsOccluded(self, rays: np.ndarray) -> np.ndarray:
         assert rays.flags["C_CONTIGUOUS"]
         out = np.zeros(rays.shape[0], dtype=np.uint8)
-        check(lib.tbvh_occluded(self._h, _ptr(rays), rays.shape[0], rays.strides[0], _ptr(out)), "tbvh_occluded")
+        stride = rays.strides[0] if rays.shape[0] else max(rays.dtype.itemsize, 64)
+        check(lib.tbvh_occluded(self._h, _ptr(rays), rays.shape[0], stride, _ptr(out)), "tbvh_occluded")
         return out
 
     # device-resident, asynchronous
