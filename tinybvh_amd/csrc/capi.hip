@@ -119,7 +119,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ) {
         break;
     case TBVH_LAYOUT_CWBVH:
         q.spillStride = c->spillEntries / 2;  // 8-byte entries
-        launch_cwbvh(any, s->nodes, s->tris, q, c->status, c->blocks, c->stream);
+        launch_cwbvh(any, s->variant, s->nodes, s->tris, q, c->status, c->blocks, c->stream);
         break;
     default:
         return fail(TBVH_E_INVALID, "scene layout %d has no query kernel", s->layout);
@@ -306,7 +306,8 @@ uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0;
 
 int tbvh_set_variant(tbvh_scene* s, int v) {
     if (!s) return fail(TBVH_E_INVALID, "null scene");
-    if (v != 0) return fail(TBVH_E_INVALID, "unknown variant %d", v);
+    const bool ok = s->layout == TBVH_LAYOUT_CWBVH ? cwbvh_variant_valid(v) : v == 0;
+    if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
     s->variant = v;
     return 0;
 }

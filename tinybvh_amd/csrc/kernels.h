@@ -7,8 +7,9 @@ namespace tbvh {
 void launch_bvh2(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                  uint32_t blocks, hipStream_t s);
 void launch_bvh4(bool anyhit, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
-void launch_cwbvh(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
+void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                   uint32_t blocks, hipStream_t s);
+bool cwbvh_variant_valid(int variant);
 void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris,
                         hipStream_t s);
 

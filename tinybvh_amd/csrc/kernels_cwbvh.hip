@@ -1,0 +1,183 @@
+// kernels_cwbvh.hip — BVH8_CWBVH Intersect / IsOccluded for gfx950 (MI355X).
+//
+// Replaces batch_cwbvh / isoccluded_cwbvh (traverse_cwbvh.cl:124-570) from scratch.
+// Blob format: nodes 5 x float4, tris 3 x float4 {e2, e1, v0|prim}, both verbatim as
+// BVH8_CWBVH::ConvertFrom writes them (tiny_bvh.h:5884-6018).  Traversal
+// state machine after Ylitie et al. 2017 as restated by the CPU mirror tiny_bvh.h:7046-7154:
+// ngroup = {child base, hits<<24 | imask}, tgroup = {tri base, tri bits}; highest set bit
+// first = front-to-back through octinv.  Hit semantics follow BVH::Intersect (inclusive
+// t range, miss leaves the record untouched).
+//
+// Scheduling: persistent one-wave workgroups, one lane = one ray, per-lane ray replacement
+// from a wave-local pool (ray_pool.h), traversal stack top in LDS / bottom in global
+// (lane_stack.h).
+#include "device_common.h"
+#include "lane_stack.h"
+#include "ray_pool.h"
+#include "kernels.h"
+
+namespace tbvh {
+
+namespace {
+
+constexpr int WG = 64;
+
+__device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+__device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+__device__ __forceinline__ uint32_t sext_s8x4(uint32_t i) {
+    // every byte with its top bit set becomes 0xff, others 0x00
+    return ((i >> 7) & 0x01010101u) * 0xffu;
+}
+
+// One node visit: fetch node `ci`, slab-test its 8 children against [0, tmax], return the
+// ordered hit mask (bits 24..31: interior children in traversal order, bits 0..23:
+// triangles).  Also returns child / triangle base and imask.
+struct NodeResult { uint32_t childBase, triBase, hitmask, imask; };
+
+__device__ __forceinline__ NodeResult visit_node(const float4* __restrict__ nodes, uint32_t nodeIdx, float3 O,
+                                                 float3 rD, float tmax, uint32_t octinv4) {
+    const float4* np = nodes + nodeIdx * 5u;
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+    const uint32_t ew = as_u32(n0.w);
+    const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
+    const float ox = (n0.x - O.x) * rD.x, oy = (n0.y - O.y) * rD.y, oz = (n0.z - O.z) * rD.z;
+    uint32_t hitmask = 0;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const uint32_t meta4 = half ? as_u32(n1.w) : as_u32(n1.z);
+        const uint32_t inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+        const uint32_t imask4 = sext_s8x4(inner4 << 3);
+        const uint32_t bitidx4 = (meta4 ^ (octinv4 & imask4)) & 0x1F1F1F1Fu;
+        const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;
+        const uint32_t qlx = half ? as_u32(n2.y) : as_u32(n2.x), qhx = half ? as_u32(n3.w) : as_u32(n3.z);
+        const uint32_t qly = half ? as_u32(n2.w) : as_u32(n2.z), qhy = half ? as_u32(n4.y) : as_u32(n4.x);
+        const uint32_t qlz = half ? as_u32(n3.y) : as_u32(n3.x), qhz = half ? as_u32(n4.w) : as_u32(n4.z);
+        const uint32_t lox = rD.x < 0 ? qhx : qlx, hix = rD.x < 0 ? qlx : qhx;
+        const uint32_t loy = rD.y < 0 ? qhy : qly, hiy = rD.y < 0 ? qly : qhy;
+        const uint32_t loz = rD.z < 0 ? qhz : qlz, hiz = rD.z < 0 ? qlz : qhz;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int sh = 8 * i;
+            const float tnx = __builtin_fmaf((float)((lox >> sh) & 255), ax, ox), tfx = __builtin_fmaf((float)((hix >> sh) & 255), ax, ox);
+            const float tny = __builtin_fmaf((float)((loy >> sh) & 255), ay, oy), tfy = __builtin_fmaf((float)((hiy >> sh) & 255), ay, oy);
+            const float tnz = __builtin_fmaf((float)((loz >> sh) & 255), az, oz), tfz = __builtin_fmaf((float)((hiz >> sh) & 255), az, oz);
+            const float cmin = __builtin_fmaxf(fmax3(tnx, tny, tnz), 0.0f);
+            const float cmax = __builtin_fminf(fmin3(tfx, tfy, tfz), tmax);
+            if (cmin <= cmax) hitmask |= ((bits4 >> sh) & 255u) << ((bitidx4 >> sh) & 255u);
+        }
+    }
+    NodeResult r;
+    r.childBase = as_u32(n1.x); r.triBase = as_u32(n1.y); r.hitmask = hitmask; r.imask = ew >> 24;
+    return r;
+}
+
+// MODE 0: whole-wave batches (a wave takes 64 consecutive rays and finishes them all).
+// MODE 1: per-lane replacement from a wave-local pool; REFILL_MIN idle lanes trigger a refill.
+template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN>
+__global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                              QueryArgs q, uint32_t* __restrict__ status) {
+    __shared__ uint2 stk[LDS_N][WG];
+    const uint32_t glane = blockIdx.x * WG + threadIdx.x;
+    LaneStack<uint2, LDS_N, WG> st;
+    st.init(&stk[0][threadIdx.x], (uint2*)q.spill + glane, gridDim.x * WG, q.spillStride);
+    RayPool<(MODE == 0 ? 64 : 64)> pool;
+    pool.init();
+
+    bool active = false;
+    uint64_t ri = 0;
+    float3 O = make_float3(0, 0, 0), D = O, rD = O;
+    float4 hit = make_float4(0, 0, 0, 0);
+    bool found = false;
+    uint32_t oct = 0, octinv4 = 0;
+    uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+
+    for (;;) {
+        // ---- ray replacement -------------------------------------------------------------
+        const uint64_t idleMask = __ballot(!active);
+        const uint32_t nIdle = (uint32_t)__popcll(idleMask);
+        if ((MODE == 0 ? nIdle == (uint32_t)WG : nIdle >= (uint32_t)REFILL_MIN) || (nIdle == (uint32_t)WG)) {
+            if (!(pool.exhausted && pool.next == pool.end)) {
+                uint64_t nri = 0;
+                if (pool.acquire(!active, (unsigned long long*)q.counter, q.nRays, nri)) {
+                    ri = nri;
+                    const RayRec* rp = q.rays + ri;
+                    O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
+                    hit = rp->hit;
+                    found = false;
+                    oct = 7u - ((D.x < 0 ? 4u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 1u : 0u));
+                    octinv4 = oct * 0x01010101u;
+                    ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
+                    st.reset();
+                    active = true;
+                }
+            }
+            if (__ballot(active) == 0) break;
+        }
+        if (!active) continue;
+
+        // ---- one traversal step ----------------------------------------------------------
+        if (ng.y > 0x00FFFFFFu) {
+            const uint32_t imask = ng.y;
+            const uint32_t bit = 31u - (uint32_t)__clz(ng.y);
+            const uint32_t cbase = ng.x;
+            ng.y &= ~(1u << bit);
+            if (ng.y > 0x00FFFFFFu) st.push(ng);
+            const uint32_t slot = (bit - 24u) ^ oct;
+            const uint32_t rel = __popc(imask & ~(0xFFFFFFFFu << slot));
+            const NodeResult r = visit_node(nodes, cbase + rel, O, rD, hit.x, octinv4);
+            ng.x = r.childBase; tg.x = r.triBase;
+            ng.y = (r.hitmask & 0xFF000000u) | r.imask;
+            tg.y = r.hitmask & 0x00FFFFFFu;
+        } else {
+            tg = ng;
+            ng = make_uint2(0u, 0u);
+        }
+        while (tg.y != 0) {
+            const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
+            tg.y &= ~(1u << ti);
+            const uint32_t ta = tg.x + ti * 3u;
+            const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
+            TriHit h;
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                found = true;
+                if (ANYHIT) break;
+                hit = make_float4(h.t, h.u, h.v, v0.w);
+            }
+        }
+        bool done = ANYHIT && found;
+        if (!done && ng.y <= 0x00FFFFFFu) {
+            if (st.empty()) done = true;
+            else ng = st.pop();
+        }
+        if (done) {
+            if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+            else if (found) q.rays[ri].hit = hit;
+            active = false;
+        }
+    }
+    if (st.overflow) atomicOr(status, 1u);
+}
+
+}  // namespace
+
+void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
+                  uint32_t blocks, hipStream_t s) {
+#define TBVH_LAUNCH(MODE, LDSN, RMIN)                                                                                      \
+    do {                                                                                                                   \
+        if (anyhit) hipLaunchKernelGGL((k_cwbvh<true, MODE, LDSN, RMIN>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status); \
+        else hipLaunchKernelGGL((k_cwbvh<false, MODE, LDSN, RMIN>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);  \
+    } while (0)
+    switch (variant) {
+    case 1: TBVH_LAUNCH(0, 16, 64); break;   // whole-wave batches (round-1 v0 behaviour)
+    case 2: TBVH_LAUNCH(1, 16, 1); break;    // replace as soon as one lane is idle
+    case 3: TBVH_LAUNCH(1, 16, 8); break;
+    case 4: TBVH_LAUNCH(1, 16, 32); break;
+    default: TBVH_LAUNCH(1, 16, 16); break;  // replace when >= 16 lanes are idle
+    }
+#undef TBVH_LAUNCH
+}
+
+bool cwbvh_variant_valid(int v) { return v >= 0 && v <= 4; }
+
+}  // namespace tbvh

@@ -187,108 +187,6 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
 }
 
 // ---------------------------------------------------------------------------------------
-// BVH8_CWBVH.  nodes: 5 x float4 per node, tris: 3 x float4 {e2, e1, v0|prim}; both
-// verbatim.  State machine after Ylitie et al. 2017 as restated by the CPU
-// mirror tiny_bvh.h:7046-7154: ngroup = {child base, hits<<24 | imask}, tgroup =
-// {tri base, tri bits}; highest set bit first = front-to-back through octinv.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t sext_s8x4(uint32_t i) {
-    // every byte with its top bit set becomes 0xff, others 0x00
-    return ((i >> 7) & 0x01010101u) * 0xffu;
-}
-
-template <bool ANYHIT>
-__global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes,
-                                              const float4* __restrict__ tris, QueryArgs q,
-                                              uint32_t* __restrict__ status) {
-    constexpr int LDS_N = 16;
-    __shared__ uint2 stk[LDS_N][WG];
-    const uint32_t glane = blockIdx.x * WG + threadIdx.x;
-    LaneStack<uint2, LDS_N, WG> st;
-    st.init(&stk[0][threadIdx.x], (uint2*)q.spill + glane, gridDim.x * WG, q.spillStride);
-    for (;;) {
-        const uint64_t base = fetch_batch((unsigned long long*)q.counter);
-        if (base >= q.nRays) break;
-        const uint64_t ri = base + threadIdx.x;
-        if (ri >= q.nRays) continue;
-        RayRec* rp = q.rays + ri;
-        const float3 O = xyz(rp->O), D = xyz(rp->D), rD = xyz(rp->rD);
-        float4 hit = rp->hit;
-        bool found = false;
-        st.reset();
-        const uint32_t oct = 7u - ((D.x < 0 ? 4u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 1u : 0u));
-        const uint32_t octinv4 = oct * 0x01010101u;
-        uint2 ng = make_uint2(0u, 0x80000000u), tg = make_uint2(0u, 0u);
-        for (;;) {
-            if (ng.y > 0x00FFFFFFu) {
-                const uint32_t imask = ng.y;
-                const uint32_t bit = 31u - (uint32_t)__clz(ng.y);
-                const uint32_t cbase = ng.x;
-                ng.y &= ~(1u << bit);
-                if (ng.y > 0x00FFFFFFu) st.push(ng);
-                const uint32_t slot = (bit - 24u) ^ oct;
-                const uint32_t rel = __popc(imask & ~(0xFFFFFFFFu << slot));
-                const uint32_t ci = (cbase + rel) * 5u;
-                const float4 n0 = nodes[ci], n1 = nodes[ci + 1], n2 = nodes[ci + 2], n3 = nodes[ci + 3], n4 = nodes[ci + 4];
-                const uint32_t ew = as_u32(n0.w);
-                const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
-                const float ox = (n0.x - O.x) * rD.x, oy = (n0.y - O.y) * rD.y, oz = (n0.z - O.z) * rD.z;
-                ng.x = as_u32(n1.x); tg.x = as_u32(n1.y);
-                uint32_t hitmask = 0;
-#pragma unroll
-                for (int half = 0; half < 2; half++) {
-                    const uint32_t meta4 = half ? as_u32(n1.w) : as_u32(n1.z);
-                    const uint32_t inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-                    const uint32_t imask4 = sext_s8x4(inner4 << 3);
-                    const uint32_t bitidx4 = (meta4 ^ (octinv4 & imask4)) & 0x1F1F1F1Fu;
-                    const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;
-                    const uint32_t qlx = half ? as_u32(n2.y) : as_u32(n2.x), qhx = half ? as_u32(n3.w) : as_u32(n3.z);
-                    const uint32_t qly = half ? as_u32(n2.w) : as_u32(n2.z), qhy = half ? as_u32(n4.y) : as_u32(n4.x);
-                    const uint32_t qlz = half ? as_u32(n3.y) : as_u32(n3.x), qhz = half ? as_u32(n4.w) : as_u32(n4.z);
-                    const uint32_t lox = rD.x < 0 ? qhx : qlx, hix = rD.x < 0 ? qlx : qhx;
-                    const uint32_t loy = rD.y < 0 ? qhy : qly, hiy = rD.y < 0 ? qly : qhy;
-                    const uint32_t loz = rD.z < 0 ? qhz : qlz, hiz = rD.z < 0 ? qlz : qhz;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        const int sh = 8 * i;
-                        const float tnx = __builtin_fmaf((float)((lox >> sh) & 255), ax, ox), tfx = __builtin_fmaf((float)((hix >> sh) & 255), ax, ox);
-                        const float tny = __builtin_fmaf((float)((loy >> sh) & 255), ay, oy), tfy = __builtin_fmaf((float)((hiy >> sh) & 255), ay, oy);
-                        const float tnz = __builtin_fmaf((float)((loz >> sh) & 255), az, oz), tfz = __builtin_fmaf((float)((hiz >> sh) & 255), az, oz);
-                        const float cmin = __builtin_fmaxf(fmax3(tnx, tny, tnz), 0.0f);
-                        const float cmax = __builtin_fminf(fmin3(tfx, tfy, tfz), hit.x);
-                        if (cmin <= cmax) hitmask |= ((bits4 >> sh) & 255u) << ((bitidx4 >> sh) & 255u);
-                    }
-                }
-                ng.y = (hitmask & 0xFF000000u) | (ew >> 24);
-                tg.y = hitmask & 0x00FFFFFFu;
-            } else {
-                tg = ng;
-                ng = make_uint2(0u, 0u);
-            }
-            while (tg.y != 0) {
-                const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
-                tg.y &= ~(1u << ti);
-                const uint32_t ta = tg.x + ti * 3u;
-                const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
-                TriHit h;
-                if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
-                    found = true;
-                    if (ANYHIT) break;
-                    hit = make_float4(h.t, h.u, h.v, v0.w);
-                }
-            }
-            if (ANYHIT && found) break;
-            if (ng.y > 0x00FFFFFFu) continue;
-            if (st.empty()) break;
-            ng = st.pop();
-        }
-        if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
-        else if (found) rp->hit = hit;
-    }
-    if (st.overflow) atomicOr(status, 1u);
-}
-
-// ---------------------------------------------------------------------------------------
 // upload helper: gather {v0|prim, e1, e2} per primIdx entry for the BVH_GPU layout.
 // e1 = v1 - v0, e2 = v2 - v0 are the same single IEEE subtractions IntersectTri performs
 // per test (tiny_bvh.h:8510-8511), so pre-computing them changes no result bit.
@@ -318,11 +216,6 @@ void launch_bvh2(bool anyhit, const float4* nodes, const float4* tris, const Que
 void launch_bvh4(bool anyhit, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
     if (anyhit) hipLaunchKernelGGL(k_bvh4<true>, dim3(blocks), dim3(WG), 0, s, data, q, status);
     else hipLaunchKernelGGL(k_bvh4<false>, dim3(blocks), dim3(WG), 0, s, data, q, status);
-}
-void launch_cwbvh(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
-                  uint32_t blocks, hipStream_t s) {
-    if (anyhit) hipLaunchKernelGGL(k_cwbvh<true>, dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
-    else hipLaunchKernelGGL(k_cwbvh<false>, dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
 }
 void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris, hipStream_t s) {
     const uint32_t bs = 256;
