@@ -144,6 +144,11 @@ int tbvh_reset_hits_device(tbvh_context* ctx, void* d_rays64, uint64_t n_rays, f
  * Synchronizes the stream. */
 float tbvh_time_last_ms(tbvh_context* ctx);
 
+/* Lane-utilisation counters of the instrumented kernel variants (development aid):
+ * out[0] wave iterations, [1] sum of active lanes, [2] sum of lanes in the node step,
+ * [3] triangle-loop iterations, [4] sum of lanes in them, [5] refill events, [6] rays handed out. */
+int tbvh_debug_stats(tbvh_context* ctx, uint64_t out[8], int reset);
+
 /* Kernel variant selection for experiments (0 = default).  Returns TBVH_E_INVALID for an
  * unknown variant of the scene's layout. */
 int tbvh_set_variant(tbvh_scene* scene, int variant);

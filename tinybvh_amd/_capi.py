@@ -49,6 +49,7 @@ SYMBOLS = {
     "tbvh_reset_hits_device": (_i, [_vp, _vp, _u64, C.c_float]),
     "tbvh_time_last_ms": (C.c_float, [_vp]),
     "tbvh_set_variant": (_i, [_vp, _i]),
+    "tbvh_debug_stats": (_i, [_vp, _vp, _i]),
     "tbvh_generate_primary_device": (_i, [_vp, C.POINTER(Camera), _vp, _u64, _u64]),
     "tbvh_generate_bounce_device": (_i, [_vp, _vp, _vp, _vp, _u64, _u32]),
     "tbvh_generate_shadow_device": (_i, [_vp, _vp, _vp, _u64, C.POINTER(C.c_float), C.c_float]),

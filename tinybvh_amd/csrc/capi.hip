@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -107,6 +108,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ) {
     QueryArgs q;
     q.rays = d_rays; q.nRays = n; q.occluded = d_occ;
     q.spill = c->spill; q.counter = (uint32_t*)c->counter;
+    q.stats = c->counter + 8;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     switch (s->layout) {
     case TBVH_LAYOUT_BVH_GPU:
@@ -183,13 +185,17 @@ int tbvh_init(int device, tbvh_context** out) {
     c->numCUs = prop.multiProcessorCount;
     // persistent grid: one-wave workgroups, enough to fill every SIMD several times over
     c->blocks = (uint32_t)c->numCUs * 16u;
+    if (const char* e = getenv("TBVH_BLOCKS_PER_CU")) {  // experiment knob
+        const int b = atoi(e);
+        if (b >= 1 && b <= 32) c->blocks = (uint32_t)c->numCUs * (uint32_t)b;
+    }
     c->spillEntries = 232;  // 32-bit entries per lane beyond the LDS part of the stack
     const size_t spillBytes = (size_t)c->blocks * 64 * c->spillEntries * 4;
     e = hipMalloc((void**)&c->spill, spillBytes);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->counter, 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->counter, 256);
     if (e != hipSuccess) { tbvh_shutdown(c); return fail(TBVH_E_NOMEM, "device allocation failed: %s", hipGetErrorString(e)); }
     c->status = (uint32_t*)(c->counter + 4);
-    hipMemset(c->counter, 0, 64);
+    hipMemset(c->counter, 0, 256);
     *out = c;
     return 0;
 }
@@ -361,6 +367,15 @@ float tbvh_time_last_ms(tbvh_context* c) {
     float ms = -1.0f;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0f;
     return ms;
+}
+
+int tbvh_debug_stats(tbvh_context* c, uint64_t out[8], int reset) {
+    if (!c || !out) return fail(TBVH_E_INVALID, "tbvh_debug_stats: null argument");
+    if (int r = setDevice(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->counter + 8, 64, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(hipMemset(c->counter + 8, 0, 64));
+    return 0;
 }
 
 // ---- ray generators ----------------------------------------------------------------------

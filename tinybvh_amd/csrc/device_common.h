@@ -80,6 +80,7 @@ struct QueryArgs {
     uint32_t* spill;       // global overflow area for traversal stacks
     uint32_t spillStride;  // entries per lane in `spill`
     uint32_t* counter;     // dynamic ray-fetch counter (persistent kernels)
+    unsigned long long* stats;  // instrumented variants: lane-utilisation counters
 };
 
 }  // namespace tbvh

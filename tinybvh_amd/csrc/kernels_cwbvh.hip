@@ -74,7 +74,7 @@ __device__ __forceinline__ NodeResult visit_node(const float4* __restrict__ node
 
 // MODE 0: whole-wave batches (a wave takes 64 consecutive rays and finishes them all).
 // MODE 1: per-lane replacement from a wave-local pool; REFILL_MIN idle lanes trigger a refill.
-template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN>
+template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false>
 __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     bool found = false;
     uint32_t oct = 0, octinv4 = 0;
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    unsigned long long sIter = 0, sActive = 0, sNode = 0, sTriIter = 0, sTri = 0, sRefill = 0, sRefilled = 0;  // STATS only
 
     for (;;) {
         // ---- ray replacement -------------------------------------------------------------
@@ -99,7 +100,9 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
         if ((MODE == 0 ? nIdle == (uint32_t)WG : nIdle >= (uint32_t)REFILL_MIN) || (nIdle == (uint32_t)WG)) {
             if (!(pool.exhausted && pool.next == pool.end)) {
                 uint64_t nri = 0;
-                if (pool.acquire(!active, (unsigned long long*)q.counter, q.nRays, nri)) {
+                const bool got = pool.acquire(!active, (unsigned long long*)q.counter, q.nRays, nri);
+                if (STATS) { sRefill++; sRefilled += __popcll(__ballot(got)); }
+                if (got) {
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
@@ -114,7 +117,59 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
             }
             if (__ballot(active) == 0) break;
         }
+        if (STATS) { sIter++; sActive += __popcll(__ballot(active)); sNode += __popcll(__ballot(active && ng.y > 0x00FFFFFFu)); }
         if (!active) continue;
+
+        if (TRI1) {
+            // ---- interleaved schedule: at most ONE triangle test and ONE node visit per lane and
+            // iteration.  A lane with pending triangles sits out the node phase (so the per-ray
+            // order of tests is exactly the mirror's: all triangles of a group before the next
+            // node), but the rest of the wave does not wait for a lane's whole triangle list.
+            bool done = false;
+            if (tg.y != 0) {
+                if (STATS) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sTriIter++; sTri += __popcll(m); } }
+                const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
+                tg.y &= ~(1u << ti);
+                const uint32_t ta = tg.x + ti * 3u;
+                const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
+                TriHit h;
+                if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                    found = true;
+                    if (ANYHIT) done = true;
+                    else hit = make_float4(h.t, h.u, h.v, v0.w);
+                }
+            }
+            if (!done && tg.y == 0) {
+                if (ng.y <= 0x00FFFFFFu) {
+                    if (st.empty()) done = true;
+                    else ng = st.pop();
+                }
+                if (!done) {
+                    if (ng.y > 0x00FFFFFFu) {
+                        const uint32_t imask = ng.y;
+                        const uint32_t bit = 31u - (uint32_t)__clz(ng.y);
+                        const uint32_t cbase = ng.x;
+                        ng.y &= ~(1u << bit);
+                        if (ng.y > 0x00FFFFFFu) st.push(ng);
+                        const uint32_t slot = (bit - 24u) ^ oct;
+                        const uint32_t rel = __popc(imask & ~(0xFFFFFFFFu << slot));
+                        const NodeResult r = visit_node(nodes, cbase + rel, O, rD, hit.x, octinv4);
+                        ng.x = r.childBase; tg.x = r.triBase;
+                        ng.y = (r.hitmask & 0xFF000000u) | r.imask;
+                        tg.y = r.hitmask & 0x00FFFFFFu;
+                    } else {  // a postponed triangle group came off the stack
+                        tg = ng;
+                        ng = make_uint2(0u, 0u);
+                    }
+                }
+            }
+            if (done) {
+                if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+                else if (found) q.rays[ri].hit = hit;
+                active = false;
+            }
+            continue;
+        }
 
         // ---- one traversal step ----------------------------------------------------------
         if (ng.y > 0x00FFFFFFu) {
@@ -134,6 +189,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
             ng = make_uint2(0u, 0u);
         }
         while (tg.y != 0) {
+            if (STATS) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sTriIter++; sTri += __popcll(m); } }
             const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
             tg.y &= ~(1u << ti);
             const uint32_t ta = tg.x + ti * 3u;
@@ -157,27 +213,47 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
         }
     }
     if (st.overflow) atomicOr(status, 1u);
+    if (STATS) {
+        // sTriIter was counted by the first active lane of each tri iteration: reduce over the wave
+        unsigned long long ti = sTriIter;
+        for (int o = 32; o > 0; o >>= 1) { ti += __shfl_xor(ti, o); sTri += __shfl_xor(sTri, o); }
+        if (threadIdx.x == 0) {
+            atomicAdd(q.stats + 0, sIter); atomicAdd(q.stats + 1, sActive); atomicAdd(q.stats + 2, sNode);
+            atomicAdd(q.stats + 3, ti); atomicAdd(q.stats + 4, sTri); atomicAdd(q.stats + 5, sRefill); atomicAdd(q.stats + 6, sRefilled);
+        }
+    }
 }
 
 }  // namespace
 
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                   uint32_t blocks, hipStream_t s) {
-#define TBVH_LAUNCH(MODE, LDSN, RMIN)                                                                                      \
+#define TBVH_LAUNCH(MODE, LDSN, RMIN, ...)                                                                                 \
     do {                                                                                                                   \
-        if (anyhit) hipLaunchKernelGGL((k_cwbvh<true, MODE, LDSN, RMIN>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status); \
-        else hipLaunchKernelGGL((k_cwbvh<false, MODE, LDSN, RMIN>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);  \
+        if (anyhit) hipLaunchKernelGGL((k_cwbvh<true, MODE, LDSN, RMIN, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status); \
+        else hipLaunchKernelGGL((k_cwbvh<false, MODE, LDSN, RMIN, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);  \
     } while (0)
     switch (variant) {
     case 1: TBVH_LAUNCH(0, 16, 64); break;   // whole-wave batches (round-1 v0 behaviour)
     case 2: TBVH_LAUNCH(1, 16, 1); break;    // replace as soon as one lane is idle
     case 3: TBVH_LAUNCH(1, 16, 8); break;
     case 4: TBVH_LAUNCH(1, 16, 32); break;
+    case 7:  // instrumented copy of variant 5 (lane-utilisation counters in q.stats)
+        hipLaunchKernelGGL((k_cwbvh<false, 1, 8, 16, false, true>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+        break;
+    case 8: TBVH_LAUNCH(1, 8, 16, true); break;   // one triangle + one node per lane and iteration
+    case 9:  // instrumented copy of variant 8
+        hipLaunchKernelGGL((k_cwbvh<false, 1, 8, 16, true, true>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+        break;
+    case 10: TBVH_LAUNCH(1, 8, 8, true); break;
+    case 11: TBVH_LAUNCH(1, 8, 24, true); break;
+    case 5: TBVH_LAUNCH(1, 8, 16); break;    // smaller LDS stack -> more waves per CU
+    case 6: TBVH_LAUNCH(1, 12, 16); break;
     default: TBVH_LAUNCH(1, 16, 16); break;  // replace when >= 16 lanes are idle
     }
 #undef TBVH_LAUNCH
 }
 
-bool cwbvh_variant_valid(int v) { return v >= 0 && v <= 4; }
+bool cwbvh_variant_valid(int v) { return v >= 0 && v <= 11; }
 
 }  // namespace tbvh

@@ -66,6 +66,14 @@ def main():
             if kind == "bounce1":
                 ctx.generate_bounce(d_verts, d_prim, d_b, n, 1); sc.intersect_device(d_b, n); ctx.synchronize()
             res[kind] = n / (np.mean(ms) * 1e-3) / 1e6
+            if a.variant in (7, 9):
+                import ctypes as C
+                st = (C.c_uint64 * 8)()
+                tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+                it, act, node, titer, tri, rf, rfd = [int(x) for x in st[:7]]
+                if it:
+                    print(f"   [{kind}] iters/wave-launch {it}  active/64 {act/it/64:.3f}  node-lanes/64 {node/it/64:.3f}  "
+                          f"tri-iters per iter {titer/it:.3f}  tri-lanes/64 {tri/max(titer,1)/64:.3f}  refills {rf} ({rfd/max(rf,1):.1f} rays each)", flush=True)
         print(f"layout {layout}: host build+upload {tb_build:.2f}s  " + "  ".join(f"{k} {v:8.1f} MRays/s" for k, v in res.items()), flush=True)
         sc.free()
     ctx.close()

@@ -10,6 +10,7 @@ d = sys.argv[1]
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "")
     return name.split("(")[0].replace("void tbvh::", "")[:60]
 
 
