@@ -201,8 +201,10 @@ typedef struct tbvh_build_params {
     uint32_t bins;          /* SAH bins per axis; 0 = default (8, BVHBINS)               */
     uint32_t max_leaf_tris; /* 0 = layout default (CWBVH 3, others 4)                   */
     uint32_t threads;       /* 0 = hardware concurrency                                  */
-    uint32_t flags;         /* reserved, 0                                               */
+    uint32_t flags;         /* TBVH_BUILD_* | (triangle cost in 1/100 of a node visit) << 8, 0 = defaults */
 } tbvh_build_params;
+#define TBVH_BUILD_GREEDY_COLLAPSE 1u /* wide layouts: SA-greedy collapse (the reference's MBVH::ConvertFrom
+                                         strategy, tiny_bvh.h:4975-5048) instead of the SAH-optimal one */
 
 int tbvh_host_build(const void* verts16, uint64_t n_tris, int layout,
                     const tbvh_build_params* params, tbvh_hostbvh** out);

@@ -62,6 +62,9 @@ struct tbvh_scene {
     int variant = 0;
     float4* nodes = nullptr;   // BVH_GPU nodes / BVH4 stream / CWBVH nodes
     float4* tris = nullptr;    // BVH_GPU gathered tris / CWBVH tris
+    char* nodesH = nullptr;    // CWBVH: 128-byte re-laid-out nodes (kernels_cwbvh_h.hip)
+    float4* nodesP = nullptr;  // CWBVH: nodes renumbered in surface-area priority order (kernels_cwbvh_c.hip)
+    uint32_t nNodes = 0;
     uint64_t nNodeBlocks = 0, nTriBlocks = 0;
     uint64_t bytes = 0;
     // TLAS
@@ -121,7 +124,9 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ) {
         break;
     case TBVH_LAYOUT_CWBVH:
         q.spillStride = c->spillEntries / 2;  // 8-byte entries
-        launch_cwbvh(any, s->variant, s->nodes, s->tris, q, c->status, c->blocks, c->stream);
+        if (s->variant >= 30) launch_cwbvh_c(any, s->variant, s->nodesP, s->tris, s->nNodes, q, c->status, (uint32_t)c->numCUs, c->stream);
+        else if (s->variant >= 20) launch_cwbvh_h(any, s->variant, s->nodesH, s->tris, q, c->status, c->blocks, c->stream);
+        else launch_cwbvh(any, s->variant, s->nodes, s->tris, q, c->status, c->blocks, c->stream);
         break;
     default:
         return fail(TBVH_E_INVALID, "scene layout %d has no query kernel", s->layout);
@@ -184,7 +189,7 @@ int tbvh_init(int device, tbvh_context** out) {
     c->stream = c->ownStream;
     c->numCUs = prop.multiProcessorCount;
     // persistent grid: one-wave workgroups, enough to fill every SIMD several times over
-    c->blocks = (uint32_t)c->numCUs * 16u;
+    c->blocks = (uint32_t)c->numCUs * 24u;
     if (const char* e = getenv("TBVH_BLOCKS_PER_CU")) {  // experiment knob
         const int b = atoi(e);
         if (b >= 1 && b <= 32) c->blocks = (uint32_t)c->numCUs * (uint32_t)b;
@@ -280,6 +285,7 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
     if (e == hipSuccess) e = hipMalloc((void**)&s->tris, (nTriBlocks ? nTriBlocks : 1) * 16);
     if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, nodes16, nNodeBlocks * 16, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && nTriBlocks) e = hipMemcpyAsync(s->tris, tris16, nTriBlocks * 16, hipMemcpyHostToDevice, c->stream);
+    s->nNodes = (uint32_t)(nNodeBlocks / 5);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "CWBVH upload failed: %s", hipGetErrorString(e)); }
     s->nNodeBlocks = nNodeBlocks; s->nTriBlocks = nTriBlocks;
@@ -303,6 +309,8 @@ void tbvh_free_scene(tbvh_scene* s) {
     hipStreamSynchronize(c->stream);
     if (s->nodes) hipFree(s->nodes);
     if (s->tris) hipFree(s->tris);
+    if (s->nodesH) hipFree(s->nodesH);
+    if (s->nodesP) hipFree(s->nodesP);
     for (size_t i = 0; i < c->scenes.size(); i++)
         if (c->scenes[i] == s) { c->scenes.erase(c->scenes.begin() + i); break; }
     delete s;
@@ -312,8 +320,26 @@ uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0;
 
 int tbvh_set_variant(tbvh_scene* s, int v) {
     if (!s) return fail(TBVH_E_INVALID, "null scene");
-    const bool ok = s->layout == TBVH_LAYOUT_CWBVH ? cwbvh_variant_valid(v) : v == 0;
+    const bool ok = s->layout == TBVH_LAYOUT_CWBVH ? (cwbvh_variant_valid(v) || (v >= 20 && v <= 39)) : v == 0;
     if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    // experimental kernels run on derived node layouts, built on first use
+    if (v >= 20 && v < 30 && !s->nodesH) {
+        HIP_TRY(hipMalloc((void**)&s->nodesH, (size_t)s->nNodes * 128));
+        launch_cwbvh_relayout(s->nodes, s->nodesH, s->nNodes, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        s->bytes += (uint64_t)s->nNodes * 128;
+    }
+    if (v >= 30 && !s->nodesP) {
+        std::vector<Vec4> in((size_t)s->nNodes * 5), pr;
+        HIP_TRY(hipMemcpy(in.data(), s->nodes, in.size() * 16, hipMemcpyDeviceToHost));
+        reorder_cwbvh_priority(in.data(), s->nNodes, pr);
+        HIP_TRY(hipMalloc((void**)&s->nodesP, pr.size() * 16));
+        HIP_TRY(hipMemcpy(s->nodesP, pr.data(), pr.size() * 16, hipMemcpyHostToDevice));
+        s->bytes += pr.size() * 16;
+    }
     s->variant = v;
     return 0;
 }
@@ -463,15 +489,19 @@ int tbvh_host_build(const void* verts16, uint64_t nTris, int layout, const tbvh_
     if (!h) return fail(TBVH_E_NOMEM, "out of host memory");
     h->layout = layout;
     BuildParams bp;
-    if (p) { bp.bins = p->bins ? p->bins : 8; bp.threads = p->threads; bp.maxLeafTris = p->max_leaf_tris; }
+    if (p) {
+        bp.bins = p->bins ? p->bins : 8; bp.threads = p->threads; bp.maxLeafTris = p->max_leaf_tris;
+        bp.greedyCollapse = (p->flags & TBVH_BUILD_GREEDY_COLLAPSE) != 0;
+        if (p->flags >> 8) bp.cPrim = (float)((p->flags >> 8) & 0xffff) * 0.01f;
+    }
     if (!bp.maxLeafTris) bp.maxLeafTris = layout == TBVH_LAYOUT_CWBVH ? 3 : 4;
     if (layout == TBVH_LAYOUT_CWBVH && bp.maxLeafTris > 3) bp.maxLeafTris = 3;
     try {
         const Vec4* v = (const Vec4*)verts16;
         build_bvh2(v, (uint32_t)nTris, bp, h->bvh2);
         if (layout == TBVH_LAYOUT_BVH_GPU) encode_bvh_gpu(h->bvh2, h->al);
-        else if (layout == TBVH_LAYOUT_BVH4_GPU) encode_bvh4_gpu(h->bvh2, v, h->blocksA);
-        else if (layout == TBVH_LAYOUT_CWBVH) encode_cwbvh(h->bvh2, v, h->blocksA, h->blocksB);
+        else if (layout == TBVH_LAYOUT_BVH4_GPU) encode_bvh4_gpu(h->bvh2, v, bp, h->blocksA);
+        else if (layout == TBVH_LAYOUT_CWBVH) encode_cwbvh(h->bvh2, v, bp, h->blocksA, h->blocksB);
     } catch (const std::bad_alloc&) {
         delete h;
         return fail(TBVH_E_NOMEM, "out of host memory while building");

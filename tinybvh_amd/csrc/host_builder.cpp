@@ -280,6 +280,105 @@ template <int M> void collapse(const BVH2& bvh, std::vector<WideNode<M>>& W) {
     }
 }
 
+// Cost-optimal collapse (the SAH dynamic program of Ylitie, Karras & Laine 2017, §3.1):
+// for every BVH2 node n and every i in 1..M-1, C(n,i) is the cheapest way to represent n's
+// subtree as a forest of at most i wide-BVH roots:
+//   C(n,1) = min( leaf:      A_n * P_n * cPrim           if the subtree has P_n <= maxLeaf tris,
+//                 internal:  A_n * cNode + min_k C(l,k) + C(r,M-k) )
+//   C(n,i) = min( min_k C(l,k) + C(r,i-k),  C(n,i-1) )   for i >= 2
+// Compared with the greedy collapse this (a) merges subtrees of <= maxLeaf triangles into one
+// leaf instead of spending a child slot per triangle, and (b) fills nodes, so a ray visits
+// fewer nodes.  Relies on two properties of build_bvh2: children have larger indices than
+// their parent, and a subtree's triangles are one contiguous primIdx range.
+template <int M> void collapse_optimal(const BVH2& bvh, uint32_t maxLeaf, float cNode, float cPrim,
+                                       std::vector<WideNode<M>>& W) {
+    const uint32_t n2 = (uint32_t)bvh.nodes.size();
+    constexpr int K = M - 1;                       // forest sizes 1..M-1
+    std::vector<float> C((size_t)n2 * K);          // C[n*K + (i-1)]
+    std::vector<uint8_t> dec((size_t)n2 * K);      // i==1: 0 = leaf, k = internal with split k (left gets k of M)
+                                                   // i>=2 : 0 = same as i-1, k = distribute with left k
+    std::vector<uint32_t> cnt(n2), first(n2);
+    auto area = [&](uint32_t n) { Box b; for (int a = 0; a < 3; a++) b.mn[a] = bvh.nodes[n].mn[a], b.mx[a] = bvh.nodes[n].mx[a]; return b.halfArea(); };
+    for (uint32_t n = n2; n-- > 0;) {
+        const Node2& nd = bvh.nodes[n];
+        float* c = &C[(size_t)n * K]; uint8_t* d = &dec[(size_t)n * K];
+        if (nd.leaf()) {
+            cnt[n] = nd.triCount; first[n] = nd.leftFirst;
+            const float leafCost = area(n) * (float)nd.triCount * cPrim;
+            for (int i = 0; i < K; i++) c[i] = leafCost, d[i] = 0;
+            continue;
+        }
+        const uint32_t l = nd.leftFirst, r = l + 1;
+        cnt[n] = cnt[l] + cnt[r]; first[n] = std::min(first[l], first[r]);
+        const float* cl = &C[(size_t)l * K]; const float* cr = &C[(size_t)r * K];
+        auto distribute = [&](int j, int& bestK) {   // min over k of C(l,k) + C(r,j-k), 1 <= k, j-k <= K
+            float best = kFar; bestK = 1;
+            for (int k = std::max(1, j - K); k <= std::min(K, j - 1); k++) {
+                const float v = cl[k - 1] + cr[j - k - 1];
+                if (v < best) best = v, bestK = k;
+            }
+            return best;
+        };
+        int kInt; const float internal = area(n) * cNode + distribute(M, kInt);
+        const float leaf = cnt[n] <= maxLeaf ? area(n) * (float)cnt[n] * cPrim : kFar;
+        if (leaf <= internal) c[0] = leaf, d[0] = 0; else c[0] = internal, d[0] = (uint8_t)kInt;
+        for (int i = 2; i <= K; i++) {
+            int k; const float v = distribute(i, k);
+            if (v < c[i - 2]) c[i - 1] = v, d[i - 1] = (uint8_t)k; else c[i - 1] = c[i - 2], d[i - 1] = 0;
+        }
+    }
+    // top-down reconstruction
+    W.clear();
+    W.reserve(n2 / 4 + 16);
+    auto boxOf = [&](uint32_t n) { Box b; for (int a = 0; a < 3; a++) b.mn[a] = bvh.nodes[n].mn[a], b.mx[a] = bvh.nodes[n].mx[a]; return b; };
+    auto makeLeaf = [&](uint32_t n) { WideNode<M> w{}; w.box = boxOf(n); w.firstTri = first[n]; w.triCount = cnt[n]; W.push_back(w); return (uint32_t)W.size() - 1; };
+    // collect the roots of the forest that represents node n with budget i
+    struct Root { uint32_t n2; };
+    std::vector<Root> roots;
+    struct Frame { uint32_t n; int i; };
+    auto gather = [&](uint32_t n, int budget) {   // expands "n as a forest of <= budget roots" into `roots`
+        std::vector<Frame> st{{n, budget}};
+        while (!st.empty()) {
+            Frame f = st.back(); st.pop_back();
+            int i = f.i;
+            while (i >= 2 && dec[(size_t)f.n * K + i - 1] == 0) i--;   // "same as i-1"
+            if (i == 1) { roots.push_back({f.n}); continue; }
+            const int k = dec[(size_t)f.n * K + i - 1];
+            const uint32_t l = bvh.nodes[f.n].leftFirst;
+            st.push_back({l + 1, i - k});
+            st.push_back({l, k});
+        }
+    };
+    struct Item { uint32_t wide, n2; };
+    std::vector<Item> stack;
+    {
+        WideNode<M> root{}; root.box = boxOf(0); W.push_back(root);
+        if (dec[0] == 0) {  // whole scene is one leaf: interior root above it (tiny_bvh.h:5036-5044)
+            const uint32_t lf = makeLeaf(0);
+            W[0].child[0] = lf; W[0].childCount = 1;
+            return;
+        }
+        stack.push_back({0, 0});
+    }
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        const int k = dec[(size_t)it.n2 * K];      // internal: left gets k, right M-k
+        const uint32_t l = bvh.nodes[it.n2].leftFirst;
+        roots.clear();
+        gather(l, k); gather(l + 1, M - k);
+        uint32_t slots[M]; const uint32_t nk = (uint32_t)roots.size();
+        for (uint32_t i = 0; i < nk; i++) {
+            const uint32_t c = roots[i].n2;
+            if (dec[(size_t)c * K] == 0) slots[i] = makeLeaf(c);
+            else { WideNode<M> w{}; w.box = boxOf(c); W.push_back(w); slots[i] = (uint32_t)W.size() - 1; }
+        }
+        for (uint32_t i = 0; i < nk; i++) W[it.wide].child[i] = slots[i];
+        W[it.wide].childCount = nk;
+        for (uint32_t i = nk; i-- > 0;)
+            if (dec[(size_t)roots[i].n2 * K] != 0) stack.push_back({slots[i], roots[i].n2});
+    }
+}
+
 inline uint32_t asU32(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float asF32(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
@@ -342,9 +441,10 @@ void encode_bvh_gpu(const BVH2& bvh, std::vector<NodeAL>& out) {
 }
 
 // BVH4_GPU stream (format: tiny_bvh.h:1248-1266, 5120-5127).
-void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& blocks) {
+void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std::vector<Vec4>& blocks) {
     std::vector<WideNode<4>> W;
-    collapse<4>(bvh, W);
+    if (p.greedyCollapse) collapse<4>(bvh, W);
+    else collapse_optimal<4>(bvh, std::max<uint32_t>(p.maxLeafTris, 1), 1.0f, p.cPrim, W);
     blocks.clear();
     blocks.reserve(W.size() * 4 + (size_t)bvh.triCount * 3);
     struct Item { uint32_t wide; uint32_t patchWord; };  // patchWord: u32 index to receive the node's block offset
@@ -413,10 +513,11 @@ void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& bloc
 }
 
 // CWBVH (format: Ylitie et al. 2017 as laid out by tiny_bvh.h:5884-6018).
-void encode_cwbvh(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& nodeBlocks,
+void encode_cwbvh(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std::vector<Vec4>& nodeBlocks,
                   std::vector<Vec4>& triBlocks) {
     std::vector<WideNode<8>> W;
-    collapse<8>(bvh, W);
+    if (p.greedyCollapse) collapse<8>(bvh, W);
+    else collapse_optimal<8>(bvh, std::min<uint32_t>(std::max<uint32_t>(p.maxLeafTris, 1), 3), 1.0f, p.cPrim, W);
     nodeBlocks.clear(); triBlocks.clear();
     nodeBlocks.reserve(W.size() * 5);
     triBlocks.reserve((size_t)bvh.triCount * 3);
@@ -560,6 +661,56 @@ void update_instance(Instance192& inst, const float* bb) {
         w.grow(t);
     }
     for (int a = 0; a < 3; a++) inst.aabbMin[a] = w.mn[a], inst.aabbMax[a] = w.mx[a];
+}
+
+}  // namespace tbvh
+
+// ---- CWBVH node renumbering for the LDS-resident top of the tree (kernels_cwbvh_c.hip) --------
+#include <queue>
+namespace tbvh {
+
+// Best-first renumbering: repeatedly take the not-yet-expanded node with the largest surface
+// area and give its interior children the next consecutive indices (slot order, so
+// childBaseIndex + popc(...) addressing still works).  The first K nodes of the result are
+// (to first order) the K nodes a random ray is most likely to visit.  Works on any valid
+// CWBVH blob, reference-built or ours; only childBaseIndex fields change.
+void reorder_cwbvh_priority(const Vec4* in, uint32_t nNodes, std::vector<Vec4>& out) {
+    out.assign((size_t)nNodes * 5, Vec4{0, 0, 0, 0});
+    auto u32 = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    auto f32 = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    auto area = [&](uint32_t n) {
+        const Vec4* p = in + (size_t)n * 5;
+        const uint32_t ew = u32(p[0].w);
+        const uint8_t* q = (const uint8_t*)(p + 2);
+        float ext[3];
+        for (int a = 0; a < 3; a++) {
+            int mx = 0;
+            for (int s = 0; s < 8; s++) mx = std::max(mx, (int)q[24 + 8 * a + s]);
+            ext[a] = std::ldexp((float)mx, (int)(int8_t)((ew >> (8 * a)) & 255));
+        }
+        return ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0];
+    };
+    std::vector<uint32_t> newIdx(nNodes, 0xffffffffu);
+    std::priority_queue<std::pair<float, uint32_t>> pq;
+    newIdx[0] = 0;
+    uint32_t next = 1;
+    pq.push({area(0), 0u});
+    while (!pq.empty()) {
+        const uint32_t n = pq.top().second; pq.pop();
+        const Vec4* p = in + (size_t)n * 5;
+        const uint32_t imask = u32(p[0].w) >> 24, base = u32(p[1].x);
+        const uint32_t cnt = (uint32_t)__builtin_popcount(imask);
+        Vec4* o = out.data() + (size_t)newIdx[n] * 5;
+        for (int k = 0; k < 5; k++) o[k] = p[k];
+        o[1].x = f32(cnt ? next : 0u);
+        for (uint32_t j = 0; j < cnt; j++) {
+            const uint32_t c = base + j;
+            if (c >= nNodes || newIdx[c] != 0xffffffffu) continue;  // malformed blob: leave as is
+            newIdx[c] = next + j;
+            pq.push({area(c), c});
+        }
+        next += cnt;
+    }
 }
 
 }  // namespace tbvh

@@ -34,6 +34,8 @@ struct BuildParams {
     uint32_t bins = 8;
     uint32_t maxLeafTris = 4;
     uint32_t threads = 0;
+    bool greedyCollapse = false;  // wide layouts: surface-area-greedy collapse instead of the SAH-optimal one
+    float cPrim = 0.3f;           // cost of one triangle test relative to one wide-node visit (optimal collapse)
 };
 
 struct BVH2 {
@@ -50,9 +52,12 @@ void build_bvh2_boxes(const float* boxes6, uint32_t count, const BuildParams& p,
 
 // Encoders.
 void encode_bvh_gpu(const BVH2& bvh, std::vector<NodeAL>& out);
-void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& blocks);
-void encode_cwbvh(const BVH2& bvh, const Vec4* verts, std::vector<Vec4>& nodeBlocks,
+void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std::vector<Vec4>& blocks);
+void encode_cwbvh(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std::vector<Vec4>& nodeBlocks,
                   std::vector<Vec4>& triBlocks);
+
+// Renumber CWBVH nodes (5 x Vec4 each) in surface-area priority order; see host_builder.cpp.
+void reorder_cwbvh_priority(const Vec4* in, uint32_t nNodes, std::vector<Vec4>& out);
 
 // BLASInstance record, 192 bytes (tiny_bvh.h:1443-1457).
 struct Instance192 {

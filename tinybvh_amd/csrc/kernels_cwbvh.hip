@@ -249,11 +249,12 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     case 11: TBVH_LAUNCH(1, 8, 24, true); break;
     case 5: TBVH_LAUNCH(1, 8, 16); break;    // smaller LDS stack -> more waves per CU
     case 6: TBVH_LAUNCH(1, 12, 16); break;
-    default: TBVH_LAUNCH(1, 16, 16); break;  // replace when >= 16 lanes are idle
+    case 12: TBVH_LAUNCH(1, 16, 16); break;  // replace when >= 16 lanes are idle, all triangles of a group at once
+    default: TBVH_LAUNCH(1, 8, 16, true); break;  // = 8
     }
 #undef TBVH_LAUNCH
 }
 
-bool cwbvh_variant_valid(int v) { return v >= 0 && v <= 11; }
+bool cwbvh_variant_valid(int v) { return v >= 0 && v <= 12; }
 
 }  // namespace tbvh
