@@ -79,6 +79,25 @@ class Oracle:
         return (r, c) if counts else r
 
 
+class OrcBlas(C.Structure):
+    _fields_ = [("nodes32", C.c_void_p), ("primIdx", C.c_void_p), ("verts16", C.c_void_p)]
+
+
+def tlas_intersect(orc: "Oracle", tlas_nodes32, tlas_idx, instances, blas_list, rays):
+    """BVH::IntersectTLAS restated (oracle/tbvh_oracle.c: orc_tlas_intersect).  blas_list:
+    [(bvh2_nodes, prim_idx, verts), ...] indexed by BLASInstance::blasIdx."""
+    keep = []
+    arr = (OrcBlas * len(blas_list))()
+    for i, (n, p, v) in enumerate(blas_list):
+        n = np.ascontiguousarray(n); p = np.ascontiguousarray(p); v = np.ascontiguousarray(v)
+        keep += [n, p, v]
+        arr[i] = OrcBlas(n.ctypes.data, p.ctypes.data, v.ctypes.data)
+    r = np.ascontiguousarray(rays).copy()
+    tn = np.ascontiguousarray(tlas_nodes32); ti = np.ascontiguousarray(tlas_idx, np.uint32); inst = np.ascontiguousarray(instances)
+    orc.lib.orc_tlas_intersect(_p(tn), _p(ti), _p(inst), C.cast(arr, C.c_void_p), _p(r), r.shape[0], r.strides[0])
+    return r
+
+
 def have_reference() -> bool:
     return os.path.exists(REF_PATH)
 

@@ -268,3 +268,64 @@ LAYOUT_CLASSES = {LAYOUT_BVH_GPU: BVH_GPU, LAYOUT_BVH4_GPU: BVH4_GPU, LAYOUT_CWB
 
 def device_count() -> int:
     return int(lib.tbvh_device_count())
+
+
+# BLASInstance, 192 bytes (tiny_bvh.h:1443-1457); transform is row-major with the translation in
+# elements 3, 7, 11 (tiny_bvh.h:513-528)
+INSTANCE_DTYPE = np.dtype([
+    ("transform", "<f4", 16), ("invTransform", "<f4", 16),
+    ("aabbMin", "<f4", 3), ("blasIdx", "<u4"), ("aabbMax", "<f4", 3), ("mask", "<u4"), ("pad", "<u4", 8),
+])
+assert INSTANCE_DTYPE.itemsize == 192
+
+
+def make_instances(transforms: np.ndarray, blas_idx, mask: int = 0xFFFF) -> np.ndarray:
+    """BLASInstance records from (n, 4, 4) row-major transforms; invTransform and the bounds are
+    filled by TLAS.Build (BLASInstance::Update, tiny_bvh.h:8386-8400)."""
+    t = np.ascontiguousarray(transforms, np.float32).reshape(-1, 16)
+    inst = np.zeros(t.shape[0], INSTANCE_DTYPE)
+    inst["transform"] = t
+    inst["invTransform"] = np.eye(4, dtype=np.float32).reshape(16)
+    inst["blasIdx"] = blas_idx
+    inst["mask"] = mask
+    return inst
+
+
+class TLAS(_Scene):
+    """Top-level BVH over BLAS instances: BVH_GPU nodes over BLASInstance records
+    (BVH_GPU::Build(BLASInstance*, ...), tiny_bvh.h:4575-4581; tiny_bvh_gpu2.cpp:108-136)."""
+    layout = LAYOUT_BVH_GPU
+
+    def Build(self, instances: np.ndarray, blas: list) -> "TLAS":
+        """instances: INSTANCE_DTYPE array with transform/blasIdx/mask set (updated in place);
+        blas: uploaded BLAS scenes (all BVH8_CWBVH or all BVH4_GPU) built with .Build()."""
+        assert instances.dtype == INSTANCE_DTYPE and instances.flags["C_CONTIGUOUS"]
+        bounds = np.zeros((len(blas), 6), np.float32)
+        for i, b in enumerate(blas):
+            v = b.host.verts[:, :3]
+            bounds[i, :3] = v.min(0); bounds[i, 3:] = v.max(0)
+        h = C.c_void_p()
+        check(lib.tbvh_host_build_tlas(_ptr(instances), instances.shape[0], _ptr(bounds), len(blas), C.byref(h)), "tbvh_host_build_tlas")
+        host = HostBVH.__new__(HostBVH)
+        host._h = h; host.layout = LAYOUT_BVH_GPU; host.verts = None; host.n_tris = instances.shape[0]
+        self.host = host
+        self.instances = instances
+        self.blas = list(blas)
+        nodes = host.blob(0, np.uint32, 16); idx = host.blob(1, np.uint32, 1)
+        if self._h:
+            return self.Update(nodes, idx, instances)
+        return self.Upload(nodes, idx, instances, blas)
+
+    def Upload(self, nodes64: np.ndarray, tlas_idx: np.ndarray, instances: np.ndarray, blas: list) -> "TLAS":
+        nodes64 = np.ascontiguousarray(nodes64); tlas_idx = np.ascontiguousarray(tlas_idx, np.uint32)
+        arr = (C.c_void_p * len(blas))(*[b._h for b in blas])
+        check(lib.tbvh_upload_tlas(self.ctx._h, _ptr(nodes64), nodes64.nbytes // 64, _ptr(tlas_idx), tlas_idx.size, _ptr(instances),
+                                   instances.shape[0], arr, len(blas), C.byref(self._h)), "tbvh_upload_tlas")
+        self.blas = list(blas)  # BLAS scenes must outlive the TLAS
+        return self
+
+    def Update(self, nodes64: np.ndarray, tlas_idx: np.ndarray, instances: np.ndarray) -> "TLAS":
+        nodes64 = np.ascontiguousarray(nodes64); tlas_idx = np.ascontiguousarray(tlas_idx, np.uint32)
+        check(lib.tbvh_update_tlas(self._h, _ptr(nodes64), nodes64.nbytes // 64, _ptr(tlas_idx), tlas_idx.size, _ptr(instances), instances.shape[0]),
+              "tbvh_update_tlas")
+        return self

@@ -67,9 +67,17 @@ struct tbvh_scene {
     uint32_t nNodes = 0;
     uint64_t nNodeBlocks = 0, nTriBlocks = 0;
     uint64_t bytes = 0;
-    // TLAS
+    // TLAS (layout = BVH_GPU nodes in `nodes`)
     bool isTlas = false;
+    uint32_t* tlasIdx = nullptr;
+    float4* instances = nullptr;
+    BlasDesc* blasDesc = nullptr;
+    int blasLayout = 0;
+    uint64_t capNodes = 0, capIdx = 0, capInst = 0;
 };
+
+struct BLASInstanceCheck { float m[32]; float mn[3]; uint32_t blasIdx; float mx[3]; uint32_t mask; uint32_t pad[8]; };
+static_assert(sizeof(BLASInstanceCheck) == 192, "BLASInstance is 192 bytes");
 
 struct tbvh_hostbvh {
     int layout = 0;
@@ -113,6 +121,14 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ) {
     q.spill = c->spill; q.counter = (uint32_t*)c->counter;
     q.stats = c->counter + 8;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (s->isTlas) {
+        q.spillStride = c->spillEntries / 2;
+        launch_tlas(any, s->blasLayout, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, c->blocks, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        c->timed = true;
+        return 0;
+    }
     switch (s->layout) {
     case TBVH_LAYOUT_BVH_GPU:
         q.spillStride = c->spillEntries;
@@ -294,12 +310,52 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
     return 0;
 }
 
-int tbvh_upload_tlas(tbvh_context*, const void*, uint64_t, const uint32_t*, uint64_t, const void*, uint64_t,
-                     tbvh_scene* const*, uint64_t, tbvh_scene**) {
-    return fail(TBVH_E_INVALID, "TLAS queries are not implemented yet");
+namespace {
+int tlasCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* idx, uint64_t nIdx, const void* inst, uint64_t nInst) {
+    tbvh_context* c = s->ctx;
+    if (nNodes > s->capNodes) { if (s->nodes) hipFree(s->nodes); s->nodes = nullptr; HIP_TRY(hipMalloc((void**)&s->nodes, nNodes * 64)); s->capNodes = nNodes; }
+    if (nIdx > s->capIdx) { if (s->tlasIdx) hipFree(s->tlasIdx); s->tlasIdx = nullptr; HIP_TRY(hipMalloc((void**)&s->tlasIdx, nIdx * 4)); s->capIdx = nIdx; }
+    if (nInst > s->capInst) { if (s->instances) hipFree(s->instances); s->instances = nullptr; HIP_TRY(hipMalloc((void**)&s->instances, nInst * 192)); s->capInst = nInst; }
+    HIP_TRY(hipMemcpyAsync(s->nodes, nodes64, nNodes * 64, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(s->tlasIdx, idx, nIdx * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(s->instances, inst, nInst * 192, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller may reuse its host arrays right away
+    s->bytes = nNodes * 64 + nIdx * 4 + nInst * 192;
+    return 0;
 }
-int tbvh_update_tlas(tbvh_scene*, const void*, uint64_t, const uint32_t*, uint64_t, const void*, uint64_t) {
-    return fail(TBVH_E_INVALID, "TLAS queries are not implemented yet");
+}  // namespace
+
+int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, const uint32_t* idx, uint64_t nIdx, const void* inst,
+                     uint64_t nInst, tbvh_scene* const* blas, uint64_t nBlas, tbvh_scene** out) {
+    if (!c || !nodes64 || !idx || !inst || !blas || !out || !nNodes || !nIdx || !nInst || !nBlas) return fail(TBVH_E_INVALID, "tbvh_upload_tlas: null/empty argument");
+    int layout = 0;
+    std::vector<BlasDesc> desc(nBlas);
+    for (uint64_t i = 0; i < nBlas; i++) {
+        const tbvh_scene* b = blas[i];
+        if (!b || b->ctx != c || b->isTlas) return fail(TBVH_E_INVALID, "BLAS %llu is null, a TLAS, or from another context", (unsigned long long)i);
+        if (b->layout != TBVH_LAYOUT_CWBVH && b->layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "BLAS %llu: layout %d is not supported under a TLAS (use BVH8_CWBVH or BVH4_GPU)", (unsigned long long)i, b->layout);
+        if (layout && b->layout != layout) return fail(TBVH_E_INVALID, "all BLASes of a TLAS must share one layout");
+        layout = b->layout;
+        desc[i].nodes = b->nodes; desc[i].tris = b->tris;
+    }
+    const BLASInstanceCheck* ic = (const BLASInstanceCheck*)inst;
+    for (uint64_t i = 0; i < nInst; i++) if (ic[i].blasIdx >= nBlas) return fail(TBVH_E_FORMAT, "instance %llu: blasIdx %u out of range", (unsigned long long)i, ic[i].blasIdx);
+    if (int r = setDevice(c)) return r;
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    s->isTlas = true; s->blasLayout = layout;
+    hipError_t e = hipMalloc((void**)&s->blasDesc, nBlas * sizeof(BlasDesc));
+    if (e == hipSuccess) e = hipMemcpy(s->blasDesc, desc.data(), nBlas * sizeof(BlasDesc), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "TLAS upload failed: %s", hipGetErrorString(e)); }
+    if (int r = tlasCopy(s, nodes64, nNodes, idx, nIdx, inst, nInst)) { tbvh_free_scene(s); return r; }
+    *out = s;
+    return 0;
+}
+
+int tbvh_update_tlas(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* idx, uint64_t nIdx, const void* inst, uint64_t nInst) {
+    if (!s || !s->isTlas || !nodes64 || !idx || !inst || !nNodes || !nIdx || !nInst) return fail(TBVH_E_INVALID, "tbvh_update_tlas: not a TLAS or null/empty argument");
+    if (int r = setDevice(s->ctx)) return r;
+    return tlasCopy(s, nodes64, nNodes, idx, nIdx, inst, nInst);
 }
 
 void tbvh_free_scene(tbvh_scene* s) {
@@ -311,6 +367,9 @@ void tbvh_free_scene(tbvh_scene* s) {
     if (s->tris) hipFree(s->tris);
     if (s->nodesH) hipFree(s->nodesH);
     if (s->nodesP) hipFree(s->nodesP);
+    if (s->tlasIdx) hipFree(s->tlasIdx);
+    if (s->instances) hipFree(s->instances);
+    if (s->blasDesc) hipFree(s->blasDesc);
     for (size_t i = 0; i < c->scenes.size(); i++)
         if (c->scenes[i] == s) { c->scenes.erase(c->scenes.begin() + i); break; }
     delete s;
