@@ -1,0 +1,32 @@
+"""The C++ hosts above the C ABI run on the GPU box: the minimal example (library's own host
+builder) and — when it was built, i.e. the reference header was present at build time — the
+reference's speedtest GPU section re-hosted on the engine with the REAL tiny_bvh.h building the
+layouts (the drop-in situation end to end, in the reference's own language)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "examples", "_build")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [4, 6, 9])
+def test_minimal_gpu_example(layout):
+    exe = os.path.join(BUILD, "minimal_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("examples/_build/minimal_gpu not built (run __graft_entry__.build())")
+    out = subprocess.run([exe, str(layout)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "of 1024 rays hit" in out.stdout
+
+
+@pytest.mark.gpu
+def test_speedtest_gpu_section_with_real_tinybvh():
+    exe = os.path.join(BUILD, "speedtest_gpu_section")
+    if not os.path.exists(exe):
+        pytest.skip("needs the reference header at build time")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all layouts agree with BVH::Intersect" in out.stdout
