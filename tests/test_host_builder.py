@@ -158,3 +158,22 @@ def test_tiny_inputs():
     same = np.tile(one, (50, 1))
     h = tb.HostBVH(same, tb.LAYOUT_CWBVH)
     assert h.blob(1, np.uint32, 4).shape[0] == 150
+
+
+@pytest.mark.parametrize("layout", [tb.LAYOUT_BVH4_GPU, tb.LAYOUT_CWBVH])
+def test_optimal_collapse_gives_same_hits_with_fewer_nodes(oracle, small_scene, layout):
+    """TBVH_BUILD_OPTIMAL_COLLAPSE (SAH dynamic program): still a valid blob of the format, same
+    hits as BVH::Intersect, fewer nodes than the greedy collapse."""
+    verts = small_scene
+    g = tb.HostBVH(verts, layout)
+    o = tb.HostBVH(verts, layout, optimal_collapse=True, c_prim=0.3)
+    assert o.blob(0, np.uint32, 4).shape[0] < g.blob(0, np.uint32, 4).shape[0]
+    for rays in ray_sets(verts):
+        want = oracle.bvh2_intersect(o.bvh2_nodes(), o.bvh2_prim_idx(), verts, rays)
+        got = oracle.bvh4_intersect(o.blob(0, np.uint32, 4), rays) if layout == tb.LAYOUT_BVH4_GPU else \
+            oracle.cwbvh_intersect(o.blob(0, np.uint32, 4), o.blob(1, np.uint32, 4), rays)
+        c = compare_hits(got, want)
+        assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["tie"] <= 2 and c["onsurf"] <= 4, c
+    if layout == tb.LAYOUT_CWBVH:
+        tris = o.blob(1, np.uint32, 4).reshape(-1, 3, 4)
+        assert sorted(tris[:, 2, 3].tolist()) == list(range(verts.shape[0] // 3))  # every triangle exactly once

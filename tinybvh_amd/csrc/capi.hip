@@ -550,7 +550,7 @@ int tbvh_host_build(const void* verts16, uint64_t nTris, int layout, const tbvh_
     BuildParams bp;
     if (p) {
         bp.bins = p->bins ? p->bins : 8; bp.threads = p->threads; bp.maxLeafTris = p->max_leaf_tris;
-        bp.greedyCollapse = (p->flags & TBVH_BUILD_GREEDY_COLLAPSE) != 0;
+        bp.greedyCollapse = (p->flags & TBVH_BUILD_OPTIMAL_COLLAPSE) == 0;
         if (p->flags >> 8) bp.cPrim = (float)((p->flags >> 8) & 0xffff) * 0.01f;
     }
     if (!bp.maxLeafTris) bp.maxLeafTris = layout == TBVH_LAYOUT_CWBVH ? 3 : 4;

@@ -34,7 +34,7 @@ struct BuildParams {
     uint32_t bins = 8;
     uint32_t maxLeafTris = 4;
     uint32_t threads = 0;
-    bool greedyCollapse = false;  // wide layouts: surface-area-greedy collapse instead of the SAH-optimal one
+    bool greedyCollapse = true;   // wide layouts: surface-area-greedy collapse (default; measured faster on the GPU) or the SAH-optimal one
     float cPrim = 0.3f;           // cost of one triangle test relative to one wide-node visit (optimal collapse)
 };
 

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--passes", type=int, default=5)
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--cam", type=int, default=0)
+    ap.add_argument("--optimal", action="store_true")
+    ap.add_argument("--cprim", type=float, default=0.0)
     a = ap.parse_args()
     verts, label = scenes.get(a.scene)
     print(f"scene: {label}: {verts.shape[0] // 3} tris", flush=True)
@@ -37,7 +39,7 @@ def main():
     ext = float((verts[:, :3].max(0) - verts[:, :3].min(0)).max())
     for layout in [int(x) for x in a.layouts.split(",")]:
         t0 = time.time()
-        sc = tb.LAYOUT_CLASSES[layout](ctx).Build(verts)
+        sc = tb.LAYOUT_CLASSES[layout](ctx).Build(verts, optimal_collapse=a.optimal, c_prim=a.cprim)
         if a.variant:
             sc.set_variant(a.variant)
         tb_build = time.time() - t0
