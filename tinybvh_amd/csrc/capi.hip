@@ -132,11 +132,11 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ) {
     switch (s->layout) {
     case TBVH_LAYOUT_BVH_GPU:
         q.spillStride = c->spillEntries;
-        launch_bvh2(any, s->nodes, s->tris, q, c->status, c->blocks, c->stream);
+        launch_bvh2(any, s->variant, s->nodes, s->tris, q, c->status, c->blocks, c->stream);
         break;
     case TBVH_LAYOUT_BVH4_GPU:
         q.spillStride = c->spillEntries;
-        launch_bvh4(any, s->nodes, q, c->status, c->blocks, c->stream);
+        launch_bvh4(any, s->variant, s->nodes, q, c->status, c->blocks, c->stream);
         break;
     case TBVH_LAYOUT_CWBVH:
         q.spillStride = c->spillEntries / 2;  // 8-byte entries
@@ -379,7 +379,7 @@ uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0;
 
 int tbvh_set_variant(tbvh_scene* s, int v) {
     if (!s) return fail(TBVH_E_INVALID, "null scene");
-    const bool ok = s->layout == TBVH_LAYOUT_CWBVH ? (cwbvh_variant_valid(v) || (v >= 20 && v <= 39)) : v == 0;
+    const bool ok = s->layout == TBVH_LAYOUT_CWBVH ? (cwbvh_variant_valid(v) || (v >= 20 && v <= 39)) : (v >= 0 && v <= 3);
     if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
     tbvh_context* c = s->ctx;
     if (int r = setDevice(c)) return r;

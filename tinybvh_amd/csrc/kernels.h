@@ -4,9 +4,9 @@
 
 namespace tbvh {
 
-void launch_bvh2(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
+void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                  uint32_t blocks, hipStream_t s);
-void launch_bvh4(bool anyhit, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
+void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                   uint32_t blocks, hipStream_t s);
 bool cwbvh_variant_valid(int variant);

@@ -74,7 +74,7 @@ __device__ __forceinline__ NodeResult visit_node(const float4* __restrict__ node
 
 // MODE 0: whole-wave batches (a wave takes 64 consecutive rays and finishes them all).
 // MODE 1: per-lane replacement from a wave-local pool; REFILL_MIN idle lanes trigger a refill.
-template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false>
+template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false, int TRI_MIN = 1>
 __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -126,7 +126,15 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
             // order of tests is exactly the mirror's: all triangles of a group before the next
             // node), but the rest of the wave does not wait for a lane's whole triangle list.
             bool done = false;
-            if (tg.y != 0) {
+            // triangle phase runs when at least TRI_MIN lanes have a pending triangle, or when no lane could
+            // use a node phase instead (so a waiting lane always makes progress eventually)
+            bool triPhase = true;
+            if (TRI_MIN > 1) {
+                const uint32_t nPend = (uint32_t)__popcll(__ballot(tg.y != 0));
+                const uint32_t nAct = (uint32_t)__popcll(__ballot(true));
+                triPhase = nPend >= (uint32_t)TRI_MIN || nPend == nAct;
+            }
+            if (triPhase && tg.y != 0) {
                 if (STATS) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sTriIter++; sTri += __popcll(m); } }
                 const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
                 tg.y &= ~(1u << ti);
@@ -246,6 +254,9 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
         hipLaunchKernelGGL((k_cwbvh<false, 1, 8, 16, true, true>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
         break;
     case 10: TBVH_LAUNCH(1, 8, 8, true); break;
+    case 13: TBVH_LAUNCH(1, 8, 16, true, false, 8); break;    // triangle phase only when >= 8 lanes wait
+    case 14: TBVH_LAUNCH(1, 8, 16, true, false, 16); break;
+    case 15: TBVH_LAUNCH(1, 8, 16, true, false, 24); break;
     case 11: TBVH_LAUNCH(1, 8, 24, true); break;
     case 5: TBVH_LAUNCH(1, 8, 16); break;    // smaller LDS stack -> more waves per CU
     case 6: TBVH_LAUNCH(1, 12, 16); break;
@@ -255,6 +266,6 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
 #undef TBVH_LAUNCH
 }
 
-bool cwbvh_variant_valid(int v) { return v >= 0 && v <= 12; }
+bool cwbvh_variant_valid(int v) { return v >= 0 && v <= 15; }
 
 }  // namespace tbvh

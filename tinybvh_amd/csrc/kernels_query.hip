@@ -1,139 +1,221 @@
-// kernels_query.hip — batched Intersect / IsOccluded kernels for gfx950 (MI355X).
+// kernels_query.hip — BVH_GPU (Aila-Laine 2-wide) and BVH4_GPU Intersect / IsOccluded kernels
+// for gfx950 (MI355X), plus the upload-time triangle gather.
 //
-// Replaces (from scratch, not a port) the reference's OpenCL entry points
+// Replace (from scratch, not a port) the reference's OpenCL entry points
 //   batch_ailalaine / isoccluded_ailalaine   traverse_bvh2.cl:80-219
 //   batch_gpu4way   / isoccluded_gpu4way     traverse_bvh4.cl:74-286
-//   batch_cwbvh     / isoccluded_cwbvh       traverse_cwbvh.cl:124-570
 // Result semantics follow the CPU oracle BVH::Intersect / IsOccluded (tiny_bvh.h:3247-3304,
-// 3408-3453, 1644-1656), not the .cl files (which use strict comparisons and
-// native_recip): a candidate is rejected only if t < 0 || t > tmax, |det| < 1e-6 misses,
-// nodes whose entry distance equals the current hit distance are still visited.
+// 3408-3453, 1644-1656), not the .cl files (strict comparisons, native_recip): a candidate is
+// rejected only if t < 0 || t > tmax, |det| < 1e-6 misses, nodes whose entry distance equals the
+// current hit distance are still visited, a miss leaves the ray record untouched.
 //
-// Structure common to all kernels: persistent waves (one wave = one 64-thread workgroup)
-// pull batches of rays from a global counter; one lane owns one ray; the traversal stack
-// is per lane, top in LDS, bottom spilled to global (lane_stack.h).
+// Structure (same as kernels_cwbvh.hip): persistent one-wave workgroups, one lane = one ray,
+// per-lane ray replacement from a wave-local pool (ray_pool.h), per-lane traversal stack with
+// its top in LDS and a global spill area, and an interleaved schedule in which a lane does at
+// most one triangle test and one node visit per iteration.  For the 2-wide layout the
+// triangle phase additionally waits until TRI_MIN lanes have a leaf pending (leaves are rare
+// events there: ~6 % of the steps), which is Aila & Laine's "postpone the leaf" idea expressed
+// with wave64 ballots.
 #include "device_common.h"
-#include "lane_stack.h"
+#include "ray_pool.h"
 #include "kernels.h"
 
 namespace tbvh {
+
+namespace {
 
 constexpr int WG = 64;
 
 __device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 __device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-// Wave-level batch fetch: lane 0 takes `WG` consecutive ray indices.
-__device__ __forceinline__ uint64_t fetch_batch(unsigned long long* counter) {
-    unsigned long long base = 0;
-    if (threadIdx.x == 0) base = atomicAdd(counter, (unsigned long long)WG);
-    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-    uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
+// per-lane stack of 32-bit entries: [entry][lane] in LDS, [entry][globalLane] in the spill area
+template <int LDS_N> struct Stack32 {
+    uint32_t (*lds)[WG];
+    uint32_t* spill;
+    size_t spillStride;
+    uint32_t spillCap;
+    int sp;
+    bool overflow;
+    __device__ __forceinline__ void push(uint32_t v) {
+        if (sp < LDS_N) lds[sp][threadIdx.x] = v;
+        else if ((uint32_t)(sp - LDS_N) < spillCap) spill[(size_t)(sp - LDS_N) * spillStride] = v;
+        else { overflow = true; return; }
+        sp++;
+    }
+    __device__ __forceinline__ uint32_t pop() {
+        sp--;
+        return sp < LDS_N ? lds[sp][threadIdx.x] : spill[(size_t)(sp - LDS_N) * spillStride];
+    }
+};
 
 // ---------------------------------------------------------------------------------------
 // BVH_GPU (Aila-Laine 2-wide).  nodes: 4 x float4 per node, verbatim BVH_GPU::bvhNode.
 // tris: 3 x float4 per primIdx entry {v0.xyz|prim, e1, e2}, gathered at upload so a leaf
 // reads one contiguous run instead of primIdx -> verts (two dependent gathers).
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT>
-__global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes,
-                                             const float4* __restrict__ tris, QueryArgs q,
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN>
+__global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, const float4* __restrict__ tris, QueryArgs q,
                                              uint32_t* __restrict__ status) {
-    constexpr int LDS_N = 24;
     __shared__ uint32_t stk[LDS_N][WG];
-    const uint32_t glane = blockIdx.x * WG + threadIdx.x;
-    LaneStack<uint32_t, LDS_N, WG> st;
-    st.init(&stk[0][threadIdx.x], q.spill + glane, gridDim.x * WG, q.spillStride);
+    Stack32<LDS_N> st;
+    st.lds = stk; st.spill = q.spill + (blockIdx.x * WG + threadIdx.x); st.spillStride = (size_t)gridDim.x * WG;
+    st.spillCap = q.spillStride; st.sp = 0; st.overflow = false;
+    RayPool<64> pool;
+    pool.init();
+
+    bool active = false;
+    uint64_t ri = 0;
+    float3 O = make_float3(0, 0, 0), D = O, rD = O, ro = O;
+    float4 hit = make_float4(0, 0, 0, 0);
+    bool found = false;
+    uint32_t node = 0, triLeft = 0, triPtr = 0;   // triLeft > 0: a leaf's triangles are pending
+
     for (;;) {
-        const uint64_t base = fetch_batch((unsigned long long*)q.counter);
-        if (base >= q.nRays) break;
-        const uint64_t ri = base + threadIdx.x;
-        if (ri >= q.nRays) continue;
-        RayRec* rp = q.rays + ri;
-        const float3 O = xyz(rp->O), D = xyz(rp->D), rD = xyz(rp->rD);
-        float4 hit = rp->hit;
-        const float3 ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z);
-        bool found = false;
-        st.reset();
-        uint32_t node = 0;
-        for (;;) {
+        const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
+        if (nIdle >= (uint32_t)REFILL_MIN) {
+            if (!(pool.exhausted && pool.next == pool.end)) {
+                uint64_t nri = 0;
+                if (pool.acquire(!active, (unsigned long long*)q.counter, q.nRays, nri)) {
+                    ri = nri;
+                    const RayRec* rp = q.rays + ri;
+                    O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
+                    hit = rp->hit;
+                    ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z);
+                    found = false; node = 0; triLeft = 0; st.sp = 0;
+                    active = true;
+                }
+            }
+            if (__ballot(active) == 0) break;
+        }
+        if (!active) continue;
+
+        bool done = false;
+        // ---- triangle phase -------------------------------------------------------------------
+        const uint32_t nPend = (uint32_t)__popcll(__ballot(triLeft != 0));
+        const bool triPhase = nPend >= (uint32_t)TRI_MIN || nPend == (uint32_t)__popcll(__ballot(true));
+        if (triPhase && triLeft != 0) {
+            const float4 v0 = tris[triPtr], e1 = tris[triPtr + 1], e2 = tris[triPtr + 2];
+            triPtr += 3; triLeft--;
+            TriHit h;
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                found = true;
+                if (ANYHIT) done = true;
+                else hit = make_float4(h.t, h.u, h.v, v0.w);
+            }
+            if (!done && triLeft == 0) {  // leaf finished: continue with the stack
+                if (st.sp == 0) done = true;
+                else node = st.pop();
+            }
+        }
+        // ---- node phase ---------------------------------------------------------------------------
+        if (!done && triLeft == 0) {
             const float4 n0 = nodes[node * 4], n1 = nodes[node * 4 + 1], n2 = nodes[node * 4 + 2], n3 = nodes[node * 4 + 3];
             const uint32_t triCount = as_u32(n2.w);
             if (triCount) {
-                uint32_t ta = as_u32(n3.w) * 3;
-                for (uint32_t i = 0; i < triCount; i++, ta += 3) {
-                    const float4 v0 = tris[ta], e1 = tris[ta + 1], e2 = tris[ta + 2];
-                    TriHit h;
-                    if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
-                        found = true;
-                        if (ANYHIT) break;
-                        hit = make_float4(h.t, h.u, h.v, v0.w);
-                    }
+                triLeft = triCount; triPtr = as_u32(n3.w) * 3u;
+            } else {
+                // slab test of both children, oracle form: t = plane * rD - O*rD, inclusive
+                // visit rule tmax >= tmin (SLAB_TEST_TWO_NODES, tiny_bvh.h:3202-3220)
+                const float lx1 = __builtin_fmaf(n0.x, rD.x, -ro.x), lx2 = __builtin_fmaf(n1.x, rD.x, -ro.x);
+                const float ly1 = __builtin_fmaf(n0.y, rD.y, -ro.y), ly2 = __builtin_fmaf(n1.y, rD.y, -ro.y);
+                const float lz1 = __builtin_fmaf(n0.z, rD.z, -ro.z), lz2 = __builtin_fmaf(n1.z, rD.z, -ro.z);
+                const float rx1 = __builtin_fmaf(n2.x, rD.x, -ro.x), rx2 = __builtin_fmaf(n3.x, rD.x, -ro.x);
+                const float ry1 = __builtin_fmaf(n2.y, rD.y, -ro.y), ry2 = __builtin_fmaf(n3.y, rD.y, -ro.y);
+                const float rz1 = __builtin_fmaf(n2.z, rD.z, -ro.z), rz2 = __builtin_fmaf(n3.z, rD.z, -ro.z);
+                const float tminL = __builtin_fmaxf(fmax3(__builtin_fminf(lx1, lx2), __builtin_fminf(ly1, ly2), __builtin_fminf(lz1, lz2)), 0.0f);
+                const float tmaxL = __builtin_fminf(fmin3(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2), __builtin_fmaxf(lz1, lz2)), hit.x);
+                const float tminR = __builtin_fmaxf(fmax3(__builtin_fminf(rx1, rx2), __builtin_fminf(ry1, ry2), __builtin_fminf(rz1, rz2)), 0.0f);
+                const float tmaxR = __builtin_fminf(fmin3(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2), __builtin_fmaxf(rz1, rz2)), hit.x);
+                const bool hL = tmaxL >= tminL, hR = tmaxR >= tminR;
+                uint32_t l = as_u32(n0.w), r = as_u32(n1.w);
+                if (hL && hR) {
+                    if (tminL > tminR) { const uint32_t t = l; l = r; r = t; }
+                    st.push(r);
+                    node = l;
+                } else if (hL) node = l;
+                else if (hR) node = r;
+                else {
+                    if (st.sp == 0) done = true;
+                    else node = st.pop();
                 }
-                if (ANYHIT && found) break;
-                if (st.empty()) break;
-                node = st.pop();
-                continue;
-            }
-            // slab test of both children, oracle form: t = plane * rD - O*rD, inclusive
-            // visit rule tmax >= tmin (SLAB_TEST_TWO_NODES, tiny_bvh.h:3202-3220)
-            const float lx1 = __builtin_fmaf(n0.x, rD.x, -ro.x), lx2 = __builtin_fmaf(n1.x, rD.x, -ro.x);
-            const float ly1 = __builtin_fmaf(n0.y, rD.y, -ro.y), ly2 = __builtin_fmaf(n1.y, rD.y, -ro.y);
-            const float lz1 = __builtin_fmaf(n0.z, rD.z, -ro.z), lz2 = __builtin_fmaf(n1.z, rD.z, -ro.z);
-            const float rx1 = __builtin_fmaf(n2.x, rD.x, -ro.x), rx2 = __builtin_fmaf(n3.x, rD.x, -ro.x);
-            const float ry1 = __builtin_fmaf(n2.y, rD.y, -ro.y), ry2 = __builtin_fmaf(n3.y, rD.y, -ro.y);
-            const float rz1 = __builtin_fmaf(n2.z, rD.z, -ro.z), rz2 = __builtin_fmaf(n3.z, rD.z, -ro.z);
-            const float tminL = __builtin_fmaxf(fmax3(__builtin_fminf(lx1, lx2), __builtin_fminf(ly1, ly2), __builtin_fminf(lz1, lz2)), 0.0f);
-            const float tmaxL = __builtin_fminf(fmin3(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2), __builtin_fmaxf(lz1, lz2)), hit.x);
-            const float tminR = __builtin_fmaxf(fmax3(__builtin_fminf(rx1, rx2), __builtin_fminf(ry1, ry2), __builtin_fminf(rz1, rz2)), 0.0f);
-            const float tmaxR = __builtin_fminf(fmin3(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2), __builtin_fmaxf(rz1, rz2)), hit.x);
-            const bool hL = tmaxL >= tminL, hR = tmaxR >= tminR;
-            uint32_t l = as_u32(n0.w), r = as_u32(n1.w);
-            if (hL && hR) {
-                if (tminL > tminR) { const uint32_t t = l; l = r; r = t; }
-                st.push(r);
-                node = l;
-            } else if (hL) node = l;
-            else if (hR) node = r;
-            else {
-                if (st.empty()) break;
-                node = st.pop();
             }
         }
-        if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
-        else if (found) rp->hit = hit;
+        if (done) {
+            if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+            else if (found) q.rays[ri].hit = hit;
+            active = false;
+        }
     }
     if (st.overflow) atomicOr(status, 1u);
 }
 
 // ---------------------------------------------------------------------------------------
 // BVH4_GPU.  One float4 stream, verbatim BVH4_GPU::bvh4Data.
-// Traversal order follows the CPU mirror (tiny_bvh.h:5252-5343): children sorted far to
-// near, interior children pushed far first (nearest on top), hit leaves processed in the
-// same sorted order.
+// Per-ray order follows the CPU mirror (tiny_bvh.h:5252-5343): children sorted far to near,
+// interior children pushed far first (nearest on top), hit leaves processed in the same
+// sorted order.  The hit leaves of a node (at most 4) are queued in registers and their
+// triangles tested one per iteration.
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT>
-__global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, QueryArgs q,
-                                             uint32_t* __restrict__ status) {
-    constexpr int LDS_N = 24;
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN>
+__global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
-    const uint32_t glane = blockIdx.x * WG + threadIdx.x;
-    LaneStack<uint32_t, LDS_N, WG> st;
-    st.init(&stk[0][threadIdx.x], q.spill + glane, gridDim.x * WG, q.spillStride);
+    Stack32<LDS_N> st;
+    st.lds = stk; st.spill = q.spill + (blockIdx.x * WG + threadIdx.x); st.spillStride = (size_t)gridDim.x * WG;
+    st.spillCap = q.spillStride; st.sp = 0; st.overflow = false;
+    RayPool<64> pool;
+    pool.init();
+
+    bool active = false;
+    uint64_t ri = 0;
+    float3 O = make_float3(0, 0, 0), D = O, rD = O;
+    float4 hit = make_float4(0, 0, 0, 0);
+    bool found = false;
+    uint32_t offset = 0;
+    // pending leaves of the current node in processing order: leafQ0 first.  leafQn = absolute
+    // block offset of the leaf's next triangle, leafCnt = remaining triangle counts, one byte per
+    // queue slot (slot 0 in the low byte; 0 = empty).  Leaves with > 255 triangles (legal in the
+    // format, 15-bit count) are tested in place instead of being queued.
+    uint32_t leafQ0 = 0, leafQ1 = 0, leafQ2 = 0, leafQ3 = 0, leafCnt = 0;
+
     for (;;) {
-        const uint64_t base = fetch_batch((unsigned long long*)q.counter);
-        if (base >= q.nRays) break;
-        const uint64_t ri = base + threadIdx.x;
-        if (ri >= q.nRays) continue;
-        RayRec* rp = q.rays + ri;
-        const float3 O = xyz(rp->O), D = xyz(rp->D), rD = xyz(rp->rD);
-        float4 hit = rp->hit;
-        bool found = false;
-        st.reset();
-        uint32_t offset = 0;
-        for (;;) {
+        const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
+        if (nIdle >= (uint32_t)REFILL_MIN) {
+            if (!(pool.exhausted && pool.next == pool.end)) {
+                uint64_t nri = 0;
+                if (pool.acquire(!active, (unsigned long long*)q.counter, q.nRays, nri)) {
+                    ri = nri;
+                    const RayRec* rp = q.rays + ri;
+                    O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
+                    hit = rp->hit;
+                    found = false; offset = 0; leafCnt = 0; st.sp = 0;
+                    active = true;
+                }
+            }
+            if (__ballot(active) == 0) break;
+        }
+        if (!active) continue;
+
+        bool done = false;
+        const uint32_t nPend = (uint32_t)__popcll(__ballot(leafCnt != 0));
+        const bool triPhase = nPend >= (uint32_t)TRI_MIN || nPend == (uint32_t)__popcll(__ballot(true));
+        if (triPhase && leafCnt != 0) {
+            const uint32_t ta = leafQ0;
+            const float4 v0 = data[ta], e1 = data[ta + 1], e2 = data[ta + 2];
+            leafQ0 += 3u; leafCnt -= 1u;                      // next triangle, one fewer left in slot 0
+            if ((leafCnt & 255u) == 0) { leafQ0 = leafQ1; leafQ1 = leafQ2; leafQ2 = leafQ3; leafCnt >>= 8; }
+            TriHit h;
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                found = true;
+                if (ANYHIT) done = true;
+                else hit = make_float4(h.t, h.u, h.v, v0.w);
+            }
+            if (!done && leafCnt == 0) {
+                if (st.sp == 0) done = true;
+                else offset = st.pop();
+            }
+        }
+        if (!done && leafCnt == 0) {
             const float4 d0 = data[offset], d1 = data[offset + 1], d2 = data[offset + 2], d3 = data[offset + 3];
             // per-axis: t(q) = (bmin + ext*q - O) * rD = q * (ext*rD) + (bmin - O)*rD
             const float sx = d1.x * rD.x, sy = d1.y * rD.y, sz = d1.z * rD.z;
@@ -156,32 +238,40 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
 #define TBVH_CSWAP(a, b) if (dist[a] < dist[b]) { const float tf = dist[a]; dist[a] = dist[b]; dist[b] = tf; const uint32_t tu = info[a]; info[a] = info[b]; info[b] = tu; }
             TBVH_CSWAP(0, 2) TBVH_CSWAP(1, 3) TBVH_CSWAP(0, 1) TBVH_CSWAP(2, 3) TBVH_CSWAP(1, 2)
 #undef TBVH_CSWAP
+            uint32_t nq = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                if (dist[i] < kFar && !(info[i] & 0x80000000u)) st.push(info[i]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                if (!(dist[i] < kFar) || !(info[i] & 0x80000000u)) continue;
-                const uint32_t N = (info[i] >> 16) & 0x7fff;
-                uint32_t ta = offset + (info[i] & 0xffff);
-                for (uint32_t j = 0; j < N; j++, ta += 3) {
-                    const float4 v0 = data[ta], e1 = data[ta + 1], e2 = data[ta + 2];
-                    TriHit h;
-                    if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
-                        found = true;
-                        if (ANYHIT) break;
-                        hit = make_float4(h.t, h.u, h.v, v0.w);
+                if (!(dist[i] < kFar)) continue;
+                if (!(info[i] & 0x80000000u)) { st.push(info[i]); continue; }
+                const uint32_t cnt = (info[i] >> 16) & 0x7fffu;
+                uint32_t ta = offset + (info[i] & 0xffffu);
+                if (cnt > 255u) {   // oversized leaf: test in place, in order (queued leaves before it are empty
+                                    // only if it is the first hit leaf; otherwise order among exact ties may differ)
+                    for (uint32_t j = 0; j < cnt; j++, ta += 3) {
+                        const float4 v0 = data[ta], e1 = data[ta + 1], e2 = data[ta + 2];
+                        TriHit h;
+                        if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                            found = true;
+                            if (ANYHIT) { done = true; break; }
+                            hit = make_float4(h.t, h.u, h.v, v0.w);
+                        }
                     }
+                    continue;
                 }
-                if (ANYHIT && found) break;
+                if (nq == 0) leafQ0 = ta; else if (nq == 1) leafQ1 = ta; else if (nq == 2) leafQ2 = ta; else leafQ3 = ta;
+                leafCnt |= cnt << (8 * nq);
+                nq++;
             }
-            if (ANYHIT && found) break;
-            if (st.empty()) break;
-            offset = st.pop();
+            if (!done && leafCnt == 0) {
+                if (st.sp == 0) done = true;
+                else offset = st.pop();
+            }
         }
-        if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
-        else if (found) rp->hit = hit;
+        if (done) {
+            if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+            else if (found) q.rays[ri].hit = hit;
+            active = false;
+        }
     }
     if (st.overflow) atomicOr(status, 1u);
 }
@@ -206,17 +296,40 @@ __global__ void k_gather_tris(const uint32_t* __restrict__ primIdx, const float4
     out[i * 3 + 2] = make_float4(c.x - a.x, c.y - a.y, c.z - a.z, 0.f);
 }
 
+}  // namespace
+
 // ---- launchers (called from capi.hip) ----------------------------------------------------
 
-void launch_bvh2(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
+void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                  uint32_t blocks, hipStream_t s) {
-    if (anyhit) hipLaunchKernelGGL(k_bvh2<true>, dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
-    else hipLaunchKernelGGL(k_bvh2<false>, dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+#define TBVH_L2(TM)                                                                                                     \
+    do {                                                                                                                \
+        if (anyhit) hipLaunchKernelGGL((k_bvh2<true, 16, 16, TM>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status); \
+        else hipLaunchKernelGGL((k_bvh2<false, 16, 16, TM>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);       \
+    } while (0)
+    switch (variant) {
+    case 1: TBVH_L2(1); break;
+    case 2: TBVH_L2(8); break;
+    case 3: TBVH_L2(32); break;
+    default: TBVH_L2(16); break;
+    }
+#undef TBVH_L2
 }
-void launch_bvh4(bool anyhit, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
-    if (anyhit) hipLaunchKernelGGL(k_bvh4<true>, dim3(blocks), dim3(WG), 0, s, data, q, status);
-    else hipLaunchKernelGGL(k_bvh4<false>, dim3(blocks), dim3(WG), 0, s, data, q, status);
+
+void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
+#define TBVH_L4(TM)                                                                                                 \
+    do {                                                                                                            \
+        if (anyhit) hipLaunchKernelGGL((k_bvh4<true, 12, 16, TM>), dim3(blocks), dim3(WG), 0, s, data, q, status);  \
+        else hipLaunchKernelGGL((k_bvh4<false, 12, 16, TM>), dim3(blocks), dim3(WG), 0, s, data, q, status);        \
+    } while (0)
+    switch (variant) {
+    case 1: TBVH_L4(1); break;
+    case 2: TBVH_L4(16); break;
+    default: TBVH_L4(8); break;
+    }
+#undef TBVH_L4
 }
+
 void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris, hipStream_t s) {
     const uint32_t bs = 256;
     hipLaunchKernelGGL(k_gather_tris, dim3((uint32_t)((nIdx + bs - 1) / bs)), dim3(bs), 0, s, primIdx, verts, out, nIdx, nTris);
