@@ -120,10 +120,16 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ) {
     q.rays = d_rays; q.nRays = n; q.occluded = d_occ;
     q.spill = c->spill; q.counter = (uint32_t*)c->counter;
     q.stats = c->counter + 8;
+    // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
+    // (about one workgroup per 256 rays, measured best for 1 M-ray launches) so every wave still
+    // has a few ray replacements' worth of work
+    uint64_t want = (n + 255) / 256;
+    const uint32_t lo = (uint32_t)c->numCUs * 4u;
+    const uint32_t blocks = (uint32_t)(want < lo ? lo : (want > c->blocks ? c->blocks : want));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (s->isTlas) {
         q.spillStride = c->spillEntries / 2;
-        launch_tlas(any, s->blasLayout, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, c->blocks, c->stream);
+        launch_tlas(any, s->blasLayout, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         c->timed = true;
@@ -132,17 +138,17 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ) {
     switch (s->layout) {
     case TBVH_LAYOUT_BVH_GPU:
         q.spillStride = c->spillEntries;
-        launch_bvh2(any, s->variant, s->nodes, s->tris, q, c->status, c->blocks, c->stream);
+        launch_bvh2(any, s->variant, s->nodes, s->tris, q, c->status, blocks, c->stream);
         break;
     case TBVH_LAYOUT_BVH4_GPU:
         q.spillStride = c->spillEntries;
-        launch_bvh4(any, s->variant, s->nodes, q, c->status, c->blocks, c->stream);
+        launch_bvh4(any, s->variant, s->nodes, q, c->status, blocks, c->stream);
         break;
     case TBVH_LAYOUT_CWBVH:
         q.spillStride = c->spillEntries / 2;  // 8-byte entries
         if (s->variant >= 30) launch_cwbvh_c(any, s->variant, s->nodesP, s->tris, s->nNodes, q, c->status, (uint32_t)c->numCUs, c->stream);
-        else if (s->variant >= 20) launch_cwbvh_h(any, s->variant, s->nodesH, s->tris, q, c->status, c->blocks, c->stream);
-        else launch_cwbvh(any, s->variant, s->nodes, s->tris, q, c->status, c->blocks, c->stream);
+        else if (s->variant >= 20) launch_cwbvh_h(any, s->variant, s->nodesH, s->tris, q, c->status, blocks, c->stream);
+        else launch_cwbvh(any, s->variant, s->nodes, s->tris, q, c->status, blocks, c->stream);
         break;
     default:
         return fail(TBVH_E_INVALID, "scene layout %d has no query kernel", s->layout);

@@ -72,9 +72,54 @@ __device__ __forceinline__ NodeResult visit_node(const float4* __restrict__ node
     return r;
 }
 
+// Same test with the 48 plane FMAs issued as 24 v_pk_fma_f32 (two children per instruction,
+// the ray-dependent scale and offset broadcast through op_sel).  tools/ubench/valu_rate.hip:
+// v_pk_fma_f32 5.6 cycles for two FMAs vs 2 x 4.1 for v_fma_f32.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ NodeResult visit_node_pk(const float4* __restrict__ nodes, uint32_t nodeIdx, float3 O,
+                                                    float3 rD, float tmax, uint32_t octinv4) {
+    const float4* np = nodes + nodeIdx * 5u;
+    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+    const uint32_t ew = as_u32(n0.w);
+    const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
+    const float ox = (n0.x - O.x) * rD.x, oy = (n0.y - O.y) * rD.y, oz = (n0.z - O.z) * rD.z;
+    const v2f ax2 = {ax, ax}, ay2 = {ay, ay}, az2 = {az, az}, ox2 = {ox, ox}, oy2 = {oy, oy}, oz2 = {oz, oz};
+    uint32_t hitmask = 0;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const uint32_t meta4 = half ? as_u32(n1.w) : as_u32(n1.z);
+        const uint32_t inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+        const uint32_t imask4 = sext_s8x4(inner4 << 3);
+        const uint32_t bitidx4 = (meta4 ^ (octinv4 & imask4)) & 0x1F1F1F1Fu;
+        const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;
+        const uint32_t qlx = half ? as_u32(n2.y) : as_u32(n2.x), qhx = half ? as_u32(n3.w) : as_u32(n3.z);
+        const uint32_t qly = half ? as_u32(n2.w) : as_u32(n2.z), qhy = half ? as_u32(n4.y) : as_u32(n4.x);
+        const uint32_t qlz = half ? as_u32(n3.y) : as_u32(n3.x), qhz = half ? as_u32(n4.w) : as_u32(n4.z);
+        const uint32_t lox = rD.x < 0 ? qhx : qlx, hix = rD.x < 0 ? qlx : qhx;
+        const uint32_t loy = rD.y < 0 ? qhy : qly, hiy = rD.y < 0 ? qly : qhy;
+        const uint32_t loz = rD.z < 0 ? qhz : qlz, hiz = rD.z < 0 ? qlz : qhz;
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            const int s0 = 8 * i, s1 = 8 * i + 8;
+#define TBVH_Q2(w) v2f{(float)(((w) >> s0) & 255), (float)(((w) >> s1) & 255)}
+            const v2f tnx = __builtin_elementwise_fma(TBVH_Q2(lox), ax2, ox2), tfx = __builtin_elementwise_fma(TBVH_Q2(hix), ax2, ox2);
+            const v2f tny = __builtin_elementwise_fma(TBVH_Q2(loy), ay2, oy2), tfy = __builtin_elementwise_fma(TBVH_Q2(hiy), ay2, oy2);
+            const v2f tnz = __builtin_elementwise_fma(TBVH_Q2(loz), az2, oz2), tfz = __builtin_elementwise_fma(TBVH_Q2(hiz), az2, oz2);
+#undef TBVH_Q2
+            const float cmin0 = __builtin_fmaxf(fmax3(tnx.x, tny.x, tnz.x), 0.0f), cmax0 = __builtin_fminf(fmin3(tfx.x, tfy.x, tfz.x), tmax);
+            const float cmin1 = __builtin_fmaxf(fmax3(tnx.y, tny.y, tnz.y), 0.0f), cmax1 = __builtin_fminf(fmin3(tfx.y, tfy.y, tfz.y), tmax);
+            if (cmin0 <= cmax0) hitmask |= ((bits4 >> s0) & 255u) << ((bitidx4 >> s0) & 255u);
+            if (cmin1 <= cmax1) hitmask |= ((bits4 >> s1) & 255u) << ((bitidx4 >> s1) & 255u);
+        }
+    }
+    NodeResult r;
+    r.childBase = as_u32(n1.x); r.triBase = as_u32(n1.y); r.hitmask = hitmask; r.imask = ew >> 24;
+    return r;
+}
+
 // MODE 0: whole-wave batches (a wave takes 64 consecutive rays and finishes them all).
 // MODE 1: per-lane replacement from a wave-local pool; REFILL_MIN idle lanes trigger a refill.
-template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false, int TRI_MIN = 1>
+template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false, int TRI_MIN = 1, bool PKFMA = false>
 __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -161,7 +206,8 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
                         if (ng.y > 0x00FFFFFFu) st.push(ng);
                         const uint32_t slot = (bit - 24u) ^ oct;
                         const uint32_t rel = __popc(imask & ~(0xFFFFFFFFu << slot));
-                        const NodeResult r = visit_node(nodes, cbase + rel, O, rD, hit.x, octinv4);
+                        const NodeResult r = PKFMA ? visit_node_pk(nodes, cbase + rel, O, rD, hit.x, octinv4)
+                                                   : visit_node(nodes, cbase + rel, O, rD, hit.x, octinv4);
                         ng.x = r.childBase; tg.x = r.triBase;
                         ng.y = (r.hitmask & 0xFF000000u) | r.imask;
                         tg.y = r.hitmask & 0x00FFFFFFu;
@@ -254,6 +300,7 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
         hipLaunchKernelGGL((k_cwbvh<false, 1, 8, 16, true, true>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
         break;
     case 10: TBVH_LAUNCH(1, 8, 8, true); break;
+    case 16: TBVH_LAUNCH(1, 8, 16, true, false, 1, true); break;  // packed plane FMAs
     case 13: TBVH_LAUNCH(1, 8, 16, true, false, 8); break;    // triangle phase only when >= 8 lanes wait
     case 14: TBVH_LAUNCH(1, 8, 16, true, false, 16); break;
     case 15: TBVH_LAUNCH(1, 8, 16, true, false, 24); break;
@@ -266,6 +313,6 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
 #undef TBVH_LAUNCH
 }
 
-bool cwbvh_variant_valid(int v) { return v >= 0 && v <= 15; }
+bool cwbvh_variant_valid(int v) { return v >= 0 && v <= 16; }
 
 }  // namespace tbvh
