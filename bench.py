@@ -10,9 +10,9 @@ stand-in), BVH8_CWBVH layout, per GPU and per step:
     16 M diffuse rays   Intersect   (incoherent: bounce depths 1, 2 and 3 in equal thirds)
     16 M shadow rays    IsOccluded  (from the primary hit points toward a point light)
 `value` = (primary + diffuse rays of ALL ranks) / wall time of the K timed steps, where a step
-runs the two Intersect passes plus the two 16-byte-per-ray hit re-arm kernels that make every
-step start from tmax again; the shadow pass is timed separately (HIP events) and reported in
-`detail`.  Rays are generated on the device before the timed region and
+runs the two Intersect passes through tbvh_intersect_device_fresh (every ray starts from
+tmax = 1e30 and every hit record is written, so each step does the full work of a new frame);
+the shadow pass is timed separately (HIP events) and reported in `detail`.  Rays are generated on the device before the timed region and
 are resident in HBM.  N > 1: the BVH is replicated, every rank traces its own batch
 (different camera / RNG seed), no data-path collective: weak scaling.
 
@@ -52,7 +52,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("TBVH_BENCH_FORCE_DIST"))  # the env knob exercises the RCCL path on one GPU
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -62,7 +63,7 @@ def main():
     from tinybvh_amd import scenes
 
     def sync_all():
-        if world > 1:
+        if use_dist:
             import torch
             dist.barrier()
             torch.cuda.synchronize()
@@ -108,12 +109,12 @@ def main():
     kern_ms = {"primary": [], "diffuse": [], "shadow": []}
 
     def step(record: bool):
-        ctx.reset_hits(d_prim, n)
-        sc.intersect_device(d_prim, n)
+        # "fresh" = re-arm (hit = {1e30,0,0,0}) fused into the traversal kernel: every step traces
+        # every ray from scratch and writes every hit record, like a new frame would
+        sc.intersect_device_fresh(d_prim, n, 1e30)
         if record:
             kern_ms["primary"].append(ctx.time_last_ms())
-        ctx.reset_hits(d_diff, n)
-        sc.intersect_device(d_diff, n)
+        sc.intersect_device_fresh(d_diff, n, 1e30)
         if record:
             kern_ms["diffuse"].append(ctx.time_last_ms())
 
@@ -131,7 +132,7 @@ def main():
         step(True)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -210,7 +211,7 @@ def main():
         }
         print(json.dumps(out), flush=True)
     sync_all()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     ctx.close()
 

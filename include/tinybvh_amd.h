@@ -134,6 +134,11 @@ int tbvh_occluded(tbvh_scene* scene, const void* rays, uint64_t n_rays,
 int tbvh_intersect_device(tbvh_scene* scene, void* d_rays64, uint64_t n_rays);
 int tbvh_occluded_device(tbvh_scene* scene, const void* d_rays64, uint64_t n_rays,
                          uint8_t* d_occluded);
+/* tbvh_reset_hits_device(rays, n, tmax) fused into tbvh_intersect_device: every ray starts from
+ * hit = {tmax, 0, 0, 0} whatever its record holds (what constructing the Ray again would give,
+ * tiny_bvh.h:695-703) and its record is always written (a miss stores {tmax, 0, 0, 0}).  For
+ * callers that re-trace a resident batch, e.g. one frame after another. */
+int tbvh_intersect_device_fresh(tbvh_scene* scene, void* d_rays64, uint64_t n_rays, float tmax);
 
 /* Re-arm a device ray batch for another Intersect: hit = {tmax, 0, 0, 0} for every record
  * (what re-running the tinybvh::Ray constructor's hit.t = t would do, tiny_bvh.h:700). */

@@ -189,3 +189,29 @@ def test_reference_built_blobs(ctx, oracle, reference, atrium_small, layout, hq)
     check_ref(got, want)
     rnd = R.random_rays(30_000, verts[:, :3].min(0), verts[:, :3].max(0), seed=4)
     check_ref(sc.Intersect(rnd.copy()), rs.intersect(1, rnd))
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_fresh_entry_point_equals_reset_plus_intersect(ctx, soup, layout):
+    """tbvh_intersect_device_fresh = tbvh_reset_hits_device + tbvh_intersect_device, fused."""
+    sc = upload(ctx, layout, soup)
+    rays = R.random_rays(10_000, (0, 0, 0), (10, 10, 10), seed=31)
+    n = rays.shape[0]
+    d = ctx.malloc(n * 64)
+    ctx.to_device(d, rays)
+    sc.intersect_device(d, n)
+    a = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(a, d)
+    # trace the already-traced batch again, fresh: same answer, and misses carry {tmax, 0, 0, 0}
+    stale = a.copy(); stale["t"] = 0.5; stale["prim"] = 77
+    ctx.to_device(d, stale)
+    sc.intersect_device_fresh(d, n, 1e30)
+    b = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(b, d)
+    hit = a["t"] < 1e30
+    for f in ("t", "u", "v", "prim"):
+        assert np.array_equal(a[f][hit], b[f][hit]), f
+    assert np.all(b["t"][~hit] == np.float32(1e30)) and np.all(b["prim"][~hit] == 0) and np.all(b["u"][~hit] == 0)
+    # two-step form gives the same records
+    ctx.to_device(d, stale); ctx.reset_hits(d, n, 1e30); sc.intersect_device(d, n)
+    c = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(c, d)
+    assert np.array_equal(b, c)
+    ctx.free(d)

@@ -214,6 +214,9 @@ class _Scene:
     def intersect_device(self, d_rays: int, n: int):
         check(lib.tbvh_intersect_device(self._h, C.c_void_p(d_rays), n), "tbvh_intersect_device")
 
+    def intersect_device_fresh(self, d_rays: int, n: int, tmax: float = 1e30):
+        check(lib.tbvh_intersect_device_fresh(self._h, C.c_void_p(d_rays), n, float(tmax)), "tbvh_intersect_device_fresh")
+
     def occluded_device(self, d_rays: int, n: int, d_out: int):
         check(lib.tbvh_occluded_device(self._h, C.c_void_p(d_rays), n, C.c_void_p(d_out)), "tbvh_occluded_device")
 

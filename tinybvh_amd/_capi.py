@@ -46,6 +46,7 @@ SYMBOLS = {
     "tbvh_occluded": (_i, [_vp, _vp, _u64, _u32, _vp]),
     "tbvh_intersect_device": (_i, [_vp, _vp, _u64]),
     "tbvh_occluded_device": (_i, [_vp, _vp, _u64, _vp]),
+    "tbvh_intersect_device_fresh": (_i, [_vp, _vp, _u64, C.c_float]),
     "tbvh_reset_hits_device": (_i, [_vp, _vp, _u64, C.c_float]),
     "tbvh_time_last_ms": (C.c_float, [_vp]),
     "tbvh_set_variant": (_i, [_vp, _i]),

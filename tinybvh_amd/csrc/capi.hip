@@ -110,7 +110,7 @@ int ensureStageOcc(tbvh_context* c, uint64_t n) {
     return 0;
 }
 
-int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ) {
+int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh = false, float freshTmax = 1e30f) {
     tbvh_context* c = s->ctx;
     if (int r = setDevice(c)) return r;
     if (n == 0) return 0;
@@ -120,6 +120,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ) {
     q.rays = d_rays; q.nRays = n; q.occluded = d_occ;
     q.spill = c->spill; q.counter = (uint32_t*)c->counter;
     q.stats = c->counter + 8;
+    q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax;
     // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
     // (about one workgroup per 256 rays, measured best for 1 M-ray launches) so every wave still
     // has a few ray replacements' worth of work
@@ -415,6 +416,12 @@ int tbvh_intersect_device(tbvh_scene* s, void* dRays, uint64_t n) {
     if (!s || (!dRays && n)) return fail(TBVH_E_INVALID, "tbvh_intersect_device: null argument");
     if (((uintptr_t)dRays) & 15) return fail(TBVH_E_INVALID, "ray array must be 16-byte aligned");
     return launchQuery(s, (RayRec*)dRays, n, nullptr);
+}
+
+int tbvh_intersect_device_fresh(tbvh_scene* s, void* dRays, uint64_t n, float tmax) {
+    if (!s || (!dRays && n)) return fail(TBVH_E_INVALID, "tbvh_intersect_device_fresh: null argument");
+    if (((uintptr_t)dRays) & 15) return fail(TBVH_E_INVALID, "ray array must be 16-byte aligned");
+    return launchQuery(s, (RayRec*)dRays, n, nullptr, true, tmax);
 }
 
 int tbvh_occluded_device(tbvh_scene* s, const void* dRays, uint64_t n, uint8_t* dOcc) {

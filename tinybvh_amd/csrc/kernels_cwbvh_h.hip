@@ -115,7 +115,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh_h(const char* __restrict__ nodes, 
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
-                    hit = rp->hit;
+                    hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
                     found = false;
                     oct = 7u - ((D.x < 0 ? 4u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 1u : 0u));
                     octinv4 = oct * 0x01010101u;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh_h(const char* __restrict__ nodes, 
         }
         if (done) {
             if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
-            else if (found) q.rays[ri].hit = hit;
+            else if (found || q.fresh) q.rays[ri].hit = hit;
             active = false;
         }
     }

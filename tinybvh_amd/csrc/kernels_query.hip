@@ -80,7 +80,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
-                    hit = rp->hit;
+                    hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
                     ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z);
                     found = false; node = 0; triLeft = 0; st.sp = 0;
                     active = true;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
         }
         if (done) {
             if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
-            else if (found) q.rays[ri].hit = hit;
+            else if (found || q.fresh) q.rays[ri].hit = hit;
             active = false;
         }
     }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
-                    hit = rp->hit;
+                    hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
                     found = false; offset = 0; leafCnt = 0; st.sp = 0;
                     active = true;
                 }
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
         }
         if (done) {
             if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
-            else if (found) q.rays[ri].hit = hit;
+            else if (found || q.fresh) q.rays[ri].hit = hit;
             active = false;
         }
     }

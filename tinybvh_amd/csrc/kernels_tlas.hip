@@ -199,7 +199,7 @@ __global__ __launch_bounds__(WG) void k_tlas(const float4* __restrict__ tlasNode
         RayRec* rp = q.rays + ri;
         const float3 O = xyz(rp->O), D = xyz(rp->D), rD = xyz(rp->rD);
         const uint32_t rayMask = as_u32(rp->O.w);
-        float4 hit = rp->hit;
+        float4 hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
         uint32_t hitInst = as_u32(rp->rD.w);
         bool found = false;
         const float3 ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z);
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(WG) void k_tlas(const float4* __restrict__ tlasNode
         }
         if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
         else if (found) { rp->hit = hit; ((uint32_t*)rp)[11] = hitInst; }   // byte 44 = hit.inst
+        else if (q.fresh) rp->hit = hit;
     }
     if (st.overflow) atomicOr(status, 1u);
 }
