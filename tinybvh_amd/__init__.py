@@ -305,8 +305,10 @@ class TLAS(_Scene):
         assert instances.dtype == INSTANCE_DTYPE and instances.flags["C_CONTIGUOUS"]
         bounds = np.zeros((len(blas), 6), np.float32)
         for i, b in enumerate(blas):
-            v = b.host.verts[:, :3]
-            bounds[i, :3] = v.min(0); bounds[i, 3:] = v.max(0)
+            if getattr(b, "_bounds", None) is None:      # root box of the BLAS, computed once
+                v = b.host.verts[:, :3]
+                b._bounds = np.concatenate([v.min(0), v.max(0)]).astype(np.float32)
+            bounds[i] = b._bounds
         h = C.c_void_p()
         check(lib.tbvh_host_build_tlas(_ptr(instances), instances.shape[0], _ptr(bounds), len(blas), C.byref(h)), "tbvh_host_build_tlas")
         host = HostBVH.__new__(HostBVH)

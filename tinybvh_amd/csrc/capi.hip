@@ -261,6 +261,7 @@ int tbvh_set_stream(tbvh_context* c, void* s) {
 int tbvh_upload_bvh_gpu(tbvh_context* c, const void* nodes64, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx,
                         const void* verts16, uint64_t nTris, tbvh_scene** out) {
     if (!c || !nodes64 || !primIdx || !verts16 || !out || nNodes == 0) return fail(TBVH_E_INVALID, "tbvh_upload_bvh_gpu: null/empty argument");
+    if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(TBVH_E_FORMAT, "%s", why);
     if (int r = setDevice(c)) return r;
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
@@ -285,6 +286,7 @@ int tbvh_upload_bvh_gpu(tbvh_context* c, const void* nodes64, uint64_t nNodes, c
 
 int tbvh_upload_bvh4_gpu(tbvh_context* c, const void* blocks16, uint64_t nBlocks, tbvh_scene** out) {
     if (!c || !blocks16 || !out || nBlocks < 4) return fail(TBVH_E_INVALID, "tbvh_upload_bvh4_gpu: null/empty argument");
+    if (const char* why = validate_bvh4_gpu((const Vec4*)blocks16, nBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
     if (int r = setDevice(c)) return r;
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH4_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
@@ -301,6 +303,7 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
                       tbvh_scene** out) {
     if (!c || !nodes16 || !out || nNodeBlocks < 5 || (nTriBlocks && !tris16)) return fail(TBVH_E_INVALID, "tbvh_upload_cwbvh: null/empty argument");
     if (nNodeBlocks % 5) return fail(TBVH_E_FORMAT, "CWBVH node blocks (%llu) not a multiple of 5", (unsigned long long)nNodeBlocks);
+    if (const char* why = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
     if (int r = setDevice(c)) return r;
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_CWBVH);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");

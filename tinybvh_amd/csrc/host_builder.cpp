@@ -714,3 +714,64 @@ void reorder_cwbvh_priority(const Vec4* in, uint32_t nNodes, std::vector<Vec4>& 
 }
 
 }  // namespace tbvh
+
+// ---- blob validation at upload: out-of-range indices must become an error code on the host,
+// ---- not a wild read on the device ----------------------------------------------------------
+namespace tbvh {
+
+const char* validate_bvh_gpu(const NodeAL* n, uint64_t nNodes, uint64_t nIdx) {
+    for (uint64_t i = 0; i < nNodes; i++) {
+        if (n[i].triCount) {
+            if ((uint64_t)n[i].firstTri + n[i].triCount > nIdx) return "BVH_GPU leaf: firstTri + triCount exceeds the primIdx array";
+        } else if (n[i].left >= nNodes || n[i].right >= nNodes) return "BVH_GPU interior node: child index out of range";
+    }
+    return nullptr;
+}
+
+const char* validate_bvh4_gpu(const Vec4* b, uint64_t nBlocks) {
+    // walk the stream from the root; every reachable node and triangle run must lie inside it
+    std::vector<uint32_t> stack{0};
+    uint64_t visited = 0;
+    while (!stack.empty()) {
+        const uint32_t o = stack.back(); stack.pop_back();
+        if ((uint64_t)o + 4 > nBlocks) return "BVH4_GPU node offset out of range";
+        if (++visited > nBlocks) return "BVH4_GPU stream contains a cycle";
+        uint32_t info[4]; std::memcpy(info, &b[o + 3], 16);
+        for (int i = 0; i < 4; i++) {
+            if (!info[i]) continue;
+            if (info[i] & 0x80000000u) {
+                const uint64_t cnt = (info[i] >> 16) & 0x7fff, rel = info[i] & 0xffff;
+                if ((uint64_t)o + rel + 3 * cnt > nBlocks) return "BVH4_GPU leaf: triangle run exceeds the stream";
+            } else stack.push_back(info[i]);
+        }
+    }
+    return nullptr;
+}
+
+const char* validate_cwbvh(const Vec4* nodes, uint64_t nNodes, uint64_t nTriBlocks) {
+    auto u32 = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    const uint32_t rootImask = u32(nodes[0].w) >> 24;
+    uint32_t rootMeta[2]; std::memcpy(rootMeta, &nodes[1].z, 8);
+    if (nNodes == 0 || (rootImask == 0 && rootMeta[0] == 0 && rootMeta[1] == 0)) return "CWBVH root node is empty";
+    for (uint64_t k = 0; k < nNodes; k++) {
+        const Vec4* p = nodes + k * 5;
+        const uint32_t imask = u32(p[0].w) >> 24, base = u32(p[1].x), triBase = u32(p[1].y);
+        const uint32_t cnt = (uint32_t)__builtin_popcount(imask);
+        if (cnt && (uint64_t)base + cnt > nNodes) return "CWBVH node: childBaseIndex + interior children exceeds the node array";
+        uint8_t meta[8]; std::memcpy(meta, &p[1].z, 8);
+        uint32_t maxTri = 0;
+        for (int s = 0; s < 8; s++) {
+            if ((imask >> s) & 1) continue;
+            const uint32_t m = meta[s];
+            if (!m) continue;
+            const uint32_t c = (m >> 5) == 1 ? 1 : (m >> 5) == 3 ? 2 : (m >> 5) == 7 ? 3 : 0;
+            if (!c) return "CWBVH leaf slot: triangle count is not unary-encoded 1..3";
+            maxTri = std::max(maxTri, (m & 31) + c);
+        }
+        if (maxTri > 24) return "CWBVH node: more than 24 triangles";
+        if (maxTri && (uint64_t)triBase + 3ull * maxTri > nTriBlocks) return "CWBVH node: triangle range exceeds the triangle array";
+    }
+    return nullptr;
+}
+
+}  // namespace tbvh

@@ -59,6 +59,11 @@ void encode_cwbvh(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std:
 // Renumber CWBVH nodes (5 x Vec4 each) in surface-area priority order; see host_builder.cpp.
 void reorder_cwbvh_priority(const Vec4* in, uint32_t nNodes, std::vector<Vec4>& out);
 
+// Structural validation of caller-supplied blobs (returns nullptr when fine, else a message).
+const char* validate_bvh_gpu(const NodeAL* nodes, uint64_t nNodes, uint64_t nIdx);
+const char* validate_bvh4_gpu(const Vec4* blocks, uint64_t nBlocks);
+const char* validate_cwbvh(const Vec4* nodes, uint64_t nNodes, uint64_t nTriBlocks);
+
 // BLASInstance record, 192 bytes (tiny_bvh.h:1443-1457).
 struct Instance192 {
     float transform[16];
