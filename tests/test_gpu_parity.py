@@ -215,3 +215,25 @@ def test_fresh_entry_point_equals_reset_plus_intersect(ctx, soup, layout):
     c = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(c, d)
     assert np.array_equal(b, c)
     ctx.free(d)
+
+
+def test_malformed_blobs_are_rejected_at_upload(ctx, soup):
+    """Out-of-range indices in a caller's blob become TBVH_E_FORMAT on the host, not a wild read."""
+    h = tb.HostBVH(soup, tb.LAYOUT_CWBVH)
+    nodes = h.blob(0, np.uint32, 4).copy(); tris = h.blob(1, np.uint32, 4)
+    nodes[1, 0] = nodes.shape[0]          # root childBaseIndex beyond the array
+    with pytest.raises(tb.TbvhError) as e:
+        tb.BVH8_CWBVH(ctx).Upload(nodes, tris)
+    assert e.value.code == -5
+    with pytest.raises(tb.TbvhError):
+        tb.BVH8_CWBVH(ctx).Upload(h.blob(0, np.uint32, 4), tris[:30])      # triangle array too short
+    with pytest.raises(tb.TbvhError):
+        tb.BVH8_CWBVH(ctx).Upload(h.blob(0, np.uint32, 4)[:7], tris)       # not a multiple of 5 blocks
+    h4 = tb.HostBVH(soup, tb.LAYOUT_BVH4_GPU)
+    b = h4.blob(0, np.uint32, 4).copy(); b[3, 0] = 0x7fffff00             # child offset far outside
+    with pytest.raises(tb.TbvhError):
+        tb.BVH4_GPU(ctx).Upload(b)
+    h2 = tb.HostBVH(soup, tb.LAYOUT_BVH_GPU)
+    n2 = h2.blob(0, np.uint32, 16).copy(); n2[0, 3] = 10 ** 9
+    with pytest.raises(tb.TbvhError):
+        tb.BVH_GPU(ctx).Upload(n2, h2.blob(1, np.uint32, 1), soup)
