@@ -186,6 +186,36 @@ int tbvh_generate_shadow_device(tbvh_context* ctx, const void* d_in_rays64,
                                 const float light_pos[3], float eps);
 
 /* ------------------------------------------------------------------------------------
+ * device-resident wavefront path tracer — the frame loop of tiny_bvh_gpu.cpp:128-158 over
+ * wavefront.cl:52-287 (Generate, { Extend, Shade } x depth, Connect, accumulate) with every
+ * queue and counter on the device: one host call enqueues a whole frame, nothing is read back
+ * unless `stats` is requested.  Extend / Connect are the traversal kernels above; shading is
+ * deliberately small (Lambert, albedo = RGB8 packed in v0.w of the hit triangle or 70 % grey,
+ * one point light with next-event estimation, two-colour sky, cosine-weighted bounces).
+ * ---------------------------------------------------------------------------------- */
+typedef struct tbvh_wavefront tbvh_wavefront;
+typedef struct tbvh_wf_params {
+    float light_pos[3], light_color[3], sky_lo[3], sky_hi[3];
+    float eps;            /* ray origin offset along the new direction                      */
+    uint32_t max_depth;   /* path segments per pixel (0 = 3, the reference's bounce count)  */
+    uint32_t seed;        /* per-frame RNG seed                                             */
+    uint32_t clear;       /* non-zero: zero the accumulator first                           */
+} tbvh_wf_params;
+typedef struct tbvh_wf_stats {
+    uint64_t extend_rays[8];  /* nearest-hit rays traced at depth d                         */
+    uint64_t shadow_rays[8];  /* any-hit rays traced after depth d                          */
+    float frame_ms;           /* HIP-event time of the whole frame                          */
+} tbvh_wf_stats;
+int  tbvh_wavefront_create(tbvh_context* ctx, uint32_t width, uint32_t height, tbvh_wavefront** out);
+void tbvh_wavefront_destroy(tbvh_wavefront* wf);
+/* d_verts16: device copy of the scene's original vertex array.  stats may be NULL (fully
+ * asynchronous); when given, the call synchronizes and fills it. */
+int  tbvh_wavefront_render(tbvh_wavefront* wf, tbvh_scene* scene, const void* d_verts16, const tbvh_camera* cam,
+                           const tbvh_wf_params* params, tbvh_wf_stats* stats);
+/* copy the float RGBA accumulator (width * height * 4 floats, row-major) to the host */
+int  tbvh_wavefront_read(tbvh_wavefront* wf, float* rgba);
+
+/* ------------------------------------------------------------------------------------
  * device buffers — replace tinyocl::Buffer for callers that keep rays resident
  * (tiny_ocl.h:130-154, 571-708).  64-bit sizes (tinyocl::Buffer::size is 32-bit,
  * tiny_ocl.h:152: 64 M rays x 64 B wraps to 0 there).

@@ -334,3 +334,42 @@ class TLAS(_Scene):
         check(lib.tbvh_update_tlas(self._h, _ptr(nodes64), nodes64.nbytes // 64, _ptr(tlas_idx), tlas_idx.size, _ptr(instances), instances.shape[0]),
               "tbvh_update_tlas")
         return self
+
+
+class Wavefront:
+    """Device-resident wavefront path tracer (tbvh_wavefront_*): one call enqueues a whole frame
+    (Generate, {Extend, Shade} x depth, Connect) with all queues and counters on the device."""
+
+    def __init__(self, ctx: Context, width: int, height: int):
+        self.ctx, self.width, self.height = ctx, width, height
+        h = C.c_void_p()
+        check(lib.tbvh_wavefront_create(ctx._h, width, height, C.byref(h)), "tbvh_wavefront_create")
+        self._h = h
+
+    def render(self, scene: _Scene, d_verts: int, cam: Camera, light_pos, light_color=(1.0, 1.0, 1.0), sky_lo=(0.6, 0.7, 0.8), sky_hi=(0.2, 0.4, 0.9),
+               eps: float = 1e-3, max_depth: int = 3, seed: int = 1, clear: bool = True, stats: bool = True):
+        p = _capi.WfParams()
+        p.light_pos[:] = [float(x) for x in light_pos]; p.light_color[:] = [float(x) for x in light_color]
+        p.sky_lo[:] = [float(x) for x in sky_lo]; p.sky_hi[:] = [float(x) for x in sky_hi]
+        p.eps, p.max_depth, p.seed, p.clear = float(eps), int(max_depth), int(seed), int(clear)
+        st = _capi.WfStats()
+        check(lib.tbvh_wavefront_render(self._h, scene._h, C.c_void_p(d_verts), C.byref(cam), C.byref(p), C.byref(st) if stats else None), "tbvh_wavefront_render")
+        if not stats:
+            return None
+        return {"extend_rays": [int(x) for x in st.extend_rays[:max_depth]], "shadow_rays": [int(x) for x in st.shadow_rays[:max_depth]], "frame_ms": float(st.frame_ms)}
+
+    def read(self) -> np.ndarray:
+        img = np.zeros((self.height, self.width, 4), np.float32)
+        check(lib.tbvh_wavefront_read(self._h, _ptr(img)), "tbvh_wavefront_read")
+        return img
+
+    def close(self):
+        if self._h and self.ctx._h:
+            lib.tbvh_wavefront_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

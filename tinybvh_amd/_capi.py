@@ -26,7 +26,20 @@ class Camera(C.Structure):
                 ("width", _u32), ("height", _u32), ("spp_x", _u32), ("spp_y", _u32)]
 
 
+class WfParams(C.Structure):
+    _fields_ = [("light_pos", C.c_float * 3), ("light_color", C.c_float * 3), ("sky_lo", C.c_float * 3), ("sky_hi", C.c_float * 3),
+                ("eps", C.c_float), ("max_depth", _u32), ("seed", _u32), ("clear", _u32)]
+
+
+class WfStats(C.Structure):
+    _fields_ = [("extend_rays", _u64 * 8), ("shadow_rays", _u64 * 8), ("frame_ms", C.c_float)]
+
+
 SYMBOLS = {
+    "tbvh_wavefront_create": (_i, [_vp, _u32, _u32, _pp]),
+    "tbvh_wavefront_destroy": (None, [_vp]),
+    "tbvh_wavefront_render": (_i, [_vp, _vp, _vp, C.POINTER(Camera), C.POINTER(WfParams), C.POINTER(WfStats)]),
+    "tbvh_wavefront_read": (_i, [_vp, _vp]),
     "tbvh_abi_version": (_i, []),
     "tbvh_last_error": (C.c_char_p, []),
     "tbvh_device_count": (_i, []),

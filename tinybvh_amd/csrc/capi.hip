@@ -110,7 +110,8 @@ int ensureStageOcc(tbvh_context* c, uint64_t n) {
     return 0;
 }
 
-int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh = false, float freshTmax = 1e30f) {
+int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh = false, float freshTmax = 1e30f,
+                const unsigned long long* nDev = nullptr) {
     tbvh_context* c = s->ctx;
     if (int r = setDevice(c)) return r;
     if (n == 0) return 0;
@@ -120,7 +121,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     q.rays = d_rays; q.nRays = n; q.occluded = d_occ;
     q.spill = c->spill; q.counter = (uint32_t*)c->counter;
     q.stats = c->counter + 8;
-    q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax;
+    q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev;
     // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
     // (about one workgroup per 256 rays, measured best for 1 M-ray launches) so every wave still
     // has a few ray replacements' worth of work
@@ -519,6 +520,122 @@ int tbvh_reset_hits_device(tbvh_context* c, void* dRays, uint64_t n, float tmax)
     if (!n) return 0;
     launch_reset_hits((RayRec*)dRays, n, tmax, c->stream);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- wavefront path tracer (device-resident Generate / Extend / Shade / Connect) ----------------
+
+struct tbvh_wavefront {
+    tbvh_context* ctx = nullptr;
+    uint32_t width = 0, height = 0;
+    uint64_t n = 0;
+    RayRec* rays[2] = {nullptr, nullptr};
+    PathAux* aux[2] = {nullptr, nullptr};
+    RayRec* shadow = nullptr;
+    PathAux* shadowAux = nullptr;
+    uint8_t* occ = nullptr;
+    float* accum = nullptr;
+    unsigned long long* counters = nullptr;   // [0],[1] path queues, [2] shadow queue, [8..] per-depth history
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+int tbvh_wavefront_create(tbvh_context* c, uint32_t width, uint32_t height, tbvh_wavefront** out) {
+    if (!c || !out || !width || !height || (width & 3) || (height & 3)) return fail(TBVH_E_INVALID, "tbvh_wavefront_create: null argument or size not a multiple of 4");
+    if (int r = setDevice(c)) return r;
+    tbvh_wavefront* w = new (std::nothrow) tbvh_wavefront;
+    if (!w) return fail(TBVH_E_NOMEM, "out of host memory");
+    w->ctx = c; w->width = width; w->height = height; w->n = (uint64_t)width * height;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipMalloc((void**)&w->rays[i], w->n * 64);
+        if (e == hipSuccess) e = hipMalloc((void**)&w->aux[i], w->n * sizeof(PathAux));
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&w->shadow, w->n * 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&w->shadowAux, w->n * sizeof(PathAux));
+    if (e == hipSuccess) e = hipMalloc((void**)&w->occ, w->n);
+    if (e == hipSuccess) e = hipMalloc((void**)&w->accum, w->n * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&w->counters, 64 * 8);
+    if (e == hipSuccess) e = hipMemset(w->accum, 0, w->n * 16);
+    if (e == hipSuccess) e = hipEventCreate(&w->e0);
+    if (e == hipSuccess) e = hipEventCreate(&w->e1);
+    if (e != hipSuccess) { tbvh_wavefront_destroy(w); return fail(TBVH_E_NOMEM, "wavefront allocation failed: %s", hipGetErrorString(e)); }
+    *out = w;
+    return 0;
+}
+
+void tbvh_wavefront_destroy(tbvh_wavefront* w) {
+    if (!w) return;
+    hipSetDevice(w->ctx->device);
+    hipStreamSynchronize(w->ctx->stream);
+    for (int i = 0; i < 2; i++) { if (w->rays[i]) hipFree(w->rays[i]); if (w->aux[i]) hipFree(w->aux[i]); }
+    if (w->shadow) hipFree(w->shadow);
+    if (w->shadowAux) hipFree(w->shadowAux);
+    if (w->occ) hipFree(w->occ);
+    if (w->accum) hipFree(w->accum);
+    if (w->counters) hipFree(w->counters);
+    if (w->e0) hipEventDestroy(w->e0);
+    if (w->e1) hipEventDestroy(w->e1);
+    delete w;
+}
+
+int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVerts, const tbvh_camera* cam, const tbvh_wf_params* p,
+                          tbvh_wf_stats* stats) {
+    if (!w || !scene || !dVerts || !cam || !p) return fail(TBVH_E_INVALID, "tbvh_wavefront_render: null argument");
+    if (scene->ctx != w->ctx) return fail(TBVH_E_INVALID, "scene and wavefront belong to different contexts");
+    if (cam->width != w->width || cam->height != w->height) return fail(TBVH_E_INVALID, "camera size differs from the wavefront's");
+    const uint32_t maxDepth = p->max_depth ? (p->max_depth > 8 ? 8 : p->max_depth) : 3;
+    tbvh_context* c = w->ctx;
+    if (int r = setDevice(c)) return r;
+    hipStream_t st = c->stream;
+    HIP_TRY(hipEventRecord(w->e0, st));
+    if (p->clear) HIP_TRY(hipMemsetAsync(w->accum, 0, w->n * 16, st));
+    HIP_TRY(hipMemsetAsync(w->counters, 0, 64 * 8, st));
+    HIP_TRY(hipMemcpyAsync(&w->counters[0], &w->n, 8, hipMemcpyHostToDevice, st));
+    CameraArgs ca;
+    memcpy(ca.eye, cam->eye, 12); memcpy(ca.p1, cam->p1, 12); memcpy(ca.p2, cam->p2, 12); memcpy(ca.p3, cam->p3, 12);
+    ca.width = cam->width; ca.height = cam->height; ca.sppX = ca.sppY = 1;
+    launch_wf_generate(ca, w->rays[0], w->aux[0], w->n, p->seed, st);
+    int cur = 0;
+    for (uint32_t d = 0; d < maxDepth; d++) {
+        const int nxt = cur ^ 1;
+        // Extend: nearest hit of every live path; the batch size lives on the device
+        if (int r = launchQuery(scene, w->rays[cur], w->n, nullptr, false, 1e30f, &w->counters[cur])) return r;
+        HIP_TRY(hipMemsetAsync(&w->counters[nxt], 0, 8, st));
+        HIP_TRY(hipMemsetAsync(&w->counters[2], 0, 8, st));
+        ShadeArgs a;
+        a.in = w->rays[cur]; a.auxIn = w->aux[cur]; a.nIn = &w->counters[cur];
+        a.out = w->rays[nxt]; a.auxOut = w->aux[nxt]; a.nOut = &w->counters[nxt];
+        a.shadow = w->shadow; a.shadowAux = w->shadowAux; a.nShadow = &w->counters[2];
+        a.verts = (const float4*)dVerts; a.accum = w->accum;
+        memcpy(a.lightPos, p->light_pos, 12); memcpy(a.lightColor, p->light_color, 12); memcpy(a.skyLo, p->sky_lo, 12); memcpy(a.skyHi, p->sky_hi, 12);
+        a.eps = p->eps; a.depth = d; a.maxDepth = maxDepth; a.seed = p->seed;
+        launch_wf_shade(a, w->n, st);
+        // Connect: any-hit over the shadow queue, then add what is unoccluded
+        if (int r = launchQuery(scene, w->shadow, w->n, w->occ, false, 1e30f, &w->counters[2])) return r;
+        launch_wf_connect(w->occ, w->shadowAux, &w->counters[2], w->accum, w->n, st);
+        HIP_TRY(hipMemcpyAsync(&w->counters[8 + 2 * d], &w->counters[cur], 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(&w->counters[9 + 2 * d], &w->counters[2], 8, hipMemcpyDeviceToDevice, st));
+        cur = nxt;
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(w->e1, st));
+    if (stats) {
+        unsigned long long h[64];
+        HIP_TRY(hipMemcpyAsync(h, w->counters, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        memset(stats, 0, sizeof *stats);
+        for (uint32_t d = 0; d < maxDepth; d++) { stats->extend_rays[d] = h[8 + 2 * d]; stats->shadow_rays[d] = h[9 + 2 * d]; }
+        HIP_TRY(hipEventElapsedTime(&stats->frame_ms, w->e0, w->e1));
+        if (int r = checkStatus(c)) return r;
+    }
+    return 0;
+}
+
+int tbvh_wavefront_read(tbvh_wavefront* w, float* rgba) {
+    if (!w || !rgba) return fail(TBVH_E_INVALID, "tbvh_wavefront_read: null argument");
+    if (int r = setDevice(w->ctx)) return r;
+    HIP_TRY(hipMemcpyAsync(rgba, w->accum, w->n * 16, hipMemcpyDeviceToHost, w->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(w->ctx->stream));
     return 0;
 }
 

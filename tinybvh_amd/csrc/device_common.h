@@ -81,6 +81,7 @@ struct QueryArgs {
     uint32_t spillStride;  // entries per lane in `spill`
     uint32_t* counter;     // dynamic ray-fetch counter (persistent kernels)
     unsigned long long* stats;  // instrumented variants: lane-utilisation counters
+    const unsigned long long* nRaysDev;  // if non-null the batch size is read from device memory (on-device queues)
     uint32_t fresh;        // 1: ignore the stored hit, start every ray from {freshTmax,0,0,0} and always write the record
     float freshTmax;
 };

@@ -36,4 +36,18 @@ void launch_gen_bounce(const TriSource& src, const RayRec* in, RayRec* out, uint
 void launch_reset_hits(RayRec* rays, uint64_t n, float tmax, hipStream_t s);
 void launch_gen_shadow(const RayRec* in, RayRec* out, uint64_t n, float lx, float ly, float lz, float eps, hipStream_t s);
 
+// wavefront path tracer stages (kernels_wavefront.hip)
+struct PathAux { float T[3]; uint32_t pixel; };   // throughput (or pending contribution) + pixel index, 16 bytes
+struct ShadeArgs {
+    const RayRec* in; const PathAux* auxIn; const unsigned long long* nIn;
+    RayRec* out; PathAux* auxOut; unsigned long long* nOut;
+    RayRec* shadow; PathAux* shadowAux; unsigned long long* nShadow;
+    const float4* verts; float* accum;
+    float lightPos[3], lightColor[3], skyLo[3], skyHi[3];
+    float eps; uint32_t depth, maxDepth, seed;
+};
+void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint64_t n, uint32_t seed, hipStream_t s);
+void launch_wf_shade(const ShadeArgs& a, uint64_t capacity, hipStream_t s);
+void launch_wf_connect(const uint8_t* occ, const PathAux* aux, const unsigned long long* nShadow, float* accum, uint64_t capacity, hipStream_t s);
+
 }  // namespace tbvh

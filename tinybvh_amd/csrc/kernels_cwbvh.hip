@@ -128,6 +128,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     st.init(&stk[0][threadIdx.x], (uint2*)q.spill + glane, gridDim.x * WG, q.spillStride);
     RayPool<(MODE == 0 ? 64 : 64)> pool;
     pool.init();
+    const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
 
     bool active = false;
     uint64_t ri = 0;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
         if ((MODE == 0 ? nIdle == (uint32_t)WG : nIdle >= (uint32_t)REFILL_MIN) || (nIdle == (uint32_t)WG)) {
             if (!(pool.exhausted && pool.next == pool.end)) {
                 uint64_t nri = 0;
-                const bool got = pool.acquire(!active, (unsigned long long*)q.counter, q.nRays, nri);
+                const bool got = pool.acquire(!active, (unsigned long long*)q.counter, nRaysTotal, nri);
                 if (STATS) { sRefill++; sRefilled += __popcll(__ballot(got)); }
                 if (got) {
                     ri = nri;

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(WGC) void k_cwbvh_c(const float4* __restrict__ node
     bool overflow = false;
     RayPool<64> pool;
     pool.init();
+    const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
 
     bool active = false;
     uint64_t ri = 0;
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(WGC) void k_cwbvh_c(const float4* __restrict__ node
         if (nIdle >= (uint32_t)REFILL_MIN) {
             if (!(pool.exhausted && pool.next == pool.end)) {
                 uint64_t nri = 0;
-                if (pool.acquire(!active, (unsigned long long*)q.counter, q.nRays, nri)) {
+                if (pool.acquire(!active, (unsigned long long*)q.counter, nRaysTotal, nri)) {
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh_h(const char* __restrict__ nodes, 
     bool overflow = false;
     RayPool<64> pool;
     pool.init();
+    const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
 
     bool active = false;
     uint64_t ri = 0;
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh_h(const char* __restrict__ nodes, 
         if (nIdle >= (uint32_t)REFILL_MIN) {
             if (!(pool.exhausted && pool.next == pool.end)) {
                 uint64_t nri = 0;
-                if (pool.acquire(!active, (unsigned long long*)q.counter, q.nRays, nri)) {
+                if (pool.acquire(!active, (unsigned long long*)q.counter, nRaysTotal, nri)) {
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);

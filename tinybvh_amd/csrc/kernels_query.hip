@@ -63,6 +63,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
     st.spillCap = q.spillStride; st.sp = 0; st.overflow = false;
     RayPool<64> pool;
     pool.init();
+    const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
 
     bool active = false;
     uint64_t ri = 0;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
         if (nIdle >= (uint32_t)REFILL_MIN) {
             if (!(pool.exhausted && pool.next == pool.end)) {
                 uint64_t nri = 0;
-                if (pool.acquire(!active, (unsigned long long*)q.counter, q.nRays, nri)) {
+                if (pool.acquire(!active, (unsigned long long*)q.counter, nRaysTotal, nri)) {
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
     st.spillCap = q.spillStride; st.sp = 0; st.overflow = false;
     RayPool<64> pool;
     pool.init();
+    const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
 
     bool active = false;
     uint64_t ri = 0;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
         if (nIdle >= (uint32_t)REFILL_MIN) {
             if (!(pool.exhausted && pool.next == pool.end)) {
                 uint64_t nri = 0;
-                if (pool.acquire(!active, (unsigned long long*)q.counter, q.nRays, nri)) {
+                if (pool.acquire(!active, (unsigned long long*)q.counter, nRaysTotal, nri)) {
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
