@@ -138,6 +138,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # whole wavefront path-traced frames (Generate, {Extend, Shade} x 3, Connect; all queues on the
+    # device) — config 4's pipeline end to end, reported in `detail` (outside the timed steps)
+    wf_detail = None
+    try:
+        for p_ in (d_tmp, d_shad):
+            ctx.free(p_)
+        wf = tb.Wavefront(ctx, a.side, a.side)
+        frames = []
+        for f in range(3):
+            frames.append(wf.render(sc, d_verts, cam, light, (3000.0, 3000.0, 3000.0), max_depth=3, seed=seed + f))
+        st = frames[-1]
+        total = sum(st["extend_rays"]) + sum(st["shadow_rays"])
+        wf_detail = {"extend_rays": st["extend_rays"], "shadow_rays": st["shadow_rays"], "frame_ms": st["frame_ms"],
+                     "mrays_all_stages": total / st["frame_ms"] / 1e3}
+        wf.close()
+    except Exception as e:
+        log(f"[bench] wavefront frame failed: {e!r}")
+
     # ---- results (rank 0) ---------------------------------------------------------------------------
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
@@ -147,6 +165,7 @@ def main():
         detail = {k + "_mrays": n / (mean[k] * 1e-3) / 1e6 for k in mean}
         detail["kernel_ms"] = mean
         detail["primary_plus_diffuse_kernel_mrays"] = 2 * n / ((mean["primary"] + mean["diffuse"]) * 1e-3) / 1e6
+        detail["wavefront_frame_3_bounces"] = wf_detail
 
         # roofline of the dominant kernel (CWBVH Intersect on the diffuse batch): algorithmic
         # bytes per ray = 64 (ray in) + 16 (hit out) + node_bytes*S + tri_bytes*T, SURVEY.md
