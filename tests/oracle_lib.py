@@ -216,3 +216,38 @@ def compare_hits(got: np.ndarray, want: np.ndarray, rtol: float = 1e-5):
     res["bit_identical"] = int(bi.sum())
     res["same_prim"] = int(sp.sum())
     return res
+
+
+# ---- the reference's own OpenCL kernels through ROCm OpenCL (oracle/ref_ocl.cpp) ----------------
+REFOCL_PATH = os.path.join(ROOT, "oracle", "_ref", "libtinybvh_refocl.so")
+
+
+class ReferenceOpenCL:
+    """batch_ailalaine / batch_gpu4way / batch_cwbvh of the reference, compiled by the OpenCL
+    driver at run time from the source text embedded at build time.  Measurement aid: lets the
+    HIP kernels be timed next to the kernels they replace on the same GPU."""
+
+    def __init__(self):
+        if not os.path.exists(REFOCL_PATH):
+            raise RuntimeError("oracle/_ref/libtinybvh_refocl.so not built (needs the reference checkout at build time)")
+        self.lib = C.CDLL(REFOCL_PATH)
+        L = self.lib
+        L.refocl_init.restype = C.c_int
+        L.refocl_error.restype = C.c_char_p
+        L.refocl_device.restype = C.c_char_p
+        L.refocl_run.restype = C.c_double
+        L.refocl_run.argtypes = [C.c_int, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64, C.c_int]
+        if L.refocl_init() != 0:
+            raise RuntimeError("reference OpenCL kernels unavailable: " + L.refocl_error().decode(errors="replace")[:2000])
+        self.device = L.refocl_device().decode()
+
+    def run(self, layout, blobs, rays, passes=3):
+        """blobs: list of numpy arrays in kernel-argument order.  Returns (rays_out, mean_ms)."""
+        r = np.ascontiguousarray(rays).copy()
+        n = (r.shape[0] // 64) * 64
+        b = [np.ascontiguousarray(x) for x in blobs] + [None, None]
+        ms = self.lib.refocl_run(layout, _p(b[0]), b[0].nbytes, _p(b[1]), b[1].nbytes if b[1] is not None else 0,
+                                 _p(b[2]), b[2].nbytes if b[2] is not None else 0, _p(r), n, passes)
+        if ms < 0:
+            raise RuntimeError("refocl_run: " + self.lib.refocl_error().decode(errors="replace")[:2000])
+        return r[:n], ms
