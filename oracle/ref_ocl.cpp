@@ -73,6 +73,21 @@ int refocl_init() {
     return 0;
 }
 
+// Debug aid: write the compiled device binary (an HSA code object) to `path` for llvm-objdump.
+int refocl_dump_binary(const char* path) {
+    if (refocl_init()) return -1;
+    size_t sz = 0;
+    clGetProgramInfo(g_prog, CL_PROGRAM_BINARY_SIZES, sizeof sz, &sz, nullptr);
+    std::vector<unsigned char> bin(sz);
+    unsigned char* ptr = bin.data();
+    clGetProgramInfo(g_prog, CL_PROGRAM_BINARIES, sizeof ptr, &ptr, nullptr);
+    FILE* f = fopen(path, "wb");
+    if (!f) return -2;
+    fwrite(bin.data(), 1, sz, f);
+    fclose(f);
+    return (int)sz;
+}
+
 // layout: 4 = batch_ailalaine(nodes, idx, verts, rays); 6 = batch_gpu4way(blocks, rays);
 //         9 = batch_cwbvh(nodes, tris, rays).  bufN / bytesN are the layout's blobs in that order.
 // rays: n packed 64-byte records (in/out).  Runs 1 warm-up + `passes` timed launches with global

@@ -46,6 +46,7 @@ struct tbvh_context {
     int numCUs = 0;
     uint32_t blocks = 0;          // persistent grid size (64-thread workgroups)
     uint32_t* spill = nullptr;    // stack spill area
+    float cohesionThreshold = 0.82f;  // AUTO schedule selection (kernels_cwbvh.hip: launch_cwbvh_auto)
     uint32_t spillEntries = 0;    // 32-bit entries per lane
     unsigned long long* counter = nullptr;  // ray-fetch counter (+ status word after it)
     uint32_t* status = nullptr;
@@ -118,10 +119,11 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     const bool any = d_occ != nullptr;
     HIP_TRY(hipMemsetAsync(c->counter, 0, 16, c->stream));
     QueryArgs q;
+    q.select = nullptr;
     q.rays = d_rays; q.nRays = n; q.occluded = d_occ;
     q.spill = c->spill; q.counter = (uint32_t*)c->counter;
     q.stats = c->counter + 8;
-    q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev;
+    q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.probeStride = 1;
     // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
     // (about one workgroup per 256 rays, measured best for 1 M-ray launches) so every wave still
     // has a few ray replacements' worth of work
@@ -148,8 +150,14 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         break;
     case TBVH_LAYOUT_CWBVH:
         q.spillStride = c->spillEntries / 2;  // 8-byte entries
-        if (s->variant >= 30) launch_cwbvh_c(any, s->variant, s->nodesP, s->tris, s->nNodes, q, c->status, (uint32_t)c->numCUs, c->stream);
-        else if (s->variant >= 20) launch_cwbvh_h(any, s->variant, s->nodesH, s->tris, q, c->status, blocks, c->stream);
+        if (s->variant >= 30 && s->variant < 40) launch_cwbvh_c(any, s->variant, s->nodesP, s->tris, s->nNodes, q, c->status, (uint32_t)c->numCUs, c->stream);
+        else if (s->variant >= 20 && s->variant < 30) launch_cwbvh_h(any, s->variant, s->nodesH, s->tris, q, c->status, blocks, c->stream);
+        else if (s->variant == 43) {
+            // AUTO: probe the batch's lane cohesion, then run the schedule that suits it
+            HIP_TRY(hipMemsetAsync(c->counter + 8, 0, 32, c->stream));
+            q.select = (const uint32_t*)(c->counter + 16);
+            launch_cwbvh_auto(any, s->nodes, s->tris, q, c->status, blocks, (uint32_t)c->numCUs * 256u, c->cohesionThreshold, c->stream);
+        }
         else launch_cwbvh(any, s->variant, s->nodes, s->tris, q, c->status, blocks, c->stream);
         break;
     default:
@@ -218,6 +226,7 @@ int tbvh_init(int device, tbvh_context** out) {
         const int b = atoi(e);
         if (b >= 1 && b <= 32) c->blocks = (uint32_t)c->numCUs * (uint32_t)b;
     }
+    if (const char* e = getenv("TBVH_COHESION_THRESHOLD")) c->cohesionThreshold = (float)atof(e);
     c->spillEntries = 232;  // 32-bit entries per lane beyond the LDS part of the stack
     const size_t spillBytes = (size_t)c->blocks * 64 * c->spillEntries * 4;
     e = hipMalloc((void**)&c->spill, spillBytes);
@@ -402,7 +411,7 @@ int tbvh_set_variant(tbvh_scene* s, int v) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         s->bytes += (uint64_t)s->nNodes * 128;
     }
-    if (v >= 30 && !s->nodesP) {
+    if (v >= 30 && v < 40 && !s->nodesP) {
         std::vector<Vec4> in((size_t)s->nNodes * 5), pr;
         HIP_TRY(hipMemcpy(in.data(), s->nodes, in.size() * 16, hipMemcpyDeviceToHost));
         reorder_cwbvh_priority(in.data(), s->nNodes, pr);

@@ -128,6 +128,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     st.init(&stk[0][threadIdx.x], (uint2*)q.spill + glane, gridDim.x * WG, q.spillStride);
     RayPool<(MODE == 0 ? 64 : 64)> pool;
     pool.init();
+    if (q.select && *q.select != 0u) return;   // AUTO mode: the lean schedule was chosen for this batch
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
 
     bool active = false;
@@ -279,7 +280,135 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Lean kernel for COHERENT batches (camera rays): one wave per 64 consecutive rays, no
+// replacement, no persistent loop, every triangle of a group tested at once — the whole wave
+// follows nearly the same path, so the bookkeeping that pays for itself on incoherent rays is
+// pure overhead here (measured against the reference's own OpenCL batch_cwbvh on the same GPU:
+// tools/vs_reference_opencl.py).  Stack: STACK_N entries per lane in private (scratch) memory,
+// like the reference kernel's `uint2 stack[32]` (traverse_cwbvh.cl:133); deeper trees are
+// reported through the status word, never silently mis-traversed.
+template <bool ANYHIT, int STACK_N, bool PROBE = false, int PROBE_STEPS = 48>
+__global__ __launch_bounds__(WG) void k_cwbvh_lean(const float4* __restrict__ nodes, const float4* __restrict__ tris, QueryArgs q,
+                                                   uint32_t* __restrict__ status) {
+    if (!PROBE && q.select && *q.select != 1u) return;   // AUTO mode: the replacement schedule was chosen
+    const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;
+    // PROBE: trace a strided sample of wave-groups for a bounded number of steps without writing
+    // anything, and record how well the 64 lanes of a wave stay together (sum of participating
+    // lanes / 64 x wave steps).  Otherwise: groups are dealt to the grid round-robin (static
+    // assignment: camera-like batches cost about the same per group).
+    const uint64_t nGroups = (nRaysTotal + WG - 1) / WG;
+    bool overflow = false;
+  for (uint64_t group = PROBE ? (uint64_t)blockIdx.x * q.probeStride : (uint64_t)blockIdx.x; group < nGroups; group += PROBE ? nGroups : gridDim.x) {
+    const uint64_t ri = group * WG + threadIdx.x;
+    if (ri >= nRaysTotal) continue;
+    RayRec* rp = q.rays + ri;
+    const float3 O = xyz(rp->O), D = xyz(rp->D), rD = xyz(rp->rD);
+    float4 hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
+    bool found = false;
+    unsigned long long pSteps = 0, pDistinct = 0, pNodeLanes = 0;
+    uint2 stack[STACK_N];
+    int sp = 0;
+    const uint32_t oct = 7u - ((D.x < 0 ? 4u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 1u : 0u));
+    const uint32_t octinv4 = oct * 0x01010101u;
+    uint2 ng = make_uint2(0u, 0x80000000u), tg = make_uint2(0u, 0u);
+    for (;;) {
+        if (ng.y > 0x00FFFFFFu) {
+            const uint32_t imask = ng.y;
+            const uint32_t bit = 31u - (uint32_t)__clz(ng.y);
+            const uint32_t cbase = ng.x;
+            ng.y &= ~(1u << bit);
+            if (ng.y > 0x00FFFFFFu) { if (sp < STACK_N) stack[sp++] = ng; else overflow = true; }
+            const uint32_t slot = (bit - 24u) ^ oct;
+            const uint32_t rel = __popc(imask & ~(0xFFFFFFFFu << slot));
+            if (PROBE) {   // a node visit weighs ~3 triangle tests
+                pSteps += 3;
+                if (pSteps > (unsigned long long)PROBE_STEPS) break;
+                // how many different nodes does the wave touch in this step?  (64-bucket hash of the node
+                // index, OR-reduced over the wave: an estimate that saturates at 64)
+                const uint32_t b = (cbase + rel) & 63u;
+                uint32_t lo = b < 32u ? 1u << b : 0u, hi = b >= 32u ? 1u << (b - 32u) : 0u;
+                for (int o = 32; o > 0; o >>= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
+                pDistinct += __popc(lo) + __popc(hi); pNodeLanes += __popcll(__ballot(true));
+            }
+            const NodeResult r = visit_node(nodes, cbase + rel, O, rD, hit.x, octinv4);
+            ng.x = r.childBase; tg.x = r.triBase;
+            ng.y = (r.hitmask & 0xFF000000u) | r.imask;
+            tg.y = r.hitmask & 0x00FFFFFFu;
+        } else {
+            tg = ng;
+            ng = make_uint2(0u, 0u);
+        }
+        while (tg.y != 0) {
+            const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
+            tg.y &= ~(1u << ti);
+            const uint32_t ta = tg.x + ti * 3u;
+            const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
+            if (PROBE) { pSteps += 1; }
+            TriHit h;
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                found = true;
+                if (ANYHIT) break;
+                hit = make_float4(h.t, h.u, h.v, v0.w);
+            }
+        }
+        if (ANYHIT && found) break;
+        if (ng.y > 0x00FFFFFFu) continue;
+        if (sp == 0) break;
+        ng = stack[--sp];
+    }
+    if (PROBE) {
+        // every lane counted the (weighted) steps it took part in; the wave's step count is the maximum
+        unsigned long long mx = pSteps;
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
+        unsigned long long sum = pSteps;
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        // pDistinct / pNodeLanes were accumulated by whichever lanes were active; take the max over lanes
+        unsigned long long dd = pDistinct, nl = pNodeLanes;
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(dd, o); dd = t > dd ? t : dd; const unsigned long long u = __shfl_xor(nl, o); nl = u > nl ? u : nl; }
+        if (threadIdx.x == 0) { atomicAdd(q.stats + 0, mx * 64ull); atomicAdd(q.stats + 1, sum); atomicAdd(q.stats + 2, dd); atomicAdd(q.stats + 3, nl); }
+        return;
+    }
+    if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+    else if (found || q.fresh) rp->hit = hit;
+  }
+    if (overflow) atomicOr(status, 1u);
+}
+
+// AUTO: decide between the two schedules from the probe's lane-cohesion measurement.
+__global__ void k_cwbvh_decide(const unsigned long long* __restrict__ stats, uint32_t* __restrict__ select, float threshold) {
+    const unsigned long long slots = stats[0], lanes = stats[1];
+    *select = (slots > 0 && (float)lanes >= threshold * (float)slots) ? 1u : 0u;
+}
+
 }  // namespace
+
+// AUTO schedule selection (variant 0).  A strided sample of up to 256 wave-groups is traced with
+// the lean schedule in probe mode (no writes); if on average >= `threshold` of a wave's lanes take
+// part in each step, the batch is "coherent" and the lean kernel runs, otherwise the persistent
+// replacement kernel.  Both are launched; the one not selected returns at once.  Measured
+// (tools/perf_probe.py --variant 42, MI355X): cohesion >= 0.84 where the lean kernel wins
+// (1.6-2.7x on the Sponza stand-in's camera and shadow rays), <= 0.80 where it does not
+// (Bistro stand-in camera rays 0.58-0.72: 0.75-0.97x; bounce rays 0.16-0.43: <= 0.5x).
+void launch_cwbvh_auto(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q0, uint32_t* status, uint32_t blocks,
+                       uint32_t leanMaxBlocks, float threshold, hipStream_t s) {
+    QueryArgs q = q0;
+    const uint64_t groups = (q.nRays + WG - 1) / WG;
+    const uint32_t probeBlocks = (uint32_t)(groups < 128 ? groups : 128);
+    const uint32_t leanBlocks = (uint32_t)(groups < (uint64_t)leanMaxBlocks ? groups : leanMaxBlocks);
+    q.probeStride = (uint32_t)(groups / probeBlocks);
+    if (anyhit) hipLaunchKernelGGL((k_cwbvh_lean<true, 32, true>), dim3(probeBlocks), dim3(WG), 0, s, nodes, tris, q, status);
+    else hipLaunchKernelGGL((k_cwbvh_lean<false, 32, true>), dim3(probeBlocks), dim3(WG), 0, s, nodes, tris, q, status);
+    hipLaunchKernelGGL(k_cwbvh_decide, dim3(1), dim3(1), 0, s, (const unsigned long long*)q.stats, const_cast<uint32_t*>(q.select), threshold);
+    q.probeStride = 1;
+    if (anyhit) {
+        hipLaunchKernelGGL((k_cwbvh_lean<true, 32>), dim3(leanBlocks), dim3(WG), 0, s, nodes, tris, q, status);
+        hipLaunchKernelGGL((k_cwbvh<true, 1, 8, 16, true>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    } else {
+        hipLaunchKernelGGL((k_cwbvh_lean<false, 32>), dim3(leanBlocks), dim3(WG), 0, s, nodes, tris, q, status);
+        hipLaunchKernelGGL((k_cwbvh<false, 1, 8, 16, true>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    }
+}
 
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                   uint32_t blocks, hipStream_t s) {
@@ -288,6 +417,26 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
         if (anyhit) hipLaunchKernelGGL((k_cwbvh<true, MODE, LDSN, RMIN, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status); \
         else hipLaunchKernelGGL((k_cwbvh<false, MODE, LDSN, RMIN, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);  \
     } while (0)
+    if (variant == 42) {   // probe only: lane-cohesion statistics of the lean schedule over the whole batch
+        QueryArgs qq = q;
+        const uint64_t ng_ = (q.nRays + WG - 1) / WG;
+        const uint32_t pb = (uint32_t)(ng_ < 128 ? ng_ : 128);
+        qq.probeStride = (uint32_t)(ng_ / pb);
+        hipLaunchKernelGGL((k_cwbvh_lean<false, 32, true>), dim3(pb), dim3(WG), 0, s, nodes, tris, qq, status);
+        return;
+    }
+    if (variant == 40 || variant == 41) {   // lean one-wave-per-64-rays kernel (coherent batches)
+        const uint64_t ng_ = (q.nRays + WG - 1) / WG;
+        const uint32_t nb = (uint32_t)(ng_ < 65536 ? ng_ : 65536);
+        if (variant == 40) {
+            if (anyhit) hipLaunchKernelGGL((k_cwbvh_lean<true, 32>), dim3(nb), dim3(WG), 0, s, nodes, tris, q, status);
+            else hipLaunchKernelGGL((k_cwbvh_lean<false, 32>), dim3(nb), dim3(WG), 0, s, nodes, tris, q, status);
+        } else {
+            if (anyhit) hipLaunchKernelGGL((k_cwbvh_lean<true, 48>), dim3(nb), dim3(WG), 0, s, nodes, tris, q, status);
+            else hipLaunchKernelGGL((k_cwbvh_lean<false, 48>), dim3(nb), dim3(WG), 0, s, nodes, tris, q, status);
+        }
+        return;
+    }
     switch (variant) {
     case 1: TBVH_LAUNCH(0, 16, 64); break;   // whole-wave batches (round-1 v0 behaviour)
     case 2: TBVH_LAUNCH(1, 16, 1); break;    // replace as soon as one lane is idle
@@ -314,6 +463,6 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
 #undef TBVH_LAUNCH
 }
 
-bool cwbvh_variant_valid(int v) { return v >= 0 && v <= 16; }
+bool cwbvh_variant_valid(int v) { return (v >= 0 && v <= 16) || (v >= 40 && v <= 43); }
 
 }  // namespace tbvh

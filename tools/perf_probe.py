@@ -68,6 +68,12 @@ def main():
             if kind == "bounce1":
                 ctx.generate_bounce(d_verts, d_prim, d_b, n, 1); sc.intersect_device(d_b, n); ctx.synchronize()
             res[kind] = n / (np.mean(ms) * 1e-3) / 1e6
+            if a.variant == 42:
+                import ctypes as C
+                st = (C.c_uint64 * 8)()
+                tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+                if st[0]:
+                    print(f"   [{kind}] lean-schedule lane cohesion E = {st[1] / st[0]:.3f}   distinct nodes per active lane = {st[2] / max(st[3], 1):.3f}", flush=True)
             if a.variant in (7, 9):
                 import ctypes as C
                 st = (C.c_uint64 * 8)()
