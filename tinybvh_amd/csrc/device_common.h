@@ -88,4 +88,17 @@ struct QueryArgs {
     float freshTmax;
 };
 
+// A float4 array known to live in global memory.  Pointers that were themselves loaded from
+// memory (per-BLAS node / triangle bases) are generic to the compiler, and loads through them
+// become flat_load: same latency, but they also hold lgkmcnt, so LDS stack traffic and node
+// fetches serialise.  GlobalF4 carries the address space, so the loads stay global_load.
+typedef float tbvh_f4 __attribute__((ext_vector_type(4)));
+struct GlobalF4 {
+    const __attribute__((address_space(1))) tbvh_f4* p;
+    __device__ __forceinline__ GlobalF4() : p(nullptr) {}
+    __device__ __forceinline__ explicit GlobalF4(const float4* q) : p((const __attribute__((address_space(1))) tbvh_f4*)q) {}
+    __device__ __forceinline__ float4 operator[](size_t i) const { const tbvh_f4 v = p[i]; return make_float4(v.x, v.y, v.z, v.w); }
+    __device__ __forceinline__ GlobalF4 operator+(size_t o) const { GlobalF4 r; r.p = p + o; return r; }
+};
+
 }  // namespace tbvh

@@ -15,6 +15,7 @@
 // replacement from a wave-local pool, one triangle + one node per lane and iteration, traversal
 // stack per lane in LDS with a global spill area.
 #include "device_common.h"
+#include "lane_stack.h"
 #include "ray_pool.h"
 #include "kernels.h"
 
@@ -76,11 +77,8 @@ __global__ __launch_bounds__(WGC) void k_cwbvh_c(const float4* __restrict__ node
     __syncthreads();
 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint2* const spill = (uint2*)q.spill + ((size_t)blockIdx.x * WGC + threadIdx.x);
-    const size_t spillStride = (size_t)gridDim.x * WGC;
-    const uint32_t spillCap = q.spillStride;
-    int sp = 0;
-    bool overflow = false;
+    LaneStack<uint2, LDS_N, 64> st;
+    st.init(&stk[wave][0][lane], (uint2*)q.spill + ((size_t)blockIdx.x * WGC + threadIdx.x), (size_t)gridDim.x * WGC, q.spillStride);
     RayPool<64> pool;
     pool.init();
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
@@ -107,7 +105,7 @@ __global__ __launch_bounds__(WGC) void k_cwbvh_c(const float4* __restrict__ node
                     oct = 7u - ((D.x < 0 ? 4u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 1u : 0u));
                     octinv4 = oct * 0x01010101u;
                     ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
-                    sp = 0;
+                    st.reset();
                     active = true;
                 }
             }
@@ -130,11 +128,8 @@ __global__ __launch_bounds__(WGC) void k_cwbvh_c(const float4* __restrict__ node
         }
         if (!done && tg.y == 0) {
             if (ng.y <= 0x00FFFFFFu) {
-                if (sp == 0) done = true;
-                else {
-                    sp--;
-                    ng = sp < LDS_N ? stk[wave][sp][lane] : spill[(size_t)(sp - LDS_N) * spillStride];
-                }
+                if (st.empty()) done = true;
+                else ng = st.pop();
             }
             if (!done) {
                 if (ng.y > 0x00FFFFFFu) {
@@ -142,12 +137,7 @@ __global__ __launch_bounds__(WGC) void k_cwbvh_c(const float4* __restrict__ node
                     const uint32_t bit = 31u - (uint32_t)__clz(ng.y);
                     const uint32_t cbase = ng.x;
                     ng.y &= ~(1u << bit);
-                    if (ng.y > 0x00FFFFFFu) {
-                        if (sp < LDS_N) stk[wave][sp][lane] = ng;
-                        else if ((uint32_t)(sp - LDS_N) < spillCap) spill[(size_t)(sp - LDS_N) * spillStride] = ng;
-                        else overflow = true;
-                        sp++;
-                    }
+                    if (ng.y > 0x00FFFFFFu) st.push(ng);
                     const uint32_t slot = (bit - 24u) ^ oct;
                     const uint32_t ci = cbase + __popc(imask & ~(0xFFFFFFFFu << slot));
                     float4 n0, n1, n2, n3, n4;
@@ -174,7 +164,7 @@ __global__ __launch_bounds__(WGC) void k_cwbvh_c(const float4* __restrict__ node
             active = false;
         }
     }
-    if (overflow) atomicOr(status, 1u);
+    if (st.overflow) atomicOr(status, 1u);
 }
 
 }  // namespace

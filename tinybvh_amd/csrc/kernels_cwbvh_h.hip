@@ -21,6 +21,7 @@
 // (ray_pool.h), at most one triangle test + one node visit per lane and iteration, traversal
 // stack in LDS with a global spill area.
 #include "device_common.h"
+#include "lane_stack.h"
 #include "ray_pool.h"
 #include "kernels.h"
 
@@ -89,11 +90,8 @@ __global__ __launch_bounds__(WG) void k_cwbvh_h(const char* __restrict__ nodes, 
                                                 uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
     const uint32_t lane = threadIdx.x;
-    uint2* const spill = (uint2*)q.spill + (blockIdx.x * WG + lane);
-    const size_t spillStride = (size_t)gridDim.x * WG;
-    const uint32_t spillCap = q.spillStride;
-    int sp = 0;
-    bool overflow = false;
+    LaneStack<uint2, LDS_N, 64> st;
+    st.init(&stk[0][lane], (uint2*)q.spill + (blockIdx.x * WG + lane), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
     pool.init();
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
@@ -122,7 +120,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh_h(const char* __restrict__ nodes, 
                     octinv4 = oct * 0x01010101u;
                     offNX = rD.x < 0 ? 80u : 32u; offNY = rD.y < 0 ? 96u : 48u; offNZ = rD.z < 0 ? 112u : 64u;
                     ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
-                    sp = 0;
+                    st.reset();
                     active = true;
                 }
             }
@@ -147,11 +145,8 @@ __global__ __launch_bounds__(WG) void k_cwbvh_h(const char* __restrict__ nodes, 
         // ---- node phase: lanes without pending triangles ----------------------------------
         if (!done && tg.y == 0) {
             if (ng.y <= 0x00FFFFFFu) {
-                if (sp == 0) done = true;
-                else {
-                    sp--;
-                    ng = sp < LDS_N ? stk[sp][lane] : spill[(size_t)(sp - LDS_N) * spillStride];
-                }
+                if (st.empty()) done = true;
+                else ng = st.pop();
             }
             if (!done) {
                 if (ng.y > 0x00FFFFFFu) {
@@ -159,12 +154,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh_h(const char* __restrict__ nodes, 
                     const uint32_t bit = 31u - (uint32_t)__clz(ng.y);
                     const uint32_t cbase = ng.x;
                     ng.y &= ~(1u << bit);
-                    if (ng.y > 0x00FFFFFFu) {  // siblings left: keep them for later
-                        if (sp < LDS_N) stk[sp][lane] = ng;
-                        else if ((uint32_t)(sp - LDS_N) < spillCap) spill[(size_t)(sp - LDS_N) * spillStride] = ng;
-                        else overflow = true;
-                        sp++;
-                    }
+                    if (ng.y > 0x00FFFFFFu) st.push(ng);
                     const uint32_t slot = (bit - 24u) ^ oct;
                     const uint32_t rel = __popc(imask & ~(0xFFFFFFFFu << slot));
                     const NodeOut r = visit_node_h(nodes, cbase + rel, O, rD, hit.x, octinv4, offNX, offNY, offNZ);
@@ -183,7 +173,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh_h(const char* __restrict__ nodes, 
             active = false;
         }
     }
-    if (overflow) atomicOr(status, 1u);
+    if (st.overflow) atomicOr(status, 1u);
 }
 
 // 80-byte reference node -> 128-byte H node (one thread per node).

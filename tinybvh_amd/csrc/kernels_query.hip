@@ -17,6 +17,7 @@
 // events there: ~6 % of the steps), which is Aila & Laine's "postpone the leaf" idea expressed
 // with wave64 ballots.
 #include "device_common.h"
+#include "lane_stack.h"
 #include "ray_pool.h"
 #include "kernels.h"
 
@@ -29,25 +30,8 @@ constexpr int WG = 64;
 __device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 __device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-// per-lane stack of 32-bit entries: [entry][lane] in LDS, [entry][globalLane] in the spill area
-template <int LDS_N> struct Stack32 {
-    uint32_t (*lds)[WG];
-    uint32_t* spill;
-    size_t spillStride;
-    uint32_t spillCap;
-    int sp;
-    bool overflow;
-    __device__ __forceinline__ void push(uint32_t v) {
-        if (sp < LDS_N) lds[sp][threadIdx.x] = v;
-        else if ((uint32_t)(sp - LDS_N) < spillCap) spill[(size_t)(sp - LDS_N) * spillStride] = v;
-        else { overflow = true; return; }
-        sp++;
-    }
-    __device__ __forceinline__ uint32_t pop() {
-        sp--;
-        return sp < LDS_N ? lds[sp][threadIdx.x] : spill[(size_t)(sp - LDS_N) * spillStride];
-    }
-};
+// per-lane stack of 32-bit entries: [entry][lane] in LDS, [entry][globalLane] in the spill area (lane_stack.h)
+template <int LDS_N> using Stack32 = LaneStack<uint32_t, LDS_N, WG>;
 
 // ---------------------------------------------------------------------------------------
 // BVH_GPU (Aila-Laine 2-wide).  nodes: 4 x float4 per node, verbatim BVH_GPU::bvhNode.
@@ -59,8 +43,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
                                              uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
     Stack32<LDS_N> st;
-    st.lds = stk; st.spill = q.spill + (blockIdx.x * WG + threadIdx.x); st.spillStride = (size_t)gridDim.x * WG;
-    st.spillCap = q.spillStride; st.sp = 0; st.overflow = false;
+    st.init(&stk[0][threadIdx.x], q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
     pool.init();
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
@@ -162,8 +145,7 @@ template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN>
 __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
     Stack32<LDS_N> st;
-    st.lds = stk; st.spill = q.spill + (blockIdx.x * WG + threadIdx.x); st.spillStride = (size_t)gridDim.x * WG;
-    st.spillCap = q.spillStride; st.sp = 0; st.overflow = false;
+    st.init(&stk[0][threadIdx.x], q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
     pool.init();
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)

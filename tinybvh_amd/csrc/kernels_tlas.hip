@@ -16,6 +16,7 @@
 // (oracle/tbvh_oracle.c: orc_xform_point / orc_xform_vec), and this file is built with
 // -ffp-contract=off, so the transformed ray — and therefore t,u,v — match bit for bit.
 #include "device_common.h"
+#include "lane_stack.h"
 #include "ray_pool.h"
 #include "kernels.h"
 
@@ -33,24 +34,7 @@ __device__ __forceinline__ float safercp(float x) {
     return x >= 0 ? kFar : -kFar;
 }
 
-struct Stack {
-    uint2* lds;     // &stk[0][lane], entry stride WG
-    uint2* spill;   // per-lane spill base, entry stride spillStride
-    size_t spillStride;
-    uint32_t spillCap;
-    int sp;
-    bool overflow;
-    template <int LDS_N> __device__ __forceinline__ void push(uint2 v) {
-        if (sp < LDS_N) lds[sp * WG] = v;
-        else if ((uint32_t)(sp - LDS_N) < spillCap) spill[(size_t)(sp - LDS_N) * spillStride] = v;
-        else { overflow = true; return; }
-        sp++;
-    }
-    template <int LDS_N> __device__ __forceinline__ uint2 pop() {
-        sp--;
-        return sp < LDS_N ? lds[sp * WG] : spill[(size_t)(sp - LDS_N) * spillStride];
-    }
-};
+typedef LaneStack<uint2, 16, WG> Stack;   // LDS top + global spill (lane_stack.h)
 
 struct RayL {  // a ray in some space + its current best hit
     float3 O, D, rD;
@@ -61,7 +45,7 @@ struct RayL {  // a ray in some space + its current best hit
 // ---- BLAS traversals; each runs until the stack is back at `base` ------------------------------
 
 template <bool ANYHIT, int LDS_N>
-__device__ __forceinline__ void blas_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris, RayL& r, Stack& st) {
+__device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 tris, RayL& r, Stack& st) {
     const int base = st.sp;
     const uint32_t oct = 7u - ((r.D.x < 0 ? 4u : 0u) | (r.D.y < 0 ? 2u : 0u) | (r.D.z < 0 ? 1u : 0u));
     const uint32_t octinv4 = oct * 0x01010101u;
@@ -72,7 +56,7 @@ __device__ __forceinline__ void blas_cwbvh(const float4* __restrict__ nodes, con
             const uint32_t bit = 31u - (uint32_t)__clz(ng.y);
             const uint32_t cbase = ng.x;
             ng.y &= ~(1u << bit);
-            if (ng.y > 0x00FFFFFFu) st.push<LDS_N>(ng);
+            if (ng.y > 0x00FFFFFFu) st.push(ng);
             const uint32_t slot = (bit - 24u) ^ oct;
             const uint32_t ci = (cbase + __popc(imask & ~(0xFFFFFFFFu << slot))) * 5u;
             const float4 n0 = nodes[ci], n1 = nodes[ci + 1], n2 = nodes[ci + 2], n3 = nodes[ci + 3], n4 = nodes[ci + 4];
@@ -125,12 +109,12 @@ __device__ __forceinline__ void blas_cwbvh(const float4* __restrict__ nodes, con
         }
         if (ng.y > 0x00FFFFFFu) continue;
         if (st.sp == base) return;
-        ng = st.pop<LDS_N>();
+        ng = st.pop();
     }
 }
 
 template <bool ANYHIT, int LDS_N>
-__device__ __forceinline__ void blas_bvh4(const float4* __restrict__ data, RayL& r, Stack& st) {
+__device__ __forceinline__ void blas_bvh4(const GlobalF4 data, RayL& r, Stack& st) {
     const int base = st.sp;
     uint32_t offset = 0;
     for (;;) {
@@ -156,7 +140,7 @@ __device__ __forceinline__ void blas_bvh4(const float4* __restrict__ data, RayL&
 #undef TBVH_CSWAP
 #pragma unroll
         for (int i = 0; i < 4; i++)
-            if (dist[i] < kFar && !(info[i] & 0x80000000u)) st.push<LDS_N>(make_uint2(info[i], 0u));
+            if (dist[i] < kFar && !(info[i] & 0x80000000u)) st.push(make_uint2(info[i], 0u));
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (!(dist[i] < kFar) || !(info[i] & 0x80000000u)) continue;
@@ -173,7 +157,7 @@ __device__ __forceinline__ void blas_bvh4(const float4* __restrict__ data, RayL&
             }
         }
         if (st.sp == base) return;
-        offset = st.pop<LDS_N>().x;
+        offset = st.pop().x;
     }
 }
 
@@ -185,9 +169,7 @@ __global__ __launch_bounds__(WG) void k_tlas(const float4* __restrict__ tlasNode
     constexpr int LDS_N = 16;
     __shared__ uint2 stk[LDS_N][WG];
     Stack st;
-    st.lds = &stk[0][threadIdx.x];
-    st.spill = (uint2*)q.spill + (blockIdx.x * WG + threadIdx.x);
-    st.spillStride = (size_t)gridDim.x * WG; st.spillCap = q.spillStride; st.sp = 0; st.overflow = false;
+    st.init(&stk[0][threadIdx.x], (uint2*)q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
     pool.init();
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
@@ -231,13 +213,13 @@ __global__ __launch_bounds__(WG) void k_tlas(const float4* __restrict__ tlasNode
                     rl.rD = make_float3(safercp(rl.D.x), safercp(rl.D.y), safercp(rl.D.z));
                     rl.hit = hit; rl.found = false;
                     const BlasDesc bd = blas[as_u32(b0.w)];
-                    if (BLAS_LAYOUT == 9) blas_cwbvh<ANYHIT, LDS_N>(bd.nodes, bd.tris, rl, st);
-                    else blas_bvh4<ANYHIT, LDS_N>(bd.nodes, rl, st);
+                    if (BLAS_LAYOUT == 9) blas_cwbvh<ANYHIT, LDS_N>(GlobalF4(bd.nodes), GlobalF4(bd.tris), rl, st);
+                    else blas_bvh4<ANYHIT, LDS_N>(GlobalF4(bd.nodes), rl, st);
                     if (rl.found) { found = true; hit = rl.hit; hitInst = ii; if (ANYHIT) break; }
                 }
                 if (ANYHIT && found) break;
                 if (st.sp == 0) break;
-                node = st.pop<LDS_N>().x;
+                node = st.pop().x;
                 continue;
             }
             // SLAB_TEST_TWO_NODES form (tiny_bvh.h:3202-3220), as in the BVH_GPU kernel
@@ -255,13 +237,13 @@ __global__ __launch_bounds__(WG) void k_tlas(const float4* __restrict__ tlasNode
             uint32_t l = as_u32(n0.w), r = as_u32(n1.w);
             if (hL && hR) {
                 if (tminL > tminR) { const uint32_t t = l; l = r; r = t; }
-                st.push<LDS_N>(make_uint2(r, 0u));
+                st.push(make_uint2(r, 0u));
                 node = l;
             } else if (hL) node = l;
             else if (hR) node = r;
             else {
                 if (st.sp == 0) break;
-                node = st.pop<LDS_N>().x;
+                node = st.pop().x;
             }
         }
         if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
