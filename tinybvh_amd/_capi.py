@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinybvh_amd.so")
+LIB_PATH = os.environ.get("TBVH_LIB_OVERRIDE") or os.path.join(_HERE, "libtinybvh_amd.so")   # override: A/B builds in tools/
 
 # every symbol include/tinybvh_amd.h declares: name -> (restype, argtypes)
 _u64, _u32, _vp, _i = C.c_uint64, C.c_uint32, C.c_void_p, C.c_int

@@ -14,6 +14,7 @@
 
 #include "host_builder.h"
 #include "kernels.h"
+#include "ray_pool.h"
 
 using namespace tbvh;
 
@@ -48,7 +49,9 @@ struct tbvh_context {
     uint32_t* spill = nullptr;    // stack spill area
     float cohesionThreshold = 0.82f;  // AUTO schedule selection (kernels_cwbvh.hip: launch_cwbvh_auto)
     uint32_t spillEntries = 0;    // 32-bit entries per lane
-    unsigned long long* counter = nullptr;  // ray-fetch counter (+ status word after it)
+    unsigned long long* counter = nullptr;  // status word, instrumentation counters, AUTO select word
+    uint32_t poolParts = 5;   // log2: 32 partitions
+    unsigned long long* pool = nullptr;     // ray-fetch counters: kPoolParts of them, 256 bytes apart (ray_pool.h)
     uint32_t* status = nullptr;
     RayRec* stageRays = nullptr;  // staging for host-array queries
     uint64_t stageCap = 0;
@@ -117,11 +120,11 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     if (int r = setDevice(c)) return r;
     if (n == 0) return 0;
     const bool any = d_occ != nullptr;
-    HIP_TRY(hipMemsetAsync(c->counter, 0, 16, c->stream));
+    HIP_TRY(hipMemsetAsync(c->pool, 0, (size_t)kPoolParts * kPoolCounterStride * 4, c->stream));
     QueryArgs q;
     q.select = nullptr;
     q.rays = d_rays; q.nRays = n; q.occluded = d_occ;
-    q.spill = c->spill; q.counter = (uint32_t*)c->counter;
+    q.spill = c->spill; q.counter = (uint32_t*)c->pool; q.poolParts = c->poolParts;
     q.stats = c->counter + 8;
     q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.probeStride = 1;
     // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
@@ -226,11 +229,16 @@ int tbvh_init(int device, tbvh_context** out) {
         const int b = atoi(e);
         if (b >= 1 && b <= 32) c->blocks = (uint32_t)c->numCUs * (uint32_t)b;
     }
+    if (const char* e = getenv("TBVH_POOL_PARTS")) {  // experiment knob
+        const int b = atoi(e);
+        if (b >= 0 && (1 << b) <= kPoolParts) c->poolParts = (uint32_t)b;   // log2 of the partition count
+    }
     if (const char* e = getenv("TBVH_COHESION_THRESHOLD")) c->cohesionThreshold = (float)atof(e);
     c->spillEntries = 232;  // 32-bit entries per lane beyond the LDS part of the stack
     const size_t spillBytes = (size_t)c->blocks * 64 * c->spillEntries * 4;
     e = hipMalloc((void**)&c->spill, spillBytes);
     if (e == hipSuccess) e = hipMalloc((void**)&c->counter, 256);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->pool, (size_t)kPoolParts * kPoolCounterStride * 4);
     if (e != hipSuccess) { tbvh_shutdown(c); return fail(TBVH_E_NOMEM, "device allocation failed: %s", hipGetErrorString(e)); }
     c->status = (uint32_t*)(c->counter + 4);
     hipMemset(c->counter, 0, 256);
@@ -245,6 +253,7 @@ void tbvh_shutdown(tbvh_context* c) {
     while (!c->scenes.empty()) tbvh_free_scene(c->scenes.back());
     if (c->spill) hipFree(c->spill);
     if (c->counter) hipFree(c->counter);
+    if (c->pool) hipFree(c->pool);
     if (c->stageRays) hipFree(c->stageRays);
     if (c->stageOcc) hipFree(c->stageOcc);
     if (c->ev0) hipEventDestroy(c->ev0);

@@ -79,7 +79,8 @@ struct QueryArgs {
     uint8_t* occluded;     // any-hit output (1 byte per ray) or nullptr
     uint32_t* spill;       // global overflow area for traversal stacks
     uint32_t spillStride;  // entries per lane in `spill`
-    uint32_t* counter;     // dynamic ray-fetch counter (persistent kernels)
+    uint32_t* counter;     // dynamic ray-fetch counters (persistent kernels): poolParts of them, 256 bytes apart
+    uint32_t poolParts;    // log2 of the number of partitions of the batch, each with its own counter (ray_pool.h)
     unsigned long long* stats;  // instrumented variants: lane-utilisation counters
     const unsigned long long* nRaysDev;  // if non-null the batch size is read from device memory (on-device queues)
     const uint32_t* select;  // AUTO schedule selection: 1 = lean kernel runs, 0 = replacement kernel runs; null = no predicate

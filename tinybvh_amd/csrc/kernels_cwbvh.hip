@@ -119,17 +119,17 @@ __device__ __forceinline__ NodeResult visit_node_pk(const float4* __restrict__ n
 
 // MODE 0: whole-wave batches (a wave takes 64 consecutive rays and finishes them all).
 // MODE 1: per-lane replacement from a wave-local pool; REFILL_MIN idle lanes trigger a refill.
-template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false, int TRI_MIN = 1, bool PKFMA = false>
+template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false, int TRI_MIN = 1, bool PKFMA = false, int CHUNK = 64>
 __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
     const uint32_t glane = blockIdx.x * WG + threadIdx.x;
     LaneStack<uint2, LDS_N, WG> st;
     st.init(&stk[0][threadIdx.x], (uint2*)q.spill + glane, gridDim.x * WG, q.spillStride);
-    RayPool<(MODE == 0 ? 64 : 64)> pool;
-    pool.init();
+    RayPool<CHUNK> pool;
     if (q.select && *q.select != 0u) return;   // AUTO mode: the lean schedule was chosen for this batch
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
+    pool.init(q.poolParts);
 
     bool active = false;
     uint64_t ri = 0;
@@ -145,9 +145,9 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
         const uint64_t idleMask = __ballot(!active);
         const uint32_t nIdle = (uint32_t)__popcll(idleMask);
         if ((MODE == 0 ? nIdle == (uint32_t)WG : nIdle >= (uint32_t)REFILL_MIN) || (nIdle == (uint32_t)WG)) {
-            if (!(pool.exhausted && pool.next == pool.end)) {
+            if (!pool.dry()) {
                 uint64_t nri = 0;
-                const bool got = pool.acquire(!active, (unsigned long long*)q.counter, nRaysTotal, nri);
+                const bool got = pool.acquire(!active, q.counter, nRaysTotal, nri);
                 if (STATS) { sRefill++; sRefilled += __popcll(__ballot(got)); }
                 if (got) {
                     ri = nri;
@@ -451,6 +451,9 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
         break;
     case 10: TBVH_LAUNCH(1, 8, 8, true); break;
     case 16: TBVH_LAUNCH(1, 8, 16, true, false, 1, true); break;  // packed plane FMAs
+    case 17: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 128); break;   // pool chunk sizes: one global atomic per CHUNK rays
+    case 18: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 256); break;
+    case 19: TBVH_LAUNCH(0, 16, 64, false, false, 1, false, 256); break;  // whole-wave batches, chunk 256
     case 13: TBVH_LAUNCH(1, 8, 16, true, false, 8); break;    // triangle phase only when >= 8 lanes wait
     case 14: TBVH_LAUNCH(1, 8, 16, true, false, 16); break;
     case 15: TBVH_LAUNCH(1, 8, 16, true, false, 24); break;
@@ -463,6 +466,6 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
 #undef TBVH_LAUNCH
 }
 
-bool cwbvh_variant_valid(int v) { return (v >= 0 && v <= 16) || (v >= 40 && v <= 43); }
+bool cwbvh_variant_valid(int v) { return (v >= 0 && v <= 19) || (v >= 40 && v <= 43); }
 
 }  // namespace tbvh

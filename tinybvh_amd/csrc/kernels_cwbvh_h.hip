@@ -93,8 +93,8 @@ __global__ __launch_bounds__(WG) void k_cwbvh_h(const char* __restrict__ nodes, 
     LaneStack<uint2, LDS_N, 64> st;
     st.init(&stk[0][lane], (uint2*)q.spill + (blockIdx.x * WG + lane), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
-    pool.init();
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
+    pool.init(q.poolParts);
 
     bool active = false;
     uint64_t ri = 0;
@@ -108,9 +108,9 @@ __global__ __launch_bounds__(WG) void k_cwbvh_h(const char* __restrict__ nodes, 
         // ---- ray replacement ---------------------------------------------------------------
         const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
         if (nIdle >= (uint32_t)REFILL_MIN) {
-            if (!(pool.exhausted && pool.next == pool.end)) {
+            if (!pool.dry()) {
                 uint64_t nri = 0;
-                if (pool.acquire(!active, (unsigned long long*)q.counter, nRaysTotal, nri)) {
+                if (pool.acquire(!active, q.counter, nRaysTotal, nri)) {
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);

@@ -45,8 +45,8 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
     Stack32<LDS_N> st;
     st.init(&stk[0][threadIdx.x], q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
-    pool.init();
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
+    pool.init(q.poolParts);
 
     bool active = false;
     uint64_t ri = 0;
@@ -58,9 +58,9 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
     for (;;) {
         const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
         if (nIdle >= (uint32_t)REFILL_MIN) {
-            if (!(pool.exhausted && pool.next == pool.end)) {
+            if (!pool.dry()) {
                 uint64_t nri = 0;
-                if (pool.acquire(!active, (unsigned long long*)q.counter, nRaysTotal, nri)) {
+                if (pool.acquire(!active, q.counter, nRaysTotal, nri)) {
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
     Stack32<LDS_N> st;
     st.init(&stk[0][threadIdx.x], q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
-    pool.init();
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
+    pool.init(q.poolParts);
 
     bool active = false;
     uint64_t ri = 0;
@@ -165,9 +165,9 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
     for (;;) {
         const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
         if (nIdle >= (uint32_t)REFILL_MIN) {
-            if (!(pool.exhausted && pool.next == pool.end)) {
+            if (!pool.dry()) {
                 uint64_t nri = 0;
-                if (pool.acquire(!active, (unsigned long long*)q.counter, nRaysTotal, nri)) {
+                if (pool.acquire(!active, q.counter, nRaysTotal, nri)) {
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);

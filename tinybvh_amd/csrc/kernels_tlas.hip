@@ -171,12 +171,12 @@ __global__ __launch_bounds__(WG) void k_tlas(const float4* __restrict__ tlasNode
     Stack st;
     st.init(&stk[0][threadIdx.x], (uint2*)q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
-    pool.init();
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
+    pool.init(q.poolParts);
     for (;;) {
         // whole-wave batches here: the nested TLAS/BLAS loops keep per-lane state in registers
         uint64_t ri = 0;
-        const bool got = pool.acquire(true, (unsigned long long*)q.counter, nRaysTotal, ri);
+        const bool got = pool.acquire(true, q.counter, nRaysTotal, ri);
         if (__ballot(got) == 0) break;
         if (!got) continue;
         RayRec* rp = q.rays + ri;

@@ -1,14 +1,26 @@
 // ray_pool.h — persistent-wave ray scheduling with per-lane replacement.
 //
-// Every wave keeps a small wave-uniform pool [next, end) of consecutive ray indices taken
-// from the global counter with one atomic per CHUNK rays.  Whenever enough lanes are idle
-// (their ray finished), the idle lanes are handed the next indices of the pool in lane
-// order — no atomic, no LDS.  Lanes therefore never wait for the slowest ray of a batch;
-// the price is that a wave's 64 rays are no longer one contiguous tile.
+// Every wave keeps a small wave-uniform pool [next, end) of consecutive ray indices.  Whenever
+// enough lanes are idle (their ray finished), the idle lanes are handed the next indices of the
+// pool in lane order — no atomic, no LDS.  Lanes therefore never wait for the slowest ray of a
+// batch; the price is that a wave's 64 rays are no longer one contiguous tile.
+//
+// The pool is refilled CHUNK rays at a time from global counters.  A single counter caps the
+// whole GPU at about 80 M chunk fetches per second (measured on MI355X: same-address device-scope
+// atomics are serialised memory-side at ~12 ns each; with 64-ray chunks that is a hard 5.1 GRays/s
+// ceiling, reached on the Sponza stand-in).  The chunks of a batch are therefore dealt round-robin
+// to 2^partsLog2 STRIPES, each with its own counter on its own 256-byte line: stripe p owns chunks
+// p, p + P, p + 2P, ...  A wave draws from stripe blockIdx % P for its whole life.  Every stripe
+// is a uniform sample of the batch, so the stripes run dry within about one chunk of each other
+// and no stealing is needed; the batch is still consumed as ONE front (good for the L2s), and
+// consecutive chunks go to different XCDs just as consecutive workgroups of a plain launch would.
 #pragma once
 #include "device_common.h"
 
 namespace tbvh {
+
+constexpr int kPoolParts = 64;          // most partitions / counters a batch can have (the launch picks q.poolParts <= this)
+constexpr int kPoolCounterStride = 64;  // in uint32_t: 256 bytes between counters
 
 __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     // number of set bits of `mask` below this lane
@@ -16,14 +28,22 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
 }
 
 template <int CHUNK> struct RayPool {
-    uint64_t next, end;  // wave-uniform
-    bool exhausted;      // wave-uniform: the global counter ran past nRays
+    static_assert(CHUNK % 64 == 0, "chunks are whole 64-ray groups");
+    uint64_t next, end;   // wave-uniform: rays in hand
+    uint32_t stripe;      // wave-uniform: this wave's stripe
+    uint32_t partsLog2;   // the batch's chunks are dealt to 2^partsLog2 stripes
+    bool exhausted;       // wave-uniform: the stripe ran past the end of the batch
 
-    __device__ __forceinline__ void init() { next = end = 0; exhausted = false; }
+    __device__ __forceinline__ void init(uint32_t log2Parts) {
+        next = end = 0; exhausted = false; partsLog2 = log2Parts;
+        stripe = blockIdx.x & ((1u << log2Parts) - 1u);
+    }
+    __device__ __forceinline__ bool dry() const { return exhausted && next == end; }
 
     // Hands out ray indices to the lanes whose `idle` is set.  Returns true for lanes that
     // received one (in `ri`).  Must be called by the whole wave (convergent).
-    __device__ __forceinline__ bool acquire(bool idle, unsigned long long* counter, uint64_t nRays, uint64_t& ri) {
+    // counters: one 32-bit count per stripe (rays of that stripe already handed out), kPoolCounterStride apart.
+    __device__ __forceinline__ bool acquire(bool idle, uint32_t* counters, uint64_t nRays, uint64_t& ri) {
         const uint64_t idleMask = __ballot(idle);
         uint32_t need = (uint32_t)__popcll(idleMask);
         uint32_t given = 0;  // indices handed out before this round, per call
@@ -32,12 +52,11 @@ template <int CHUNK> struct RayPool {
         while (need > 0) {
             if (next == end) {
                 if (exhausted) break;
-                unsigned long long base = 0;
+                uint32_t base = 0;
                 if ((threadIdx.x & 63u) == 0)  // the whole wave is here (convergent call)
-                    base = atomicAdd(counter, (unsigned long long)CHUNK);
-                const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base);
-                const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
-                next = ((uint64_t)hi << 32) | lo;
+                    base = atomicAdd(counters + (size_t)stripe * kPoolCounterStride, (uint32_t)CHUNK);
+                // the stripe's k-th chunk is chunk k * P + stripe of the batch
+                next = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(base) << partsLog2) + (uint64_t)stripe * CHUNK;
                 end = next + CHUNK;
                 if (end >= nRays) { end = nRays; exhausted = true; }
                 if (next >= nRays) { next = end = 0; exhausted = true; break; }
