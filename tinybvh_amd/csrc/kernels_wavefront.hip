@@ -40,16 +40,25 @@ __device__ __forceinline__ void put_ray(RayRec* r, float3 O, float3 D, float tma
     r->hit = make_float4(tmax, 0.f, 0.f, 0.f);
 }
 
-// wave-aggregated append: returns this lane's slot in the queue (or ~0 if !want)
-__device__ __forceinline__ uint32_t queue_slot(bool want, unsigned long long* counter) {
+// Block-aggregated append: returns this thread's slot in the queue (or ~0 if !want).  ONE global atomic per
+// workgroup and queue: same-address atomics are serialised memory-side at ~12 ns each on MI355X, so a
+// per-wave append (262 k atomics for a 16.7 M-path stage) would cost milliseconds by itself.
+// Must be reached by every thread of the workgroup.  sh: kShadeWaves + 1 words of LDS.
+constexpr int kShadeBlock = 512, kShadeWaves = kShadeBlock / 64;
+__device__ __forceinline__ uint32_t queue_slot(bool want, unsigned long long* counter, uint32_t* sh) {
     const uint64_t m = __ballot(want);
-    if (m == 0) return 0xffffffffu;
-    const uint32_t n = (uint32_t)__popcll(m);
-    unsigned long long base = 0;
-    const int leader = __ffsll((unsigned long long)m) - 1;
-    if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(counter, (unsigned long long)n);
-    base = __shfl(base, leader);
-    return want ? (uint32_t)base + lane_rank(m) : 0xffffffffu;
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) sh[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < kShadeWaves; w++) { const uint32_t t = sh[w]; sh[w] = tot; tot += t; }
+        sh[kShadeWaves] = tot ? (uint32_t)atomicAdd(counter, (unsigned long long)tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t slot = sh[kShadeWaves] + sh[wave] + lane_rank(m);
+    __syncthreads();   // sh is reused by the next append
+    return want ? slot : 0xffffffffu;
 }
 
 __global__ void k_wf_generate(CameraArgs cam, RayRec* __restrict__ rays, PathAux* __restrict__ aux, uint64_t n, uint32_t seed) {
@@ -72,7 +81,8 @@ __global__ void k_wf_generate(CameraArgs cam, RayRec* __restrict__ rays, PathAux
     aux[i].pixel = py * cam.width + px;
 }
 
-__global__ void k_wf_shade(ShadeArgs a) {
+__global__ __launch_bounds__(kShadeBlock) void k_wf_shade(ShadeArgs a) {
+    __shared__ uint32_t qsh[kShadeWaves + 1];
     const uint64_t n = *a.nIn;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < n;
@@ -128,14 +138,14 @@ __global__ void k_wf_shade(ShadeArgs a) {
             }
         }
     }
-    // the whole wave takes part in the two queue appends
-    const uint32_t sb = queue_slot(wantBounce, a.nOut);
+    // the whole workgroup takes part in the two queue appends
+    const uint32_t sb = queue_slot(wantBounce, a.nOut, qsh);
     if (wantBounce) {
         put_ray(a.out + sb, make_float3(I.x + R.x * a.eps, I.y + R.y * a.eps, I.z + R.z * a.eps), R, kFar);
         PathAux o; o.T[0] = T.x; o.T[1] = T.y; o.T[2] = T.z; o.pixel = pixel;
         a.auxOut[sb] = o;
     }
-    const uint32_t ss = queue_slot(wantShadow, a.nShadow);
+    const uint32_t ss = queue_slot(wantShadow, a.nShadow, qsh);
     if (wantShadow) {
         put_ray(a.shadow + ss, make_float3(I.x + L.x * a.eps, I.y + L.y * a.eps, I.z + L.z * a.eps), L, ldist - 2.0f * a.eps);
         PathAux o; o.T[0] = contrib.x; o.T[1] = contrib.y; o.T[2] = contrib.z; o.pixel = pixel;
@@ -157,7 +167,7 @@ void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint6
     hipLaunchKernelGGL(k_wf_generate, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, cam, rays, aux, n, seed);
 }
 void launch_wf_shade(const ShadeArgs& a, uint64_t capacity, hipStream_t s) {
-    hipLaunchKernelGGL(k_wf_shade, dim3((uint32_t)((capacity + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(k_wf_shade, dim3((uint32_t)((capacity + kShadeBlock - 1) / kShadeBlock)), dim3(kShadeBlock), 0, s, a);
 }
 void launch_wf_connect(const uint8_t* occ, const PathAux* aux, const unsigned long long* nShadow, float* accum, uint64_t capacity, hipStream_t s) {
     hipLaunchKernelGGL(k_wf_connect, dim3((uint32_t)((capacity + 255) / 256)), dim3(256), 0, s, occ, aux, nShadow, accum);
