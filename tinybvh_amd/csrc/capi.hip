@@ -47,10 +47,10 @@ struct tbvh_context {
     int numCUs = 0;
     uint32_t blocks = 0;          // persistent grid size (64-thread workgroups)
     uint32_t* spill = nullptr;    // stack spill area
-    float cohesionThreshold = 0.82f;  // AUTO schedule selection (kernels_cwbvh.hip: launch_cwbvh_auto)
     uint32_t spillEntries = 0;    // 32-bit entries per lane
-    unsigned long long* counter = nullptr;  // status word, instrumentation counters, AUTO select word
+    unsigned long long* counter = nullptr;  // status word, instrumentation counters
     uint32_t poolParts = 5;   // log2: 32 partitions
+    uint32_t raysPerBlock = 192;   // small batches: one workgroup per this many rays (measured best of 128..384 on 1 M-ray batches)
     unsigned long long* pool = nullptr;     // ray-fetch counters: kPoolParts of them, 256 bytes apart (ray_pool.h)
     uint32_t* status = nullptr;
     RayRec* stageRays = nullptr;  // staging for host-array queries
@@ -122,15 +122,14 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     const bool any = d_occ != nullptr;
     HIP_TRY(hipMemsetAsync(c->pool, 0, (size_t)kPoolParts * kPoolCounterStride * 4, c->stream));
     QueryArgs q;
-    q.select = nullptr;
     q.rays = d_rays; q.nRays = n; q.occluded = d_occ;
     q.spill = c->spill; q.counter = (uint32_t*)c->pool; q.poolParts = c->poolParts;
     q.stats = c->counter + 8;
-    q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.probeStride = 1;
+    q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev;
     // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
-    // (about one workgroup per 256 rays, measured best for 1 M-ray launches) so every wave still
+    // (about one workgroup per 192 rays, measured best for 1 M-ray launches) so every wave still
     // has a few ray replacements' worth of work
-    uint64_t want = (n + 255) / 256;
+    uint64_t want = (n + c->raysPerBlock - 1) / c->raysPerBlock;
     const uint32_t lo = (uint32_t)c->numCUs * 4u;
     const uint32_t blocks = (uint32_t)(want < lo ? lo : (want > c->blocks ? c->blocks : want));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -155,12 +154,6 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         q.spillStride = c->spillEntries / 2;  // 8-byte entries
         if (s->variant >= 30 && s->variant < 40) launch_cwbvh_c(any, s->variant, s->nodesP, s->tris, s->nNodes, q, c->status, (uint32_t)c->numCUs, c->stream);
         else if (s->variant >= 20 && s->variant < 30) launch_cwbvh_h(any, s->variant, s->nodesH, s->tris, q, c->status, blocks, c->stream);
-        else if (s->variant == 43) {
-            // AUTO: probe the batch's lane cohesion, then run the schedule that suits it
-            HIP_TRY(hipMemsetAsync(c->counter + 8, 0, 32, c->stream));
-            q.select = (const uint32_t*)(c->counter + 16);
-            launch_cwbvh_auto(any, s->nodes, s->tris, q, c->status, blocks, (uint32_t)c->numCUs * 256u, c->cohesionThreshold, c->stream);
-        }
         else launch_cwbvh(any, s->variant, s->nodes, s->tris, q, c->status, blocks, c->stream);
         break;
     default:
@@ -229,11 +222,14 @@ int tbvh_init(int device, tbvh_context** out) {
         const int b = atoi(e);
         if (b >= 1 && b <= 32) c->blocks = (uint32_t)c->numCUs * (uint32_t)b;
     }
+    if (const char* e = getenv("TBVH_RAYS_PER_BLOCK")) {  // experiment knob
+        const int b = atoi(e);
+        if (b >= 64 && b <= 4096) c->raysPerBlock = (uint32_t)b;
+    }
     if (const char* e = getenv("TBVH_POOL_PARTS")) {  // experiment knob
         const int b = atoi(e);
         if (b >= 0 && (1 << b) <= kPoolParts) c->poolParts = (uint32_t)b;   // log2 of the partition count
     }
-    if (const char* e = getenv("TBVH_COHESION_THRESHOLD")) c->cohesionThreshold = (float)atof(e);
     c->spillEntries = 232;  // 32-bit entries per lane beyond the LDS part of the stack
     const size_t spillBytes = (size_t)c->blocks * 64 * c->spillEntries * 4;
     e = hipMalloc((void**)&c->spill, spillBytes);

@@ -83,8 +83,6 @@ struct QueryArgs {
     uint32_t poolParts;    // log2 of the number of partitions of the batch, each with its own counter (ray_pool.h)
     unsigned long long* stats;  // instrumented variants: lane-utilisation counters
     const unsigned long long* nRaysDev;  // if non-null the batch size is read from device memory (on-device queues)
-    const uint32_t* select;  // AUTO schedule selection: 1 = lean kernel runs, 0 = replacement kernel runs; null = no predicate
-    uint32_t probeStride;  // probe launches: trace every probeStride-th group of 64 rays
     uint32_t fresh;        // 1: ignore the stored hit, start every ray from {freshTmax,0,0,0} and always write the record
     float freshTmax;
 };

@@ -119,7 +119,14 @@ __device__ __forceinline__ NodeResult visit_node_pk(const float4* __restrict__ n
 
 // MODE 0: whole-wave batches (a wave takes 64 consecutive rays and finishes them all).
 // MODE 1: per-lane replacement from a wave-local pool; REFILL_MIN idle lanes trigger a refill.
-template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false, int TRI_MIN = 1, bool PKFMA = false, int CHUNK = 64>
+// ADAPT: every wave starts in LOCKSTEP (it takes 64 new rays only when all 64 lanes are idle, so the lanes
+// stay in the same phase and touch the same nodes: fastest for coherent batches) and measures each
+// generation's lane cohesion = active lane-iterations / (64 x iterations); when the running estimate falls
+// below kLockstepKeep, or a single generation has already wasted more than 1 - kLockstepBail, the wave
+// switches for the rest of the launch to per-lane replacement (REFILL_MIN idle lanes trigger a refill:
+// fastest for incoherent batches).  No separate probe pass, no host-side decision.
+constexpr uint32_t kLockstepKeep = 184, kLockstepBail = 179;   // x / 256: 0.72, 0.70
+template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false, int TRI_MIN = 1, bool PKFMA = false, int CHUNK = 64, bool ADAPT = false>
 __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -127,7 +134,6 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     LaneStack<uint2, LDS_N, WG> st;
     st.init(&stk[0][threadIdx.x], (uint2*)q.spill + glane, gridDim.x * WG, q.spillStride);
     RayPool<CHUNK> pool;
-    if (q.select && *q.select != 0u) return;   // AUTO mode: the lean schedule was chosen for this batch
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
     pool.init(q.poolParts);
 
@@ -138,13 +144,31 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     bool found = false;
     uint32_t oct = 0, octinv4 = 0;
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    bool lockstep = ADAPT;                          // ADAPT only; wave-uniform
+    uint32_t genIters = 0, genActive = 0, ema = 0;  // ADAPT only; wave-uniform
     unsigned long long sIter = 0, sActive = 0, sNode = 0, sTriIter = 0, sTri = 0, sRefill = 0, sRefilled = 0;  // STATS only
 
     for (;;) {
         // ---- ray replacement -------------------------------------------------------------
         const uint64_t idleMask = __ballot(!active);
         const uint32_t nIdle = (uint32_t)__popcll(idleMask);
-        if ((MODE == 0 ? nIdle == (uint32_t)WG : nIdle >= (uint32_t)REFILL_MIN) || (nIdle == (uint32_t)WG)) {
+        if (ADAPT && lockstep) {
+            genIters++; genActive += (uint32_t)WG - nIdle;
+            if (nIdle == (uint32_t)WG) {   // a generation ended: fold its cohesion into the running estimate
+                if (genIters > 1) {
+                    const uint32_t e = genActive * 4u / genIters;   // x / 256
+                    ema = ema ? (ema + e) >> 1 : e;
+                    if (STATS) {   // histogram of per-generation cohesion, 8 bins: <.5 .5-.6 .6-.7 .7-.75 .75-.8 .8-.85 .85-.9 >=.9
+                        const uint32_t b = e < 128u ? 0u : e < 154u ? 1u : e < 179u ? 2u : e < 192u ? 3u : e < 205u ? 4u : e < 218u ? 5u : e < 230u ? 6u : 7u;
+                        if (threadIdx.x == 0) atomicAdd(q.stats + b, 1ull);
+                    } else if (ema < kLockstepKeep) lockstep = false;
+                }
+                genIters = 0; genActive = 0;
+            } else if (!STATS && genIters >= 16u && genActive * 4u < kLockstepBail * genIters) lockstep = false;
+        }
+        const bool wantRefill = ADAPT ? (lockstep ? nIdle == (uint32_t)WG : nIdle >= (uint32_t)REFILL_MIN)
+                                      : (MODE == 0 ? nIdle == (uint32_t)WG : nIdle >= (uint32_t)REFILL_MIN);
+        if (wantRefill || (nIdle == (uint32_t)WG)) {
             if (!pool.dry()) {
                 uint64_t nri = 0;
                 const bool got = pool.acquire(!active, q.counter, nRaysTotal, nri);
@@ -269,7 +293,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
         }
     }
     if (st.overflow) atomicOr(status, 1u);
-    if (STATS) {
+    if (STATS && !ADAPT) {
         // sTriIter was counted by the first active lane of each tri iteration: reduce over the wave
         unsigned long long ti = sTriIter;
         for (int o = 32; o > 0; o >>= 1) { ti += __shfl_xor(ti, o); sTri += __shfl_xor(sTri, o); }
@@ -288,25 +312,21 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
 // tools/vs_reference_opencl.py).  Stack: STACK_N entries per lane in private (scratch) memory,
 // like the reference kernel's `uint2 stack[32]` (traverse_cwbvh.cl:133); deeper trees are
 // reported through the status word, never silently mis-traversed.
-template <bool ANYHIT, int STACK_N, bool PROBE = false, int PROBE_STEPS = 48>
+template <bool ANYHIT, int STACK_N>
 __global__ __launch_bounds__(WG) void k_cwbvh_lean(const float4* __restrict__ nodes, const float4* __restrict__ tris, QueryArgs q,
                                                    uint32_t* __restrict__ status) {
-    if (!PROBE && q.select && *q.select != 1u) return;   // AUTO mode: the replacement schedule was chosen
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;
-    // PROBE: trace a strided sample of wave-groups for a bounded number of steps without writing
-    // anything, and record how well the 64 lanes of a wave stay together (sum of participating
-    // lanes / 64 x wave steps).  Otherwise: groups are dealt to the grid round-robin (static
-    // assignment: camera-like batches cost about the same per group).
+    // groups are dealt to the grid round-robin (static assignment: camera-like batches cost about the
+    // same per group)
     const uint64_t nGroups = (nRaysTotal + WG - 1) / WG;
     bool overflow = false;
-  for (uint64_t group = PROBE ? (uint64_t)blockIdx.x * q.probeStride : (uint64_t)blockIdx.x; group < nGroups; group += PROBE ? nGroups : gridDim.x) {
+  for (uint64_t group = blockIdx.x; group < nGroups; group += gridDim.x) {
     const uint64_t ri = group * WG + threadIdx.x;
     if (ri >= nRaysTotal) continue;
     RayRec* rp = q.rays + ri;
     const float3 O = xyz(rp->O), D = xyz(rp->D), rD = xyz(rp->rD);
     float4 hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
     bool found = false;
-    unsigned long long pSteps = 0, pDistinct = 0, pNodeLanes = 0;
     uint2 stack[STACK_N];
     int sp = 0;
     const uint32_t oct = 7u - ((D.x < 0 ? 4u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 1u : 0u));
@@ -321,16 +341,6 @@ __global__ __launch_bounds__(WG) void k_cwbvh_lean(const float4* __restrict__ no
             if (ng.y > 0x00FFFFFFu) { if (sp < STACK_N) stack[sp++] = ng; else overflow = true; }
             const uint32_t slot = (bit - 24u) ^ oct;
             const uint32_t rel = __popc(imask & ~(0xFFFFFFFFu << slot));
-            if (PROBE) {   // a node visit weighs ~3 triangle tests
-                pSteps += 3;
-                if (pSteps > (unsigned long long)PROBE_STEPS) break;
-                // how many different nodes does the wave touch in this step?  (64-bucket hash of the node
-                // index, OR-reduced over the wave: an estimate that saturates at 64)
-                const uint32_t b = (cbase + rel) & 63u;
-                uint32_t lo = b < 32u ? 1u << b : 0u, hi = b >= 32u ? 1u << (b - 32u) : 0u;
-                for (int o = 32; o > 0; o >>= 1) { lo |= __shfl_xor(lo, o); hi |= __shfl_xor(hi, o); }
-                pDistinct += __popc(lo) + __popc(hi); pNodeLanes += __popcll(__ballot(true));
-            }
             const NodeResult r = visit_node(nodes, cbase + rel, O, rD, hit.x, octinv4);
             ng.x = r.childBase; tg.x = r.triBase;
             ng.y = (r.hitmask & 0xFF000000u) | r.imask;
@@ -344,7 +354,6 @@ __global__ __launch_bounds__(WG) void k_cwbvh_lean(const float4* __restrict__ no
             tg.y &= ~(1u << ti);
             const uint32_t ta = tg.x + ti * 3u;
             const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
-            if (PROBE) { pSteps += 1; }
             TriHit h;
             if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
                 found = true;
@@ -357,58 +366,13 @@ __global__ __launch_bounds__(WG) void k_cwbvh_lean(const float4* __restrict__ no
         if (sp == 0) break;
         ng = stack[--sp];
     }
-    if (PROBE) {
-        // every lane counted the (weighted) steps it took part in; the wave's step count is the maximum
-        unsigned long long mx = pSteps;
-        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(mx, o); mx = t > mx ? t : mx; }
-        unsigned long long sum = pSteps;
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-        // pDistinct / pNodeLanes were accumulated by whichever lanes were active; take the max over lanes
-        unsigned long long dd = pDistinct, nl = pNodeLanes;
-        for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(dd, o); dd = t > dd ? t : dd; const unsigned long long u = __shfl_xor(nl, o); nl = u > nl ? u : nl; }
-        if (threadIdx.x == 0) { atomicAdd(q.stats + 0, mx * 64ull); atomicAdd(q.stats + 1, sum); atomicAdd(q.stats + 2, dd); atomicAdd(q.stats + 3, nl); }
-        return;
-    }
     if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
     else if (found || q.fresh) rp->hit = hit;
   }
     if (overflow) atomicOr(status, 1u);
 }
 
-// AUTO: decide between the two schedules from the probe's lane-cohesion measurement.
-__global__ void k_cwbvh_decide(const unsigned long long* __restrict__ stats, uint32_t* __restrict__ select, float threshold) {
-    const unsigned long long slots = stats[0], lanes = stats[1];
-    *select = (slots > 0 && (float)lanes >= threshold * (float)slots) ? 1u : 0u;
-}
-
 }  // namespace
-
-// AUTO schedule selection (variant 0).  A strided sample of up to 256 wave-groups is traced with
-// the lean schedule in probe mode (no writes); if on average >= `threshold` of a wave's lanes take
-// part in each step, the batch is "coherent" and the lean kernel runs, otherwise the persistent
-// replacement kernel.  Both are launched; the one not selected returns at once.  Measured
-// (tools/perf_probe.py --variant 42, MI355X): cohesion >= 0.84 where the lean kernel wins
-// (1.6-2.7x on the Sponza stand-in's camera and shadow rays), <= 0.80 where it does not
-// (Bistro stand-in camera rays 0.58-0.72: 0.75-0.97x; bounce rays 0.16-0.43: <= 0.5x).
-void launch_cwbvh_auto(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q0, uint32_t* status, uint32_t blocks,
-                       uint32_t leanMaxBlocks, float threshold, hipStream_t s) {
-    QueryArgs q = q0;
-    const uint64_t groups = (q.nRays + WG - 1) / WG;
-    const uint32_t probeBlocks = (uint32_t)(groups < 128 ? groups : 128);
-    const uint32_t leanBlocks = (uint32_t)(groups < (uint64_t)leanMaxBlocks ? groups : leanMaxBlocks);
-    q.probeStride = (uint32_t)(groups / probeBlocks);
-    if (anyhit) hipLaunchKernelGGL((k_cwbvh_lean<true, 32, true>), dim3(probeBlocks), dim3(WG), 0, s, nodes, tris, q, status);
-    else hipLaunchKernelGGL((k_cwbvh_lean<false, 32, true>), dim3(probeBlocks), dim3(WG), 0, s, nodes, tris, q, status);
-    hipLaunchKernelGGL(k_cwbvh_decide, dim3(1), dim3(1), 0, s, (const unsigned long long*)q.stats, const_cast<uint32_t*>(q.select), threshold);
-    q.probeStride = 1;
-    if (anyhit) {
-        hipLaunchKernelGGL((k_cwbvh_lean<true, 32>), dim3(leanBlocks), dim3(WG), 0, s, nodes, tris, q, status);
-        hipLaunchKernelGGL((k_cwbvh<true, 1, 8, 16, true>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
-    } else {
-        hipLaunchKernelGGL((k_cwbvh_lean<false, 32>), dim3(leanBlocks), dim3(WG), 0, s, nodes, tris, q, status);
-        hipLaunchKernelGGL((k_cwbvh<false, 1, 8, 16, true>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
-    }
-}
 
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                   uint32_t blocks, hipStream_t s) {
@@ -417,14 +381,6 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
         if (anyhit) hipLaunchKernelGGL((k_cwbvh<true, MODE, LDSN, RMIN, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status); \
         else hipLaunchKernelGGL((k_cwbvh<false, MODE, LDSN, RMIN, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);  \
     } while (0)
-    if (variant == 42) {   // probe only: lane-cohesion statistics of the lean schedule over the whole batch
-        QueryArgs qq = q;
-        const uint64_t ng_ = (q.nRays + WG - 1) / WG;
-        const uint32_t pb = (uint32_t)(ng_ < 128 ? ng_ : 128);
-        qq.probeStride = (uint32_t)(ng_ / pb);
-        hipLaunchKernelGGL((k_cwbvh_lean<false, 32, true>), dim3(pb), dim3(WG), 0, s, nodes, tris, qq, status);
-        return;
-    }
     if (variant == 40 || variant == 41) {   // lean one-wave-per-64-rays kernel (coherent batches)
         const uint64_t ng_ = (q.nRays + WG - 1) / WG;
         const uint32_t nb = (uint32_t)(ng_ < 65536 ? ng_ : 65536);
@@ -451,6 +407,11 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
         break;
     case 10: TBVH_LAUNCH(1, 8, 8, true); break;
     case 16: TBVH_LAUNCH(1, 8, 16, true, false, 1, true); break;  // packed plane FMAs
+    case 44: TBVH_LAUNCH(1, 8, 64, true); break;
+    case 45: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 64, true); break;
+    case 46:  // lockstep throughout + histogram of per-generation lane cohesion in q.stats
+        hipLaunchKernelGGL((k_cwbvh<false, 1, 8, 16, true, true, 1, false, 64, true>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+        break;   // adaptive: lockstep while the lanes stay together   // interleaved schedule, but a wave only takes new rays when all 64 lanes are idle
     case 17: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 128); break;   // pool chunk sizes: one global atomic per CHUNK rays
     case 18: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 256); break;
     case 19: TBVH_LAUNCH(0, 16, 64, false, false, 1, false, 256); break;  // whole-wave batches, chunk 256
@@ -461,11 +422,11 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     case 5: TBVH_LAUNCH(1, 8, 16); break;    // smaller LDS stack -> more waves per CU
     case 6: TBVH_LAUNCH(1, 12, 16); break;
     case 12: TBVH_LAUNCH(1, 16, 16); break;  // replace when >= 16 lanes are idle, all triangles of a group at once
-    default: TBVH_LAUNCH(1, 8, 16, true); break;  // = 8
+    default: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 64, true); break;  // = 45: the adaptive schedule is the default
     }
 #undef TBVH_LAUNCH
 }
 
-bool cwbvh_variant_valid(int v) { return (v >= 0 && v <= 19) || (v >= 40 && v <= 43); }
+bool cwbvh_variant_valid(int v) { return (v >= 0 && v <= 19) || (v >= 40 && v <= 46 && v != 42 && v != 43); }
 
 }  // namespace tbvh

@@ -68,12 +68,12 @@ def main():
             if kind == "bounce1":
                 ctx.generate_bounce(d_verts, d_prim, d_b, n, 1); sc.intersect_device(d_b, n); ctx.synchronize()
             res[kind] = n / (np.mean(ms) * 1e-3) / 1e6
-            if a.variant == 42:
+            if a.variant == 46:
                 import ctypes as C
                 st = (C.c_uint64 * 8)()
                 tb.lib.tbvh_debug_stats(ctx._h, st, 1)
-                if st[0]:
-                    print(f"   [{kind}] lean-schedule lane cohesion E = {st[1] / st[0]:.3f}   distinct nodes per active lane = {st[2] / max(st[3], 1):.3f}", flush=True)
+                tot = max(sum(int(x) for x in st), 1)
+                print(f"   [{kind}] generation cohesion histogram (<.5 .5-.6 .6-.7 .7-.75 .75-.8 .8-.85 .85-.9 >=.9): " + " ".join(f"{int(x) / tot:.3f}" for x in st), flush=True)
             if a.variant in (7, 9):
                 import ctypes as C
                 st = (C.c_uint64 * 8)()
