@@ -119,13 +119,7 @@ __device__ __forceinline__ NodeResult visit_node_pk(const float4* __restrict__ n
 
 // MODE 0: whole-wave batches (a wave takes 64 consecutive rays and finishes them all).
 // MODE 1: per-lane replacement from a wave-local pool; REFILL_MIN idle lanes trigger a refill.
-// ADAPT: every wave starts in LOCKSTEP (it takes 64 new rays only when all 64 lanes are idle, so the lanes
-// stay in the same phase and touch the same nodes: fastest for coherent batches) and measures each
-// generation's lane cohesion = active lane-iterations / (64 x iterations); when the running estimate falls
-// below kLockstepKeep, or a single generation has already wasted more than 1 - kLockstepBail, the wave
-// switches for the rest of the launch to per-lane replacement (REFILL_MIN idle lanes trigger a refill:
-// fastest for incoherent batches).  No separate probe pass, no host-side decision.
-constexpr uint32_t kLockstepKeep = 184, kLockstepBail = 179;   // x / 256: 0.72, 0.70
+// ADAPT: the wave's LockstepGovernor (ray_pool.h) decides when it takes new rays.
 template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false, int TRI_MIN = 1, bool PKFMA = false, int CHUNK = 64, bool ADAPT = false>
 __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
@@ -407,11 +401,11 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
         break;
     case 10: TBVH_LAUNCH(1, 8, 8, true); break;
     case 16: TBVH_LAUNCH(1, 8, 16, true, false, 1, true); break;  // packed plane FMAs
-    case 44: TBVH_LAUNCH(1, 8, 64, true); break;
-    case 45: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 64, true); break;
+    case 44: TBVH_LAUNCH(1, 8, 64, true); break;   // lockstep throughout: a wave only takes new rays when all 64 lanes are idle
+    case 45: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 64, true); break;   // adaptive (= default)
     case 46:  // lockstep throughout + histogram of per-generation lane cohesion in q.stats
         hipLaunchKernelGGL((k_cwbvh<false, 1, 8, 16, true, true, 1, false, 64, true>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
-        break;   // adaptive: lockstep while the lanes stay together   // interleaved schedule, but a wave only takes new rays when all 64 lanes are idle
+        break;
     case 17: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 128); break;   // pool chunk sizes: one global atomic per CHUNK rays
     case 18: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 256); break;
     case 19: TBVH_LAUNCH(0, 16, 64, false, false, 1, false, 256); break;  // whole-wave batches, chunk 256

@@ -38,7 +38,7 @@ template <int LDS_N> using Stack32 = LaneStack<uint32_t, LDS_N, WG>;
 // tris: 3 x float4 per primIdx entry {v0.xyz|prim, e1, e2}, gathered at upload so a leaf
 // reads one contiguous run instead of primIdx -> verts (two dependent gathers).
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false>
 __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, const float4* __restrict__ tris, QueryArgs q,
                                              uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
@@ -55,9 +55,11 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
     bool found = false;
     uint32_t node = 0, triLeft = 0, triPtr = 0;   // triLeft > 0: a leaf's triangles are pending
 
+    LockstepGovernor gov;   // ADAPT only
+    gov.init();
     for (;;) {
         const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
-        if (nIdle >= (uint32_t)REFILL_MIN) {
+        if ((ADAPT ? gov.want_refill(nIdle, (uint32_t)REFILL_MIN) : nIdle >= (uint32_t)REFILL_MIN) || nIdle == (uint32_t)WG) {
             if (!pool.dry()) {
                 uint64_t nri = 0;
                 if (pool.acquire(!active, q.counter, nRaysTotal, nri)) {
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
 // sorted order.  The hit leaves of a node (at most 4) are queued in registers and their
 // triangles tested one per iteration.
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false>
 __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
     Stack32<LDS_N> st;
@@ -162,9 +164,11 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
     // format, 15-bit count) are tested in place instead of being queued.
     uint32_t leafQ0 = 0, leafQ1 = 0, leafQ2 = 0, leafQ3 = 0, leafCnt = 0;
 
+    LockstepGovernor gov;   // ADAPT only
+    gov.init();
     for (;;) {
         const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
-        if (nIdle >= (uint32_t)REFILL_MIN) {
+        if ((ADAPT ? gov.want_refill(nIdle, (uint32_t)REFILL_MIN) : nIdle >= (uint32_t)REFILL_MIN) || nIdle == (uint32_t)WG) {
             if (!pool.dry()) {
                 uint64_t nri = 0;
                 if (pool.acquire(!active, q.counter, nRaysTotal, nri)) {
@@ -286,30 +290,32 @@ __global__ void k_gather_tris(const uint32_t* __restrict__ primIdx, const float4
 
 void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                  uint32_t blocks, hipStream_t s) {
-#define TBVH_L2(TM)                                                                                                     \
+#define TBVH_L2(...)                                                                                                    \
     do {                                                                                                                \
-        if (anyhit) hipLaunchKernelGGL((k_bvh2<true, 16, 16, TM>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status); \
-        else hipLaunchKernelGGL((k_bvh2<false, 16, 16, TM>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);       \
+        if (anyhit) hipLaunchKernelGGL((k_bvh2<true, 16, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status); \
+        else hipLaunchKernelGGL((k_bvh2<false, 16, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);       \
     } while (0)
     switch (variant) {
     case 1: TBVH_L2(1); break;
     case 2: TBVH_L2(8); break;
     case 3: TBVH_L2(32); break;
-    default: TBVH_L2(16); break;
+    case 4: TBVH_L2(16, true); break;   // adaptive (LockstepGovernor, ray_pool.h): +8 % on coherent camera rays, -2..9 % elsewhere: not the default
+    default: TBVH_L2(16); break;        // per-lane replacement throughout
     }
 #undef TBVH_L2
 }
 
 void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
-#define TBVH_L4(TM)                                                                                                 \
+#define TBVH_L4(...)                                                                                                \
     do {                                                                                                            \
-        if (anyhit) hipLaunchKernelGGL((k_bvh4<true, 12, 16, TM>), dim3(blocks), dim3(WG), 0, s, data, q, status);  \
-        else hipLaunchKernelGGL((k_bvh4<false, 12, 16, TM>), dim3(blocks), dim3(WG), 0, s, data, q, status);        \
+        if (anyhit) hipLaunchKernelGGL((k_bvh4<true, 12, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, data, q, status);  \
+        else hipLaunchKernelGGL((k_bvh4<false, 12, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, data, q, status);        \
     } while (0)
     switch (variant) {
     case 1: TBVH_L4(1); break;
     case 2: TBVH_L4(16); break;
-    default: TBVH_L4(8); break;
+    case 4: TBVH_L4(8, true); break;   // adaptive (LockstepGovernor, ray_pool.h): +6 % on coherent camera rays, -2..8 % elsewhere: not the default
+    default: TBVH_L4(8); break;        // per-lane replacement throughout
     }
 #undef TBVH_L4
 }

@@ -27,6 +27,38 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Per-wave schedule governor of the adaptive kernels.  Every wave starts in LOCKSTEP: it takes 64 new
+// rays only when all 64 lanes are idle, so the lanes stay in the same phase and touch the same nodes
+// (fastest for coherent batches).  It measures each generation's lane cohesion = active
+// lane-iterations / (64 x iterations); when the running estimate falls below kLockstepKeep, or a
+// single generation has already wasted more than 1 - kLockstepBail, the wave switches for the rest of
+// the launch to per-lane replacement (refillMin idle lanes trigger a refill: fastest for incoherent
+// batches).  All state is wave-uniform; no probe pass, no host-side decision.
+// Measured per-generation cohesion (tools/perf_probe.py --variant 46): camera / shadow rays of the
+// Sponza stand-in 0.75-0.95, bounce rays < 0.6 everywhere, Bistro stand-in camera rays spread over 0.3-1.
+constexpr uint32_t kLockstepKeep = 184, kLockstepBail = 179;   // x / 256: 0.72, 0.70
+struct LockstepGovernor {
+    bool lockstep;
+    uint32_t genIters, genActive, ema;
+    __device__ __forceinline__ void init() { lockstep = true; genIters = 0; genActive = 0; ema = 0; }
+    // Call once per traversal iteration with the number of idle lanes; returns whether the wave should
+    // take new rays now.
+    __device__ __forceinline__ bool want_refill(uint32_t nIdle, uint32_t refillMin) {
+        if (lockstep) {
+            genIters++; genActive += 64u - nIdle;
+            if (nIdle == 64u) {   // a generation ended: fold its cohesion into the running estimate
+                if (genIters > 1u) {
+                    const uint32_t e = genActive * 4u / genIters;   // x / 256
+                    ema = ema ? (ema + e) >> 1 : e;
+                    if (ema < kLockstepKeep) lockstep = false;
+                }
+                genIters = 0; genActive = 0;
+            } else if (genIters >= 16u && genActive * 4u < kLockstepBail * genIters) lockstep = false;
+        }
+        return lockstep ? nIdle == 64u : nIdle >= refillMin;
+    }
+};
+
 template <int CHUNK> struct RayPool {
     static_assert(CHUNK % 64 == 0, "chunks are whole 64-ray groups");
     uint64_t next, end;   // wave-uniform: rays in hand
