@@ -26,15 +26,17 @@ tr = [r for r in rows("kt/**/*kernel_trace.csv") if "k_cwbvh<false" in r["Kernel
 tr.sort(key=lambda r: int(r["Start_Timestamp"]))
 dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in tr]
 print("  k_cwbvh<false> launches (ms, dispatch order):", [round(x, 3) for x in dur])
-# bench order: 3 launches while building the batches, then (primary, diffuse) per step
-steps = dur[3:]
+# bench order: 3 launches while building the batches, then (primary, diffuse) per step for the 1 warm-up +
+# 3 timed steps of tools/bench_profile.sh; whatever follows belongs to the shadow / wavefront extras
+N_PAIRS = 4
+steps = dur[3:3 + 2 * N_PAIRS]
 if len(steps) >= 2:
     out["rocprof_primary_ms"] = sum(steps[0::2]) / len(steps[0::2])
     out["rocprof_diffuse_ms"] = sum(steps[1::2]) / len(steps[1::2])
 for name, key in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     v = [r for r in rows(name + "/**/*counter_collection.csv") if "k_cwbvh<false" in r["Kernel_Name"] and r["Counter_Name"] == key]
     v.sort(key=lambda r: int(r["Start_Timestamp"]))
-    vals = [float(r["Counter_Value"]) for r in v][3:]
+    vals = [float(r["Counter_Value"]) for r in v][3:3 + 2 * N_PAIRS]
     if len(vals) >= 2:
         out[key + "_primary_KB"] = sum(vals[0::2]) / len(vals[0::2])
         out[key + "_diffuse_KB"] = sum(vals[1::2]) / len(vals[1::2])
