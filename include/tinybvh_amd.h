@@ -109,6 +109,23 @@ int tbvh_update_tlas(tbvh_scene* tlas, const void* tlas_nodes64, uint64_t n_node
                      const uint32_t* tlas_idx, uint64_t n_idx,
                      const void* instances192, uint64_t n_instances);
 
+/* Per-frame TLAS rebuild ON THE DEVICE (no host build, no node upload): does BLASInstance::Update
+ * (tiny_bvh.h:8386-8427) for every instance and builds a new BVH_GPU-format TLAS over them, replacing
+ * BVH::Build(BLASInstance*, ...) + BVH_GPU::ConvertFrom of the reference frame loop
+ * (tiny_bvh.h:2221-2259, 4612-4655; tiny_bvh_gpu2.cpp:113-130).  The instance records on the device
+ * keep their blasIdx / mask; transform, invTransform, aabbMin, aabbMax are rewritten.
+ *   transforms    n_instances x 16 floats (BLASInstance::transform, row-major); host memory
+ *                 (on_device = 0, staged asynchronously) or device memory (on_device = 1); NULL keeps
+ *                 the transforms already in the records (e.g. written there by the caller's kernel)
+ *   blas_bounds6  per BLAS min.xyz, max.xyz (the BLAS root box: bvhNode[0].aabbMin/aabbMax); needed on
+ *                 the first call, NULL afterwards
+ * Asynchronous on the context's stream; tbvh_time_last_ms() reports the device time of the rebuild.
+ * The tree is an LBVH, not the reference's binned-SAH TLAS: same hit records, different node order. */
+int tbvh_rebuild_tlas_device(tbvh_scene* tlas, const void* transforms, int on_device,
+                             const float* blas_bounds6, uint64_t n_blas);
+/* Read the TLAS back (tests, inspection): any of the three buffers may be NULL. */
+int tbvh_tlas_download(tbvh_scene* tlas, void* tlas_nodes64, uint64_t cap_nodes, uint32_t* tlas_idx, uint64_t cap_idx,
+                       void* instances192, uint64_t cap_instances, uint64_t* n_nodes_out);
 void     tbvh_free_scene(tbvh_scene* scene);
 int      tbvh_scene_layout(const tbvh_scene* scene);
 uint64_t tbvh_scene_device_bytes(const tbvh_scene* scene);

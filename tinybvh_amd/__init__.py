@@ -336,6 +336,45 @@ class TLAS(_Scene):
         return self
 
 
+    def _blas_bounds(self, blas: list) -> np.ndarray:
+        bounds = np.zeros((len(blas), 6), np.float32)
+        for i, b in enumerate(blas):
+            if getattr(b, "_bounds", None) is None:      # root box of the BLAS, computed once
+                v = b.host.verts[:, :3]
+                b._bounds = np.concatenate([v.min(0), v.max(0)]).astype(np.float32)
+            bounds[i] = b._bounds
+        return bounds
+
+    def RebuildOnDevice(self, transforms=None, on_device: bool = False) -> "TLAS":
+        """Per-frame rebuild on the GPU (tbvh_rebuild_tlas_device): instance update + LBVH TLAS, no host
+        build and no node upload.  transforms: (n, 16) float32 array (host), a device pointer (int,
+        on_device=True), or None to keep the transforms already in the device records."""
+        bounds = None
+        if not getattr(self, "_bounds_sent", False):
+            bounds = self._blas_bounds(self.blas)
+        if transforms is None:
+            t = None
+        elif on_device:
+            t = C.c_void_p(int(transforms))
+        else:
+            transforms = np.ascontiguousarray(transforms, np.float32)
+            assert transforms.size == self.instances.shape[0] * 16
+            t = _ptr(transforms)
+        check(lib.tbvh_rebuild_tlas_device(self._h, t, 1 if on_device else 0, _ptr(bounds) if bounds is not None else None,
+                                           len(self.blas) if bounds is not None else 0), "tbvh_rebuild_tlas_device")
+        self._bounds_sent = True
+        return self
+
+    def Download(self):
+        """(nodes64 as (n,16) uint32, tlas_idx, instances) currently on the device."""
+        n = self.instances.shape[0]
+        nn = C.c_uint64(0)
+        check(lib.tbvh_tlas_download(self._h, None, 0, None, 0, None, 0, C.byref(nn)), "tbvh_tlas_download")
+        nodes = np.zeros((nn.value, 16), np.uint32); idx = np.zeros(n, np.uint32); inst = np.zeros(n, INSTANCE_DTYPE)
+        check(lib.tbvh_tlas_download(self._h, _ptr(nodes), nn.value, _ptr(idx), n, _ptr(inst), n, C.byref(nn)), "tbvh_tlas_download")
+        return nodes, idx, inst
+
+
 class Wavefront:
     """Device-resident wavefront path tracer (tbvh_wavefront_*): one call enqueues a whole frame
     (Generate, {Extend, Shade} x depth, Connect) with all queues and counters on the device."""

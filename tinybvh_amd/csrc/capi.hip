@@ -78,6 +78,13 @@ struct tbvh_scene {
     BlasDesc* blasDesc = nullptr;
     int blasLayout = 0;
     uint64_t capNodes = 0, capIdx = 0, capInst = 0;
+    uint64_t nInst = 0, nBlas = 0, nTlasNodes = 0;
+    // device-side TLAS rebuild (kernels_tlasbuild.hip)
+    float* blasBounds = nullptr;      // 6 floats per BLAS
+    float* xformStage = nullptr;      // staged transforms (16 floats per instance) when the caller passes host memory
+    void* buildScratch = nullptr;
+    size_t buildScratchBytes = 0, sortTempBytes = 0;
+    uint64_t buildScratchFor = 0;     // instance count the scratch was sized for
 };
 
 struct BLASInstanceCheck { float m[32]; float mn[3]; uint32_t blasIdx; float mx[3]; uint32_t mask; uint32_t pad[8]; };
@@ -346,6 +353,7 @@ int tlasCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t
     HIP_TRY(hipMemcpyAsync(s->instances, inst, nInst * 192, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // the caller may reuse its host arrays right away
     s->bytes = nNodes * 64 + nIdx * 4 + nInst * 192;
+    s->nInst = nInst; s->nTlasNodes = nNodes;
     return 0;
 }
 }  // namespace
@@ -368,7 +376,7 @@ int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, cons
     if (int r = setDevice(c)) return r;
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
-    s->isTlas = true; s->blasLayout = layout;
+    s->isTlas = true; s->blasLayout = layout; s->nBlas = nBlas;
     hipError_t e = hipMalloc((void**)&s->blasDesc, nBlas * sizeof(BlasDesc));
     if (e == hipSuccess) e = hipMemcpy(s->blasDesc, desc.data(), nBlas * sizeof(BlasDesc), hipMemcpyHostToDevice);
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "TLAS upload failed: %s", hipGetErrorString(e)); }
@@ -383,6 +391,62 @@ int tbvh_update_tlas(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const 
     return tlasCopy(s, nodes64, nNodes, idx, nIdx, inst, nInst);
 }
 
+int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice, const float* blasBounds6, uint64_t nBlas) {
+    if (!s || !s->isTlas) return fail(TBVH_E_INVALID, "tbvh_rebuild_tlas_device: not a TLAS");
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    const uint64_t n = s->nInst;
+    if (n == 0 || n > 0x7fffffffull) return fail(TBVH_E_INVALID, "tbvh_rebuild_tlas_device: %llu instances", (unsigned long long)n);
+    if (blasBounds6) {
+        if (nBlas != s->nBlas) return fail(TBVH_E_INVALID, "tbvh_rebuild_tlas_device: %llu BLAS bounds for a TLAS over %llu BLASes", (unsigned long long)nBlas, (unsigned long long)s->nBlas);
+        if (!s->blasBounds) HIP_TRY(hipMalloc((void**)&s->blasBounds, s->nBlas * 24));
+        HIP_TRY(hipMemcpyAsync(s->blasBounds, blasBounds6, s->nBlas * 24, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // the caller's array may go away
+    }
+    if (!s->blasBounds) return fail(TBVH_E_INVALID, "tbvh_rebuild_tlas_device: the first call needs blas_bounds6");
+    // an LBVH over n leaves has 2n - 1 nodes and n index entries
+    const uint64_t nNodes = 2 * n - 1;
+    if (nNodes > s->capNodes) { if (s->nodes) hipFree(s->nodes); s->nodes = nullptr; s->capNodes = 0; HIP_TRY(hipMalloc((void**)&s->nodes, nNodes * 64)); s->capNodes = nNodes; }
+    if (n > s->capIdx) { if (s->tlasIdx) hipFree(s->tlasIdx); s->tlasIdx = nullptr; s->capIdx = 0; HIP_TRY(hipMalloc((void**)&s->tlasIdx, n * 4)); s->capIdx = n; }
+    if (s->buildScratchFor != n) {
+        if (s->buildScratch) hipFree(s->buildScratch);
+        s->buildScratch = nullptr; s->buildScratchFor = 0;
+        s->buildScratchBytes = tlas_build_scratch_bytes((uint32_t)n, &s->sortTempBytes);
+        HIP_TRY(hipMalloc(&s->buildScratch, s->buildScratchBytes));
+        s->buildScratchFor = n;
+    }
+    const float* xf = nullptr;
+    if (transforms) {
+        if (onDevice) xf = (const float*)transforms;
+        else {
+            if (!s->xformStage) HIP_TRY(hipMalloc((void**)&s->xformStage, s->capInst * 64));
+            HIP_TRY(hipMemcpyAsync(s->xformStage, transforms, n * 64, hipMemcpyHostToDevice, c->stream));
+            xf = s->xformStage;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(launch_tlas_rebuild(s->nodes, s->tlasIdx, s->instances, xf, s->blasBounds, (uint32_t)n, (uint32_t)s->nBlas, s->buildScratch, s->sortTempBytes, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    s->bytes = nNodes * 64 + n * 4 + n * 192;
+    s->nTlasNodes = nNodes;
+    return 0;
+}
+
+int tbvh_tlas_download(tbvh_scene* s, void* nodes64, uint64_t capNodes, uint32_t* idx, uint64_t capIdx, void* instances192, uint64_t capInst,
+                       uint64_t* nNodesOut) {
+    if (!s || !s->isTlas) return fail(TBVH_E_INVALID, "tbvh_tlas_download: not a TLAS");
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t n = s->nInst, nNodes = s->nTlasNodes;
+    if (nNodesOut) *nNodesOut = nNodes;
+    if (nodes64) { if (capNodes < nNodes) return fail(TBVH_E_INVALID, "tbvh_tlas_download: node buffer too small"); HIP_TRY(hipMemcpy(nodes64, s->nodes, nNodes * 64, hipMemcpyDeviceToHost)); }
+    if (idx) { if (capIdx < n) return fail(TBVH_E_INVALID, "tbvh_tlas_download: index buffer too small"); HIP_TRY(hipMemcpy(idx, s->tlasIdx, n * 4, hipMemcpyDeviceToHost)); }
+    if (instances192) { if (capInst < n) return fail(TBVH_E_INVALID, "tbvh_tlas_download: instance buffer too small"); HIP_TRY(hipMemcpy(instances192, s->instances, n * 192, hipMemcpyDeviceToHost)); }
+    return 0;
+}
+
 void tbvh_free_scene(tbvh_scene* s) {
     if (!s) return;
     tbvh_context* c = s->ctx;
@@ -395,6 +459,9 @@ void tbvh_free_scene(tbvh_scene* s) {
     if (s->tlasIdx) hipFree(s->tlasIdx);
     if (s->instances) hipFree(s->instances);
     if (s->blasDesc) hipFree(s->blasDesc);
+    if (s->blasBounds) hipFree(s->blasBounds);
+    if (s->xformStage) hipFree(s->xformStage);
+    if (s->buildScratch) hipFree(s->buildScratch);
     for (size_t i = 0; i < c->scenes.size(); i++)
         if (c->scenes[i] == s) { c->scenes.erase(c->scenes.begin() + i); break; }
     delete s;

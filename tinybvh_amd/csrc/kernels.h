@@ -18,6 +18,10 @@ void launch_cwbvh_c(bool anyhit, int variant, const float4* nodes, const float4*
 struct BlasDesc { const float4* nodes; const float4* tris; };  // one per BLAS of a TLAS
 void launch_tlas(bool anyhit, int blasLayout, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances,
                  const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
+// device TLAS rebuild (kernels_tlasbuild.hip)
+size_t tlas_build_scratch_bytes(uint32_t n, size_t* sortTempBytes);
+hipError_t launch_tlas_rebuild(float4* tlasNodes, uint32_t* tlasIdx, float4* instances, const float* transformsDev, const float* blasBoundsDev,
+                               uint32_t n, uint32_t nBlas, void* scratch, size_t sortTempBytes, hipStream_t s);
 void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris,
                         hipStream_t s);
 

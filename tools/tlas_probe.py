@@ -50,6 +50,22 @@ def main():
         ms = ctx.time_last_ms()
         print(f"frame {f}: {inst.shape[0]} instances of {label} ({verts.shape[0] // 3} tris), BLAS layout {a.layout}: host TLAS rebuild+upload {t_host * 1e3:.2f} ms, "
               f"trace {n} rays {ms:.3f} ms = {n / ms / 1e3:.1f} MRays/s", flush=True)
+    # the same frames with the TLAS rebuilt on the device (tbvh_rebuild_tlas_device): transforms go up (64 B per
+    # instance), instance update + LBVH build run on the GPU
+    for f in range(a.frames):
+        inst = instances(a.side, float(f))
+        xf = np.ascontiguousarray(inst["transform"])
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        tlas.RebuildOnDevice(xf)
+        t_call = time.perf_counter() - t0
+        ctx.synchronize()
+        t_sync = time.perf_counter() - t0
+        ms_build = ctx.time_last_ms()
+        tlas.intersect_device_fresh(d_rays, n, 1e30)
+        ms = ctx.time_last_ms()
+        print(f"frame {f}: DEVICE TLAS rebuild: host call {t_call * 1e3:.3f} ms (returns before the GPU is done), until done {t_sync * 1e3:.3f} ms, "
+              f"device time {ms_build:.3f} ms; trace {ms:.3f} ms = {n / ms / 1e3:.1f} MRays/s", flush=True)
     hits = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(hits, d_rays)
     print("hit fraction", float((hits["t"] < 1e30).mean()), "distinct instances hit", len(np.unique(hits["inst"][hits["t"] < 1e30])))
     ctx.close()
