@@ -109,6 +109,21 @@ int tbvh_update_tlas(tbvh_scene* tlas, const void* tlas_nodes64, uint64_t n_node
                      const uint32_t* tlas_idx, uint64_t n_idx,
                      const void* instances192, uint64_t n_instances);
 
+/* Read a BLAS scene's device blobs back (tests, caching a refitted blob): which = 0 nodes, 1 triangle
+ * records (BVH_GPU: the gathered {v0|prim, e1, e2} form; BVH4_GPU has none).  dst = NULL only reports the size. */
+int tbvh_scene_download(tbvh_scene* scene, int which, void* dst, uint64_t cap_bytes, uint64_t* bytes_out);
+
+/* BLAS refit ON THE DEVICE for animated meshes: same topology and triangle order, every box recomputed
+ * bottom-up from the new vertex positions, CWBVH nodes re-quantised, triangle records re-gathered.
+ * Replaces "BVH::Refit (tiny_bvh.h:3055-3093) / MBVH::Refit (4925-4961) on the host, ConvertFrom again
+ * (4612-4655, 5884-6018), upload" of the reference flow.  verts16: the caller's bvhvec4 vertex array
+ * (3 per triangle, n_tris triangles, same indexing as at build time); host memory (on_device = 0, staged
+ * asynchronously) or device memory (1).  Works on BVH8_CWBVH and BVH_GPU scenes, including reference-built
+ * blobs; BVH4_GPU scenes are re-uploaded instead.  Asynchronous; tbvh_time_last_ms() = device time.
+ * A vertex array shorter than the blob's primitive indices is reported (TBVH_E_FORMAT) by the next
+ * synchronising call. */
+int tbvh_refit(tbvh_scene* scene, const void* verts16, uint64_t n_tris, int on_device);
+
 /* Per-frame TLAS rebuild ON THE DEVICE (no host build, no node upload): does BLASInstance::Update
  * (tiny_bvh.h:8386-8427) for every instance and builds a new BVH_GPU-format TLAS over them, replacing
  * BVH::Build(BLASInstance*, ...) + BVH_GPU::ConvertFrom of the reference frame loop

@@ -1,0 +1,103 @@
+"""Device-side BLAS refit (tbvh_refit): after the vertices move, queries through the
+refitted blob must return the reference's hit records for the NEW geometry (BVH::Intersect on a BVH
+built over the moved vertices: hit records do not depend on the tree), the refitted boxes must be
+conservative, and refitting to unchanged vertices must reproduce the encoder's blob."""
+import numpy as np
+import pytest
+
+import tinybvh_amd as tb
+from tinybvh_amd import rays as R
+from tinybvh_amd import scenes
+from oracle_lib import compare_hits
+
+
+def deform(verts, amount, seed):
+    """Smooth, seeded displacement of every vertex (shared vertices move together: the mesh stays closed)."""
+    v = verts.copy()
+    p = v[:, :3]
+    rng = np.random.default_rng(seed)
+    k = rng.uniform(0.5, 2.0, (3, 3)).astype(np.float32); ph = rng.uniform(0, 6.28, 3).astype(np.float32)
+    d = np.stack([np.sin(p @ k[0] + ph[0]), np.sin(p @ k[1] + ph[1]), np.sin(p @ k[2] + ph[2])], 1).astype(np.float32)
+    v[:, :3] = p + np.float32(amount) * d
+    return v
+
+
+def oracle_hits(oracle, verts, rays):
+    h = tb.HostBVH(verts, tb.LAYOUT_BVH_GPU)
+    return oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
+
+
+def check(got, want):
+    c = compare_hits(got, want)
+    assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
+    assert c["tie"] <= 4 and c["onsurf"] <= 4, c
+    assert c["bit_identical"] == c["same_prim"], c
+    return c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [tb.LAYOUT_CWBVH, tb.LAYOUT_BVH_GPU])
+def test_refit_parity(ctx, oracle, layout):
+    verts = scenes.blob(8000, seed=3)
+    sc = tb.LAYOUT_CLASSES[layout](ctx).Build(verts)
+    lo, hi = verts[:, :3].min(0) - 0.5, verts[:, :3].max(0) + 0.5
+    rays = R.random_rays(40_000, lo, hi, seed=11)
+    check(sc.Intersect(rays.copy()), oracle_hits(oracle, verts, rays))
+    for frame, amount in enumerate((0.05, 0.2, 0.0)):       # the last frame returns to the rest pose
+        v2 = deform(verts, amount, seed=frame) if amount else verts
+        sc.Refit(v2)
+        want = oracle_hits(oracle, v2, rays)
+        c = check(sc.Intersect(rays.copy()), want)
+        assert c["hits"] > 4000
+        occ = sc.IsOccluded(rays.copy())
+        assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+    # vertices that already live on the device
+    v3 = deform(verts, 0.1, seed=9)
+    d_v = ctx.malloc(v3.nbytes); ctx.to_device(d_v, v3)
+    sc.Refit((d_v, v3.shape[0] // 3), on_device=True)
+    check(sc.Intersect(rays.copy()), oracle_hits(oracle, v3, rays))
+    ctx.free(d_v)
+
+
+@pytest.mark.gpu
+def test_refit_to_same_vertices_reproduces_the_encoder(ctx):
+    """CWBVH: the device re-quantisation is the host encoder's arithmetic: same vertices -> same node bytes."""
+    verts = scenes.soup(3000, seed=5)
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    before_n = sc.host.blob(0, np.uint32, 4).copy(); before_t = sc.host.blob(1, np.uint32, 4).copy()
+    sc.Refit(verts)
+    n, t = sc.download_blobs()
+    assert np.array_equal(t, before_t)
+    same = np.all(n.reshape(-1, 20) == before_n.reshape(-1, 20), axis=1)
+    assert same.mean() > 0.999, f"{(~same).sum()} of {same.size} nodes differ"
+
+
+@pytest.mark.gpu
+def test_refit_on_reference_built_blob(ctx, oracle):
+    """Blobs built by the real tiny_bvh.h (golden fixture) are refittable too."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soup_2k.npz"))
+    verts = g["verts"]
+    rays = g["rays"].copy()
+    v2 = deform(verts, 0.03, seed=2)
+    want = oracle_hits(oracle, v2, rays)
+    for k in (0, 1):                                     # BVH::Build and BuildHQ (SBVH: prims shared between leaves)
+        sc = tb.BVH8_CWBVH(ctx).Upload(g[f"cwbvh_nodes_{k}"], g[f"cwbvh_tris_{k}"])
+        sc.Refit(v2)
+        check(sc.Intersect(rays.copy()), want)
+        sg = tb.BVH_GPU(ctx).Upload(g[f"bvhgpu_nodes_{k}"], g[f"bvhgpu_idx_{k}"], verts)
+        sg.Refit(v2)
+        check(sg.Intersect(rays.copy()), want)
+
+
+@pytest.mark.gpu
+def test_refit_errors(ctx):
+    verts = scenes.soup(600, seed=1)
+    b4 = tb.BVH4_GPU(ctx).Build(verts)
+    with pytest.raises(tb.TbvhError):
+        b4.Refit(verts)                                  # BVH4_GPU is not refittable on the device
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    sc.Refit(verts[: 3 * 100])                          # vertex array shorter than the blob's primitives
+    r = R.random_rays(64, (-1, -1, -1), (1, 1, 1), seed=1)
+    with pytest.raises(tb.TbvhError):
+        sc.Intersect(r)                                  # reported by the next synchronising call

@@ -192,6 +192,30 @@ class _Scene:
     def device_bytes(self) -> int:
         return int(lib.tbvh_scene_device_bytes(self._h))
 
+    def Refit(self, verts, on_device: bool = False):
+        """Refit this BLAS on the device to moved vertices (tbvh_refit; BVH::Refit, tiny_bvh.h:3055-3093):
+        verts is the (3 n_tris, 4) float32 vertex array (host) or a device pointer with n_tris = on_device."""
+        if on_device:
+            ptr, n_tris = C.c_void_p(int(verts[0])), int(verts[1])
+        else:
+            verts = np.ascontiguousarray(verts, np.float32)
+            assert verts.ndim == 2 and verts.shape[1] == 4 and verts.shape[0] % 3 == 0
+            ptr, n_tris = _ptr(verts), verts.shape[0] // 3
+        check(lib.tbvh_refit(self._h, ptr, n_tris, 1 if on_device else 0), "tbvh_refit")
+        return self
+
+    def download_blobs(self):
+        """(nodes, triangle records) as (n, 4) uint32 arrays of 16-byte blocks, read back from the device."""
+        out = []
+        for which in (0, 1):
+            nb = C.c_uint64(0)
+            check(lib.tbvh_scene_download(self._h, which, None, 0, C.byref(nb)), "tbvh_scene_download")
+            a = np.zeros((nb.value // 16, 4), np.uint32)
+            if nb.value:
+                check(lib.tbvh_scene_download(self._h, which, _ptr(a), nb.value, C.byref(nb)), "tbvh_scene_download")
+            out.append(a)
+        return tuple(out)
+
     def set_variant(self, v: int):
         check(lib.tbvh_set_variant(self._h, v), "tbvh_set_variant")
 

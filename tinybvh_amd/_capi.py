@@ -53,6 +53,8 @@ SYMBOLS = {
     "tbvh_upload_tlas": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _pp, _u64, _pp]),
     "tbvh_update_tlas": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u64]),
     "tbvh_rebuild_tlas_device": (_i, [_vp, _vp, _i, _vp, _u64]),
+    "tbvh_refit": (_i, [_vp, _vp, _u64, _i]),
+    "tbvh_scene_download": (_i, [_vp, _i, _vp, _u64, _vp]),
     "tbvh_tlas_download": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp]),
     "tbvh_free_scene": (None, [_vp]),
     "tbvh_scene_layout": (_i, [_vp]),

@@ -85,6 +85,11 @@ struct tbvh_scene {
     void* buildScratch = nullptr;
     size_t buildScratchBytes = 0, sortTempBytes = 0;
     uint64_t buildScratchFor = 0;     // instance count the scratch was sized for
+    // device-side BLAS refit (kernels_refit.hip)
+    void* refitScratch = nullptr;
+    bool refitParentsValid = false;
+    float4* vertStage = nullptr;      // staged vertices when the caller passes host memory
+    uint64_t vertStageTris = 0;
 };
 
 struct BLASInstanceCheck { float m[32]; float mn[3]; uint32_t blasIdx; float mx[3]; uint32_t mask; uint32_t pad[8]; };
@@ -179,6 +184,10 @@ int checkStatus(tbvh_context* c) {
     if (st & 1u) {
         hipMemsetAsync(c->status, 0, 4, c->stream);
         return fail(TBVH_E_FORMAT, "traversal stack overflow (tree deeper than the spill area allows)");
+    }
+    if (st & 2u) {
+        hipMemsetAsync(c->status, 0, 4, c->stream);
+        return fail(TBVH_E_FORMAT, "refit: a triangle record refers to a primitive beyond the vertex array");
     }
     return 0;
 }
@@ -391,6 +400,54 @@ int tbvh_update_tlas(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const 
     return tlasCopy(s, nodes64, nNodes, idx, nIdx, inst, nInst);
 }
 
+int tbvh_scene_download(tbvh_scene* s, int which, void* dst, uint64_t capBytes, uint64_t* bytesOut) {
+    if (!s || s->isTlas || (which != 0 && which != 1)) return fail(TBVH_E_INVALID, "tbvh_scene_download: not a BLAS scene or bad blob selector");
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    const void* src = which == 0 ? (const void*)s->nodes : (const void*)s->tris;
+    const uint64_t bytes = (which == 0 ? s->nNodeBlocks : s->nTriBlocks) * 16;
+    if (bytesOut) *bytesOut = src ? bytes : 0;
+    if (!dst) return 0;
+    if (!src) return fail(TBVH_E_INVALID, "tbvh_scene_download: this layout has no such blob");
+    if (capBytes < bytes) return fail(TBVH_E_INVALID, "tbvh_scene_download: buffer too small (%llu < %llu bytes)", (unsigned long long)capBytes, (unsigned long long)bytes);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice) {
+    if (!s || !verts16 || !nTris) return fail(TBVH_E_INVALID, "tbvh_refit: null/empty argument");
+    if (s->isTlas) return fail(TBVH_E_INVALID, "tbvh_refit: a TLAS is rebuilt with tbvh_rebuild_tlas_device / tbvh_update_tlas");
+    if (s->layout != TBVH_LAYOUT_CWBVH && s->layout != TBVH_LAYOUT_BVH_GPU)
+        return fail(TBVH_E_INVALID, "tbvh_refit: layout %d is not refittable on the device (BVH8_CWBVH and BVH_GPU are)", s->layout);
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    const uint32_t nNodes = (uint32_t)(s->layout == TBVH_LAYOUT_CWBVH ? s->nNodeBlocks / 5 : s->nNodeBlocks / 4);
+    const uint64_t nRecords = s->nTriBlocks / 3;
+    if (!s->refitScratch) HIP_TRY(hipMalloc(&s->refitScratch, refit_scratch_bytes(s->layout, nNodes)));
+    const float4* dv = (const float4*)verts16;
+    if (!onDevice) {
+        if (s->vertStageTris < nTris) {
+            if (s->vertStage) hipFree(s->vertStage);
+            s->vertStage = nullptr; s->vertStageTris = 0;
+            HIP_TRY(hipMalloc((void**)&s->vertStage, nTris * 48));
+            s->vertStageTris = nTris;
+        }
+        HIP_TRY(hipMemcpyAsync(s->vertStage, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream));
+        dv = s->vertStage;
+    }
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(launch_refit(s->layout, s->nodes, nNodes, s->tris, nRecords, dv, nTris, s->refitScratch, s->refitParentsValid, c->status, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    s->refitParentsValid = true;
+    // derived node layouts of the experiment kernels would be stale now
+    if (s->nodesH) { hipStreamSynchronize(c->stream); hipFree(s->nodesH); s->nodesH = nullptr; }
+    if (s->nodesP) { hipStreamSynchronize(c->stream); hipFree(s->nodesP); s->nodesP = nullptr; }
+    if (s->variant >= 20 && s->variant < 40) s->variant = 0;
+    return 0;
+}
+
 int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice, const float* blasBounds6, uint64_t nBlas) {
     if (!s || !s->isTlas) return fail(TBVH_E_INVALID, "tbvh_rebuild_tlas_device: not a TLAS");
     tbvh_context* c = s->ctx;
@@ -410,6 +467,8 @@ int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice
     if (n > s->capIdx) { if (s->tlasIdx) hipFree(s->tlasIdx); s->tlasIdx = nullptr; s->capIdx = 0; HIP_TRY(hipMalloc((void**)&s->tlasIdx, n * 4)); s->capIdx = n; }
     if (s->buildScratchFor != n) {
         if (s->buildScratch) hipFree(s->buildScratch);
+    if (s->refitScratch) hipFree(s->refitScratch);
+    if (s->vertStage) hipFree(s->vertStage);
         s->buildScratch = nullptr; s->buildScratchFor = 0;
         s->buildScratchBytes = tlas_build_scratch_bytes((uint32_t)n, &s->sortTempBytes);
         HIP_TRY(hipMalloc(&s->buildScratch, s->buildScratchBytes));
@@ -462,6 +521,8 @@ void tbvh_free_scene(tbvh_scene* s) {
     if (s->blasBounds) hipFree(s->blasBounds);
     if (s->xformStage) hipFree(s->xformStage);
     if (s->buildScratch) hipFree(s->buildScratch);
+    if (s->refitScratch) hipFree(s->refitScratch);
+    if (s->vertStage) hipFree(s->vertStage);
     for (size_t i = 0; i < c->scenes.size(); i++)
         if (c->scenes[i] == s) { c->scenes.erase(c->scenes.begin() + i); break; }
     delete s;

@@ -22,6 +22,10 @@ void launch_tlas(bool anyhit, int blasLayout, const float4* tlasNodes, const uin
 size_t tlas_build_scratch_bytes(uint32_t n, size_t* sortTempBytes);
 hipError_t launch_tlas_rebuild(float4* tlasNodes, uint32_t* tlasIdx, float4* instances, const float* transformsDev, const float* blasBoundsDev,
                                uint32_t n, uint32_t nBlas, void* scratch, size_t sortTempBytes, hipStream_t s);
+// device BLAS refit (kernels_refit.hip)
+size_t refit_scratch_bytes(int layout, uint32_t nNodes);
+hipError_t launch_refit(int layout, float4* nodes, uint32_t nNodes, float4* tris, uint64_t nTriRecords, const float4* verts, uint64_t nTris,
+                        void* scratch, bool parentsValid, uint32_t* status, hipStream_t s);
 void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris,
                         hipStream_t s);
 
