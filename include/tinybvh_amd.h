@@ -109,6 +109,16 @@ int tbvh_update_tlas(tbvh_scene* tlas, const void* tlas_nodes64, uint64_t n_node
                      const uint32_t* tlas_idx, uint64_t n_idx,
                      const void* instances192, uint64_t n_instances);
 
+/* BVH2 -> wide layout conversion ON THE DEVICE: replaces BVH8_CWBVH::ConvertFrom (tiny_bvh.h:5884-6018, with
+ * the MBVH<8> collapse of 4975-5048) for callers that have a plain BVH2.  nodes32 = BVH::bvhNode (32-byte
+ * BVHNode: aabbMin, leftFirst, aabbMax, triCount; children adjacent; tiny_bvh.h:1050-1062), n_nodes =
+ * usedNodes, prim_idx = BVH::primIdx (n_idx = idxCount), verts16 = the vertex array; all three in host memory
+ * (on_device = 0) or device memory (1).  Leaves must hold at most 3 triangles (BVH::SplitLeafs(3), which the
+ * reference's ConvertFrom also requires); otherwise TBVH_E_FORMAT.  layout: TBVH_LAYOUT_CWBVH.
+ * Synchronous (one small read-back per level of the wide tree); tbvh_time_last_ms() = time spent converting. */
+int tbvh_convert_bvh2_device(tbvh_context* ctx, const void* nodes32, uint64_t n_nodes, const uint32_t* prim_idx, uint64_t n_idx,
+                             const void* verts16, uint64_t n_tris, int on_device, int layout, tbvh_scene** out);
+
 /* Read a BLAS scene's device blobs back (tests, caching a refitted blob): which = 0 nodes, 1 triangle
  * records (BVH_GPU: the gathered {v0|prim, e1, e2} form; BVH4_GPU has none).  dst = NULL only reports the size. */
 int tbvh_scene_download(tbvh_scene* scene, int which, void* dst, uint64_t cap_bytes, uint64_t* bytes_out);

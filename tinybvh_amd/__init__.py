@@ -283,6 +283,14 @@ class BVH8_CWBVH(_Scene):
         self.host = HostBVH(verts, LAYOUT_CWBVH, **kw)
         return self.Upload(self.host.blob(0, np.uint32, 4), self.host.blob(1, np.uint32, 4))
 
+    def ConvertFromBVH2(self, nodes32: np.ndarray, prim_idx: np.ndarray, verts: np.ndarray) -> "BVH8_CWBVH":
+        """BVH8_CWBVH::ConvertFrom on the device (tbvh_convert_bvh2_device): a plain BVH2 (32-byte BVHNode
+        array with leaves of at most 3 triangles, primIdx, vertices) goes up, the GPU collapses and encodes."""
+        nodes32 = np.ascontiguousarray(nodes32); prim_idx = np.ascontiguousarray(prim_idx, np.uint32); verts = np.ascontiguousarray(verts, np.float32)
+        check(lib.tbvh_convert_bvh2_device(self.ctx._h, _ptr(nodes32), nodes32.nbytes // 32, _ptr(prim_idx), prim_idx.size, _ptr(verts), verts.shape[0] // 3,
+                                           0, LAYOUT_CWBVH, C.byref(self._h)), "tbvh_convert_bvh2_device")
+        return self
+
     def Upload(self, nodes16: np.ndarray, tris16: np.ndarray) -> "BVH8_CWBVH":
         nodes16 = np.ascontiguousarray(nodes16); tris16 = np.ascontiguousarray(tris16)
         check(lib.tbvh_upload_cwbvh(self.ctx._h, _ptr(nodes16), nodes16.nbytes // 16, _ptr(tris16), tris16.nbytes // 16,

@@ -18,6 +18,7 @@
 //      floor/ceil in units of 2^e and then verified against the decode lo + q * 2^e the kernel uses.
 //      Slot assignment, child order and triangle order are topology and stay.
 #include "device_common.h"
+#include "cwbvh_encode.h"
 #include "kernels.h"
 
 namespace tbvh {
@@ -29,9 +30,6 @@ __device__ __forceinline__ float3 ld_agent3(const float4* p) {   // written by a
     const float* f = (const float*)p;
     return make_float3(ld_agent_f(f), ld_agent_f(f + 1), ld_agent_f(f + 2));
 }
-__device__ __forceinline__ float3 min3(float3 a, float3 b) { return make_float3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
-__device__ __forceinline__ float3 max3(float3 a, float3 b) { return make_float3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
-
 // ---- triangle records -----------------------------------------------------------------------
 
 // CWBVH: {e2, e1, v0|prim} per triangle (tiny_bvh.h:6004-6008); BVH_GPU gathered form: {v0|prim, e1, e2}.
@@ -133,44 +131,7 @@ __device__ void cw_encode(float4* __restrict__ np, uint32_t nNodes, const float4
         mn = min3(mn, a); mx = max3(mx, b);
     }
     outMn = mn; outMx = mx;
-    const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
-    int e[3];
-    uint32_t q[6][2] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};   // qlo_x qlo_y qlo_z qhi_x qhi_y qhi_z, 8 bytes each
-    for (int a = 0; a < 3; a++) {
-        const float ext = hi[a] - lo[a];
-        // smallest e with extent <= 255 * 2^e: start one below the estimate and let the same guard as the host
-        // encoder (no child plane may need more than 255 steps, the far face must reach the box) raise it
-        int ea = ext > 0 ? ilogbf(ext * (1.0f / 255.0f)) : -126;
-        if (ea < -126) ea = -126;
-        for (;;) {
-            const float sc = ldexpf(1.0f, -ea);
-            bool ok = true;
-            for (int s = 0; s < 8; s++) if (used[s]) {
-                const float cm = a == 0 ? cmx[s].x : a == 1 ? cmx[s].y : cmx[s].z;
-                if (ceilf((cm - lo[a]) * sc) > 255.f) ok = false;
-            }
-            if (lo[a] + ldexpf(255.0f, ea) < hi[a]) ok = false;
-            if (ok || ea >= 127) break;
-            ea++;
-        }
-        e[a] = ea;
-        const float inv = ldexpf(1.0f, -ea), sc = ldexpf(1.0f, ea);
-        for (int s = 0; s < 8; s++) if (used[s]) {
-            const float cl = a == 0 ? cmn[s].x : a == 1 ? cmn[s].y : cmn[s].z;
-            const float ch = a == 0 ? cmx[s].x : a == 1 ? cmx[s].y : cmx[s].z;
-            int ql = (int)floorf((cl - lo[a]) * inv), qh = (int)ceilf((ch - lo[a]) * inv);
-            ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql); qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
-            while (ql > 0 && lo[a] + sc * (float)ql > cl) ql--;
-            while (qh < 255 && lo[a] + sc * (float)qh < ch) qh++;
-            q[a][s >> 2] |= (uint32_t)ql << (8 * (s & 3));
-            q[3 + a][s >> 2] |= (uint32_t)qh << (8 * (s & 3));
-        }
-    }
-    const uint32_t eim = ((uint32_t)(uint8_t)(int8_t)e[0]) | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) | ((uint32_t)(uint8_t)(int8_t)e[2] << 16) | (imask << 24);
-    np[0] = make_float4(lo[0], lo[1], lo[2], as_f32(eim));
-    np[2] = make_float4(as_f32(q[0][0]), as_f32(q[0][1]), as_f32(q[1][0]), as_f32(q[1][1]));
-    np[3] = make_float4(as_f32(q[2][0]), as_f32(q[2][1]), as_f32(q[3][0]), as_f32(q[3][1]));
-    np[4] = make_float4(as_f32(q[4][0]), as_f32(q[4][1]), as_f32(q[5][0]), as_f32(q[5][1]));
+    cw_quantize_write(np, mn, mx, cmn, cmx, used, imask, childBase, triBase, m0, m1);
 }
 
 __global__ void k_cw_refit(float4* __restrict__ nodes, uint32_t nNodes, const float4* __restrict__ tris, const float4* __restrict__ verts,
