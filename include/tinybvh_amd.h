@@ -119,6 +119,15 @@ int tbvh_update_tlas(tbvh_scene* tlas, const void* tlas_nodes64, uint64_t n_node
 int tbvh_convert_bvh2_device(tbvh_context* ctx, const void* nodes32, uint64_t n_nodes, const uint32_t* prim_idx, uint64_t n_idx,
                              const void* verts16, uint64_t n_tris, int on_device, int layout, tbvh_scene** out);
 
+/* BVH BUILD on the device: triangles -> LBVH (Morton order, Karras topology) -> BVH8_CWBVH, nothing on the host.
+ * The fast path for content whose topology changes every frame or whose host build (BVH::Build,
+ * tiny_bvh.h:2124-2461) is the bottleneck; the tree is of lower quality than the binned-SAH build (more node
+ * visits per ray), so it is not what the host builder or the bench use.  verts16: bvhvec4 vertices, 3 per
+ * triangle, host (on_device = 0) or device memory (1); max_leaf_tris 1..3 (0 = 3).  layout: TBVH_LAYOUT_CWBVH.
+ * prim indices in the hit records are the triangle's index in verts16, as with every other builder. */
+int tbvh_build_device(tbvh_context* ctx, const void* verts16, uint64_t n_tris, int on_device, int layout,
+                      uint32_t max_leaf_tris, tbvh_scene** out);
+
 /* Read a BLAS scene's device blobs back (tests, caching a refitted blob): which = 0 nodes, 1 triangle
  * records (BVH_GPU: the gathered {v0|prim, e1, e2} form; BVH4_GPU has none).  dst = NULL only reports the size. */
 int tbvh_scene_download(tbvh_scene* scene, int which, void* dst, uint64_t cap_bytes, uint64_t* bytes_out);

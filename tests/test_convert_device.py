@@ -73,3 +73,32 @@ def test_convert_edge_cases(ctx, oracle):
     bad = good.bvh2_nodes().copy(); bad.view(np.uint32).reshape(-1, 8)[0, 3] = 0x7fffff00
     with pytest.raises(tb.TbvhError):
         tb.BVH8_CWBVH(ctx).ConvertFromBVH2(bad, good.bvh2_prim_idx(), soup)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,n,leaf", [("soup", 3000, 3), ("blob", 20000, 1), ("atrium", 0, 3), ("soup", 1, 3), ("soup", 2, 2)])
+def test_build_on_device_parity(ctx, oracle, scene, n, leaf):
+    """tbvh_build_device: LBVH + collapse + encode on the GPU.  A different tree than the host's SAH build, the
+    same hit records (BVH::Intersect restated, on the host-built BVH2 of the same triangles)."""
+    verts = scenes.soup(n, seed=4) if scene == "soup" else scenes.blob(n, seed=7) if scene == "blob" else scenes.get("sponza")[0]
+    sc = tb.BVH8_CWBVH(ctx).BuildOnDevice(verts, max_leaf_tris=leaf)
+    nodes, tris = sc.download_blobs()
+    n_tris = verts.shape[0] // 3
+    prims = tris.reshape(-1, 3, 4)[:, 2, 3]
+    assert np.array_equal(np.sort(prims), np.arange(n_tris, dtype=np.uint32))      # every triangle exactly once
+    tb.BVH8_CWBVH(ctx).Upload(nodes, tris)                                           # passes the blob validator
+    host = tb.HostBVH(verts, tb.LAYOUT_CWBVH)
+    lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+    pad = 0.05 * (hi - lo) + 0.01
+    rays = R.random_rays(40_000, lo - pad, hi + pad, seed=3)
+    want = oracle.bvh2_intersect(host.bvh2_nodes(), host.bvh2_prim_idx(), verts, rays)
+    c = check(sc.Intersect(rays.copy()), want)
+    if n_tris > 100:
+        assert c["hits"] > 2000
+    occ = sc.IsOccluded(rays.copy())
+    assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+    # rebuilt after the geometry moved: still the reference's answers
+    v2 = verts.copy(); v2[:, 0] += 0.1 * np.sin(3.0 * verts[:, 1])
+    sc2 = tb.BVH8_CWBVH(ctx).BuildOnDevice(v2, max_leaf_tris=leaf)
+    h2 = tb.HostBVH(v2, tb.LAYOUT_CWBVH)
+    check(sc2.Intersect(rays.copy()), oracle.bvh2_intersect(h2.bvh2_nodes(), h2.bvh2_prim_idx(), v2, rays))

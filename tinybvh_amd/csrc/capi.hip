@@ -400,16 +400,53 @@ int tbvh_update_tlas(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const 
     return tlasCopy(s, nodes64, nNodes, idx, nIdx, inst, nInst);
 }
 
+namespace {
+// BVH2 (device arrays) -> CWBVH scene.  msBefore: device time already spent on this request (builder), added to the report.
+int convertDeviceImpl(tbvh_context* c, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris,
+                      tbvh_scene** out) {
+    struct Tmp {
+        void *nodes = nullptr, *tris = nullptr, *itA = nullptr, *itB = nullptr, *cnt = nullptr;
+        ~Tmp() { for (void* p : {nodes, tris, itA, itB, cnt}) if (p) hipFree(p); }
+    } t;
+    // worst case: every BVH2 interior node becomes a wide node ((n + 1) / 2 of them in a full binary tree, + the root)
+    const uint32_t capNodes = (uint32_t)(nNodes2 / 2 + 2);
+    HIP_TRY(hipMalloc(&t.nodes, (size_t)capNodes * 80)); HIP_TRY(hipMalloc(&t.tris, nIdx * 48));
+    HIP_TRY(hipMalloc(&t.itA, (size_t)capNodes * 8)); HIP_TRY(hipMalloc(&t.itB, (size_t)capNodes * 8)); HIP_TRY(hipMalloc(&t.cnt, 16));
+    uint32_t nWide = 0, levels = 0; uint64_t nWideTris = 0;
+    HIP_TRY(run_convert_cwbvh(dN2, (uint32_t)nNodes2, dIdx, nIdx, dV, nTris, (float4*)t.nodes, capNodes, (float4*)t.tris, nIdx, (uint2*)t.itA, (uint2*)t.itB,
+                              (uint32_t*)t.cnt, c->status, c->stream, &nWide, &nWideTris, &levels));
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpy(&st, c->status, 4, hipMemcpyDeviceToHost));
+    if (st & 12u) {
+        hipMemset(c->status, 0, 4);
+        return fail(TBVH_E_FORMAT, (st & 8u) ? "BVH2 -> CWBVH: a BVH2 leaf holds more than 3 triangles (SplitLeafs(3) first, like BVH8_CWBVH::ConvertFrom)"
+                                             : "BVH2 -> CWBVH: malformed BVH2 (child, primitive or triangle index out of range)");
+    }
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_CWBVH);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    // keep exactly what was produced
+    hipError_t e = hipMalloc((void**)&s->nodes, (size_t)nWide * 80);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->tris, (nWideTris ? nWideTris : 1) * 48);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, t.nodes, (size_t)nWide * 80, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && nWideTris) e = hipMemcpyAsync(s->tris, t.tris, nWideTris * 48, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH2 -> CWBVH: %s", hipGetErrorString(e)); }
+    s->nNodes = nWide; s->nNodeBlocks = (uint64_t)nWide * 5; s->nTriBlocks = nWideTris * 3;
+    s->bytes = (s->nNodeBlocks + s->nTriBlocks) * 16;
+    *out = s;
+    return 0;
+}
+}  // namespace
+
 int tbvh_convert_bvh2_device(tbvh_context* c, const void* nodes32, uint64_t nNodes2, const uint32_t* primIdx, uint64_t nIdx, const void* verts16,
                              uint64_t nTris, int onDevice, int layout, tbvh_scene** out) {
     if (!c || !nodes32 || !primIdx || !verts16 || !out || nNodes2 == 0 || nIdx == 0 || nTris == 0) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: null/empty argument");
     if (layout != TBVH_LAYOUT_CWBVH) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: target layout %d not supported (BVH8_CWBVH is)", layout);
     if (nNodes2 > 0x7fffffffull || nIdx > 0x7fffffffull) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: BVH2 too large for 32-bit node / triangle indices");
     if (int r = setDevice(c)) return r;
-    // everything the conversion needs, freed on every exit path
     struct Tmp {
-        void *n2 = nullptr, *idx = nullptr, *v = nullptr, *nodes = nullptr, *tris = nullptr, *itA = nullptr, *itB = nullptr, *cnt = nullptr;
-        ~Tmp() { for (void* p : {n2, idx, v, nodes, tris, itA, itB, cnt}) if (p) hipFree(p); }
+        void *n2 = nullptr, *idx = nullptr, *v = nullptr;
+        ~Tmp() { for (void* p : {n2, idx, v}) if (p) hipFree(p); }
     } t;
     const float4 *dN2 = (const float4*)nodes32, *dV = (const float4*)verts16;
     const uint32_t* dIdx = primIdx;
@@ -420,36 +457,39 @@ int tbvh_convert_bvh2_device(tbvh_context* c, const void* nodes32, uint64_t nNod
         HIP_TRY(hipMemcpyAsync(t.v, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream));
         dN2 = (const float4*)t.n2; dIdx = (const uint32_t*)t.idx; dV = (const float4*)t.v;
     }
-    // worst case: every BVH2 interior node becomes a wide node ((n + 1) / 2 of them in a full binary tree, + the root)
-    const uint32_t capNodes = (uint32_t)(nNodes2 / 2 + 2);
-    HIP_TRY(hipMalloc(&t.nodes, (size_t)capNodes * 80)); HIP_TRY(hipMalloc(&t.tris, nIdx * 48));
-    HIP_TRY(hipMalloc(&t.itA, (size_t)capNodes * 8)); HIP_TRY(hipMalloc(&t.itB, (size_t)capNodes * 8)); HIP_TRY(hipMalloc(&t.cnt, 16));
-    uint32_t nWide = 0, levels = 0; uint64_t nWideTris = 0;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(run_convert_cwbvh(dN2, (uint32_t)nNodes2, dIdx, nIdx, dV, nTris, (float4*)t.nodes, capNodes, (float4*)t.tris, nIdx, (uint2*)t.itA, (uint2*)t.itB,
-                              (uint32_t*)t.cnt, c->status, c->stream, &nWide, &nWideTris, &levels));
+    const int r = convertDeviceImpl(c, dN2, nNodes2, dIdx, nIdx, dV, nTris, out);
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
-    uint32_t st = 0;
-    HIP_TRY(hipMemcpy(&st, c->status, 4, hipMemcpyDeviceToHost));
-    if (st & 12u) {
-        hipMemset(c->status, 0, 4);
-        return fail(TBVH_E_FORMAT, (st & 8u) ? "tbvh_convert_bvh2_device: a BVH2 leaf holds more than 3 triangles (SplitLeafs(3) first, like BVH8_CWBVH::ConvertFrom)"
-                                             : "tbvh_convert_bvh2_device: malformed BVH2 (child, primitive or triangle index out of range)");
+    return r;
+}
+
+int tbvh_build_device(tbvh_context* c, const void* verts16, uint64_t nTris, int onDevice, int layout, uint32_t maxLeafTris, tbvh_scene** out) {
+    if (!c || !verts16 || !out || nTris == 0) return fail(TBVH_E_INVALID, "tbvh_build_device: null/empty argument");
+    if (layout != TBVH_LAYOUT_CWBVH) return fail(TBVH_E_INVALID, "tbvh_build_device: target layout %d not supported (BVH8_CWBVH is)", layout);
+    if (nTris > 0x3fffffffull) return fail(TBVH_E_INVALID, "tbvh_build_device: too many triangles for 32-bit node indices");
+    if (maxLeafTris == 0) maxLeafTris = 3;
+    if (maxLeafTris > 3) return fail(TBVH_E_INVALID, "tbvh_build_device: at most 3 triangles per leaf (CWBVH)");
+    if (int r = setDevice(c)) return r;
+    struct Tmp {
+        void *v = nullptr, *n2 = nullptr, *idx = nullptr, *scratch = nullptr;
+        ~Tmp() { for (void* p : {v, n2, idx, scratch}) if (p) hipFree(p); }
+    } t;
+    const float4* dV = (const float4*)verts16;
+    if (!onDevice) {
+        HIP_TRY(hipMalloc(&t.v, nTris * 48));
+        HIP_TRY(hipMemcpyAsync(t.v, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream));
+        dV = (const float4*)t.v;
     }
-    tbvh_scene* s = newScene(c, TBVH_LAYOUT_CWBVH);
-    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
-    // keep exactly what was produced
-    hipError_t e = hipMalloc((void**)&s->nodes, (size_t)nWide * 80);
-    if (e == hipSuccess) e = hipMalloc((void**)&s->tris, (nWideTris ? nWideTris : 1) * 48);
-    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, t.nodes, (size_t)nWide * 80, hipMemcpyDeviceToDevice, c->stream);
-    if (e == hipSuccess && nWideTris) e = hipMemcpyAsync(s->tris, t.tris, nWideTris * 48, hipMemcpyDeviceToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "tbvh_convert_bvh2_device: %s", hipGetErrorString(e)); }
-    s->nNodes = nWide; s->nNodeBlocks = (uint64_t)nWide * 5; s->nTriBlocks = nWideTris * 3;
-    s->bytes = (s->nNodeBlocks + s->nTriBlocks) * 16;
-    *out = s;
-    return 0;
+    size_t sortTemp = 0;
+    const size_t scratchBytes = lbvh_scratch_bytes((uint32_t)nTris, &sortTemp);
+    HIP_TRY(hipMalloc(&t.n2, nTris * 2 * 32)); HIP_TRY(hipMalloc(&t.idx, nTris * 4)); HIP_TRY(hipMalloc(&t.scratch, scratchBytes));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(launch_lbvh_build(dV, (uint32_t)nTris, maxLeafTris, (float4*)t.n2, (uint32_t*)t.idx, t.scratch, sortTemp, c->stream));
+    const int r = convertDeviceImpl(c, (const float4*)t.n2, nTris * 2, (const uint32_t*)t.idx, nTris, dV, nTris, out);
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return r;
 }
 
 int tbvh_scene_download(tbvh_scene* s, int which, void* dst, uint64_t capBytes, uint64_t* bytesOut) {

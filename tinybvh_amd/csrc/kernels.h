@@ -22,6 +22,10 @@ void launch_tlas(bool anyhit, int blasLayout, const float4* tlasNodes, const uin
 size_t tlas_build_scratch_bytes(uint32_t n, size_t* sortTempBytes);
 hipError_t launch_tlas_rebuild(float4* tlasNodes, uint32_t* tlasIdx, float4* instances, const float* transformsDev, const float* blasBoundsDev,
                                uint32_t n, uint32_t nBlas, void* scratch, size_t sortTempBytes, hipStream_t s);
+// LBVH build on the device (kernels_build.hip)
+size_t lbvh_scratch_bytes(uint32_t n, size_t* sortTempBytes);
+hipError_t launch_lbvh_build(const float4* verts, uint32_t n, uint32_t maxLeaf, float4* nodes32, uint32_t* primIdx, void* scratch, size_t sortTempBytes,
+                             hipStream_t s);
 // BVH2 -> CWBVH conversion on the device (kernels_convert.hip)
 hipError_t run_convert_cwbvh(const float4* nodes2, uint32_t nNodes2, const uint32_t* primIdx, uint64_t nIdx, const float4* verts, uint64_t nTris,
                              float4* cwNodes, uint32_t capNodes, float4* cwTris, uint64_t capTris, uint2* itemsA, uint2* itemsB, uint32_t* counters,

@@ -1,0 +1,221 @@
+// kernels_build.hip — BVH construction on the device: triangles -> LBVH (BVH2 in the reference's 32-byte
+// BVHNode format) ("a GPU LBVH builder feeding the conversions").
+//
+// For content that changes topology every frame, or scenes whose host build (BVH::Build,
+// tiny_bvh.h:2124-2461: seconds for Bistro) is the bottleneck: 30-bit Morton codes of the triangle
+// centroids, radix sort, Karras 2012 topology, bottom-up boxes.  The result is written directly in the
+// layout BVH::Build produces — 32-byte nodes {aabbMin, leftFirst, aabbMax, triCount}, root at 0, node 1
+// unused, the two children of a node adjacent (tiny_bvh.h:1050-1062) — plus a primIdx array, so it feeds
+// tbvh_convert_bvh2_device (kernels_convert.hip) and every other BVH2 consumer unchanged:
+//   * Karras interior node i keeps its children at 2 + 2i and 3 + 2i;
+//   * an interior node whose sorted range holds at most 3 triangles is emitted as a LEAF over that
+//     range (leftFirst = range start, triCount = range size): the 3-triangle leaves CWBVH wants
+//     (BVH::SplitLeafs(3) in reverse) at no cost, because a Karras node covers a contiguous sorted range.
+// An LBVH is a lower-quality tree than the binned-SAH build (more nodes visited per ray); it is the
+// fast path, not the default.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "cwbvh_encode.h"
+#include "device_common.h"
+#include "kernels.h"
+
+namespace tbvh {
+
+namespace {
+
+__device__ __forceinline__ uint32_t enc_f32(float f) {   // order-preserving float -> uint
+    const uint32_t b = as_u32(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(uint32_t e) { return as_f32((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
+
+__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+// per-triangle box + centroid bounds of the scene (wave reduction, one atomic set per wave)
+__global__ void k_tri_boxes(const float4* __restrict__ verts, uint32_t n, float4* __restrict__ triMin, float4* __restrict__ triMax,
+                            uint32_t* __restrict__ centreBounds) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float3 mn = make_float3(1e30f, 1e30f, 1e30f), mx = make_float3(-1e30f, -1e30f, -1e30f);
+    float3 cmn = mn, cmx = mx;
+    if (i < n) {
+        for (int k = 0; k < 3; k++) { const float4 v = verts[3 * (uint64_t)i + k]; const float3 p = make_float3(v.x, v.y, v.z); mn = min3(mn, p); mx = max3(mx, p); }
+        triMin[i] = make_float4(mn.x, mn.y, mn.z, 0.f); triMax[i] = make_float4(mx.x, mx.y, mx.z, 0.f);
+        cmn = cmx = make_float3(0.5f * (mn.x + mx.x), 0.5f * (mn.y + mx.y), 0.5f * (mn.z + mx.z));
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        cmn = min3(cmn, make_float3(__shfl_xor(cmn.x, o), __shfl_xor(cmn.y, o), __shfl_xor(cmn.z, o)));
+        cmx = max3(cmx, make_float3(__shfl_xor(cmx.x, o), __shfl_xor(cmx.y, o), __shfl_xor(cmx.z, o)));
+    }
+    if ((threadIdx.x & 63u) == 0 && cmn.x <= cmx.x) {
+        atomicMin(centreBounds + 0, enc_f32(cmn.x)); atomicMin(centreBounds + 1, enc_f32(cmn.y)); atomicMin(centreBounds + 2, enc_f32(cmn.z));
+        atomicMax(centreBounds + 3, enc_f32(cmx.x)); atomicMax(centreBounds + 4, enc_f32(cmx.y)); atomicMax(centreBounds + 5, enc_f32(cmx.z));
+    }
+}
+
+__global__ void k_tri_morton(const float4* __restrict__ triMin, const float4* __restrict__ triMax, const uint32_t* __restrict__ centreBounds,
+                             uint32_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = triMin[i], b = triMax[i];
+    const float c[3] = {0.5f * (a.x + b.x), 0.5f * (a.y + b.y), 0.5f * (a.z + b.z)};
+    uint32_t q[3];
+    for (int k = 0; k < 3; k++) {
+        const float lo = dec_f32(centreBounds[k]), hi = dec_f32(centreBounds[3 + k]);
+        const float ext = hi - lo;
+        float u = ext > 0 ? (c[k] - lo) / ext : 0.f;
+        u = u < 0 ? 0.f : (u > 1 ? 1.f : u);
+        const uint32_t v = (uint32_t)(u * 1023.0f);
+        q[k] = v > 1023u ? 1023u : v;
+    }
+    keys[i] = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+    vals[i] = i;
+}
+
+__device__ __forceinline__ int delta(const uint32_t* __restrict__ keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint32_t a = keys[i], b = keys[j];
+    return a == b ? 32 + __clz((uint32_t)(i ^ j)) : __clz(a ^ b);
+}
+
+// Karras 2012.  Per interior node i: its two children (leaf k is numbered n - 1 + k), its sorted range.
+// parent[c] = i, bit 31 set for the right child.
+__global__ void k_topology(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ parent, uint2* __restrict__ children, uint2* __restrict__ range) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int N = (int)n;
+    if (i >= N - 1) return;
+    const int d = delta(keys, N, i, i + 1) - delta(keys, N, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, N, i, i - d);
+    int lmax = 2;
+    while (delta(keys, N, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, N, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, N, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+        if (delta(keys, N, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const uint32_t left = lo == gamma ? (uint32_t)(N - 1 + gamma) : (uint32_t)gamma;
+    const uint32_t right = hi == gamma + 1 ? (uint32_t)(N - 1 + gamma + 1) : (uint32_t)(gamma + 1);
+    children[i] = make_uint2(left, right);
+    range[i] = make_uint2((uint32_t)lo, (uint32_t)(hi - lo + 1));
+    parent[left] = (uint32_t)i;
+    parent[right] = (uint32_t)i | 0x80000000u;
+}
+
+__device__ __forceinline__ float3 ld_agent3(const float4* p) {   // written by another CU during this kernel: bypass the non-coherent L1
+    const float* f = (const float*)p;
+    return make_float3(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// position of a node in the output array: the root at 0, the children of Karras node p at 2 + 2p and 3 + 2p
+__device__ __forceinline__ uint32_t out_pos(uint32_t parentEntry) { return 2u + 2u * (parentEntry & 0x7fffffffu) + (parentEntry >> 31); }
+
+// One thread per triangle (= Karras leaf): write the single-triangle leaf node, then climb; the second thread to
+// reach an interior node owns it: union of the child boxes, node record in BVHNode format.
+__global__ void k_wald_nodes(const uint32_t* __restrict__ sortedTri, const float4* __restrict__ triMin, const float4* __restrict__ triMax,
+                             const uint32_t* __restrict__ parent, const uint2* __restrict__ children, const uint2* __restrict__ range,
+                             uint32_t* __restrict__ flags, float4* __restrict__ boxMin, float4* __restrict__ boxMax, uint32_t n, uint32_t maxLeaf,
+                             float4* __restrict__ nodes32) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t tri = sortedTri[k];
+    float3 mn = make_float3(triMin[tri].x, triMin[tri].y, triMin[tri].z), mx = make_float3(triMax[tri].x, triMax[tri].y, triMax[tri].z);
+    if (n == 1) {   // a single triangle: the root is the leaf
+        nodes32[0] = make_float4(mn.x, mn.y, mn.z, as_f32(0u)); nodes32[1] = make_float4(mx.x, mx.y, mx.z, as_f32(1u));
+        return;
+    }
+    uint32_t node = n - 1 + k;            // Karras numbering: leaves after the n - 1 interior nodes
+    uint32_t pe = parent[node];
+    {
+        float4* o = nodes32 + 2 * (size_t)out_pos(pe);
+        o[0] = make_float4(mn.x, mn.y, mn.z, as_f32(k)); o[1] = make_float4(mx.x, mx.y, mx.z, as_f32(1u));
+    }
+    boxMin[node] = make_float4(mn.x, mn.y, mn.z, 0.f); boxMax[node] = make_float4(mx.x, mx.y, mx.z, 0.f);
+    for (;;) {
+        __threadfence();
+        node = pe & 0x7fffffffu;
+        if (atomicAdd(flags + node, 1u) == 0u) return;   // the sibling subtree is not finished yet
+        __threadfence();
+        const uint2 ch = children[node];
+        mn = min3(ld_agent3(boxMin + ch.x), ld_agent3(boxMin + ch.y));
+        mx = max3(ld_agent3(boxMax + ch.x), ld_agent3(boxMax + ch.y));
+        const uint2 rg = range[node];
+        const bool leaf = rg.y <= maxLeaf;   // a whole (contiguous) range of at most maxLeaf triangles: one leaf
+        const uint32_t pos = node == 0 ? 0u : out_pos(parent[node]);
+        float4* o = nodes32 + 2 * (size_t)pos;
+        o[0] = make_float4(mn.x, mn.y, mn.z, as_f32(leaf ? rg.x : 2u + 2u * node));
+        o[1] = make_float4(mx.x, mx.y, mx.z, as_f32(leaf ? rg.y : 0u));
+        if (node == 0) return;
+        boxMin[node] = make_float4(mn.x, mn.y, mn.z, 0.f); boxMax[node] = make_float4(mx.x, mx.y, mx.z, 0.f);
+        pe = parent[node];
+    }
+}
+
+struct Scratch {
+    float4 *triMin, *triMax, *boxMin, *boxMax;
+    uint32_t *keysA, *keysB, *valsA, *parent, *flags, *bounds;
+    uint2 *children, *range;
+    void* sortTemp;
+    size_t total;
+};
+Scratch carve(void* base, uint32_t n, size_t sortTempBytes) {
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    Scratch s;
+    s.triMin = (float4*)take((size_t)n * 16); s.triMax = (float4*)take((size_t)n * 16);
+    s.boxMin = (float4*)take((size_t)n * 32); s.boxMax = (float4*)take((size_t)n * 32);   // 2n - 1 Karras nodes
+    s.keysA = (uint32_t*)take((size_t)n * 4); s.keysB = (uint32_t*)take((size_t)n * 4);
+    s.valsA = (uint32_t*)take((size_t)n * 4);
+    s.parent = (uint32_t*)take((size_t)n * 8);
+    s.children = (uint2*)take((size_t)n * 8); s.range = (uint2*)take((size_t)n * 8);
+    s.flags = (uint32_t*)take((size_t)n * 4);
+    s.bounds = (uint32_t*)take(64);
+    s.sortTemp = take(sortTempBytes);
+    s.total = (size_t)(p - (char*)base);
+    return s;
+}
+
+}  // namespace
+
+size_t lbvh_scratch_bytes(uint32_t n, size_t* sortTempBytes) {
+    size_t tmp = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 30);
+    *sortTempBytes = tmp;
+    return carve(nullptr, n, tmp).total;
+}
+
+// verts: 3 float4 per triangle (device).  Out: nodes32 (2n BVHNode records; [1] unused), primIdx (n entries = the
+// triangles in Morton order).  maxLeaf: 1..3 triangles per leaf.
+hipError_t launch_lbvh_build(const float4* verts, uint32_t n, uint32_t maxLeaf, float4* nodes32, uint32_t* primIdx, void* scratch, size_t sortTempBytes,
+                             hipStream_t s) {
+    const Scratch sc = carve(scratch, n, sortTempBytes);
+    hipError_t e;
+    if ((e = hipMemsetAsync(sc.bounds, 0xff, 12, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(sc.bounds + 3, 0x00, 12, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(sc.flags, 0, (size_t)n * 4, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(nodes32, 0, 64, s)) != hipSuccess) return e;   // root + the unused node 1
+    const uint32_t bs = 256, nb = (n + bs - 1) / bs;
+    hipLaunchKernelGGL(k_tri_boxes, dim3(nb), dim3(bs), 0, s, verts, n, sc.triMin, sc.triMax, sc.bounds);
+    hipLaunchKernelGGL(k_tri_morton, dim3(nb), dim3(bs), 0, s, sc.triMin, sc.triMax, sc.bounds, n, sc.keysA, sc.valsA);
+    size_t tmp = sortTempBytes;
+    if ((e = hipcub::DeviceRadixSort::SortPairs(sc.sortTemp, tmp, sc.keysA, sc.keysB, sc.valsA, primIdx, (int)n, 0, 30, s)) != hipSuccess) return e;
+    if (n > 1) hipLaunchKernelGGL(k_topology, dim3(nb), dim3(bs), 0, s, sc.keysB, n, sc.parent, sc.children, sc.range);
+    hipLaunchKernelGGL(k_wald_nodes, dim3(nb), dim3(bs), 0, s, primIdx, sc.triMin, sc.triMax, sc.parent, sc.children, sc.range, sc.flags, sc.boxMin, sc.boxMax, n,
+                       maxLeaf, nodes32);
+    return hipGetLastError();
+}
+
+}  // namespace tbvh
