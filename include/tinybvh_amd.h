@@ -138,7 +138,8 @@ int tbvh_scene_download(tbvh_scene* scene, int which, void* dst, uint64_t cap_by
  * (4612-4655, 5884-6018), upload" of the reference flow.  verts16: the caller's bvhvec4 vertex array
  * (3 per triangle, n_tris triangles, same indexing as at build time); host memory (on_device = 0, staged
  * asynchronously) or device memory (1).  Works on BVH8_CWBVH and BVH_GPU scenes, including reference-built
- * blobs; BVH4_GPU scenes are re-uploaded instead.  Asynchronous; tbvh_time_last_ms() = device time.
+ * blobs; BVH4_GPU scenes are re-uploaded instead.  Returns when the refit is done (the bottom-up passes are
+ * launched in batches with one 4-byte read-back each); tbvh_time_last_ms() = time spent refitting.
  * A vertex array shorter than the blob's primitive indices is reported (TBVH_E_FORMAT) by the next
  * synchronising call. */
 int tbvh_refit(tbvh_scene* scene, const void* verts16, uint64_t n_tris, int on_device);

@@ -87,7 +87,6 @@ struct tbvh_scene {
     uint64_t buildScratchFor = 0;     // instance count the scratch was sized for
     // device-side BLAS refit (kernels_refit.hip)
     void* refitScratch = nullptr;
-    bool refitParentsValid = false;
     float4* vertStage = nullptr;      // staged vertices when the caller passes host memory
     uint64_t vertStageTris = 0;
 };
@@ -529,10 +528,9 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
         dv = s->vertStage;
     }
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(launch_refit(s->layout, s->nodes, nNodes, s->tris, nRecords, dv, nTris, s->refitScratch, s->refitParentsValid, c->status, c->stream));
+    HIP_TRY(launch_refit(s->layout, s->nodes, nNodes, s->tris, nRecords, dv, nTris, s->refitScratch, c->status, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
-    s->refitParentsValid = true;
     // derived node layouts of the experiment kernels would be stale now
     if (s->nodesH) { hipStreamSynchronize(c->stream); hipFree(s->nodesH); s->nodesH = nullptr; }
     if (s->nodesP) { hipStreamSynchronize(c->stream); hipFree(s->nodesP); s->nodesP = nullptr; }

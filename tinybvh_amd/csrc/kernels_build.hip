@@ -123,45 +123,52 @@ __device__ __forceinline__ float3 ld_agent3(const float4* p) {   // written by a
 // position of a node in the output array: the root at 0, the children of Karras node p at 2 + 2p and 3 + 2p
 __device__ __forceinline__ uint32_t out_pos(uint32_t parentEntry) { return 2u + 2u * (parentEntry & 0x7fffffffu) + (parentEntry >> 31); }
 
-// One thread per triangle (= Karras leaf): write the single-triangle leaf node, then climb; the second thread to
-// reach an interior node owns it: union of the child boxes, node record in BVHNode format.
-__global__ void k_wald_nodes(const uint32_t* __restrict__ sortedTri, const float4* __restrict__ triMin, const float4* __restrict__ triMax,
-                             const uint32_t* __restrict__ parent, const uint2* __restrict__ children, const uint2* __restrict__ range,
-                             uint32_t* __restrict__ flags, float4* __restrict__ boxMin, float4* __restrict__ boxMax, uint32_t n, uint32_t maxLeaf,
-                             float4* __restrict__ nodes32) {
+// Bottom-up boxes WITHOUT device-scope fences.  A Karras-style climb (the first child to arrive leaves, the
+// second continues) needs a release/acquire pair per node, and on MI355X an agent-scope fence writes back and
+// invalidates L2 (the 8 XCDs' L2s are not coherent with each other): ~1-2 us each, 25 ms for Bistro.  Instead:
+//   pass 0      one thread per triangle writes its leaf node and box;
+//   pass p >= 1 one thread per interior node that is not done yet: if both children were done BEFORE this pass
+//               (done[] holds the pass number, kernel boundaries make earlier passes visible), take the union,
+//               write the BVHNode record, mark done = p.
+// A node at height h completes in pass h, so the number of passes is the tree height (40-60 for scenes, each
+// pass ~10 us: it only reads 12 bytes per unfinished node).
+__global__ void k_wald_leaves(const uint32_t* __restrict__ sortedTri, const float4* __restrict__ triMin, const float4* __restrict__ triMax,
+                              const uint32_t* __restrict__ parent, float4* __restrict__ boxMin, float4* __restrict__ boxMax, uint32_t n,
+                              float4* __restrict__ nodes32) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t tri = sortedTri[k];
-    float3 mn = make_float3(triMin[tri].x, triMin[tri].y, triMin[tri].z), mx = make_float3(triMax[tri].x, triMax[tri].y, triMax[tri].z);
+    const float4 mn = triMin[tri], mx = triMax[tri];
     if (n == 1) {   // a single triangle: the root is the leaf
         nodes32[0] = make_float4(mn.x, mn.y, mn.z, as_f32(0u)); nodes32[1] = make_float4(mx.x, mx.y, mx.z, as_f32(1u));
         return;
     }
-    uint32_t node = n - 1 + k;            // Karras numbering: leaves after the n - 1 interior nodes
-    uint32_t pe = parent[node];
-    {
-        float4* o = nodes32 + 2 * (size_t)out_pos(pe);
-        o[0] = make_float4(mn.x, mn.y, mn.z, as_f32(k)); o[1] = make_float4(mx.x, mx.y, mx.z, as_f32(1u));
-    }
+    const uint32_t node = n - 1 + k;      // Karras numbering: leaves after the n - 1 interior nodes
+    float4* o = nodes32 + 2 * (size_t)out_pos(parent[node]);
+    o[0] = make_float4(mn.x, mn.y, mn.z, as_f32(k)); o[1] = make_float4(mx.x, mx.y, mx.z, as_f32(1u));
+    boxMin[node] = mn; boxMax[node] = mx;
+}
+
+__global__ void k_wald_pass(const uint32_t* __restrict__ parent, const uint2* __restrict__ children, const uint2* __restrict__ range,
+                            uint32_t* __restrict__ done, float4* __restrict__ boxMin, float4* __restrict__ boxMax, uint32_t n, uint32_t maxLeaf,
+                            uint32_t pass, float4* __restrict__ nodes32) {
+    const uint32_t node = blockIdx.x * blockDim.x + threadIdx.x;
+    if (node + 1 >= n) return;            // n - 1 interior nodes
+    if (done[node]) return;
+    const uint2 ch = children[node];
+    const uint32_t dl = ch.x >= n - 1 ? 1u : done[ch.x], dr = ch.y >= n - 1 ? 1u : done[ch.y];   // leaves were written in pass 0
+    if (dl == 0u || dr == 0u || dl >= pass || dr >= pass) return;
+    const float4 lmn = boxMin[ch.x], lmx = boxMax[ch.x], rmn = boxMin[ch.y], rmx = boxMax[ch.y];
+    const float3 mn = make_float3(fminf(lmn.x, rmn.x), fminf(lmn.y, rmn.y), fminf(lmn.z, rmn.z));
+    const float3 mx = make_float3(fmaxf(lmx.x, rmx.x), fmaxf(lmx.y, rmx.y), fmaxf(lmx.z, rmx.z));
+    const uint2 rg = range[node];
+    const bool leaf = rg.y <= maxLeaf;   // a whole (contiguous) range of at most maxLeaf triangles: one leaf
+    const uint32_t pos = node == 0 ? 0u : out_pos(parent[node]);
+    float4* o = nodes32 + 2 * (size_t)pos;
+    o[0] = make_float4(mn.x, mn.y, mn.z, as_f32(leaf ? rg.x : 2u + 2u * node));
+    o[1] = make_float4(mx.x, mx.y, mx.z, as_f32(leaf ? rg.y : 0u));
     boxMin[node] = make_float4(mn.x, mn.y, mn.z, 0.f); boxMax[node] = make_float4(mx.x, mx.y, mx.z, 0.f);
-    for (;;) {
-        __threadfence();
-        node = pe & 0x7fffffffu;
-        if (atomicAdd(flags + node, 1u) == 0u) return;   // the sibling subtree is not finished yet
-        __threadfence();
-        const uint2 ch = children[node];
-        mn = min3(ld_agent3(boxMin + ch.x), ld_agent3(boxMin + ch.y));
-        mx = max3(ld_agent3(boxMax + ch.x), ld_agent3(boxMax + ch.y));
-        const uint2 rg = range[node];
-        const bool leaf = rg.y <= maxLeaf;   // a whole (contiguous) range of at most maxLeaf triangles: one leaf
-        const uint32_t pos = node == 0 ? 0u : out_pos(parent[node]);
-        float4* o = nodes32 + 2 * (size_t)pos;
-        o[0] = make_float4(mn.x, mn.y, mn.z, as_f32(leaf ? rg.x : 2u + 2u * node));
-        o[1] = make_float4(mx.x, mx.y, mx.z, as_f32(leaf ? rg.y : 0u));
-        if (node == 0) return;
-        boxMin[node] = make_float4(mn.x, mn.y, mn.z, 0.f); boxMax[node] = make_float4(mx.x, mx.y, mx.z, 0.f);
-        pe = parent[node];
-    }
+    done[node] = pass;
 }
 
 struct Scratch {
@@ -213,8 +220,16 @@ hipError_t launch_lbvh_build(const float4* verts, uint32_t n, uint32_t maxLeaf, 
     size_t tmp = sortTempBytes;
     if ((e = hipcub::DeviceRadixSort::SortPairs(sc.sortTemp, tmp, sc.keysA, sc.keysB, sc.valsA, primIdx, (int)n, 0, 30, s)) != hipSuccess) return e;
     if (n > 1) hipLaunchKernelGGL(k_topology, dim3(nb), dim3(bs), 0, s, sc.keysB, n, sc.parent, sc.children, sc.range);
-    hipLaunchKernelGGL(k_wald_nodes, dim3(nb), dim3(bs), 0, s, primIdx, sc.triMin, sc.triMax, sc.parent, sc.children, sc.range, sc.flags, sc.boxMin, sc.boxMax, n,
-                       maxLeaf, nodes32);
+    hipLaunchKernelGGL(k_wald_leaves, dim3(nb), dim3(bs), 0, s, primIdx, sc.triMin, sc.triMax, sc.parent, sc.boxMin, sc.boxMax, n, nodes32);
+    // passes in batches; after each batch look at the root's done word (pass numbers start at 2: 1 means "leaf")
+    uint32_t pass = 2, rootDone = n > 1 ? 0u : 1u;
+    while (!rootDone) {
+        for (int k = 0; k < 24; k++, pass++)
+            hipLaunchKernelGGL(k_wald_pass, dim3(nb), dim3(bs), 0, s, sc.parent, sc.children, sc.range, sc.flags, sc.boxMin, sc.boxMax, n, maxLeaf, pass, nodes32);
+        if ((e = hipMemcpyAsync(&rootDone, sc.flags, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        if (pass > 2u + 24u * 100000u) return hipErrorUnknown;
+    }
     return hipGetLastError();
 }
 

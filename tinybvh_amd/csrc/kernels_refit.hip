@@ -9,10 +9,13 @@
 //      in v0.w says which triangle it is (works for reference-built blobs too, including SBVH ones
 //      whose prims are referenced from several leaves: the leaf box then is the full triangle's box,
 //      which is conservative);
-//   2. leaves compute their boxes from the vertices, interior nodes from their children: one thread
-//      starts at every node that has no interior child and climbs; an atomic counter per node lets the
-//      last arriving child continue (Karras-style), so no level ordering or parent-before-child index
-//      assumption is needed;
+//   2. boxes are rebuilt bottom-up in PASSES, one kernel launch each: a node is finished in the first pass in
+//      which all of its interior children were finished by an EARLIER pass (done[] holds pass numbers; kernel
+//      boundaries make earlier passes visible everywhere).  No atomics and no device-scope fences: on MI355X an
+//      agent-scope release/acquire pair writes back and invalidates L2 (the 8 XCDs' L2s are not coherent with
+//      each other), ~1-2 us each, which made the classic "last child to arrive climbs on" scheme 26 ms for the
+//      5.6 M-node BVH_GPU of Bistro.  The number of passes is the height of the tree (10-14 for CWBVH, 40-60 for
+//      BVH_GPU); no level ordering or parent-before-child index assumption is needed;
 //   3. CWBVH nodes are re-quantised exactly like the host encoder (host_builder.cpp: encode_cwbvh):
 //      origin = node box minimum, per-axis exponent = smallest e with extent <= 255 * 2^e, child planes
 //      floor/ceil in units of 2^e and then verified against the decode lo + q * 2^e the kernel uses.
@@ -25,11 +28,6 @@ namespace tbvh {
 
 namespace {
 
-__device__ __forceinline__ float ld_agent_f(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float3 ld_agent3(const float4* p) {   // written by another CU during this kernel: bypass the non-coherent L1
-    const float* f = (const float*)p;
-    return make_float3(ld_agent_f(f), ld_agent_f(f + 1), ld_agent_f(f + 2));
-}
 // ---- triangle records -----------------------------------------------------------------------
 
 // CWBVH: {e2, e1, v0|prim} per triangle (tiny_bvh.h:6004-6008); BVH_GPU gathered form: {v0|prim, e1, e2}.
@@ -56,53 +54,49 @@ __device__ __forceinline__ void grow_prim(const float4* __restrict__ verts, uint
 }
 
 // ---- BVH_GPU (Aila-Laine) ---------------------------------------------------------------------
-// node = {lmin, left | lmax, right | rmin, triCount | rmax, firstTri} (tiny_bvh.h:1095-1105)
+// node = {lmin, left | lmax, right | rmin, triCount | rmax, firstTri} (tiny_bvh.h:1095-1105): an interior node
+// stores the boxes of its two children, so a child's own box is the union of the two boxes IT stores.
 
-// parent[c] = parent node index, bit 31 set when c is the right child
-__global__ void k_al_parents(const float4* __restrict__ nodes, uint32_t nNodes, uint32_t* __restrict__ parent) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nNodes) return;
-    if (as_u32(nodes[i * 4 + 2].w)) return;   // leaf
-    const uint32_t l = as_u32(nodes[i * 4].w), r = as_u32(nodes[i * 4 + 1].w);
-    if (l < nNodes) parent[l] = i;
-    if (r < nNodes) parent[r] = i | 0x80000000u;
+// Box of child c of an interior node; false when c is an interior node that was not finished before this pass.
+// Leaves are marked done = 1 by the first pass (pass 2), so later passes can tell "unfinished interior node"
+// from the done word alone, without touching the child's record.
+__device__ __forceinline__ bool al_child_box(const float4* __restrict__ nodes, uint32_t nNodes, const float4* __restrict__ tris, const float4* __restrict__ verts,
+                                             const uint32_t* __restrict__ done, uint32_t pass, uint32_t c, float3& mn, float3& mx) {
+    mn = make_float3(1e30f, 1e30f, 1e30f); mx = make_float3(-1e30f, -1e30f, -1e30f);
+    if (c >= nNodes) return true;   // malformed: leave an empty box
+    const uint32_t d = done[c];
+    if (d >= pass || (d == 0u && pass > 2u)) return false;
+    const float4 c2 = nodes[(size_t)c * 4 + 2], c3 = nodes[(size_t)c * 4 + 3];
+    const uint32_t cnt = as_u32(c2.w);
+    if (cnt) {
+        const uint32_t first = as_u32(c3.w);
+        for (uint32_t k = 0; k < cnt; k++) grow_prim(verts, as_u32(tris[3 * (uint64_t)(first + k)].w), mn, mx);
+        return true;
+    }
+    if (d == 0u) return false;      // first pass: an interior child cannot be finished yet
+    const float4 c0 = nodes[(size_t)c * 4], c1 = nodes[(size_t)c * 4 + 1];
+    mn = min3(make_float3(c0.x, c0.y, c0.z), make_float3(c2.x, c2.y, c2.z));
+    mx = max3(make_float3(c1.x, c1.y, c1.z), make_float3(c3.x, c3.y, c3.z));
+    return true;
 }
 
-__global__ void k_al_refit(float4* __restrict__ nodes, uint32_t nNodes, const float4* __restrict__ tris, const float4* __restrict__ verts,
-                           const uint32_t* __restrict__ parent, uint32_t* __restrict__ arrived) {
-    uint32_t node = blockIdx.x * blockDim.x + threadIdx.x;
-    if (node >= nNodes) return;
-    const uint32_t cnt = as_u32(nodes[node * 4 + 2].w);
-    if (!cnt || node == 0) return;   // interior nodes are finished by their last child; a root leaf has no box to store
-    const uint32_t first = as_u32(nodes[node * 4 + 3].w);
-    float3 mn = make_float3(1e30f, 1e30f, 1e30f), mx = make_float3(-1e30f, -1e30f, -1e30f);
-    for (uint32_t k = 0; k < cnt; k++) grow_prim(verts, as_u32(tris[3 * (uint64_t)(first + k)].w), mn, mx);
-    for (;;) {
-        const uint32_t pe = parent[node], p = pe & 0x7fffffffu;
-        if (pe == 0xffffffffu) return;   // not referenced by any node (hole in the blob)
-        float4* pn = nodes + (size_t)p * 4;
-        const int o = (pe >> 31) ? 2 : 0;        // this child's {min, max} pair inside the parent record
-        pn[o] = make_float4(mn.x, mn.y, mn.z, pn[o].w);
-        pn[o + 1] = make_float4(mx.x, mx.y, mx.z, pn[o + 1].w);
-        __threadfence();
-        if (atomicAdd(arrived + p, 1u) == 0u) return;   // the sibling subtree is not finished yet
-        __threadfence();
-        if (p == 0) return;                              // the root's own box is not stored anywhere
-        const float3 smn = ld_agent3(pn + (2 - o)), smx = ld_agent3(pn + (3 - o));
-        mn = min3(mn, smn); mx = max3(mx, smx);
-        node = p;
-    }
+__global__ void k_al_pass(float4* __restrict__ nodes, uint32_t nNodes, const float4* __restrict__ tris, const float4* __restrict__ verts,
+                          uint32_t* __restrict__ done, uint32_t pass) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nNodes || done[i]) return;
+    float4* np = nodes + (size_t)i * 4;
+    const float* w = (const float*)np;
+    const uint32_t left = as_u32(w[3]), right = as_u32(w[7]), cnt = as_u32(w[11]);   // the .w of the first three float4
+    if (cnt) { done[i] = 1u; return; }   // leaf: nothing stored in it depends on the vertices
+    float3 lmn, lmx, rmn, rmx;
+    if (!al_child_box(nodes, nNodes, tris, verts, done, pass, left, lmn, lmx)) return;
+    if (!al_child_box(nodes, nNodes, tris, verts, done, pass, right, rmn, rmx)) return;
+    np[0] = make_float4(lmn.x, lmn.y, lmn.z, as_f32(left)); np[1] = make_float4(lmx.x, lmx.y, lmx.z, as_f32(right));
+    np[2] = make_float4(rmn.x, rmn.y, rmn.z, as_f32(0u)); np[3] = make_float4(rmx.x, rmx.y, rmx.z, np[3].w);
+    done[i] = pass;
 }
 
 // ---- BVH8_CWBVH -----------------------------------------------------------------------------------
-
-__global__ void k_cw_parents(const float4* __restrict__ nodes, uint32_t nNodes, uint32_t* __restrict__ parent) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nNodes) return;
-    const uint32_t imask = as_u32(nodes[(size_t)j * 5].w) >> 24, base = as_u32(nodes[(size_t)j * 5 + 1].x);
-    const uint32_t n = __popc(imask);
-    for (uint32_t k = 0; k < n; k++) if (base + k < nNodes) parent[base + k] = j;
-}
 
 // Re-encode node j from the boxes of its children (leaf children: from the vertices; interior children:
 // nodeBox[child], complete by the time this runs).  Returns the node's own box.
@@ -121,7 +115,7 @@ __device__ void cw_encode(float4* __restrict__ np, uint32_t nNodes, const float4
         float3 a = make_float3(1e30f, 1e30f, 1e30f), b = make_float3(-1e30f, -1e30f, -1e30f);
         if ((imask >> s) & 1u) {
             const uint32_t c = childBase + __popc(imask & ((1u << s) - 1u));
-            if (c < nNodes) { a = ld_agent3(boxMin + c); b = ld_agent3(boxMax + c); }
+            if (c < nNodes) { const float4 bn = boxMin[c], bx = boxMax[c]; a = make_float3(bn.x, bn.y, bn.z); b = make_float3(bx.x, bx.y, bx.z); }
         } else {
             // triBase counts float4 blocks (3 per triangle: the kernel addresses triBase + 3 * triangle), meta bits 0-4 the triangle offset
             const uint32_t first = triBase / 3u + (meta & 31u), cnt = __popc(meta >> 5);
@@ -134,54 +128,56 @@ __device__ void cw_encode(float4* __restrict__ np, uint32_t nNodes, const float4
     cw_quantize_write(np, mn, mx, cmn, cmx, used, imask, childBase, triBase, m0, m1);
 }
 
-__global__ void k_cw_refit(float4* __restrict__ nodes, uint32_t nNodes, const float4* __restrict__ tris, const float4* __restrict__ verts,
-                           const uint32_t* __restrict__ parent, uint32_t* __restrict__ arrived, float4* __restrict__ boxMin, float4* __restrict__ boxMax) {
-    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= nNodes) return;
-    if (as_u32(nodes[(size_t)j * 5].w) >> 24) return;   // has interior children: finished by the last of them
-    if (j != 0 && parent[j] == 0xffffffffu) return;      // not referenced by any node (hole in the blob)
-    for (;;) {
-        float3 mn, mx;
-        cw_encode(nodes + (size_t)j * 5, nNodes, tris, verts, boxMin, boxMax, mn, mx);
-        if (j == 0) return;
-        boxMin[j] = make_float4(mn.x, mn.y, mn.z, 0.f); boxMax[j] = make_float4(mx.x, mx.y, mx.z, 0.f);
-        __threadfence();
-        const uint32_t p = parent[j];
-        const uint32_t need = __popc(as_u32(nodes[(size_t)p * 5].w) >> 24);
-        if (atomicAdd(arrived + p, 1u) + 1u < need) return;   // other interior children of p are still open
-        __threadfence();
-        j = p;
+__global__ void k_cw_pass(float4* __restrict__ nodes, uint32_t nNodes, const float4* __restrict__ tris, const float4* __restrict__ verts,
+                          uint32_t* __restrict__ done, uint32_t pass, float4* __restrict__ boxMin, float4* __restrict__ boxMax) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nNodes || done[j]) return;
+    const uint32_t imask = as_u32(nodes[(size_t)j * 5].w) >> 24, base = as_u32(nodes[(size_t)j * 5 + 1].x);
+    const uint32_t nc = __popc(imask);
+    for (uint32_t k = 0; k < nc; k++) {
+        const uint32_t c = base + k;
+        if (c >= nNodes) continue;             // malformed: cw_encode leaves that child's box empty
+        const uint32_t d = done[c];
+        if (d == 0u || d >= pass) return;      // an interior child is not finished yet (or only in this pass)
     }
+    float3 mn, mx;
+    cw_encode(nodes + (size_t)j * 5, nNodes, tris, verts, boxMin, boxMax, mn, mx);
+    boxMin[j] = make_float4(mn.x, mn.y, mn.z, 0.f); boxMax[j] = make_float4(mx.x, mx.y, mx.z, 0.f);
+    done[j] = pass;
 }
 
 }  // namespace
 
 size_t refit_scratch_bytes(int layout, uint32_t nNodes) {
-    // parent + arrived (u32 each) [+ boxMin, boxMax (float4 each) for CWBVH]
-    return (size_t)nNodes * 8 + (layout == 9 ? (size_t)nNodes * 32 : 0) + 1024;
+    // done (u32) [+ boxMin, boxMax (float4 each) for CWBVH]
+    return (size_t)nNodes * 4 + (layout == 9 ? (size_t)nNodes * 32 : 0) + 1024;
 }
 
-// scratch layout: parent[nNodes] | arrived[nNodes] | boxMin[nNodes] | boxMax[nNodes]; parentsValid says whether
-// parent[] was already filled by an earlier refit of this scene (topology never changes)
+// scratch layout: done[nNodes] | boxMin[nNodes] | boxMax[nNodes]
 hipError_t launch_refit(int layout, float4* nodes, uint32_t nNodes, float4* tris, uint64_t nTriRecords, const float4* verts, uint64_t nTris,
-                        void* scratch, bool parentsValid, uint32_t* status, hipStream_t s) {
-    uint32_t* parent = (uint32_t*)scratch;
-    uint32_t* arrived = parent + nNodes;
-    float4* boxMin = (float4*)(((uintptr_t)(arrived + nNodes) + 255) & ~(uintptr_t)255);
+                        void* scratch, uint32_t* status, hipStream_t s) {
+    uint32_t* done = (uint32_t*)scratch;
+    float4* boxMin = (float4*)(((uintptr_t)(done + nNodes) + 255) & ~(uintptr_t)255);
     float4* boxMax = boxMin + nNodes;
     const uint32_t bs = 128, nb = (nNodes + bs - 1) / bs;
     const uint32_t tb = (uint32_t)((nTriRecords + 255) / 256);
-    hipError_t e = hipMemsetAsync(arrived, 0, (size_t)nNodes * 4, s);
-    if (e == hipSuccess && !parentsValid) e = hipMemsetAsync(parent, 0xff, (size_t)nNodes * 4, s);
+    hipError_t e = hipMemsetAsync(done, 0, (size_t)nNodes * 4, s);
     if (e != hipSuccess) return e;
-    if (layout == 9) {
-        if (nTriRecords) hipLaunchKernelGGL(k_regather<true>, dim3(tb), dim3(256), 0, s, tris, verts, nTriRecords, nTris, status);
-        if (!parentsValid) hipLaunchKernelGGL(k_cw_parents, dim3(nb), dim3(bs), 0, s, nodes, nNodes, parent);
-        hipLaunchKernelGGL(k_cw_refit, dim3(nb), dim3(bs), 0, s, nodes, nNodes, tris, verts, parent, arrived, boxMin, boxMax);
-    } else {
-        if (nTriRecords) hipLaunchKernelGGL(k_regather<false>, dim3(tb), dim3(256), 0, s, tris, verts, nTriRecords, nTris, status);
-        if (!parentsValid) hipLaunchKernelGGL(k_al_parents, dim3(nb), dim3(bs), 0, s, nodes, nNodes, parent);
-        hipLaunchKernelGGL(k_al_refit, dim3(nb), dim3(bs), 0, s, nodes, nNodes, tris, verts, parent, arrived);
+    if (nTriRecords) {
+        if (layout == 9) hipLaunchKernelGGL(k_regather<true>, dim3(tb), dim3(256), 0, s, tris, verts, nTriRecords, nTris, status);
+        else hipLaunchKernelGGL(k_regather<false>, dim3(tb), dim3(256), 0, s, tris, verts, nTriRecords, nTris, status);
+    }
+    // passes in batches; after each batch look at the root's done word (pass numbers start at 2)
+    const int batch = layout == 9 ? 6 : 24;
+    uint32_t pass = 2, rootDone = 0;
+    while (!rootDone) {
+        for (int k = 0; k < batch; k++, pass++) {
+            if (layout == 9) hipLaunchKernelGGL(k_cw_pass, dim3(nb), dim3(bs), 0, s, nodes, nNodes, tris, verts, done, pass, boxMin, boxMax);
+            else hipLaunchKernelGGL(k_al_pass, dim3(nb), dim3(bs), 0, s, nodes, nNodes, tris, verts, done, pass);
+        }
+        if ((e = hipMemcpyAsync(&rootDone, done, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        if (pass > 200000u) return hipErrorUnknown;   // cyclic blob
     }
     return hipGetLastError();
 }

@@ -33,7 +33,7 @@ for layout in [int(x) for x in a.layouts.split(",")]:
     for it in range(4):
         sc.Refit((d_v, v2.shape[0] // 3), on_device=True); ctx.synchronize(); ms.append(ctx.time_last_ms())
     ctx.generate_primary(cam, d_rays, 0, n); sc.intersect_device(d_rays, n); t1 = ctx.time_last_ms()
-    print(f"{label}: layout {layout}: {verts.shape[0] // 3} tris, {sc.device_bytes / 1e6:.0f} MB on device; refit {ms[0]:.3f} ms first (builds parent links), "
+    print(f"{label}: layout {layout}: {verts.shape[0] // 3} tris, {sc.device_bytes / 1e6:.0f} MB on device; refit {ms[0]:.3f} ms first call, "
           f"{np.mean(ms[1:]):.3f} ms after = {verts.shape[0] // 3 / np.mean(ms[1:]) / 1e3:.0f} Mtris/s; trace {n} camera rays {t0:.3f} ms before, {t1:.3f} ms after", flush=True)
     sc.free()
 ctx.close()
