@@ -67,6 +67,7 @@ struct tbvh_scene {
     float4* nodes = nullptr;   // BVH_GPU nodes / BVH4 stream / CWBVH nodes
     float4* tris = nullptr;    // BVH_GPU gathered tris / CWBVH tris
     char* nodesH = nullptr;    // CWBVH: 128-byte re-laid-out nodes (kernels_cwbvh_h.hip)
+    float4* nodes128 = nullptr; // CWBVH: the same nodes padded to 128 bytes (variant 47)
     float4* nodesP = nullptr;  // CWBVH: nodes renumbered in surface-area priority order (kernels_cwbvh_c.hip)
     uint32_t nNodes = 0;
     uint64_t nNodeBlocks = 0, nTriBlocks = 0;
@@ -165,7 +166,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         q.spillStride = c->spillEntries / 2;  // 8-byte entries
         if (s->variant >= 30 && s->variant < 40) launch_cwbvh_c(any, s->variant, s->nodesP, s->tris, s->nNodes, q, c->status, (uint32_t)c->numCUs, c->stream);
         else if (s->variant >= 20 && s->variant < 30) launch_cwbvh_h(any, s->variant, s->nodesH, s->tris, q, c->status, blocks, c->stream);
-        else launch_cwbvh(any, s->variant, s->nodes, s->tris, q, c->status, blocks, c->stream);
+        else launch_cwbvh(any, s->variant, s->variant == 47 ? s->nodes128 : s->nodes, s->tris, q, c->status, blocks, c->stream);
         break;
     default:
         return fail(TBVH_E_INVALID, "scene layout %d has no query kernel", s->layout);
@@ -533,6 +534,7 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
     c->timed = true;
     // derived node layouts of the experiment kernels would be stale now
     if (s->nodesH) { hipStreamSynchronize(c->stream); hipFree(s->nodesH); s->nodesH = nullptr; }
+    if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copy current
     if (s->nodesP) { hipStreamSynchronize(c->stream); hipFree(s->nodesP); s->nodesP = nullptr; }
     if (s->variant >= 20 && s->variant < 40) s->variant = 0;
     return 0;
@@ -604,6 +606,7 @@ void tbvh_free_scene(tbvh_scene* s) {
     if (s->nodes) hipFree(s->nodes);
     if (s->tris) hipFree(s->tris);
     if (s->nodesH) hipFree(s->nodesH);
+    if (s->nodes128) hipFree(s->nodes128);
     if (s->nodesP) hipFree(s->nodesP);
     if (s->tlasIdx) hipFree(s->tlasIdx);
     if (s->instances) hipFree(s->instances);
@@ -627,6 +630,13 @@ int tbvh_set_variant(tbvh_scene* s, int v) {
     tbvh_context* c = s->ctx;
     if (int r = setDevice(c)) return r;
     // experimental kernels run on derived node layouts, built on first use
+    if (v == 47 && !s->nodes128) {
+        HIP_TRY(hipMalloc((void**)&s->nodes128, (size_t)s->nNodes * 128));
+        launch_cwbvh_pad(s->nodes, s->nodes128, s->nNodes, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        s->bytes += (uint64_t)s->nNodes * 128;
+    }
     if (v >= 20 && v < 30 && !s->nodesH) {
         HIP_TRY(hipMalloc((void**)&s->nodesH, (size_t)s->nNodes * 128));
         launch_cwbvh_relayout(s->nodes, s->nodesH, s->nNodes, c->stream);

@@ -10,6 +10,7 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                   uint32_t blocks, hipStream_t s);
 bool cwbvh_variant_valid(int variant);
+void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream_t s);
 void launch_cwbvh_h(bool anyhit, int variant, const char* nodesH, const float4* tris, const QueryArgs& q, uint32_t* status,
                     uint32_t blocks, hipStream_t s);
 void launch_cwbvh_relayout(const float4* src, char* dst, uint32_t nNodes, hipStream_t s);

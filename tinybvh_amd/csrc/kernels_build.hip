@@ -2,7 +2,7 @@
 // BVHNode format) ("a GPU LBVH builder feeding the conversions").
 //
 // For content that changes topology every frame, or scenes whose host build (BVH::Build,
-// tiny_bvh.h:2124-2461: seconds for Bistro) is the bottleneck: 30-bit Morton codes of the triangle
+// tiny_bvh.h:2124-2461: seconds for Bistro) is the bottleneck: 63-bit Morton codes of the triangle
 // centroids, radix sort, Karras 2012 topology, bottom-up boxes.  The result is written directly in the
 // layout BVH::Build produces — 32-byte nodes {aabbMin, leftFirst, aabbMax, triCount}, root at 0, node 1
 // unused, the two children of a node adjacent (tiny_bvh.h:1050-1062) — plus a primIdx array, so it feeds
@@ -30,12 +30,14 @@ __device__ __forceinline__ uint32_t enc_f32(float f) {   // order-preserving flo
 }
 __device__ __forceinline__ float dec_f32(uint32_t e) { return as_f32((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
 
-__device__ __forceinline__ uint32_t spread10(uint32_t v) {   // 10 bits -> every third bit
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
-    return v;
+__device__ __forceinline__ unsigned long long spread21(uint32_t v) {   // 21 bits -> every third bit of 63
+    unsigned long long x = v & 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
 }
 
 // per-triangle box + centroid bounds of the scene (wave reduction, one atomic set per wave)
@@ -60,7 +62,7 @@ __global__ void k_tri_boxes(const float4* __restrict__ verts, uint32_t n, float4
 }
 
 __global__ void k_tri_morton(const float4* __restrict__ triMin, const float4* __restrict__ triMax, const uint32_t* __restrict__ centreBounds,
-                             uint32_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                             uint32_t n, unsigned long long* __restrict__ keys, uint32_t* __restrict__ vals) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 a = triMin[i], b = triMax[i];
@@ -71,22 +73,24 @@ __global__ void k_tri_morton(const float4* __restrict__ triMin, const float4* __
         const float ext = hi - lo;
         float u = ext > 0 ? (c[k] - lo) / ext : 0.f;
         u = u < 0 ? 0.f : (u > 1 ? 1.f : u);
-        const uint32_t v = (uint32_t)(u * 1023.0f);
-        q[k] = v > 1023u ? 1023u : v;
+        const uint32_t v = (uint32_t)(u * 2097151.0f);
+        q[k] = v > 2097151u ? 2097151u : v;
     }
-    keys[i] = (spread10(q[0]) << 2) | (spread10(q[1]) << 1) | spread10(q[2]);
+    // 63-bit codes (21 bits per axis): with 30-bit codes a 2.8 M-triangle scene puts dozens of triangles into one
+    // cell, and everything below that is split by array position instead of by space
+    keys[i] = (spread21(q[0]) << 2) | (spread21(q[1]) << 1) | spread21(q[2]);
     vals[i] = i;
 }
 
-__device__ __forceinline__ int delta(const uint32_t* __restrict__ keys, int n, int i, int j) {
+__device__ __forceinline__ int delta(const unsigned long long* __restrict__ keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    const uint32_t a = keys[i], b = keys[j];
-    return a == b ? 32 + __clz((uint32_t)(i ^ j)) : __clz(a ^ b);
+    const unsigned long long a = keys[i], b = keys[j];
+    return a == b ? 64 + __clz((uint32_t)(i ^ j)) : __clzll(a ^ b);
 }
 
 // Karras 2012.  Per interior node i: its two children (leaf k is numbered n - 1 + k), its sorted range.
 // parent[c] = i, bit 31 set for the right child.
-__global__ void k_topology(const uint32_t* __restrict__ keys, uint32_t n, uint32_t* __restrict__ parent, uint2* __restrict__ children, uint2* __restrict__ range) {
+__global__ void k_topology(const unsigned long long* __restrict__ keys, uint32_t n, uint32_t* __restrict__ parent, uint2* __restrict__ children, uint2* __restrict__ range) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int N = (int)n;
     if (i >= N - 1) return;
@@ -173,7 +177,8 @@ __global__ void k_wald_pass(const uint32_t* __restrict__ parent, const uint2* __
 
 struct Scratch {
     float4 *triMin, *triMax, *boxMin, *boxMax;
-    uint32_t *keysA, *keysB, *valsA, *parent, *flags, *bounds;
+    unsigned long long *keysA, *keysB;
+    uint32_t *valsA, *parent, *flags, *bounds;
     uint2 *children, *range;
     void* sortTemp;
     size_t total;
@@ -184,7 +189,7 @@ Scratch carve(void* base, uint32_t n, size_t sortTempBytes) {
     Scratch s;
     s.triMin = (float4*)take((size_t)n * 16); s.triMax = (float4*)take((size_t)n * 16);
     s.boxMin = (float4*)take((size_t)n * 32); s.boxMax = (float4*)take((size_t)n * 32);   // 2n - 1 Karras nodes
-    s.keysA = (uint32_t*)take((size_t)n * 4); s.keysB = (uint32_t*)take((size_t)n * 4);
+    s.keysA = (unsigned long long*)take((size_t)n * 8); s.keysB = (unsigned long long*)take((size_t)n * 8);
     s.valsA = (uint32_t*)take((size_t)n * 4);
     s.parent = (uint32_t*)take((size_t)n * 8);
     s.children = (uint2*)take((size_t)n * 8); s.range = (uint2*)take((size_t)n * 8);
@@ -199,7 +204,7 @@ Scratch carve(void* base, uint32_t n, size_t sortTempBytes) {
 
 size_t lbvh_scratch_bytes(uint32_t n, size_t* sortTempBytes) {
     size_t tmp = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 30);
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 63);
     *sortTempBytes = tmp;
     return carve(nullptr, n, tmp).total;
 }
@@ -218,7 +223,7 @@ hipError_t launch_lbvh_build(const float4* verts, uint32_t n, uint32_t maxLeaf, 
     hipLaunchKernelGGL(k_tri_boxes, dim3(nb), dim3(bs), 0, s, verts, n, sc.triMin, sc.triMax, sc.bounds);
     hipLaunchKernelGGL(k_tri_morton, dim3(nb), dim3(bs), 0, s, sc.triMin, sc.triMax, sc.bounds, n, sc.keysA, sc.valsA);
     size_t tmp = sortTempBytes;
-    if ((e = hipcub::DeviceRadixSort::SortPairs(sc.sortTemp, tmp, sc.keysA, sc.keysB, sc.valsA, primIdx, (int)n, 0, 30, s)) != hipSuccess) return e;
+    if ((e = hipcub::DeviceRadixSort::SortPairs(sc.sortTemp, tmp, sc.keysA, sc.keysB, sc.valsA, primIdx, (int)n, 0, 63, s)) != hipSuccess) return e;
     if (n > 1) hipLaunchKernelGGL(k_topology, dim3(nb), dim3(bs), 0, s, sc.keysB, n, sc.parent, sc.children, sc.range);
     hipLaunchKernelGGL(k_wald_leaves, dim3(nb), dim3(bs), 0, s, primIdx, sc.triMin, sc.triMax, sc.parent, sc.boxMin, sc.boxMax, n, nodes32);
     // passes in batches; after each batch look at the root's done word (pass numbers start at 2: 1 means "leaf")

@@ -35,9 +35,10 @@ __device__ __forceinline__ uint32_t sext_s8x4(uint32_t i) {
 // triangles).  Also returns child / triangle base and imask.
 struct NodeResult { uint32_t childBase, triBase, hitmask, imask; };
 
+template <int NSTRIDE = 5>
 __device__ __forceinline__ NodeResult visit_node(const float4* __restrict__ nodes, uint32_t nodeIdx, float3 O,
                                                  float3 rD, float tmax, uint32_t octinv4) {
-    const float4* np = nodes + nodeIdx * 5u;
+    const float4* np = nodes + (size_t)nodeIdx * (uint32_t)NSTRIDE;
     const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
     const uint32_t ew = as_u32(n0.w);
     const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
@@ -120,7 +121,8 @@ __device__ __forceinline__ NodeResult visit_node_pk(const float4* __restrict__ n
 // MODE 0: whole-wave batches (a wave takes 64 consecutive rays and finishes them all).
 // MODE 1: per-lane replacement from a wave-local pool; REFILL_MIN idle lanes trigger a refill.
 // ADAPT: the wave's LockstepGovernor (ray_pool.h) decides when it takes new rays.
-template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false, int TRI_MIN = 1, bool PKFMA = false, int CHUNK = 64, bool ADAPT = false>
+template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false, int TRI_MIN = 1, bool PKFMA = false, int CHUNK = 64, bool ADAPT = false,
+          int NSTRIDE = 5>
 __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
                         const uint32_t slot = (bit - 24u) ^ oct;
                         const uint32_t rel = __popc(imask & ~(0xFFFFFFFFu << slot));
                         const NodeResult r = PKFMA ? visit_node_pk(nodes, cbase + rel, O, rD, hit.x, octinv4)
-                                                   : visit_node(nodes, cbase + rel, O, rD, hit.x, octinv4);
+                                                   : visit_node<NSTRIDE>(nodes, cbase + rel, O, rD, hit.x, octinv4);
                         ng.x = r.childBase; tg.x = r.triBase;
                         ng.y = (r.hitmask & 0xFF000000u) | r.imask;
                         tg.y = r.hitmask & 0x00FFFFFFu;
@@ -403,6 +405,7 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     case 16: TBVH_LAUNCH(1, 8, 16, true, false, 1, true); break;  // packed plane FMAs
     case 44: TBVH_LAUNCH(1, 8, 64, true); break;   // lockstep throughout: a wave only takes new rays when all 64 lanes are idle
     case 45: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 64, true); break;   // adaptive (= default)
+    case 47: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 64, true, 8); break;   // adaptive, nodes padded to 128 bytes (one cache line per node)
     case 46:  // lockstep throughout + histogram of per-generation lane cohesion in q.stats
         hipLaunchKernelGGL((k_cwbvh<false, 1, 8, 16, true, true, 1, false, 64, true>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
         break;
@@ -421,6 +424,19 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
 #undef TBVH_LAUNCH
 }
 
-bool cwbvh_variant_valid(int v) { return (v >= 0 && v <= 19) || (v >= 40 && v <= 46 && v != 42 && v != 43); }
+namespace {
+__global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__ dst, uint32_t nNodes) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // one thread per float4 of the padded array
+    if (i >= nNodes * 8u) return;
+    const uint32_t n = i >> 3, k = i & 7u;
+    dst[i] = k < 5u ? src[n * 5u + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+}  // namespace
+// 80-byte nodes straddle 128-byte lines (1.6 lines per node on average); the padded copy costs 60 % more node memory
+void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream_t s) {
+    hipLaunchKernelGGL(k_pad_nodes, dim3((nNodes * 8u + 255u) / 256u), dim3(256), 0, s, src, dst, nNodes);
+}
+
+bool cwbvh_variant_valid(int v) { return (v >= 0 && v <= 19) || (v >= 40 && v <= 47 && v != 42 && v != 43); }
 
 }  // namespace tbvh
