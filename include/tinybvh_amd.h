@@ -114,7 +114,9 @@ int tbvh_update_tlas(tbvh_scene* tlas, const void* tlas_nodes64, uint64_t n_node
  * BVHNode: aabbMin, leftFirst, aabbMax, triCount; children adjacent; tiny_bvh.h:1050-1062), n_nodes =
  * usedNodes, prim_idx = BVH::primIdx (n_idx = idxCount), verts16 = the vertex array; all three in host memory
  * (on_device = 0) or device memory (1).  Leaves must hold at most 3 triangles (BVH::SplitLeafs(3), which the
- * reference's ConvertFrom also requires); otherwise TBVH_E_FORMAT.  layout: TBVH_LAYOUT_CWBVH.
+ * reference's ConvertFrom also requires) for TBVH_LAYOUT_CWBVH; otherwise TBVH_E_FORMAT.  layout: TBVH_LAYOUT_CWBVH, or
+ * TBVH_LAYOUT_BVH4_GPU (BVH4_GPU::ConvertFrom, tiny_bvh.h:5115-5244: 4-wide collapse, quantised child boxes,
+ * triangles inline after their node).
  * Synchronous (one small read-back per level of the wide tree); tbvh_time_last_ms() = time spent converting. */
 int tbvh_convert_bvh2_device(tbvh_context* ctx, const void* nodes32, uint64_t n_nodes, const uint32_t* prim_idx, uint64_t n_idx,
                              const void* verts16, uint64_t n_tris, int on_device, int layout, tbvh_scene** out);
@@ -123,7 +125,8 @@ int tbvh_convert_bvh2_device(tbvh_context* ctx, const void* nodes32, uint64_t n_
  * The fast path for content whose topology changes every frame or whose host build (BVH::Build,
  * tiny_bvh.h:2124-2461) is the bottleneck; the tree is of lower quality than the binned-SAH build (more node
  * visits per ray), so it is not what the host builder or the bench use.  verts16: bvhvec4 vertices, 3 per
- * triangle, host (on_device = 0) or device memory (1); max_leaf_tris 1..3 (0 = 3).  layout: TBVH_LAYOUT_CWBVH.
+ * triangle, host (on_device = 0) or device memory (1); layout: TBVH_LAYOUT_CWBVH (max_leaf_tris 1..3, 0 = 3) or
+ * TBVH_LAYOUT_BVH4_GPU (1..4, 0 = 4).
  * prim indices in the hit records are the triangle's index in verts16, as with every other builder. */
 int tbvh_build_device(tbvh_context* ctx, const void* verts16, uint64_t n_tris, int on_device, int layout,
                       uint32_t max_leaf_tris, tbvh_scene** out);

@@ -102,3 +102,27 @@ def test_build_on_device_parity(ctx, oracle, scene, n, leaf):
     sc2 = tb.BVH8_CWBVH(ctx).BuildOnDevice(v2, max_leaf_tris=leaf)
     h2 = tb.HostBVH(v2, tb.LAYOUT_CWBVH)
     check(sc2.Intersect(rays.copy()), oracle.bvh2_intersect(h2.bvh2_nodes(), h2.bvh2_prim_idx(), v2, rays))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scene,n", [("soup", 3000), ("blob", 20000), ("atrium", 0), ("soup", 1)])
+def test_bvh4_gpu_convert_and_build_on_device(ctx, oracle, scene, n):
+    """BVH4_GPU as the target: conversion of a host BVH2 and the full device build."""
+    verts = scenes.soup(n, seed=4) if scene == "soup" else scenes.blob(n, seed=7) if scene == "blob" else scenes.get("sponza")[0]
+    host = tb.HostBVH(verts, tb.LAYOUT_BVH4_GPU)
+    n2, pi = host.bvh2_nodes(), host.bvh2_prim_idx()
+    lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+    pad = 0.05 * (hi - lo) + 0.01
+    rays = R.random_rays(40_000, lo - pad, hi + pad, seed=3)
+    want = oracle.bvh2_intersect(n2, pi, verts, rays)
+    conv = tb.BVH4_GPU(ctx).ConvertFromBVH2(n2, pi, verts)
+    blocks, _ = conv.download_blobs()
+    assert blocks.shape[0] == host.blob(0, np.uint32, 4).shape[0]      # same collapse as the host encoder: same stream length
+    tb.BVH4_GPU(ctx).Upload(blocks)                                       # passes the blob validator
+    check(conv.Intersect(rays.copy()), want)
+    built = tb.BVH4_GPU(ctx).BuildOnDevice(verts)
+    b2, _ = built.download_blobs()
+    tb.BVH4_GPU(ctx).Upload(b2)
+    check(built.Intersect(rays.copy()), want)
+    occ = built.IsOccluded(rays.copy())
+    assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2

@@ -269,6 +269,19 @@ class BVH4_GPU(_Scene):
         self.host = HostBVH(verts, LAYOUT_BVH4_GPU, **kw)
         return self.Upload(self.host.blob(0, np.uint32, 4))
 
+    def BuildOnDevice(self, verts: np.ndarray, max_leaf_tris: int = 4) -> "BVH4_GPU":
+        """LBVH build + 4-wide collapse + encode on the GPU (tbvh_build_device)."""
+        verts = np.ascontiguousarray(verts, np.float32)
+        check(lib.tbvh_build_device(self.ctx._h, _ptr(verts), verts.shape[0] // 3, 0, LAYOUT_BVH4_GPU, max_leaf_tris, C.byref(self._h)), "tbvh_build_device")
+        return self
+
+    def ConvertFromBVH2(self, nodes32: np.ndarray, prim_idx: np.ndarray, verts: np.ndarray) -> "BVH4_GPU":
+        """BVH4_GPU::ConvertFrom on the device (tbvh_convert_bvh2_device)."""
+        nodes32 = np.ascontiguousarray(nodes32); prim_idx = np.ascontiguousarray(prim_idx, np.uint32); verts = np.ascontiguousarray(verts, np.float32)
+        check(lib.tbvh_convert_bvh2_device(self.ctx._h, _ptr(nodes32), nodes32.nbytes // 32, _ptr(prim_idx), prim_idx.size, _ptr(verts), verts.shape[0] // 3,
+                                           0, LAYOUT_BVH4_GPU, C.byref(self._h)), "tbvh_convert_bvh2_device")
+        return self
+
     def Upload(self, blocks16: np.ndarray) -> "BVH4_GPU":
         blocks16 = np.ascontiguousarray(blocks16)
         check(lib.tbvh_upload_bvh4_gpu(self.ctx._h, _ptr(blocks16), blocks16.nbytes // 16, C.byref(self._h)), "tbvh_upload_bvh4_gpu")

@@ -402,8 +402,40 @@ int tbvh_update_tlas(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const 
 
 namespace {
 // BVH2 (device arrays) -> CWBVH scene.  msBefore: device time already spent on this request (builder), added to the report.
-int convertDeviceImpl(tbvh_context* c, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris,
+int convertDeviceImpl4(tbvh_context* c, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris,
+                       tbvh_scene** out) {
+    struct Tmp {
+        void *blocks = nullptr, *itA = nullptr, *itB = nullptr, *cnt = nullptr;
+        ~Tmp() { for (void* p : {blocks, itA, itB, cnt}) if (p) hipFree(p); }
+    } t;
+    const uint64_t capItems = nNodes2 / 2 + 2, capBlocks = capItems * 4 + nIdx * 3;
+    if (capBlocks > 0xffffffffull) return fail(TBVH_E_INVALID, "BVH2 -> BVH4_GPU: stream would exceed 32-bit block indices");
+    HIP_TRY(hipMalloc(&t.blocks, capBlocks * 16));
+    HIP_TRY(hipMalloc(&t.itA, capItems * 8)); HIP_TRY(hipMalloc(&t.itB, capItems * 8)); HIP_TRY(hipMalloc(&t.cnt, 16));
+    uint64_t nBlocks = 0; uint32_t levels = 0;
+    HIP_TRY(run_convert_bvh4(dN2, (uint32_t)nNodes2, dIdx, nIdx, dV, nTris, (float4*)t.blocks, capBlocks, (uint2*)t.itA, (uint2*)t.itB, (uint32_t*)t.cnt, c->status,
+                             c->stream, &nBlocks, &levels));
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpy(&st, c->status, 4, hipMemcpyDeviceToHost));
+    if (st & 12u) {
+        hipMemset(c->status, 0, 4);
+        return fail(TBVH_E_FORMAT, (st & 8u) ? "BVH2 -> BVH4_GPU: a node's inline triangles exceed the 16-bit relative offset (leaves too large)"
+                                             : "BVH2 -> BVH4_GPU: malformed BVH2 (child, primitive or triangle index out of range)");
+    }
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH4_GPU);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    hipError_t e = hipMalloc((void**)&s->nodes, nBlocks * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, t.blocks, nBlocks * 16, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH2 -> BVH4_GPU: %s", hipGetErrorString(e)); }
+    s->nNodeBlocks = nBlocks; s->bytes = nBlocks * 16;
+    *out = s;
+    return 0;
+}
+
+int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris,
                       tbvh_scene** out) {
+    if (layout == TBVH_LAYOUT_BVH4_GPU) return convertDeviceImpl4(c, dN2, nNodes2, dIdx, nIdx, dV, nTris, out);
     struct Tmp {
         void *nodes = nullptr, *tris = nullptr, *itA = nullptr, *itB = nullptr, *cnt = nullptr;
         ~Tmp() { for (void* p : {nodes, tris, itA, itB, cnt}) if (p) hipFree(p); }
@@ -441,7 +473,7 @@ int convertDeviceImpl(tbvh_context* c, const float4* dN2, uint64_t nNodes2, cons
 int tbvh_convert_bvh2_device(tbvh_context* c, const void* nodes32, uint64_t nNodes2, const uint32_t* primIdx, uint64_t nIdx, const void* verts16,
                              uint64_t nTris, int onDevice, int layout, tbvh_scene** out) {
     if (!c || !nodes32 || !primIdx || !verts16 || !out || nNodes2 == 0 || nIdx == 0 || nTris == 0) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: null/empty argument");
-    if (layout != TBVH_LAYOUT_CWBVH) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: target layout %d not supported (BVH8_CWBVH is)", layout);
+    if (layout != TBVH_LAYOUT_CWBVH && layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: target layout %d not supported (BVH8_CWBVH and BVH4_GPU are)", layout);
     if (nNodes2 > 0x7fffffffull || nIdx > 0x7fffffffull) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: BVH2 too large for 32-bit node / triangle indices");
     if (int r = setDevice(c)) return r;
     struct Tmp {
@@ -458,7 +490,7 @@ int tbvh_convert_bvh2_device(tbvh_context* c, const void* nodes32, uint64_t nNod
         dN2 = (const float4*)t.n2; dIdx = (const uint32_t*)t.idx; dV = (const float4*)t.v;
     }
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    const int r = convertDeviceImpl(c, dN2, nNodes2, dIdx, nIdx, dV, nTris, out);
+    const int r = convertDeviceImpl(c, layout, dN2, nNodes2, dIdx, nIdx, dV, nTris, out);
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     return r;
@@ -466,10 +498,11 @@ int tbvh_convert_bvh2_device(tbvh_context* c, const void* nodes32, uint64_t nNod
 
 int tbvh_build_device(tbvh_context* c, const void* verts16, uint64_t nTris, int onDevice, int layout, uint32_t maxLeafTris, tbvh_scene** out) {
     if (!c || !verts16 || !out || nTris == 0) return fail(TBVH_E_INVALID, "tbvh_build_device: null/empty argument");
-    if (layout != TBVH_LAYOUT_CWBVH) return fail(TBVH_E_INVALID, "tbvh_build_device: target layout %d not supported (BVH8_CWBVH is)", layout);
+    if (layout != TBVH_LAYOUT_CWBVH && layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "tbvh_build_device: target layout %d not supported (BVH8_CWBVH and BVH4_GPU are)", layout);
     if (nTris > 0x3fffffffull) return fail(TBVH_E_INVALID, "tbvh_build_device: too many triangles for 32-bit node indices");
-    if (maxLeafTris == 0) maxLeafTris = 3;
-    if (maxLeafTris > 3) return fail(TBVH_E_INVALID, "tbvh_build_device: at most 3 triangles per leaf (CWBVH)");
+    const uint32_t leafCap = layout == TBVH_LAYOUT_CWBVH ? 3u : 4u;
+    if (maxLeafTris == 0) maxLeafTris = leafCap;
+    if (maxLeafTris > leafCap) return fail(TBVH_E_INVALID, "tbvh_build_device: at most %u triangles per leaf for this layout", leafCap);
     if (int r = setDevice(c)) return r;
     struct Tmp {
         void *v = nullptr, *n2 = nullptr, *idx = nullptr, *scratch = nullptr;
@@ -486,7 +519,7 @@ int tbvh_build_device(tbvh_context* c, const void* verts16, uint64_t nTris, int 
     HIP_TRY(hipMalloc(&t.n2, nTris * 2 * 32)); HIP_TRY(hipMalloc(&t.idx, nTris * 4)); HIP_TRY(hipMalloc(&t.scratch, scratchBytes));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(launch_lbvh_build(dV, (uint32_t)nTris, maxLeafTris, (float4*)t.n2, (uint32_t*)t.idx, t.scratch, sortTemp, c->stream));
-    const int r = convertDeviceImpl(c, (const float4*)t.n2, nTris * 2, (const uint32_t*)t.idx, nTris, dV, nTris, out);
+    const int r = convertDeviceImpl(c, layout, (const float4*)t.n2, nTris * 2, (const uint32_t*)t.idx, nTris, dV, nTris, out);
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     return r;

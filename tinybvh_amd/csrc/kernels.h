@@ -31,6 +31,9 @@ hipError_t launch_lbvh_build(const float4* verts, uint32_t n, uint32_t maxLeaf, 
 hipError_t run_convert_cwbvh(const float4* nodes2, uint32_t nNodes2, const uint32_t* primIdx, uint64_t nIdx, const float4* verts, uint64_t nTris,
                              float4* cwNodes, uint32_t capNodes, float4* cwTris, uint64_t capTris, uint2* itemsA, uint2* itemsB, uint32_t* counters,
                              uint32_t* status, hipStream_t s, uint32_t* nNodesOut, uint64_t* nTrisOut, uint32_t* levelsOut);
+hipError_t run_convert_bvh4(const float4* nodes2, uint32_t nNodes2, const uint32_t* primIdx, uint64_t nIdx, const float4* verts, uint64_t nTris,
+                            float4* blocks, uint64_t capBlocks, uint2* itemsA, uint2* itemsB, uint32_t* counters, uint32_t* status, hipStream_t s,
+                            uint64_t* nBlocksOut, uint32_t* levelsOut);
 // device BLAS refit (kernels_refit.hip)
 size_t refit_scratch_bytes(int layout, uint32_t nNodes);
 hipError_t launch_refit(int layout, float4* nodes, uint32_t nNodes, float4* tris, uint64_t nTriRecords, const float4* verts, uint64_t nTris,

@@ -131,6 +131,103 @@ __global__ void k_convert_level(const float4* __restrict__ nodes2, uint32_t nNod
     cw_quantize_write(cwNodes + (size_t)item.y * 5, self.mn, self.mx, cmn, cmx, used, imask, childBase, triFirst * 3u, m0, m1);
 }
 
+
+// ---- BVH4_GPU (tiny_bvh.h:5115-5244; host_builder.cpp: encode_bvh4_gpu) ---------------------------------------
+// One float4 stream: a node is 4 blocks {bmin | qxmin x4} {ext/255 | qxmax x4} {qymin, qymax, qzmin, qzmax x4}
+// {childInfo x4}; the triangles of its leaf children follow it inline as {v0|prim, e1, e2}.  childInfo: interior =
+// block index of the child node; leaf = 1<<31 | triCount<<16 | offset of its first triangle relative to the node.
+// A node and its inline triangles are one allocation (one atomic); the block index of an interior child is not
+// known when the parent is written, so the child patches it into the parent's childInfo word when it is emitted
+// one level later (the host encoder does the same with its patchWord).
+// counters: [0] blocks allocated, [2] work items for the next level.  items: x = BVH2 node, y = u32 index (into the
+// stream viewed as words) of the childInfo word to patch, 0xffffffff for the root.
+__global__ void k_convert4_level(const float4* __restrict__ nodes2, uint32_t nNodes2, const uint32_t* __restrict__ primIdx, uint64_t nIdx,
+                                 const float4* __restrict__ verts, uint64_t nTris, const uint2* __restrict__ itemsIn, uint32_t nIn,
+                                 uint2* __restrict__ itemsOut, uint32_t* __restrict__ counters, float4* __restrict__ blocks, uint64_t capBlocks,
+                                 uint32_t* __restrict__ status) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nIn) return;
+    const uint2 item = itemsIn[t];
+    const N2 self = load_n2(nodes2, item.x);
+    uint32_t kids[4];
+    uint32_t nk;
+    if (self.triCount) { kids[0] = item.x; nk = 1; }   // single-leaf BVH2: the root gets that leaf as its only child
+    else {
+        kids[0] = self.leftFirst; kids[1] = self.leftFirst + 1; nk = 2;
+        if (kids[1] >= nNodes2) { atomicOr(status, 4u); return; }
+        while (nk < 4u) {
+            int best = -1; float bestSA = -1.f;
+            for (uint32_t i = 0; i < nk; i++) {
+                const N2 c = load_n2(nodes2, kids[i]);
+                if (c.triCount) continue;
+                const float sa = half_area(c);
+                if (sa > bestSA) { bestSA = sa; best = (int)i; }
+            }
+            if (best < 0) break;
+            const uint32_t l = load_n2(nodes2, kids[best]).leftFirst;
+            if (l + 1 >= nNodes2) { atomicOr(status, 4u); return; }
+            kids[best] = l; kids[nk++] = l + 1;
+        }
+    }
+    N2 kid[4];
+    uint32_t nT = 0, nInner = 0;
+    for (uint32_t i = 0; i < nk; i++) {
+        kid[i] = load_n2(nodes2, kids[i]);
+        if (kid[i].triCount) { if (kid[i].triCount >= 32768u) { atomicOr(status, 8u); return; } nT += kid[i].triCount; } else nInner++;
+    }
+    if (4u + 3u * nT >= 65536u) { atomicOr(status, 8u); return; }   // inline triangles must stay within the 16-bit relative offset
+    const uint32_t base = atomicAdd(counters + 0, 4u + 3u * nT);
+    const uint32_t outFirst = nInner ? atomicAdd(counters + 2, nInner) : 0u;
+    if ((uint64_t)base + 4u + 3u * nT > capBlocks) { atomicOr(status, 4u); return; }
+    if (item.y != 0xffffffffu) ((uint32_t*)blocks)[item.y] = base;
+    // quantisation frame (reference: scale 254.999 / extent, decode bmin + (extent / 255) * q; the decode step is
+    // nudged up until 255 steps really reach the far face, and every plane is verified against the decode)
+    const float bmn[3] = {self.mn.x, self.mn.y, self.mn.z}, bmx[3] = {self.mx.x, self.mx.y, self.mx.z};
+    float ext[3], scale[3], e255[3], guard[3];
+    for (int a = 0; a < 3; a++) {
+        ext[a] = bmx[a] - bmn[a];
+        scale[a] = ext[a] > 1e-10f ? 254.999f / ext[a] : 0.f;
+        e255[a] = ext[a] * (1.0f / 255.0f);
+        guard[a] = 4e-7f * fmaxf(fmaxf(fabsf(bmn[a]), fabsf(bmx[a])), ext[a]);
+        while (ext[a] > 0 && bmn[a] + e255[a] * 255.0f < bmx[a] + guard[a]) e255[a] = nextafterf(e255[a], 1e30f);
+    }
+    uint32_t info[4] = {0, 0, 0, 0}, q[6] = {0, 0, 0, 0, 0, 0};   // q: xmin, xmax, ymin, ymax, zmin, zmax; byte i = child i
+    uint32_t rel = 4, inner = 0;
+    for (uint32_t i = 0; i < nk; i++) {
+        const N2& c = kid[i];
+        const float cmn[3] = {c.mn.x, c.mn.y, c.mn.z}, cmx[3] = {c.mx.x, c.mx.y, c.mx.z};
+        for (int a = 0; a < 3; a++) {
+            int lo = (int)floorf((cmn[a] - bmn[a]) * scale[a]), hi = (int)ceilf((cmx[a] - bmn[a]) * scale[a]);
+            lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo); hi = hi < 0 ? 0 : (hi > 255 ? 255 : hi);
+            while (lo > 0 && bmn[a] + e255[a] * (float)lo > cmn[a] - guard[a]) lo--;
+            while (hi < 255 && bmn[a] + e255[a] * (float)hi < cmx[a] + guard[a]) hi++;
+            q[2 * a] |= (uint32_t)lo << (8 * i); q[2 * a + 1] |= (uint32_t)hi << (8 * i);
+        }
+        if (c.triCount) {
+            info[i] = 0x80000000u | (c.triCount << 16) | rel;
+            for (uint32_t j = 0; j < c.triCount; j++) {
+                const uint64_t pi = (uint64_t)c.leftFirst + j;
+                const uint32_t prim = pi < nIdx ? primIdx[pi] : 0xffffffffu;
+                float4* o = blocks + (size_t)base + rel + 3 * j;
+                if (prim >= nTris) { atomicOr(status, 4u); o[0] = o[1] = o[2] = make_float4(0, 0, 0, 0); continue; }
+                const float4 v0 = verts[3 * (uint64_t)prim], v1 = verts[3 * (uint64_t)prim + 1], v2 = verts[3 * (uint64_t)prim + 2];
+                o[0] = make_float4(v0.x, v0.y, v0.z, as_f32(prim));
+                o[1] = make_float4(v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v1.w - v0.w);
+                o[2] = make_float4(v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, v2.w - v0.w);
+            }
+            rel += 3 * c.triCount;
+        } else {
+            itemsOut[outFirst + inner] = make_uint2(kids[i], (base + 3u) * 4u + i);
+            inner++;
+        }
+    }
+    float4* nb = blocks + (size_t)base;
+    nb[0] = make_float4(bmn[0], bmn[1], bmn[2], as_f32(q[0]));
+    nb[1] = make_float4(e255[0], e255[1], e255[2], as_f32(q[1]));
+    nb[2] = make_float4(as_f32(q[2]), as_f32(q[3]), as_f32(q[4]), as_f32(q[5]));
+    nb[3] = make_float4(as_f32(info[0]), as_f32(info[1]), as_f32(info[2]), as_f32(info[3]));   // interior entries are patched by the children
+}
+
 }  // namespace
 
 // itemsA/itemsB: two work-item arrays of capNodes entries; counters: 4 x u32 in device memory.
@@ -162,4 +259,34 @@ hipError_t run_convert_cwbvh(const float4* nodes2, uint32_t nNodes2, const uint3
     return hipSuccess;
 }
 
+}  // namespace tbvh
+
+namespace tbvh {
+// BVH4_GPU: same driver loop, one stream.  Returns the number of 16-byte blocks.
+hipError_t run_convert_bvh4(const float4* nodes2, uint32_t nNodes2, const uint32_t* primIdx, uint64_t nIdx, const float4* verts, uint64_t nTris,
+                            float4* blocks, uint64_t capBlocks, uint2* itemsA, uint2* itemsB, uint32_t* counters, uint32_t* status, hipStream_t s,
+                            uint64_t* nBlocksOut, uint32_t* levelsOut) {
+    const uint32_t init[4] = {0u, 0u, 0u, 0u};
+    const uint2 root = make_uint2(0u, 0xffffffffu);
+    hipError_t e = hipMemcpyAsync(counters, init, 16, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(itemsA, &root, 8, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    uint32_t nIn = 1, levels = 0;
+    uint2 *in = itemsA, *out = itemsB;
+    while (nIn) {
+        if ((e = hipMemsetAsync(counters + 2, 0, 4, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_convert4_level, dim3((nIn + 63) / 64), dim3(64), 0, s, nodes2, nNodes2, primIdx, nIdx, verts, nTris, in, nIn, out, counters,
+                           blocks, capBlocks, status);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        uint32_t c[3];
+        if ((e = hipMemcpyAsync(c, counters, 12, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        nIn = c[2];
+        *nBlocksOut = c[0];
+        uint2* t = in; in = out; out = t;
+        if (++levels > 4096) return hipErrorUnknown;   // cyclic input
+    }
+    *levelsOut = levels;
+    return hipSuccess;
+}
 }  // namespace tbvh
