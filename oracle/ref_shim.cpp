@@ -103,12 +103,14 @@ static void ensureLayout(RefScene* s, int layout) {
     if (layout == 8 && !s->cpu8) { s->cpu8 = new BVH8_CPU(); if (s->hq) s->cpu8->BuildHQ(s->verts, s->triCount); else s->cpu8->Build(s->verts, s->triCount); }
 }
 
-// Blob access.  layout: 1 = BVH (Wald), 4 = BVH_GPU, 6 = BVH4_GPU, 9 = CWBVH.
+// Blob access.  layout: 1 = BVH (Wald), 4 = BVH_GPU, 6 = BVH4_GPU, 9 = CWBVH, 19 = the BVH2 the CWBVH was
+// converted from (bvh8.bvh after Compact + SplitLeafs(3), tiny_bvh.h:5829-5835): the input a device-side
+// ConvertFrom replacement gets from a tinybvh user.
 // which: 0 = nodes / blocks, 1 = primIdx (layouts 1, 4) or triangle blocks (layout 9).
 // Returns element count; *out receives the pointer (owned by the scene).
 uint64_t ref_blob(void* h, int layout, int which, const void** out) {
     RefScene* s = (RefScene*)h;
-    ensureLayout(s, layout);
+    ensureLayout(s, layout == 19 ? 9 : layout);
     switch (layout) {
     case 1:
         if (which == 0) { *out = s->bvh.bvhNode; return s->bvh.usedNodes; }
@@ -121,6 +123,9 @@ uint64_t ref_blob(void* h, int layout, int which, const void** out) {
     case 9:
         if (which == 0) { *out = s->cw->bvh8Data; return s->cw->usedBlocks; }
         *out = s->cw->bvh8Tris; return (uint64_t)s->cw->bvh8.idxCount * 3;
+    case 19:
+        if (which == 0) { *out = s->cw->bvh8.bvh.bvhNode; return s->cw->bvh8.bvh.usedNodes; }
+        *out = s->cw->bvh8.bvh.primIdx; return s->cw->bvh8.bvh.idxCount;
     }
     *out = nullptr; return 0;
 }

@@ -26,6 +26,20 @@ def test_fixtures_exist():
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
+def test_oracle_on_reference_split_leaf_bvh2(oracle, path):
+    """The BVH2 the reference converts its CWBVH from (leaves of at most 3 triangles; the device conversion's input
+    fixture) is a valid BVH2: the restated BVH::Intersect on it returns the reference's hit records."""
+    g = np.load(path)
+    verts, rays, hits = g["verts"], g["rays"], hitrec(g["hits"])
+    for k in (0, 1):
+        n2, pi = g[f"bvh2s3_nodes_{k}"], g[f"bvh2s3_idx_{k}"].reshape(-1)
+        assert int(n2[:, 7].max()) <= 3
+        got = oracle.bvh2_intersect(n2, pi, verts, rays)
+        c = compare_hits(got, hits)
+        assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["tie"] <= 4, c
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
 def test_oracle_reproduces_reference_hits(oracle, path):
     g = np.load(path)
     verts, rays, hits = g["verts"], g["rays"], hitrec(g["hits"])
