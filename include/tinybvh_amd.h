@@ -158,6 +158,8 @@ int tbvh_refit(tbvh_scene* scene, const void* verts16, uint64_t n_tris, int on_d
  *   blas_bounds6  per BLAS min.xyz, max.xyz (the BLAS root box: bvhNode[0].aabbMin/aabbMax); needed on
  *                 the first call, NULL afterwards
  * Asynchronous on the context's stream; tbvh_time_last_ms() reports the device time of the rebuild.
+ * The instance update follows BLASInstance::Update / InvertTransform operation for operation (including the FMA
+ * contraction of the reference build), so the records equal the ones tinybvh computes bit for bit.
  * The tree is an LBVH, not the reference's binned-SAH TLAS: same hit records, different node order. */
 int tbvh_rebuild_tlas_device(tbvh_scene* tlas, const void* transforms, int on_device,
                              const float* blas_bounds6, uint64_t n_blas);

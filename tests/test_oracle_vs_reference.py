@@ -87,3 +87,63 @@ def test_reference_counts_match_oracle_counts(oracle, reference):
         s, t = rs.counts(layout, rays)
         _, c = fn()
         assert (int(c[0]), int(c[1])) == (s, t), layout
+
+
+def _random_instances(n, seed, projective_every=0):
+    rng = np.random.default_rng(seed)
+    T = np.zeros((n, 4, 4), np.float32)
+    for i in range(n):
+        a, b, c = rng.random(3) * 6.28
+        ca, sa, cb, sb, cc, sc = np.cos(a), np.sin(a), np.cos(b), np.sin(b), np.cos(c), np.sin(c)
+        Rm = np.array([[cb * cc, -cb * sc, sb], [sa * sb * cc + ca * sc, -sa * sb * sc + ca * cc, -sa * cb], [-ca * sb * cc + sa * sc, ca * sb * sc + sa * cc, ca * cb]])
+        T[i, :3, :3] = Rm @ np.diag(0.3 + rng.random(3)); T[i, :3, 3] = rng.normal(0, 4, 3); T[i, 3, 3] = 1
+        if projective_every and i % projective_every == 0:
+            T[i, 3, :3] = rng.normal(0, 0.02, 3); T[i, 3, 3] = 1 + rng.normal(0, 0.05)
+    return tb.make_instances(T, (np.arange(n) % 2).astype(np.uint32))
+
+
+def test_instance_update_is_bit_identical_to_the_reference(reference):
+    """BLASInstance::Update (inverse + world box) restated in host_builder.cpp (and run unchanged on the device by
+    tbvh_rebuild_tlas_device) against the real thing, affine and projective transforms."""
+    import ctypes as C
+    v0, v1 = scenes.blob(1500, seed=3), scenes.soup(800, seed=2)
+    r0, r1 = reference.build(v0, hq=False, threaded=False), reference.build(v1, hq=False, threaded=False)
+    inst = _random_instances(600, seed=11, projective_every=5)
+    mine, theirs = inst.copy(), inst.copy()
+    bounds = np.stack([np.concatenate([v[:, :3].min(0), v[:, :3].max(0)]) for v in (v0, v1)]).astype(np.float32)
+    h = C.c_void_p()
+    tb.check(tb.lib.tbvh_host_build_tlas(C.c_void_p(mine.ctypes.data), mine.shape[0], C.c_void_p(bounds.ctypes.data), 2, C.byref(h)), "tbvh_host_build_tlas")
+    tb.lib.tbvh_host_free(h)
+    arr = (C.c_void_p * 2)(r0.h, r1.h)
+    t = reference.lib.ref_tlas_build(C.c_void_p(theirs.ctypes.data), theirs.shape[0], arr, 2)
+    reference.lib.ref_tlas_free(t)
+    for f in ("invTransform", "aabbMin", "aabbMax"):
+        assert np.array_equal(mine[f].view(np.uint32), theirs[f].view(np.uint32)), f
+
+
+def test_restated_tlas_traversal_equals_the_reference(oracle, reference):
+    """BVH::IntersectTLAS restated (orc_tlas_intersect) on the reference's own TLAS and instance records."""
+    import ctypes as C
+    from oracle_lib import tlas_intersect
+    v0, v1 = scenes.blob(3000, seed=3), scenes.soup(1500, seed=2, extent=1.6, size=0.25)
+    r0, r1 = reference.build(v0, hq=False, threaded=False), reference.build(v1, hq=False, threaded=False)
+    inst = _random_instances(64, seed=4)
+    inst["transform"].reshape(-1, 4, 4)[:, :3, 3] *= 0.6
+    arr = (C.c_void_p * 2)(r0.h, r1.h)
+    t = reference.lib.ref_tlas_build(C.c_void_p(inst.ctypes.data), inst.shape[0], arr, 2)
+    rays = R.random_rays(20_000, (-8, -8, -8), (8, 8, 8), seed=9)
+    rays["inst"] = 0
+    want = np.ascontiguousarray(rays).copy()
+    reference.lib.ref_tlas_intersect(t, C.c_void_p(want.ctypes.data), want.shape[0], want.strides[0])
+    p = C.c_void_p()
+    nn = reference.lib.ref_tlas_blob(t, 2, C.byref(p)); nodes = np.frombuffer((C.c_char * (nn * 32)).from_address(p.value), np.uint32).reshape(-1, 8).copy()
+    ni = reference.lib.ref_tlas_blob(t, 1, C.byref(p)); idx = np.frombuffer((C.c_char * (ni * 4)).from_address(p.value), np.uint32).copy()
+    bl = [(r.blob(1, 0, np.uint32, 8), r.blob(1, 1, np.uint32, 1).reshape(-1), v) for r, v in ((r0, v0), (r1, v1))]
+    got = tlas_intersect(oracle, nodes, idx, inst, bl, rays)
+    reference.lib.ref_tlas_free(t)
+    assert int((want["t"] < 1e30).sum()) > 1000
+    c = compare_hits(got, want)
+    assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
+    same = (want["t"] < 1e30) & (got["prim"] == want["prim"]) & (got["t"] == want["t"])
+    print("TLAS hits", c["hits"], "bit-identical", c["bit_identical"], "same prim", c["same_prim"], "ties", c["tie"])
+    assert np.array_equal(got["inst"][same], want["inst"][same])

@@ -626,37 +626,71 @@ void encode_cwbvh(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std:
 
 // ---- instances ---------------------------------------------------------------------------
 
-static bool invert4x4(const float* m, float* out) {
-    // Gauss-Jordan with partial pivoting in double precision.
-    double a[4][8];
-    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) a[r][c] = m[r * 4 + c], a[r][4 + c] = r == c;
-    for (int c = 0; c < 4; c++) {
-        int piv = c;
-        for (int r = c + 1; r < 4; r++) if (std::fabs(a[r][c]) > std::fabs(a[piv][c])) piv = r;
-        if (a[piv][c] == 0) return false;
-        if (piv != c) for (int k = 0; k < 8; k++) std::swap(a[piv][k], a[c][k]);
-        const double d = 1.0 / a[c][c];
-        for (int k = 0; k < 8; k++) a[c][k] *= d;
-        for (int r = 0; r < 4; r++) if (r != c) {
-            const double f = a[r][c];
-            if (f != 0) for (int k = 0; k < 8; k++) a[r][k] -= f * a[c][k];
-        }
+// BLASInstance::InvertTransform (tiny_bvh.h:8402-8427): the MESA cofactor formula in float.  To hand a tinybvh
+// user the very records tinybvh itself would compute, the evaluation follows the reference build (g++ 11.4 -O3
+// -mavx2 -mfma, -ffp-contract=fast) operation for operation.  Every six-term cofactor sum is ONE rounded triple
+// product plus five terms fused into the running sum (fma((x*y), z, sum), the inner product rounded); which term is
+// the rounded one differs between the two halves of the matrix because the compiler SLP-vectorised rows 0-7 (term 0
+// rounded, terms 1..5 fused in order) and left rows 8-15 scalar (term 1 rounded, then term 0, 2, 3, 4, 5 fused).
+// Found by exhaustive search over the evaluation orders against the real reference (64 000 of 64 000 elements of
+// 4 000 random matrices bit-identical) and pinned in tests/test_oracle_vs_reference.py.  The same table and code run
+// on the device (kernels_tlasbuild.hip).
+namespace {
+struct Term { int s, a, b, c; };   // s * T[a] * T[b] * T[c]
+static const Term kCof[16][6] = {
+    {{+1, 5, 10, 15}, {-1, 5, 11, 14}, {-1, 9, 6, 15}, {+1, 9, 7, 14}, {+1, 13, 6, 11}, {-1, 13, 7, 10}},
+    {{-1, 1, 10, 15}, {+1, 1, 11, 14}, {+1, 9, 2, 15}, {-1, 9, 3, 14}, {-1, 13, 2, 11}, {+1, 13, 3, 10}},
+    {{+1, 1, 6, 15}, {-1, 1, 7, 14}, {-1, 5, 2, 15}, {+1, 5, 3, 14}, {+1, 13, 2, 7}, {-1, 13, 3, 6}},
+    {{-1, 1, 6, 11}, {+1, 1, 7, 10}, {+1, 5, 2, 11}, {-1, 5, 3, 10}, {-1, 9, 2, 7}, {+1, 9, 3, 6}},
+    {{-1, 4, 10, 15}, {+1, 4, 11, 14}, {+1, 8, 6, 15}, {-1, 8, 7, 14}, {-1, 12, 6, 11}, {+1, 12, 7, 10}},
+    {{+1, 0, 10, 15}, {-1, 0, 11, 14}, {-1, 8, 2, 15}, {+1, 8, 3, 14}, {+1, 12, 2, 11}, {-1, 12, 3, 10}},
+    {{-1, 0, 6, 15}, {+1, 0, 7, 14}, {+1, 4, 2, 15}, {-1, 4, 3, 14}, {-1, 12, 2, 7}, {+1, 12, 3, 6}},
+    {{+1, 0, 6, 11}, {-1, 0, 7, 10}, {-1, 4, 2, 11}, {+1, 4, 3, 10}, {+1, 8, 2, 7}, {-1, 8, 3, 6}},
+    {{+1, 4, 9, 15}, {-1, 4, 11, 13}, {-1, 8, 5, 15}, {+1, 8, 7, 13}, {+1, 12, 5, 11}, {-1, 12, 7, 9}},
+    {{-1, 0, 9, 15}, {+1, 0, 11, 13}, {+1, 8, 1, 15}, {-1, 8, 3, 13}, {-1, 12, 1, 11}, {+1, 12, 3, 9}},
+    {{+1, 0, 5, 15}, {-1, 0, 7, 13}, {-1, 4, 1, 15}, {+1, 4, 3, 13}, {+1, 12, 1, 7}, {-1, 12, 3, 5}},
+    {{-1, 0, 5, 11}, {+1, 0, 7, 9}, {+1, 4, 1, 11}, {-1, 4, 3, 9}, {-1, 8, 1, 7}, {+1, 8, 3, 5}},
+    {{-1, 4, 9, 14}, {+1, 4, 10, 13}, {+1, 8, 5, 14}, {-1, 8, 6, 13}, {-1, 12, 5, 10}, {+1, 12, 6, 9}},
+    {{+1, 0, 9, 14}, {-1, 0, 10, 13}, {-1, 8, 1, 14}, {+1, 8, 2, 13}, {+1, 12, 1, 10}, {-1, 12, 2, 9}},
+    {{-1, 0, 5, 14}, {+1, 0, 6, 13}, {+1, 4, 1, 14}, {-1, 4, 2, 13}, {-1, 12, 1, 6}, {+1, 12, 2, 5}},
+    {{+1, 0, 5, 10}, {-1, 0, 6, 9}, {-1, 4, 1, 10}, {+1, 4, 2, 9}, {+1, 8, 1, 6}, {-1, 8, 2, 5}},
+};
+}  // namespace
+static bool invert4x4(const float* T, float* iT) {
+    for (int k = 0; k < 16; k++) {
+        const Term* t = kCof[k];
+        // inner products (rounded); a leading minus in the source negates the first factor, which is exact
+        float m[6];
+        for (int j = 0; j < 6; j++) m[j] = T[t[j].a] * T[t[j].b];
+        const int r = k < 8 ? 0 : 1;                                    // the term that is a plain (rounded) product
+        const float tr = m[r] * T[t[r].c];
+        float s = t[r].s > 0 ? tr : -tr;
+        for (int j = 0; j < 6; j++) if (j != r) s = std::fma(t[j].s > 0 ? m[j] : -m[j], T[t[j].c], s);
+        iT[k] = s;
     }
-    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) out[r * 4 + c] = (float)a[r][4 + c];
+    const float p1 = T[1] * iT[4];
+    float det = std::fma(T[0], iT[0], p1);
+    det = std::fma(T[2], iT[8], det);
+    det = std::fma(T[3], iT[12], det);
+    if (det == 0) return false;
+    const float invdet = 1.0f / det;
+    for (int i = 0; i < 16; i++) iT[i] *= invdet;
     return true;
 }
 
 // Same job as BLASInstance::Update (tiny_bvh.h:8386-8400): invert the transform, then take
 // the world-space box of the 8 transformed corners of the BLAS root box.
 void update_instance(Instance192& inst, const float* bb) {
-    if (!invert4x4(inst.transform, inst.invTransform)) std::memcpy(inst.invTransform, inst.transform, 64);
+    invert4x4(inst.transform, inst.invTransform);   // a singular transform leaves the unscaled cofactors behind, as in the reference
     Box w; w.reset();
     const float* T = inst.transform;
     for (int j = 0; j < 8; j++) {
         const float p[3] = {(j & 1) ? bb[3] : bb[0], (j & 2) ? bb[4] : bb[1], (j & 4) ? bb[5] : bb[2]};
         float t[3];
-        for (int r = 0; r < 3; r++) t[r] = T[r * 4] * p[0] + T[r * 4 + 1] * p[1] + T[r * 4 + 2] * p[2] + T[r * 4 + 3];
-        const float ww = T[12] * p[0] + T[13] * p[1] + T[14] * p[2] + T[15];
+        // tinybvh_transform_point (tiny_bvh.h:512-522) as the reference build contracts it: the first product is fused
+        // into the first addition, the second is a rounded product, the third is fused, the translation is added last
+        for (int r = 0; r < 3; r++) t[r] = std::fma(T[r * 4 + 2], p[2], std::fma(T[r * 4], p[0], T[r * 4 + 1] * p[1])) + T[r * 4 + 3];
+        const float ww = std::fma(T[14], p[2], std::fma(T[12], p[0], T[13] * p[1])) + T[15];
         if (ww != 1.0f) { const float r = 1.0f / ww; t[0] *= r; t[1] *= r; t[2] *= r; }
         w.grow(t);
     }

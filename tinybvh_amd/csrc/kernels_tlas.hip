@@ -200,16 +200,18 @@ __global__ __launch_bounds__(WG) void k_tlas(const float4* __restrict__ tlasNode
                     if (!(as_u32(b1.w) & rayMask)) continue;       // tiny_bvh.h:3326
                     const float4 r0 = ip[4], r1 = ip[5], r2 = ip[6], r3 = ip[7];   // invTransform rows
                     RayL rl;
-                    {   // tinybvh_transform_point (tiny_bvh.h:513-522), unfused like the oracle
-                        const float px = r0.x * O.x + r0.y * O.y + r0.z * O.z + r0.w;
-                        const float py = r1.x * O.x + r1.y * O.y + r1.z * O.z + r1.w;
-                        const float pz = r2.x * O.x + r2.y * O.y + r2.z * O.z + r2.w;
-                        const float w = r3.x * O.x + r3.y * O.y + r3.z * O.z + r3.w;
+                    {   // tinybvh_transform_point (tiny_bvh.h:512-522) with the reference build's contraction (first product fused
+                        // into the first addition, the second rounded, the third fused, translation added last): the oracle
+                        // restates it the same way and is pinned bit for bit against the real IntersectTLAS
+                        const float px = __builtin_fmaf(r0.z, O.z, __builtin_fmaf(r0.x, O.x, r0.y * O.y)) + r0.w;
+                        const float py = __builtin_fmaf(r1.z, O.z, __builtin_fmaf(r1.x, O.x, r1.y * O.y)) + r1.w;
+                        const float pz = __builtin_fmaf(r2.z, O.z, __builtin_fmaf(r2.x, O.x, r2.y * O.y)) + r2.w;
+                        const float w = __builtin_fmaf(r3.z, O.z, __builtin_fmaf(r3.x, O.x, r3.y * O.y)) + r3.w;
                         if (w == 1) rl.O = make_float3(px, py, pz);
                         else { const float iw = 1.f / w; rl.O = make_float3(px * iw, py * iw, pz * iw); }
                     }
-                    rl.D = make_float3(r0.x * D.x + r0.y * D.y + r0.z * D.z, r1.x * D.x + r1.y * D.y + r1.z * D.z,
-                                       r2.x * D.x + r2.y * D.y + r2.z * D.z);   // tinybvh_transform_vector (523-528)
+                    rl.D = make_float3(__builtin_fmaf(r0.z, D.z, __builtin_fmaf(r0.x, D.x, r0.y * D.y)), __builtin_fmaf(r1.z, D.z, __builtin_fmaf(r1.x, D.x, r1.y * D.y)),
+                                       __builtin_fmaf(r2.z, D.z, __builtin_fmaf(r2.x, D.x, r2.y * D.y)));   // tinybvh_transform_vector (523-528), same contraction
                     rl.rD = make_float3(safercp(rl.D.x), safercp(rl.D.y), safercp(rl.D.z));
                     rl.hit = hit; rl.found = false;
                     const BlasDesc bd = blas[as_u32(b0.w)];

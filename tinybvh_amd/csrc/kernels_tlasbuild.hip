@@ -32,25 +32,46 @@ __device__ __forceinline__ float dec_f32(uint32_t e) {
     return as_f32(b);
 }
 
-// Gauss-Jordan with partial pivoting in double precision: the same arithmetic, operation for
-// operation, as the host builder's update_instance (host_builder.cpp: invert4x4), so device-built
-// and host-built records are bit-identical.
-__device__ bool invert4x4(const float* m, float* out) {
-    double a[4][8];
-    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) { a[r][c] = m[r * 4 + c]; a[r][4 + c] = r == c ? 1.0 : 0.0; }
-    for (int c = 0; c < 4; c++) {
-        int piv = c;
-        for (int r = c + 1; r < 4; r++) if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
-        if (a[piv][c] == 0) return false;
-        if (piv != c) for (int k = 0; k < 8; k++) { const double t = a[piv][k]; a[piv][k] = a[c][k]; a[c][k] = t; }
-        const double d = 1.0 / a[c][c];
-        for (int k = 0; k < 8; k++) a[c][k] *= d;
-        for (int r = 0; r < 4; r++) if (r != c) {
-            const double f = a[r][c];
-            if (f != 0) for (int k = 0; k < 8; k++) a[r][k] -= f * a[c][k];
-        }
+// BLASInstance::InvertTransform (tiny_bvh.h:8402-8427): the float cofactor formula, evaluated operation for operation
+// like the reference build — the same table and order as host_builder.cpp: invert4x4, where the order was found by
+// exhaustive search against the real reference.  Host-built, device-built and tinybvh-built records are bit-identical.
+struct CofTerm { signed char s; unsigned char a, b, c; };   // s * T[a] * T[b] * T[c]
+__device__ const CofTerm kCof[16][6] = {
+    {{+1, 5, 10, 15}, {-1, 5, 11, 14}, {-1, 9, 6, 15}, {+1, 9, 7, 14}, {+1, 13, 6, 11}, {-1, 13, 7, 10}},
+    {{-1, 1, 10, 15}, {+1, 1, 11, 14}, {+1, 9, 2, 15}, {-1, 9, 3, 14}, {-1, 13, 2, 11}, {+1, 13, 3, 10}},
+    {{+1, 1, 6, 15}, {-1, 1, 7, 14}, {-1, 5, 2, 15}, {+1, 5, 3, 14}, {+1, 13, 2, 7}, {-1, 13, 3, 6}},
+    {{-1, 1, 6, 11}, {+1, 1, 7, 10}, {+1, 5, 2, 11}, {-1, 5, 3, 10}, {-1, 9, 2, 7}, {+1, 9, 3, 6}},
+    {{-1, 4, 10, 15}, {+1, 4, 11, 14}, {+1, 8, 6, 15}, {-1, 8, 7, 14}, {-1, 12, 6, 11}, {+1, 12, 7, 10}},
+    {{+1, 0, 10, 15}, {-1, 0, 11, 14}, {-1, 8, 2, 15}, {+1, 8, 3, 14}, {+1, 12, 2, 11}, {-1, 12, 3, 10}},
+    {{-1, 0, 6, 15}, {+1, 0, 7, 14}, {+1, 4, 2, 15}, {-1, 4, 3, 14}, {-1, 12, 2, 7}, {+1, 12, 3, 6}},
+    {{+1, 0, 6, 11}, {-1, 0, 7, 10}, {-1, 4, 2, 11}, {+1, 4, 3, 10}, {+1, 8, 2, 7}, {-1, 8, 3, 6}},
+    {{+1, 4, 9, 15}, {-1, 4, 11, 13}, {-1, 8, 5, 15}, {+1, 8, 7, 13}, {+1, 12, 5, 11}, {-1, 12, 7, 9}},
+    {{-1, 0, 9, 15}, {+1, 0, 11, 13}, {+1, 8, 1, 15}, {-1, 8, 3, 13}, {-1, 12, 1, 11}, {+1, 12, 3, 9}},
+    {{+1, 0, 5, 15}, {-1, 0, 7, 13}, {-1, 4, 1, 15}, {+1, 4, 3, 13}, {+1, 12, 1, 7}, {-1, 12, 3, 5}},
+    {{-1, 0, 5, 11}, {+1, 0, 7, 9}, {+1, 4, 1, 11}, {-1, 4, 3, 9}, {-1, 8, 1, 7}, {+1, 8, 3, 5}},
+    {{-1, 4, 9, 14}, {+1, 4, 10, 13}, {+1, 8, 5, 14}, {-1, 8, 6, 13}, {-1, 12, 5, 10}, {+1, 12, 6, 9}},
+    {{+1, 0, 9, 14}, {-1, 0, 10, 13}, {-1, 8, 1, 14}, {+1, 8, 2, 13}, {+1, 12, 1, 10}, {-1, 12, 2, 9}},
+    {{-1, 0, 5, 14}, {+1, 0, 6, 13}, {+1, 4, 1, 14}, {-1, 4, 2, 13}, {-1, 12, 1, 6}, {+1, 12, 2, 5}},
+    {{+1, 0, 5, 10}, {-1, 0, 6, 9}, {-1, 4, 1, 10}, {+1, 4, 2, 9}, {+1, 8, 1, 6}, {-1, 8, 2, 5}},
+};
+__device__ bool invert4x4(const float* T, float* iT) {
+    for (int k = 0; k < 16; k++) {
+        const CofTerm* t = kCof[k];
+        float m[6];
+        for (int j = 0; j < 6; j++) m[j] = T[t[j].a] * T[t[j].b];
+        const int r = k < 8 ? 0 : 1;   // the term that is a plain (rounded) product
+        const float tr = m[r] * T[t[r].c];
+        float s = t[r].s > 0 ? tr : -tr;
+        for (int j = 0; j < 6; j++) if (j != r) s = __builtin_fmaf(t[j].s > 0 ? m[j] : -m[j], T[t[j].c], s);
+        iT[k] = s;
     }
-    for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) out[r * 4 + c] = (float)a[r][4 + c];
+    const float p1 = T[1] * iT[4];
+    float det = __builtin_fmaf(T[0], iT[0], p1);
+    det = __builtin_fmaf(T[2], iT[8], det);
+    det = __builtin_fmaf(T[3], iT[12], det);
+    if (det == 0) return false;
+    const float invdet = 1.0f / det;
+    for (int i = 0; i < 16; i++) iT[i] *= invdet;
     return true;
 }
 
@@ -69,7 +90,7 @@ __global__ void k_instance_update(float4* __restrict__ instances, const float* _
     } else {
         for (int r = 0; r < 4; r++) { const float4 v = rec[r]; T[r * 4] = v.x; T[r * 4 + 1] = v.y; T[r * 4 + 2] = v.z; T[r * 4 + 3] = v.w; }
     }
-    if (!invert4x4(T, inv)) for (int k = 0; k < 16; k++) inv[k] = T[k];
+    invert4x4(T, inv);   // a singular transform leaves the unscaled cofactors behind, as in the reference ("invert failed. That's bad.")
     for (int r = 0; r < 4; r++) rec[4 + r] = make_float4(inv[r * 4], inv[r * 4 + 1], inv[r * 4 + 2], inv[r * 4 + 3]);
     const uint32_t blasIdx = as_u32(rec[8].w);
     const float* bb = blasBounds + (size_t)(blasIdx < nBlas ? blasIdx : 0u) * 6;
@@ -77,8 +98,9 @@ __global__ void k_instance_update(float4* __restrict__ instances, const float* _
     for (int j = 0; j < 8; j++) {
         const float p[3] = {(j & 1) ? bb[3] : bb[0], (j & 2) ? bb[4] : bb[1], (j & 4) ? bb[5] : bb[2]};
         float t[3];
-        for (int r = 0; r < 3; r++) t[r] = T[r * 4] * p[0] + T[r * 4 + 1] * p[1] + T[r * 4 + 2] * p[2] + T[r * 4 + 3];
-        const float ww = T[12] * p[0] + T[13] * p[1] + T[14] * p[2] + T[15];
+        // tinybvh_transform_point (tiny_bvh.h:512-522) as the reference build contracts it (host_builder.cpp: update_instance)
+        for (int r = 0; r < 3; r++) t[r] = __builtin_fmaf(T[r * 4 + 2], p[2], __builtin_fmaf(T[r * 4], p[0], T[r * 4 + 1] * p[1])) + T[r * 4 + 3];
+        const float ww = __builtin_fmaf(T[14], p[2], __builtin_fmaf(T[12], p[0], T[13] * p[1])) + T[15];
         if (ww != 1.0f) { const float r = 1.0f / ww; t[0] *= r; t[1] *= r; t[2] *= r; }
         for (int a = 0; a < 3; a++) { mn[a] = t[a] < mn[a] ? t[a] : mn[a]; mx[a] = t[a] > mx[a] ? t[a] : mx[a]; }
     }
