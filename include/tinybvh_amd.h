@@ -135,6 +135,13 @@ int tbvh_build_device(tbvh_context* ctx, const void* verts16, uint64_t n_tris, i
  * records (BVH_GPU: the gathered {v0|prim, e1, e2} form; BVH4_GPU has none).  dst = NULL only reports the size. */
 int tbvh_scene_download(tbvh_scene* scene, int which, void* dst, uint64_t cap_bytes, uint64_t* bytes_out);
 
+/* Opacity micromaps — BVHBase::SetOpacityMicroMaps (tiny_bvh.h:823-826): N x N bits per triangle (N * N bits rounded up to
+ * whole 32-bit words per triangle, triangle i's words first word at i * ((N * N + 31) / 32)); a ray / triangle hit whose
+ * barycentrics land on a clear bit is not a hit, exactly as in IntersectTri / TriOccludes (tiny_bvh.h:8514-8522,
+ * 8562-8570; traverse_bvh2.cl:112-117).  Honoured by Intersect and IsOccluded of every layout; for instanced scenes set
+ * the maps on the BLASes before uploading their TLAS.  map_data = NULL or N = 0 removes the maps.  The data is copied. */
+int tbvh_set_opacity_micromaps(tbvh_scene* blas, const uint32_t* map_data, uint32_t N, uint64_t n_tris, int on_device);
+
 /* BLAS refit ON THE DEVICE for animated meshes: same topology and triangle order, every box recomputed
  * bottom-up from the new vertex positions, CWBVH nodes re-quantised, triangle records re-gathered.
  * Replaces "BVH::Refit (tiny_bvh.h:3055-3093) / MBVH::Refit (4925-4961) on the host, ConvertFrom again

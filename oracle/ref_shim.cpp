@@ -130,6 +130,8 @@ uint64_t ref_blob(void* h, int layout, int which, const void** out) {
     *out = nullptr; return 0;
 }
 const void* ref_verts(void* h) { return ((RefScene*)h)->verts; }
+// BVHBase::SetOpacityMicroMaps on the scene's BVH (the oracle layout); mapData must outlive the queries.
+void ref_set_opmap(void* h, uint32_t* mapData, uint32_t N) { ((RefScene*)h)->bvh.SetOpacityMicroMaps(mapData, N); }
 
 // Per-ray queries through the reference's own traversal code.
 // layout 1: BVH::Intersect (THE oracle, tiny_bvh.h:3222); 4/6/9: the CPU mirrors of the GPU

@@ -48,6 +48,11 @@ class Oracle:
         r = np.ascontiguousarray(rays).copy()
         return r
 
+    def set_opmap(self, map_data, n):
+        """Opacity micromaps for ALL following oracle queries (None clears); the array must stay alive."""
+        self._opmap = None if map_data is None else np.ascontiguousarray(map_data, np.uint32)
+        self.lib.orc_set_opmap(_p(self._opmap) if self._opmap is not None else None, int(n))
+
     def bvh2_intersect(self, nodes32, prim_idx, verts, rays, counts=False):
         r = self._prep(rays)
         c = np.zeros(2, np.uint64) if counts else None
@@ -118,6 +123,7 @@ class Reference:
         L.ref_occluded.restype = C.c_int; L.ref_occluded.argtypes = [_vp, C.c_int, _vp, _u64, _u32, _vp]
         L.ref_counts.restype = C.c_int; L.ref_counts.argtypes = [_vp, C.c_int, _vp, _u64, _u32, C.POINTER(_u64), C.POINTER(_u64)]
         L.ref_time_mt.restype = C.c_double; L.ref_time_mt.argtypes = [_vp, C.c_int, _vp, _u64, _u32, C.c_int, C.c_int, C.POINTER(_u64)]
+        L.ref_set_opmap.restype = None; L.ref_set_opmap.argtypes = [_vp, _vp, _u32]
         L.ref_tlas_build.restype = _vp; L.ref_tlas_build.argtypes = [_vp, _u32, C.POINTER(_vp), _u32]
         L.ref_tlas_free.argtypes = [_vp]; L.ref_tlas_free.restype = None
         L.ref_tlas_intersect.restype = C.c_int; L.ref_tlas_intersect.argtypes = [_vp, _vp, _u64, _u32]

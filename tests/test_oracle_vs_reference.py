@@ -147,3 +147,40 @@ def test_restated_tlas_traversal_equals_the_reference(oracle, reference):
     same = (want["t"] < 1e30) & (got["prim"] == want["prim"]) & (got["t"] == want["t"])
     print("TLAS hits", c["hits"], "bit-identical", c["bit_identical"], "same prim", c["same_prim"], "ties", c["tie"])
     assert np.array_equal(got["inst"][same], want["inst"][same])
+
+
+def random_opmap(n_tris, N, seed, density=0.6):
+    rng = np.random.default_rng(seed)
+    wpt = (N * N + 31) // 32
+    m = np.zeros((n_tris, wpt), np.uint32)
+    bits = rng.random((n_tris, N * N)) < density
+    for b in range(N * N):
+        m[:, b >> 5] |= (bits[:, b].astype(np.uint32) << np.uint32(b & 31))
+    return m
+
+
+@pytest.mark.parametrize("N", [4, 8, 32])
+def test_opacity_micromaps_equal_the_reference(oracle, reference, N):
+    """IntersectTri / TriOccludes with opacity micromaps (tiny_bvh.h:8514-8522, 8562-8570): restated index arithmetic
+    against the real BVH::Intersect / IsOccluded with SetOpacityMicroMaps."""
+    import ctypes as C
+    verts = scenes.blob(4000, seed=3)
+    rs = reference.build(verts, hq=False, threaded=False)
+    om = random_opmap(verts.shape[0] // 3, N, seed=N)
+    prim, rnd = batches(verts)
+    rays = np.concatenate([prim, rnd])
+    plain = rs.intersect(1, rays)
+    reference.lib.ref_set_opmap(rs.h, C.c_void_p(om.ctypes.data), N)
+    want = rs.intersect(1, rays)
+    sh = R.shadow(plain, verts[:, :3].max(0) * 1.5, 1e-5)
+    want_occ = rs.occluded(1, sh)
+    reference.lib.ref_set_opmap(rs.h, None, 0)
+    assert int((want["prim"] != plain["prim"]).sum()) > 500          # the maps really cut holes
+    oracle.set_opmap(om, N)
+    try:
+        got = oracle.bvh2_intersect(rs.blob(1, 0, np.uint32, 8), rs.blob(1, 1, np.uint32, 1).reshape(-1), verts, rays)
+        got_occ = oracle.bvh2_occluded(rs.blob(1, 0, np.uint32, 8), rs.blob(1, 1, np.uint32, 1).reshape(-1), verts, sh)
+    finally:
+        oracle.set_opmap(None, 0)
+    exact(got, want)
+    assert np.array_equal(got_occ, want_occ)

@@ -204,6 +204,17 @@ class _Scene:
         check(lib.tbvh_refit(self._h, ptr, n_tris, 1 if on_device else 0), "tbvh_refit")
         return self
 
+    def SetOpacityMicroMaps(self, map_data, N: int):
+        """BVHBase::SetOpacityMicroMaps (tiny_bvh.h:826): map_data = uint32 array of n_tris * ceil(N*N/32) words, or None to clear."""
+        if map_data is None or N == 0:
+            check(lib.tbvh_set_opacity_micromaps(self._h, None, 0, 0, 0), "tbvh_set_opacity_micromaps")
+            return self
+        m = np.ascontiguousarray(map_data, np.uint32).reshape(-1)
+        wpt = (N * N + 31) // 32
+        assert m.size % wpt == 0
+        check(lib.tbvh_set_opacity_micromaps(self._h, _ptr(m), N, m.size // wpt, 0), "tbvh_set_opacity_micromaps")
+        return self
+
     def download_blobs(self):
         """(nodes, triangle records) as (n, 4) uint32 arrays of 16-byte blocks, read back from the device."""
         out = []

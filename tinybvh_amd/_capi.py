@@ -54,6 +54,7 @@ SYMBOLS = {
     "tbvh_update_tlas": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u64]),
     "tbvh_rebuild_tlas_device": (_i, [_vp, _vp, _i, _vp, _u64]),
     "tbvh_refit": (_i, [_vp, _vp, _u64, _i]),
+    "tbvh_set_opacity_micromaps": (_i, [_vp, _vp, _u32, _u64, _i]),
     "tbvh_scene_download": (_i, [_vp, _i, _vp, _u64, _vp]),
     "tbvh_build_device": (_i, [_vp, _vp, _u64, _i, _i, _u32, _vp]),
     "tbvh_convert_bvh2_device": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _i, _i, _vp]),

@@ -90,6 +90,9 @@ struct tbvh_scene {
     // device-side BLAS refit (kernels_refit.hip)
     void* refitScratch = nullptr;
     float4* vertStage = nullptr;      // staged vertices when the caller passes host memory
+    // opacity micromaps (BVHBase::SetOpacityMicroMaps)
+    uint32_t* opmap = nullptr;
+    uint32_t opmapN = 0;
     uint64_t vertStageTris = 0;
 };
 
@@ -138,7 +141,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     q.rays = d_rays; q.nRays = n; q.occluded = d_occ;
     q.spill = c->spill; q.counter = (uint32_t*)c->pool; q.poolParts = c->poolParts;
     q.stats = c->counter + 8;
-    q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev;
+    q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.omm = Omm{s->opmap, s->opmapN};
     // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
     // (about one workgroup per 192 rays, measured best for 1 M-ray launches) so every wave still
     // has a few ray replacements' worth of work
@@ -386,7 +389,7 @@ int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, cons
         if (b->layout != TBVH_LAYOUT_CWBVH && b->layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "BLAS %llu: layout %d is not supported under a TLAS (use BVH8_CWBVH or BVH4_GPU)", (unsigned long long)i, b->layout);
         if (layout && b->layout != layout) return fail(TBVH_E_INVALID, "all BLASes of a TLAS must share one layout");
         layout = b->layout;
-        desc[i].nodes = b->nodes; desc[i].tris = b->tris;
+        desc[i].nodes = b->nodes; desc[i].tris = b->tris; desc[i].opmap = b->opmap; desc[i].opmapN = b->opmapN; desc[i].pad = 0;
     }
     const BLASInstanceCheck* ic = (const BLASInstanceCheck*)inst;
     for (uint64_t i = 0; i < nInst; i++) if (ic[i].blasIdx >= nBlas) return fail(TBVH_E_FORMAT, "instance %llu: blasIdx %u out of range", (unsigned long long)i, ic[i].blasIdx);
@@ -533,6 +536,27 @@ int tbvh_build_device(tbvh_context* c, const void* verts16, uint64_t nTris, int 
     return r;
 }
 
+int tbvh_set_opacity_micromaps(tbvh_scene* s, const uint32_t* mapData, uint32_t N, uint64_t nTris, int onDevice) {
+    if (!s || s->isTlas) return fail(TBVH_E_INVALID, "tbvh_set_opacity_micromaps: not a BLAS scene (set the maps on the BLASes before uploading their TLAS)");
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));   // no query may still read the old maps
+    if (s->opmap) { hipFree(s->opmap); s->opmap = nullptr; }
+    s->opmapN = 0;
+    if (!mapData || N == 0) return 0;            // cleared
+    if (N > 1024 || nTris == 0) return fail(TBVH_E_INVALID, "tbvh_set_opacity_micromaps: N = %u, %llu triangles", N, (unsigned long long)nTris);
+    const uint64_t wordsPerTri = ((uint64_t)N * N + 31) >> 5, words = wordsPerTri * nTris;
+    // the reference's index can run one row past the map when u + v == 1 exactly (tiny_bvh.h:8518-8519): keep that read inside the allocation
+    const uint64_t pad = (((uint64_t)N + 1) * (N + 1) + 63) >> 5;
+    HIP_TRY(hipMalloc((void**)&s->opmap, (words + pad) * 4));
+    HIP_TRY(hipMemsetAsync(s->opmap + words, 0, pad * 4, c->stream));
+    HIP_TRY(hipMemcpyAsync(s->opmap, mapData, words * 4, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    s->opmapN = N;
+    s->bytes += (words + pad) * 4;
+    return 0;
+}
+
 int tbvh_scene_download(tbvh_scene* s, int which, void* dst, uint64_t capBytes, uint64_t* bytesOut) {
     if (!s || s->isTlas || (which != 0 && which != 1)) return fail(TBVH_E_INVALID, "tbvh_scene_download: not a BLAS scene or bad blob selector");
     tbvh_context* c = s->ctx;
@@ -601,6 +625,7 @@ int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice
     if (s->buildScratchFor != n) {
         if (s->buildScratch) hipFree(s->buildScratch);
     if (s->refitScratch) hipFree(s->refitScratch);
+    if (s->opmap) hipFree(s->opmap);
     if (s->vertStage) hipFree(s->vertStage);
         s->buildScratch = nullptr; s->buildScratchFor = 0;
         s->buildScratchBytes = tlas_build_scratch_bytes((uint32_t)n, &s->sortTempBytes);
@@ -656,6 +681,7 @@ void tbvh_free_scene(tbvh_scene* s) {
     if (s->xformStage) hipFree(s->xformStage);
     if (s->buildScratch) hipFree(s->buildScratch);
     if (s->refitScratch) hipFree(s->refitScratch);
+    if (s->opmap) hipFree(s->opmap);
     if (s->vertStage) hipFree(s->vertStage);
     for (size_t i = 0; i < c->scenes.size(); i++)
         if (c->scenes[i] == s) { c->scenes.erase(c->scenes.begin() + i); break; }

@@ -51,10 +51,22 @@ __device__ __forceinline__ float dot_zyx(float3 a, float3 b) {
     return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x));
 }
 
+// Opacity micromaps (BVHBase::SetOpacityMicroMaps, tiny_bvh.h:823-826): n x n bits per triangle; a hit whose
+// barycentrics fall on a clear bit is no hit (IntersectTri / TriOccludes, tiny_bvh.h:8514-8522, 8562-8570).
+struct Omm { const uint32_t* map; uint32_t n; };   // map == nullptr: none
+__device__ __forceinline__ bool omm_opaque(Omm om, uint32_t prim, float u, float v) {
+    const float fN = (float)om.n;
+    const int row = (int)((u + v) * fN), diag = (int)((1 - u) * fN);
+    const int idx = (row * row) + (int)(v * fN) + (diag - ((int)om.n - 1 - row));
+    const uint32_t* m = om.map + (size_t)prim * ((om.n * om.n + 31u) >> 5);
+    return (m[idx >> 5] >> (idx & 31)) & 1u;
+}
+
 // Returns true when the triangle {v0, e1, e2} is hit within [0, tmax] (both ends
-// inclusive, like the reference: rejects only t < 0 || t > tmax).
+// inclusive, like the reference: rejects only t < 0 || t > tmax) and, with opacity
+// micromaps set, the hit point is opaque.
 __device__ __forceinline__ bool tri_test(float3 O, float3 D, float3 v0, float3 e1, float3 e2,
-                                         float tmax, TriHit& h) {
+                                         float tmax, TriHit& h, Omm om = Omm{nullptr, 0u}, uint32_t prim = 0u) {
     const float3 hh = crossA(D, e2);
     const float a = dot_zxy(e1, hh);
     if (__builtin_fabsf(a) < 0.000001f) return false;
@@ -66,6 +78,7 @@ __device__ __forceinline__ bool tri_test(float3 O, float3 D, float3 v0, float3 e
     if (u < 0 || v < 0 || u + v > 1) return false;
     const float t = f * dot_zxy(e2, q);
     if (t < 0 || t > tmax) return false;
+    if (om.map && !omm_opaque(om, prim, u, v)) return false;
     h.t = t; h.u = u; h.v = v;
     return true;
 }
@@ -83,6 +96,7 @@ struct QueryArgs {
     uint32_t poolParts;    // log2 of the number of partitions of the batch, each with its own counter (ray_pool.h)
     unsigned long long* stats;  // instrumented variants: lane-utilisation counters
     const unsigned long long* nRaysDev;  // if non-null the batch size is read from device memory (on-device queues)
+    Omm omm;               // opacity micromaps of the scene (map == nullptr: none)
     uint32_t fresh;        // 1: ignore the stored hit, start every ray from {freshTmax,0,0,0} and always write the record
     float freshTmax;
 };

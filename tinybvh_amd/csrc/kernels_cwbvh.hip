@@ -208,7 +208,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
                 const uint32_t ta = tg.x + ti * 3u;
                 const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
                 TriHit h;
-                if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
                     found = true;
                     if (ANYHIT) done = true;
                     else hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
             const uint32_t ta = tg.x + ti * 3u;
             const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
                 found = true;
                 if (ANYHIT) break;
                 hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh_lean(const float4* __restrict__ no
             const uint32_t ta = tg.x + ti * 3u;
             const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
                 found = true;
                 if (ANYHIT) break;
                 hit = make_float4(h.t, h.u, h.v, v0.w);

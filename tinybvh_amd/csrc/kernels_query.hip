@@ -84,7 +84,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
             const float4 v0 = tris[triPtr], e1 = tris[triPtr + 1], e2 = tris[triPtr + 2];
             triPtr += 3; triLeft--;
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
             leafQ0 += 3u; leafCnt -= 1u;                      // next triangle, one fewer left in slot 0
             if ((leafCnt & 255u) == 0) { leafQ0 = leafQ1; leafQ1 = leafQ2; leafQ2 = leafQ3; leafCnt >>= 8; }
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
                     for (uint32_t j = 0; j < cnt; j++, ta += 3) {
                         const float4 v0 = data[ta], e1 = data[ta + 1], e2 = data[ta + 2];
                         TriHit h;
-                        if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                        if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
                             found = true;
                             if (ANYHIT) { done = true; break; }
                             hit = make_float4(h.t, h.u, h.v, v0.w);

@@ -45,7 +45,7 @@ struct RayL {  // a ray in some space + its current best hit
 // ---- BLAS traversals; each runs until the stack is back at `base` ------------------------------
 
 template <bool ANYHIT, int LDS_N>
-__device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 tris, RayL& r, Stack& st) {
+__device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 tris, RayL& r, Stack& st, const Omm om) {
     const int base = st.sp;
     const uint32_t oct = 7u - ((r.D.x < 0 ? 4u : 0u) | (r.D.y < 0 ? 2u : 0u) | (r.D.z < 0 ? 1u : 0u));
     const uint32_t octinv4 = oct * 0x01010101u;
@@ -101,7 +101,7 @@ __device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 
             const uint32_t ta = tg.x + ti * 3u;
             const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
             TriHit h;
-            if (tri_test(r.O, r.D, xyz(v0), xyz(e1), xyz(e2), r.hit.x, h)) {
+            if (tri_test(r.O, r.D, xyz(v0), xyz(e1), xyz(e2), r.hit.x, h, om, as_u32(v0.w))) {
                 r.found = true;
                 if (ANYHIT) { st.sp = base; return; }
                 r.hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -114,7 +114,7 @@ __device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 
 }
 
 template <bool ANYHIT, int LDS_N>
-__device__ __forceinline__ void blas_bvh4(const GlobalF4 data, RayL& r, Stack& st) {
+__device__ __forceinline__ void blas_bvh4(const GlobalF4 data, RayL& r, Stack& st, const Omm om) {
     const int base = st.sp;
     uint32_t offset = 0;
     for (;;) {
@@ -149,7 +149,7 @@ __device__ __forceinline__ void blas_bvh4(const GlobalF4 data, RayL& r, Stack& s
             for (uint32_t j = 0; j < N; j++, ta += 3) {
                 const float4 v0 = data[ta], e1 = data[ta + 1], e2 = data[ta + 2];
                 TriHit h;
-                if (tri_test(r.O, r.D, xyz(v0), xyz(e1), xyz(e2), r.hit.x, h)) {
+                if (tri_test(r.O, r.D, xyz(v0), xyz(e1), xyz(e2), r.hit.x, h, om, as_u32(v0.w))) {
                     r.found = true;
                     if (ANYHIT) { st.sp = base; return; }
                     r.hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -215,8 +215,8 @@ __global__ __launch_bounds__(WG) void k_tlas(const float4* __restrict__ tlasNode
                     rl.rD = make_float3(safercp(rl.D.x), safercp(rl.D.y), safercp(rl.D.z));
                     rl.hit = hit; rl.found = false;
                     const BlasDesc bd = blas[as_u32(b0.w)];
-                    if (BLAS_LAYOUT == 9) blas_cwbvh<ANYHIT, LDS_N>(GlobalF4(bd.nodes), GlobalF4(bd.tris), rl, st);
-                    else blas_bvh4<ANYHIT, LDS_N>(GlobalF4(bd.nodes), rl, st);
+                    if (BLAS_LAYOUT == 9) blas_cwbvh<ANYHIT, LDS_N>(GlobalF4(bd.nodes), GlobalF4(bd.tris), rl, st, Omm{bd.opmap, bd.opmapN});
+                    else blas_bvh4<ANYHIT, LDS_N>(GlobalF4(bd.nodes), rl, st, Omm{bd.opmap, bd.opmapN});
                     if (rl.found) { found = true; hit = rl.hit; hitInst = ii; if (ANYHIT) break; }
                 }
                 if (ANYHIT && found) break;
