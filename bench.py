@@ -156,6 +156,25 @@ def main():
     except Exception as e:
         log(f"[bench] wavefront frame failed: {e!r}")
 
+    # the device-side maintenance operations on the same scene (outside the timed steps, rank 0 only): refit of the
+    # uploaded blob to displaced vertices and a full LBVH rebuild, reported in `detail`
+    dev_ops = None
+    if rank == 0:
+        try:
+            moved = verts.copy()
+            moved[:, 1] += np.float32(1e-3) * np.sin(verts[:, 0]).astype(np.float32)
+            ctx.to_device(d_verts, moved)
+            n_tris = verts.shape[0] // 3
+            sc.Refit((d_verts, n_tris), on_device=True); sc.Refit((d_verts, n_tris), on_device=True)
+            ms_refit = ctx.time_last_ms()
+            built = tb.BVH8_CWBVH(ctx).BuildOnDevice(moved); built.free()
+            built = tb.BVH8_CWBVH(ctx).BuildOnDevice(moved)
+            ms_build = ctx.time_last_ms()
+            built.free()
+            dev_ops = {"refit_ms": ms_refit, "device_build_ms": ms_build, "triangles": n_tris}
+        except Exception as e:
+            log(f"[bench] device refit / build failed: {e!r}")
+
     # ---- results (rank 0) ---------------------------------------------------------------------------
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
@@ -166,6 +185,7 @@ def main():
         detail["kernel_ms"] = mean
         detail["primary_plus_diffuse_kernel_mrays"] = 2 * n / ((mean["primary"] + mean["diffuse"]) * 1e-3) / 1e6
         detail["wavefront_frame_3_bounces"] = wf_detail
+        detail["device_side_ops"] = dev_ops
 
         # roofline of the dominant kernel (CWBVH Intersect on the diffuse batch): algorithmic
         # bytes per ray = 64 (ray in) + 16 (hit out) + node_bytes*S + tri_bytes*T, SURVEY.md
