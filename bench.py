@@ -14,7 +14,7 @@ runs the two Intersect passes through tbvh_intersect_device_fresh (every ray sta
 tmax = 1e30 and every hit record is written, so each step does the full work of a new frame);
 the shadow pass is timed separately (HIP events) and reported in `detail`.  Rays are generated on the device before the timed region and
 are resident in HBM.  N > 1: the BVH is replicated, every rank traces its own batch
-(different camera / RNG seed), no data-path collective: weak scaling.
+(same camera, its own RNG seed for the bounce rays), no data-path collective: weak scaling.
 
 One process per GPU; launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -83,7 +83,7 @@ def main():
     # ---- ray batches on the device (untimed) -----------------------------------------------------
     n = a.side * a.side
     cams = scenes.STREET_CAMERAS if a.scene == "bistro" else scenes.SPONZA_CAMERAS
-    eye, view = cams[rank % len(cams)]
+    eye, view = cams[0]   # the same camera on every rank: equal work per GPU, so the N-GPU aggregate measures scaling, not workload differences
     cam = R.camera(eye, view, a.side, a.side, 1, 1)
     d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
     d_prim, d_diff, d_shad, d_tmp = (ctx.malloc(n * 64) for _ in range(4))
