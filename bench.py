@@ -74,7 +74,10 @@ def main():
     verts, label = scenes.get(a.scene)
     n_tris = verts.shape[0] // 3
     ctx = tb.Context(local_rank)
-    sc = tb.LAYOUT_CLASSES[a.layout](ctx).Build(verts)
+    # N ranks build the same BVH at the same time on one host: give each its share of the cores (the build is deterministic
+    # whatever the thread count)
+    build_threads = max(1, (os.cpu_count() or 8) // world) if world > 1 else 0
+    sc = tb.LAYOUT_CLASSES[a.layout](ctx).Build(verts, threads=build_threads)
     if a.variant:
         sc.set_variant(a.variant)
     if rank == 0:
