@@ -140,13 +140,14 @@ class HostBVH:
         self._h = h
 
     def blob(self, which: int, dtype, width: int) -> np.ndarray:
-        """Zero-copy numpy view of blob `which` (valid while this object lives)."""
+        """Zero-copy numpy view of blob `which` (the view keeps this object alive)."""
         p = lib.tbvh_host_blob(self._h, which)
         n = lib.tbvh_host_blob_count(self._h, which)
         if not p or n == 0:
             return np.zeros((0, width), dtype=dtype)
         nbytes = n * np.dtype(dtype).itemsize * width
         buf = (C.c_char * nbytes).from_address(p)
+        buf._owner = self   # the view keeps this object (and so the native blob) alive
         a = np.frombuffer(buf, dtype=dtype).reshape(n, width)
         a.flags.writeable = False
         return a
