@@ -10,6 +10,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "host_builder.h"
@@ -58,6 +63,11 @@ struct tbvh_context {
     uint64_t stageCap = 0;
     uint8_t* stageOcc = nullptr;
     uint64_t stageOccCap = 0;
+    // host-array queries of more than a few 10 k rays go through pinned staging in chunks: worker threads gather the
+    // 64-byte prefixes of the caller's records into a pinned buffer while the previous chunk is in flight (a pageable
+    // hipMemcpy2D moves ~9 GB/s because one CPU thread does the staging copy), and the 20 result bytes per ray come back
+    // packed (k_pack_hits) and are scattered by the same workers
+    struct HostPipe* pipe = nullptr;
     std::vector<tbvh_scene*> scenes;
 };
 
@@ -129,6 +139,143 @@ int ensureStageOcc(tbvh_context* c, uint64_t n) {
     c->stageOccCap = n;
     return 0;
 }
+
+// ---- pipelined host <-> device staging -------------------------------------------------------------------------
+}  // namespace
+struct HostPipe {
+    static constexpr uint64_t kChunk = 1ull << 18;   // rays per chunk: 16 MB up, 5 MB down
+    void* pinUp[2] = {nullptr, nullptr};
+    void* pinDown[2] = {nullptr, nullptr};
+    hipEvent_t evUp[2] = {nullptr, nullptr}, evDown[2] = {nullptr, nullptr};
+    uint32_t* packed = nullptr;   // device: 5 dwords per ray (bytes 44..63 of the record)
+    uint64_t packedCap = 0;
+    // a small persistent worker pool: parallel_for(n, fn) runs fn(part, parts) on every worker and the caller
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cvWork, cvDone;
+    std::function<void(uint32_t, uint32_t)> job;
+    uint64_t generation = 0;
+    uint32_t pending = 0;
+    bool quit = false;
+    void start(uint32_t nThreads) {
+        for (uint32_t t = 0; t < nThreads; t++)
+            workers.emplace_back([this, t, nThreads] {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::function<void(uint32_t, uint32_t)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cvWork.wait(lk, [&] { return quit || generation != seen; });
+                        if (quit) return;
+                        seen = generation; f = job;
+                    }
+                    f(t + 1, nThreads + 1);
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        if (--pending == 0) cvDone.notify_all();
+                    }
+                }
+            });
+    }
+    void parallel_for(const std::function<void(uint32_t, uint32_t)>& f) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = f; pending = (uint32_t)workers.size(); generation++;
+        }
+        cvWork.notify_all();
+        f(0, (uint32_t)workers.size() + 1);
+        std::unique_lock<std::mutex> lk(m);
+        cvDone.wait(lk, [&] { return pending == 0; });
+    }
+    ~HostPipe() {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cvWork.notify_all();
+        for (auto& w : workers) w.join();
+        for (int i = 0; i < 2; i++) {
+            if (pinUp[i]) hipHostFree(pinUp[i]);
+            if (pinDown[i]) hipHostFree(pinDown[i]);
+            if (evUp[i]) hipEventDestroy(evUp[i]);
+            if (evDown[i]) hipEventDestroy(evDown[i]);
+        }
+        if (packed) hipFree(packed);
+    }
+};
+namespace {
+
+int ensurePipe(tbvh_context* c, uint64_t n) {
+    if (!c->pipe) {
+        HostPipe* p = new (std::nothrow) HostPipe;
+        if (!p) return fail(TBVH_E_NOMEM, "out of host memory");
+        c->pipe = p;
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipHostMalloc(&p->pinUp[i], HostPipe::kChunk * 64, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(&p->pinDown[i], HostPipe::kChunk * 20, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&p->evUp[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p->evDown[i], hipEventDisableTiming));
+        }
+        uint32_t hw = std::thread::hardware_concurrency();
+        uint32_t t = hw >= 32 ? 7 : hw >= 8 ? 3 : hw >= 4 ? 1 : 0;   // + the calling thread
+        if (const char* e = getenv("TBVH_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) t = (uint32_t)v - 1; }
+        p->start(t);
+    }
+    HostPipe* p = c->pipe;
+    if (p->packedCap < n) {
+        if (p->packed) hipFree(p->packed);
+        p->packed = nullptr; p->packedCap = 0;
+        HIP_TRY(hipMalloc((void**)&p->packed, n * 20));
+        p->packedCap = n;
+    }
+    return 0;
+}
+
+// caller records (stride bytes apart) -> device array of 64-byte records
+int pipeUpload(tbvh_context* c, const char* rays, uint64_t n, uint32_t stride, RayRec* dst) {
+    HostPipe* p = c->pipe;
+    for (uint64_t first = 0, k = 0; first < n; first += HostPipe::kChunk, k++) {
+        const uint64_t cnt = n - first < HostPipe::kChunk ? n - first : HostPipe::kChunk;
+        const int b = (int)(k & 1);
+        if (k >= 2) HIP_TRY(hipEventSynchronize(p->evUp[b]));   // the DMA that last read this buffer is done
+        char* pin = (char*)p->pinUp[b];
+        const char* src = rays + first * stride;
+        p->parallel_for([=](uint32_t part, uint32_t parts) {
+            const uint64_t lo = cnt * part / parts, hi = cnt * (part + 1) / parts;
+            if (stride == 64) std::memcpy(pin + lo * 64, src + lo * 64, (hi - lo) * 64);
+            else for (uint64_t i = lo; i < hi; i++) std::memcpy(pin + i * 64, src + i * stride, 64);
+        });
+        HIP_TRY(hipMemcpyAsync(dst + first, pin, cnt * 64, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(p->evUp[b], c->stream));
+    }
+    return 0;
+}
+
+// device records -> bytes 44..63 of the caller's records
+int pipeDownloadHits(tbvh_context* c, char* rays, uint64_t n, uint32_t stride, const RayRec* src) {
+    HostPipe* p = c->pipe;
+    launch_pack_hits(src, p->packed, n, c->stream);
+    HIP_TRY(hipGetLastError());
+    const uint64_t chunks = (n + HostPipe::kChunk - 1) / HostPipe::kChunk;
+    auto issue = [&](uint64_t k) -> int {
+        const uint64_t first = k * HostPipe::kChunk, cnt = n - first < HostPipe::kChunk ? n - first : HostPipe::kChunk;
+        HIP_TRY(hipMemcpyAsync(p->pinDown[k & 1], (const char*)p->packed + first * 20, cnt * 20, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(p->evDown[k & 1], c->stream));
+        return 0;
+    };
+    if (int r = issue(0)) return r;
+    for (uint64_t k = 0; k < chunks; k++) {
+        if (k + 1 < chunks) if (int r = issue(k + 1)) return r;   // next chunk in flight while this one is scattered
+        HIP_TRY(hipEventSynchronize(p->evDown[k & 1]));
+        const uint64_t first = k * HostPipe::kChunk, cnt = n - first < HostPipe::kChunk ? n - first : HostPipe::kChunk;
+        const char* pin = (const char*)p->pinDown[k & 1];
+        char* dstRays = rays + first * stride;
+        p->parallel_for([=](uint32_t part, uint32_t parts) {
+            const uint64_t lo = cnt * part / parts, hi = cnt * (part + 1) / parts;
+            for (uint64_t i = lo; i < hi; i++) std::memcpy(dstRays + i * stride + 44, pin + i * 20, 20);
+        });
+    }
+    return 0;
+}
+
+constexpr uint64_t kPipeMinRays = 1ull << 15;
 
 int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh = false, float freshTmax = 1e30f,
                 const unsigned long long* nDev = nullptr) {
@@ -279,6 +426,7 @@ void tbvh_shutdown(tbvh_context* c) {
     if (c->pool) hipFree(c->pool);
     if (c->stageRays) hipFree(c->stageRays);
     if (c->stageOcc) hipFree(c->stageOcc);
+    delete c->pipe;
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->ownStream) hipStreamDestroy(c->ownStream);
@@ -750,6 +898,13 @@ int tbvh_intersect(tbvh_scene* s, void* rays, uint64_t n, uint32_t stride) {
     tbvh_context* c = s->ctx;
     if (int r = setDevice(c)) return r;
     if (int r = ensureStage(c, n)) return r;
+    if (n >= kPipeMinRays) {   // pinned, chunked, multi-threaded staging (see HostPipe)
+        if (int r = ensurePipe(c, n)) return r;
+        if (int r = pipeUpload(c, (const char*)rays, n, stride, c->stageRays)) return r;
+        if (int r = launchQuery(s, c->stageRays, n, nullptr)) return r;
+        if (int r = pipeDownloadHits(c, (char*)rays, n, stride, c->stageRays)) return r;
+        return checkStatus(c);
+    }
     HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
     if (int r = launchQuery(s, c->stageRays, n, nullptr)) return r;
     // copy back bytes 44..63 of every record (hit.inst + hit)
@@ -765,7 +920,10 @@ int tbvh_occluded(tbvh_scene* s, const void* rays, uint64_t n, uint32_t stride, 
     if (int r = setDevice(c)) return r;
     if (int r = ensureStage(c, n)) return r;
     if (int r = ensureStageOcc(c, n)) return r;
-    HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
+    if (n >= kPipeMinRays) {
+        if (int r = ensurePipe(c, n)) return r;
+        if (int r = pipeUpload(c, (const char*)rays, n, stride, c->stageRays)) return r;
+    } else HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
     if (int r = launchQuery(s, c->stageRays, n, c->stageOcc)) return r;
     HIP_TRY(hipMemcpyAsync(occ, c->stageOcc, n, hipMemcpyDeviceToHost, c->stream));
     return checkStatus(c);

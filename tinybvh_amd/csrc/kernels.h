@@ -38,6 +38,7 @@ hipError_t run_convert_bvh4(const float4* nodes2, uint32_t nNodes2, const uint32
 size_t refit_scratch_bytes(int layout, uint32_t nNodes);
 hipError_t launch_refit(int layout, float4* nodes, uint32_t nNodes, float4* tris, uint64_t nTriRecords, const float4* verts, uint64_t nTris,
                         void* scratch, uint32_t* status, hipStream_t s);
+void launch_pack_hits(const RayRec* rays, uint32_t* out, uint64_t n, hipStream_t s);
 void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris,
                         hipStream_t s);
 

@@ -114,4 +114,18 @@ void launch_gen_shadow(const RayRec* in, RayRec* out, uint64_t n, float lx, floa
     hipLaunchKernelGGL(k_gen_shadow, dim3((uint32_t)((n + bs - 1) / bs)), dim3(bs), 0, s, in, out, n, lx, ly, lz, eps);
 }
 
+// bytes 44..63 (hit.inst, t, u, v, prim) of every ray record, packed as 5 dwords per ray for the host read-back
+namespace {
+__global__ void k_pack_hits(const RayRec* __restrict__ rays, uint32_t* __restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* w = (const uint32_t*)(rays + i);
+    uint32_t* o = out + i * 5;
+    o[0] = w[11]; o[1] = w[12]; o[2] = w[13]; o[3] = w[14]; o[4] = w[15];
+}
+}  // namespace
+void launch_pack_hits(const RayRec* rays, uint32_t* out, uint64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_hits, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, rays, out, n);
+}
+
 }  // namespace tbvh
