@@ -147,8 +147,8 @@ int tbvh_set_opacity_micromaps(tbvh_scene* blas, const uint32_t* map_data, uint3
  * Replaces "BVH::Refit (tiny_bvh.h:3055-3093) / MBVH::Refit (4925-4961) on the host, ConvertFrom again
  * (4612-4655, 5884-6018), upload" of the reference flow.  verts16: the caller's bvhvec4 vertex array
  * (3 per triangle, n_tris triangles, same indexing as at build time); host memory (on_device = 0, staged
- * asynchronously) or device memory (1).  Works on BVH8_CWBVH and BVH_GPU scenes, including reference-built
- * blobs; BVH4_GPU scenes are re-uploaded instead.  Returns when the refit is done (the bottom-up passes are
+ * asynchronously) or device memory (1).  Works on all three layouts, including reference-built blobs
+ * (BVH4_GPU: the first call walks the stream once to list its nodes level by level).  Returns when the refit is done (the bottom-up passes are
  * launched in batches with one 4-byte read-back each); tbvh_time_last_ms() = time spent refitting.
  * A vertex array shorter than the blob's primitive indices is reported (TBVH_E_FORMAT) by the next
  * synchronising call. */

@@ -36,7 +36,7 @@ def check(got, want):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout", [tb.LAYOUT_CWBVH, tb.LAYOUT_BVH_GPU])
+@pytest.mark.parametrize("layout", [tb.LAYOUT_CWBVH, tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU])
 def test_refit_parity(ctx, oracle, layout):
     verts = scenes.blob(8000, seed=3)
     sc = tb.LAYOUT_CLASSES[layout](ctx).Build(verts)
@@ -88,14 +88,17 @@ def test_refit_on_reference_built_blob(ctx, oracle):
         sg = tb.BVH_GPU(ctx).Upload(g[f"bvhgpu_nodes_{k}"], g[f"bvhgpu_idx_{k}"], verts)
         sg.Refit(v2)
         check(sg.Intersect(rays.copy()), want)
+        s4 = tb.BVH4_GPU(ctx).Upload(g[f"bvh4_{k}"])
+        s4.Refit(v2)
+        check(s4.Intersect(rays.copy()), want)
 
 
 @pytest.mark.gpu
 def test_refit_errors(ctx):
     verts = scenes.soup(600, seed=1)
-    b4 = tb.BVH4_GPU(ctx).Build(verts)
+    tl = tb.TLAS(ctx).Build(tb.make_instances(np.eye(4, dtype=np.float32)[None], np.zeros(1, np.uint32)), [tb.BVH8_CWBVH(ctx).Build(verts)])
     with pytest.raises(tb.TbvhError):
-        b4.Refit(verts)                                  # BVH4_GPU is not refittable on the device
+        tb.check(tb.lib.tbvh_refit(tl._h, verts.ctypes.data_as(__import__("ctypes").c_void_p), verts.shape[0] // 3, 0), "refit of a TLAS")
     sc = tb.BVH8_CWBVH(ctx).Build(verts)
     sc.Refit(verts[: 3 * 100])                          # vertex array shorter than the blob's primitives
     r = R.random_rays(64, (-1, -1, -1), (1, 1, 1), seed=1)

@@ -99,6 +99,7 @@ struct tbvh_scene {
     uint64_t buildScratchFor = 0;     // instance count the scratch was sized for
     // device-side BLAS refit (kernels_refit.hip)
     void* refitScratch = nullptr;
+    std::vector<uint32_t> b4Levels;   // BVH4_GPU: first node of every tree level in the item list (filled by the first refit)
     float4* vertStage = nullptr;      // staged vertices when the caller passes host memory
     // opacity micromaps (BVHBase::SetOpacityMicroMaps)
     uint32_t* opmap = nullptr;
@@ -723,10 +724,35 @@ int tbvh_scene_download(tbvh_scene* s, int which, void* dst, uint64_t capBytes, 
 int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice) {
     if (!s || !verts16 || !nTris) return fail(TBVH_E_INVALID, "tbvh_refit: null/empty argument");
     if (s->isTlas) return fail(TBVH_E_INVALID, "tbvh_refit: a TLAS is rebuilt with tbvh_rebuild_tlas_device / tbvh_update_tlas");
-    if (s->layout != TBVH_LAYOUT_CWBVH && s->layout != TBVH_LAYOUT_BVH_GPU)
-        return fail(TBVH_E_INVALID, "tbvh_refit: layout %d is not refittable on the device (BVH8_CWBVH and BVH_GPU are)", s->layout);
     tbvh_context* c = s->ctx;
     if (int r = setDevice(c)) return r;
+    if (s->layout == TBVH_LAYOUT_BVH4_GPU) {
+        // node list per level, child-box hand-over area: sized for the most nodes the stream can hold (4 blocks each)
+        const uint32_t capNodes = (uint32_t)(s->nNodeBlocks / 4 + 1);
+        if (!s->refitScratch) HIP_TRY(hipMalloc(&s->refitScratch, (size_t)capNodes * (16 + 128) + 256));
+        const float4* dv4 = (const float4*)verts16;
+        if (!onDevice) {
+            if (s->vertStageTris < nTris) {
+                if (s->vertStage) hipFree(s->vertStage);
+                s->vertStage = nullptr; s->vertStageTris = 0;
+                HIP_TRY(hipMalloc((void**)&s->vertStage, nTris * 48));
+                s->vertStageTris = nTris;
+            }
+            HIP_TRY(hipMemcpyAsync(s->vertStage, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream));
+            dv4 = s->vertStage;
+        }
+        char* base = (char*)s->refitScratch;
+        uint32_t* counter = (uint32_t*)base;
+        void* items = base + 256;
+        float4* childBox = (float4*)(base + 256 + (size_t)capNodes * 16);
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        HIP_TRY(run_refit_bvh4(s->nodes, s->nNodeBlocks, dv4, nTris, items, capNodes, counter, childBox, s->b4Levels, c->status, c->stream));
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        c->timed = true;
+        return 0;
+    }
+    if (s->layout != TBVH_LAYOUT_CWBVH && s->layout != TBVH_LAYOUT_BVH_GPU)
+        return fail(TBVH_E_INVALID, "tbvh_refit: layout %d is not refittable", s->layout);
     const uint32_t nNodes = (uint32_t)(s->layout == TBVH_LAYOUT_CWBVH ? s->nNodeBlocks / 5 : s->nNodeBlocks / 4);
     const uint64_t nRecords = s->nTriBlocks / 3;
     if (!s->refitScratch) HIP_TRY(hipMalloc(&s->refitScratch, refit_scratch_bytes(s->layout, nNodes)));

@@ -463,7 +463,11 @@ void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, const BuildParams& p, s
             scale[a] = ext[a] > 1e-10f ? 254.999f / ext[a] : 0.f;
             e255[a] = ext[a] * (1.0f / 255.0f);
             const float guard = 4e-7f * std::max(std::max(std::fabs(n.box.mn[a]), std::fabs(n.box.mx[a])), ext[a]);
-            while (ext[a] > 0 && n.box.mn[a] + e255[a] * 255.0f < n.box.mx[a] + guard) e255[a] = std::nextafter(e255[a], kFar);
+            if (ext[a] > 0) {   // the decode step must carry 255 steps past the far face: jump there, then settle ulp by ulp
+                const float need = ((n.box.mx[a] + guard) - n.box.mn[a]) * (1.0f / 255.0f);
+                if (need > e255[a]) e255[a] = need;
+                while (n.box.mn[a] + e255[a] * 255.0f < n.box.mx[a] + guard) e255[a] = std::nextafter(e255[a], kFar);
+            }
         }
         for (uint32_t i = 0; i < n.childCount; i++) {
             const WideNode<4>& c = W[n.child[i]];

@@ -1,5 +1,6 @@
 // kernels.h — host-visible launchers of the device kernels (defined in kernels_*.hip).
 #pragma once
+#include <vector>
 #include "device_common.h"
 
 namespace tbvh {
@@ -35,6 +36,8 @@ hipError_t run_convert_bvh4(const float4* nodes2, uint32_t nNodes2, const uint32
                             float4* blocks, uint64_t capBlocks, uint2* itemsA, uint2* itemsB, uint32_t* counters, uint32_t* status, hipStream_t s,
                             uint64_t* nBlocksOut, uint32_t* levelsOut);
 // device BLAS refit (kernels_refit.hip)
+hipError_t run_refit_bvh4(float4* blocks, uint64_t nBlocks, const float4* verts, uint64_t nTris, void* itemsDev, uint32_t capNodes, uint32_t* counterDev,
+                          float4* childBox, std::vector<uint32_t>& levelFirst, uint32_t* status, hipStream_t s);
 size_t refit_scratch_bytes(int layout, uint32_t nNodes);
 hipError_t launch_refit(int layout, float4* nodes, uint32_t nNodes, float4* tris, uint64_t nTriRecords, const float4* verts, uint64_t nTris,
                         void* scratch, uint32_t* status, hipStream_t s);

@@ -189,7 +189,11 @@ __global__ void k_convert4_level(const float4* __restrict__ nodes2, uint32_t nNo
         scale[a] = ext[a] > 1e-10f ? 254.999f / ext[a] : 0.f;
         e255[a] = ext[a] * (1.0f / 255.0f);
         guard[a] = 4e-7f * fmaxf(fmaxf(fabsf(bmn[a]), fabsf(bmx[a])), ext[a]);
-        while (ext[a] > 0 && bmn[a] + e255[a] * 255.0f < bmx[a] + guard[a]) e255[a] = nextafterf(e255[a], 1e30f);
+        if (ext[a] > 0) {   // the decode step must carry 255 steps past the far face: jump there, then settle ulp by ulp
+            const float need = ((bmx[a] + guard[a]) - bmn[a]) * (1.0f / 255.0f);
+            if (need > e255[a]) e255[a] = need;
+            while (bmn[a] + e255[a] * 255.0f < bmx[a] + guard[a]) e255[a] = nextafterf(e255[a], 1e30f);
+        }
     }
     uint32_t info[4] = {0, 0, 0, 0}, q[6] = {0, 0, 0, 0, 0, 0};   // q: xmin, xmax, ymin, ymax, zmin, zmax; byte i = child i
     uint32_t rel = 4, inner = 0;

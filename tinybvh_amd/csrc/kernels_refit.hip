@@ -24,6 +24,8 @@
 #include "cwbvh_encode.h"
 #include "kernels.h"
 
+#include <vector>
+
 namespace tbvh {
 
 namespace {
@@ -146,6 +148,102 @@ __global__ void k_cw_pass(float4* __restrict__ nodes, uint32_t nNodes, const flo
     done[j] = pass;
 }
 
+// ---- BVH4_GPU -------------------------------------------------------------------------------------------
+// One float4 stream (tiny_bvh.h:5115-5244): node = {bmin | qxmin x4} {ext/255 | qxmax x4} {qymin qymax qzmin qzmax x4}
+// {childInfo x4}, the triangles of its leaf children inline after it.  There is no node table, so the first refit walks
+// the tree once, level by level, and keeps the list of node offsets per level (k_b4_collect); a refit then runs the
+// levels deepest first: each node re-gathers the triangles of its leaf children, takes the boxes its interior children
+// left in its slot of `childBox` one launch earlier, re-quantises itself like the host encoder (encode_bvh4_gpu /
+// kernels_convert.hip) and hands its own box up.
+struct B4Item { uint32_t offset, parent, slot, pad; };   // parent = ordinal of the parent node in the item array, slot 0..3
+
+__global__ void k_b4_collect(const float4* __restrict__ blocks, uint64_t nBlocks, const B4Item* __restrict__ items, uint32_t first, uint32_t count,
+                             B4Item* __restrict__ out, uint32_t* __restrict__ counter, uint32_t cap) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const B4Item it = items[first + t];
+    if ((uint64_t)it.offset + 4 > nBlocks) return;
+    const float4 info = blocks[(size_t)it.offset + 3];
+    const uint32_t ci[4] = {as_u32(info.x), as_u32(info.y), as_u32(info.z), as_u32(info.w)};
+    for (uint32_t i = 0; i < 4; i++) {
+        if (ci[i] == 0u || (ci[i] >> 31)) continue;   // empty or leaf
+        const uint32_t k = atomicAdd(counter, 1u);
+        if (k < cap) out[k] = B4Item{ci[i], first + t, i, 0u};
+    }
+}
+
+__global__ void k_b4_refit_level(float4* __restrict__ blocks, uint64_t nBlocks, const float4* __restrict__ verts, uint64_t nTris,
+                                 const B4Item* __restrict__ items, uint32_t first, uint32_t count, float4* __restrict__ childBox, uint32_t* __restrict__ status) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t ord = first + t;
+    const B4Item it = items[ord];
+    float4* nb = blocks + (size_t)it.offset;
+    const float4 info = nb[3];
+    const uint32_t ci[4] = {as_u32(info.x), as_u32(info.y), as_u32(info.z), as_u32(info.w)};
+    float3 cmn[4], cmx[4];
+    bool used[4];
+    float3 mn = make_float3(1e30f, 1e30f, 1e30f), mx = make_float3(-1e30f, -1e30f, -1e30f);
+    for (uint32_t i = 0; i < 4; i++) {
+        used[i] = ci[i] != 0u;
+        if (!used[i]) continue;
+        float3 a = make_float3(1e30f, 1e30f, 1e30f), b = make_float3(-1e30f, -1e30f, -1e30f);
+        if (ci[i] >> 31) {   // leaf: triangles inline at offset + rel, {v0|prim, e1, e2}
+            const uint32_t cnt = (ci[i] >> 16) & 0x7fffu, rel = ci[i] & 0xffffu;
+            for (uint32_t j = 0; j < cnt; j++) {
+                float4* tr = nb + rel + 3 * j;
+                if ((uint64_t)it.offset + rel + 3 * j + 3 > nBlocks) break;
+                const uint32_t prim = as_u32(tr[0].w);
+                if (prim >= nTris) { atomicOr(status, 2u); continue; }
+                const float4 v0 = verts[3 * (uint64_t)prim], v1 = verts[3 * (uint64_t)prim + 1], v2 = verts[3 * (uint64_t)prim + 2];
+                tr[0] = make_float4(v0.x, v0.y, v0.z, as_f32(prim));
+                tr[1] = make_float4(v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v1.w - v0.w);
+                tr[2] = make_float4(v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, v2.w - v0.w);
+                a = min3(a, min3(make_float3(v0.x, v0.y, v0.z), min3(make_float3(v1.x, v1.y, v1.z), make_float3(v2.x, v2.y, v2.z))));
+                b = max3(b, max3(make_float3(v0.x, v0.y, v0.z), max3(make_float3(v1.x, v1.y, v1.z), make_float3(v2.x, v2.y, v2.z))));
+            }
+        } else {             // interior: its box was left in our slot by the previous (deeper) launch
+            const float4 bn = childBox[((size_t)ord * 4 + i) * 2], bx = childBox[((size_t)ord * 4 + i) * 2 + 1];
+            a = make_float3(bn.x, bn.y, bn.z); b = make_float3(bx.x, bx.y, bx.z);
+        }
+        cmn[i] = a; cmx[i] = b;
+        mn = min3(mn, a); mx = max3(mx, b);
+    }
+    // quantisation frame exactly as the host encoder's / the device conversion's
+    const float bmn[3] = {mn.x, mn.y, mn.z}, bmx[3] = {mx.x, mx.y, mx.z};
+    float ext[3], scale[3], e255[3], guard[3];
+    for (int a = 0; a < 3; a++) {
+        ext[a] = bmx[a] - bmn[a];
+        scale[a] = ext[a] > 1e-10f ? 254.999f / ext[a] : 0.f;
+        e255[a] = ext[a] * (1.0f / 255.0f);
+        guard[a] = 4e-7f * fmaxf(fmaxf(fabsf(bmn[a]), fabsf(bmx[a])), ext[a]);
+        if (ext[a] > 0) {   // the decode step must carry 255 steps past the far face: jump there, then settle ulp by ulp
+            const float need = ((bmx[a] + guard[a]) - bmn[a]) * (1.0f / 255.0f);
+            if (need > e255[a]) e255[a] = need;
+            while (bmn[a] + e255[a] * 255.0f < bmx[a] + guard[a]) e255[a] = nextafterf(e255[a], 1e30f);
+        }
+    }
+    uint32_t q[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t i = 0; i < 4; i++) {
+        if (!used[i]) continue;
+        const float lo3[3] = {cmn[i].x, cmn[i].y, cmn[i].z}, hi3[3] = {cmx[i].x, cmx[i].y, cmx[i].z};
+        for (int a = 0; a < 3; a++) {
+            int lo = (int)floorf((lo3[a] - bmn[a]) * scale[a]), hi = (int)ceilf((hi3[a] - bmn[a]) * scale[a]);
+            lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo); hi = hi < 0 ? 0 : (hi > 255 ? 255 : hi);
+            while (lo > 0 && bmn[a] + e255[a] * (float)lo > lo3[a] - guard[a]) lo--;
+            while (hi < 255 && bmn[a] + e255[a] * (float)hi < hi3[a] + guard[a]) hi++;
+            q[2 * a] |= (uint32_t)lo << (8 * i); q[2 * a + 1] |= (uint32_t)hi << (8 * i);
+        }
+    }
+    nb[0] = make_float4(bmn[0], bmn[1], bmn[2], as_f32(q[0]));
+    nb[1] = make_float4(e255[0], e255[1], e255[2], as_f32(q[1]));
+    nb[2] = make_float4(as_f32(q[2]), as_f32(q[3]), as_f32(q[4]), as_f32(q[5]));
+    if (ord != 0) {   // hand the box up
+        childBox[((size_t)it.parent * 4 + it.slot) * 2] = make_float4(mn.x, mn.y, mn.z, 0.f);
+        childBox[((size_t)it.parent * 4 + it.slot) * 2 + 1] = make_float4(mx.x, mx.y, mx.z, 0.f);
+    }
+}
+
 }  // namespace
 
 size_t refit_scratch_bytes(int layout, uint32_t nNodes) {
@@ -178,6 +276,40 @@ hipError_t launch_refit(int layout, float4* nodes, uint32_t nNodes, float4* tris
         if ((e = hipMemcpyAsync(&rootDone, done, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
         if (pass > 200000u) return hipErrorUnknown;   // cyclic blob
+    }
+    return hipGetLastError();
+}
+
+}  // namespace tbvh
+
+namespace tbvh {
+
+// BVH4_GPU refit.  items: capacity capNodes; levelFirst: host array filled by the first call (node list per level, root
+// level first); childBox: capNodes * 8 float4.  Returns the number of nodes found (0 on the calls that reuse the lists).
+hipError_t run_refit_bvh4(float4* blocks, uint64_t nBlocks, const float4* verts, uint64_t nTris, void* itemsDev, uint32_t capNodes, uint32_t* counterDev,
+                          float4* childBox, std::vector<uint32_t>& levelFirst, uint32_t* status, hipStream_t s) {
+    B4Item* items = (B4Item*)itemsDev;
+    hipError_t e;
+    if (levelFirst.empty()) {   // walk the tree once: items[levelFirst[l] .. levelFirst[l + 1]) = the nodes of level l
+        const B4Item root = {0u, 0u, 0u, 0u};
+        if ((e = hipMemcpyAsync(items, &root, sizeof root, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+        levelFirst.push_back(0); levelFirst.push_back(1);
+        for (;;) {
+            const uint32_t first = levelFirst[levelFirst.size() - 2], count = levelFirst.back() - first;
+            if ((e = hipMemsetAsync(counterDev, 0, 4, s)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_b4_collect, dim3((count + 127) / 128), dim3(128), 0, s, blocks, nBlocks, items, first, count, items + levelFirst.back(), counterDev,
+                               capNodes - levelFirst.back());
+            uint32_t found = 0;
+            if ((e = hipMemcpyAsync(&found, counterDev, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+            if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+            if (found == 0) break;
+            if (levelFirst.back() + (uint64_t)found > capNodes || levelFirst.size() > 4096) { levelFirst.clear(); return hipErrorUnknown; }   // malformed (cyclic) stream
+            levelFirst.push_back(levelFirst.back() + found);
+        }
+    }
+    for (size_t l = levelFirst.size() - 1; l-- > 0;) {
+        const uint32_t first = levelFirst[l], count = levelFirst[l + 1] - first;
+        hipLaunchKernelGGL(k_b4_refit_level, dim3((count + 127) / 128), dim3(128), 0, s, blocks, nBlocks, verts, nTris, items, first, count, childBox, status);
     }
     return hipGetLastError();
 }
