@@ -125,8 +125,8 @@ int tbvh_convert_bvh2_device(tbvh_context* ctx, const void* nodes32, uint64_t n_
  * The fast path for content whose topology changes every frame or whose host build (BVH::Build,
  * tiny_bvh.h:2124-2461) is the bottleneck; the tree is of lower quality than the binned-SAH build (more node
  * visits per ray), so it is not what the host builder or the bench use.  verts16: bvhvec4 vertices, 3 per
- * triangle, host (on_device = 0) or device memory (1); layout: TBVH_LAYOUT_CWBVH (max_leaf_tris 1..3, 0 = 3) or
- * TBVH_LAYOUT_BVH4_GPU (1..4, 0 = 4).
+ * triangle, host (on_device = 0) or device memory (1); layout: TBVH_LAYOUT_CWBVH (max_leaf_tris 1..3, 0 = the
+ * default 1: Morton ranges make poor multi-triangle leaves) or TBVH_LAYOUT_BVH4_GPU (1..4, 0 = 4).
  * prim indices in the hit records are the triangle's index in verts16, as with every other builder. */
 int tbvh_build_device(tbvh_context* ctx, const void* verts16, uint64_t n_tris, int on_device, int layout,
                       uint32_t max_leaf_tris, tbvh_scene** out);

@@ -308,7 +308,7 @@ class BVH8_CWBVH(_Scene):
         self.host = HostBVH(verts, LAYOUT_CWBVH, **kw)
         return self.Upload(self.host.blob(0, np.uint32, 4), self.host.blob(1, np.uint32, 4))
 
-    def BuildOnDevice(self, verts: np.ndarray, max_leaf_tris: int = 3) -> "BVH8_CWBVH":
+    def BuildOnDevice(self, verts: np.ndarray, max_leaf_tris: int = 0) -> "BVH8_CWBVH":
         """LBVH build + wide collapse + encode on the GPU (tbvh_build_device); nothing is built on the host."""
         verts = np.ascontiguousarray(verts, np.float32)
         check(lib.tbvh_build_device(self.ctx._h, _ptr(verts), verts.shape[0] // 3, 0, LAYOUT_CWBVH, max_leaf_tris, C.byref(self._h)), "tbvh_build_device")

@@ -661,7 +661,10 @@ int tbvh_build_device(tbvh_context* c, const void* verts16, uint64_t nTris, int 
     if (layout != TBVH_LAYOUT_CWBVH && layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "tbvh_build_device: target layout %d not supported (BVH8_CWBVH and BVH4_GPU are)", layout);
     if (nTris > 0x3fffffffull) return fail(TBVH_E_INVALID, "tbvh_build_device: too many triangles for 32-bit node indices");
     const uint32_t leafCap = layout == TBVH_LAYOUT_CWBVH ? 3u : 4u;
-    if (maxLeafTris == 0) maxLeafTris = leafCap;
+    // default: one triangle per leaf for CWBVH.  Contiguous Morton ranges make poor multi-triangle leaves: measured on the
+    // Bistro stand-in, 1 / 2 / 3 triangles per leaf trace camera rays at 3629 / 3354 / 3125 and bounce rays at 2323 / 2150 /
+    // 1884 MRays/s (the host SAH tree: 3300 / 2480), for 13 instead of 8 ms of build time and 22 % more memory
+    if (maxLeafTris == 0) maxLeafTris = layout == TBVH_LAYOUT_CWBVH ? 1u : leafCap;
     if (maxLeafTris > leafCap) return fail(TBVH_E_INVALID, "tbvh_build_device: at most %u triangles per leaf for this layout", leafCap);
     if (int r = setDevice(c)) return r;
     struct Tmp {
