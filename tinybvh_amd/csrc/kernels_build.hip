@@ -40,16 +40,18 @@ __device__ __forceinline__ unsigned long long spread21(uint32_t v) {   // 21 bit
     return x;
 }
 
-// per-triangle box + centroid bounds of the scene (wave reduction, one atomic set per wave)
+// per-triangle box + centroid bounds of the scene.  Grid-stride over the triangles, wave reduction, then ONE set of six
+// atomics per wave at the very end: the six words share a cache line, and same-line atomics are serialised memory-side
+// (~12 ns each): one set per 64 triangles cost 3 ms for Bistro, one per wave of a 2048-block grid costs nothing.
 __global__ void k_tri_boxes(const float4* __restrict__ verts, uint32_t n, float4* __restrict__ triMin, float4* __restrict__ triMax,
                             uint32_t* __restrict__ centreBounds) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    float3 mn = make_float3(1e30f, 1e30f, 1e30f), mx = make_float3(-1e30f, -1e30f, -1e30f);
-    float3 cmn = mn, cmx = mx;
-    if (i < n) {
+    float3 cmn = make_float3(1e30f, 1e30f, 1e30f), cmx = make_float3(-1e30f, -1e30f, -1e30f);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        float3 mn = make_float3(1e30f, 1e30f, 1e30f), mx = make_float3(-1e30f, -1e30f, -1e30f);
         for (int k = 0; k < 3; k++) { const float4 v = verts[3 * (uint64_t)i + k]; const float3 p = make_float3(v.x, v.y, v.z); mn = min3(mn, p); mx = max3(mx, p); }
         triMin[i] = make_float4(mn.x, mn.y, mn.z, 0.f); triMax[i] = make_float4(mx.x, mx.y, mx.z, 0.f);
-        cmn = cmx = make_float3(0.5f * (mn.x + mx.x), 0.5f * (mn.y + mx.y), 0.5f * (mn.z + mx.z));
+        const float3 c = make_float3(0.5f * (mn.x + mx.x), 0.5f * (mn.y + mx.y), 0.5f * (mn.z + mx.z));
+        cmn = min3(cmn, c); cmx = max3(cmx, c);
     }
     for (int o = 32; o > 0; o >>= 1) {
         cmn = min3(cmn, make_float3(__shfl_xor(cmn.x, o), __shfl_xor(cmn.y, o), __shfl_xor(cmn.z, o)));
@@ -220,7 +222,7 @@ hipError_t launch_lbvh_build(const float4* verts, uint32_t n, uint32_t maxLeaf, 
     if ((e = hipMemsetAsync(sc.flags, 0, (size_t)n * 4, s)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(nodes32, 0, 64, s)) != hipSuccess) return e;   // root + the unused node 1
     const uint32_t bs = 256, nb = (n + bs - 1) / bs;
-    hipLaunchKernelGGL(k_tri_boxes, dim3(nb), dim3(bs), 0, s, verts, n, sc.triMin, sc.triMax, sc.bounds);
+    hipLaunchKernelGGL(k_tri_boxes, dim3(nb < 2048u ? nb : 2048u), dim3(bs), 0, s, verts, n, sc.triMin, sc.triMax, sc.bounds);
     hipLaunchKernelGGL(k_tri_morton, dim3(nb), dim3(bs), 0, s, sc.triMin, sc.triMax, sc.bounds, n, sc.keysA, sc.valsA);
     size_t tmp = sortTempBytes;
     if ((e = hipcub::DeviceRadixSort::SortPairs(sc.sortTemp, tmp, sc.keysA, sc.keysB, sc.valsA, primIdx, (int)n, 0, 63, s)) != hipSuccess) return e;
