@@ -1050,7 +1050,7 @@ int tbvh_wavefront_create(tbvh_context* c, uint32_t width, uint32_t height, tbvh
     if (e == hipSuccess) e = hipMalloc((void**)&w->shadowAux, w->n * sizeof(PathAux));
     if (e == hipSuccess) e = hipMalloc((void**)&w->occ, w->n);
     if (e == hipSuccess) e = hipMalloc((void**)&w->accum, w->n * 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&w->counters, 64 * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&w->counters, 256 * 8);
     if (e == hipSuccess) e = hipMemset(w->accum, 0, w->n * 16);
     if (e == hipSuccess) e = hipEventCreate(&w->e0);
     if (e == hipSuccess) e = hipEventCreate(&w->e1);
@@ -1085,8 +1085,11 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
     hipStream_t st = c->stream;
     HIP_TRY(hipEventRecord(w->e0, st));
     if (p->clear) HIP_TRY(hipMemsetAsync(w->accum, 0, w->n * 16, st));
-    HIP_TRY(hipMemsetAsync(w->counters, 0, 64 * 8, st));
-    HIP_TRY(hipMemcpyAsync(&w->counters[0], &w->n, 8, hipMemcpyHostToDevice, st));
+    // the two path-queue counters and the shadow-queue counter sit on their own 256-byte lines (words 0, 32, 64): appends to
+    // different queues hit different lines (same-line atomics are serialised memory-side); per-depth history from word 96 on
+    auto QC = [&](int i) { return &w->counters[i < 8 ? i * 32 : 96 + (i - 8)]; };
+    HIP_TRY(hipMemsetAsync(w->counters, 0, 256 * 8, st));
+    HIP_TRY(hipMemcpyAsync(QC(0), &w->n, 8, hipMemcpyHostToDevice, st));
     CameraArgs ca;
     memcpy(ca.eye, cam->eye, 12); memcpy(ca.p1, cam->p1, 12); memcpy(ca.p2, cam->p2, 12); memcpy(ca.p3, cam->p3, 12);
     ca.width = cam->width; ca.height = cam->height; ca.sppX = ca.sppY = 1;
@@ -1095,32 +1098,32 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
     for (uint32_t d = 0; d < maxDepth; d++) {
         const int nxt = cur ^ 1;
         // Extend: nearest hit of every live path; the batch size lives on the device
-        if (int r = launchQuery(scene, w->rays[cur], w->n, nullptr, false, 1e30f, &w->counters[cur])) return r;
-        HIP_TRY(hipMemsetAsync(&w->counters[nxt], 0, 8, st));
-        HIP_TRY(hipMemsetAsync(&w->counters[2], 0, 8, st));
+        if (int r = launchQuery(scene, w->rays[cur], w->n, nullptr, false, 1e30f, QC(cur))) return r;
+        HIP_TRY(hipMemsetAsync(QC(nxt), 0, 8, st));
+        HIP_TRY(hipMemsetAsync(QC(2), 0, 8, st));
         ShadeArgs a;
-        a.in = w->rays[cur]; a.auxIn = w->aux[cur]; a.nIn = &w->counters[cur];
-        a.out = w->rays[nxt]; a.auxOut = w->aux[nxt]; a.nOut = &w->counters[nxt];
-        a.shadow = w->shadow; a.shadowAux = w->shadowAux; a.nShadow = &w->counters[2];
+        a.in = w->rays[cur]; a.auxIn = w->aux[cur]; a.nIn = QC(cur);
+        a.out = w->rays[nxt]; a.auxOut = w->aux[nxt]; a.nOut = QC(nxt);
+        a.shadow = w->shadow; a.shadowAux = w->shadowAux; a.nShadow = QC(2);
         a.verts = (const float4*)dVerts; a.accum = w->accum;
         memcpy(a.lightPos, p->light_pos, 12); memcpy(a.lightColor, p->light_color, 12); memcpy(a.skyLo, p->sky_lo, 12); memcpy(a.skyHi, p->sky_hi, 12);
         a.eps = p->eps; a.depth = d; a.maxDepth = maxDepth; a.seed = p->seed;
         launch_wf_shade(a, w->n, st);
         // Connect: any-hit over the shadow queue, then add what is unoccluded
-        if (int r = launchQuery(scene, w->shadow, w->n, w->occ, false, 1e30f, &w->counters[2])) return r;
-        launch_wf_connect(w->occ, w->shadowAux, &w->counters[2], w->accum, w->n, st);
-        HIP_TRY(hipMemcpyAsync(&w->counters[8 + 2 * d], &w->counters[cur], 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(&w->counters[9 + 2 * d], &w->counters[2], 8, hipMemcpyDeviceToDevice, st));
+        if (int r = launchQuery(scene, w->shadow, w->n, w->occ, false, 1e30f, QC(2))) return r;
+        launch_wf_connect(w->occ, w->shadowAux, QC(2), w->accum, w->n, st);
+        HIP_TRY(hipMemcpyAsync(QC(8 + 2 * d), QC(cur), 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipMemcpyAsync(QC(9 + 2 * d), QC(2), 8, hipMemcpyDeviceToDevice, st));
         cur = nxt;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(w->e1, st));
     if (stats) {
         unsigned long long h[64];
-        HIP_TRY(hipMemcpyAsync(h, w->counters, sizeof h, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(h, QC(8), sizeof h, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         memset(stats, 0, sizeof *stats);
-        for (uint32_t d = 0; d < maxDepth; d++) { stats->extend_rays[d] = h[8 + 2 * d]; stats->shadow_rays[d] = h[9 + 2 * d]; }
+        for (uint32_t d = 0; d < maxDepth; d++) { stats->extend_rays[d] = h[2 * d]; stats->shadow_rays[d] = h[1 + 2 * d]; }
         HIP_TRY(hipEventElapsedTime(&stats->frame_ms, w->e0, w->e1));
         if (int r = checkStatus(c)) return r;
     }

@@ -44,7 +44,7 @@ __device__ __forceinline__ void put_ray(RayRec* r, float3 O, float3 D, float tma
 // workgroup and queue: same-address atomics are serialised memory-side at ~12 ns each on MI355X, so a
 // per-wave append (262 k atomics for a 16.7 M-path stage) would cost milliseconds by itself.
 // Must be reached by every thread of the workgroup.  sh: kShadeWaves + 1 words of LDS.
-constexpr int kShadeBlock = 512, kShadeWaves = kShadeBlock / 64;
+constexpr int kShadeBlock = 1024, kShadeWaves = kShadeBlock / 64;
 __device__ __forceinline__ uint32_t queue_slot(bool want, unsigned long long* counter, uint32_t* sh) {
     const uint64_t m = __ballot(want);
     const uint32_t wave = threadIdx.x >> 6;
