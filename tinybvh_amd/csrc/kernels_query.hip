@@ -38,7 +38,7 @@ template <int LDS_N> using Stack32 = LaneStack<uint32_t, LDS_N, WG>;
 // tris: 3 x float4 per primIdx entry {v0.xyz|prim, e1, e2}, gathered at upload so a leaf
 // reads one contiguous run instead of primIdx -> verts (two dependent gathers).
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1>
 __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, const float4* __restrict__ tris, QueryArgs q,
                                              uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
@@ -94,7 +94,10 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
                 else node = st.pop();
             }
         }
-        // ---- node phase ---------------------------------------------------------------------------
+        // ---- node phase: NODE_REPS visits per iteration (the per-iteration bookkeeping — idle / pending ballots, the refill
+        // check — is a sizeable part of a 2-wide step) ---------------------------------------------
+#pragma unroll
+        for (int rep = 0; rep < NODE_REPS; rep++)
         if (!done && triLeft == 0) {
             const float4 n0 = nodes[node * 4], n1 = nodes[node * 4 + 1], n2 = nodes[node * 4 + 2], n3 = nodes[node * 4 + 3];
             const uint32_t triCount = as_u32(n2.w);
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
 // sorted order.  The hit leaves of a node (at most 4) are queued in registers and their
 // triangles tested one per iteration.
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1>
 __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
     Stack32<LDS_N> st;
@@ -203,6 +206,8 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
                 else offset = st.pop();
             }
         }
+#pragma unroll
+        for (int rep = 0; rep < NODE_REPS; rep++)   // several node visits per iteration, as in k_bvh2
         if (!done && leafCnt == 0) {
             const float4 d0 = data[offset], d1 = data[offset + 1], d2 = data[offset + 2], d3 = data[offset + 3];
             // per-axis: t(q) = (bmin + ext*q - O) * rD = q * (ext*rD) + (bmin - O)*rD
@@ -299,8 +304,11 @@ void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tr
     case 1: TBVH_L2(1); break;
     case 2: TBVH_L2(8); break;
     case 3: TBVH_L2(32); break;
+    case 5: TBVH_L2(16, false, 2); break;   // two node visits per iteration
+    case 6: TBVH_L2(16, false, 3); break;
     case 4: TBVH_L2(16, true); break;   // adaptive (LockstepGovernor, ray_pool.h): +8 % on coherent camera rays, -2..9 % elsewhere: not the default
-    default: TBVH_L2(16); break;        // per-lane replacement throughout
+    case 7: TBVH_L2(16); break;                // one node visit per iteration (the former default)
+    default: TBVH_L2(16, false, 3); break;     // per-lane replacement throughout, three node visits per iteration (measured +5..14 % over one)
     }
 #undef TBVH_L2
 }
@@ -314,6 +322,8 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
     switch (variant) {
     case 1: TBVH_L4(1); break;
     case 2: TBVH_L4(16); break;
+    case 5: TBVH_L4(8, false, 2); break;   // two node visits per iteration
+    case 6: TBVH_L4(8, false, 3); break;
     case 4: TBVH_L4(8, true); break;   // adaptive (LockstepGovernor, ray_pool.h): +6 % on coherent camera rays, -2..8 % elsewhere: not the default
     default: TBVH_L4(8); break;        // per-lane replacement throughout
     }
