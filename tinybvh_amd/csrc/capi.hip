@@ -869,7 +869,7 @@ uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0;
 
 int tbvh_set_variant(tbvh_scene* s, int v) {
     if (!s) return fail(TBVH_E_INVALID, "null scene");
-    const bool ok = s->layout == TBVH_LAYOUT_CWBVH ? (cwbvh_variant_valid(v) || (v >= 20 && v <= 39)) : (v >= 0 && v <= 7);
+    const bool ok = s->layout == TBVH_LAYOUT_CWBVH ? (cwbvh_variant_valid(v) || (v >= 20 && v <= 39)) : (v >= 0 && v <= 8);
     if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
     tbvh_context* c = s->ctx;
     if (int r = setDevice(c)) return r;

@@ -306,9 +306,10 @@ void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tr
     case 3: TBVH_L2(32); break;
     case 5: TBVH_L2(16, false, 2); break;   // two node visits per iteration
     case 6: TBVH_L2(16, false, 3); break;
-    case 4: TBVH_L2(16, true); break;   // adaptive (LockstepGovernor, ray_pool.h): +8 % on coherent camera rays, -2..9 % elsewhere: not the default
+    case 4: TBVH_L2(16, true); break;   // adaptive, one node visit per iteration
     case 7: TBVH_L2(16); break;                // one node visit per iteration (the former default)
-    default: TBVH_L2(16, false, 3); break;     // per-lane replacement throughout, three node visits per iteration (measured +5..14 % over one)
+    case 8: TBVH_L2(16, false, 3); break;      // per-lane replacement throughout, three node visits per iteration (+5..14 % over one)
+    default: TBVH_L2(16, true, 3); break;      // + the lockstep governor (ray_pool.h): Sponza camera rays +9 %, shadow +6 %; small incoherent batches -3..5 %
     }
 #undef TBVH_L2
 }
