@@ -298,14 +298,15 @@ int tbvh_copy_from_device(tbvh_context* ctx, void* dst, const void* d_src, uint6
  * ---------------------------------------------------------------------------------- */
 typedef struct tbvh_build_params {
     uint32_t bins;          /* SAH bins per axis; 0 = default (8, BVHBINS)               */
-    uint32_t max_leaf_tris; /* 0 = layout default (CWBVH 3, others 4)                   */
+    uint32_t max_leaf_tris; /* 0 = layout default (CWBVH 1 with the optimal collapse, 3 with the greedy one; others 4) */
     uint32_t threads;       /* 0 = hardware concurrency                                  */
     uint32_t flags;         /* TBVH_BUILD_* | (triangle cost in 1/100 of a node visit) << 8, 0 = defaults */
 } tbvh_build_params;
 #define TBVH_BUILD_OPTIMAL_COLLAPSE 2u /* wide layouts: SAH-optimal collapse (Ylitie et al. 2017 dynamic program: merges
-                                          <= 3-triangle subtrees into leaves, fills nodes; ~2.5x fewer nodes) instead of the
-                                          default surface-area-greedy collapse (the strategy of MBVH::ConvertFrom,
-                                          tiny_bvh.h:4975-5048).  Same speed within 3 % on MI355X, half the node memory. */
+                                          <= 3-triangle subtrees into leaves, fills nodes) instead of the surface-area-greedy
+                                          collapse (the strategy of MBVH::ConvertFrom, tiny_bvh.h:4975-5048).  DEFAULT for
+                                          BVH8_CWBVH, with a triangle test priced like a node visit (flags >> 8 = 100). */
+#define TBVH_BUILD_GREEDY_COLLAPSE 4u  /* force the greedy collapse (the reference's strategy; default for BVH4_GPU) */
 
 int tbvh_host_build(const void* verts16, uint64_t n_tris, int layout,
                     const tbvh_build_params* params, tbvh_hostbvh** out);

@@ -165,8 +165,8 @@ def test_optimal_collapse_gives_same_hits_with_fewer_nodes(oracle, small_scene, 
     """TBVH_BUILD_OPTIMAL_COLLAPSE (SAH dynamic program): still a valid blob of the format, same
     hits as BVH::Intersect, fewer nodes than the greedy collapse."""
     verts = small_scene
-    g = tb.HostBVH(verts, layout)
-    o = tb.HostBVH(verts, layout, optimal_collapse=True, c_prim=0.3)
+    g = tb.HostBVH(verts, layout, greedy_collapse=True)
+    o = tb.HostBVH(verts, layout, optimal_collapse=True, c_prim=0.3, max_leaf_tris=3)
     assert o.blob(0, np.uint32, 4).shape[0] < g.blob(0, np.uint32, 4).shape[0]
     for rays in ray_sets(verts):
         want = oracle.bvh2_intersect(o.bvh2_nodes(), o.bvh2_prim_idx(), verts, rays)
