@@ -305,8 +305,9 @@ typedef struct tbvh_build_params {
 #define TBVH_BUILD_OPTIMAL_COLLAPSE 2u /* wide layouts: SAH-optimal collapse (Ylitie et al. 2017 dynamic program: merges
                                           <= 3-triangle subtrees into leaves, fills nodes) instead of the surface-area-greedy
                                           collapse (the strategy of MBVH::ConvertFrom, tiny_bvh.h:4975-5048).  DEFAULT for
-                                          BVH8_CWBVH, with a triangle test priced like a node visit (flags >> 8 = 100). */
-#define TBVH_BUILD_GREEDY_COLLAPSE 4u  /* force the greedy collapse (the reference's strategy; default for BVH4_GPU) */
+                                          BVH8_CWBVH and BVH4_GPU, with a triangle test priced like a node visit
+                                          (flags >> 8 = 100). */
+#define TBVH_BUILD_GREEDY_COLLAPSE 4u  /* force the greedy collapse (the reference's strategy) */
 
 int tbvh_host_build(const void* verts16, uint64_t n_tris, int layout,
                     const tbvh_build_params* params, tbvh_hostbvh** out);

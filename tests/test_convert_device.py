@@ -109,7 +109,7 @@ def test_build_on_device_parity(ctx, oracle, scene, n, leaf):
 def test_bvh4_gpu_convert_and_build_on_device(ctx, oracle, scene, n):
     """BVH4_GPU as the target: conversion of a host BVH2 and the full device build."""
     verts = scenes.soup(n, seed=4) if scene == "soup" else scenes.blob(n, seed=7) if scene == "blob" else scenes.get("sponza")[0]
-    host = tb.HostBVH(verts, tb.LAYOUT_BVH4_GPU)
+    host = tb.HostBVH(verts, tb.LAYOUT_BVH4_GPU, greedy_collapse=True)   # the device conversion is the greedy collapse
     n2, pi = host.bvh2_nodes(), host.bvh2_prim_idx()
     lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
     pad = 0.05 * (hi - lo) + 0.01
@@ -117,7 +117,7 @@ def test_bvh4_gpu_convert_and_build_on_device(ctx, oracle, scene, n):
     want = oracle.bvh2_intersect(n2, pi, verts, rays)
     conv = tb.BVH4_GPU(ctx).ConvertFromBVH2(n2, pi, verts)
     blocks, _ = conv.download_blobs()
-    assert blocks.shape[0] == host.blob(0, np.uint32, 4).shape[0]      # same collapse as the host encoder: same stream length
+    assert blocks.shape[0] == host.blob(0, np.uint32, 4).shape[0]      # same collapse as the host's greedy encoder: same stream length
     tb.BVH4_GPU(ctx).Upload(blocks)                                       # passes the blob validator
     check(conv.Intersect(rays.copy()), want)
     built = tb.BVH4_GPU(ctx).BuildOnDevice(verts)

@@ -237,3 +237,55 @@ def test_malformed_blobs_are_rejected_at_upload(ctx, soup):
     n2 = h2.blob(0, np.uint32, 16).copy(); n2[0, 3] = 10 ** 9
     with pytest.raises(tb.TbvhError):
         tb.BVH_GPU(ctx).Upload(n2, h2.blob(1, np.uint32, 1), soup)
+
+
+def handmade_bvh4_big_leaves(verts, counts):
+    """A BVH4_GPU stream (tiny_bvh.h:1248-1266) made by hand: one root node whose leaf children hold
+    `counts` triangles each (the format's leaf count is 15 bits; the host builder never makes leaves
+    that large, a caller's builder may).  Child boxes = the full node box (quantised 0..255)."""
+    verts = verts.reshape(-1, 3, 4)
+    assert sum(counts) == verts.shape[0] and len(counts) <= 4
+    lo = verts[:, :, :3].min((0, 1)); hi = verts[:, :, :3].max((0, 1))
+    ext = (hi - lo) * np.float32(1.0001)
+    blocks = np.zeros((4 + 3 * verts.shape[0], 4), np.float32)
+    u = blocks.view(np.uint32)
+    k = len(counts)
+    q0 = 0; q1 = sum(255 << (8 * i) for i in range(k))
+    blocks[0, :3] = lo; u[0, 3] = q0                      # bmin | xmin bytes
+    blocks[1, :3] = ext / np.float32(255.0); u[1, 3] = q1  # extent / 255 | xmax bytes
+    u[2] = (q0, q1, q0, q1)                                # ymin, ymax, zmin, zmax bytes
+    first = 0
+    for i, c in enumerate(counts):
+        off = 4 + 3 * first
+        assert off < 65536 and c < 32768
+        u[3, i] = 0x80000000 | (c << 16) | off            # leaf | count | offset relative to the node
+        for j in range(first, first + c):
+            v0, v1, v2 = verts[j, 0, :3], verts[j, 1, :3], verts[j, 2, :3]
+            b = 4 + 3 * j
+            blocks[b, :3] = v0; u[b, 3] = j
+            blocks[b + 1, :3] = v1 - v0
+            blocks[b + 2, :3] = v2 - v0
+        first += c
+    return blocks
+
+
+@pytest.mark.parametrize("counts", [(300,), (700, 40, 260), (255, 256, 1, 488), (1000, 4000)])
+def test_bvh4_leaves_beyond_255_triangles(ctx, oracle, counts):
+    """Leaves of more than 255 triangles are legal in BVH4_GPU (15-bit count); the kernel queues
+    them with 16-bit counters like any other leaf."""
+    verts = scenes.soup(sum(counts), seed=21, extent=6.0, size=0.9)
+    blocks = handmade_bvh4_big_leaves(verts, counts)
+    rays = R.random_rays(30_000, (-1, -1, -1), (7, 7, 7), seed=13)
+    mirror = oracle.bvh4_intersect(blocks.view(np.uint32), rays.copy())
+    host = tb.HostBVH(verts, tb.LAYOUT_BVH2_WALD)
+    want = oracle.bvh2_intersect(host.bvh2_nodes(), host.bvh2_prim_idx(), verts, rays.copy())
+    c = compare_hits(mirror, want)                          # the hand-made stream says what the scene says
+    assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["hits"] > 1000, c
+    sc = tb.BVH4_GPU(ctx).Upload(blocks)
+    got = sc.Intersect(rays.copy())
+    assert_parity(got, want)
+    m = compare_hits(got, mirror)
+    assert m["bit_identical"] == m["hits"] and m["hitmiss"] == 0 and m["prim_mismatch"] == 0, m   # same visit order as the mirror
+    occ = sc.IsOccluded(rays.copy())
+    assert np.array_equal(occ.astype(bool), want["t"] < 1e30)
+    sc.free()

@@ -18,7 +18,7 @@ void launch_cwbvh_relayout(const float4* src, char* dst, uint32_t nNodes, hipStr
 void launch_cwbvh_c(bool anyhit, int variant, const float4* nodes, const float4* tris, uint32_t nNodes, const QueryArgs& q,
                     uint32_t* status, uint32_t blocks, hipStream_t s);
 struct BlasDesc { const float4* nodes; const float4* tris; const uint32_t* opmap; uint32_t opmapN; uint32_t pad; };  // one per BLAS of a TLAS
-void launch_tlas(bool anyhit, int blasLayout, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances,
+void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances,
                  const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
 // device TLAS rebuild (kernels_tlasbuild.hip)
 size_t tlas_build_scratch_bytes(uint32_t n, size_t* sortTempBytes);

@@ -38,7 +38,7 @@ template <int LDS_N> using Stack32 = LaneStack<uint32_t, LDS_N, WG>;
 // tris: 3 x float4 per primIdx entry {v0.xyz|prim, e1, e2}, gathered at upload so a leaf
 // reads one contiguous run instead of primIdx -> verts (two dependent gathers).
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, uint32_t GOV_KEEP = kLockstepKeep>
 __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, const float4* __restrict__ tris, QueryArgs q,
                                              uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
     bool found = false;
     uint32_t node = 0, triLeft = 0, triPtr = 0;   // triLeft > 0: a leaf's triangles are pending
 
-    LockstepGovernor gov;   // ADAPT only
+    LockstepGovernorT<GOV_KEEP, GOV_KEEP - 5u> gov;   // ADAPT only
     gov.init();
     for (;;) {
         const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
@@ -146,8 +146,8 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
 // sorted order.  The hit leaves of a node (at most 4) are queued in registers and their
 // triangles tested one per iteration.
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1>
-__global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, QueryArgs q, uint32_t* __restrict__ status) {
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT, int NODE_REPS, bool SIGNSEL, uint32_t GOV_KEEP>
+__device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const QueryArgs& q, uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
     Stack32<LDS_N> st;
     st.init(&stk[0][threadIdx.x], q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
@@ -162,12 +162,12 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
     bool found = false;
     uint32_t offset = 0;
     // pending leaves of the current node in processing order: leafQ0 first.  leafQn = absolute
-    // block offset of the leaf's next triangle, leafCnt = remaining triangle counts, one byte per
-    // queue slot (slot 0 in the low byte; 0 = empty).  Leaves with > 255 triangles (legal in the
-    // format, 15-bit count) are tested in place instead of being queued.
-    uint32_t leafQ0 = 0, leafQ1 = 0, leafQ2 = 0, leafQ3 = 0, leafCnt = 0;
+    // block offset of the leaf's next triangle; remaining triangle counts in 16-bit fields (the
+    // format's count is 15 bits): slots 0, 1 in leafCnt (slot 0 low), slots 2, 3 in leafCntB.
+    // The queue is kept compacted towards slot 0, so leafCnt == 0 means no leaf is pending.
+    uint32_t leafQ0 = 0, leafQ1 = 0, leafQ2 = 0, leafQ3 = 0, leafCnt = 0, leafCntB = 0;
 
-    LockstepGovernor gov;   // ADAPT only
+    LockstepGovernorT<GOV_KEEP, GOV_KEEP - 5u> gov;   // ADAPT only
     gov.init();
     for (;;) {
         const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
                     const RayRec* rp = q.rays + ri;
                     O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
                     hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
-                    found = false; offset = 0; leafCnt = 0; st.sp = 0;
+                    found = false; offset = 0; leafCnt = 0; leafCntB = 0; st.sp = 0;
                     active = true;
                 }
             }
@@ -194,7 +194,10 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
             const uint32_t ta = leafQ0;
             const float4 v0 = data[ta], e1 = data[ta + 1], e2 = data[ta + 2];
             leafQ0 += 3u; leafCnt -= 1u;                      // next triangle, one fewer left in slot 0
-            if ((leafCnt & 255u) == 0) { leafQ0 = leafQ1; leafQ1 = leafQ2; leafQ2 = leafQ3; leafCnt >>= 8; }
+            if ((leafCnt & 0xffffu) == 0) {
+                leafQ0 = leafQ1; leafQ1 = leafQ2; leafQ2 = leafQ3;
+                leafCnt = __builtin_amdgcn_alignbit(leafCntB, leafCnt, 16); leafCntB >>= 16;
+            }
             TriHit h;
             if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
                 found = true;
@@ -217,9 +220,25 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
             const uint32_t qy0 = as_u32(d2.x), qy1 = as_u32(d2.y), qz0 = as_u32(d2.z), qz1 = as_u32(d2.w);
             float dist[4];
             uint32_t info[4] = { as_u32(d3.x), as_u32(d3.y), as_u32(d3.z), as_u32(d3.w) };
+            // SIGNSEL: the sign of the ray direction says which of the two quantised planes of an axis is the near one
+            // (q0 <= q1 and t is monotonic in q), so the words are swapped once per node instead of a min and a max per
+            // child and axis.  NaNs (0 * inf on degenerate axes) drop out of max3 / min3 as they do out of the min / max pairs.
+            const bool ngx = sx < 0.f, ngy = sy < 0.f, ngz = sz < 0.f;
+            const uint32_t nx = ngx ? qx1 : qx0, fx = ngx ? qx0 : qx1;
+            const uint32_t ny = ngy ? qy1 : qy0, fy = ngy ? qy0 : qy1;
+            const uint32_t nz = ngz ? qz1 : qz0, fz = ngz ? qz0 : qz1;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const int sh = 8 * i;
+                if (SIGNSEL) {
+                    const float x1 = __builtin_fmaf((float)((nx >> sh) & 255), sx, bx), x2 = __builtin_fmaf((float)((fx >> sh) & 255), sx, bx);
+                    const float y1 = __builtin_fmaf((float)((ny >> sh) & 255), sy, by), y2 = __builtin_fmaf((float)((fy >> sh) & 255), sy, by);
+                    const float z1 = __builtin_fmaf((float)((nz >> sh) & 255), sz, bz), z2 = __builtin_fmaf((float)((fz >> sh) & 255), sz, bz);
+                    const float tmin = __builtin_fmaxf(fmax3(x1, y1, z1), 0.0f);
+                    const float tmax = __builtin_fminf(fmin3(x2, y2, z2), hit.x);
+                    dist[i] = (tmin > tmax || info[i] == 0) ? kFar : tmin;
+                    continue;
+                }
                 const float x1 = __builtin_fmaf((float)((qx0 >> sh) & 255), sx, bx), x2 = __builtin_fmaf((float)((qx1 >> sh) & 255), sx, bx);
                 const float y1 = __builtin_fmaf((float)((qy0 >> sh) & 255), sy, by), y2 = __builtin_fmaf((float)((qy1 >> sh) & 255), sy, by);
                 const float z1 = __builtin_fmaf((float)((qz0 >> sh) & 255), sz, bz), z2 = __builtin_fmaf((float)((qz1 >> sh) & 255), sz, bz);
@@ -237,22 +256,10 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
                 if (!(dist[i] < kFar)) continue;
                 if (!(info[i] & 0x80000000u)) { st.push(info[i]); continue; }
                 const uint32_t cnt = (info[i] >> 16) & 0x7fffu;
-                uint32_t ta = offset + (info[i] & 0xffffu);
-                if (cnt > 255u) {   // oversized leaf: test in place, in order (queued leaves before it are empty
-                                    // only if it is the first hit leaf; otherwise order among exact ties may differ)
-                    for (uint32_t j = 0; j < cnt; j++, ta += 3) {
-                        const float4 v0 = data[ta], e1 = data[ta + 1], e2 = data[ta + 2];
-                        TriHit h;
-                        if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
-                            found = true;
-                            if (ANYHIT) { done = true; break; }
-                            hit = make_float4(h.t, h.u, h.v, v0.w);
-                        }
-                    }
-                    continue;
-                }
+                if (cnt == 0) continue;   // an empty leaf would break the compaction of the queue
+                const uint32_t ta = offset + (info[i] & 0xffffu);
                 if (nq == 0) leafQ0 = ta; else if (nq == 1) leafQ1 = ta; else if (nq == 2) leafQ2 = ta; else leafQ3 = ta;
-                leafCnt |= cnt << (8 * nq);
+                if (nq < 2) leafCnt |= cnt << (16 * nq); else leafCntB |= cnt << (16 * (nq - 2));
                 nq++;
             }
             if (!done && leafCnt == 0) {
@@ -267,6 +274,16 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
         }
     }
     if (st.overflow) atomicOr(status, 1u);
+}
+
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, bool SIGNSEL = false, uint32_t GOV_KEEP = kLockstepKeep>
+__global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, QueryArgs q, uint32_t* __restrict__ status) {
+    bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP>(data, q, status);
+}
+// the same with the register budget of 8 waves per SIMD (<= 64 VGPRs; left alone the compiler takes 65-68)
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, bool SIGNSEL = false, uint32_t GOV_KEEP = kLockstepKeep>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh4_w8(const float4* __restrict__ data, QueryArgs q, uint32_t* __restrict__ status) {
+    bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP>(data, q, status);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -308,6 +325,9 @@ void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tr
     case 6: TBVH_L2(16, false, 3); break;
     case 4: TBVH_L2(16, true); break;   // adaptive, one node visit per iteration
     case 7: TBVH_L2(16); break;                // one node visit per iteration (the former default)
+    case 9: TBVH_L2(16, true, 3, 205); break;
+    case 10: TBVH_L2(16, true, 3, 218); break;
+    case 11: TBVH_L2(16, true, 3, 230); break;
     case 8: TBVH_L2(16, false, 3); break;      // per-lane replacement throughout, three node visits per iteration (+5..14 % over one)
     default: TBVH_L2(16, true, 3); break;      // + the lockstep governor (ray_pool.h): Sponza camera rays +9 %, shadow +6 %; small incoherent batches -3..5 %
     }
@@ -320,15 +340,27 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
         if (anyhit) hipLaunchKernelGGL((k_bvh4<true, 12, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, data, q, status);  \
         else hipLaunchKernelGGL((k_bvh4<false, 12, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, data, q, status);        \
     } while (0)
+#define TBVH_L4W(...)                                                                                               \
+    do {                                                                                                            \
+        if (anyhit) hipLaunchKernelGGL((k_bvh4_w8<true, 12, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, data, q, status);  \
+        else hipLaunchKernelGGL((k_bvh4_w8<false, 12, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, data, q, status);        \
+    } while (0)
     switch (variant) {
     case 1: TBVH_L4(1); break;
     case 2: TBVH_L4(16); break;
     case 5: TBVH_L4(8, false, 2); break;   // two node visits per iteration
     case 6: TBVH_L4(8, false, 3); break;
+    case 7: TBVH_L4(8, false, 1, true); break;   // sign-selected near / far planes
+    case 8: TBVH_L4(8, true, 1, true); break;    // + governor
+    case 9: TBVH_L4W(8, false, 1, true); break;    // sign-selected planes, <= 64 VGPRs
+    case 10: TBVH_L4W(8, false, 1, false); break;
+    case 11: TBVH_L4W(8, true, 1, true); break;    // + governor
     case 4: TBVH_L4(8, true); break;   // adaptive (LockstepGovernor, ray_pool.h): +6 % on coherent camera rays, -2..8 % elsewhere: not the default
-    default: TBVH_L4(8); break;        // per-lane replacement throughout
+    case 12: TBVH_L4(8); break;        // the former default: min / max pairs per plane, compiler's register budget (65-68 VGPRs)
+    default: TBVH_L4W(8, false, 1, true); break;   // per-lane replacement throughout, sign-selected planes, 8 waves per SIMD
     }
 #undef TBVH_L4
+#undef TBVH_L4W
 }
 
 void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris, hipStream_t s) {

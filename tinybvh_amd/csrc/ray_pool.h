@@ -37,7 +37,7 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
 // Measured per-generation cohesion (tools/perf_probe.py --variant 46): camera / shadow rays of the
 // Sponza stand-in 0.75-0.95, bounce rays < 0.6 everywhere, Bistro stand-in camera rays spread over 0.3-1.
 constexpr uint32_t kLockstepKeep = 184, kLockstepBail = 179;   // x / 256: 0.72, 0.70
-struct LockstepGovernor {
+template <uint32_t KEEP = kLockstepKeep, uint32_t BAIL = kLockstepBail> struct LockstepGovernorT {
     bool lockstep;
     uint32_t genIters, genActive, ema;
     __device__ __forceinline__ void init() { lockstep = true; genIters = 0; genActive = 0; ema = 0; }
@@ -50,14 +50,16 @@ struct LockstepGovernor {
                 if (genIters > 1u) {
                     const uint32_t e = genActive * 4u / genIters;   // x / 256
                     ema = ema ? (ema + e) >> 1 : e;
-                    if (ema < kLockstepKeep) lockstep = false;
+                    if (ema < KEEP) lockstep = false;
                 }
                 genIters = 0; genActive = 0;
-            } else if (genIters >= 16u && genActive * 4u < kLockstepBail * genIters) lockstep = false;
+            } else if (genIters >= 16u && genActive * 4u < BAIL * genIters) lockstep = false;
         }
         return lockstep ? nIdle == 64u : nIdle >= refillMin;
     }
 };
+
+typedef LockstepGovernorT<> LockstepGovernor;
 
 template <int CHUNK> struct RayPool {
     static_assert(CHUNK % 64 == 0, "chunks are whole 64-ray groups");

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--layout", type=int, default=6)
     ap.add_argument("--side", type=int, default=10)
     ap.add_argument("--frames", type=int, default=4)
+    ap.add_argument("--variant", type=int, default=0)
     a = ap.parse_args()
     verts, label = scenes.get("dragon")
     ctx = tb.Context(0)
@@ -46,6 +47,8 @@ def main():
         t0 = time.perf_counter()
         tlas.Build(inst, [blas])          # host: BLASInstance update + TLAS build + upload/update
         t_host = time.perf_counter() - t0
+        if a.variant:
+            tlas.set_variant(a.variant)
         tlas.intersect_device_fresh(d_rays, n, 1e30)
         ms = ctx.time_last_ms()
         print(f"frame {f}: {inst.shape[0]} instances of {label} ({verts.shape[0] // 3} tris), BLAS layout {a.layout}: host TLAS rebuild+upload {t_host * 1e3:.2f} ms, "
@@ -62,6 +65,8 @@ def main():
         ctx.synchronize()
         t_sync = time.perf_counter() - t0
         ms_build = ctx.time_last_ms()
+        if a.variant:
+            tlas.set_variant(a.variant)
         tlas.intersect_device_fresh(d_rays, n, 1e30)
         ms = ctx.time_last_ms()
         print(f"frame {f}: DEVICE TLAS rebuild: host call {t_call * 1e3:.3f} ms (returns before the GPU is done), until done {t_sync * 1e3:.3f} ms, "
