@@ -122,7 +122,7 @@ __device__ __forceinline__ NodeResult visit_node_pk(const float4* __restrict__ n
 // MODE 1: per-lane replacement from a wave-local pool; REFILL_MIN idle lanes trigger a refill.
 // ADAPT: the wave's LockstepGovernor (ray_pool.h) decides when it takes new rays.
 template <bool ANYHIT, int MODE, int LDS_N, int REFILL_MIN, bool TRI1 = false, bool STATS = false, int TRI_MIN = 1, bool PKFMA = false, int CHUNK = 64, bool ADAPT = false,
-          int NSTRIDE = 5>
+          int NSTRIDE = 5, bool HAS_OMM = true>
 __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
                 const uint32_t ta = tg.x + ti * 3u;
                 const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
                 TriHit h;
-                if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
+                if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w))) {
                     found = true;
                     if (ANYHIT) done = true;
                     else hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
             const uint32_t ta = tg.x + ti * 3u;
             const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w))) {
                 found = true;
                 if (ANYHIT) break;
                 hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -419,7 +419,10 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     case 5: TBVH_LAUNCH(1, 8, 16); break;    // smaller LDS stack -> more waves per CU
     case 6: TBVH_LAUNCH(1, 12, 16); break;
     case 12: TBVH_LAUNCH(1, 16, 16); break;  // replace when >= 16 lanes are idle, all triangles of a group at once
-    default: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 64, true); break;  // = 45: the adaptive schedule is the default
+    default:   // = 45: the adaptive schedule is the default; without opacity micromaps the check is compiled out (+1-2 %)
+        if (q.omm.map) TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 64, true);
+        else TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 64, true, 5, false);
+        break;
     }
 #undef TBVH_LAUNCH
 }

@@ -38,7 +38,7 @@ template <int LDS_N> using Stack32 = LaneStack<uint32_t, LDS_N, WG>;
 // tris: 3 x float4 per primIdx entry {v0.xyz|prim, e1, e2}, gathered at upload so a leaf
 // reads one contiguous run instead of primIdx -> verts (two dependent gathers).
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, uint32_t GOV_KEEP = kLockstepKeep>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, uint32_t GOV_KEEP = kLockstepKeep, bool HAS_OMM = true>
 __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, const float4* __restrict__ tris, QueryArgs q,
                                              uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
             const float4 v0 = tris[triPtr], e1 = tris[triPtr + 1], e2 = tris[triPtr + 2];
             triPtr += 3; triLeft--;
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w))) {
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
 // sorted order.  The hit leaves of a node (at most 4) are queued in registers and their
 // triangles tested one per iteration.
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT, int NODE_REPS, bool SIGNSEL, uint32_t GOV_KEEP>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT, int NODE_REPS, bool SIGNSEL, uint32_t GOV_KEEP, bool HAS_OMM>
 __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const QueryArgs& q, uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
     Stack32<LDS_N> st;
@@ -199,7 +199,7 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
                 leafCnt = __builtin_amdgcn_alignbit(leafCntB, leafCnt, 16); leafCntB >>= 16;
             }
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, q.omm, as_u32(v0.w))) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w))) {
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -276,14 +276,14 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
     if (st.overflow) atomicOr(status, 1u);
 }
 
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, bool SIGNSEL = false, uint32_t GOV_KEEP = kLockstepKeep>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, bool SIGNSEL = false, uint32_t GOV_KEEP = kLockstepKeep, bool HAS_OMM = true>
 __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, QueryArgs q, uint32_t* __restrict__ status) {
-    bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP>(data, q, status);
+    bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP, HAS_OMM>(data, q, status);
 }
 // the same with the register budget of 8 waves per SIMD (<= 64 VGPRs; left alone the compiler takes 65-68)
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, bool SIGNSEL = false, uint32_t GOV_KEEP = kLockstepKeep>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, bool SIGNSEL = false, uint32_t GOV_KEEP = kLockstepKeep, bool HAS_OMM = true>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh4_w8(const float4* __restrict__ data, QueryArgs q, uint32_t* __restrict__ status) {
-    bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP>(data, q, status);
+    bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP, HAS_OMM>(data, q, status);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -329,7 +329,10 @@ void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tr
     case 10: TBVH_L2(16, true, 3, 218); break;
     case 11: TBVH_L2(16, true, 3, 230); break;
     case 8: TBVH_L2(16, false, 3); break;      // per-lane replacement throughout, three node visits per iteration (+5..14 % over one)
-    default: TBVH_L2(16, true, 3); break;      // + the lockstep governor (ray_pool.h): Sponza camera rays +9 %, shadow +6 %; small incoherent batches -3..5 %
+    default:   // + the lockstep governor (ray_pool.h): Sponza camera rays +9 %, shadow +6 %; small incoherent batches -3..5 %
+        if (q.omm.map) TBVH_L2(16, true, 3);
+        else TBVH_L2(16, true, 3, kLockstepKeep, false);   // no opacity micromaps: the check is compiled out
+        break;
     }
 #undef TBVH_L2
 }
@@ -357,7 +360,10 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
     case 11: TBVH_L4W(8, true, 1, true); break;    // + governor
     case 4: TBVH_L4(8, true); break;   // adaptive (LockstepGovernor, ray_pool.h): +6 % on coherent camera rays, -2..8 % elsewhere: not the default
     case 12: TBVH_L4(8); break;        // the former default: min / max pairs per plane, compiler's register budget (65-68 VGPRs)
-    default: TBVH_L4W(8, false, 1, true); break;   // per-lane replacement throughout, sign-selected planes, 8 waves per SIMD
+    default:   // per-lane replacement throughout, sign-selected planes, 8 waves per SIMD
+        if (q.omm.map) TBVH_L4W(8, false, 1, true);
+        else TBVH_L4W(8, false, 1, true, kLockstepKeep, false);   // no opacity micromaps: the check is compiled out
+        break;
     }
 #undef TBVH_L4
 #undef TBVH_L4W
