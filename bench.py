@@ -76,7 +76,7 @@ def main():
     ctx = tb.Context(local_rank)
     # N ranks build the same BVH at the same time on one host: give each its share of the cores (the build is deterministic
     # whatever the thread count)
-    build_threads = max(1, (os.cpu_count() or 8) // world) if world > 1 else 0
+    build_threads = max(1, usable_cores() // world) if world > 1 else 0
     sc = tb.LAYOUT_CLASSES[a.layout](ctx).Build(verts, threads=build_threads)
     if a.variant:
         sc.set_variant(a.variant)
@@ -258,6 +258,22 @@ def main():
     ctx.close()
 
 
+def usable_cores():
+    """Host threads this process can really run at once: the affinity mask, cut by the cgroup CPU quota if there is one
+    (os.cpu_count() reports the whole machine even inside a container limited to a few cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(tb, ctx, verts, d_prim, d_diff, n):
     """Reference BVH8_CPU (AVX2) on all host cores over a bounded sample of the same rays
     (oracle/_ref, kind 'reference'); falls back to the single-threaded C oracle ('port')."""
@@ -270,7 +286,7 @@ def cpu_baseline(tb, ctx, verts, d_prim, d_diff, n):
         ctx.from_device(buf, d + ((n - ns) // 2) * 64)
         b = buf.copy(); b["t"] = 1e30
         batches.append(b)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     if have_reference():
         ref = Reference()
         t0 = time.time()

@@ -34,7 +34,7 @@ __device__ __forceinline__ float safercp(float x) {
     return x >= 0 ? kFar : -kFar;
 }
 
-typedef LaneStack<uint2, 16, WG> Stack;   // LDS top + global spill (lane_stack.h)
+template <int LDS_N> using StackT = LaneStack<uint2, LDS_N, WG>;   // LDS top + global spill (lane_stack.h)
 
 struct RayL {  // a ray in some space + its current best hit
     float3 O, D, rD;
@@ -45,7 +45,7 @@ struct RayL {  // a ray in some space + its current best hit
 // ---- BLAS traversals; each runs until the stack is back at `base` ------------------------------
 
 template <bool ANYHIT, int LDS_N>
-__device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 tris, RayL& r, Stack& st, const Omm om) {
+__device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 tris, RayL& r, StackT<LDS_N>& st, const Omm om) {
     const int base = st.sp;
     const uint32_t oct = 7u - ((r.D.x < 0 ? 4u : 0u) | (r.D.y < 0 ? 2u : 0u) | (r.D.z < 0 ? 1u : 0u));
     const uint32_t octinv4 = oct * 0x01010101u;
@@ -114,7 +114,7 @@ __device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 
 }
 
 template <bool ANYHIT, int LDS_N>
-__device__ __forceinline__ void blas_bvh4(const GlobalF4 data, RayL& r, Stack& st, const Omm om) {
+__device__ __forceinline__ void blas_bvh4(const GlobalF4 data, RayL& r, StackT<LDS_N>& st, const Omm om) {
     const int base = st.sp;
     uint32_t offset = 0;
     for (;;) {
@@ -162,13 +162,12 @@ __device__ __forceinline__ void blas_bvh4(const GlobalF4 data, RayL& r, Stack& s
 }
 
 // instance record = BLASInstance, 12 float4 (192 bytes)
-template <bool ANYHIT, int BLAS_LAYOUT>
+template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N>
 __device__ __forceinline__ void tlas_body(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
                                           const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, const QueryArgs& q,
                                           uint32_t* __restrict__ status) {
-    constexpr int LDS_N = 16;
     __shared__ uint2 stk[LDS_N][WG];
-    Stack st;
+    StackT<LDS_N> st;
     st.init(&stk[0][threadIdx.x], (uint2*)q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
@@ -255,38 +254,42 @@ __device__ __forceinline__ void tlas_body(const float4* __restrict__ tlasNodes, 
     if (st.overflow) atomicOr(status, 1u);
 }
 
-template <bool ANYHIT, int BLAS_LAYOUT>
+template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N = 16>
 __global__ __launch_bounds__(WG) void k_tlas(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
                                              const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, QueryArgs q,
                                              uint32_t* __restrict__ status) {
-    tlas_body<ANYHIT, BLAS_LAYOUT>(tlasNodes, tlasIdx, instances, blas, q, status);
+    tlas_body<ANYHIT, BLAS_LAYOUT, LDS_N>(tlasNodes, tlasIdx, instances, blas, q, status);
 }
 // the same with the register budget of 5 waves per SIMD (<= 96 VGPRs; left alone the compiler takes 88-115)
-template <bool ANYHIT, int BLAS_LAYOUT>
+template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N = 16>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_tlas_w5(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
                                              const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, QueryArgs q,
                                              uint32_t* __restrict__ status) {
-    tlas_body<ANYHIT, BLAS_LAYOUT>(tlasNodes, tlasIdx, instances, blas, q, status);
+    tlas_body<ANYHIT, BLAS_LAYOUT, LDS_N>(tlasNodes, tlasIdx, instances, blas, q, status);
 }
 
 }  // namespace
 
 void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances,
                  const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
-#define TBVH_LT(K)                                                                                                                      \
+#define TBVH_LT(K, ...)                                                                                                                      \
     do {                                                                                                                                \
         if (blasLayout == 9) {                                                                                                          \
-            if (anyhit) hipLaunchKernelGGL((K<true, 9>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status); \
-            else hipLaunchKernelGGL((K<false, 9>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);       \
+            if (anyhit) hipLaunchKernelGGL((K<true, 9, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status); \
+            else hipLaunchKernelGGL((K<false, 9, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);       \
         } else {                                                                                                                        \
-            if (anyhit) hipLaunchKernelGGL((K<true, 6>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status); \
-            else hipLaunchKernelGGL((K<false, 6>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);       \
+            if (anyhit) hipLaunchKernelGGL((K<true, 6, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status); \
+            else hipLaunchKernelGGL((K<false, 6, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);       \
         }                                                                                                                               \
     } while (0)
-    // BVH4_GPU BLASes: 93 VGPRs without spilling -> 5 waves per SIMD instead of 4: +3-4 % (1000 instances, 8.3 M camera rays:
-    // 2.10 -> 2.02 ms); the CWBVH closest-hit instantiation would spill at that budget and measured no gain
-    if (variant == 1 || (variant == 0 && blasLayout != 9)) TBVH_LT(k_tlas_w5);
-    else TBVH_LT(k_tlas);
+    // Default: the register budget of 5 waves per SIMD (<= 96 VGPRs; left alone the compiler takes 88-115 and runs 4) and a
+    // 12-entry LDS stack top (6 KB per workgroup: 20 workgroups per CU fit the 160 KB).  1000 instances, 8.3 M camera rays:
+    // BVH4_GPU BLASes 2.10 -> 1.95 ms, CWBVH BLASes 2.73 -> 2.56 ms.
+    if (variant == 2) TBVH_LT(k_tlas_w5, 8);
+    else if (variant == 4) TBVH_LT(k_tlas, 8);
+    else if (variant == 5) TBVH_LT(k_tlas, 16);        // the former default
+    else if (variant == 1) TBVH_LT(k_tlas_w5, 16);
+    else TBVH_LT(k_tlas_w5, 12);
 #undef TBVH_LT
 }
 
