@@ -35,11 +35,16 @@ __device__ __forceinline__ uint32_t sext_s8x4(uint32_t i) {
 // triangles).  Also returns child / triangle base and imask.
 struct NodeResult { uint32_t childBase, triBase, hitmask, imask; };
 
+struct NodeRec { float4 n0, n1, n2, n3, n4; };   // one 80-byte CWBVH node
+
 template <int NSTRIDE = 5>
-__device__ __forceinline__ NodeResult visit_node(const float4* __restrict__ nodes, uint32_t nodeIdx, float3 O,
-                                                 float3 rD, float tmax, uint32_t octinv4) {
+__device__ __forceinline__ NodeRec load_node(const float4* __restrict__ nodes, uint32_t nodeIdx) {
     const float4* np = nodes + (size_t)nodeIdx * (uint32_t)NSTRIDE;
-    const float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3], n4 = np[4];
+    return NodeRec{np[0], np[1], np[2], np[3], np[4]};
+}
+
+__device__ __forceinline__ NodeResult test_node(const NodeRec& nr, float3 O, float3 rD, float tmax, uint32_t octinv4) {
+    const float4 n0 = nr.n0, n1 = nr.n1, n2 = nr.n2, n3 = nr.n3, n4 = nr.n4;
     const uint32_t ew = as_u32(n0.w);
     const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
     const float ox = (n0.x - O.x) * rD.x, oy = (n0.y - O.y) * rD.y, oz = (n0.z - O.z) * rD.z;
@@ -71,6 +76,12 @@ __device__ __forceinline__ NodeResult visit_node(const float4* __restrict__ node
     NodeResult r;
     r.childBase = as_u32(n1.x); r.triBase = as_u32(n1.y); r.hitmask = hitmask; r.imask = ew >> 24;
     return r;
+}
+
+template <int NSTRIDE = 5>
+__device__ __forceinline__ NodeResult visit_node(const float4* __restrict__ nodes, uint32_t nodeIdx, float3 O,
+                                                 float3 rD, float tmax, uint32_t octinv4) {
+    return test_node(load_node<NSTRIDE>(nodes, nodeIdx), O, rD, tmax, octinv4);
 }
 
 // Same test with the 48 plane FMAs issued as 24 v_pk_fma_f32 (two children per instruction,
@@ -142,7 +153,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
     bool lockstep = ADAPT;                          // ADAPT only; wave-uniform
     uint32_t genIters = 0, genActive = 0, ema = 0;  // ADAPT only; wave-uniform
-    unsigned long long sIter = 0, sActive = 0, sNode = 0, sTriIter = 0, sTri = 0, sRefill = 0, sRefilled = 0;  // STATS only
+    unsigned long long sIter = 0, sActive = 0, sNode = 0, sTriIter = 0, sTri = 0, sRefill = 0, sRefilled = 0, sNodeIter = 0, sNodeUni = 0, sNodeLanes = 0;  // STATS only
 
     for (;;) {
         // ---- ray replacement -------------------------------------------------------------
@@ -228,6 +239,12 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
                         if (ng.y > 0x00FFFFFFu) st.push(ng);
                         const uint32_t slot = (bit - 24u) ^ oct;
                         const uint32_t rel = __popc(imask & ~(0xFFFFFFFFu << slot));
+                        if (STATS) {   // how many node-visit iterations have all their lanes on ONE node
+                            const unsigned long long m = __ballot(true);
+                            const uint32_t idx = cbase + rel, f = (uint32_t)__builtin_amdgcn_readfirstlane(idx);
+                            const bool uni = __ballot(idx != f) == 0;
+                            if (lane_rank(m) == 0) { sNodeIter++; sNodeUni += uni ? 1u : 0u; sNodeLanes += __popcll(m); }
+                        }
                         const NodeResult r = PKFMA ? visit_node_pk(nodes, cbase + rel, O, rD, hit.x, octinv4)
                                                    : visit_node<NSTRIDE>(nodes, cbase + rel, O, rD, hit.x, octinv4);
                         ng.x = r.childBase; tg.x = r.triBase;
@@ -292,7 +309,8 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     if (STATS && !ADAPT) {
         // sTriIter was counted by the first active lane of each tri iteration: reduce over the wave
         unsigned long long ti = sTriIter;
-        for (int o = 32; o > 0; o >>= 1) { ti += __shfl_xor(ti, o); sTri += __shfl_xor(sTri, o); }
+        for (int o = 32; o > 0; o >>= 1) { ti += __shfl_xor(ti, o); sTri += __shfl_xor(sTri, o); sNodeIter += __shfl_xor(sNodeIter, o); sNodeUni += __shfl_xor(sNodeUni, o); sNodeLanes += __shfl_xor(sNodeLanes, o); }
+        if (REFILL_MIN == 64) { sRefill = sNodeIter; sRefilled = sNodeUni; sNode = sNodeLanes; }   // the lockstep statistics variant reports these instead
         if (threadIdx.x == 0) {
             atomicAdd(q.stats + 0, sIter); atomicAdd(q.stats + 1, sActive); atomicAdd(q.stats + 2, sNode);
             atomicAdd(q.stats + 3, ti); atomicAdd(q.stats + 4, sTri); atomicAdd(q.stats + 5, sRefill); atomicAdd(q.stats + 6, sRefilled);
@@ -403,6 +421,7 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
         break;
     case 10: TBVH_LAUNCH(1, 8, 8, true); break;
     case 16: TBVH_LAUNCH(1, 8, 16, true, false, 1, true); break;  // packed plane FMAs
+    case 48: TBVH_LAUNCH(1, 8, 64, true, true); break;   // lockstep throughout + statistics (node-visit uniformity)
     case 44: TBVH_LAUNCH(1, 8, 64, true); break;   // lockstep throughout: a wave only takes new rays when all 64 lanes are idle
     case 45: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 64, true); break;   // adaptive (= default)
     case 47: TBVH_LAUNCH(1, 8, 16, true, false, 1, false, 64, true, 8); break;   // adaptive, nodes padded to 128 bytes (one cache line per node)
@@ -440,6 +459,6 @@ void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream
     hipLaunchKernelGGL(k_pad_nodes, dim3((nNodes * 8u + 255u) / 256u), dim3(256), 0, s, src, dst, nNodes);
 }
 
-bool cwbvh_variant_valid(int v) { return (v >= 0 && v <= 19) || (v >= 40 && v <= 47 && v != 42 && v != 43); }
+bool cwbvh_variant_valid(int v) { return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43); }
 
 }  // namespace tbvh

@@ -74,6 +74,12 @@ def main():
                 tb.lib.tbvh_debug_stats(ctx._h, st, 1)
                 tot = max(sum(int(x) for x in st), 1)
                 print(f"   [{kind}] generation cohesion histogram (<.5 .5-.6 .6-.7 .7-.75 .75-.8 .8-.85 .85-.9 >=.9): " + " ".join(f"{int(x) / tot:.3f}" for x in st), flush=True)
+            if a.variant == 48:
+                import ctypes as C
+                st = (C.c_uint64 * 8)()
+                tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+                it, act, nlanes, titer, tri, niter, nuni = [int(x) for x in st[:7]]
+                print(f"   [{kind}] lockstep: node-visit iterations {niter}, uniform {nuni} ({nuni / max(niter, 1):.3f}), lanes per node iteration {nlanes / max(niter, 1):.1f}", flush=True)
             if a.variant in (7, 9):
                 import ctypes as C
                 st = (C.c_uint64 * 8)()
