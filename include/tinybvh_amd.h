@@ -317,6 +317,22 @@ int tbvh_host_build(const void* verts16, uint64_t n_tris, int layout,
 int tbvh_host_build_tlas(void* instances192, uint64_t n_instances,
                          const float* blas_bounds6, uint64_t n_blas, tbvh_hostbvh** out);
 void     tbvh_host_free(tbvh_hostbvh* h);
+
+/* ---- blob cache: files of BVH8_CWBVH::Save / Load (tiny_bvh.h:5786-5820) ------------------------------------------
+ * The reference's file is: u32 header (sub | minor<<8 | major<<16 | layout<<24), u32 triCount, a raw dump of the C++
+ * object, the node blocks, the triangle blocks.  The object dump ties a file to one tinybvh version and C++ ABI; these
+ * two functions read and write the files of tinybvh 1.6.7 built for x86-64 (LP64), the version this library mirrors,
+ * and refuse anything else with TBVH_E_FORMAT (same checks as Load: version, layout, triangle count; plus the file
+ * length against the counts in the object dump, plus the structural validation every uploaded blob gets).
+ * A file written here loads in BVH8_CWBVH::Load and traces there; a file written by BVH8_CWBVH::Save reads here. */
+/* nodes16 / tris16: the blobs of tbvh_upload_cwbvh (bvh8Data, bvh8Tris); n_tris: BVH8_CWBVH::triCount (primitives);
+ * bounds6: min.xyz, max.xyz of the scene for the object's aabbMin / aabbMax, or NULL to use the root node's box. */
+int tbvh_cwbvh_file_write(const char* path, const void* nodes16, uint64_t n_node_blocks, const void* tris16,
+                          uint64_t n_tri_blocks, uint64_t n_tris, const float* bounds6);
+/* expected_tris: as BVH8_CWBVH::Load's expectedTris (mismatch = TBVH_E_FORMAT); 0 accepts any count.  On success *out
+ * is a host BVH of layout TBVH_LAYOUT_CWBVH holding blobs 0 (nodes) and 1 (triangles) — pass it to tbvh_upload_host —
+ * and *n_tris_out (optional) the file's triCount. */
+int tbvh_cwbvh_file_read(const char* path, uint64_t expected_tris, tbvh_hostbvh** out, uint64_t* n_tris_out);
 int      tbvh_host_layout(const tbvh_hostbvh* h);
 /* blob accessors; which = 0 nodes, 1 prim indices / triangles (layout dependent):
  *   BVH2_WALD: 0 = 32-byte nodes, 1 = primIdx (u32)

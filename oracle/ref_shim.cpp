@@ -255,4 +255,38 @@ uint64_t ref_tlas_blob(void* h, int which, const void** out) {
     *out = nullptr; return 0;
 }
 
+// ---- BVH8_CWBVH::Save / Load (tiny_bvh.h:5786-5820): the file a blob cache has to read and write -----------------
+// The file embeds a raw dump of the C++ object, so a reader needs the object's size and the offsets of the fields Load
+// uses afterwards.  out[0..15]: sizeof(BVH8_CWBVH), then the byte offsets of layout, triCount, idxCount, aabbMin, aabbMax,
+// opmapN, opmap, bvh8Data, bvh8Tris, allocatedBlocks, usedBlocks, bvh8.idxCount, ownBVH8, c_trav, hqbvhbins.
+void ref_cwbvh_object_layout(uint32_t out[16]) {
+    BVH8_CWBVH o;
+    const char* b = (const char*)&o;
+#define OFF(m) (uint32_t)((const char*)&(o.m) - b)
+    out[0] = (uint32_t)sizeof(BVH8_CWBVH);
+    out[1] = OFF(layout); out[2] = OFF(triCount); out[3] = OFF(idxCount); out[4] = OFF(aabbMin); out[5] = OFF(aabbMax);
+    out[6] = OFF(opmapN); out[7] = OFF(opmap); out[8] = OFF(bvh8Data); out[9] = OFF(bvh8Tris);
+    out[10] = OFF(allocatedBlocks); out[11] = OFF(usedBlocks); out[12] = OFF(bvh8.idxCount); out[13] = OFF(ownBVH8);
+    out[14] = OFF(c_trav); out[15] = OFF(hqbvhbins);
+#undef OFF
+}
+// the 560-byte image of a default-constructed object (flags, cost constants, ... as the reference initialises them)
+void ref_cwbvh_default_image(void* out, uint32_t bytes) {
+    BVH8_CWBVH o;
+    std::memcpy(out, (const void*)&o, bytes < sizeof o ? bytes : sizeof o);
+}
+int ref_cwbvh_save(void* h, const char* path) {
+    RefScene* s = (RefScene*)h;
+    ensureLayout(s, 9);
+    s->cw->Save(path);
+    return 0;
+}
+// BVH8_CWBVH::Load on a fresh object, then BVH8_CWBVH::Intersect over the rays.  Returns 0, or 1 if Load refused the file.
+int ref_cwbvh_load_and_intersect(const char* path, uint32_t expectedTris, void* rays, uint64_t n, uint32_t stride) {
+    BVH8_CWBVH cw;
+    if (!cw.Load(path, expectedTris)) return 1;
+    forRays(rays, n, stride, [&](Ray& r) { cw.Intersect(r); });
+    return 0;
+}
+
 }  // extern "C"

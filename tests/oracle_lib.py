@@ -128,10 +128,28 @@ class Reference:
         L.ref_tlas_free.argtypes = [_vp]; L.ref_tlas_free.restype = None
         L.ref_tlas_intersect.restype = C.c_int; L.ref_tlas_intersect.argtypes = [_vp, _vp, _u64, _u32]
         L.ref_tlas_blob.restype = _u64; L.ref_tlas_blob.argtypes = [_vp, C.c_int, C.POINTER(_vp)]
+        L.ref_cwbvh_object_layout.restype = None; L.ref_cwbvh_object_layout.argtypes = [C.POINTER(_u32)]
+        L.ref_cwbvh_default_image.restype = None; L.ref_cwbvh_default_image.argtypes = [_vp, _u32]
+        L.ref_cwbvh_save.restype = C.c_int; L.ref_cwbvh_save.argtypes = [_vp, C.c_char_p]
+        L.ref_cwbvh_load_and_intersect.restype = C.c_int; L.ref_cwbvh_load_and_intersect.argtypes = [C.c_char_p, _u32, _vp, _u64, _u32]
         assert L.ref_selfcheck() == 0, "tinybvh::Ray layout differs from the 64-byte record"
 
     def build(self, verts, hq=False, threaded=False):
         return RefScene(self, verts, hq, threaded)
+
+    def cwbvh_object_layout(self):
+        """sizeof(BVH8_CWBVH) and the offsets a Save / Load compatible file needs (ref_shim.cpp)."""
+        o = (_u32 * 16)()
+        self.lib.ref_cwbvh_object_layout(o)
+        keys = ("size", "layout", "triCount", "idxCount", "aabbMin", "aabbMax", "opmapN", "opmap", "bvh8Data", "bvh8Tris",
+                "allocatedBlocks", "usedBlocks", "bvh8.idxCount", "ownBVH8", "c_trav", "hqbvhbins")
+        return dict(zip(keys, [int(x) for x in o]))
+
+    def cwbvh_load_and_intersect(self, path, expected_tris, rays):
+        """BVH8_CWBVH::Load on a fresh object + BVH8_CWBVH::Intersect; None if Load refused the file."""
+        r = np.ascontiguousarray(rays).copy()
+        rc = self.lib.ref_cwbvh_load_and_intersect(os.fsencode(path), expected_tris, _p(r), r.shape[0], r.strides[0])
+        return None if rc else r
 
 
 class RefScene:
@@ -155,6 +173,9 @@ class RefScene:
         if not p.value or not n:
             return np.zeros((0, width), dtype)
         return np.frombuffer((C.c_char * nbytes).from_address(p.value), dtype=dtype).reshape(n, width).copy()
+
+    def cwbvh_save(self, path):
+        assert self.ref.lib.ref_cwbvh_save(self.h, os.fsencode(path)) == 0
 
     def intersect(self, layout, rays):
         r = np.ascontiguousarray(rays).copy()

@@ -10,6 +10,8 @@ from __future__ import annotations
 import ctypes as C
 from typing import Optional
 
+import os
+
 import numpy as np
 
 from . import _capi
@@ -138,6 +140,19 @@ class HostBVH:
         h = C.c_void_p()
         check(lib.tbvh_host_build(_ptr(verts), self.n_tris, layout, C.byref(bp), C.byref(h)), "tbvh_host_build")
         self._h = h
+
+    @classmethod
+    def from_cwbvh_file(cls, path: str, expected_tris: int = 0) -> "HostBVH":
+        """The blobs of a BVH8_CWBVH::Save file (tbvh_cwbvh_file_read); no BVH2 and no vertices come with it."""
+        self = cls.__new__(cls)
+        h = C.c_void_p(); n = C.c_uint64(0)
+        self._h = None
+        check(lib.tbvh_cwbvh_file_read(os.fsencode(path), expected_tris, C.byref(h), C.byref(n)), "tbvh_cwbvh_file_read")
+        self._h = h
+        self.verts = None
+        self.n_tris = int(n.value)
+        self.layout = LAYOUT_CWBVH
+        return self
 
     def blob(self, which: int, dtype, width: int) -> np.ndarray:
         """Zero-copy numpy view of blob `which` (the view keeps this object alive)."""
@@ -321,6 +336,25 @@ class BVH8_CWBVH(_Scene):
         check(lib.tbvh_convert_bvh2_device(self.ctx._h, _ptr(nodes32), nodes32.nbytes // 32, _ptr(prim_idx), prim_idx.size, _ptr(verts), verts.shape[0] // 3,
                                            0, LAYOUT_CWBVH, C.byref(self._h)), "tbvh_convert_bvh2_device")
         return self
+
+    def Save(self, path: str, n_tris: int = 0, bounds=None) -> None:
+        """BVH8_CWBVH::Save (tiny_bvh.h:5786-5795): a file BVH8_CWBVH::Load accepts.  The blobs come from the host
+        copy if this scene was built here, else they are read back from the device."""
+        host = getattr(self, "host", None)
+        if host is not None:
+            nodes, tris = host.blob(0, np.uint32, 4), host.blob(1, np.uint32, 4)
+            n_tris = n_tris or host.n_tris
+        else:
+            nodes, tris = self.download_blobs()
+        n_tris = n_tris or tris.shape[0] // 3
+        b = None if bounds is None else np.ascontiguousarray(bounds, np.float32).reshape(6)
+        check(lib.tbvh_cwbvh_file_write(os.fsencode(path), _ptr(nodes), nodes.shape[0], _ptr(tris), tris.shape[0], n_tris,
+                                        None if b is None else _ptr(b)), "tbvh_cwbvh_file_write")
+
+    def Load(self, path: str, expected_tris: int = 0) -> "BVH8_CWBVH":
+        """BVH8_CWBVH::Load (tiny_bvh.h:5797-5820) + upload: also reads files written by the reference itself."""
+        self.host = HostBVH.from_cwbvh_file(path, expected_tris)
+        return self.Upload(self.host.blob(0, np.uint32, 4), self.host.blob(1, np.uint32, 4))
 
     def Upload(self, nodes16: np.ndarray, tris16: np.ndarray) -> "BVH8_CWBVH":
         nodes16 = np.ascontiguousarray(nodes16); tris16 = np.ascontiguousarray(tris16)

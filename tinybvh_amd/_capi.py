@@ -81,6 +81,8 @@ SYMBOLS = {
     "tbvh_host_build": (_i, [_vp, _u64, _i, C.POINTER(BuildParams), _pp]),
     "tbvh_host_build_tlas": (_i, [_vp, _u64, _vp, _u64, _pp]),
     "tbvh_host_free": (None, [_vp]),
+    "tbvh_cwbvh_file_write": (_i, [C.c_char_p, _vp, _u64, _vp, _u64, _u64, _vp]),
+    "tbvh_cwbvh_file_read": (_i, [C.c_char_p, _u64, _pp, C.POINTER(_u64)]),
     "tbvh_host_layout": (_i, [_vp]),
     "tbvh_host_blob": (_vp, [_vp, _i]),
     "tbvh_host_blob_count": (_u64, [_vp, _i]),

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -1225,6 +1226,95 @@ int tbvh_host_build_tlas(void* instances192, uint64_t nInst, const float* blasBo
     BuildParams bp; bp.maxLeafTris = 1; bp.threads = 1;
     build_bvh2_boxes(boxes.data(), (uint32_t)nInst, bp, h->bvh2);
     encode_bvh_gpu(h->bvh2, h->al);
+    *out = h;
+    return 0;
+}
+
+// ---- BVH8_CWBVH::Save / Load compatible files (tiny_bvh.h:5786-5820) -----------------------------------------------
+// File: u32 header = sub | minor << 8 | major << 16 | layout << 24, u32 triCount, a raw dump of the C++ object
+// (sizeof(BVH8_CWBVH) bytes), usedBlocks x 16 bytes of nodes, idxCount x 64 bytes of triangle space (48 used per entry).
+// The object dump makes the format specific to one tinybvh version and C++ ABI: the constants below are tinybvh 1.6.7
+// built for x86-64 / LP64 (g++ and clang lay the class out identically: Itanium ABI), checked against the real header by
+// tests/test_cwbvh_file.py (oracle/ref_shim.cpp: ref_cwbvh_object_layout) and, on every read, against the file length.
+namespace {
+constexpr uint32_t kCwFileHeader = 7u | (6u << 8) | (1u << 16) | (10u << 24);   // 1.6.7, LAYOUT_CWBVH (tiny_bvh.h:92-94, 788)
+constexpr uint32_t kCwObjBytes = 560, kCwOffRefittable = 1, kCwOffLayout = 32, kCwOffTriCount = 44, kCwOffIdxCount = 48,
+                   kCwOffCTrav = 52, kCwOffCInt = 56, kCwOffBins = 64, kCwOffAabbMin = 72, kCwOffAabbMax = 84,
+                   kCwOffAllocatedBlocks = 128, kCwOffUsedBlocks = 132, kCwOffBvh8IdxCount = 184, kCwOffOwnBvh8 = 552;
+struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose(f); } };
+}  // namespace
+
+int tbvh_cwbvh_file_write(const char* path, const void* nodes16, uint64_t nNodeBlocks, const void* tris16, uint64_t nTriBlocks,
+                          uint64_t nTris, const float* bounds6) {
+    if (!path || !nodes16 || !tris16) return fail(TBVH_E_INVALID, "tbvh_cwbvh_file_write: null argument");
+    if (nNodeBlocks == 0 || nNodeBlocks % 5 || nTriBlocks % 3 || nNodeBlocks > 0xffffffffull || nTriBlocks / 3 > 0xffffffffull || nTris > 0xffffffffull)
+        return fail(TBVH_E_INVALID, "tbvh_cwbvh_file_write: node blocks must be a multiple of 5, triangle blocks of 3, counts 32-bit");
+    if (const char* e = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_write: %s", e);
+    const uint32_t idxCount = (uint32_t)(nTriBlocks / 3), usedBlocks = (uint32_t)nNodeBlocks, triCount = (uint32_t)nTris;
+    unsigned char obj[kCwObjBytes];
+    std::memset(obj, 0, sizeof obj);                 // pointers, context, the embedded MBVH<8>: all rebuilt by Load
+    obj[kCwOffRefittable] = 1;
+    auto put32 = [&](uint32_t off, uint32_t v) { std::memcpy(obj + off, &v, 4); };
+    auto putf = [&](uint32_t off, float v) { std::memcpy(obj + off, &v, 4); };
+    put32(kCwOffLayout, 10u); put32(kCwOffTriCount, triCount); put32(kCwOffIdxCount, idxCount);
+    putf(kCwOffCTrav, 1.0f); putf(kCwOffCInt, 1.0f); put32(kCwOffBins, 8u);
+    float b[6];
+    if (bounds6) std::memcpy(b, bounds6, sizeof b);
+    else {   // the root node's own box: origin + 255 quantisation steps of 2^e per axis (a superset of the true bounds)
+        const float* n0 = (const float*)nodes16;
+        uint32_t ew; std::memcpy(&ew, n0 + 3, 4);
+        for (int a = 0; a < 3; a++) { b[a] = n0[a]; b[3 + a] = n0[a] + 255.0f * std::ldexp(1.0f, (int)(int8_t)(ew >> (8 * a))); }
+    }
+    for (int a = 0; a < 3; a++) { putf(kCwOffAabbMin + 4 * a, b[a]); putf(kCwOffAabbMax + 4 * a, b[3 + a]); }
+    put32(kCwOffAllocatedBlocks, usedBlocks); put32(kCwOffUsedBlocks, usedBlocks); put32(kCwOffBvh8IdxCount, idxCount);
+    obj[kCwOffOwnBvh8] = 1;
+    FileCloser fc{fopen(path, "wb")};
+    if (!fc.f) return fail(TBVH_E_INVALID, "tbvh_cwbvh_file_write: cannot open %s", path);
+    const uint32_t head[2] = {kCwFileHeader, triCount};
+    bool ok = fwrite(head, 4, 2, fc.f) == 2 && fwrite(obj, 1, sizeof obj, fc.f) == sizeof obj &&
+              fwrite(nodes16, 16, usedBlocks, fc.f) == usedBlocks;
+    // the reference writes idxCount x 4 blocks of triangle space, of which 3 per entry are used (uncompressed triangles)
+    ok = ok && fwrite(tris16, 16, (size_t)idxCount * 3, fc.f) == (size_t)idxCount * 3;
+    const std::vector<unsigned char> pad(1 << 16, 0);
+    for (uint64_t left = (uint64_t)idxCount * 16; ok && left;) {
+        const size_t k = (size_t)(left < pad.size() ? left : pad.size());
+        ok = fwrite(pad.data(), 1, k, fc.f) == k; left -= k;
+    }
+    if (!ok) return fail(TBVH_E_INVALID, "tbvh_cwbvh_file_write: short write to %s", path);
+    return 0;
+}
+
+int tbvh_cwbvh_file_read(const char* path, uint64_t expectedTris, tbvh_hostbvh** out, uint64_t* nTrisOut) {
+    if (!path || !out) return fail(TBVH_E_INVALID, "tbvh_cwbvh_file_read: null argument");
+    FileCloser fc{fopen(path, "rb")};
+    if (!fc.f) return fail(TBVH_E_INVALID, "tbvh_cwbvh_file_read: cannot open %s", path);
+    uint32_t head[2];
+    unsigned char obj[kCwObjBytes];
+    if (fread(head, 4, 2, fc.f) != 2 || fread(obj, 1, sizeof obj, fc.f) != sizeof obj) return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_read: %s is too short", path);
+    // the checks of BVH8_CWBVH::Load (tiny_bvh.h:5806-5812): version, layout, triangle count
+    if (head[0] != kCwFileHeader)
+        return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_read: header %08x is not tinybvh 1.6.7 / LAYOUT_CWBVH (%08x)", head[0], kCwFileHeader);
+    if (expectedTris && head[1] != expectedTris) return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_read: file holds %u triangles, expected %llu", head[1], (unsigned long long)expectedTris);
+    uint32_t usedBlocks, idxCount;
+    std::memcpy(&usedBlocks, obj + kCwOffUsedBlocks, 4); std::memcpy(&idxCount, obj + kCwOffBvh8IdxCount, 4);
+    if (fseek(fc.f, 0, SEEK_END)) return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_read: cannot seek in %s", path);
+    const long long len = ftell(fc.f);
+    const long long want = 8ll + kCwObjBytes + (long long)usedBlocks * 16 + (long long)idxCount * 64;
+    if (len != want || usedBlocks == 0 || usedBlocks % 5)
+        return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_read: %s: length %lld does not match the object dump (usedBlocks %u, idxCount %u): "
+                                   "written by a build with a different object layout?", path, len, usedBlocks, idxCount);
+    if (fseek(fc.f, 8 + kCwObjBytes, SEEK_SET)) return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_read: cannot seek in %s", path);
+    tbvh_hostbvh* h = new (std::nothrow) tbvh_hostbvh;
+    if (!h) return fail(TBVH_E_NOMEM, "out of host memory");
+    h->layout = TBVH_LAYOUT_CWBVH;
+    try {
+        h->blocksA.resize(usedBlocks); h->blocksB.resize((size_t)idxCount * 3);
+    } catch (const std::bad_alloc&) { delete h; return fail(TBVH_E_NOMEM, "out of host memory"); }
+    if (fread(h->blocksA.data(), 16, usedBlocks, fc.f) != usedBlocks || fread(h->blocksB.data(), 16, (size_t)idxCount * 3, fc.f) != (size_t)idxCount * 3) {
+        delete h; return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_read: short read from %s", path);
+    }
+    if (const char* e = validate_cwbvh(h->blocksA.data(), usedBlocks / 5, (uint64_t)idxCount * 3)) { delete h; return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_read: %s", e); }
+    if (nTrisOut) *nTrisOut = head[1];
     *out = h;
     return 0;
 }
