@@ -253,9 +253,11 @@ int tbvh_generate_shadow_device(tbvh_context* ctx, const void* d_in_rays64,
  * device-resident wavefront path tracer — the frame loop of tiny_bvh_gpu.cpp:128-158 over
  * wavefront.cl:52-287 (Generate, { Extend, Shade } x depth, Connect, accumulate) with every
  * queue and counter on the device: one host call enqueues a whole frame, nothing is read back
- * unless `stats` is requested.  Extend / Connect are the traversal kernels above; shading is
- * deliberately small (Lambert, albedo = RGB8 packed in v0.w of the hit triangle or 70 % grey,
- * one point light with next-event estimation, two-colour sky, cosine-weighted bounces).
+ * unless `stats` is requested.  Extend / Connect are the traversal kernels above; Shade follows
+ * wavefront.cl:127-246: the material of a triangle is v0.w of its first vertex = type << 24 | RGB8 (type 0 diffuse,
+ * 1 = MATERIAL_LIGHT, 2 = MATERIAL_SPECULAR; RGB 0 = 70 % grey), next-event estimation towards a rectangular light
+ * with multiple importance sampling, postponed BRDF pdf, the reference's path flags.  Extensions: light_size 0 = point
+ * light, a two-colour sky, any number of diffuse bounces unless TBVH_WF_ONE_DIFFUSE_BOUNCE.
  * ---------------------------------------------------------------------------------- */
 typedef struct tbvh_wavefront tbvh_wavefront;
 typedef struct tbvh_wf_params {
@@ -264,7 +266,14 @@ typedef struct tbvh_wf_params {
     uint32_t max_depth;   /* path segments per pixel (0 = 3, the reference's bounce count)  */
     uint32_t seed;        /* per-frame RNG seed                                             */
     uint32_t clear;       /* non-zero: zero the accumulator first                           */
+    float light_size[2];  /* extent of the rectangular light along x and z, centred at light_pos, facing down
+                             (wavefront.cl:208: 9 x 5); 0, 0 = point light                   */
+    uint32_t flags;       /* TBVH_WF_*                                                      */
 } tbvh_wf_params;
+#define TBVH_WF_ONE_DIFFUSE_BOUNCE 1u /* a path ends at its second diffuse vertex, as in wavefront.cl:233 */
+#define TBVH_MATERIAL_DIFFUSE  0u     /* v0.w of a triangle's first vertex: type << 24 | 0xRRGGBB (wavefront.cl:12-13, 160) */
+#define TBVH_MATERIAL_LIGHT    1u
+#define TBVH_MATERIAL_SPECULAR 2u
 typedef struct tbvh_wf_stats {
     uint64_t extend_rays[8];  /* nearest-hit rays traced at depth d                         */
     uint64_t shadow_rays[8];  /* any-hit rays traced after depth d                          */
@@ -278,6 +287,8 @@ int  tbvh_wavefront_render(tbvh_wavefront* wf, tbvh_scene* scene, const void* d_
                            const tbvh_wf_params* params, tbvh_wf_stats* stats);
 /* copy the float RGBA accumulator (width * height * 4 floats, row-major) to the host */
 int  tbvh_wavefront_read(tbvh_wavefront* wf, float* rgba);
+/* Finalize (wavefront.cl:275-286): accumulator * scale, square root, 8 bits per channel: width * height x 0x00RRGGBB */
+int  tbvh_wavefront_finalize(tbvh_wavefront* wf, float scale, uint32_t* pixels);
 
 /* ------------------------------------------------------------------------------------
  * device buffers — replace tinyocl::Buffer for callers that keep rays resident

@@ -100,3 +100,136 @@ def test_multi_bounce_bookkeeping(ctx):
     b = wf.read()
     assert 1.8 < b[..., :3].mean() / a[..., :3].mean() < 2.2
     wf.close(); ctx.free(d_verts)
+
+
+# ---- materials (wavefront.cl:127-246): v0.w of a triangle's first vertex = type << 24 | RGB8 ------------------------
+
+def quad(p0, du, dv, material):
+    """Two triangles p0, p0+du, p0+du+dv / p0, p0+du+dv, p0+dv with the material word in v0.w of each."""
+    p0, du, dv = (np.asarray(x, np.float32) for x in (p0, du, dv))
+    v = np.zeros((6, 4), np.float32)
+    v[0, :3], v[1, :3], v[2, :3] = p0, p0 + du, p0 + du + dv
+    v[3, :3], v[4, :3], v[5, :3] = p0, p0 + du + dv, p0 + dv
+    w = np.frombuffer(np.array([material], np.uint32).tobytes(), np.float32)[0]
+    v[0, 3] = w; v[3, 3] = w
+    return v
+
+
+def down_camera(eye, half, W, H):
+    """A pinhole at `eye` looking straight down at a (2 half)^2 patch one unit below it."""
+    cam = tb.Camera()
+    e = np.asarray(eye, np.float32)
+    cam.eye[:] = [float(x) for x in e]
+    cam.p1[:] = [float(e[0] - half), float(e[1] - 1), float(e[2] - half)]
+    cam.p2[:] = [float(e[0] + half), float(e[1] - 1), float(e[2] - half)]
+    cam.p3[:] = [float(e[0] - half), float(e[1] - 1), float(e[2] + half)]
+    cam.width, cam.height, cam.spp_x, cam.spp_y = W, H, 1, 1
+    return cam
+
+
+def setup(ctx, verts, W, H):
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    d = ctx.malloc(verts.nbytes); ctx.to_device(d, verts)
+    return sc, d, tb.Wavefront(ctx, W, H)
+
+
+def test_emitter_seen_from_the_camera_and_finalize(ctx):
+    """A MATERIAL_LIGHT triangle ends the path with T * lightColor (camera paths carry PATH_LAST_SPECULAR: no MIS)."""
+    W = H = 64
+    verts = quad((-50, 0, -50), (100, 0, 0), (0, 0, 100), (tb.MATERIAL_LIGHT << 24) | 0xFFFFFF)
+    sc, d, wf = setup(ctx, verts, W, H)
+    st = wf.render(sc, d, down_camera((0, 5, 0), 0.2, W, H), (0, 9, 0), (0.25, 0.5, 1.0), sky_lo=(0, 0, 0), sky_hi=(0, 0, 0), max_depth=3, light_size=(9, 5))
+    img = wf.read()[..., :3]
+    assert np.allclose(img, np.array([0.25, 0.5, 1.0], np.float32)[None, None, :], rtol=1e-6)
+    assert st["extend_rays"] == [W * H, 0, 0] and st["shadow_rays"] == [0, 0, 0]      # the path ends there
+    px = wf.finalize(1.0)
+    assert px.shape == (H, W) and (px == ((127 << 16) | (180 << 8) | 255)).all()       # sqrt(0.25), sqrt(0.5), 1 -> 8 bit
+    wf.close(); ctx.free(d)
+
+
+def test_mirror_reflects_the_sky(ctx):
+    """MATERIAL_SPECULAR: R = D - 2 N (N.D), throughput * colour, no shadow rays; the reflected ray leaves the scene
+    and picks the sky colour of its direction."""
+    W = H = 64
+    verts = quad((-50, 0, -50), (100, 0, 0), (0, 0, 100), (tb.MATERIAL_SPECULAR << 24) | 0x8040FF)
+    sc, d, wf = setup(ctx, verts, W, H)
+    eye, view = (0.0, 3.0, -6.0), (0.0, -0.5, 1.0)
+    cam = R.camera(eye, view, W, H, 1, 1)
+    lo, hi = (0.9, 0.5, 0.1), (0.1, 0.3, 0.8)
+    st = wf.render(sc, d, cam, (0, 9, 0), (1, 1, 1), sky_lo=lo, sky_hi=hi, max_depth=3, seed=2)
+    img = wf.read()[..., :3].reshape(-1, 3).astype(np.float64)
+    assert st["shadow_rays"] == [0, 0, 0]
+    # host: the same jittered primary rays, reflected about +y
+    n = W * H
+    with np.errstate(over="ignore"):
+        i = np.arange(n, dtype=np.uint32)
+        s = wang(np.uint32(2) * np.uint32(9781) + i * np.uint32(6271) + np.uint32(1)); s = np.where(s == 0, np.uint32(1), s)
+        s = xorshift(s); r0 = (s >> np.uint32(8)).astype(np.float32) * np.float32(1 / 16777216)
+        s = xorshift(s); r1 = (s >> np.uint32(8)).astype(np.float32) * np.float32(1 / 16777216)
+    in_tile = i & 15; tile = i >> 4; tiles_x = W // 4
+    px = (tile % tiles_x) * 4 + (in_tile & 3); py = (tile // tiles_x) * 4 + (in_tile >> 2)
+    u = (px.astype(np.float32) + r0) / np.float32(W); v = (py.astype(np.float32) + r1) / np.float32(H)
+    e = np.array(cam.eye, np.float32); p1 = np.array(cam.p1, np.float32); p2 = np.array(cam.p2, np.float32); p3 = np.array(cam.p3, np.float32)
+    D = p1 + u[:, None] * (p2 - p1) + v[:, None] * (p3 - p1) - e
+    D = D / np.linalg.norm(D, axis=1, keepdims=True)
+    hits_floor = D[:, 1] < 0
+    t = -e[1] / np.where(hits_floor, D[:, 1], -1.0)
+    P = e + t[:, None] * D
+    hits_floor &= (np.abs(P[:, 0]) < 50) & (np.abs(P[:, 2]) < 50)
+    Ry = np.where(hits_floor, -D[:, 1], D[:, 1])                                          # mirror about the floor, else straight to the sky
+    k = 0.5 * (Ry + 1.0)
+    sky = np.array(lo)[None, :] + k[:, None] * (np.array(hi) - np.array(lo))[None, :]
+    col = np.array([0x80, 0x40, 0xFF], np.float64) * 0.00392
+    want = np.where(hits_floor[:, None], sky * col[None, :], sky)
+    ref = np.zeros((n, 3)); np.add.at(ref, (py * W + px).astype(np.int64), want)
+    assert np.abs(img - ref).max() < 2e-4
+    assert st["extend_rays"][:2] == [n, int(hits_floor.sum())] and st["extend_rays"][2] == 0
+    wf.close(); ctx.free(d)
+
+
+def test_area_light_with_mis_matches_the_irradiance_integral(ctx):
+    """A diffuse floor under the reference's 9 x 5 rectangular light (wavefront.cl:208), light sampling + BSDF sampling
+    combined by MIS: the radiance leaving the point below the light's centre is albedo / pi * E with
+    E = Le * integral cos cos' / d^2 dA over the rectangle (direct light only: one plane, black sky)."""
+    W = H = 128
+    hgt, sx, sz, Le, rho = 4.0, 9.0, 5.0, np.array([6.0, 5.0, 4.0]), np.array([0xC0, 0xC0, 0x60]) * 0.00392
+    floor = quad((-60, 0, -60), (120, 0, 0), (0, 0, 120), (tb.MATERIAL_DIFFUSE << 24) | 0xC0C060)
+    # the emitter faces down: same rectangle the light sampling assumes, centred at light_pos
+    lamp = quad((-sx / 2, hgt, -sz / 2), (0, 0, sz), (sx, 0, 0), (tb.MATERIAL_LIGHT << 24) | 0xFFFFFF)
+    verts = np.concatenate([floor, lamp])
+    sc, d, wf = setup(ctx, verts, W, H)
+    cam = down_camera((0.0, 1.0, 0.0), 0.02, W, H)             # under the lamp, looking at the floor around the origin
+    frames = 24
+    for f in range(frames):
+        wf.render(sc, d, cam, (0, hgt, 0), tuple(Le), sky_lo=(0, 0, 0), sky_hi=(0, 0, 0), eps=1e-3, max_depth=2, seed=11 + f, clear=(f == 0),
+                  light_size=(sx, sz), stats=False)
+    got = wf.read()[..., :3].reshape(-1, 3).astype(np.float64).mean(0) / frames
+    # quadrature of the irradiance integral at the origin
+    m = 600
+    xs = (np.arange(m) + 0.5) / m * sx - sx / 2; zs = (np.arange(m) + 0.5) / m * sz - sz / 2
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    d2 = X * X + Z * Z + hgt * hgt
+    E = (hgt * hgt / (d2 * d2)).sum() * (sx / m) * (sz / m)    # cos = cos' = h / d
+    want = rho / np.pi * Le * E
+    assert np.all(np.abs(got - want) < 0.02 * want), (got, want)
+    # light sampling alone (no bounce rays, so the BSDF-sampled half of the MIS pair is missing) must come out darker,
+    # by what the bounce rays that reach the lamp carry: the two strategies really are weighted against each other
+    wf.render(sc, d, cam, (0, hgt, 0), tuple(Le), sky_lo=(0, 0, 0), sky_hi=(0, 0, 0), eps=1e-3, max_depth=1, seed=5, light_size=(sx, sz), stats=False)
+    nee_only = wf.read()[..., :3].reshape(-1, 3).astype(np.float64).mean(0)
+    assert np.all(nee_only < 0.9 * want) and np.all(nee_only > 0.2 * want)
+    wf.close(); ctx.free(d)
+
+
+def test_one_diffuse_bounce_flag_is_the_references_path_length(ctx):
+    """TBVH_WF_ONE_DIFFUSE_BOUNCE: a path ends at its second diffuse vertex (wavefront.cl:233), so an all-diffuse scene
+    traces primary rays and one generation of bounce rays however large max_depth is."""
+    verts = scenes.atrium(40_000, seed=1)
+    W, H = 256, 128
+    sc, d, wf = setup(ctx, verts, W, H)
+    cam = R.camera(*scenes.SPONZA_CAMERAS[1], W, H, 1, 1)
+    a = wf.render(sc, d, cam, (0.0, 24.0, 0.0), (300.0, 300.0, 300.0), max_depth=4, seed=3)
+    b = wf.render(sc, d, cam, (0.0, 24.0, 0.0), (300.0, 300.0, 300.0), max_depth=4, seed=3, one_diffuse_bounce=True)
+    assert a["extend_rays"][2] > 0 and a["extend_rays"][3] > 0
+    assert b["extend_rays"][:2] == a["extend_rays"][:2] and b["extend_rays"][2:] == [0, 0]
+    assert b["shadow_rays"][:2] == a["shadow_rays"][:2] and b["shadow_rays"][2:] == [0, 0]
+    wf.close(); ctx.free(d)

@@ -21,6 +21,8 @@ LAYOUT_BVH2_WALD = 1
 LAYOUT_BVH_GPU = 4
 LAYOUT_BVH4_GPU = 6
 LAYOUT_CWBVH = 9
+# wavefront materials: v0.w of a triangle's first vertex = type << 24 | 0xRRGGBB (wavefront.cl:12-13, 160)
+MATERIAL_DIFFUSE, MATERIAL_LIGHT, MATERIAL_SPECULAR = 0, 1, 2
 
 BVH_FAR = np.float32(1e30)
 
@@ -483,11 +485,13 @@ class Wavefront:
         self._h = h
 
     def render(self, scene: _Scene, d_verts: int, cam: Camera, light_pos, light_color=(1.0, 1.0, 1.0), sky_lo=(0.6, 0.7, 0.8), sky_hi=(0.2, 0.4, 0.9),
-               eps: float = 1e-3, max_depth: int = 3, seed: int = 1, clear: bool = True, stats: bool = True):
+               eps: float = 1e-3, max_depth: int = 3, seed: int = 1, clear: bool = True, stats: bool = True,
+               light_size=(0.0, 0.0), one_diffuse_bounce: bool = False):
         p = _capi.WfParams()
         p.light_pos[:] = [float(x) for x in light_pos]; p.light_color[:] = [float(x) for x in light_color]
         p.sky_lo[:] = [float(x) for x in sky_lo]; p.sky_hi[:] = [float(x) for x in sky_hi]
         p.eps, p.max_depth, p.seed, p.clear = float(eps), int(max_depth), int(seed), int(clear)
+        p.light_size[:] = [float(x) for x in light_size]; p.flags = 1 if one_diffuse_bounce else 0
         st = _capi.WfStats()
         check(lib.tbvh_wavefront_render(self._h, scene._h, C.c_void_p(d_verts), C.byref(cam), C.byref(p), C.byref(st) if stats else None), "tbvh_wavefront_render")
         if not stats:
@@ -498,6 +502,12 @@ class Wavefront:
         img = np.zeros((self.height, self.width, 4), np.float32)
         check(lib.tbvh_wavefront_read(self._h, _ptr(img)), "tbvh_wavefront_read")
         return img
+
+    def finalize(self, scale: float = 1.0) -> np.ndarray:
+        """Finalize of wavefront.cl:275-286: (height, width) uint32 0x00RRGGBB."""
+        px = np.zeros((self.height, self.width), np.uint32)
+        check(lib.tbvh_wavefront_finalize(self._h, float(scale), _ptr(px)), "tbvh_wavefront_finalize")
+        return px
 
     def close(self):
         if self._h and self.ctx._h:

@@ -28,7 +28,7 @@ class Camera(C.Structure):
 
 class WfParams(C.Structure):
     _fields_ = [("light_pos", C.c_float * 3), ("light_color", C.c_float * 3), ("sky_lo", C.c_float * 3), ("sky_hi", C.c_float * 3),
-                ("eps", C.c_float), ("max_depth", _u32), ("seed", _u32), ("clear", _u32)]
+                ("eps", C.c_float), ("max_depth", _u32), ("seed", _u32), ("clear", _u32), ("light_size", C.c_float * 2), ("flags", _u32)]
 
 
 class WfStats(C.Structure):
@@ -40,6 +40,7 @@ SYMBOLS = {
     "tbvh_wavefront_destroy": (None, [_vp]),
     "tbvh_wavefront_render": (_i, [_vp, _vp, _vp, C.POINTER(Camera), C.POINTER(WfParams), C.POINTER(WfStats)]),
     "tbvh_wavefront_read": (_i, [_vp, _vp]),
+    "tbvh_wavefront_finalize": (_i, [_vp, C.c_float, _vp]),
     "tbvh_abi_version": (_i, []),
     "tbvh_last_error": (C.c_char_p, []),
     "tbvh_device_count": (_i, []),

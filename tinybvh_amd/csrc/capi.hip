@@ -1108,6 +1108,7 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
         a.shadow = w->shadow; a.shadowAux = w->shadowAux; a.nShadow = QC(2);
         a.verts = (const float4*)dVerts; a.accum = w->accum;
         memcpy(a.lightPos, p->light_pos, 12); memcpy(a.lightColor, p->light_color, 12); memcpy(a.skyLo, p->sky_lo, 12); memcpy(a.skyHi, p->sky_hi, 12);
+        a.lightSize[0] = p->light_size[0]; a.lightSize[1] = p->light_size[1]; a.flags = p->flags;
         a.eps = p->eps; a.depth = d; a.maxDepth = maxDepth; a.seed = p->seed;
         launch_wf_shade(a, w->n, st);
         // Connect: any-hit over the shadow queue, then add what is unoccluded
@@ -1135,6 +1136,17 @@ int tbvh_wavefront_read(tbvh_wavefront* w, float* rgba) {
     if (!w || !rgba) return fail(TBVH_E_INVALID, "tbvh_wavefront_read: null argument");
     if (int r = setDevice(w->ctx)) return r;
     HIP_TRY(hipMemcpyAsync(rgba, w->accum, w->n * 16, hipMemcpyDeviceToHost, w->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+    return 0;
+}
+
+int tbvh_wavefront_finalize(tbvh_wavefront* w, float scale, uint32_t* pixels) {
+    if (!w || !pixels) return fail(TBVH_E_INVALID, "tbvh_wavefront_finalize: null argument");
+    if (int r = setDevice(w->ctx)) return r;
+    uint32_t* d = (uint32_t*)w->shadow;   // 4 bytes per pixel in the shadow-ray buffer (64 bytes per pixel, idle between frames)
+    launch_wf_finalize(w->accum, scale, d, w->n, w->ctx->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(pixels, d, w->n * 4, hipMemcpyDeviceToHost, w->ctx->stream));
     HIP_TRY(hipStreamSynchronize(w->ctx->stream));
     return 0;
 }

@@ -61,17 +61,19 @@ void launch_reset_hits(RayRec* rays, uint64_t n, float tmax, hipStream_t s);
 void launch_gen_shadow(const RayRec* in, RayRec* out, uint64_t n, float lx, float ly, float lz, float eps, hipStream_t s);
 
 // wavefront path tracer stages (kernels_wavefront.hip)
-struct PathAux { float T[3]; uint32_t pixel; };   // throughput (or pending contribution) + pixel index, 16 bytes
+struct PathAux { float T[3]; uint32_t pixel; };   // throughput + pixel << 8 | depth << 4 | path flags (paths), or pending contribution + pixel (shadow rays); 16 bytes
 struct ShadeArgs {
     const RayRec* in; const PathAux* auxIn; const unsigned long long* nIn;
     RayRec* out; PathAux* auxOut; unsigned long long* nOut;
     RayRec* shadow; PathAux* shadowAux; unsigned long long* nShadow;
     const float4* verts; float* accum;
     float lightPos[3], lightColor[3], skyLo[3], skyHi[3];
-    float eps; uint32_t depth, maxDepth, seed;
+    float lightSize[2];   // extent of the rectangular light along x and z (0, 0 = point light)
+    float eps; uint32_t depth, maxDepth, seed, flags;   // flags bit 0: at most one diffuse bounce per path (wavefront.cl:233)
 };
 void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint64_t n, uint32_t seed, hipStream_t s);
 void launch_wf_shade(const ShadeArgs& a, uint64_t capacity, hipStream_t s);
+void launch_wf_finalize(const float* accum, float scale, uint32_t* pixels, uint64_t n, hipStream_t s);
 void launch_wf_connect(const uint8_t* occ, const PathAux* aux, const unsigned long long* nShadow, float* accum, uint64_t capacity, hipStream_t s);
 
 }  // namespace tbvh

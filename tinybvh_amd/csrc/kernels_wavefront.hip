@@ -9,11 +9,18 @@
 // pixel.  Queue sizes never visit the host: the traversal kernels read their batch size from
 // device memory (QueryArgs::nRaysDev).
 //
-// Shading is deliberately small (this repository accelerates traversal, not materials):
-// Lambert surfaces with the albedo packed as RGB8 in v0.w of the hit triangle
-// (rgb32_to_vec3(as_uint(v0.w)), wavefront.cl:160/202; 0 = 70 % grey), one point light with
-// next-event estimation, a two-colour sky on a miss, cosine-weighted bounces
-// (tools.cl:31-39), RNG = WangHash + xorshift32 (tools.cl:9-11).
+// Shading follows wavefront.cl:127-246: the material of a triangle lives in v0.w of its first vertex —
+// type << 24 | RGB8, type 0 diffuse (Lambert), 1 = MATERIAL_LIGHT (emits lightColor, ends the path), 2 = MATERIAL_SPECULAR
+// (pure mirror) — next-event estimation towards a rectangular light in the xz-plane with the reference's solid-angle pdf
+// and MIS against the BRDF pdf, the BRDF pdf of a bounce is "postponed" to the next vertex (carried in D.w of the ray
+// record, as PathState::T.w does there), path flags PATH_LAST_SPECULAR / PATH_VIA_DIFFUSE packed with pixel and depth
+// exactly like PathState::O.w (pixel << 8 | depth << 4 | flags).  Where the .cl file slips, the intent is followed, not
+// the letter: a path that leaves the scene is weighted by 1 / pdf like every other vertex (wavefront.cl:151-156 adds the
+// sky before the division), the light pdf of a BSDF-sampled light hit uses the hit distance (it reads D.w, which nothing
+// ever writes: 1e30), cosine-weighted bounces use Malley's construction (tools.cl:34-39 feeds a half sphere into
+// normalize(N + R)).  Extensions kept from the first version: RGB 0 means 70 % grey (scenes without materials), a light of
+// size 0 is a point light (no MIS), a two-colour sky, any number of diffuse bounces unless TBVH_WF_ONE_DIFFUSE_BOUNCE asks
+// for the reference's single one.  RNG = WangHash + xorshift32 (tools.cl:9-11).
 #include "device_common.h"
 #include "kernels.h"
 #include "ray_pool.h"
@@ -33,9 +40,13 @@ __device__ __forceinline__ float3 norm3(float3 a) {
     const float r = l == 0 ? 0.f : 1.0f / l;
     return make_float3(a.x * r, a.y * r, a.z * r);
 }
-__device__ __forceinline__ void put_ray(RayRec* r, float3 O, float3 D, float tmax) {
+constexpr uint32_t kPathLastSpecular = 1u, kPathViaDiffuse = 2u;   // wavefront.cl:9-10
+constexpr uint32_t kMaterialLight = 1u, kMaterialSpecular = 2u;    // wavefront.cl:12-13
+// pdf: the postponed BRDF pdf of the bounce that made this ray (PathState::T.w); D.w of the 64-byte record is free
+// (tinybvh::Ray::instIdx, only used inside the reference's CPU TLAS traversal)
+__device__ __forceinline__ void put_ray(RayRec* r, float3 O, float3 D, float tmax, float pdf = 1.0f) {
     r->O = make_float4(O.x, O.y, O.z, as_f32(0xFFFFu));
-    r->D = make_float4(D.x, D.y, D.z, 0.f);
+    r->D = make_float4(D.x, D.y, D.z, pdf);
     r->rD = make_float4(safercp_w(D.x), safercp_w(D.y), safercp_w(D.z), 0.f);
     r->hit = make_float4(tmax, 0.f, 0.f, 0.f);
 }
@@ -76,9 +87,9 @@ __global__ void k_wf_generate(CameraArgs cam, RayRec* __restrict__ rays, PathAux
     const float3 P = make_float3(cam.p1[0] + u * (cam.p2[0] - cam.p1[0]) + v * (cam.p3[0] - cam.p1[0]),
                                  cam.p1[1] + u * (cam.p2[1] - cam.p1[1]) + v * (cam.p3[1] - cam.p1[1]),
                                  cam.p1[2] + u * (cam.p2[2] - cam.p1[2]) + v * (cam.p3[2] - cam.p1[2]));
-    put_ray(rays + i, eye, norm3(make_float3(P.x - eye.x, P.y - eye.y, P.z - eye.z)), kFar);
+    put_ray(rays + i, eye, norm3(make_float3(P.x - eye.x, P.y - eye.y, P.z - eye.z)), kFar, 1.0f);
     aux[i].T[0] = aux[i].T[1] = aux[i].T[2] = 1.0f;
-    aux[i].pixel = py * cam.width + px;
+    aux[i].pixel = ((py * cam.width + px) << 8) | kPathLastSpecular;   // wavefront.cl:88
 }
 
 __global__ __launch_bounds__(kShadeBlock) void k_wf_shade(ShadeArgs a) {
@@ -88,61 +99,103 @@ __global__ __launch_bounds__(kShadeBlock) void k_wf_shade(ShadeArgs a) {
     const bool live = i < n;
     bool wantBounce = false, wantShadow = false;
     float3 I = make_float3(0, 0, 0), N = I, R = I, L = I, T = I, contrib = I;
-    float ldist = 0;
-    uint32_t pixel = 0;
+    float ldist = 0, newPdf = 1.0f;
+    uint32_t pixel = 0, newFlags = 0;
     if (live) {
         const RayRec r = a.in[i];
         const PathAux ax = a.auxIn[i];
-        pixel = ax.pixel;
+        pixel = ax.pixel >> 8;
+        const uint32_t flags = ax.pixel & 15u;
         T = make_float3(ax.T[0], ax.T[1], ax.T[2]);
+        const float brdfPdf = r.D.w;                       // postponed pdf of the bounce that led here (1 for camera / mirror)
+        const float ipdf = brdfPdf > 0 ? 1.0f / brdfPdf : 0.f;
         const float3 O = xyz(r.O), D = xyz(r.D);
+        const bool areaLight = a.lightSize[0] > 0 && a.lightSize[1] > 0;
+        const float lightArea = a.lightSize[0] * a.lightSize[1];
         if (!(r.hit.x < kFar)) {
-            // miss: sky = lerp(horizon, zenith) by D.y
+            // end path on sky (wavefront.cl:151-156): lerp(horizon, zenith) by D.y
             const float k = 0.5f * (D.y + 1.0f);
             const float3 sky = make_float3(a.skyLo[0] + k * (a.skyHi[0] - a.skyLo[0]), a.skyLo[1] + k * (a.skyHi[1] - a.skyLo[1]), a.skyLo[2] + k * (a.skyHi[2] - a.skyLo[2]));
-            atomicAdd(&a.accum[pixel * 4 + 0], T.x * sky.x); atomicAdd(&a.accum[pixel * 4 + 1], T.y * sky.y); atomicAdd(&a.accum[pixel * 4 + 2], T.z * sky.z);
+            atomicAdd(&a.accum[pixel * 4 + 0], T.x * ipdf * sky.x); atomicAdd(&a.accum[pixel * 4 + 1], T.y * ipdf * sky.y); atomicAdd(&a.accum[pixel * 4 + 2], T.z * ipdf * sky.z);
         } else {
             const uint32_t prim = as_u32(r.hit.w);
             const float4 v0 = a.verts[(uint64_t)prim * 3], v1 = a.verts[(uint64_t)prim * 3 + 1], v2 = a.verts[(uint64_t)prim * 3 + 2];
-            const float3 e1 = make_float3(v1.x - v0.x, v1.y - v0.y, v1.z - v0.z), e2 = make_float3(v2.x - v0.x, v2.y - v0.y, v2.z - v0.z);
-            N = norm3(make_float3(e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x));
-            if (N.x * D.x + N.y * D.y + N.z * D.z > 0) N = make_float3(-N.x, -N.y, -N.z);
-            I = make_float3(O.x + r.hit.x * D.x, O.y + r.hit.x * D.y, O.z + r.hit.x * D.z);
-            const uint32_t c = as_u32(v0.w);
-            const float3 albedo = c ? make_float3((float)((c >> 16) & 255) * 0.00392f, (float)((c >> 8) & 255) * 0.00392f, (float)(c & 255) * 0.00392f)
-                                    : make_float3(0.7f, 0.7f, 0.7f);
-            uint32_t s = wang(a.seed * 7919u + pixel * 2699u + a.depth * 104729u + 17u);
-            if (!s) s = 1;
-            // next-event estimation toward the point light
-            L = make_float3(a.lightPos[0] - I.x, a.lightPos[1] - I.y, a.lightPos[2] - I.z);
-            ldist = sqrtf(L.x * L.x + L.y * L.y + L.z * L.z);
-            const float il = ldist > 0 ? 1.0f / ldist : 0.f;
-            L = make_float3(L.x * il, L.y * il, L.z * il);
-            const float ndl = N.x * L.x + N.y * L.y + N.z * L.z;
-            if (ndl > 0 && ldist > 2.0f * a.eps) {
-                const float g = ndl * il * il * 0.31830988f;   // albedo/pi * cos / d^2
-                contrib = make_float3(T.x * albedo.x * a.lightColor[0] * g, T.y * albedo.y * a.lightColor[1] * g, T.z * albedo.z * a.lightColor[2] * g);
-                wantShadow = true;
-            }
-            if (a.depth + 1 < a.maxDepth) {
-                // cosine-weighted bounce about N (tools.cl:31-39): pdf cancels cos/pi, T *= albedo
-                const float r0 = rnd(s), r1 = rnd(s);
-                const float rr = sqrtf(1.0f - r1 * r1), phi = 6.2831853f * r0;
-                float3 t1 = fabsf(N.x) > 0.9f ? make_float3(0, 1, 0) : make_float3(1, 0, 0);
-                float3 bx = norm3(make_float3(t1.y * N.z - t1.z * N.y, t1.z * N.x - t1.x * N.z, t1.x * N.y - t1.y * N.x));
-                float3 by = make_float3(N.y * bx.z - N.z * bx.y, N.z * bx.x - N.x * bx.z, N.x * bx.y - N.y * bx.x);
-                const float cx = cosf(phi) * rr, cy = sinf(phi) * rr;
-                R = norm3(make_float3(N.x + cx * bx.x + cy * by.x + 0.f, N.y + cx * bx.y + cy * by.y, N.z + cx * bx.z + cy * by.z));
-                T = make_float3(T.x * albedo.x, T.y * albedo.y, T.z * albedo.z);
-                wantBounce = true;
+            const uint32_t c = as_u32(v0.w), materialType = c >> 24;
+            if (materialType == kMaterialLight) {
+                // end path on light (wavefront.cl:163-178): alone after a mirror or from the camera, else MIS with the light sampling
+                float w = ipdf;
+                if (!(flags & kPathLastSpecular) && areaLight) {
+                    const float solid = __builtin_fminf(6.2831853f, lightArea / (r.hit.x * r.hit.x) * fabsf(D.y));
+                    const float lightPdf = solid > 0 ? 1.0f / solid : kFar;
+                    w = 1.0f / (lightPdf + brdfPdf);
+                }
+                atomicAdd(&a.accum[pixel * 4 + 0], T.x * w * a.lightColor[0]); atomicAdd(&a.accum[pixel * 4 + 1], T.y * w * a.lightColor[1]);
+                atomicAdd(&a.accum[pixel * 4 + 2], T.z * w * a.lightColor[2]);
+            } else {
+                T = make_float3(T.x * ipdf, T.y * ipdf, T.z * ipdf);   // apply the postponed pdf (wavefront.cl:180)
+                const float3 e1 = make_float3(v1.x - v0.x, v1.y - v0.y, v1.z - v0.z), e2 = make_float3(v2.x - v0.x, v2.y - v0.y, v2.z - v0.z);
+                N = norm3(make_float3(e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x));
+                const float nd = N.x * D.x + N.y * D.y + N.z * D.z;
+                if (nd > 0) N = make_float3(-N.x, -N.y, -N.z);
+                I = make_float3(O.x + r.hit.x * D.x, O.y + r.hit.x * D.y, O.z + r.hit.x * D.z);
+                const uint32_t rgb = c & 0xffffffu;
+                const float3 color = rgb ? make_float3((float)((rgb >> 16) & 255) * 0.00392f, (float)((rgb >> 8) & 255) * 0.00392f, (float)(rgb & 255) * 0.00392f)
+                                         : make_float3(0.7f, 0.7f, 0.7f);
+                uint32_t s = wang(a.seed * 7919u + pixel * 2699u + a.depth * 104729u + 17u);
+                if (!s) s = 1;
+                const float r0 = rnd(s), r1 = rnd(s), r2 = rnd(s), r3 = rnd(s);
+                if (materialType != kMaterialSpecular) {
+                    // direct illumination: next event estimation (wavefront.cl:205-222)
+                    const float3 Pl = areaLight ? make_float3(a.lightPos[0] + (r2 - 0.5f) * a.lightSize[0], a.lightPos[1], a.lightPos[2] + (r3 - 0.5f) * a.lightSize[1])
+                                                : make_float3(a.lightPos[0], a.lightPos[1], a.lightPos[2]);
+                    L = make_float3(Pl.x - I.x, Pl.y - I.y, Pl.z - I.z);
+                    ldist = sqrtf(L.x * L.x + L.y * L.y + L.z * L.z);
+                    const float il = ldist > 0 ? 1.0f / ldist : 0.f;
+                    L = make_float3(L.x * il, L.y * il, L.z * il);
+                    const float ndl = N.x * L.x + N.y * L.y + N.z * L.z;
+                    if (ndl > 0 && ldist > 2.0f * a.eps) {
+                        float g;
+                        if (areaLight) {   // MIS: light pdf = 1 / solid angle of the rectangle seen from I, BRDF pdf = cos / pi
+                            const float solid = __builtin_fminf(6.2831853f, lightArea * il * il * fabsf(L.y));
+                            const float lightPdf = solid > 0 ? 1.0f / solid : kFar;
+                            g = 0.31830988f * ndl / (lightPdf + ndl * 0.31830988f);
+                        } else
+                            g = ndl * il * il * 0.31830988f;   // point light: albedo / pi * cos / d^2
+                        contrib = make_float3(T.x * color.x * a.lightColor[0] * g, T.y * color.y * a.lightColor[1] * g, T.z * color.z * a.lightColor[2] * g);
+                        wantShadow = true;
+                    }
+                }
+                if (a.depth + 1 < a.maxDepth) {
+                    if (materialType == kMaterialSpecular) {   // wavefront.cl:225-232
+                        const float k2 = 2.0f * (N.x * D.x + N.y * D.y + N.z * D.z);
+                        R = make_float3(D.x - k2 * N.x, D.y - k2 * N.y, D.z - k2 * N.z);
+                        T = make_float3(T.x * color.x, T.y * color.y, T.z * color.z);
+                        newPdf = 1.0f; newFlags = kPathLastSpecular;
+                        wantBounce = true;
+                    } else if (!((a.flags & 1u) && (flags & kPathViaDiffuse))) {   // wavefront.cl:233-242
+                        // cosine-weighted bounce about N (Malley): pdf = cos / pi, postponed to the next vertex
+                        const float rr = sqrtf(r1), cz = sqrtf(1.0f - r1), phi = 6.2831853f * r0;
+                        const float3 t1 = fabsf(N.x) > 0.9f ? make_float3(0, 1, 0) : make_float3(1, 0, 0);
+                        const float3 bx = norm3(make_float3(t1.y * N.z - t1.z * N.y, t1.z * N.x - t1.x * N.z, t1.x * N.y - t1.y * N.x));
+                        const float3 by = make_float3(N.y * bx.z - N.z * bx.y, N.z * bx.x - N.x * bx.z, N.x * bx.y - N.y * bx.x);
+                        const float cx = cosf(phi) * rr, cy = sinf(phi) * rr;
+                        R = norm3(make_float3(cz * N.x + cx * bx.x + cy * by.x, cz * N.y + cx * bx.y + cy * by.y, cz * N.z + cx * bx.z + cy * by.z));
+                        const float ndr = __builtin_fmaxf(N.x * R.x + N.y * R.y + N.z * R.z, 1e-6f);
+                        newPdf = ndr * 0.31830988f;
+                        const float k3 = ndr * 0.31830988f;   // T *= dot(N, R) * BRDF, BRDF = color / pi
+                        T = make_float3(T.x * color.x * k3, T.y * color.y * k3, T.z * color.z * k3);
+                        newFlags = kPathViaDiffuse;
+                        wantBounce = true;
+                    }
+                }
             }
         }
     }
     // the whole workgroup takes part in the two queue appends
     const uint32_t sb = queue_slot(wantBounce, a.nOut, qsh);
     if (wantBounce) {
-        put_ray(a.out + sb, make_float3(I.x + R.x * a.eps, I.y + R.y * a.eps, I.z + R.z * a.eps), R, kFar);
-        PathAux o; o.T[0] = T.x; o.T[1] = T.y; o.T[2] = T.z; o.pixel = pixel;
+        put_ray(a.out + sb, make_float3(I.x + R.x * a.eps, I.y + R.y * a.eps, I.z + R.z * a.eps), R, kFar, newPdf);
+        PathAux o; o.T[0] = T.x; o.T[1] = T.y; o.T[2] = T.z; o.pixel = (pixel << 8) | (((a.depth + 1u) & 15u) << 4) | newFlags;
         a.auxOut[sb] = o;
     }
     const uint32_t ss = queue_slot(wantShadow, a.nShadow, qsh);
@@ -151,6 +204,16 @@ __global__ __launch_bounds__(kShadeBlock) void k_wf_shade(ShadeArgs a) {
         PathAux o; o.T[0] = contrib.x; o.T[1] = contrib.y; o.T[2] = contrib.z; o.pixel = pixel;
         a.shadowAux[ss] = o;
     }
+}
+
+// Finalize (wavefront.cl:275-286): accumulator * scale -> sqrt -> 8 bits per channel, 0x00RRGGBB
+__global__ void k_wf_finalize(const float* __restrict__ accum, float scale, uint32_t* __restrict__ pixels, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float r = __builtin_fminf(sqrtf(__builtin_fmaxf(accum[i * 4] * scale, 0.f)), 1.0f) * 255.0f;
+    const float g = __builtin_fminf(sqrtf(__builtin_fmaxf(accum[i * 4 + 1] * scale, 0.f)), 1.0f) * 255.0f;
+    const float b = __builtin_fminf(sqrtf(__builtin_fmaxf(accum[i * 4 + 2] * scale, 0.f)), 1.0f) * 255.0f;
+    pixels[i] = ((uint32_t)(int)r << 16) + ((uint32_t)(int)g << 8) + (uint32_t)(int)b;
 }
 
 __global__ void k_wf_connect(const uint8_t* __restrict__ occluded, const PathAux* __restrict__ aux, const unsigned long long* __restrict__ nShadow,
@@ -168,6 +231,9 @@ void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint6
 }
 void launch_wf_shade(const ShadeArgs& a, uint64_t capacity, hipStream_t s) {
     hipLaunchKernelGGL(k_wf_shade, dim3((uint32_t)((capacity + kShadeBlock - 1) / kShadeBlock)), dim3(kShadeBlock), 0, s, a);
+}
+void launch_wf_finalize(const float* accum, float scale, uint32_t* pixels, uint64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(k_wf_finalize, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, accum, scale, pixels, n);
 }
 void launch_wf_connect(const uint8_t* occ, const PathAux* aux, const unsigned long long* nShadow, float* accum, uint64_t capacity, hipStream_t s) {
     hipLaunchKernelGGL(k_wf_connect, dim3((uint32_t)((capacity + 255) / 256)), dim3(256), 0, s, occ, aux, nShadow, accum);
