@@ -95,6 +95,34 @@ def test_tlas_parity(ctx, oracle, layout):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", [tb.LAYOUT_CWBVH, tb.LAYOUT_BVH4_GPU])
+@pytest.mark.parametrize("variant,name", [(3, "nested loops"), (7, "flat loop, per-lane replacement"), (6, "flat loop, lockstep governor"),
+                                          (9, "flat loop, lockstep"), (13, "nested then flat"), (5, "round-1 kernel")])
+def test_every_tlas_kernel_gives_the_same_records(ctx, oracle, layout, variant, name):
+    """The TLAS query exists as nested loops (whole-wave batches), as one flat loop with per-lane ray replacement, and as
+    the adaptive pair; the default picks by BLAS layout.  All of them must return the oracle's records — the same
+    instances, nodes and triangles are visited in the same per-ray order."""
+    verts = scenes.blob(5000, seed=11)
+    blas = [tb.LAYOUT_CLASSES[layout](ctx).Build(verts)]
+    inst = grid_instances(5, 0.5, 3)
+    tlas = tb.TLAS(ctx).Build(inst, blas)
+    rng_rays = R.random_rays(40_000, (-2, -2, -2), (9, 9, 9), seed=31)                       # incoherent
+    cam = R.camera((-4.0, 9.0, -6.0), (0.55, -0.45, 0.7), 256, 128, 1, 1)
+    cam_rays = R.primary(cam)                                                                # coherent
+    for rays in (rng_rays, cam_rays):
+        want = oracle_tlas(oracle, tlas, blas, rays)
+        tlas.set_variant(0)
+        base = tlas.Intersect(rays.copy())
+        tlas.set_variant(variant)
+        got = tlas.Intersect(rays.copy())
+        c = check(got, want)
+        assert c["hits"] > 1000, (name, c)
+        assert np.array_equal(got.view(np.uint8), base.view(np.uint8)), name                 # and bit for bit what the default returns
+        occ = tlas.IsOccluded(rays.copy())
+        assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2, name
+
+
+@pytest.mark.gpu
 def test_tlas_rejects_bad_input(ctx):
     verts = scenes.soup(500, seed=1)
     b2 = tb.BVH_GPU(ctx).Build(verts)

@@ -56,6 +56,7 @@ struct tbvh_context {
     uint32_t spillEntries = 0;    // 32-bit entries per lane
     unsigned long long* counter = nullptr;  // status word, instrumentation counters
     uint32_t poolParts = 5;   // log2: 32 partitions
+    int tlasVariant = 0;           // TBVH_TLAS_VARIANT: kernel variant of TLAS scenes that did not pick one (experiment knob)
     bool gridOverride = false;     // TBVH_BLOCKS_PER_CU / TBVH_RAYS_PER_BLOCK given: no per-scene adjustment
     uint32_t raysPerBlock = 192;   // small batches: one workgroup per this many rays (measured best of 128..384 on 1 M-ray batches)
     unsigned long long* pool = nullptr;     // ray-fetch counters: kPoolParts of them, 256 bytes apart (ray_pool.h)
@@ -307,7 +308,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (s->isTlas) {
         q.spillStride = c->spillEntries / 2;
-        launch_tlas(any, s->blasLayout, s->variant, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+        launch_tlas(any, s->blasLayout, s->variant ? s->variant : c->tlasVariant, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         c->timed = true;
@@ -402,6 +403,7 @@ int tbvh_init(int device, tbvh_context** out) {
         const int b = atoi(e);
         if (b >= 64 && b <= 4096) { c->raysPerBlock = (uint32_t)b; c->gridOverride = true; }
     }
+    if (const char* e = getenv("TBVH_TLAS_VARIANT")) c->tlasVariant = atoi(e);   // experiment knob
     if (const char* e = getenv("TBVH_POOL_PARTS")) {  // experiment knob
         const int b = atoi(e);
         if (b >= 0 && (1 << b) <= kPoolParts) c->poolParts = (uint32_t)b;   // log2 of the partition count
@@ -870,7 +872,7 @@ uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0;
 
 int tbvh_set_variant(tbvh_scene* s, int v) {
     if (!s) return fail(TBVH_E_INVALID, "null scene");
-    const bool ok = s->layout == TBVH_LAYOUT_CWBVH ? (cwbvh_variant_valid(v) || (v >= 20 && v <= 39)) : (v >= 0 && v <= 12);
+    const bool ok = s->layout == TBVH_LAYOUT_CWBVH ? (cwbvh_variant_valid(v) || (v >= 20 && v <= 39)) : (v >= 0 && v <= 16);
     if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
     tbvh_context* c = s->ctx;
     if (int r = setDevice(c)) return r;

@@ -42,15 +42,28 @@ struct RayL {  // a ray in some space + its current best hit
     bool found;
 };
 
+// Lane cohesion of the nested loops, for the adaptive kernel: every loop body calls tick() — each lane counts its own
+// trips, the first active lane counts the wave's in an LDS word; at the end of a 64-ray generation
+// sum(lane trips) / (64 x wave trips) says how much of the wave the nested loops kept busy.
+struct WaveTicks {
+    TBVH_AS_LDS uint32_t* trips;
+    uint32_t mine;
+    __device__ __forceinline__ void tick() {
+        mine++;
+        if (lane_rank(__ballot(true)) == 0) __hip_atomic_fetch_add((uint32_t*)trips, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+};
+
 // ---- BLAS traversals; each runs until the stack is back at `base` ------------------------------
 
-template <bool ANYHIT, int LDS_N>
-__device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 tris, RayL& r, StackT<LDS_N>& st, const Omm om) {
+template <bool ANYHIT, int LDS_N, bool TICK>
+__device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 tris, RayL& r, StackT<LDS_N>& st, const Omm om, WaveTicks& tk) {
     const int base = st.sp;
     const uint32_t oct = 7u - ((r.D.x < 0 ? 4u : 0u) | (r.D.y < 0 ? 2u : 0u) | (r.D.z < 0 ? 1u : 0u));
     const uint32_t octinv4 = oct * 0x01010101u;
     uint2 ng = make_uint2(0u, 0x80000000u), tg = make_uint2(0u, 0u);
     for (;;) {
+        if (TICK) tk.tick();
         if (ng.y > 0x00FFFFFFu) {
             const uint32_t imask = ng.y;
             const uint32_t bit = 31u - (uint32_t)__clz(ng.y);
@@ -113,11 +126,12 @@ __device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 
     }
 }
 
-template <bool ANYHIT, int LDS_N>
-__device__ __forceinline__ void blas_bvh4(const GlobalF4 data, RayL& r, StackT<LDS_N>& st, const Omm om) {
+template <bool ANYHIT, int LDS_N, bool TICK>
+__device__ __forceinline__ void blas_bvh4(const GlobalF4 data, RayL& r, StackT<LDS_N>& st, const Omm om, WaveTicks& tk) {
     const int base = st.sp;
     uint32_t offset = 0;
     for (;;) {
+        if (TICK) tk.tick();
         const float4 d0 = data[offset], d1 = data[offset + 1], d2 = data[offset + 2], d3 = data[offset + 3];
         const float sx = d1.x * r.rD.x, sy = d1.y * r.rD.y, sz = d1.z * r.rD.z;
         const float bx = (d0.x - r.O.x) * r.rD.x, by = (d0.y - r.O.y) * r.rD.y, bz = (d0.z - r.O.z) * r.rD.z;
@@ -162,22 +176,21 @@ __device__ __forceinline__ void blas_bvh4(const GlobalF4 data, RayL& r, StackT<L
 }
 
 // instance record = BLASInstance, 12 float4 (192 bytes)
-template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N>
-__device__ __forceinline__ void tlas_body(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
+// ADAPT 0: run until the batch is used up.  ADAPT 1: measure the lane cohesion of every 64-ray generation (WaveTicks) and
+// return false as soon as one falls below KEEP / 256 — the caller continues with the flat loop (tlas_flat_body); returns
+// true when the batch is used up.  ADAPT 2: statistics (histogram of the cohesion in q.stats), never switches.
+template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N, int ADAPT, uint32_t KEEP>
+__device__ __forceinline__ bool tlas_body(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
                                           const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, const QueryArgs& q,
-                                          uint32_t* __restrict__ status) {
-    __shared__ uint2 stk[LDS_N][WG];
-    StackT<LDS_N> st;
-    st.init(&stk[0][threadIdx.x], (uint2*)q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
-    RayPool<64> pool;
-    const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
-    pool.init(q.poolParts);
+                                          StackT<LDS_N>& st, RayPool<64>& pool, const uint64_t nRaysTotal, TBVH_AS_LDS uint32_t* ldsTrips) {
+    WaveTicks tk; tk.trips = ldsTrips; tk.mine = 0;
     for (;;) {
         // whole-wave batches here: the nested TLAS/BLAS loops keep per-lane state in registers
         uint64_t ri = 0;
         const bool got = pool.acquire(true, q.counter, nRaysTotal, ri);
         if (__ballot(got) == 0) break;
-        if (!got) continue;
+        if (ADAPT) { tk.mine = 0; if ((threadIdx.x & 63u) == 0) *ldsTrips = 0u; }
+        if (got) {
         RayRec* rp = q.rays + ri;
         const float3 O = xyz(rp->O), D = xyz(rp->D), rD = xyz(rp->rD);
         const uint32_t rayMask = as_u32(rp->O.w);
@@ -188,6 +201,7 @@ __device__ __forceinline__ void tlas_body(const float4* __restrict__ tlasNodes, 
         st.sp = 0;
         uint32_t node = 0;
         for (;;) {
+            if (ADAPT) tk.tick();
             const float4 n0 = tlasNodes[node * 4], n1 = tlasNodes[node * 4 + 1], n2 = tlasNodes[node * 4 + 2], n3 = tlasNodes[node * 4 + 3];
             const uint32_t cnt = as_u32(n2.w);
             if (cnt) {
@@ -214,8 +228,9 @@ __device__ __forceinline__ void tlas_body(const float4* __restrict__ tlasNodes, 
                     rl.rD = make_float3(safercp(rl.D.x), safercp(rl.D.y), safercp(rl.D.z));
                     rl.hit = hit; rl.found = false;
                     const BlasDesc bd = blas[as_u32(b0.w)];
-                    if (BLAS_LAYOUT == 9) blas_cwbvh<ANYHIT, LDS_N>(GlobalF4(bd.nodes), GlobalF4(bd.tris), rl, st, Omm{bd.opmap, bd.opmapN});
-                    else blas_bvh4<ANYHIT, LDS_N>(GlobalF4(bd.nodes), rl, st, Omm{bd.opmap, bd.opmapN});
+                    if (ADAPT) tk.tick();   // cohesion is sampled where the lanes part ways: TLAS nodes and instance entries (ticks inside the BLAS loops cost 18 %; instance entries alone separate camera rays from random ones less cleanly)
+                    if (BLAS_LAYOUT == 9) blas_cwbvh<ANYHIT, LDS_N, false>(GlobalF4(bd.nodes), GlobalF4(bd.tris), rl, st, Omm{bd.opmap, bd.opmapN}, tk);
+                    else blas_bvh4<ANYHIT, LDS_N, false>(GlobalF4(bd.nodes), rl, st, Omm{bd.opmap, bd.opmapN}, tk);
                     if (rl.found) { found = true; hit = rl.hit; hitInst = ii; if (ANYHIT) break; }
                 }
                 if (ANYHIT && found) break;
@@ -250,7 +265,328 @@ __device__ __forceinline__ void tlas_body(const float4* __restrict__ tlasNodes, 
         if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
         else if (found) { rp->hit = hit; ((uint32_t*)rp)[11] = hitInst; }   // byte 44 = hit.inst
         else if (q.fresh) rp->hit = hit;
+        }
+        if (ADAPT) {
+            uint32_t sum = tk.mine;
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const uint32_t trips = *ldsTrips;
+            const uint32_t e = trips ? sum * 4u / trips : 256u;   // x / 256
+            if (ADAPT == 2) {
+                const uint32_t b = e < 64u ? 0u : e < 96u ? 1u : e < 128u ? 2u : e < 154u ? 3u : e < 179u ? 4u : e < 205u ? 5u : e < 230u ? 6u : 7u;
+                if ((threadIdx.x & 63u) == 0) atomicAdd(q.stats + b, 1ull);
+            } else if (e < KEEP) return false;
+        }
     }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same query as ONE flat loop with per-lane ray replacement (the structure of kernels_cwbvh.hip / kernels_query.hip):
+// every lane is in one of three modes and does one step of it per iteration —
+//   TLAS      one 2-wide node of the top-level tree (a leaf switches to INSTANCE),
+//   INSTANCE  take the next instance of the current TLAS leaf: mask test, ray into instance space (-> BLAS), or, when
+//             the leaf is used up, pop the TLAS stack (-> TLAS) or finish the ray,
+//   BLAS      one triangle test or one node visit of the instance's BVH; back at the stack base the world ray is read
+//             again from the record (-> INSTANCE),
+// so a lane never waits for the longest instance list, the deepest BLAS traversal or the slowest ray of its wave, which
+// is what the nested loops of tlas_body cost (three levels of "everybody waits for the slowest").  Idle lanes take new
+// rays as in the other kernels.  Per ray the order of instances, nodes and triangles is the nested version's.
+// ---------------------------------------------------------------------------------------------------------------
+template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N, int REFILL_MIN, int PHASE_MIN, bool ADAPT>
+__device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
+                                               const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, const QueryArgs& q,
+                                               StackT<LDS_N>& st, RayPool<64>& pool, const uint64_t nRaysTotal) {
+    enum : uint32_t { M_TLAS = 0, M_INST = 1, M_BLAS = 2 };
+
+    bool active = false, found = false;
+    uint64_t ri = 0;
+    float3 O = make_float3(0, 0, 0), D = O, rD = O;      // the ray in the CURRENT space (world, or the instance's)
+    float4 hit = make_float4(0, 0, 0, 0);
+    uint32_t hitInst = 0, rayMask = 0, mode = M_TLAS, node = 0, leafNext = 0, leafEnd = 0, curInst = 0, blasIdx = 0;
+    int base = 0;
+    GlobalF4 bnodes, btris;
+    // BVH4_GPU BLAS state (kernels_query.hip: k_bvh4)
+    uint32_t offset = 0, leafQ0 = 0, leafQ1 = 0, leafQ2 = 0, leafQ3 = 0, leafCnt = 0, leafCntB = 0;
+    // CWBVH BLAS state (kernels_cwbvh.hip: k_cwbvh)
+    uint32_t oct = 0;
+    uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+
+    LockstepGovernor gov;   // ADAPT only: lockstep (whole-wave generations) while the rays are coherent, per-lane replacement otherwise
+    gov.init();
+    for (;;) {
+        const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
+        if ((ADAPT ? gov.want_refill(nIdle, (uint32_t)REFILL_MIN) : nIdle >= (uint32_t)REFILL_MIN) || nIdle == (uint32_t)WG) {
+            if (!pool.dry()) {
+                uint64_t nri = 0;
+                if (pool.acquire(!active, q.counter, nRaysTotal, nri)) {
+                    ri = nri;
+                    const RayRec* rp = q.rays + ri;
+                    O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
+                    rayMask = as_u32(rp->O.w);
+                    hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
+                    hitInst = as_u32(rp->rD.w);
+                    found = false; mode = M_TLAS; node = 0; st.sp = 0;
+                    active = true;
+                }
+            }
+            if (__ballot(active) == 0) break;
+        }
+        // Phase gating: a mode's code runs in this iteration only if at least PHASE_MIN lanes are in that mode, or it is the
+        // mode most lanes are in (so somebody always makes progress).  Without it nearly every iteration pays for all three
+        // code paths with a handful of lanes each; with it lanes regroup (a lane waits a few iterations for company).
+        const uint32_t nA = (uint32_t)__popcll(__ballot(active && mode == M_TLAS)), nB = (uint32_t)__popcll(__ballot(active && mode == M_INST)),
+                       nC = (uint32_t)__popcll(__ballot(active && mode == M_BLAS));
+        const uint32_t nMax = nA > nB ? (nA > nC ? nA : nC) : (nB > nC ? nB : nC);
+        const bool runA = PHASE_MIN <= 1 || nA >= (uint32_t)PHASE_MIN || nA == nMax, runB = PHASE_MIN <= 1 || nB >= (uint32_t)PHASE_MIN || nB == nMax,
+                   runC = PHASE_MIN <= 1 || nC >= (uint32_t)PHASE_MIN || nC == nMax;
+        if (!active) continue;
+        bool done = false;
+
+        if (mode == M_BLAS) { if (runC) {
+            bool pop = false;   // this lane's BLAS step ended with nothing pending: take the next stack entry (or leave the BLAS)
+            if (BLAS_LAYOUT == 9) {
+                if (tg.y != 0) {   // one triangle
+                    const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
+                    tg.y &= ~(1u << ti);
+                    const uint32_t ta = tg.x + ti * 3u;
+                    const float4 e2 = btris[ta], e1 = btris[ta + 1], v0 = btris[ta + 2];
+                    TriHit h;
+                    if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                        const BlasDesc bd = blas[blasIdx];   // opacity micromaps are per BLAS: looked up only for a candidate hit
+                        if (!bd.opmap || omm_opaque(Omm{bd.opmap, bd.opmapN}, as_u32(v0.w), h.u, h.v)) {
+                            found = true; hitInst = curInst;
+                            if (ANYHIT) done = true;
+                            else hit = make_float4(h.t, h.u, h.v, v0.w);
+                        }
+                    }
+                }
+                if (!done && tg.y == 0) {
+                    if (ng.y <= 0x00FFFFFFu) pop = true;
+                    else {
+                        const uint32_t imask = ng.y;
+                        const uint32_t bit = 31u - (uint32_t)__clz(ng.y);
+                        const uint32_t cbase = ng.x;
+                        ng.y &= ~(1u << bit);
+                        if (ng.y > 0x00FFFFFFu) st.push(ng);
+                        const uint32_t slot = (bit - 24u) ^ oct;
+                        const uint32_t octinv4 = oct * 0x01010101u;
+                        const uint32_t ci = (cbase + __popc(imask & ~(0xFFFFFFFFu << slot))) * 5u;
+                        const float4 n0 = bnodes[ci], n1 = bnodes[ci + 1], n2 = bnodes[ci + 2], n3 = bnodes[ci + 3], n4 = bnodes[ci + 4];
+                        const uint32_t ew = as_u32(n0.w);
+                        const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
+                        const float ox = (n0.x - O.x) * rD.x, oy = (n0.y - O.y) * rD.y, oz = (n0.z - O.z) * rD.z;
+                        uint32_t hitmask = 0;
+#pragma unroll
+                        for (int half = 0; half < 2; half++) {
+                            const uint32_t meta4 = half ? as_u32(n1.w) : as_u32(n1.z);
+                            const uint32_t inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
+                            const uint32_t imask4 = sext_s8x4(inner4 << 3);
+                            const uint32_t bitidx4 = (meta4 ^ (octinv4 & imask4)) & 0x1F1F1F1Fu;
+                            const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;
+                            const uint32_t qlx = half ? as_u32(n2.y) : as_u32(n2.x), qhx = half ? as_u32(n3.w) : as_u32(n3.z);
+                            const uint32_t qly = half ? as_u32(n2.w) : as_u32(n2.z), qhy = half ? as_u32(n4.y) : as_u32(n4.x);
+                            const uint32_t qlz = half ? as_u32(n3.y) : as_u32(n3.x), qhz = half ? as_u32(n4.w) : as_u32(n4.z);
+                            const uint32_t lox = rD.x < 0 ? qhx : qlx, hix = rD.x < 0 ? qlx : qhx;
+                            const uint32_t loy = rD.y < 0 ? qhy : qly, hiy = rD.y < 0 ? qly : qhy;
+                            const uint32_t loz = rD.z < 0 ? qhz : qlz, hiz = rD.z < 0 ? qlz : qhz;
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const int sh = 8 * i;
+                                const float tnx = __builtin_fmaf((float)((lox >> sh) & 255), ax, ox), tfx = __builtin_fmaf((float)((hix >> sh) & 255), ax, ox);
+                                const float tny = __builtin_fmaf((float)((loy >> sh) & 255), ay, oy), tfy = __builtin_fmaf((float)((hiy >> sh) & 255), ay, oy);
+                                const float tnz = __builtin_fmaf((float)((loz >> sh) & 255), az, oz), tfz = __builtin_fmaf((float)((hiz >> sh) & 255), az, oz);
+                                const float cmin = __builtin_fmaxf(fmax3(tnx, tny, tnz), 0.0f);
+                                const float cmax = __builtin_fminf(fmin3(tfx, tfy, tfz), hit.x);
+                                if (cmin <= cmax) hitmask |= ((bits4 >> sh) & 255u) << ((bitidx4 >> sh) & 255u);
+                            }
+                        }
+                        ng.x = as_u32(n1.x); tg.x = as_u32(n1.y);
+                        ng.y = (hitmask & 0xFF000000u) | (ew >> 24);
+                        tg.y = hitmask & 0x00FFFFFFu;
+                        if (tg.y == 0 && ng.y <= 0x00FFFFFFu) pop = true;
+                    }
+                }
+                if (pop) {
+                    if (st.sp == base) mode = M_INST;
+                    else {
+                        ng = st.pop();
+                        if (ng.y <= 0x00FFFFFFu) { tg = ng; ng = make_uint2(0u, 0u); }   // a postponed triangle group
+                    }
+                }
+            } else {
+                if (leafCnt != 0) {   // one triangle of the pending leaves
+                    const uint32_t ta = leafQ0;
+                    const float4 v0 = bnodes[ta], e1 = bnodes[ta + 1], e2 = bnodes[ta + 2];
+                    leafQ0 += 3u; leafCnt -= 1u;
+                    if ((leafCnt & 0xffffu) == 0) {
+                        leafQ0 = leafQ1; leafQ1 = leafQ2; leafQ2 = leafQ3;
+                        leafCnt = __builtin_amdgcn_alignbit(leafCntB, leafCnt, 16); leafCntB >>= 16;
+                    }
+                    TriHit h;
+                    if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                        const BlasDesc bd = blas[blasIdx];
+                        if (!bd.opmap || omm_opaque(Omm{bd.opmap, bd.opmapN}, as_u32(v0.w), h.u, h.v)) {
+                            found = true; hitInst = curInst;
+                            if (ANYHIT) done = true;
+                            else hit = make_float4(h.t, h.u, h.v, v0.w);
+                        }
+                    }
+                    if (!done && leafCnt == 0) pop = true;
+                } else {   // one node
+                    const float4 d0 = bnodes[offset], d1 = bnodes[offset + 1], d2 = bnodes[offset + 2], d3 = bnodes[offset + 3];
+                    const float sx = d1.x * rD.x, sy = d1.y * rD.y, sz = d1.z * rD.z;
+                    const float bx = (d0.x - O.x) * rD.x, by = (d0.y - O.y) * rD.y, bz = (d0.z - O.z) * rD.z;
+                    const uint32_t qx0 = as_u32(d0.w), qx1 = as_u32(d1.w);
+                    const uint32_t qy0 = as_u32(d2.x), qy1 = as_u32(d2.y), qz0 = as_u32(d2.z), qz1 = as_u32(d2.w);
+                    const bool ngx = sx < 0.f, ngy = sy < 0.f, ngz = sz < 0.f;   // near / far plane words by the sign of the direction
+                    const uint32_t nx = ngx ? qx1 : qx0, fx = ngx ? qx0 : qx1;
+                    const uint32_t ny = ngy ? qy1 : qy0, fy = ngy ? qy0 : qy1;
+                    const uint32_t nz = ngz ? qz1 : qz0, fz = ngz ? qz0 : qz1;
+                    float dist[4];
+                    uint32_t info[4] = { as_u32(d3.x), as_u32(d3.y), as_u32(d3.z), as_u32(d3.w) };
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int sh = 8 * i;
+                        const float x1 = __builtin_fmaf((float)((nx >> sh) & 255), sx, bx), x2 = __builtin_fmaf((float)((fx >> sh) & 255), sx, bx);
+                        const float y1 = __builtin_fmaf((float)((ny >> sh) & 255), sy, by), y2 = __builtin_fmaf((float)((fy >> sh) & 255), sy, by);
+                        const float z1 = __builtin_fmaf((float)((nz >> sh) & 255), sz, bz), z2 = __builtin_fmaf((float)((fz >> sh) & 255), sz, bz);
+                        const float tmin = __builtin_fmaxf(fmax3(x1, y1, z1), 0.0f);
+                        const float tmax = __builtin_fminf(fmin3(x2, y2, z2), hit.x);
+                        dist[i] = (tmin > tmax || info[i] == 0) ? kFar : tmin;
+                    }
+#define TBVH_CSWAP(a, b) if (dist[a] < dist[b]) { const float tf = dist[a]; dist[a] = dist[b]; dist[b] = tf; const uint32_t tu = info[a]; info[a] = info[b]; info[b] = tu; }
+                    TBVH_CSWAP(0, 2) TBVH_CSWAP(1, 3) TBVH_CSWAP(0, 1) TBVH_CSWAP(2, 3) TBVH_CSWAP(1, 2)
+#undef TBVH_CSWAP
+                    uint32_t nq = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        if (!(dist[i] < kFar)) continue;
+                        if (!(info[i] & 0x80000000u)) { st.push(make_uint2(info[i], 0u)); continue; }
+                        const uint32_t cnt = (info[i] >> 16) & 0x7fffu;
+                        if (cnt == 0) continue;
+                        const uint32_t ta = offset + (info[i] & 0xffffu);
+                        if (nq == 0) leafQ0 = ta; else if (nq == 1) leafQ1 = ta; else if (nq == 2) leafQ2 = ta; else leafQ3 = ta;
+                        if (nq < 2) leafCnt |= cnt << (16 * nq); else leafCntB |= cnt << (16 * (nq - 2));
+                        nq++;
+                    }
+                    if (leafCnt == 0) pop = true;
+                }
+                if (pop) {
+                    if (st.sp == base) mode = M_INST;
+                    else offset = st.pop().x;
+                }
+            }
+            if (mode == M_INST && !done) {   // back in world space: the ray as the caller gave it
+                const RayRec* rp = q.rays + ri;
+                O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
+            }
+        } } else if (mode == M_INST) { if (runB) {
+            if (leafNext == leafEnd) {   // TLAS leaf done
+                if (st.sp == 0) done = true;
+                else { node = st.pop().x; mode = M_TLAS; }
+            } else {
+                const uint32_t ii = tlasIdx[leafNext++];
+                const float4* ip = instances + (size_t)ii * 12;
+                const float4 b0 = ip[8], b1 = ip[9];                      // aabbMin|blasIdx, aabbMax|mask
+                if (as_u32(b1.w) & rayMask) {                              // tiny_bvh.h:3326
+                    const float4 r0 = ip[4], r1 = ip[5], r2 = ip[6], r3 = ip[7];   // invTransform rows
+                    // tinybvh_transform_point / _vector with the reference build's contraction (see tlas_body)
+                    const float px = __builtin_fmaf(r0.z, O.z, __builtin_fmaf(r0.x, O.x, r0.y * O.y)) + r0.w;
+                    const float py = __builtin_fmaf(r1.z, O.z, __builtin_fmaf(r1.x, O.x, r1.y * O.y)) + r1.w;
+                    const float pz = __builtin_fmaf(r2.z, O.z, __builtin_fmaf(r2.x, O.x, r2.y * O.y)) + r2.w;
+                    const float w = __builtin_fmaf(r3.z, O.z, __builtin_fmaf(r3.x, O.x, r3.y * O.y)) + r3.w;
+                    const float3 lD = make_float3(__builtin_fmaf(r0.z, D.z, __builtin_fmaf(r0.x, D.x, r0.y * D.y)), __builtin_fmaf(r1.z, D.z, __builtin_fmaf(r1.x, D.x, r1.y * D.y)),
+                                                  __builtin_fmaf(r2.z, D.z, __builtin_fmaf(r2.x, D.x, r2.y * D.y)));
+                    if (w == 1) O = make_float3(px, py, pz);
+                    else { const float iw = 1.f / w; O = make_float3(px * iw, py * iw, pz * iw); }
+                    D = lD;
+                    rD = make_float3(safercp(D.x), safercp(D.y), safercp(D.z));
+                    blasIdx = as_u32(b0.w);
+                    const BlasDesc bd = blas[blasIdx];
+                    bnodes = GlobalF4(bd.nodes); btris = GlobalF4(bd.tris);
+                    curInst = ii; base = st.sp; mode = M_BLAS;
+                    if (BLAS_LAYOUT == 9) {
+                        oct = 7u - ((D.x < 0 ? 4u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 1u : 0u));
+                        ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
+                    } else { offset = 0; leafCnt = 0; leafCntB = 0; }
+                }
+            }
+        } } else if (runA) {
+            const float4 n0 = tlasNodes[node * 4], n1 = tlasNodes[node * 4 + 1], n2 = tlasNodes[node * 4 + 2], n3 = tlasNodes[node * 4 + 3];
+            const uint32_t cnt = as_u32(n2.w);
+            if (cnt) { leafNext = as_u32(n3.w); leafEnd = leafNext + cnt; mode = M_INST; }
+            else {
+                // SLAB_TEST_TWO_NODES form (tiny_bvh.h:3202-3220), as in the BVH_GPU kernel
+                const float3 ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z);
+                const float lx1 = __builtin_fmaf(n0.x, rD.x, -ro.x), lx2 = __builtin_fmaf(n1.x, rD.x, -ro.x);
+                const float ly1 = __builtin_fmaf(n0.y, rD.y, -ro.y), ly2 = __builtin_fmaf(n1.y, rD.y, -ro.y);
+                const float lz1 = __builtin_fmaf(n0.z, rD.z, -ro.z), lz2 = __builtin_fmaf(n1.z, rD.z, -ro.z);
+                const float rx1 = __builtin_fmaf(n2.x, rD.x, -ro.x), rx2 = __builtin_fmaf(n3.x, rD.x, -ro.x);
+                const float ry1 = __builtin_fmaf(n2.y, rD.y, -ro.y), ry2 = __builtin_fmaf(n3.y, rD.y, -ro.y);
+                const float rz1 = __builtin_fmaf(n2.z, rD.z, -ro.z), rz2 = __builtin_fmaf(n3.z, rD.z, -ro.z);
+                const float tminL = __builtin_fmaxf(fmax3(__builtin_fminf(lx1, lx2), __builtin_fminf(ly1, ly2), __builtin_fminf(lz1, lz2)), 0.0f);
+                const float tmaxL = __builtin_fminf(fmin3(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2), __builtin_fmaxf(lz1, lz2)), hit.x);
+                const float tminR = __builtin_fmaxf(fmax3(__builtin_fminf(rx1, rx2), __builtin_fminf(ry1, ry2), __builtin_fminf(rz1, rz2)), 0.0f);
+                const float tmaxR = __builtin_fminf(fmin3(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2), __builtin_fmaxf(rz1, rz2)), hit.x);
+                const bool hL = tmaxL >= tminL, hR = tmaxR >= tminR;
+                uint32_t l = as_u32(n0.w), r = as_u32(n1.w);
+                if (hL && hR) {
+                    if (tminL > tminR) { const uint32_t t = l; l = r; r = t; }
+                    st.push(make_uint2(r, 0u));
+                    node = l;
+                } else if (hL) node = l;
+                else if (hR) node = r;
+                else {
+                    if (st.sp == 0) done = true;
+                    else node = st.pop().x;
+                }
+            }
+        }
+        if (done) {
+            RayRec* rp = q.rays + ri;
+            if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+            else if (found) { rp->hit = hit; ((uint32_t*)rp)[11] = hitInst; }   // byte 44 = hit.inst
+            else if (q.fresh) rp->hit = hit;
+            active = false;
+        }
+    }
+}
+
+// kernel prologue shared by all TLAS kernels: LDS stack top, spill area, ray pool
+#define TBVH_TLAS_PROLOGUE                                                                                                          \
+    __shared__ uint2 stk[LDS_N][WG];                                                                                                \
+    __shared__ uint32_t ldsTrips;                                                                                                   \
+    StackT<LDS_N> st;                                                                                                               \
+    st.init(&stk[0][threadIdx.x], (uint2*)q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);       \
+    RayPool<64> pool;                                                                                                               \
+    const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays; /* batch size may live on the device (wavefront queues) */      \
+    pool.init(q.poolParts);
+
+template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N = 12, int REFILL_MIN = 16, int PHASE_MIN = 16, bool ADAPT = false>
+__global__ __launch_bounds__(WG) void k_tlas_flat(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
+                                                  const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, QueryArgs q,
+                                                  uint32_t* __restrict__ status) {
+    TBVH_TLAS_PROLOGUE
+    (void)ldsTrips;
+    tlas_flat_body<ANYHIT, BLAS_LAYOUT, LDS_N, REFILL_MIN, PHASE_MIN, ADAPT>(tlasNodes, tlasIdx, instances, blas, q, st, pool, nRaysTotal);
+    if (st.overflow) atomicOr(status, 1u);
+}
+template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N = 12, int REFILL_MIN = 16, int PHASE_MIN = 16, bool ADAPT = false>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_tlas_flat_w5(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
+                                                  const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, QueryArgs q,
+                                                  uint32_t* __restrict__ status) {
+    TBVH_TLAS_PROLOGUE
+    (void)ldsTrips;
+    tlas_flat_body<ANYHIT, BLAS_LAYOUT, LDS_N, REFILL_MIN, PHASE_MIN, ADAPT>(tlasNodes, tlasIdx, instances, blas, q, st, pool, nRaysTotal);
+    if (st.overflow) atomicOr(status, 1u);
+}
+template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N = 12, int REFILL_MIN = 16, int PHASE_MIN = 16, bool ADAPT = false>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_tlas_flat_w6(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
+                                                  const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, QueryArgs q,
+                                                  uint32_t* __restrict__ status) {
+    TBVH_TLAS_PROLOGUE
+    (void)ldsTrips;
+    tlas_flat_body<ANYHIT, BLAS_LAYOUT, LDS_N, REFILL_MIN, PHASE_MIN, ADAPT>(tlasNodes, tlasIdx, instances, blas, q, st, pool, nRaysTotal);
     if (st.overflow) atomicOr(status, 1u);
 }
 
@@ -258,14 +594,30 @@ template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N = 16>
 __global__ __launch_bounds__(WG) void k_tlas(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
                                              const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, QueryArgs q,
                                              uint32_t* __restrict__ status) {
-    tlas_body<ANYHIT, BLAS_LAYOUT, LDS_N>(tlasNodes, tlasIdx, instances, blas, q, status);
+    TBVH_TLAS_PROLOGUE
+    tlas_body<ANYHIT, BLAS_LAYOUT, LDS_N, 0, 0u>(tlasNodes, tlasIdx, instances, blas, q, st, pool, nRaysTotal, (TBVH_AS_LDS uint32_t*)&ldsTrips);
+    if (st.overflow) atomicOr(status, 1u);
 }
 // the same with the register budget of 5 waves per SIMD (<= 96 VGPRs; left alone the compiler takes 88-115)
 template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N = 16>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_tlas_w5(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
                                              const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, QueryArgs q,
                                              uint32_t* __restrict__ status) {
-    tlas_body<ANYHIT, BLAS_LAYOUT, LDS_N>(tlasNodes, tlasIdx, instances, blas, q, status);
+    TBVH_TLAS_PROLOGUE
+    tlas_body<ANYHIT, BLAS_LAYOUT, LDS_N, 0, 0u>(tlasNodes, tlasIdx, instances, blas, q, st, pool, nRaysTotal, (TBVH_AS_LDS uint32_t*)&ldsTrips);
+    if (st.overflow) atomicOr(status, 1u);
+}
+
+// Adaptive: every wave starts with the nested loops (fastest while its 64 rays stay together) and moves to the flat loop
+// with per-lane replacement for the rest of the launch once a generation's lane cohesion drops below KEEP / 256.
+template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N = 12, uint32_t KEEP = 128, int STATS = 0>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_tlas_adaptive(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
+                                             const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, QueryArgs q,
+                                             uint32_t* __restrict__ status) {
+    TBVH_TLAS_PROLOGUE
+    if (!tlas_body<ANYHIT, BLAS_LAYOUT, LDS_N, STATS ? 2 : 1, KEEP>(tlasNodes, tlasIdx, instances, blas, q, st, pool, nRaysTotal, (TBVH_AS_LDS uint32_t*)&ldsTrips))
+        tlas_flat_body<ANYHIT, BLAS_LAYOUT, LDS_N, 16, 32, false>(tlasNodes, tlasIdx, instances, blas, q, st, pool, nRaysTotal);
+    if (st.overflow) atomicOr(status, 1u);
 }
 
 }  // namespace
@@ -282,14 +634,29 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
             else hipLaunchKernelGGL((K<false, 6, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);       \
         }                                                                                                                               \
     } while (0)
-    // Default: the register budget of 5 waves per SIMD (<= 96 VGPRs; left alone the compiler takes 88-115 and runs 4) and a
-    // 12-entry LDS stack top (6 KB per workgroup: 20 workgroups per CU fit the 160 KB).  1000 instances, 8.3 M camera rays:
-    // BVH4_GPU BLASes 2.10 -> 1.95 ms, CWBVH BLASes 2.73 -> 2.56 ms.
-    if (variant == 2) TBVH_LT(k_tlas_w5, 8);
+    // Defaults (1000 instances of a 100 k-triangle BLAS; 8.3 M camera rays / 8.4 M random rays, Intersect, MRays/s):
+    //                                   BVH4_GPU BLASes        CWBVH BLASes
+    //   nested loops (k_tlas_w5)        4240 /  535            3140 /  385
+    //   flat loop (k_tlas_flat_w6)      3280 / 1315            3320 / 1350
+    //   nested, then flat (adaptive)    3980 / 1300-1380       3000 /  920
+    // CWBVH BLASes: the flat loop wins on both; BVH4_GPU BLASes: the nested loops are 24 % faster on camera rays and 2.5 x
+    // slower on incoherent ones, so every wave starts nested and moves to the flat loop once the lane cohesion of a
+    // 64-ray generation falls below 0.375 (camera rays: 99 % of the generations above 0.5; random rays: all below 0.375).
+    if (variant == 0) {
+        if (blasLayout == 9) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);
+        else TBVH_LT(k_tlas_adaptive, 12, 96);
+    }
+    else if (variant == 6) TBVH_LT(k_tlas_flat_w6, 12, 16, 32, true);   // flat loop under the lockstep governor
+    else if (variant == 7) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);         // flat loop, per-lane replacement throughout
+    else if (variant == 9) TBVH_LT(k_tlas_flat_w6, 12, 64, 16);         // flat loop, lockstep throughout
+    else if (variant == 12) TBVH_LT(k_tlas_adaptive, 12, 128, 1);        // statistics: cohesion histogram of the nested loops
+    else if (variant == 13) TBVH_LT(k_tlas_adaptive, 12, 96);
+    else if (variant == 14) TBVH_LT(k_tlas_adaptive, 12, 128);
+    else if (variant == 2) TBVH_LT(k_tlas_w5, 8);
     else if (variant == 4) TBVH_LT(k_tlas, 8);
-    else if (variant == 5) TBVH_LT(k_tlas, 16);        // the former default
+    else if (variant == 5) TBVH_LT(k_tlas, 16);        // round-1 kernel: nested loops, compiler's register budget (4 waves per SIMD)
     else if (variant == 1) TBVH_LT(k_tlas_w5, 16);
-    else TBVH_LT(k_tlas_w5, 12);
+    else TBVH_LT(k_tlas_w5, 12);                        // 3: nested loops at 5 waves per SIMD, 12-entry LDS stack top
 #undef TBVH_LT
 }
 

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--side", type=int, default=10)
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--random", type=int, default=0, help="also trace this many incoherent rays (random origins and directions inside the grid)")
     a = ap.parse_args()
     verts, label = scenes.get("dragon")
     ctx = tb.Context(0)
@@ -71,6 +72,34 @@ def main():
         ms = ctx.time_last_ms()
         print(f"frame {f}: DEVICE TLAS rebuild: host call {t_call * 1e3:.3f} ms (returns before the GPU is done), until done {t_sync * 1e3:.3f} ms, "
               f"device time {ms_build:.3f} ms; trace {ms:.3f} ms = {n / ms / 1e3:.1f} MRays/s", flush=True)
+    if a.variant == 12:
+        import ctypes as C
+        st = (C.c_uint64 * 8)()
+        tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+        tot = max(sum(int(x) for x in st), 1)
+        print("   camera rays: generation cohesion histogram (<.25 -.375 -.5 -.6 -.7 -.8 -.9 >=.9): " + " ".join(f"{int(x) / tot:.3f}" for x in st), flush=True)
+    if a.random:
+        m = a.random
+        rr = R.random_rays(m, (-1.0, -1.0, -1.0), (ext, ext, ext), seed=9)
+        d_rr = ctx.malloc(m * 64); ctx.to_device(d_rr, rr)
+        d_occ = ctx.malloc(m)
+        ms = []
+        for k in range(4):
+            tlas.intersect_device_fresh(d_rr, m, 1e30); t = ctx.time_last_ms()
+            if k:
+                ms.append(t)
+        mo = []
+        for k in range(4):
+            tlas.occluded_device(d_rr, m, d_occ); t = ctx.time_last_ms()
+            if k:
+                mo.append(t)
+        if a.variant == 12:
+            import ctypes as C
+            st = (C.c_uint64 * 8)()
+            tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+            tot = max(sum(int(x) for x in st), 1)
+            print("   incoherent: generation cohesion histogram (<.25 -.375 -.5 -.6 -.7 -.8 -.9 >=.9): " + " ".join(f"{int(x) / tot:.3f}" for x in st), flush=True)
+        print(f"incoherent: {m} random rays: Intersect {np.mean(ms):.3f} ms = {m / np.mean(ms) / 1e3:.1f} MRays/s, IsOccluded {np.mean(mo):.3f} ms = {m / np.mean(mo) / 1e3:.1f} MRays/s", flush=True)
     hits = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(hits, d_rays)
     print("hit fraction", float((hits["t"] < 1e30).mean()), "distinct instances hit", len(np.unique(hits["inst"][hits["t"] < 1e30])))
     ctx.close()
