@@ -178,6 +178,53 @@ def main():
         except Exception as e:
             log(f"[bench] device refit / build failed: {e!r}")
 
+    # BASELINE config 5 next to the headline number (outside the timed steps, rank 0 only): 1000 instances of the Dragon
+    # stand-in (10 x 10 x 10 grid, scale 0.07, seeded rotation), 3840 x 2160 camera rays per frame through the TLAS, the
+    # TLAS rebuilt on the device from new transforms every frame; plus the same number of incoherent rays
+    tlas_detail = None
+    if rank == 0:
+        try:
+            dv, dlabel = scenes.get("dragon")
+            blas = tb.BVH4_GPU(ctx).Build(dv)
+            side, scale = 10, 0.7
+
+            def frame_instances(t):
+                g = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+                ang = (t * 0.5 + np.arange(g.shape[0]) * 0.37).astype(np.float32)
+                c_, s_ = np.cos(ang), np.sin(ang)
+                T = np.zeros((g.shape[0], 4, 4), np.float32)
+                T[:, 0, 0] = c_ * scale; T[:, 0, 2] = s_ * scale; T[:, 1, 1] = scale; T[:, 2, 0] = -s_ * scale; T[:, 2, 2] = c_ * scale; T[:, 3, 3] = 1
+                T[:, :3, 3] = g * 2.0
+                return tb.make_instances(T, np.zeros(g.shape[0], np.uint32))
+            W_, H_ = 3840, 2160
+            nt = W_ * H_
+            ext = 2.0 * side
+            tcam = R.camera((-0.6 * ext, 0.8 * ext, -0.9 * ext), (0.62, -0.38, 0.68), W_, H_, 1, 1)
+            d_tr = ctx.malloc(nt * 64)
+            ctx.generate_primary(tcam, d_tr, 0, nt)
+            tlas = tb.TLAS(ctx).Build(frame_instances(0.0), [blas])
+            ms_trace, ms_rebuild = [], []
+            for f in range(4):
+                tlas.RebuildOnDevice(np.ascontiguousarray(frame_instances(float(f))["transform"]))
+                rb = ctx.time_last_ms()
+                tlas.intersect_device_fresh(d_tr, nt, 1e30)
+                if f:
+                    ms_rebuild.append(rb); ms_trace.append(ctx.time_last_ms())
+            rr = R.random_rays(1 << 22, (-1.0, -1.0, -1.0), (ext, ext, ext), seed=9)
+            ctx.to_device(d_tr, rr)
+            ms_inc = []
+            for f in range(3):
+                tlas.intersect_device_fresh(d_tr, rr.shape[0], 1e30)
+                if f:
+                    ms_inc.append(ctx.time_last_ms())
+            tlas_detail = {"instances": side ** 3, "blas": dlabel, "blas_layout": "BVH4_GPU", "camera_rays": nt,
+                           "camera_mrays": nt / float(np.mean(ms_trace)) / 1e3, "trace_ms": float(np.mean(ms_trace)),
+                           "device_tlas_rebuild_ms": float(np.mean(ms_rebuild)),
+                           "incoherent_rays": int(rr.shape[0]), "incoherent_mrays": rr.shape[0] / float(np.mean(ms_inc)) / 1e3}
+            ctx.free(d_tr); tlas.free(); blas.free()
+        except Exception as e:
+            log(f"[bench] TLAS configuration failed: {e!r}")
+
     # ---- results (rank 0) ---------------------------------------------------------------------------
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
@@ -189,6 +236,7 @@ def main():
         detail["primary_plus_diffuse_kernel_mrays"] = 2 * n / ((mean["primary"] + mean["diffuse"]) * 1e-3) / 1e6
         detail["wavefront_frame_3_bounces"] = wf_detail
         detail["device_side_ops"] = dev_ops
+        detail["tlas_1000_instances"] = tlas_detail
 
         # roofline of the dominant kernel (CWBVH Intersect on the diffuse batch): algorithmic
         # bytes per ray = 64 (ray in) + 16 (hit out) + node_bytes*S + tri_bytes*T, SURVEY.md
