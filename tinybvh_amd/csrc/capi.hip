@@ -877,21 +877,22 @@ int tbvh_set_variant(tbvh_scene* s, int v) {
     tbvh_context* c = s->ctx;
     if (int r = setDevice(c)) return r;
     // experimental kernels run on derived node layouts, built on first use
-    if (v == 47 && !s->nodes128) {
+    const bool cw = s->layout == TBVH_LAYOUT_CWBVH && !s->isTlas;
+    if (cw && v == 47 && !s->nodes128) {
         HIP_TRY(hipMalloc((void**)&s->nodes128, (size_t)s->nNodes * 128));
         launch_cwbvh_pad(s->nodes, s->nodes128, s->nNodes, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
         s->bytes += (uint64_t)s->nNodes * 128;
     }
-    if (v >= 20 && v < 30 && !s->nodesH) {
+    if (cw && v >= 20 && v < 30 && !s->nodesH) {
         HIP_TRY(hipMalloc((void**)&s->nodesH, (size_t)s->nNodes * 128));
         launch_cwbvh_relayout(s->nodes, s->nodesH, s->nNodes, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
         s->bytes += (uint64_t)s->nNodes * 128;
     }
-    if (v >= 30 && v < 40 && !s->nodesP) {
+    if (cw && v >= 30 && v < 40 && !s->nodesP) {
         std::vector<Vec4> in((size_t)s->nNodes * 5), pr;
         HIP_TRY(hipMemcpy(in.data(), s->nodes, in.size() * 16, hipMemcpyDeviceToHost));
         reorder_cwbvh_priority(in.data(), s->nNodes, pr);

@@ -649,6 +649,8 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
     else if (variant == 6) TBVH_LT(k_tlas_flat_w6, 12, 16, 32, true);   // flat loop under the lockstep governor
     else if (variant == 7) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);         // flat loop, per-lane replacement throughout
     else if (variant == 9) TBVH_LT(k_tlas_flat_w6, 12, 64, 16);         // flat loop, lockstep throughout
+    // flat-loop parameters swept without effect beyond +-3 %: phase threshold 24 / 40 / 48, refill threshold 8 / 24 / 32 (8: incoherent
+    // rays +3 %, camera rays -3 %), register budgets of 5 waves per SIMD or the compiler's own (-8 %, -2 %), 8- / 16-entry LDS stack top (0 %, -12 %)
     else if (variant == 12) TBVH_LT(k_tlas_adaptive, 12, 128, 1);        // statistics: cohesion histogram of the nested loops
     else if (variant == 13) TBVH_LT(k_tlas_adaptive, 12, 96);
     else if (variant == 14) TBVH_LT(k_tlas_adaptive, 12, 128);
