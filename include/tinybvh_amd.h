@@ -99,7 +99,9 @@ int tbvh_upload_cwbvh(tbvh_context* ctx, const void* nodes16, uint64_t n_node_bl
 
 /* TLAS in BVH_GPU format over BLASInstance records (tiny_bvh.h:1443-1457, 192 bytes
  * each) — replaces the uploads of tiny_bvh_gpu2.cpp:122-130.  blas[i] is the scene for
- * BLASInstance::blasIdx == i.  tlas_idx = tlas.bvh.primIdx (instance indices). */
+ * BLASInstance::blasIdx == i.  tlas_idx = tlas.bvh.primIdx (instance indices).
+ * The BLASes may be BVH8_CWBVH, BVH4_GPU or BVH_GPU scenes, also mixed within one TLAS (as traverse_tlas.cl:50-72
+ * selects the BLAS traversal per instance through blasDesc[].blasType). */
 int tbvh_upload_tlas(tbvh_context* ctx, const void* tlas_nodes64, uint64_t n_nodes,
                      const uint32_t* tlas_idx, uint64_t n_idx,
                      const void* instances192, uint64_t n_instances,

@@ -123,9 +123,44 @@ def test_every_tlas_kernel_gives_the_same_records(ctx, oracle, layout, variant, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layouts", [(tb.LAYOUT_BVH_GPU,), (tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH_GPU), (tb.LAYOUT_CWBVH, tb.LAYOUT_BVH_GPU),
+                                     (tb.LAYOUT_BVH4_GPU, tb.LAYOUT_CWBVH, tb.LAYOUT_BVH_GPU)])
+def test_bvh_gpu_blases_and_mixed_blas_layouts(ctx, oracle, layouts):
+    """traverse_tlas.cl:50-72 picks the BLAS traversal per instance (blasDesc[].blasType: CWBVH for static geometry,
+    Aila-Laine BVH_GPU for dynamic / rigid meshes).  Same here: a TLAS may mix BVH8_CWBVH, BVH4_GPU and BVH_GPU BLASes."""
+    meshes = [scenes.blob(4000, seed=3), scenes.soup(1500, seed=9, extent=1.6, size=0.25), scenes.blob(2500, seed=8)]
+    meshes[1][:, :3] -= 0.8
+    blas = [tb.LAYOUT_CLASSES[l](ctx).Build(meshes[i]) for i, l in enumerate(layouts)]
+    inst = grid_instances(4, 0.55, 5, n_blas=len(blas))
+    inst["mask"][::7] = 0x0002
+    tlas = tb.TLAS(ctx).Build(inst, blas)
+    rays = R.random_rays(40_000, (-2, -2, -2), (8, 8, 8), seed=16)
+    rays["mask"][::4] = 0x00F1
+    want = oracle_tlas(oracle, tlas, blas, rays)
+    got = tlas.Intersect(rays.copy())
+    c = check(got, want)
+    assert c["hits"] > 3000
+    for k in range(len(blas)):                                  # every BLAS of the mix is actually hit
+        hit = got["t"] < 1e30
+        assert np.any(inst["blasIdx"][got["inst"][hit]] == k), k
+    occ = tlas.IsOccluded(rays.copy())
+    assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+    cam = R.camera((-4.0, 9.0, -6.0), (0.55, -0.45, 0.7), 256, 128, 1, 1)
+    cr = R.primary(cam)
+    check(tlas.Intersect(cr.copy()), oracle_tlas(oracle, tlas, blas, cr))
+    # the device-side TLAS rebuild and a refit of a BVH_GPU BLAS keep working under the mix
+    tlas.RebuildOnDevice()
+    check(tlas.Intersect(rays.copy()), want)
+
+
+@pytest.mark.gpu
 def test_tlas_rejects_bad_input(ctx):
     verts = scenes.soup(500, seed=1)
-    b2 = tb.BVH_GPU(ctx).Build(verts)
+    b = tb.BVH8_CWBVH(ctx).Build(verts)
     inst = grid_instances(2, 0.5, 1)
+    tlas = tb.TLAS(ctx).Build(inst, [b])
+    with pytest.raises(tb.TbvhError, match="TLAS"):      # a TLAS cannot be a BLAS
+        tb.TLAS(ctx).Upload(tlas.host.blob(0, np.uint32, 16), tlas.host.blob(1, np.uint32, 1), inst.copy(), [tlas])
+    bad = inst.copy(); bad["blasIdx"][3] = 7
     with pytest.raises(tb.TbvhError):
-        tb.TLAS(ctx).Build(inst, [b2])   # BVH_GPU BLASes are not supported under a TLAS
+        tb.TLAS(ctx).Build(bad, [b])                     # blasIdx out of range

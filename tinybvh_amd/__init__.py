@@ -400,7 +400,7 @@ class TLAS(_Scene):
 
     def Build(self, instances: np.ndarray, blas: list) -> "TLAS":
         """instances: INSTANCE_DTYPE array with transform/blasIdx/mask set (updated in place);
-        blas: uploaded BLAS scenes (all BVH8_CWBVH or all BVH4_GPU) built with .Build()."""
+        blas: uploaded BLAS scenes (BVH8_CWBVH, BVH4_GPU or BVH_GPU, also mixed) built with .Build()."""
         assert instances.dtype == INSTANCE_DTYPE and instances.flags["C_CONTIGUOUS"]
         bounds = np.zeros((len(blas), 6), np.float32)
         for i, b in enumerate(blas):

@@ -538,10 +538,10 @@ int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, cons
     for (uint64_t i = 0; i < nBlas; i++) {
         const tbvh_scene* b = blas[i];
         if (!b || b->ctx != c || b->isTlas) return fail(TBVH_E_INVALID, "BLAS %llu is null, a TLAS, or from another context", (unsigned long long)i);
-        if (b->layout != TBVH_LAYOUT_CWBVH && b->layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "BLAS %llu: layout %d is not supported under a TLAS (use BVH8_CWBVH or BVH4_GPU)", (unsigned long long)i, b->layout);
-        if (layout && b->layout != layout) return fail(TBVH_E_INVALID, "all BLASes of a TLAS must share one layout");
-        layout = b->layout;
-        desc[i].nodes = b->nodes; desc[i].tris = b->tris; desc[i].opmap = b->opmap; desc[i].opmapN = b->opmapN; desc[i].pad = 0;
+        if (b->layout != TBVH_LAYOUT_CWBVH && b->layout != TBVH_LAYOUT_BVH4_GPU && b->layout != TBVH_LAYOUT_BVH_GPU)
+            return fail(TBVH_E_INVALID, "BLAS %llu: layout %d cannot be a BLAS", (unsigned long long)i, b->layout);
+        layout = i == 0 ? b->layout : (layout == b->layout ? layout : 0);   // 0: the BLASes mix layouts (traverse_tlas.cl:50-72)
+        desc[i].nodes = b->nodes; desc[i].tris = b->tris; desc[i].opmap = b->opmap; desc[i].opmapN = b->opmapN; desc[i].layout = (uint32_t)b->layout;
     }
     const BLASInstanceCheck* ic = (const BLASInstanceCheck*)inst;
     for (uint64_t i = 0; i < nInst; i++) if (ic[i].blasIdx >= nBlas) return fail(TBVH_E_FORMAT, "instance %llu: blasIdx %u out of range", (unsigned long long)i, ic[i].blasIdx);

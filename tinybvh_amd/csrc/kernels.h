@@ -17,7 +17,7 @@ void launch_cwbvh_h(bool anyhit, int variant, const char* nodesH, const float4* 
 void launch_cwbvh_relayout(const float4* src, char* dst, uint32_t nNodes, hipStream_t s);
 void launch_cwbvh_c(bool anyhit, int variant, const float4* nodes, const float4* tris, uint32_t nNodes, const QueryArgs& q,
                     uint32_t* status, uint32_t blocks, hipStream_t s);
-struct BlasDesc { const float4* nodes; const float4* tris; const uint32_t* opmap; uint32_t opmapN; uint32_t pad; };  // one per BLAS of a TLAS
+struct BlasDesc { const float4* nodes; const float4* tris; const uint32_t* opmap; uint32_t opmapN; uint32_t layout; };  // one per BLAS of a TLAS (layout: TBVH_LAYOUT_*)
 void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances,
                  const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
 // device TLAS rebuild (kernels_tlasbuild.hip)

@@ -303,9 +303,11 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
     float3 O = make_float3(0, 0, 0), D = O, rD = O;      // the ray in the CURRENT space (world, or the instance's)
     float4 hit = make_float4(0, 0, 0, 0);
     uint32_t hitInst = 0, rayMask = 0, mode = M_TLAS, node = 0, leafNext = 0, leafEnd = 0, curInst = 0, blasIdx = 0;
+    uint32_t blay = (uint32_t)BLAS_LAYOUT;   // layout of the BLAS being traversed; BLAS_LAYOUT == 0: per instance (BlasDesc::layout)
     int base = 0;
     GlobalF4 bnodes, btris;
-    // BVH4_GPU BLAS state (kernels_query.hip: k_bvh4)
+    // BVH4_GPU BLAS state (kernels_query.hip: k_bvh4); a BVH_GPU BLAS reuses offset (node), leafCnt (triangles left) and
+    // leafQ0 (next triangle record) as k_bvh2's node / triLeft / triPtr
     uint32_t offset = 0, leafQ0 = 0, leafQ1 = 0, leafQ2 = 0, leafQ3 = 0, leafCnt = 0, leafCntB = 0;
     // CWBVH BLAS state (kernels_cwbvh.hip: k_cwbvh)
     uint32_t oct = 0;
@@ -344,7 +346,8 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
 
         if (mode == M_BLAS) { if (runC) {
             bool pop = false;   // this lane's BLAS step ended with nothing pending: take the next stack entry (or leave the BLAS)
-            if (BLAS_LAYOUT == 9) {
+            const uint32_t lay = BLAS_LAYOUT ? (uint32_t)BLAS_LAYOUT : blay;
+            if (lay == 9) {
                 if (tg.y != 0) {   // one triangle
                     const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
                     tg.y &= ~(1u << ti);
@@ -413,7 +416,7 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
                         if (ng.y <= 0x00FFFFFFu) { tg = ng; ng = make_uint2(0u, 0u); }   // a postponed triangle group
                     }
                 }
-            } else {
+            } else if (lay == 6) {
                 if (leafCnt != 0) {   // one triangle of the pending leaves
                     const uint32_t ta = leafQ0;
                     const float4 v0 = bnodes[ta], e1 = bnodes[ta + 1], e2 = bnodes[ta + 2];
@@ -475,6 +478,51 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
                     if (st.sp == base) mode = M_INST;
                     else offset = st.pop().x;
                 }
+            } else {   // BVH_GPU (Aila-Laine 2-wide) BLAS: nodes 4 x float4, triangles gathered {v0|prim, e1, e2} (kernels_query.hip: k_bvh2)
+                if (leafCnt != 0) {   // one triangle of the current leaf
+                    const float4 v0 = btris[leafQ0], e1 = btris[leafQ0 + 1], e2 = btris[leafQ0 + 2];
+                    leafQ0 += 3u; leafCnt -= 1u;
+                    TriHit h;
+                    if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                        const BlasDesc bd = blas[blasIdx];
+                        if (!bd.opmap || omm_opaque(Omm{bd.opmap, bd.opmapN}, as_u32(v0.w), h.u, h.v)) {
+                            found = true; hitInst = curInst;
+                            if (ANYHIT) done = true;
+                            else hit = make_float4(h.t, h.u, h.v, v0.w);
+                        }
+                    }
+                    if (!done && leafCnt == 0) pop = true;
+                } else {   // one node
+                    const float4 n0 = bnodes[offset * 4], n1 = bnodes[offset * 4 + 1], n2 = bnodes[offset * 4 + 2], n3 = bnodes[offset * 4 + 3];
+                    const uint32_t triCount = as_u32(n2.w);
+                    if (triCount) { leafCnt = triCount; leafQ0 = as_u32(n3.w) * 3u; }
+                    else {
+                        const float3 ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z);
+                        const float lx1 = __builtin_fmaf(n0.x, rD.x, -ro.x), lx2 = __builtin_fmaf(n1.x, rD.x, -ro.x);
+                        const float ly1 = __builtin_fmaf(n0.y, rD.y, -ro.y), ly2 = __builtin_fmaf(n1.y, rD.y, -ro.y);
+                        const float lz1 = __builtin_fmaf(n0.z, rD.z, -ro.z), lz2 = __builtin_fmaf(n1.z, rD.z, -ro.z);
+                        const float rx1 = __builtin_fmaf(n2.x, rD.x, -ro.x), rx2 = __builtin_fmaf(n3.x, rD.x, -ro.x);
+                        const float ry1 = __builtin_fmaf(n2.y, rD.y, -ro.y), ry2 = __builtin_fmaf(n3.y, rD.y, -ro.y);
+                        const float rz1 = __builtin_fmaf(n2.z, rD.z, -ro.z), rz2 = __builtin_fmaf(n3.z, rD.z, -ro.z);
+                        const float tminL = __builtin_fmaxf(fmax3(__builtin_fminf(lx1, lx2), __builtin_fminf(ly1, ly2), __builtin_fminf(lz1, lz2)), 0.0f);
+                        const float tmaxL = __builtin_fminf(fmin3(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2), __builtin_fmaxf(lz1, lz2)), hit.x);
+                        const float tminR = __builtin_fmaxf(fmax3(__builtin_fminf(rx1, rx2), __builtin_fminf(ry1, ry2), __builtin_fminf(rz1, rz2)), 0.0f);
+                        const float tmaxR = __builtin_fminf(fmin3(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2), __builtin_fmaxf(rz1, rz2)), hit.x);
+                        const bool hL = tmaxL >= tminL, hR = tmaxR >= tminR;
+                        uint32_t l = as_u32(n0.w), r = as_u32(n1.w);
+                        if (hL && hR) {
+                            if (tminL > tminR) { const uint32_t t = l; l = r; r = t; }
+                            st.push(make_uint2(r, 0u));
+                            offset = l;
+                        } else if (hL) offset = l;
+                        else if (hR) offset = r;
+                        else pop = true;
+                    }
+                }
+                if (pop) {
+                    if (st.sp == base) mode = M_INST;
+                    else offset = st.pop().x;
+                }
             }
             if (mode == M_INST && !done) {   // back in world space: the ray as the caller gave it
                 const RayRec* rp = q.rays + ri;
@@ -505,7 +553,8 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
                     const BlasDesc bd = blas[blasIdx];
                     bnodes = GlobalF4(bd.nodes); btris = GlobalF4(bd.tris);
                     curInst = ii; base = st.sp; mode = M_BLAS;
-                    if (BLAS_LAYOUT == 9) {
+                    if (BLAS_LAYOUT == 0) blay = bd.layout;
+                    if ((BLAS_LAYOUT ? (uint32_t)BLAS_LAYOUT : blay) == 9) {
                         oct = 7u - ((D.x < 0 ? 4u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 1u : 0u));
                         ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
                     } else { offset = 0; leafCnt = 0; leafCntB = 0; }
@@ -642,6 +691,17 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
     // CWBVH BLASes: the flat loop wins on both; BVH4_GPU BLASes: the nested loops are 24 % faster on camera rays and 2.5 x
     // slower on incoherent ones, so every wave starts nested and moves to the flat loop once the lane cohesion of a
     // 64-ray generation falls below 0.375 (camera rays: 99 % of the generations above 0.5; random rays: all below 0.375).
+    // BVH_GPU BLASes and TLASes that mix BLAS layouts (as traverse_tlas.cl:50-72 allows: blasDesc[].blasType) exist in the flat loop only
+    if (blasLayout == 4 || blasLayout == 0) {
+        if (blasLayout == 4) {
+            if (anyhit) hipLaunchKernelGGL((k_tlas_flat_w6<true, 4, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
+            else hipLaunchKernelGGL((k_tlas_flat_w6<false, 4, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
+        } else {
+            if (anyhit) hipLaunchKernelGGL((k_tlas_flat_w5<true, 0, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
+            else hipLaunchKernelGGL((k_tlas_flat_w5<false, 0, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
+        }
+        return;
+    }
     if (variant == 0) {
         if (blasLayout == 9) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);
         else TBVH_LT(k_tlas_adaptive, 12, 96);
