@@ -139,14 +139,18 @@ __device__ __forceinline__ void blas_bvh4(const GlobalF4 data, RayL& r, StackT<L
         const uint32_t qy0 = as_u32(d2.x), qy1 = as_u32(d2.y), qz0 = as_u32(d2.z), qz1 = as_u32(d2.w);
         float dist[4];
         uint32_t info[4] = { as_u32(d3.x), as_u32(d3.y), as_u32(d3.z), as_u32(d3.w) };
+        const bool ngx = sx < 0.f, ngy = sy < 0.f, ngz = sz < 0.f;   // near / far plane words by the sign of the direction (as k_bvh4)
+        const uint32_t nx = ngx ? qx1 : qx0, fx = ngx ? qx0 : qx1;
+        const uint32_t ny = ngy ? qy1 : qy0, fy = ngy ? qy0 : qy1;
+        const uint32_t nz = ngz ? qz1 : qz0, fz = ngz ? qz0 : qz1;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int sh = 8 * i;
-            const float x1 = __builtin_fmaf((float)((qx0 >> sh) & 255), sx, bx), x2 = __builtin_fmaf((float)((qx1 >> sh) & 255), sx, bx);
-            const float y1 = __builtin_fmaf((float)((qy0 >> sh) & 255), sy, by), y2 = __builtin_fmaf((float)((qy1 >> sh) & 255), sy, by);
-            const float z1 = __builtin_fmaf((float)((qz0 >> sh) & 255), sz, bz), z2 = __builtin_fmaf((float)((qz1 >> sh) & 255), sz, bz);
-            const float tmin = __builtin_fmaxf(fmax3(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2), __builtin_fminf(z1, z2)), 0.0f);
-            const float tmax = __builtin_fminf(fmin3(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2), __builtin_fmaxf(z1, z2)), r.hit.x);
+            const float x1 = __builtin_fmaf((float)((nx >> sh) & 255), sx, bx), x2 = __builtin_fmaf((float)((fx >> sh) & 255), sx, bx);
+            const float y1 = __builtin_fmaf((float)((ny >> sh) & 255), sy, by), y2 = __builtin_fmaf((float)((fy >> sh) & 255), sy, by);
+            const float z1 = __builtin_fmaf((float)((nz >> sh) & 255), sz, bz), z2 = __builtin_fmaf((float)((fz >> sh) & 255), sz, bz);
+            const float tmin = __builtin_fmaxf(fmax3(x1, y1, z1), 0.0f);
+            const float tmax = __builtin_fminf(fmin3(x2, y2, z2), r.hit.x);
             dist[i] = (tmin > tmax || info[i] == 0) ? kFar : tmin;
         }
 #define TBVH_CSWAP(a, b) if (dist[a] < dist[b]) { const float tf = dist[a]; dist[a] = dist[b]; dist[b] = tf; const uint32_t tu = info[a]; info[a] = info[b]; info[b] = tu; }
