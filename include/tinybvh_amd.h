@@ -287,6 +287,10 @@ void tbvh_wavefront_destroy(tbvh_wavefront* wf);
  * asynchronous); when given, the call synchronizes and fills it. */
 int  tbvh_wavefront_render(tbvh_wavefront* wf, tbvh_scene* scene, const void* d_verts16, const tbvh_camera* cam,
                            const tbvh_wf_params* params, tbvh_wf_stats* stats);
+/* TLAS scenes (the path tracer of tiny_bvh_gpu2.cpp / wavefront2.cl): one device vertex array per BLAS, in blasIdx order
+ * (wavefront2.cl:183 picks bistroVerts / dragonVerts by instance); tbvh_wavefront_render then takes the TLAS scene and
+ * ignores d_verts16.  Normals go to world space through the instance's inverse transform. */
+int  tbvh_wavefront_set_blas_vertices(tbvh_wavefront* wf, const void* const* d_verts16_per_blas, uint64_t n_blas);
 /* copy the float RGBA accumulator (width * height * 4 floats, row-major) to the host */
 int  tbvh_wavefront_read(tbvh_wavefront* wf, float* rgba);
 /* Finalize (wavefront.cl:275-286): accumulator * scale, square root, 8 bits per channel: width * height x 0x00RRGGBB */

@@ -233,3 +233,76 @@ def test_one_diffuse_bounce_flag_is_the_references_path_length(ctx):
     assert b["extend_rays"][:2] == a["extend_rays"][:2] and b["extend_rays"][2:] == [0, 0]
     assert b["shadow_rays"][:2] == a["shadow_rays"][:2] and b["shadow_rays"][2:] == [0, 0]
     wf.close(); ctx.free(d)
+
+
+# ---- the path tracer over a TLAS (tiny_bvh_gpu2.cpp / wavefront2.cl): vertices per BLAS, normals through the instance ----
+
+def rot(axis, deg):
+    a = np.deg2rad(deg); c, s = np.cos(a), np.sin(a)
+    M = np.eye(4, dtype=np.float32)
+    i, j = {"x": (1, 2), "y": (2, 0), "z": (0, 1)}[axis]
+    M[i, i] = c; M[i, j] = -s; M[j, i] = s; M[j, j] = c
+    return M
+
+
+def test_tlas_scene_area_light_through_instances(ctx):
+    """The MIS test again, but floor and lamp are instances: the lamp BLAS is a 5 x 9 rectangle at its local origin,
+    turned 90 degrees about y and lifted by its instance transform into the 9 x 5 rectangle the light sampling assumes;
+    the floor BLAS is a unit quad scaled 120 x 1 x 60."""
+    W = H = 128
+    hgt, sx, sz, Le, rho = 4.0, 9.0, 5.0, np.array([6.0, 5.0, 4.0]), np.array([0xC0, 0xC0, 0x60]) * 0.00392
+    floor = quad((-0.5, 0, -0.5), (1, 0, 0), (0, 0, 1), (tb.MATERIAL_DIFFUSE << 24) | 0xC0C060)
+    lamp = quad((-sz / 2, 0, -sx / 2), (0, 0, sx), (sz, 0, 0), (tb.MATERIAL_LIGHT << 24) | 0xFFFFFF)
+    blas = [tb.BVH8_CWBVH(ctx).Build(floor), tb.BVH_GPU(ctx).Build(lamp)]            # mixed BLAS layouts while we are at it
+    T = np.stack([np.diag([120.0, 1.0, 60.0, 1.0]).astype(np.float32), rot("y", 90.0)])
+    T[1, 1, 3] = hgt
+    inst = tb.make_instances(T, np.array([0, 1], np.uint32))
+    tlas = tb.TLAS(ctx).Build(inst, blas)
+    dv = []
+    for v in (floor, lamp):
+        d = ctx.malloc(v.nbytes); ctx.to_device(d, v); dv.append(d)
+    wf = tb.Wavefront(ctx, W, H)
+    wf.set_blas_vertices(dv)
+    cam = down_camera((0.0, 1.0, 0.0), 0.02, W, H)
+    frames = 24
+    for f in range(frames):
+        wf.render(tlas, 0, cam, (0, hgt, 0), tuple(Le), sky_lo=(0, 0, 0), sky_hi=(0, 0, 0), eps=1e-3, max_depth=2, seed=41 + f, clear=(f == 0),
+                  light_size=(sx, sz), stats=False)
+    got = wf.read()[..., :3].reshape(-1, 3).astype(np.float64).mean(0) / frames
+    m = 600
+    xs = (np.arange(m) + 0.5) / m * sx - sx / 2; zs = (np.arange(m) + 0.5) / m * sz - sz / 2
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    d2 = X * X + Z * Z + hgt * hgt
+    E = (hgt * hgt / (d2 * d2)).sum() * (sx / m) * (sz / m)
+    want = rho / np.pi * Le * E
+    assert np.all(np.abs(got - want) < 0.02 * want), (got, want)
+    wf.close()
+    for d in dv:
+        ctx.free(d)
+
+
+def test_tlas_scene_tilted_mirror_instance(ctx):
+    """A mirror quad tilted 25 degrees about z by its instance transform (and scaled non-uniformly): the reflected sky
+    colour follows the WORLD normal, i.e. the local normal through the transpose of the inverse transform."""
+    W = H = 64
+    mirror = quad((-0.5, 0, -0.5), (1, 0, 0), (0, 0, 1), (tb.MATERIAL_SPECULAR << 24) | 0xFFFFFF)
+    blas = [tb.BVH4_GPU(ctx).Build(mirror)]
+    M = rot("z", 25.0) @ np.diag([80.0, 3.0, 40.0, 1.0]).astype(np.float32)
+    inst = tb.make_instances(M[None].astype(np.float32), np.array([0], np.uint32))
+    tlas = tb.TLAS(ctx).Build(inst, blas)
+    d = ctx.malloc(mirror.nbytes); ctx.to_device(d, mirror)
+    wf = tb.Wavefront(ctx, W, H)
+    wf.set_blas_vertices([d])
+    cam = down_camera((0.0, 6.0, 0.0), 0.05, W, H)
+    lo, hi = (0.9, 0.5, 0.1), (0.1, 0.3, 0.8)
+    st = wf.render(tlas, 0, cam, (0, 9, 0), (1, 1, 1), sky_lo=lo, sky_hi=hi, max_depth=2, seed=2)
+    img = wf.read()[..., :3].reshape(-1, 3).astype(np.float64)
+    assert st["extend_rays"] == [W * H, W * H] and st["shadow_rays"] == [0, 0]
+    N = (rot("z", 25.0)[:3, :3] @ np.array([0.0, 1.0, 0.0]))                       # world normal of the tilted plane
+    Dc = np.array([0.0, -1.0, 0.0])                                                 # the narrow camera looks straight down
+    Rc = Dc - 2.0 * N * (N @ Dc)
+    k = 0.5 * (Rc[1] + 1.0)
+    want = np.array(lo) + k * (np.array(hi) - np.array(lo))
+    assert np.abs(img.mean(0) - want).max() < 0.01, (img.mean(0), want)            # +- the 0.05 field of view
+    assert img.std(0).max() < 0.02
+    wf.close(); ctx.free(d)

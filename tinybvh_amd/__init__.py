@@ -493,7 +493,7 @@ class Wavefront:
         p.eps, p.max_depth, p.seed, p.clear = float(eps), int(max_depth), int(seed), int(clear)
         p.light_size[:] = [float(x) for x in light_size]; p.flags = 1 if one_diffuse_bounce else 0
         st = _capi.WfStats()
-        check(lib.tbvh_wavefront_render(self._h, scene._h, C.c_void_p(d_verts), C.byref(cam), C.byref(p), C.byref(st) if stats else None), "tbvh_wavefront_render")
+        check(lib.tbvh_wavefront_render(self._h, scene._h, C.c_void_p(d_verts) if d_verts else None, C.byref(cam), C.byref(p), C.byref(st) if stats else None), "tbvh_wavefront_render")
         if not stats:
             return None
         return {"extend_rays": [int(x) for x in st.extend_rays[:max_depth]], "shadow_rays": [int(x) for x in st.shadow_rays[:max_depth]], "frame_ms": float(st.frame_ms)}
@@ -502,6 +502,11 @@ class Wavefront:
         img = np.zeros((self.height, self.width, 4), np.float32)
         check(lib.tbvh_wavefront_read(self._h, _ptr(img)), "tbvh_wavefront_read")
         return img
+
+    def set_blas_vertices(self, d_verts_per_blas: list) -> None:
+        """TLAS scenes: the device vertex array of every BLAS, in blasIdx order (tbvh_wavefront_set_blas_vertices)."""
+        arr = (C.c_void_p * len(d_verts_per_blas))(*[int(p) for p in d_verts_per_blas])
+        check(lib.tbvh_wavefront_set_blas_vertices(self._h, arr, len(d_verts_per_blas)), "tbvh_wavefront_set_blas_vertices")
 
     def finalize(self, scale: float = 1.0) -> np.ndarray:
         """Finalize of wavefront.cl:275-286: (height, width) uint32 0x00RRGGBB."""

@@ -40,6 +40,7 @@ SYMBOLS = {
     "tbvh_wavefront_destroy": (None, [_vp]),
     "tbvh_wavefront_render": (_i, [_vp, _vp, _vp, C.POINTER(Camera), C.POINTER(WfParams), C.POINTER(WfStats)]),
     "tbvh_wavefront_read": (_i, [_vp, _vp]),
+    "tbvh_wavefront_set_blas_vertices": (_i, [_vp, _vp, _u64]),
     "tbvh_wavefront_finalize": (_i, [_vp, C.c_float, _vp]),
     "tbvh_abi_version": (_i, []),
     "tbvh_last_error": (C.c_char_p, []),

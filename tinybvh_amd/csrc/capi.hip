@@ -1035,6 +1035,8 @@ struct tbvh_wavefront {
     PathAux* shadowAux = nullptr;
     uint8_t* occ = nullptr;
     float* accum = nullptr;
+    const float4** blasVerts = nullptr;        // device array: vertex array of every BLAS (TLAS scenes)
+    uint64_t nBlasVerts = 0;
     unsigned long long* counters = nullptr;   // [0],[1] path queues, [2] shadow queue, [8..] per-depth history
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
@@ -1073,14 +1075,29 @@ void tbvh_wavefront_destroy(tbvh_wavefront* w) {
     if (w->occ) hipFree(w->occ);
     if (w->accum) hipFree(w->accum);
     if (w->counters) hipFree(w->counters);
+    if (w->blasVerts) hipFree((void*)w->blasVerts);
     if (w->e0) hipEventDestroy(w->e0);
     if (w->e1) hipEventDestroy(w->e1);
     delete w;
 }
 
+int tbvh_wavefront_set_blas_vertices(tbvh_wavefront* w, const void* const* dVertsPerBlas, uint64_t nBlas) {
+    if (!w || !dVertsPerBlas || !nBlas) return fail(TBVH_E_INVALID, "tbvh_wavefront_set_blas_vertices: null/empty argument");
+    if (int r = setDevice(w->ctx)) return r;
+    HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+    if (w->blasVerts) { hipFree((void*)w->blasVerts); w->blasVerts = nullptr; w->nBlasVerts = 0; }
+    HIP_TRY(hipMalloc((void**)&w->blasVerts, nBlas * sizeof(void*)));
+    HIP_TRY(hipMemcpy((void*)w->blasVerts, dVertsPerBlas, nBlas * sizeof(void*), hipMemcpyHostToDevice));
+    w->nBlasVerts = nBlas;
+    return 0;
+}
+
 int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVerts, const tbvh_camera* cam, const tbvh_wf_params* p,
                           tbvh_wf_stats* stats) {
-    if (!w || !scene || !dVerts || !cam || !p) return fail(TBVH_E_INVALID, "tbvh_wavefront_render: null argument");
+    if (!w || !scene || !cam || !p) return fail(TBVH_E_INVALID, "tbvh_wavefront_render: null argument");
+    if (scene->isTlas) {
+        if (w->nBlasVerts < scene->nBlas) return fail(TBVH_E_INVALID, "tbvh_wavefront_render: a TLAS scene needs tbvh_wavefront_set_blas_vertices (%llu BLASes)", (unsigned long long)scene->nBlas);
+    } else if (!dVerts) return fail(TBVH_E_INVALID, "tbvh_wavefront_render: null vertex array");
     if (scene->ctx != w->ctx) return fail(TBVH_E_INVALID, "scene and wavefront belong to different contexts");
     if (cam->width != w->width || cam->height != w->height) return fail(TBVH_E_INVALID, "camera size differs from the wavefront's");
     const uint32_t maxDepth = p->max_depth ? (p->max_depth > 8 ? 8 : p->max_depth) : 3;
@@ -1110,6 +1127,7 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
         a.out = w->rays[nxt]; a.auxOut = w->aux[nxt]; a.nOut = QC(nxt);
         a.shadow = w->shadow; a.shadowAux = w->shadowAux; a.nShadow = QC(2);
         a.verts = (const float4*)dVerts; a.accum = w->accum;
+        a.blasVerts = scene->isTlas ? w->blasVerts : nullptr; a.instances = scene->isTlas ? scene->instances : nullptr;
         memcpy(a.lightPos, p->light_pos, 12); memcpy(a.lightColor, p->light_color, 12); memcpy(a.skyLo, p->sky_lo, 12); memcpy(a.skyHi, p->sky_hi, 12);
         a.lightSize[0] = p->light_size[0]; a.lightSize[1] = p->light_size[1]; a.flags = p->flags;
         a.eps = p->eps; a.depth = d; a.maxDepth = maxDepth; a.seed = p->seed;

@@ -67,6 +67,7 @@ struct ShadeArgs {
     RayRec* out; PathAux* auxOut; unsigned long long* nOut;
     RayRec* shadow; PathAux* shadowAux; unsigned long long* nShadow;
     const float4* verts; float* accum;
+    const float4* const* blasVerts; const float4* instances;   // TLAS scenes: vertex array per BLAS, BLASInstance records (else nullptr)
     float lightPos[3], lightColor[3], skyLo[3], skyHi[3];
     float lightSize[2];   // extent of the rectangular light along x and z (0, 0 = point light)
     float eps; uint32_t depth, maxDepth, seed, flags;   // flags bit 0: at most one diffuse bounce per path (wavefront.cl:233)

@@ -119,7 +119,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_wf_shade(ShadeArgs a) {
             atomicAdd(&a.accum[pixel * 4 + 0], T.x * ipdf * sky.x); atomicAdd(&a.accum[pixel * 4 + 1], T.y * ipdf * sky.y); atomicAdd(&a.accum[pixel * 4 + 2], T.z * ipdf * sky.z);
         } else {
             const uint32_t prim = as_u32(r.hit.w);
-            const float4 v0 = a.verts[(uint64_t)prim * 3], v1 = a.verts[(uint64_t)prim * 3 + 1], v2 = a.verts[(uint64_t)prim * 3 + 2];
+            // geometry at the hit: a TLAS hit names the instance in byte 44 of the record (wavefront2.cl:180-186 unpacks
+            // prim | inst << 24 and picks the BLAS's vertex array); the triangle is in the instance's space
+            const float4* vb = a.verts;
+            const float4* ip = nullptr;
+            if (a.instances) {
+                ip = a.instances + (size_t)as_u32(r.rD.w) * 12;
+                vb = a.blasVerts[as_u32(ip[8].w)];
+            }
+            const float4 v0 = vb[(uint64_t)prim * 3], v1 = vb[(uint64_t)prim * 3 + 1], v2 = vb[(uint64_t)prim * 3 + 2];
             const uint32_t c = as_u32(v0.w), materialType = c >> 24;
             if (materialType == kMaterialLight) {
                 // end path on light (wavefront.cl:163-178): alone after a mirror or from the camera, else MIS with the light sampling
@@ -134,7 +142,12 @@ __global__ __launch_bounds__(kShadeBlock) void k_wf_shade(ShadeArgs a) {
             } else {
                 T = make_float3(T.x * ipdf, T.y * ipdf, T.z * ipdf);   // apply the postponed pdf (wavefront.cl:180)
                 const float3 e1 = make_float3(v1.x - v0.x, v1.y - v0.y, v1.z - v0.z), e2 = make_float3(v2.x - v0.x, v2.y - v0.y, v2.z - v0.z);
-                N = norm3(make_float3(e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x));
+                N = make_float3(e1.y * e2.z - e1.z * e2.y, e1.z * e2.x - e1.x * e2.z, e1.x * e2.y - e1.y * e2.x);
+                if (ip) {   // normal to world space: transpose of the inverse transform (rows 4..6 of the instance record)
+                    const float4 i0 = ip[4], i1 = ip[5], i2 = ip[6];
+                    N = make_float3(i0.x * N.x + i1.x * N.y + i2.x * N.z, i0.y * N.x + i1.y * N.y + i2.y * N.z, i0.z * N.x + i1.z * N.y + i2.z * N.z);
+                }
+                N = norm3(N);
                 const float nd = N.x * D.x + N.y * D.y + N.z * D.z;
                 if (nd > 0) N = make_float3(-N.x, -N.y, -N.z);
                 I = make_float3(O.x + r.hit.x * D.x, O.y + r.hit.x * D.y, O.z + r.hit.x * D.z);
