@@ -42,15 +42,21 @@ struct RayL {  // a ray in some space + its current best hit
     bool found;
 };
 
-// Lane cohesion of the nested loops, for the adaptive kernel: every loop body calls tick() — each lane counts its own
-// trips, the first active lane counts the wave's in an LDS word; at the end of a 64-ray generation
-// sum(lane trips) / (64 x wave trips) says how much of the wave the nested loops kept busy.
+// Lane cohesion of the nested loops, for the adaptive kernel: every TLAS node and every instance entry calls tick() — each
+// lane counts its own; at the end of a 64-ray generation mean / max of the lanes' counts says how evenly the wave's rays
+// worked (the busiest lane's count is the number of trips the wave made at this level).  TBVH_TLAS_TICK_LDS = 1 counts the
+// wave's trips exactly in an LDS word instead (first active lane, one ds_add per tick): same separation, 4 % slower.
+#ifndef TBVH_TLAS_TICK_LDS
+#define TBVH_TLAS_TICK_LDS 0
+#endif
 struct WaveTicks {
     TBVH_AS_LDS uint32_t* trips;
     uint32_t mine;
     __device__ __forceinline__ void tick() {
         mine++;
+#if TBVH_TLAS_TICK_LDS
         if (lane_rank(__ballot(true)) == 0) __hip_atomic_fetch_add((uint32_t*)trips, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
     }
 };
 
@@ -188,6 +194,7 @@ __device__ __forceinline__ bool tlas_body(const float4* __restrict__ tlasNodes, 
                                           const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, const QueryArgs& q,
                                           StackT<LDS_N>& st, RayPool<64>& pool, const uint64_t nRaysTotal, TBVH_AS_LDS uint32_t* ldsTrips) {
     WaveTicks tk; tk.trips = ldsTrips; tk.mine = 0;
+    uint32_t ema = 0;   // ADAPT 1: running cohesion estimate, x / 256
     for (;;) {
         // whole-wave batches here: the nested TLAS/BLAS loops keep per-lane state in registers
         uint64_t ri = 0;
@@ -273,12 +280,23 @@ __device__ __forceinline__ bool tlas_body(const float4* __restrict__ tlasNodes, 
         if (ADAPT) {
             uint32_t sum = tk.mine;
             for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+#if TBVH_TLAS_TICK_LDS
             const uint32_t trips = *ldsTrips;
+#else
+            uint32_t trips = tk.mine;   // the busiest lane's count: every TLAS node and instance entry it made was a trip of the wave
+            for (int o = 32; o > 0; o >>= 1) { const uint32_t t2 = __shfl_xor(trips, o); trips = t2 > trips ? t2 : trips; }
+#endif
             const uint32_t e = trips ? sum * 4u / trips : 256u;   // x / 256
             if (ADAPT == 2) {
                 const uint32_t b = e < 64u ? 0u : e < 96u ? 1u : e < 128u ? 2u : e < 154u ? 3u : e < 179u ? 4u : e < 205u ? 5u : e < 230u ? 6u : 7u;
                 if ((threadIdx.x & 63u) == 0) atomicAdd(q.stats + b, 1ull);
-            } else if (e < KEEP) return false;
+            } else {
+                // running estimate as in LockstepGovernor: one ragged generation among coherent ones (a wave at the edge of the
+                // image) does not send the wave to the flat loop for the rest of the launch, two in a row do; an incoherent batch
+                // leaves after its first generation
+                ema = ema ? (ema + e) >> 1 : e;
+                if (ema < KEEP) return false;
+            }
         }
     }
     return true;
@@ -689,26 +707,16 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
     } while (0)
     // Defaults (1000 instances of a 100 k-triangle BLAS; 8.3 M camera rays / 8.4 M random rays, Intersect, MRays/s):
     //                                   BVH4_GPU BLASes        CWBVH BLASes
-    //   nested loops (k_tlas_w5)        4240 /  535            3140 /  385
-    //   flat loop (k_tlas_flat_w6)      3280 / 1315            3320 / 1350
-    //   nested, then flat (adaptive)    3980 / 1300-1380       3000 /  920
-    // CWBVH BLASes: the flat loop wins on both; BVH4_GPU BLASes: the nested loops are 24 % faster on camera rays and 2.5 x
-    // slower on incoherent ones, so every wave starts nested and moves to the flat loop once the lane cohesion of a
-    // 64-ray generation falls below 0.375 (camera rays: 99 % of the generations above 0.5; random rays: all below 0.375).
-    // BVH_GPU BLASes and TLASes that mix BLAS layouts (as traverse_tlas.cl:50-72 allows: blasDesc[].blasType) exist in the flat loop only
-    if (blasLayout == 4 || blasLayout == 0) {
-        if (blasLayout == 4) {
-            if (anyhit) hipLaunchKernelGGL((k_tlas_flat_w6<true, 4, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
-            else hipLaunchKernelGGL((k_tlas_flat_w6<false, 4, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
-        } else {
-            if (anyhit) hipLaunchKernelGGL((k_tlas_flat_w5<true, 0, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
-            else hipLaunchKernelGGL((k_tlas_flat_w5<false, 0, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
-        }
-        return;
-    }
+    //   nested loops (k_tlas_w5)        4350 /  565            3140 /  385
+    //   flat loop (k_tlas_flat_w6)      3280 / 1315            3320 / 1690
+    //   nested, then flat (adaptive)    4300 / 1370            3000 /  920
+    // CWBVH BLASes: the flat loop wins on both; BVH4_GPU BLASes: the nested loops are 30 % faster on camera rays and 2.4 x
+    // slower on incoherent ones, so every wave starts nested and moves to the flat loop once its running estimate of the
+    // lane cohesion of a 64-ray generation (mean / max of the lanes' TLAS-node and instance-entry counts) falls below 0.55:
+    // camera rays: 99 % of the generations above 0.5; random rays: 99.7 % below.
     if (variant == 0) {
         if (blasLayout == 9) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);
-        else TBVH_LT(k_tlas_adaptive, 12, 96);
+        else TBVH_LT(k_tlas_adaptive, 12, 140);
     }
     else if (variant == 6) TBVH_LT(k_tlas_flat_w6, 12, 16, 32, true);   // flat loop under the lockstep governor
     else if (variant == 7) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);         // flat loop, per-lane replacement throughout
@@ -716,8 +724,8 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
     // flat-loop parameters swept without effect beyond +-3 %: phase threshold 24 / 40 / 48, refill threshold 8 / 24 / 32 (8: incoherent
     // rays +3 %, camera rays -3 %), register budgets of 5 waves per SIMD or the compiler's own (-8 %, -2 %), 8- / 16-entry LDS stack top (0 %, -12 %)
     else if (variant == 12) TBVH_LT(k_tlas_adaptive, 12, 128, 1);        // statistics: cohesion histogram of the nested loops
-    else if (variant == 13) TBVH_LT(k_tlas_adaptive, 12, 96);
-    else if (variant == 14) TBVH_LT(k_tlas_adaptive, 12, 128);
+    else if (variant == 13) TBVH_LT(k_tlas_adaptive, 12, 128);
+    else if (variant == 14) TBVH_LT(k_tlas_adaptive, 12, 154);
     else if (variant == 2) TBVH_LT(k_tlas_w5, 8);
     else if (variant == 4) TBVH_LT(k_tlas, 8);
     else if (variant == 5) TBVH_LT(k_tlas, 16);        // round-1 kernel: nested loops, compiler's register budget (4 waves per SIMD)
