@@ -714,6 +714,17 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
     // slower on incoherent ones, so every wave starts nested and moves to the flat loop once its running estimate of the
     // lane cohesion of a 64-ray generation (mean / max of the lanes' TLAS-node and instance-entry counts) falls below 0.55:
     // camera rays: 99 % of the generations above 0.5; random rays: 99.7 % below.
+    // BVH_GPU BLASes and TLASes that mix BLAS layouts (as traverse_tlas.cl:50-72 allows: blasDesc[].blasType) exist in the flat loop only
+    if (blasLayout == 4 || blasLayout == 0) {
+        if (blasLayout == 4) {
+            if (anyhit) hipLaunchKernelGGL((k_tlas_flat_w6<true, 4, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
+            else hipLaunchKernelGGL((k_tlas_flat_w6<false, 4, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
+        } else {
+            if (anyhit) hipLaunchKernelGGL((k_tlas_flat_w5<true, 0, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
+            else hipLaunchKernelGGL((k_tlas_flat_w5<false, 0, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
+        }
+        return;
+    }
     if (variant == 0) {
         if (blasLayout == 9) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);
         else TBVH_LT(k_tlas_adaptive, 12, 140);
