@@ -11,10 +11,20 @@
 //     on acceptance hit.inst = instance index (INST_IDX_BITS == 32: byte 44 of the ray record,
 //     tiny_bvh.h:665, 8526) — a full 32-bit id, unlike the reference device code's
 //     prim | inst << 24 packing (traverse_tlas.cl:77) that aliases above 256 instances.
-// BLAS layouts: BVH8_CWBVH and BVH4_GPU (all BLASes of one TLAS share a layout).  The point
-// and vector transforms are written as the same unfused mul/add chains as the oracle
-// (oracle/tbvh_oracle.c: orc_xform_point / orc_xform_vec), and this file is built with
-// -ffp-contract=off, so the transformed ray — and therefore t,u,v — match bit for bit.
+// BLAS layouts: BVH8_CWBVH, BVH4_GPU and BVH_GPU, also mixed within one TLAS (traverse_tlas.cl:50-72 selects the BLAS
+// traversal per instance through blasDesc[].blasType).  The point and vector transforms follow the reference build's FMA
+// contraction (oracle/tbvh_oracle.c: orc_xform_point / orc_xform_vec, pinned bit for bit against the real
+// BVH::IntersectTLAS), and this file is built with -ffp-contract=off, so the transformed ray — and therefore t,u,v —
+// match bit for bit.
+//
+// Three kernels, one result (tests/test_tlas.py runs them all against the oracle and against each other):
+//   k_tlas / k_tlas_w5   nested loops, whole-wave batches: TLAS walk -> instances of a leaf -> BLAS traversal.  Fastest while
+//                        the 64 rays of a wave stay together (camera rays), 2.5-4 x slower than the flat loop otherwise.
+//   k_tlas_flat          ONE loop, per-lane ray replacement: every lane is in TLAS / INSTANCE / BLAS mode and does one
+//                        step of it per iteration; a mode's code runs when enough lanes are in it (phase gating).
+//   k_tlas_adaptive      starts nested, measures the lane cohesion of each 64-ray generation, moves to the flat loop
+//                        when the rays turn out incoherent.
+// launch_tlas picks: CWBVH BLASes -> flat; BVH4_GPU BLASes -> adaptive; BVH_GPU BLASes or mixed layouts -> flat.
 #include "device_common.h"
 #include "lane_stack.h"
 #include "ray_pool.h"
