@@ -62,11 +62,22 @@ def main():
     from tinybvh_amd import rays as R
     from tinybvh_amd import scenes
 
+    def flush_c_stdio():
+        # RCCL prints a banner ("Hostname", "Librccl path") through C stdio when the communicator comes up; a pipe holds
+        # it back until exit, i.e. until after the JSON line.  Every rank pushes it out at the barriers instead, so that
+        # rank 0's JSON line is the last line of the job's stdout.
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+
     def sync_all():
         if use_dist:
             import torch
             dist.barrier()
             torch.cuda.synchronize()
+            flush_c_stdio()
         ctx.synchronize()
 
     # ---- scene + layout (host build, untimed) ------------------------------------------------
@@ -309,6 +320,7 @@ def main():
                        "rays_per_gpu_per_step": 2 * n, "shadow_rays_per_gpu": n, "sharding": f"rays x{world}, BVH replicated, no collective"},
             "detail": detail, "roofline": roof, "cpu_baseline": cpu,
         }
+        flush_c_stdio()
         print(json.dumps(out), flush=True)
     sync_all()
     if use_dist:
