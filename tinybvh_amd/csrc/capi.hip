@@ -216,7 +216,7 @@ int ensurePipe(tbvh_context* c, uint64_t n) {
             HIP_TRY(hipEventCreateWithFlags(&p->evUp[i], hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&p->evDown[i], hipEventDisableTiming));
         }
-        uint32_t hw = std::thread::hardware_concurrency();
+        uint32_t hw = usable_host_threads();
         uint32_t t = hw >= 32 ? 7 : hw >= 8 ? 3 : hw >= 4 ? 1 : 0;   // + the calling thread
         if (const char* e = getenv("TBVH_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) t = (uint32_t)v - 1; }
         p->start(t);

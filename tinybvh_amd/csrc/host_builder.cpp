@@ -11,6 +11,12 @@
 // rules: conservative floor/ceil) but the tree that goes in is built by this file.
 #include "host_builder.h"
 
+#if defined(__linux__)
+#include <sched.h>
+#endif
+#include <cstdio>
+#include <cstdlib>
+
 #include <algorithm>
 #include <atomic>
 #include <cassert>
@@ -154,7 +160,7 @@ void buildFromPrims(const std::vector<Prim>& prims, const BuildParams& p, BVH2& 
     B.prims = prims.data(); B.idx = out.primIdx.data();
     B.bins = std::min<uint32_t>(std::max<uint32_t>(p.bins ? p.bins : 8, 2), Builder::kMaxBins);
     B.maxLeaf = std::max<uint32_t>(p.maxLeafTris ? p.maxLeafTris : 4, 1);
-    uint32_t threads = p.threads ? p.threads : std::max(1u, std::thread::hardware_concurrency());
+    uint32_t threads = p.threads ? p.threads : usable_host_threads();
     if (n < 65536) threads = 1;
 
     out.nodes.reserve((size_t)n * 2);
@@ -385,6 +391,28 @@ inline float asF32(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 }  // namespace
 
 // ---- public: builders -------------------------------------------------------------------
+
+uint32_t usable_host_threads() {
+    uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+#if defined(__linux__)
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int c = CPU_COUNT(&set);
+        if (c > 0) n = std::min<uint32_t>(n, (uint32_t)c);
+    }
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {   // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[32] = {0};
+        long long period = 0;
+        if (std::fscanf(f, "%31s %lld", q, &period) == 2 && period > 0 && std::strcmp(q, "max") != 0) {
+            const long long quota = std::atoll(q);
+            if (quota > 0) n = std::min<uint32_t>(n, (uint32_t)std::max<long long>(1, (quota + period / 2) / period));
+        }
+        std::fclose(f);
+    }
+#endif
+    return std::max(1u, n);
+}
 
 void build_bvh2(const Vec4* verts, uint32_t triCount, const BuildParams& p, BVH2& out) {
     std::vector<Prim> prims(triCount);

@@ -30,6 +30,11 @@ struct NodeAL {
 };
 static_assert(sizeof(NodeAL) == 64, "Aila-Laine node is 64 bytes");
 
+// Host threads this process can really run at once: hardware_concurrency() cut by the affinity mask and by the cgroup
+// CPU quota (inside a container limited to 16 cores of a 256-thread machine hardware_concurrency() still says 256, and
+// 256 builder threads on 16 cores are slower than 16).
+uint32_t usable_host_threads();
+
 struct BuildParams {
     uint32_t bins = 8;
     uint32_t maxLeafTris = 4;
