@@ -342,8 +342,9 @@ template <int M> void collapse_optimal(const BVH2& bvh, uint32_t maxLeaf, float 
     struct Root { uint32_t n2; };
     std::vector<Root> roots;
     struct Frame { uint32_t n; int i; };
+    std::vector<Frame> st;                          // reused by every gather call (one heap allocation, not one per wide node)
     auto gather = [&](uint32_t n, int budget) {   // expands "n as a forest of <= budget roots" into `roots`
-        std::vector<Frame> st{{n, budget}};
+        st.clear(); st.push_back({n, budget});
         while (!st.empty()) {
             Frame f = st.back(); st.pop_back();
             int i = f.i;
@@ -545,115 +546,165 @@ void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, const BuildParams& p, s
 }
 
 // CWBVH (format: Ylitie et al. 2017 as laid out by tiny_bvh.h:5884-6018).
+// Runs body(first, last) over [0, n) on `threads` threads (contiguous ranges; the calling thread takes one).
+template <class F> static void parallel_ranges(size_t n, uint32_t threads, F body) {
+    threads = (uint32_t)std::min<size_t>(std::max<uint32_t>(threads, 1), std::max<size_t>(n / 4096, 1));
+    if (threads <= 1) { body((size_t)0, n); return; }
+    std::vector<std::thread> pool;
+    for (uint32_t t = 1; t < threads; t++) pool.emplace_back([=] { body(n * t / threads, n * (t + 1) / threads); });
+    body((size_t)0, n / threads);
+    for (auto& t : pool) t.join();
+}
+
 void encode_cwbvh(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std::vector<Vec4>& nodeBlocks,
                   std::vector<Vec4>& triBlocks) {
     std::vector<WideNode<8>> W;
     if (p.greedyCollapse) collapse<8>(bvh, W);
     else collapse_optimal<8>(bvh, std::min<uint32_t>(std::max<uint32_t>(p.maxLeafTris, 1), 3), 1.0f, p.cPrim, W);
-    nodeBlocks.clear(); triBlocks.clear();
-    nodeBlocks.reserve(W.size() * 5);
-    triBlocks.reserve((size_t)bvh.triCount * 3);
-    struct Item { uint32_t wide; uint32_t addr; };  // addr = node index in the output
-    std::vector<Item> stack{{0, 0}};
-    nodeBlocks.resize(5, Vec4{0, 0, 0, 0});
-    while (!stack.empty()) {
-        const Item it = stack.back(); stack.pop_back();
-        const WideNode<8>& n = W[it.wide];
-        // --- slot assignment: children go to the octant slot their centroid offset points
-        // at (slot bit 2 = -x, bit 1 = -y, bit 0 = -z side), solved greedily on the
-        // cost matrix cost[s][i] = dot(centroid_i - centroid_node, dir_s).
-        float cost[8][8];
-        int slotOf[8], childIn[8];
-        for (int s = 0; s < 8; s++) childIn[s] = -1;
-        for (int i = 0; i < 8; i++) slotOf[i] = -1;
-        float nc[3];
-        for (int a = 0; a < 3; a++) nc[a] = 0.5f * (n.box.mn[a] + n.box.mx[a]);
-        for (uint32_t i = 0; i < n.childCount; i++) {
-            const Box& cb = W[n.child[i]].box;
-            float d[3];
-            for (int a = 0; a < 3; a++) d[a] = 0.5f * (cb.mn[a] + cb.mx[a]) - nc[a];
-            for (int s = 0; s < 8; s++)
-                cost[s][i] = ((s & 4) ? -d[0] : d[0]) + ((s & 2) ? -d[1] : d[1]) + ((s & 1) ? -d[2] : d[2]);
-        }
-        for (uint32_t k = 0; k < n.childCount; k++) {
-            float best = kFar; int bs = -1, bi = -1;
-            for (int s = 0; s < 8; s++) if (childIn[s] < 0)
-                for (uint32_t i = 0; i < n.childCount; i++) if (slotOf[i] < 0 && cost[s][i] < best)
-                    best = cost[s][i], bs = s, bi = (int)i;
-            slotOf[bi] = bs; childIn[bs] = bi;
-        }
-        // --- per-axis exponent: smallest e with extent / 2^e <= 255
-        int e[3];
-        float inv[3];
-        for (int a = 0; a < 3; a++) {
-            const float ext = n.box.mx[a] - n.box.mn[a];
-            int ea = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0f)) : -126;
-            ea = std::max(ea, -126);
-            // guard the ceil() of every child against 255 overflow from rounding
-            for (;;) {
-                const float s = std::ldexp(1.0f, -ea);
-                bool ok = true;
-                for (uint32_t i = 0; i < n.childCount; i++)
-                    if (std::ceil((W[n.child[i]].box.mx[a] - n.box.mn[a]) * s) > 255.f) ok = false;
-                if (n.box.mn[a] + std::ldexp(255.0f, ea) < n.box.mx[a]) ok = false;
-                if (ok) break;
-                ea++;
+    const uint32_t threads = p.threads ? p.threads : usable_host_threads();
+    // Three passes, so that the expensive parts run on all threads while the output stays byte for byte what a single
+    // depth-first walk writes: (1) octant slot assignment per node, parallel; (2) the depth-first walk itself, which only
+    // hands out node and triangle addresses, serial; (3) quantisation and triangle records per node, parallel.
+    // --- pass 1: children go to the octant slot their centroid offset points at (slot bit 2 = -x, bit 1 = -y, bit 0 =
+    // -z side), solved greedily on the cost matrix cost[s][i] = dot(centroid_i - centroid_node, dir_s).
+    struct Slots { int8_t childIn[8]; };
+    std::vector<Slots> slots(W.size());
+    parallel_ranges(W.size(), threads, [&](size_t lo, size_t hi) {
+        for (size_t wi = lo; wi < hi; wi++) {
+            const WideNode<8>& n = W[wi];
+            Slots& so = slots[wi];
+            for (int s = 0; s < 8; s++) so.childIn[s] = -1;
+            if (n.triCount) continue;   // leaves have no children
+            float cost[8][8];
+            int slotOf[8];
+            for (int i = 0; i < 8; i++) slotOf[i] = -1;
+            float nc[3];
+            for (int a = 0; a < 3; a++) nc[a] = 0.5f * (n.box.mn[a] + n.box.mx[a]);
+            for (uint32_t i = 0; i < n.childCount; i++) {
+                const Box& cb = W[n.child[i]].box;
+                float d[3];
+                for (int a = 0; a < 3; a++) d[a] = 0.5f * (cb.mn[a] + cb.mx[a]) - nc[a];
+                for (int s = 0; s < 8; s++)
+                    cost[s][i] = ((s & 4) ? -d[0] : d[0]) + ((s & 2) ? -d[1] : d[1]) + ((s & 1) ? -d[2] : d[2]);
             }
-            e[a] = ea; inv[a] = std::ldexp(1.0f, -ea);
-        }
-        uint8_t meta[8] = {}, q[6][8] = {};
-        uint32_t imask = 0, childBase = 0, triBase = 0, nInner = 0, nTris = 0;
-        for (int s = 0; s < 8; s++) {
-            if (childIn[s] < 0) continue;
-            const uint32_t ci = n.child[childIn[s]];
-            const WideNode<8>& c = W[ci];
-            for (int a = 0; a < 3; a++) {
-                // floor / ceil in units of 2^e (tiny_bvh.h:5952-5957), then checked against the
-                // decode lo + q * 2^e so float rounding of the subtraction cannot shrink the box
-                const float sc = std::ldexp(1.0f, e[a]);
-                int lo = (int)std::floor((c.box.mn[a] - n.box.mn[a]) * inv[a]);
-                int hi = (int)std::ceil((c.box.mx[a] - n.box.mn[a]) * inv[a]);
-                lo = std::min(std::max(lo, 0), 255); hi = std::min(std::max(hi, 0), 255);
-                while (lo > 0 && n.box.mn[a] + sc * (float)lo > c.box.mn[a]) lo--;
-                while (hi < 255 && n.box.mn[a] + sc * (float)hi < c.box.mx[a]) hi++;
-                q[a][s] = (uint8_t)lo;
-                q[3 + a][s] = (uint8_t)hi;
+            for (uint32_t k = 0; k < n.childCount; k++) {
+                float best = kFar; int bs = -1, bi = -1;
+                for (int s = 0; s < 8; s++) if (so.childIn[s] < 0)
+                    for (uint32_t i = 0; i < n.childCount; i++) if (slotOf[i] < 0 && cost[s][i] < best)
+                        best = cost[s][i], bs = s, bi = (int)i;
+                slotOf[bi] = bs; so.childIn[bs] = (int8_t)bi;
             }
-            if (!c.triCount) {
-                const uint32_t addr = (uint32_t)(nodeBlocks.size() / 5);
-                nodeBlocks.resize(nodeBlocks.size() + 5, Vec4{0, 0, 0, 0});
-                if (nInner++ == 0) childBase = addr;
-                imask |= 1u << s;
-                meta[s] = (uint8_t)((1u << 5) | (24 + s));
-                stack.push_back({ci, addr});
-            } else {
-                assert(c.triCount <= 3);
-                if (nTris == 0) triBase = (uint32_t)triBlocks.size();
-                const uint32_t unary = c.triCount == 1 ? 1u : c.triCount == 2 ? 3u : 7u;
-                meta[s] = (uint8_t)((unary << 5) | nTris);
-                nTris += c.triCount;
-                for (uint32_t j = 0; j < c.triCount; j++) {
-                    const uint32_t prim = bvh.primIdx[c.firstTri + j];
-                    const Vec4 v0 = verts[3 * (size_t)prim], v1 = verts[3 * (size_t)prim + 1], v2 = verts[3 * (size_t)prim + 2];
-                    triBlocks.push_back(Vec4{v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, v2.w - v0.w});
-                    triBlocks.push_back(Vec4{v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v1.w - v0.w});
-                    triBlocks.push_back(Vec4{v0.x, v0.y, v0.z, asF32(prim)});
+        }
+    });
+    // --- pass 2: depth-first walk: output node index per interior wide node, first triangle block per node
+    struct Placed { uint32_t wide, addr, childBase, triBase; };
+    std::vector<Placed> placed;
+    placed.reserve(W.size());
+    {
+        struct Item { uint32_t wide; uint32_t addr; };
+        std::vector<Item> stack{{0, 0}};
+        uint32_t nNodes = 1;
+        uint64_t nTriBlocks = 0;
+        while (!stack.empty()) {
+            const Item it = stack.back(); stack.pop_back();
+            const WideNode<8>& n = W[it.wide];
+            Placed pl{it.wide, it.addr, 0, 0};
+            uint32_t nInner = 0, nTris = 0;
+            for (int s = 0; s < 8; s++) {
+                const int k = slots[it.wide].childIn[s];
+                if (k < 0) continue;
+                const uint32_t ci = n.child[k];
+                const WideNode<8>& c = W[ci];
+                if (!c.triCount) {
+                    const uint32_t addr = nNodes++;
+                    if (nInner++ == 0) pl.childBase = addr;
+                    stack.push_back({ci, addr});
+                } else {
+                    if (nTris == 0) pl.triBase = (uint32_t)nTriBlocks;
+                    nTris += c.triCount;
+                    nTriBlocks += 3ull * c.triCount;
                 }
             }
+            assert(nTris <= 24);
+            placed.push_back(pl);
         }
-        assert(nTris <= 24);
-        Vec4* nb = nodeBlocks.data() + (size_t)it.addr * 5;
-        const uint32_t eim = ((uint32_t)(uint8_t)(int8_t)e[0]) | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) |
-                             ((uint32_t)(uint8_t)(int8_t)e[2] << 16) | (imask << 24);
-        uint32_t m0, m1; std::memcpy(&m0, meta, 4); std::memcpy(&m1, meta + 4, 4);
-        nb[0] = Vec4{n.box.mn[0], n.box.mn[1], n.box.mn[2], asF32(eim)};
-        nb[1] = Vec4{asF32(childBase), asF32(triBase), asF32(m0), asF32(m1)};
-        uint32_t w[12];
-        std::memcpy(w, q, 48);  // qlo_x[8] qlo_y[8] qlo_z[8] qhi_x[8] qhi_y[8] qhi_z[8]
-        nb[2] = Vec4{asF32(w[0]), asF32(w[1]), asF32(w[2]), asF32(w[3])};
-        nb[3] = Vec4{asF32(w[4]), asF32(w[5]), asF32(w[6]), asF32(w[7])};
-        nb[4] = Vec4{asF32(w[8]), asF32(w[9]), asF32(w[10]), asF32(w[11])};
+        nodeBlocks.assign((size_t)nNodes * 5, Vec4{0, 0, 0, 0});
+        triBlocks.assign((size_t)nTriBlocks, Vec4{0, 0, 0, 0});
     }
+    // --- pass 3: one output node (and its triangle records) per placed entry
+    parallel_ranges(placed.size(), threads, [&](size_t plo, size_t phi) {
+        for (size_t pi = plo; pi < phi; pi++) {
+            const Placed& pl = placed[pi];
+            const WideNode<8>& n = W[pl.wide];
+            const int8_t* childIn = slots[pl.wide].childIn;
+            // per-axis exponent: smallest e with extent / 2^e <= 255
+            int e[3];
+            float inv[3];
+            for (int a = 0; a < 3; a++) {
+                const float ext = n.box.mx[a] - n.box.mn[a];
+                int ea = ext > 0 ? (int)std::ceil(std::log2(ext / 255.0f)) : -126;
+                ea = std::max(ea, -126);
+                // guard the ceil() of every child against 255 overflow from rounding
+                for (;;) {
+                    const float sc = std::ldexp(1.0f, -ea);
+                    bool ok = true;
+                    for (uint32_t i = 0; i < n.childCount; i++)
+                        if (std::ceil((W[n.child[i]].box.mx[a] - n.box.mn[a]) * sc) > 255.f) ok = false;
+                    if (n.box.mn[a] + std::ldexp(255.0f, ea) < n.box.mx[a]) ok = false;
+                    if (ok) break;
+                    ea++;
+                }
+                e[a] = ea; inv[a] = std::ldexp(1.0f, -ea);
+            }
+            uint8_t meta[8] = {}, q[6][8] = {};
+            uint32_t imask = 0, nTris = 0;
+            size_t triOut = pl.triBase;
+            for (int s = 0; s < 8; s++) {
+                if (childIn[s] < 0) continue;
+                const uint32_t ci = n.child[childIn[s]];
+                const WideNode<8>& c = W[ci];
+                for (int a = 0; a < 3; a++) {
+                    // floor / ceil in units of 2^e (tiny_bvh.h:5952-5957), then checked against the
+                    // decode lo + q * 2^e so float rounding of the subtraction cannot shrink the box
+                    const float sc = std::ldexp(1.0f, e[a]);
+                    int lo = (int)std::floor((c.box.mn[a] - n.box.mn[a]) * inv[a]);
+                    int hi = (int)std::ceil((c.box.mx[a] - n.box.mn[a]) * inv[a]);
+                    lo = std::min(std::max(lo, 0), 255); hi = std::min(std::max(hi, 0), 255);
+                    while (lo > 0 && n.box.mn[a] + sc * (float)lo > c.box.mn[a]) lo--;
+                    while (hi < 255 && n.box.mn[a] + sc * (float)hi < c.box.mx[a]) hi++;
+                    q[a][s] = (uint8_t)lo;
+                    q[3 + a][s] = (uint8_t)hi;
+                }
+                if (!c.triCount) {
+                    imask |= 1u << s;
+                    meta[s] = (uint8_t)((1u << 5) | (24 + s));
+                } else {
+                    assert(c.triCount <= 3);
+                    const uint32_t unary = c.triCount == 1 ? 1u : c.triCount == 2 ? 3u : 7u;
+                    meta[s] = (uint8_t)((unary << 5) | nTris);
+                    nTris += c.triCount;
+                    for (uint32_t j = 0; j < c.triCount; j++) {
+                        const uint32_t prim = bvh.primIdx[c.firstTri + j];
+                        const Vec4 v0 = verts[3 * (size_t)prim], v1 = verts[3 * (size_t)prim + 1], v2 = verts[3 * (size_t)prim + 2];
+                        triBlocks[triOut++] = Vec4{v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, v2.w - v0.w};
+                        triBlocks[triOut++] = Vec4{v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v1.w - v0.w};
+                        triBlocks[triOut++] = Vec4{v0.x, v0.y, v0.z, asF32(prim)};
+                    }
+                }
+            }
+            Vec4* nb = nodeBlocks.data() + (size_t)pl.addr * 5;
+            const uint32_t eim = ((uint32_t)(uint8_t)(int8_t)e[0]) | ((uint32_t)(uint8_t)(int8_t)e[1] << 8) |
+                                 ((uint32_t)(uint8_t)(int8_t)e[2] << 16) | (imask << 24);
+            uint32_t m0, m1; std::memcpy(&m0, meta, 4); std::memcpy(&m1, meta + 4, 4);
+            nb[0] = Vec4{n.box.mn[0], n.box.mn[1], n.box.mn[2], asF32(eim)};
+            nb[1] = Vec4{asF32(pl.childBase), asF32(pl.triBase), asF32(m0), asF32(m1)};
+            uint32_t w[12];
+            std::memcpy(w, q, 48);  // qlo_x[8] qlo_y[8] qlo_z[8] qhi_x[8] qhi_y[8] qhi_z[8]
+            nb[2] = Vec4{asF32(w[0]), asF32(w[1]), asF32(w[2]), asF32(w[3])};
+            nb[3] = Vec4{asF32(w[4]), asF32(w[5]), asF32(w[6]), asF32(w[7])};
+            nb[4] = Vec4{asF32(w[8]), asF32(w[9]), asF32(w[10]), asF32(w[11])};
+        }
+    });
 }
 
 // ---- instances ---------------------------------------------------------------------------
