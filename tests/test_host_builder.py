@@ -179,13 +179,14 @@ def test_optimal_collapse_gives_same_hits_with_fewer_nodes(oracle, small_scene, 
         assert sorted(tris[:, 2, 3].tolist()) == list(range(verts.shape[0] // 3))  # every triangle exactly once
 
 
+@pytest.mark.parametrize("layout", [tb.LAYOUT_CWBVH, tb.LAYOUT_BVH4_GPU])
 @pytest.mark.parametrize("kw", [{}, {"greedy_collapse": True}, {"max_leaf_tris": 3}])
-def test_cwbvh_encoder_output_does_not_depend_on_the_thread_count(kw):
-    """encode_cwbvh runs its slot assignment and quantisation passes on all threads; the blobs must be byte for byte
-    what one thread writes (addresses come from a serial depth-first walk in between)."""
+def test_wide_encoder_output_does_not_depend_on_the_thread_count(layout, kw):
+    """encode_cwbvh / encode_bvh4_gpu run their quantisation passes on all threads; the blobs must be byte for byte what
+    one thread writes (addresses come from a serial depth-first walk)."""
     verts = scenes.blob(90_000, seed=13)       # above the 65 536-triangle threshold of the threaded BVH2 build
-    ref = tb.HostBVH(verts, tb.LAYOUT_CWBVH, threads=1, **kw)
+    ref = tb.HostBVH(verts, layout, threads=1, **kw)
     for th in (2, 5, 16, 0):
-        h = tb.HostBVH(verts, tb.LAYOUT_CWBVH, threads=th, **kw)
+        h = tb.HostBVH(verts, layout, threads=th, **kw)
         assert np.array_equal(h.blob(0, np.uint32, 4), ref.blob(0, np.uint32, 4)), th
         assert np.array_equal(h.blob(1, np.uint32, 4), ref.blob(1, np.uint32, 4)), th

@@ -469,83 +469,6 @@ void encode_bvh_gpu(const BVH2& bvh, std::vector<NodeAL>& out) {
     out.resize(next);
 }
 
-// BVH4_GPU stream (format: tiny_bvh.h:1248-1266, 5120-5127, SURVEY A.3).
-void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std::vector<Vec4>& blocks) {
-    std::vector<WideNode<4>> W;
-    if (p.greedyCollapse) collapse<4>(bvh, W);
-    else collapse_optimal<4>(bvh, std::max<uint32_t>(p.maxLeafTris, 1), 1.0f, p.cPrim, W);
-    blocks.clear();
-    blocks.reserve(W.size() * 4 + (size_t)bvh.triCount * 3);
-    struct Item { uint32_t wide; uint32_t patchWord; };  // patchWord: u32 index to receive the node's block offset
-    std::vector<Item> stack{{0, 0xffffffffu}};
-    while (!stack.empty()) {
-        const Item it = stack.back(); stack.pop_back();
-        const WideNode<4>& n = W[it.wide];
-        const uint32_t base = (uint32_t)blocks.size();
-        if (it.patchWord != 0xffffffffu) reinterpret_cast<uint32_t*>(blocks.data())[it.patchWord] = base;
-        blocks.resize(blocks.size() + 4, Vec4{0, 0, 0, 0});
-        uint32_t info[4] = {0, 0, 0, 0};
-        uint8_t q[6][4] = {};  // xmin, xmax, ymin, ymax, zmin, zmax per child
-        const float ext[3] = {n.box.mx[0] - n.box.mn[0], n.box.mx[1] - n.box.mn[1], n.box.mx[2] - n.box.mn[2]};
-        float scale[3], e255[3];
-        for (int a = 0; a < 3; a++) {
-            scale[a] = ext[a] > 1e-10f ? 254.999f / ext[a] : 0.f;
-            e255[a] = ext[a] * (1.0f / 255.0f);
-            const float guard = 4e-7f * std::max(std::max(std::fabs(n.box.mn[a]), std::fabs(n.box.mx[a])), ext[a]);
-            if (ext[a] > 0) {   // the decode step must carry 255 steps past the far face: jump there, then settle ulp by ulp
-                const float need = ((n.box.mx[a] + guard) - n.box.mn[a]) * (1.0f / 255.0f);
-                if (need > e255[a]) e255[a] = need;
-                while (n.box.mn[a] + e255[a] * 255.0f < n.box.mx[a] + guard) e255[a] = std::nextafter(e255[a], kFar);
-            }
-        }
-        for (uint32_t i = 0; i < n.childCount; i++) {
-            const WideNode<4>& c = W[n.child[i]];
-            for (int a = 0; a < 3; a++) {
-                // The reference quantises with floor/ceil(rel * 254.999 / extent)
-                // (tiny_bvh.h:5196-5231) and decodes with bmin + (extent/255) * q; the 254.999
-                // makes the decoded maximum fall short of the true one by up to 4e-6 * rel, so a
-                // reference-encoded BVH4_GPU can cull a box a ray grazes.  Same format here, but
-                // the quantised box is verified against the decode and widened until it really
-                // contains the child (with a few-ulp guard for decoder rounding).
-                const float guard = 4e-7f * std::max(std::max(std::fabs(n.box.mn[a]), std::fabs(n.box.mx[a])), ext[a]);
-                int lo = (int)std::floor((c.box.mn[a] - n.box.mn[a]) * scale[a]);
-                int hi = (int)std::ceil((c.box.mx[a] - n.box.mn[a]) * scale[a]);
-                lo = std::min(std::max(lo, 0), 255); hi = std::min(std::max(hi, 0), 255);
-                while (lo > 0 && n.box.mn[a] + e255[a] * (float)lo > c.box.mn[a] - guard) lo--;
-                while (hi < 255 && n.box.mn[a] + e255[a] * (float)hi < c.box.mx[a] + guard) hi++;
-                q[2 * a][i] = (uint8_t)lo;
-                q[2 * a + 1][i] = (uint8_t)hi;
-            }
-            if (c.triCount) {
-                const uint32_t rel = (uint32_t)blocks.size() - base;
-                assert(rel < 65536 && c.triCount < 32768);
-                info[i] = 0x80000000u | (c.triCount << 16) | rel;
-                for (uint32_t j = 0; j < c.triCount; j++) {
-                    const uint32_t prim = bvh.primIdx[c.firstTri + j];
-                    const Vec4 v0 = verts[3 * (size_t)prim], v1 = verts[3 * (size_t)prim + 1], v2 = verts[3 * (size_t)prim + 2];
-                    blocks.push_back(Vec4{v0.x, v0.y, v0.z, asF32(prim)});
-                    blocks.push_back(Vec4{v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v1.w - v0.w});
-                    blocks.push_back(Vec4{v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, v2.w - v0.w});
-                }
-            }
-        }
-        // interior children: offsets are patched in when each child is emitted
-        for (uint32_t i = n.childCount; i-- > 0;) {
-            if (W[n.child[i]].triCount) continue;
-            stack.push_back({n.child[i], (base + 3) * 4 + i});
-        }
-        Vec4* nb = blocks.data() + base;
-        uint32_t w0, w1, w2[4];
-        std::memcpy(&w0, q[0], 4); std::memcpy(&w1, q[1], 4);
-        std::memcpy(&w2[0], q[2], 4); std::memcpy(&w2[1], q[3], 4); std::memcpy(&w2[2], q[4], 4); std::memcpy(&w2[3], q[5], 4);
-        nb[0] = Vec4{n.box.mn[0], n.box.mn[1], n.box.mn[2], asF32(w0)};
-        nb[1] = Vec4{e255[0], e255[1], e255[2], asF32(w1)};
-        nb[2] = Vec4{asF32(w2[0]), asF32(w2[1]), asF32(w2[2]), asF32(w2[3])};
-        nb[3] = Vec4{asF32(info[0]), asF32(info[1]), asF32(info[2]), asF32(info[3])};
-    }
-}
-
-// CWBVH (format: Ylitie et al. 2017 as laid out by tiny_bvh.h:5884-6018, SURVEY A.4).
 // Runs body(first, last) over [0, n) on `threads` threads (contiguous ranges; the calling thread takes one).
 template <class F> static void parallel_ranges(size_t n, uint32_t threads, F body) {
     threads = (uint32_t)std::min<size_t>(std::max<uint32_t>(threads, 1), std::max<size_t>(n / 4096, 1));
@@ -556,6 +479,98 @@ template <class F> static void parallel_ranges(size_t n, uint32_t threads, F bod
     for (auto& t : pool) t.join();
 }
 
+// BVH4_GPU stream (format: tiny_bvh.h:1248-1266, 5120-5127, SURVEY A.3).
+void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std::vector<Vec4>& blocks) {
+    std::vector<WideNode<4>> W;
+    if (p.greedyCollapse) collapse<4>(bvh, W);
+    else collapse_optimal<4>(bvh, std::max<uint32_t>(p.maxLeafTris, 1), 1.0f, p.cPrim, W);
+    const uint32_t threads = p.threads ? p.threads : usable_host_threads();
+    // Two passes: a serial depth-first walk hands out the block offset of every interior node (node = 4 blocks, followed
+    // by the triangles of its leaf children in child order), then the nodes are quantised and written on all threads —
+    // byte for byte what one walk that does both would write.
+    constexpr uint32_t kNone = 0xffffffffu;
+    std::vector<uint32_t> baseOf(W.size(), kNone);   // block offset of interior wide node w
+    std::vector<uint32_t> order;                      // interior wide nodes in emission order
+    order.reserve(W.size());
+    uint64_t total = 0;
+    {
+        std::vector<uint32_t> stack{0};
+        while (!stack.empty()) {
+            const uint32_t wi = stack.back(); stack.pop_back();
+            const WideNode<4>& n = W[wi];
+            baseOf[wi] = (uint32_t)total;
+            order.push_back(wi);
+            total += 4;
+            for (uint32_t i = 0; i < n.childCount; i++) if (W[n.child[i]].triCount) total += 3ull * W[n.child[i]].triCount;
+            for (uint32_t i = n.childCount; i-- > 0;) if (!W[n.child[i]].triCount) stack.push_back(n.child[i]);
+        }
+    }
+    assert(total <= 0xffffffffull);
+    blocks.assign((size_t)total, Vec4{0, 0, 0, 0});
+    parallel_ranges(order.size(), threads, [&](size_t olo, size_t ohi) {
+        for (size_t oi = olo; oi < ohi; oi++) {
+            const WideNode<4>& n = W[order[oi]];
+            const uint32_t base = baseOf[order[oi]];
+            uint32_t out = base + 4;   // next free block: the inline triangles follow the node
+            uint32_t info[4] = {0, 0, 0, 0};
+            uint8_t q[6][4] = {};  // xmin, xmax, ymin, ymax, zmin, zmax per child
+            const float ext[3] = {n.box.mx[0] - n.box.mn[0], n.box.mx[1] - n.box.mn[1], n.box.mx[2] - n.box.mn[2]};
+            float scale[3], e255[3];
+            for (int a = 0; a < 3; a++) {
+                scale[a] = ext[a] > 1e-10f ? 254.999f / ext[a] : 0.f;
+                e255[a] = ext[a] * (1.0f / 255.0f);
+                const float guard = 4e-7f * std::max(std::max(std::fabs(n.box.mn[a]), std::fabs(n.box.mx[a])), ext[a]);
+                if (ext[a] > 0) {   // the decode step must carry 255 steps past the far face: jump there, then settle ulp by ulp
+                    const float need = ((n.box.mx[a] + guard) - n.box.mn[a]) * (1.0f / 255.0f);
+                    if (need > e255[a]) e255[a] = need;
+                    while (n.box.mn[a] + e255[a] * 255.0f < n.box.mx[a] + guard) e255[a] = std::nextafter(e255[a], kFar);
+                }
+            }
+            for (uint32_t i = 0; i < n.childCount; i++) {
+                const WideNode<4>& c = W[n.child[i]];
+                for (int a = 0; a < 3; a++) {
+                    // The reference quantises with floor/ceil(rel * 254.999 / extent)
+                    // (tiny_bvh.h:5196-5231) and decodes with bmin + (extent/255) * q; the 254.999
+                    // makes the decoded maximum fall short of the true one by up to 4e-6 * rel, so a
+                    // reference-encoded BVH4_GPU can cull a box a ray grazes.  Same format here, but
+                    // the quantised box is verified against the decode and widened until it really
+                    // contains the child (with a few-ulp guard for decoder rounding).
+                    const float guard = 4e-7f * std::max(std::max(std::fabs(n.box.mn[a]), std::fabs(n.box.mx[a])), ext[a]);
+                    int lo = (int)std::floor((c.box.mn[a] - n.box.mn[a]) * scale[a]);
+                    int hi = (int)std::ceil((c.box.mx[a] - n.box.mn[a]) * scale[a]);
+                    lo = std::min(std::max(lo, 0), 255); hi = std::min(std::max(hi, 0), 255);
+                    while (lo > 0 && n.box.mn[a] + e255[a] * (float)lo > c.box.mn[a] - guard) lo--;
+                    while (hi < 255 && n.box.mn[a] + e255[a] * (float)hi < c.box.mx[a] + guard) hi++;
+                    q[2 * a][i] = (uint8_t)lo;
+                    q[2 * a + 1][i] = (uint8_t)hi;
+                }
+                if (c.triCount) {
+                    const uint32_t rel = out - base;
+                    assert(rel < 65536 && c.triCount < 32768);
+                    info[i] = 0x80000000u | (c.triCount << 16) | rel;
+                    for (uint32_t j = 0; j < c.triCount; j++) {
+                        const uint32_t prim = bvh.primIdx[c.firstTri + j];
+                        const Vec4 v0 = verts[3 * (size_t)prim], v1 = verts[3 * (size_t)prim + 1], v2 = verts[3 * (size_t)prim + 2];
+                        blocks[out++] = Vec4{v0.x, v0.y, v0.z, asF32(prim)};
+                        blocks[out++] = Vec4{v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v1.w - v0.w};
+                        blocks[out++] = Vec4{v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, v2.w - v0.w};
+                    }
+                } else
+                    info[i] = baseOf[n.child[i]];   // interior child: its absolute block offset
+            }
+            Vec4* nb = blocks.data() + base;
+            uint32_t w0, w1, w2[4];
+            std::memcpy(&w0, q[0], 4); std::memcpy(&w1, q[1], 4);
+            std::memcpy(&w2[0], q[2], 4); std::memcpy(&w2[1], q[3], 4); std::memcpy(&w2[2], q[4], 4); std::memcpy(&w2[3], q[5], 4);
+            nb[0] = Vec4{n.box.mn[0], n.box.mn[1], n.box.mn[2], asF32(w0)};
+            nb[1] = Vec4{e255[0], e255[1], e255[2], asF32(w1)};
+            nb[2] = Vec4{asF32(w2[0]), asF32(w2[1]), asF32(w2[2]), asF32(w2[3])};
+            nb[3] = Vec4{asF32(info[0]), asF32(info[1]), asF32(info[2]), asF32(info[3])};
+        }
+    });
+}
+
+// CWBVH (format: Ylitie et al. 2017 as laid out by tiny_bvh.h:5884-6018, SURVEY A.4).
 void encode_cwbvh(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std::vector<Vec4>& nodeBlocks,
                   std::vector<Vec4>& triBlocks) {
     std::vector<WideNode<8>> W;
