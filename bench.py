@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--scene", default="bistro")
     ap.add_argument("--side", type=int, default=4096, help="primary rays per GPU = side^2")
-    ap.add_argument("--layout", type=int, default=9)
+    ap.add_argument("--layout", type=int, default=10, help="5 BVH_GPU, 8 BVH4_GPU, 10 BVH8_CWBVH (BVHBase::BVHType)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
     a = ap.parse_args()
@@ -297,7 +297,7 @@ def main():
                     traffic = json.load(open(pmc)).get("diffuse_kernel_hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
-            roof = {"bound": "hbm", "kernel": "k_cwbvh<false> (diffuse batch)" if a.layout == 9 else "intersect (diffuse batch)",
+            roof = {"bound": "hbm", "kernel": "k_cwbvh<false> (diffuse batch)" if a.layout == tb.LAYOUT_CWBVH else "intersect (diffuse batch)",
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                     "traffic": traffic, "algorithmic_bytes_per_ray": bytes_per_ray, "nodes_per_ray": S, "tris_per_ray": T,
                     "avg_launch_ms": mean["diffuse"]}
@@ -316,7 +316,7 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}; BVH8_CWBVH; per GPU per step {n} primary + {n} diffuse (depth 1-3) Intersect; + {n} shadow IsOccluded timed separately",
-                       "scene_tris": n_tris, "layout": {4: "BVH_GPU", 6: "BVH4_GPU", 9: "BVH8_CWBVH"}[a.layout],
+                       "scene_tris": n_tris, "layout": {5: "BVH_GPU", 8: "BVH4_GPU", 10: "BVH8_CWBVH"}[a.layout],
                        "rays_per_gpu_per_step": 2 * n, "shadow_rays_per_gpu": n, "sharding": f"rays x{world}, BVH replicated, no collective"},
             "detail": detail, "roofline": roof, "cpu_baseline": cpu,
         }

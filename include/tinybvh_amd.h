@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TBVH_ABI_VERSION 1
+#define TBVH_ABI_VERSION 2
 
 /* error codes */
 #define TBVH_OK            0
@@ -50,11 +50,12 @@ extern "C" {
 #define TBVH_E_NOMEM      -4   /* host or device allocation failed                      */
 #define TBVH_E_FORMAT     -5   /* blob failed validation (e.g. CWBVH root is a leaf)    */
 
-/* layouts; values follow BVHBase::BVHType (tiny_bvh.h:773-791) where one exists */
+/* layouts; the values ARE BVHBase::BVHType (tiny_bvh.h:773-791), so a caller can pass bvh.layout
+ * (ABI version 1 used 4 / 6 / 9 here, which are LAYOUT_BVH_SOA / LAYOUT_MBVH / LAYOUT_MBVH8 in the reference) */
 #define TBVH_LAYOUT_BVH2_WALD  1  /* LAYOUT_BVH       32-byte nodes (host/oracle only)   */
-#define TBVH_LAYOUT_BVH_GPU    4  /* LAYOUT_BVH_GPU   Aila-Laine 64-byte nodes           */
-#define TBVH_LAYOUT_BVH4_GPU   6  /* LAYOUT_BVH4_GPU  quantized 4-wide + inline tris     */
-#define TBVH_LAYOUT_CWBVH      9  /* LAYOUT_CWBVH     compressed wide BVH8               */
+#define TBVH_LAYOUT_BVH_GPU    5  /* LAYOUT_BVH_GPU   Aila-Laine 64-byte nodes           */
+#define TBVH_LAYOUT_BVH4_GPU   8  /* LAYOUT_BVH4_GPU  quantized 4-wide + inline tris     */
+#define TBVH_LAYOUT_CWBVH     10  /* LAYOUT_CWBVH     compressed wide BVH8               */
 
 typedef struct tbvh_context tbvh_context;  /* one HIP device + stream + scratch          */
 typedef struct tbvh_scene   tbvh_scene;    /* one uploaded layout (BLAS or TLAS)         */
@@ -101,7 +102,10 @@ int tbvh_upload_cwbvh(tbvh_context* ctx, const void* nodes16, uint64_t n_node_bl
  * each) — replaces the uploads of tiny_bvh_gpu2.cpp:122-130.  blas[i] is the scene for
  * BLASInstance::blasIdx == i.  tlas_idx = tlas.bvh.primIdx (instance indices).
  * The BLASes may be BVH8_CWBVH, BVH4_GPU or BVH_GPU scenes, also mixed within one TLAS (as traverse_tlas.cl:50-72
- * selects the BLAS traversal per instance through blasDesc[].blasType). */
+ * selects the BLAS traversal per instance through blasDesc[].blasType).
+ * The TLAS keeps references to its BLAS scenes: tbvh_free_scene on a BLAS that a live TLAS still uses is deferred until the
+ * last such TLAS is freed, and tbvh_set_opacity_micromaps on a BLAS updates every TLAS built over it.
+ * The TLAS blobs are validated (child / primIdx / blasIdx ranges; TBVH_E_FORMAT), here and in tbvh_update_tlas. */
 int tbvh_upload_tlas(tbvh_context* ctx, const void* tlas_nodes64, uint64_t n_nodes,
                      const uint32_t* tlas_idx, uint64_t n_idx,
                      const void* instances192, uint64_t n_instances,

@@ -12,7 +12,7 @@ BUILD = os.path.join(ROOT, "examples", "_build")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout", [4, 6, 9])
+@pytest.mark.parametrize("layout", [5, 8, 10])
 def test_minimal_gpu_example(layout):
     exe = os.path.join(BUILD, "minimal_gpu")
     if not os.path.exists(exe):

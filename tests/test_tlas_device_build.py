@@ -171,3 +171,70 @@ def test_device_rebuild_errors(ctx):
     import ctypes as C
     with pytest.raises(tb.TbvhError):
         tb.check(tb.lib.tbvh_rebuild_tlas_device(tlas._h, None, 0, C.c_void_p(bounds.ctypes.data), 2), "wrong BLAS count")
+
+
+@pytest.mark.gpu
+def test_rebuild_after_the_tlas_grew(ctx, oracle):
+    """A TLAS updated to more instances than it was created with, then rebuilt on the device from host transforms:
+    the staging buffer of the transforms follows the new instance count (it used to keep its first size)."""
+    verts = scenes.blob(1500, seed=5)
+    blas = [tb.BVH8_CWBVH(ctx).Build(verts)]
+    small = grid_instances(3, 0.5, 4)
+    tlas = tb.TLAS(ctx).Build(small, blas)
+    tlas.RebuildOnDevice(np.ascontiguousarray(small["transform"]))            # stages 27 transforms
+    big = grid_instances(6, 0.5, 4)
+    tlas.Build(big, blas)                                                     # update path: 216 instances
+    tlas._bounds_sent = True
+    tlas.RebuildOnDevice(np.ascontiguousarray(big["transform"]))              # stages 216
+    rays = R.random_rays(20_000, (-2, -2, -2), (12, 12, 12), seed=8)
+    ref = tb.TLAS(ctx).Build(big.copy(), blas)
+    check(tlas.Intersect(rays.copy()), oracle_tlas(oracle, ref, blas, rays))
+
+
+@pytest.mark.gpu
+def test_tlas_blobs_are_validated(ctx):
+    verts = scenes.blob(1500, seed=5)
+    blas = [tb.BVH8_CWBVH(ctx).Build(verts)]
+    inst = grid_instances(2, 0.5, 4)
+    tlas = tb.TLAS(ctx).Build(inst, blas)
+    nodes = tlas.host.blob(0, np.uint32, 16).copy(); idx = tlas.host.blob(1, np.uint32, 1).copy()
+    bad = inst.copy(); bad["blasIdx"][3] = 7
+    with pytest.raises(tb.TbvhError):
+        tlas.Update(nodes, idx, bad)                                          # blasIdx beyond the BLAS list
+    bad_idx = idx.copy(); bad_idx[0] = 1000
+    with pytest.raises(tb.TbvhError):
+        tlas.Update(nodes, bad_idx, inst)                                     # primIdx beyond the instances
+    bad_nodes = nodes.copy()
+    interior = np.flatnonzero(bad_nodes[:, 11] == 0)
+    bad_nodes[interior[0], 3] = 0x7fffffff
+    with pytest.raises(tb.TbvhError):
+        tlas.Update(bad_nodes, idx, inst)                                     # child beyond the node array
+    with pytest.raises(tb.TbvhError):
+        tb.TLAS(ctx).Upload(nodes, idx, bad, blas)
+    tlas.Update(nodes, idx, inst)                                             # the good blobs still go through
+
+
+@pytest.mark.gpu
+def test_blas_freed_or_remapped_under_a_live_tlas(ctx, oracle):
+    """tbvh_free_scene on a BLAS that a TLAS still uses is deferred; opacity maps set on a BLAS after the TLAS upload
+    reach the TLAS's descriptor."""
+    verts = scenes.blob(1500, seed=5)
+    blas = tb.BVH8_CWBVH(ctx).Build(verts)
+    inst = grid_instances(2, 0.5, 4)
+    tlas = tb.TLAS(ctx).Build(inst, [blas])
+    rays = R.random_rays(20_000, (-2, -2, -2), (5, 5, 5), seed=8)
+    want = oracle_tlas(oracle, tlas, [blas], rays)
+    # all-clear maps: nothing can be hit any more
+    n_tris = verts.shape[0] // 3
+    blas.SetOpacityMicroMaps(np.zeros((n_tris, 1), np.uint32), 4)
+    got = tlas.Intersect(rays.copy())
+    assert np.all(got["t"] == rays["t"])
+    blas.SetOpacityMicroMaps(None, 0)
+    check(tlas.Intersect(rays.copy()), want)
+    import ctypes as C
+    tb.lib.tbvh_free_scene(blas._h)                                           # deferred: the TLAS still points at it
+    for _ in range(4):                                                        # allocations in between would reuse freed memory
+        tmp = ctx.malloc(verts.nbytes * 4); ctx.to_device(tmp, np.zeros(verts.nbytes, np.uint8)); ctx.free(tmp)
+    check(tlas.Intersect(rays.copy()), want)
+    blas._h = C.c_void_p()                                                    # the handle is gone for the wrapper
+    tlas.free()

@@ -18,9 +18,9 @@ from . import _capi
 from ._capi import BuildParams, Camera, TbvhError, check, lib
 
 LAYOUT_BVH2_WALD = 1
-LAYOUT_BVH_GPU = 4
-LAYOUT_BVH4_GPU = 6
-LAYOUT_CWBVH = 9
+LAYOUT_BVH_GPU = 5
+LAYOUT_BVH4_GPU = 8
+LAYOUT_CWBVH = 10
 # wavefront materials: v0.w of a triangle's first vertex = type << 24 | 0xRRGGBB (wavefront.cl:12-13, 160)
 MATERIAL_DIFFUSE, MATERIAL_LIGHT, MATERIAL_SPECULAR = 0, 1, 2
 

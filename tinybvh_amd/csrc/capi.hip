@@ -24,6 +24,9 @@
 
 using namespace tbvh;
 
+static_assert(kLayoutBvhGpu == TBVH_LAYOUT_BVH_GPU && kLayoutBvh4Gpu == TBVH_LAYOUT_BVH4_GPU && kLayoutCwbvh == TBVH_LAYOUT_CWBVH,
+              "kernels.h and the public header agree on the layout codes");
+
 namespace {
 
 thread_local char g_err[512] = "";
@@ -96,6 +99,13 @@ struct tbvh_scene {
     // device-side TLAS rebuild (kernels_tlasbuild.hip)
     float* blasBounds = nullptr;      // 6 floats per BLAS
     float* xformStage = nullptr;      // staged transforms (16 floats per instance) when the caller passes host memory
+    uint64_t xformStageCap = 0;       // instances the staging buffer holds
+    // BLAS <-> TLAS references: a TLAS snapshots its BLASes' device pointers (BlasDesc), so a BLAS knows the TLASes that
+    // use it (their descriptors are refreshed when its opacity maps change) and outlives them (tbvh_free_scene on a BLAS
+    // that is still referenced only marks it; the memory goes when the last TLAS over it is freed)
+    std::vector<tbvh_scene*> blasList;   // TLAS: its BLASes, in blasIdx order
+    std::vector<tbvh_scene*> usedBy;     // BLAS: the TLASes built over it (one entry per reference)
+    bool zombie = false;                 // BLAS: freed by the caller while still referenced
     void* buildScratch = nullptr;
     size_t buildScratchBytes = 0, sortTempBytes = 0;
     uint64_t buildScratchFor = 0;     // instance count the scratch was sized for
@@ -424,6 +434,12 @@ void tbvh_shutdown(tbvh_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->ownStream) hipStreamSynchronize(c->ownStream);
+    for (;;) {   // TLASes first: they hold references to their BLASes
+        tbvh_scene* t = nullptr;
+        for (tbvh_scene* s : c->scenes) if (s->isTlas) { t = s; break; }
+        if (!t) break;
+        tbvh_free_scene(t);
+    }
     while (!c->scenes.empty()) tbvh_free_scene(c->scenes.back());
     if (c->spill) hipFree(c->spill);
     if (c->counter) hipFree(c->counter);
@@ -517,6 +533,11 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
 namespace {
 int tlasCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* idx, uint64_t nIdx, const void* inst, uint64_t nInst) {
     tbvh_context* c = s->ctx;
+    // same hardening as the BLAS uploads: the TLAS kernels index instances[idx[]] and blas[blasIdx] unguarded
+    if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(TBVH_E_FORMAT, "TLAS: %s", why);
+    for (uint64_t i = 0; i < nIdx; i++) if (idx[i] >= nInst) return fail(TBVH_E_FORMAT, "TLAS: primIdx[%llu] = %u is not an instance (%llu instances)", (unsigned long long)i, idx[i], (unsigned long long)nInst);
+    const BLASInstanceCheck* ic = (const BLASInstanceCheck*)inst;
+    for (uint64_t i = 0; i < nInst; i++) if (ic[i].blasIdx >= s->nBlas) return fail(TBVH_E_FORMAT, "instance %llu: blasIdx %u out of range (%llu BLASes)", (unsigned long long)i, ic[i].blasIdx, (unsigned long long)s->nBlas);
     if (nNodes > s->capNodes) { if (s->nodes) hipFree(s->nodes); s->nodes = nullptr; HIP_TRY(hipMalloc((void**)&s->nodes, nNodes * 64)); s->capNodes = nNodes; }
     if (nIdx > s->capIdx) { if (s->tlasIdx) hipFree(s->tlasIdx); s->tlasIdx = nullptr; HIP_TRY(hipMalloc((void**)&s->tlasIdx, nIdx * 4)); s->capIdx = nIdx; }
     if (nInst > s->capInst) { if (s->instances) hipFree(s->instances); s->instances = nullptr; HIP_TRY(hipMalloc((void**)&s->instances, nInst * 192)); s->capInst = nInst; }
@@ -537,18 +558,17 @@ int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, cons
     std::vector<BlasDesc> desc(nBlas);
     for (uint64_t i = 0; i < nBlas; i++) {
         const tbvh_scene* b = blas[i];
-        if (!b || b->ctx != c || b->isTlas) return fail(TBVH_E_INVALID, "BLAS %llu is null, a TLAS, or from another context", (unsigned long long)i);
+        if (!b || b->ctx != c || b->isTlas || b->zombie) return fail(TBVH_E_INVALID, "BLAS %llu is null, freed, a TLAS, or from another context", (unsigned long long)i);
         if (b->layout != TBVH_LAYOUT_CWBVH && b->layout != TBVH_LAYOUT_BVH4_GPU && b->layout != TBVH_LAYOUT_BVH_GPU)
             return fail(TBVH_E_INVALID, "BLAS %llu: layout %d cannot be a BLAS", (unsigned long long)i, b->layout);
         layout = i == 0 ? b->layout : (layout == b->layout ? layout : 0);   // 0: the BLASes mix layouts (traverse_tlas.cl:50-72)
         desc[i].nodes = b->nodes; desc[i].tris = b->tris; desc[i].opmap = b->opmap; desc[i].opmapN = b->opmapN; desc[i].layout = (uint32_t)b->layout;
     }
-    const BLASInstanceCheck* ic = (const BLASInstanceCheck*)inst;
-    for (uint64_t i = 0; i < nInst; i++) if (ic[i].blasIdx >= nBlas) return fail(TBVH_E_FORMAT, "instance %llu: blasIdx %u out of range", (unsigned long long)i, ic[i].blasIdx);
     if (int r = setDevice(c)) return r;
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
     s->isTlas = true; s->blasLayout = layout; s->nBlas = nBlas;
+    for (uint64_t i = 0; i < nBlas; i++) { s->blasList.push_back(blas[i]); blas[i]->usedBy.push_back(s); }
     hipError_t e = hipMalloc((void**)&s->blasDesc, nBlas * sizeof(BlasDesc));
     if (e == hipSuccess) e = hipMemcpy(s->blasDesc, desc.data(), nBlas * sizeof(BlasDesc), hipMemcpyHostToDevice);
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "TLAS upload failed: %s", hipGetErrorString(e)); }
@@ -691,6 +711,19 @@ int tbvh_build_device(tbvh_context* c, const void* verts16, uint64_t nTris, int 
     return r;
 }
 
+namespace {
+// the TLASes over BLAS b hold a snapshot of its device pointers: rewrite their entries for b
+int refreshBlasDescs(tbvh_scene* b) {
+    for (tbvh_scene* t : b->usedBy)
+        for (size_t i = 0; i < t->blasList.size(); i++)
+            if (t->blasList[i] == b) {
+                BlasDesc d; d.nodes = b->nodes; d.tris = b->tris; d.opmap = b->opmap; d.opmapN = b->opmapN; d.layout = (uint32_t)b->layout;
+                HIP_TRY(hipMemcpy(t->blasDesc + i, &d, sizeof d, hipMemcpyHostToDevice));
+            }
+    return 0;
+}
+}  // namespace
+
 int tbvh_set_opacity_micromaps(tbvh_scene* s, const uint32_t* mapData, uint32_t N, uint64_t nTris, int onDevice) {
     if (!s || s->isTlas) return fail(TBVH_E_INVALID, "tbvh_set_opacity_micromaps: not a BLAS scene (set the maps on the BLASes before uploading their TLAS)");
     tbvh_context* c = s->ctx;
@@ -698,7 +731,7 @@ int tbvh_set_opacity_micromaps(tbvh_scene* s, const uint32_t* mapData, uint32_t 
     HIP_TRY(hipStreamSynchronize(c->stream));   // no query may still read the old maps
     if (s->opmap) { hipFree(s->opmap); s->opmap = nullptr; }
     s->opmapN = 0;
-    if (!mapData || N == 0) return 0;            // cleared
+    if (!mapData || N == 0) return refreshBlasDescs(s);            // cleared
     if (N > 1024 || nTris == 0) return fail(TBVH_E_INVALID, "tbvh_set_opacity_micromaps: N = %u, %llu triangles", N, (unsigned long long)nTris);
     const uint64_t wordsPerTri = ((uint64_t)N * N + 31) >> 5, words = wordsPerTri * nTris;
     // the reference's index can run one row past the map when u + v == 1 exactly (tiny_bvh.h:8518-8519): keep that read inside the allocation
@@ -709,7 +742,7 @@ int tbvh_set_opacity_micromaps(tbvh_scene* s, const uint32_t* mapData, uint32_t 
     HIP_TRY(hipStreamSynchronize(c->stream));
     s->opmapN = N;
     s->bytes += (words + pad) * 4;
-    return 0;
+    return refreshBlasDescs(s);
 }
 
 int tbvh_scene_download(tbvh_scene* s, int which, void* dst, uint64_t capBytes, uint64_t* bytesOut) {
@@ -804,9 +837,6 @@ int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice
     if (n > s->capIdx) { if (s->tlasIdx) hipFree(s->tlasIdx); s->tlasIdx = nullptr; s->capIdx = 0; HIP_TRY(hipMalloc((void**)&s->tlasIdx, n * 4)); s->capIdx = n; }
     if (s->buildScratchFor != n) {
         if (s->buildScratch) hipFree(s->buildScratch);
-    if (s->refitScratch) hipFree(s->refitScratch);
-    if (s->opmap) hipFree(s->opmap);
-    if (s->vertStage) hipFree(s->vertStage);
         s->buildScratch = nullptr; s->buildScratchFor = 0;
         s->buildScratchBytes = tlas_build_scratch_bytes((uint32_t)n, &s->sortTempBytes);
         HIP_TRY(hipMalloc(&s->buildScratch, s->buildScratchBytes));
@@ -816,7 +846,12 @@ int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice
     if (transforms) {
         if (onDevice) xf = (const float*)transforms;
         else {
-            if (!s->xformStage) HIP_TRY(hipMalloc((void**)&s->xformStage, s->capInst * 64));
+            if (s->xformStageCap < n) {   // tbvh_update_tlas may have grown the instance array since the last rebuild
+                if (s->xformStage) hipFree(s->xformStage);
+                s->xformStage = nullptr; s->xformStageCap = 0;
+                HIP_TRY(hipMalloc((void**)&s->xformStage, n * 64));
+                s->xformStageCap = n;
+            }
             HIP_TRY(hipMemcpyAsync(s->xformStage, transforms, n * 64, hipMemcpyHostToDevice, c->stream));
             xf = s->xformStage;
         }
@@ -849,6 +884,15 @@ void tbvh_free_scene(tbvh_scene* s) {
     tbvh_context* c = s->ctx;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
+    if (!s->isTlas && !s->usedBy.empty()) { s->zombie = true; return; }   // a TLAS still points at this BLAS's memory: freed with the last such TLAS
+    if (s->isTlas) {
+        std::vector<tbvh_scene*> mine;
+        mine.swap(s->blasList);
+        for (tbvh_scene* b : mine) {
+            for (size_t i = 0; i < b->usedBy.size(); i++) if (b->usedBy[i] == s) { b->usedBy.erase(b->usedBy.begin() + i); break; }
+            if (b->zombie && b->usedBy.empty()) { b->zombie = false; tbvh_free_scene(b); }
+        }
+    }
     if (s->nodes) hipFree(s->nodes);
     if (s->tris) hipFree(s->tris);
     if (s->nodesH) hipFree(s->nodesH);

@@ -5,6 +5,9 @@
 
 namespace tbvh {
 
+// layout codes as in include/tinybvh_amd.h (= BVHBase::BVHType, tiny_bvh.h:773-791); capi.hip checks they agree
+constexpr int kLayoutBvhGpu = 5, kLayoutBvh4Gpu = 8, kLayoutCwbvh = 10;
+
 void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                  uint32_t blocks, hipStream_t s);
 void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);

@@ -248,7 +248,7 @@ __global__ void k_b4_refit_level(float4* __restrict__ blocks, uint64_t nBlocks, 
 
 size_t refit_scratch_bytes(int layout, uint32_t nNodes) {
     // done (u32) [+ boxMin, boxMax (float4 each) for CWBVH]
-    return (size_t)nNodes * 4 + (layout == 9 ? (size_t)nNodes * 32 : 0) + 1024;
+    return (size_t)nNodes * 4 + (layout == kLayoutCwbvh ? (size_t)nNodes * 32 : 0) + 1024;
 }
 
 // scratch layout: done[nNodes] | boxMin[nNodes] | boxMax[nNodes]
@@ -262,15 +262,15 @@ hipError_t launch_refit(int layout, float4* nodes, uint32_t nNodes, float4* tris
     hipError_t e = hipMemsetAsync(done, 0, (size_t)nNodes * 4, s);
     if (e != hipSuccess) return e;
     if (nTriRecords) {
-        if (layout == 9) hipLaunchKernelGGL(k_regather<true>, dim3(tb), dim3(256), 0, s, tris, verts, nTriRecords, nTris, status);
+        if (layout == kLayoutCwbvh) hipLaunchKernelGGL(k_regather<true>, dim3(tb), dim3(256), 0, s, tris, verts, nTriRecords, nTris, status);
         else hipLaunchKernelGGL(k_regather<false>, dim3(tb), dim3(256), 0, s, tris, verts, nTriRecords, nTris, status);
     }
     // passes in batches; after each batch look at the root's done word (pass numbers start at 2)
-    const int batch = layout == 9 ? 6 : 24;
+    const int batch = layout == kLayoutCwbvh ? 6 : 24;
     uint32_t pass = 2, rootDone = 0;
     while (!rootDone) {
         for (int k = 0; k < batch; k++, pass++) {
-            if (layout == 9) hipLaunchKernelGGL(k_cw_pass, dim3(nb), dim3(bs), 0, s, nodes, nNodes, tris, verts, done, pass, boxMin, boxMax);
+            if (layout == kLayoutCwbvh) hipLaunchKernelGGL(k_cw_pass, dim3(nb), dim3(bs), 0, s, nodes, nNodes, tris, verts, done, pass, boxMin, boxMax);
             else hipLaunchKernelGGL(k_al_pass, dim3(nb), dim3(bs), 0, s, nodes, nNodes, tris, verts, done, pass);
         }
         if ((e = hipMemcpyAsync(&rootDone, done, 4, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;

@@ -250,7 +250,7 @@ __device__ __forceinline__ bool tlas_body(const float4* __restrict__ tlasNodes, 
                     rl.hit = hit; rl.found = false;
                     const BlasDesc bd = blas[as_u32(b0.w)];
                     if (ADAPT) tk.tick();   // cohesion is sampled where the lanes part ways: TLAS nodes and instance entries (ticks inside the BLAS loops cost 18 %; instance entries alone separate camera rays from random ones less cleanly)
-                    if (BLAS_LAYOUT == 9) blas_cwbvh<ANYHIT, LDS_N, false>(GlobalF4(bd.nodes), GlobalF4(bd.tris), rl, st, Omm{bd.opmap, bd.opmapN}, tk);
+                    if (BLAS_LAYOUT == kLayoutCwbvh) blas_cwbvh<ANYHIT, LDS_N, false>(GlobalF4(bd.nodes), GlobalF4(bd.tris), rl, st, Omm{bd.opmap, bd.opmapN}, tk);
                     else blas_bvh4<ANYHIT, LDS_N, false>(GlobalF4(bd.nodes), rl, st, Omm{bd.opmap, bd.opmapN}, tk);
                     if (rl.found) { found = true; hit = rl.hit; hitInst = ii; if (ANYHIT) break; }
                 }
@@ -379,7 +379,7 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
         if (mode == M_BLAS) { if (runC) {
             bool pop = false;   // this lane's BLAS step ended with nothing pending: take the next stack entry (or leave the BLAS)
             const uint32_t lay = BLAS_LAYOUT ? (uint32_t)BLAS_LAYOUT : blay;
-            if (lay == 9) {
+            if (lay == (uint32_t)kLayoutCwbvh) {
                 if (tg.y != 0) {   // one triangle
                     const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
                     tg.y &= ~(1u << ti);
@@ -448,7 +448,7 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
                         if (ng.y <= 0x00FFFFFFu) { tg = ng; ng = make_uint2(0u, 0u); }   // a postponed triangle group
                     }
                 }
-            } else if (lay == 6) {
+            } else if (lay == (uint32_t)kLayoutBvh4Gpu) {
                 if (leafCnt != 0) {   // one triangle of the pending leaves
                     const uint32_t ta = leafQ0;
                     const float4 v0 = bnodes[ta], e1 = bnodes[ta + 1], e2 = bnodes[ta + 2];
@@ -586,7 +586,7 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
                     bnodes = GlobalF4(bd.nodes); btris = GlobalF4(bd.tris);
                     curInst = ii; base = st.sp; mode = M_BLAS;
                     if (BLAS_LAYOUT == 0) blay = bd.layout;
-                    if ((BLAS_LAYOUT ? (uint32_t)BLAS_LAYOUT : blay) == 9) {
+                    if ((BLAS_LAYOUT ? (uint32_t)BLAS_LAYOUT : blay) == (uint32_t)kLayoutCwbvh) {
                         oct = 7u - ((D.x < 0 ? 4u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 1u : 0u));
                         ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
                     } else { offset = 0; leafCnt = 0; leafCntB = 0; }
@@ -707,12 +707,12 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
                  const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
 #define TBVH_LT(K, ...)                                                                                                                      \
     do {                                                                                                                                \
-        if (blasLayout == 9) {                                                                                                          \
-            if (anyhit) hipLaunchKernelGGL((K<true, 9, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status); \
-            else hipLaunchKernelGGL((K<false, 9, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);       \
+        if (blasLayout == kLayoutCwbvh) {                                                                                                       \
+            if (anyhit) hipLaunchKernelGGL((K<true, kLayoutCwbvh, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status); \
+            else hipLaunchKernelGGL((K<false, kLayoutCwbvh, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);       \
         } else {                                                                                                                        \
-            if (anyhit) hipLaunchKernelGGL((K<true, 6, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status); \
-            else hipLaunchKernelGGL((K<false, 6, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);       \
+            if (anyhit) hipLaunchKernelGGL((K<true, kLayoutBvh4Gpu, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status); \
+            else hipLaunchKernelGGL((K<false, kLayoutBvh4Gpu, ##__VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);       \
         }                                                                                                                               \
     } while (0)
     // Defaults (1000 instances of a 100 k-triangle BLAS; 8.3 M camera rays / 8.4 M random rays, Intersect, MRays/s):
@@ -725,10 +725,10 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
     // lane cohesion of a 64-ray generation (mean / max of the lanes' TLAS-node and instance-entry counts) falls below 0.55:
     // camera rays: 99 % of the generations above 0.5; random rays: 99.7 % below.
     // BVH_GPU BLASes and TLASes that mix BLAS layouts (as traverse_tlas.cl:50-72 allows: blasDesc[].blasType) exist in the flat loop only
-    if (blasLayout == 4 || blasLayout == 0) {
-        if (blasLayout == 4) {
-            if (anyhit) hipLaunchKernelGGL((k_tlas_flat_w6<true, 4, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
-            else hipLaunchKernelGGL((k_tlas_flat_w6<false, 4, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
+    if (blasLayout == kLayoutBvhGpu || blasLayout == 0) {
+        if (blasLayout == kLayoutBvhGpu) {
+            if (anyhit) hipLaunchKernelGGL((k_tlas_flat_w6<true, kLayoutBvhGpu, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
+            else hipLaunchKernelGGL((k_tlas_flat_w6<false, kLayoutBvhGpu, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
         } else {
             if (anyhit) hipLaunchKernelGGL((k_tlas_flat_w5<true, 0, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
             else hipLaunchKernelGGL((k_tlas_flat_w5<false, 0, 12, 16, 32>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);
@@ -736,7 +736,7 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
         return;
     }
     if (variant == 0) {
-        if (blasLayout == 9) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);
+        if (blasLayout == kLayoutCwbvh) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);
         else TBVH_LT(k_tlas_adaptive, 12, 140);
     }
     else if (variant == 6) TBVH_LT(k_tlas_flat_w6, 12, 16, 32, true);   // flat loop under the lockstep governor

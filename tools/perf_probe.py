@@ -17,7 +17,7 @@ from tinybvh_amd import scenes  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--scene", default="sponza")
-    ap.add_argument("--layouts", default="4,6,9")
+    ap.add_argument("--layouts", default="5,8,10")
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--spp", type=int, default=1)

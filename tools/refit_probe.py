@@ -14,7 +14,7 @@ from tinybvh_amd import scenes  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--scene", default="bistro")
-ap.add_argument("--layouts", default="9,4")
+ap.add_argument("--layouts", default="10,5")
 ap.add_argument("--side", type=int, default=2048)
 a = ap.parse_args()
 verts, label = scenes.get(a.scene)

@@ -27,7 +27,7 @@ def instances(n_side, t, scale=0.07 * 10):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--layout", type=int, default=6)
+    ap.add_argument("--layout", type=int, default=8)
     ap.add_argument("--side", type=int, default=10)
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--variant", type=int, default=0)

@@ -33,7 +33,7 @@ ctx = tb.Context(0)
 d = ctx.malloc(n * 64)
 d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
 res = {}
-for layout, name in ((4, "BVH_GPU"), (6, "BVH4_GPU"), (9, "BVH8_CWBVH")):
+for layout, name in ((5, "BVH_GPU"), (8, "BVH4_GPU"), (10, "BVH8_CWBVH")):
     sc = tb.LAYOUT_CLASSES[layout](ctx).Build(verts)
     h = sc.host
     ctx.generate_primary(cam, d, 0, n)
@@ -48,20 +48,20 @@ for layout, name in ((4, "BVH_GPU"), (6, "BVH4_GPU"), (9, "BVH8_CWBVH")):
         if p:
             ms.append(t)
     mine = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(mine, d)
-    if layout == 4:
+    if layout == 5:
         blobs = [h.blob(0, np.uint32, 16), h.blob(1, np.uint32, 1), verts]
-    elif layout == 6:
+    elif layout == 8:
         blobs = [h.blob(0, np.uint32, 4)]
     else:
         blobs = [h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4)]
-    theirs, ref_ms = ocl.run(layout, blobs, rays, passes=3)
+    theirs, ref_ms = ocl.run({5: 4, 8: 6, 10: 9}[layout], blobs, rays, passes=3)
     # the .cl kernels always overwrite `hit` (miss = t 1e30) and use strict comparisons / native_recip:
     # compare loosely (hit/miss and prim; t to 1e-4) just to show both sides trace the same thing
     c = compare_hits(mine[: theirs.shape[0]], theirs, rtol=1e-4)
     hip = n / (np.mean(ms) * 1e-3) / 1e6
     ref = theirs.shape[0] / (ref_ms * 1e-3) / 1e6
     res[name] = {"hip_mrays": hip, "reference_opencl_mrays": ref, "speedup": hip / ref, "hits": c["hits"], "hitmiss": c["hitmiss"], "prim_mismatch": c["prim_mismatch"]}
-    print(f"{name:11s} HIP {hip:8.1f} MRays/s   reference OpenCL ({'batch_ailalaine' if layout == 4 else 'batch_gpu4way' if layout == 6 else 'batch_cwbvh'}) {ref:8.1f} MRays/s   x{hip / ref:.2f}   "
+    print(f"{name:11s} HIP {hip:8.1f} MRays/s   reference OpenCL ({'batch_ailalaine' if layout == 5 else 'batch_gpu4way' if layout == 8 else 'batch_cwbvh'}) {ref:8.1f} MRays/s   x{hip / ref:.2f}   "
           f"[agreement: hits {c['hits']}, hit/miss diff {c['hitmiss']}, prim diff {c['prim_mismatch']}]", flush=True)
     sc.free()
 if a.out:
