@@ -210,6 +210,19 @@ int tbvh_occluded_device(tbvh_scene* scene, const void* d_rays64, uint64_t n_ray
  * callers that re-trace a resident batch, e.g. one frame after another. */
 int tbvh_intersect_device_fresh(tbvh_scene* scene, void* d_rays64, uint64_t n_rays, float tmax);
 
+/* ONE ray array over SEVERAL devices (the reference has a single process-global OpenCL device, tiny_ocl.h:362-364;
+ * SURVEY.md §8(e)): scenes[i] is the same BVH uploaded through the context of device i (the BVH is replicated), the
+ * array is cut into n_devices contiguous shards whose boundaries are multiples of 64 rays (tbvh_shard_range), one host
+ * thread per device stages, traces and reads back its shard, and the results land in the caller's array in place —
+ * bytes 44..63 of each record, or occluded[i], exactly as tbvh_intersect / tbvh_occluded on one device would write
+ * them.  No exchange between devices.  Every scene must belong to a different context.  With n_devices = 1 this is
+ * tbvh_intersect / tbvh_occluded. */
+int tbvh_intersect_sharded(tbvh_scene* const* scenes, uint32_t n_devices, void* rays, uint64_t n_rays, uint32_t stride_bytes);
+int tbvh_occluded_sharded(tbvh_scene* const* scenes, uint32_t n_devices, const void* rays, uint64_t n_rays,
+                          uint32_t stride_bytes, uint8_t* occluded);
+/* shard `rank` of `world` covers rays [*begin, *end) */
+void tbvh_shard_range(uint64_t n_rays, uint32_t rank, uint32_t world, uint64_t* begin, uint64_t* end);
+
 /* Re-arm a device ray batch for another Intersect: hit = {tmax, 0, 0, 0} for every record
  * (what re-running the tinybvh::Ray constructor's hit.t = t would do, tiny_bvh.h:700). */
 int tbvh_reset_hits_device(tbvh_context* ctx, void* d_rays64, uint64_t n_rays, float tmax);

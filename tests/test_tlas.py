@@ -113,7 +113,10 @@ def test_every_tlas_kernel_gives_the_same_records(ctx, oracle, layout, variant, 
         want = oracle_tlas(oracle, tlas, blas, rays)
         tlas.set_variant(0)
         base = tlas.Intersect(rays.copy())
-        tlas.set_variant(variant)
+        try:
+            tlas.set_variant(variant)
+        except tb.TbvhError:
+            pytest.skip("kernel variants other than the default exist in experiment builds only (make EXPERIMENTS=1)")
         got = tlas.Intersect(rays.copy())
         c = check(got, want)
         assert c["hits"] > 1000, (name, c)

@@ -368,6 +368,23 @@ class BVH8_CWBVH(_Scene):
 LAYOUT_CLASSES = {LAYOUT_BVH_GPU: BVH_GPU, LAYOUT_BVH4_GPU: BVH4_GPU, LAYOUT_CWBVH: BVH8_CWBVH}
 
 
+def intersect_sharded(replicas: list, rays: np.ndarray) -> np.ndarray:
+    """ONE ray array over several devices (tbvh_intersect_sharded): replicas[i] is the same BVH uploaded
+    through its own Context; contiguous wave-aligned shards, one host thread per device, results written in place."""
+    assert rays.flags["C_CONTIGUOUS"] and rays.dtype.itemsize in (64, 128)
+    arr = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
+    check(lib.tbvh_intersect_sharded(arr, len(replicas), _ptr(rays), rays.shape[0], rays.dtype.itemsize), "tbvh_intersect_sharded")
+    return rays
+
+
+def occluded_sharded(replicas: list, rays: np.ndarray) -> np.ndarray:
+    assert rays.flags["C_CONTIGUOUS"] and rays.dtype.itemsize in (64, 128)
+    occ = np.zeros(rays.shape[0], np.uint8)
+    arr = (C.c_void_p * len(replicas))(*[r._h for r in replicas])
+    check(lib.tbvh_occluded_sharded(arr, len(replicas), _ptr(rays), rays.shape[0], rays.dtype.itemsize, _ptr(occ)), "tbvh_occluded_sharded")
+    return occ
+
+
 def device_count() -> int:
     return int(lib.tbvh_device_count())
 

@@ -66,6 +66,9 @@ SYMBOLS = {
     "tbvh_scene_device_bytes": (_u64, [_vp]),
     "tbvh_intersect": (_i, [_vp, _vp, _u64, _u32]),
     "tbvh_occluded": (_i, [_vp, _vp, _u64, _u32, _vp]),
+    "tbvh_intersect_sharded": (_i, [_vp, _u32, _vp, _u64, _u32]),
+    "tbvh_occluded_sharded": (_i, [_vp, _u32, _vp, _u64, _u32, _vp]),
+    "tbvh_shard_range": (None, [_u64, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
     "tbvh_intersect_device": (_i, [_vp, _vp, _u64]),
     "tbvh_occluded_device": (_i, [_vp, _vp, _u64, _vp]),
     "tbvh_intersect_device_fresh": (_i, [_vp, _vp, _u64, C.c_float]),

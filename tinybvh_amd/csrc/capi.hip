@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -335,9 +336,12 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         break;
     case TBVH_LAYOUT_CWBVH:
         q.spillStride = c->spillEntries / 2;  // 8-byte entries
+#if TBVH_EXPERIMENTS
         if (s->variant >= 30 && s->variant < 40) launch_cwbvh_c(any, s->variant, s->nodesP, s->tris, s->nNodes, q, c->status, (uint32_t)c->numCUs, c->stream);
         else if (s->variant >= 20 && s->variant < 30) launch_cwbvh_h(any, s->variant, s->nodesH, s->tris, q, c->status, blocks, c->stream);
-        else launch_cwbvh(any, s->variant, s->variant == 47 ? s->nodes128 : s->nodes, s->tris, q, c->status, blocks, c->stream);
+        else
+#endif
+        launch_cwbvh(any, s->variant, cwbvh_variant_padded(s->variant) ? s->nodes128 : s->nodes, s->tris, q, c->status, blocks, c->stream);
         break;
     default:
         return fail(TBVH_E_INVALID, "scene layout %d has no query kernel", s->layout);
@@ -916,19 +920,21 @@ uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0;
 
 int tbvh_set_variant(tbvh_scene* s, int v) {
     if (!s) return fail(TBVH_E_INVALID, "null scene");
-    const bool ok = s->layout == TBVH_LAYOUT_CWBVH ? (cwbvh_variant_valid(v) || (v >= 20 && v <= 39)) : (v >= 0 && v <= 16);
-    if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
+    const bool ok = s->isTlas ? tlas_variant_valid(v)
+                  : s->layout == TBVH_LAYOUT_CWBVH ? (cwbvh_variant_valid(v) || (TBVH_EXPERIMENTS && v >= 20 && v <= 39)) : bvh_variant_valid(v);
+    if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d%s", v, s->layout, TBVH_EXPERIMENTS ? "" : " (experiment variants need a library built with make EXPERIMENTS=1)");
     tbvh_context* c = s->ctx;
     if (int r = setDevice(c)) return r;
     // experimental kernels run on derived node layouts, built on first use
     const bool cw = s->layout == TBVH_LAYOUT_CWBVH && !s->isTlas;
-    if (cw && v == 47 && !s->nodes128) {
+    if (cw && cwbvh_variant_padded(v) && !s->nodes128) {
         HIP_TRY(hipMalloc((void**)&s->nodes128, (size_t)s->nNodes * 128));
         launch_cwbvh_pad(s->nodes, s->nodes128, s->nNodes, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
         s->bytes += (uint64_t)s->nNodes * 128;
     }
+#if TBVH_EXPERIMENTS
     if (cw && v >= 20 && v < 30 && !s->nodesH) {
         HIP_TRY(hipMalloc((void**)&s->nodesH, (size_t)s->nNodes * 128));
         launch_cwbvh_relayout(s->nodes, s->nodesH, s->nNodes, c->stream);
@@ -944,6 +950,7 @@ int tbvh_set_variant(tbvh_scene* s, int v) {
         HIP_TRY(hipMemcpy(s->nodesP, pr.data(), pr.size() * 16, hipMemcpyHostToDevice));
         s->bytes += pr.size() * 16;
     }
+#endif
     s->variant = v;
     return 0;
 }
@@ -1004,6 +1011,55 @@ int tbvh_occluded(tbvh_scene* s, const void* rays, uint64_t n, uint32_t stride, 
     if (int r = launchQuery(s, c->stageRays, n, c->stageOcc)) return r;
     HIP_TRY(hipMemcpyAsync(occ, c->stageOcc, n, hipMemcpyDeviceToHost, c->stream));
     return checkStatus(c);
+}
+
+// ---- one ray array over several devices -----------------------------------------------------------
+// The BVH is replicated (scenes[i] = the same blobs uploaded through context i), the ray array is cut into contiguous,
+// wave-aligned shards (the same arithmetic as tinybvh_amd/sharding.py: shard_range), one host thread per device drives
+// that device's staging + kernel + read-back, results land in the caller's array in place.  No collective.
+void tbvh_shard_range(uint64_t n_rays, uint32_t rank, uint32_t world, uint64_t* begin, uint64_t* end) {
+    const uint64_t align = 64, units = (n_rays + align - 1) / align;
+    const uint64_t base = world ? units / world : 0, extra = world ? units % world : 0;
+    const uint64_t b = (uint64_t)rank * base + (rank < extra ? rank : extra), e = b + base + (rank < extra ? 1 : 0);
+    if (begin) *begin = b * align < n_rays ? b * align : n_rays;
+    if (end) *end = e * align < n_rays ? e * align : n_rays;
+}
+
+namespace {
+int shardedQuery(tbvh_scene* const* scenes, uint32_t nDev, void* rays, uint64_t n, uint32_t stride, uint8_t* occ, const char* who) {
+    if (!scenes || nDev == 0 || (!rays && n)) return fail(TBVH_E_INVALID, "%s: null/empty argument", who);
+    if (stride < 64 || (stride & 3)) return fail(TBVH_E_INVALID, "stride must be >= 64 and a multiple of 4 (got %u)", stride);
+    for (uint32_t i = 0; i < nDev; i++) {
+        if (!scenes[i]) return fail(TBVH_E_INVALID, "%s: scene %u is null", who, i);
+        if (scenes[i]->layout != scenes[0]->layout || scenes[i]->isTlas != scenes[0]->isTlas) return fail(TBVH_E_INVALID, "%s: scene %u is not a replica of scene 0 (layout differs)", who, i);
+        for (uint32_t j = 0; j < i; j++) if (scenes[j]->ctx == scenes[i]->ctx) return fail(TBVH_E_INVALID, "%s: scenes %u and %u share a context (one context, i.e. one stream and staging area, per shard)", who, j, i);
+    }
+    if (n == 0) return 0;
+    std::vector<int> rc(nDev, 0);
+    std::vector<std::string> msg(nDev);
+    auto work = [&](uint32_t i) {
+        uint64_t b, e;
+        tbvh_shard_range(n, i, nDev, &b, &e);
+        if (e == b) return;
+        char* base = (char*)rays + b * stride;
+        rc[i] = occ ? tbvh_occluded(scenes[i], base, e - b, stride, occ + b) : tbvh_intersect(scenes[i], base, e - b, stride);
+        if (rc[i]) msg[i] = tbvh_last_error();   // the worker's thread-local message
+    };
+    std::vector<std::thread> th;
+    for (uint32_t i = 1; i < nDev; i++) th.emplace_back(work, i);
+    work(0);
+    for (auto& t : th) t.join();
+    for (uint32_t i = 0; i < nDev; i++) if (rc[i]) return fail(rc[i], "%s: shard %u (device %d): %s", who, i, scenes[i]->ctx->device, msg[i].c_str());
+    return 0;
+}
+}  // namespace
+
+int tbvh_intersect_sharded(tbvh_scene* const* scenes, uint32_t nDev, void* rays, uint64_t n, uint32_t stride) {
+    return shardedQuery(scenes, nDev, rays, n, stride, nullptr, "tbvh_intersect_sharded");
+}
+int tbvh_occluded_sharded(tbvh_scene* const* scenes, uint32_t nDev, const void* rays, uint64_t n, uint32_t stride, uint8_t* occ) {
+    if (!occ && n) return fail(TBVH_E_INVALID, "tbvh_occluded_sharded: null output");
+    return shardedQuery(scenes, nDev, (void*)rays, n, stride, occ, "tbvh_occluded_sharded");
 }
 
 float tbvh_time_last_ms(tbvh_context* c) {

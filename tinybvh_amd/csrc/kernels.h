@@ -3,6 +3,12 @@
 #include <vector>
 #include "device_common.h"
 
+// TBVH_EXPERIMENTS = 1 (make EXPERIMENTS=1) also builds the measured-and-rejected kernel variants reachable through
+// tbvh_set_variant; the default build holds only the kernels the dispatchers pick.
+#ifndef TBVH_EXPERIMENTS
+#define TBVH_EXPERIMENTS 0
+#endif
+
 namespace tbvh {
 
 // layout codes as in include/tinybvh_amd.h (= BVHBase::BVHType, tiny_bvh.h:773-791); capi.hip checks they agree
@@ -14,6 +20,11 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                   uint32_t blocks, hipStream_t s);
 bool cwbvh_variant_valid(int variant);
+bool cwbvh_variant_padded(int variant);   // runs on the 128-byte padded node copy
+bool bvh_variant_valid(int variant);       // BVH_GPU / BVH4_GPU kernels
+bool tlas_variant_valid(int variant);
+void launch_cwbvh_exp(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
+                      uint32_t blocks, hipStream_t s);   // experiment builds only
 void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream_t s);
 void launch_cwbvh_h(bool anyhit, int variant, const char* nodesH, const float4* tris, const QueryArgs& q, uint32_t* status,
                     uint32_t blocks, hipStream_t s);

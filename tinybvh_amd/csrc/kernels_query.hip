@@ -318,6 +318,7 @@ void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tr
         else hipLaunchKernelGGL((k_bvh2<false, 16, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);       \
     } while (0)
     switch (variant) {
+#if TBVH_EXPERIMENTS
     case 1: TBVH_L2(1); break;
     case 2: TBVH_L2(8); break;
     case 3: TBVH_L2(32); break;
@@ -329,6 +330,7 @@ void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tr
     case 10: TBVH_L2(16, true, 3, 218); break;
     case 11: TBVH_L2(16, true, 3, 230); break;
     case 8: TBVH_L2(16, false, 3); break;      // per-lane replacement throughout, three node visits per iteration (+5..14 % over one)
+#endif
     default:   // + the lockstep governor (ray_pool.h): Sponza camera rays +9 %, shadow +6 %; small incoherent batches -3..5 %
         if (q.omm.map) TBVH_L2(16, true, 3);
         else TBVH_L2(16, true, 3, kLockstepKeep, false);   // no opacity micromaps: the check is compiled out
@@ -349,6 +351,7 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
         else hipLaunchKernelGGL((k_bvh4_w8<false, 12, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, data, q, status);        \
     } while (0)
     switch (variant) {
+#if TBVH_EXPERIMENTS
     case 1: TBVH_L4(1); break;
     case 2: TBVH_L4(16); break;
     case 5: TBVH_L4(8, false, 2); break;   // two node visits per iteration
@@ -360,6 +363,7 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
     case 11: TBVH_L4W(8, true, 1, true); break;    // + governor
     case 4: TBVH_L4(8, true); break;   // adaptive (LockstepGovernor, ray_pool.h): +6 % on coherent camera rays, -2..8 % elsewhere: not the default
     case 12: TBVH_L4(8); break;        // the former default: min / max pairs per plane, compiler's register budget (65-68 VGPRs)
+#endif
     default:   // per-lane replacement throughout, sign-selected planes, 8 waves per SIMD
         if (q.omm.map) TBVH_L4W(8, false, 1, true);
         else TBVH_L4W(8, false, 1, true, kLockstepKeep, false);   // no opacity micromaps: the check is compiled out
@@ -368,6 +372,8 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
 #undef TBVH_L4
 #undef TBVH_L4W
 }
+
+bool bvh_variant_valid(int v) { return TBVH_EXPERIMENTS ? (v >= 0 && v <= 16) : v == 0; }
 
 void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris, hipStream_t s) {
     const uint32_t bs = 256;

@@ -735,11 +735,8 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
         }
         return;
     }
-    if (variant == 0) {
-        if (blasLayout == kLayoutCwbvh) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);
-        else TBVH_LT(k_tlas_adaptive, 12, 140);
-    }
-    else if (variant == 6) TBVH_LT(k_tlas_flat_w6, 12, 16, 32, true);   // flat loop under the lockstep governor
+#if TBVH_EXPERIMENTS
+    if (variant == 6) TBVH_LT(k_tlas_flat_w6, 12, 16, 32, true);   // flat loop under the lockstep governor
     else if (variant == 7) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);         // flat loop, per-lane replacement throughout
     else if (variant == 9) TBVH_LT(k_tlas_flat_w6, 12, 64, 16);         // flat loop, lockstep throughout
     // flat-loop parameters swept without effect beyond +-3 %: phase threshold 24 / 40 / 48, refill threshold 8 / 24 / 32 (8: incoherent
@@ -751,8 +748,16 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
     else if (variant == 4) TBVH_LT(k_tlas, 8);
     else if (variant == 5) TBVH_LT(k_tlas, 16);        // round-1 kernel: nested loops, compiler's register budget (4 waves per SIMD)
     else if (variant == 1) TBVH_LT(k_tlas_w5, 16);
-    else TBVH_LT(k_tlas_w5, 12);                        // 3: nested loops at 5 waves per SIMD, 12-entry LDS stack top
+    else if (variant != 0) TBVH_LT(k_tlas_w5, 12);       // 3: nested loops at 5 waves per SIMD, 12-entry LDS stack top
+    else
+#endif
+    {
+        if (blasLayout == kLayoutCwbvh) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);
+        else TBVH_LT(k_tlas_adaptive, 12, 140);
+    }
 #undef TBVH_LT
 }
+
+bool tlas_variant_valid(int v) { return TBVH_EXPERIMENTS ? (v >= 0 && v <= 14) : v == 0; }
 
 }  // namespace tbvh

@@ -1,0 +1,123 @@
+"""A/B of kernel variants on the contract bench's own batches (not the contract benchmark — that is bench.py): the scene is
+built once, the primary / diffuse (bounce depths 1-3 in thirds) / shadow batches are generated once exactly as bench.py
+does, then every requested variant traces them PASSES times (tbvh_intersect_device_fresh, HIP events).  Needs a library
+built with `make -C tinybvh_amd/csrc EXPERIMENTS=1` for variants other than 0.
+    python tools/ab_probe.py --variants 0,51,52,53 [--scene bistro --side 4096 --layout 10 --stats 59,60,61]"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import tinybvh_amd as tb  # noqa: E402
+from tinybvh_amd import rays as R  # noqa: E402
+from tinybvh_amd import scenes  # noqa: E402
+
+
+def make_batches(ctx, sc, verts, cam, n, seed=1000):
+    d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
+    d_prim, d_diff, d_shad = (ctx.malloc(n * 64) for _ in range(3))
+    ext = float((verts[:, :3].max(0) - verts[:, :3].min(0)).max())
+    light = (0.0, 0.9 * float(verts[:, 1].max()), 0.0)
+    third = n // 3
+    ctx.generate_primary(cam, d_prim, 0, n)
+    sc.intersect_device(d_prim, n)
+    ctx.generate_shadow(d_prim, d_shad, n, light, ext * 5e-7)
+    ctx.generate_bounce(d_verts, d_prim, d_diff, n, seed + 1)
+    sc.intersect_device(d_diff + third * 64, n - third)
+    ctx.generate_bounce(d_verts, d_diff + third * 64, d_diff + third * 64, n - third, seed + 2)
+    sc.intersect_device(d_diff + 2 * third * 64, n - 2 * third)
+    ctx.generate_bounce(d_verts, d_diff + 2 * third * 64, d_diff + 2 * third * 64, n - 2 * third, seed + 3)
+    ctx.reset_hits(d_prim, n)
+    ctx.synchronize()
+    ctx.free(d_verts)
+    return d_prim, d_diff, d_shad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scene", default="bistro")
+    ap.add_argument("--side", type=int, default=4096)
+    ap.add_argument("--layout", type=int, default=10)
+    ap.add_argument("--variants", default="0")
+    ap.add_argument("--stats", default="", help="statistics variants (lane utilisation counters)")
+    ap.add_argument("--passes", type=int, default=4)
+    ap.add_argument("--out", default="")
+    ap.add_argument("--device-build", action="store_true")
+    a = ap.parse_args()
+    verts, label = scenes.get(a.scene)
+    ctx = tb.Context(0)
+    t0 = time.time()
+    cls = tb.LAYOUT_CLASSES[a.layout]
+    sc = cls(ctx).BuildOnDevice(verts) if a.device_build else cls(ctx).Build(verts)
+    print(f"scene: {label}: {verts.shape[0] // 3} tris; layout {a.layout}; build+upload {time.time() - t0:.1f}s; {sc.device_bytes / 1e6:.0f} MB", flush=True)
+    n = a.side * a.side
+    cams = scenes.STREET_CAMERAS if a.scene == "bistro" else scenes.SPONZA_CAMERAS
+    cam = R.camera(*cams[0], a.side, a.side, 1, 1)
+    d_prim, d_diff, d_shad = make_batches(ctx, sc, verts, cam, n)
+    d_occ = ctx.malloc(n)
+    res = {}
+    ref_hits = {}
+    for v in [int(x) for x in a.variants.split(",") if x]:
+        try:
+            sc.set_variant(v)
+        except tb.TbvhError as e:
+            print(f"variant {v}: {e}", flush=True)
+            continue
+        row = {}
+        for kind, d in (("primary", d_prim), ("diffuse", d_diff), ("shadow", d_shad)):
+            ms = []
+            for p in range(a.passes + 1):
+                if kind == "shadow":
+                    sc.occluded_device(d, n, d_occ)
+                else:
+                    sc.intersect_device_fresh(d, n, 1e30)
+                t = ctx.time_last_ms()
+                if p:
+                    ms.append(t)
+            row[kind] = n / (float(np.mean(ms)) * 1e-3) / 1e6
+            # cheap cross-check between variants: checksum of the hit prims (ties may differ) and number of hits
+            if kind != "shadow":
+                buf = np.zeros(min(n, 1 << 20), tb.RAY_DTYPE); ctx.from_device(buf, d)
+                key = (kind,)
+                sig = (int((buf["t"] < 1e30).sum()), int(buf["prim"].astype(np.uint64).sum()))
+                if v == 0 or key not in ref_hits:
+                    ref_hits.setdefault(key, (buf["prim"].copy(), buf["t"].copy()))
+                pr, tt = ref_hits[key]
+                row[kind + "_prim_diff"] = int((pr != buf["prim"]).sum())
+                row[kind + "_t_diff"] = int((tt != buf["t"]).sum())
+        res[v] = row
+        print(f"variant {v:3d}: primary {row['primary']:7.1f}  diffuse {row['diffuse']:7.1f}  shadow {row['shadow']:7.1f} MRays/s   "
+              f"primary+diffuse {2 * n / (n / row['primary'] + n / row['diffuse']):7.1f}   [vs first variant, first 1M rays: prim differs {row['primary_prim_diff']}/{row['diffuse_prim_diff']}, "
+              f"t differs {row['primary_t_diff']}/{row['diffuse_t_diff']}]", flush=True)
+    for v in [int(x) for x in a.stats.split(",") if x]:
+        try:
+            sc.set_variant(v)
+        except tb.TbvhError as e:
+            print(f"stats variant {v}: {e}", flush=True)
+            continue
+        for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
+            st = (C.c_uint64 * 8)()
+            tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+            sc.intersect_device_fresh(d, n, 1e30)
+            ms = ctx.time_last_ms()
+            tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+            it, act, node, titer, tri, rf, rfd, niter = [int(x) for x in st]
+            it = max(it, 1)
+            print(f"stats {v} [{kind}] {ms:.2f} ms: wave-iterations {it}  per ray {it * 64 / n:.1f}  active/64 {act / it / 64:.3f}  "
+                  f"node phases/iter {niter / it:.3f} at {node / max(niter, 1) / 64:.3f} lanes  ({node / n:.2f} node visits/ray)  "
+                  f"tri phases/iter {titer / it:.3f} at {tri / max(titer, 1) / 64:.3f} lanes ({tri / n:.2f} tri tests/ray)  "
+                  f"refills {rf} ({rfd / max(rf, 1):.1f} rays each)", flush=True)
+            res[f"stats{v}_{kind}"] = dict(ms=ms, iters=it, active=act, node_lanes=node, node_iters=niter, tri_iters=titer, tri_lanes=tri, refills=rf)
+    if a.out:
+        json.dump(res, open(a.out, "w"), indent=1)
+    sc.free(); ctx.close()
+
+
+if __name__ == "__main__":
+    main()

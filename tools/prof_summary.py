@@ -27,8 +27,10 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.cs
         meta[k] = (r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"), r.get("Scratch_Size"))
     print("== pmc", os.path.relpath(f, d))
     for k, cs in agg.items():
-        if "k_cwbvh" not in k and "k_bvh" not in k:
+        if "k_cwbvh" not in k and "k_bvh" not in k and "k_tlas" not in k:
             continue
         print(f"  {k}  vgpr/agpr/sgpr/lds/scratch={meta[k]}")
         for c, v in cs.items():
             print(f"      {c:36s} n={len(v):3d} mean={sum(v)/len(v):16.1f} min={min(v):16.1f} max={max(v):16.1f}")
+            if len(v) <= 16:   # per dispatch, in launch order (tools/ab_probe.py: 3 preparation launches, then primary / diffuse passes)
+                print("          per dispatch: " + " ".join(f"{x:.4g}" for x in v))
