@@ -15,6 +15,14 @@ tmax = 1e30 and every hit record is written, so each step does the full work of 
 the shadow pass is timed separately (HIP events) and reported in `detail`.  Rays are generated on the device before the timed region and
 are resident in HBM.  N > 1: the BVH is replicated, every rank traces its own batch
 (same camera, its own RNG seed for the bounce rays), no data-path collective: weak scaling.
+Beside it, `detail.config4_strong` is BASELINE.json configs[3] as specified: ONE 64 M-ray diffuse batch (8192 x 8192
+camera, bounce depths 1-3) cut into N contiguous wave-aligned shards (tinybvh_amd.sharding.shard_range), one per rank,
+timed with the same barrier / max-over-ranks rule: strong scaling.
+
+`roofline` carries the contract's algorithmic-HBM line for the dominant kernel (diffuse batch) and for the primary batch,
+the measured device copy bandwidth as a second denominator, the fabric-side traffic measured LIVE by a rocprofv3 --pmc
+child run of this same script (FETCH_SIZE and WRITE_SIZE in separate passes, MI355X_MICROARCH.md corrections), and the
+VALU-issue roofline of both kernels (what actually bounds them: DESIGN.md §5).
 
 One process per GPU; launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -46,6 +54,9 @@ def main():
     ap.add_argument("--layout", type=int, default=10, help="5 BVH_GPU, 8 BVH4_GPU, 10 BVH8_CWBVH (BVHBase::BVHType)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic from profiles/)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the 64 M-ray strong-scaling batch of config 4")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -120,6 +131,14 @@ def main():
     ctx.reset_hits(d_prim, n)
     ctx.synchronize()
 
+    if a.pmc_child:   # under rocprofv3 --pmc: 3 preparation launches above, then (primary, diffuse) x 3; nothing else
+        for _ in range(3):
+            sc.intersect_device_fresh(d_prim, n, 1e30)
+            sc.intersect_device_fresh(d_diff, n, 1e30)
+        ctx.synchronize()
+        ctx.close()
+        return
+
     kern_ms = {"primary": [], "diffuse": [], "shadow": []}
 
     def step(record: bool):
@@ -151,6 +170,48 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # ---- config 4 as BASELINE.json words it: ONE 64 M-ray diffuse batch, sharded over the ranks (strong scaling) ------
+    strong = None
+    if not a.no_strong:
+        try:
+            from tinybvh_amd.sharding import shard_range
+            side4 = 8192 if a.side >= 4096 else 2 * a.side
+            n4 = side4 * side4
+            b4, e4 = shard_range(n4, rank, world)
+            m4 = e4 - b4
+            cam4 = R.camera(eye, view, side4, side4, 1, 1)
+            d_a, d_b = ctx.malloc(max(m4, 1) * 64), ctx.malloc(max(m4, 1) * 64)
+            if m4:
+                # this rank's slice [b4, e4) of the global batch: camera rays of those pixels, bounced 1-3 times (thirds)
+                ctx.generate_primary(cam4, d_a, b4, m4)
+                sc.intersect_device(d_a, m4)
+                t3 = m4 // 3
+                ctx.generate_bounce(d_verts, d_a, d_b, m4, 4001)
+                sc.intersect_device(d_b + t3 * 64, m4 - t3)
+                ctx.generate_bounce(d_verts, d_b + t3 * 64, d_b + t3 * 64, m4 - t3, 4002)
+                sc.intersect_device(d_b + 2 * t3 * 64, m4 - 2 * t3)
+                ctx.generate_bounce(d_verts, d_b + 2 * t3 * 64, d_b + 2 * t3 * 64, m4 - 2 * t3, 4003)
+                sc.intersect_device_fresh(d_b, m4, 1e30)      # warm-up
+            sync_all()
+            t0 = time.perf_counter()
+            reps4 = 3
+            for _ in range(reps4):
+                if m4:
+                    sc.intersect_device_fresh(d_b, m4, 1e30)
+            sync_all()
+            el4 = time.perf_counter() - t0
+            if use_dist:
+                import torch
+                t = torch.tensor([el4], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el4 = float(t.item())
+            strong = {"workload": f"one {n4}-ray diffuse batch (depth 1-3), {world} contiguous wave-aligned shard(s), BVH replicated, no collective",
+                      "rays": n4, "ms_per_batch": el4 / reps4 * 1e3, "mrays": n4 / (el4 / reps4) / 1e6, "scaling": "strong",
+                      "rank0_shard": [b4, e4]}
+            ctx.free(d_a); ctx.free(d_b)
+        except Exception as e:
+            log(f"[bench] config 4 strong-scaling batch failed: {e!r}")
 
     # whole wavefront path-traced frames (Generate, {Extend, Shade} x 3, Connect; all queues on the
     # device) — config 4's pipeline end to end, reported in `detail` (outside the timed steps)
@@ -258,49 +319,80 @@ def main():
         detail["wavefront_frame_3_bounces"] = wf_detail
         detail["device_side_ops"] = dev_ops
         detail["tlas_1000_instances"] = tlas_detail
+        detail["config4_strong"] = strong
 
-        # roofline of the dominant kernel (CWBVH Intersect on the diffuse batch): algorithmic
-        # bytes per ray = 64 (ray in) + 16 (hit out) + node_bytes*S + tri_bytes*T, SURVEY.md
-        # §8(d), with S,T counted by the oracle's mirror of this layout on a sample of the same rays.
+        # roofline.  (1) The contract's line: algorithmic bytes per ray = 64 (ray in) + 16 (hit out) + node_bytes*S +
+        # tri_bytes*T, S / T counted by the oracle's mirror of this layout on a strided sample of the
+        # same rays, over the kernel's average launch time (HIP events around every timed launch) — for the dominant
+        # kernel (diffuse batch) and, in `primary`, for the camera batch.  (2) The VALU-issue roofline of both kernels:
+        # useful lane-operations per ray = S * (VALU instructions of one node visit) + T * (of one triangle test) + the
+        # per-ray fixed part, counted in the ISA of the shipped kernel, against 256 CUs x 4 SIMDs x 16
+        # lanes per clock (a wave64 VALU instruction issues over 4 cycles) at 2.4 GHz.
         roof = None
         try:
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             from oracle_lib import Oracle
             orc = Oracle()
             ns = 65536
-            sample = np.zeros(ns, dtype=tb.RAY_DTYPE)
             stride = max(n // ns, 1)
-            # strided sample of the diffuse batch, re-armed
-            full = np.zeros(n, dtype=tb.RAY_DTYPE) if n * 64 <= (2 << 30) else None
-            if full is not None:
-                ctx.from_device(full, d_diff)
+            h = sc.host
+
+            def counts(dptr):
+                full = np.zeros(n, dtype=tb.RAY_DTYPE)
+                ctx.from_device(full, dptr)
                 sample = full[::stride][:ns].copy()
                 del full
-            sample["t"] = 1e30
-            h = sc.host
-            if a.layout == tb.LAYOUT_CWBVH:
-                _, cnt = orc.cwbvh_intersect(h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4), sample, counts=True)
-                nb, tbytes = 80, 48
-            elif a.layout == tb.LAYOUT_BVH4_GPU:
-                _, cnt = orc.bvh4_intersect(h.blob(0, np.uint32, 4), sample, counts=True)
-                nb, tbytes = 64, 48
-            else:
-                _, cnt = orc.bvhgpu_intersect(h.blob(0, np.uint32, 16), h.blob(1, np.uint32, 1), verts, sample, counts=True)
-                nb, tbytes = 64, 52
-            S, T = float(cnt[0]) / sample.shape[0], float(cnt[1]) / sample.shape[0]
-            bytes_per_ray = 64 + 16 + nb * S + tbytes * T
-            achieved = bytes_per_ray * n / (mean["diffuse"] * 1e-3) / 1e9
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(pmc):
-                try:
-                    traffic = json.load(open(pmc)).get("diffuse_kernel_hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            roof = {"bound": "hbm", "kernel": "k_cwbvh<false> (diffuse batch)" if a.layout == tb.LAYOUT_CWBVH else "intersect (diffuse batch)",
-                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                    "traffic": traffic, "algorithmic_bytes_per_ray": bytes_per_ray, "nodes_per_ray": S, "tris_per_ray": T,
-                    "avg_launch_ms": mean["diffuse"]}
+                sample["t"] = 1e30
+                if a.layout == tb.LAYOUT_CWBVH:
+                    _, cnt = orc.cwbvh_intersect(h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4), sample, counts=True)
+                elif a.layout == tb.LAYOUT_BVH4_GPU:
+                    _, cnt = orc.bvh4_intersect(h.blob(0, np.uint32, 4), sample, counts=True)
+                else:
+                    _, cnt = orc.bvhgpu_intersect(h.blob(0, np.uint32, 16), h.blob(1, np.uint32, 1), verts, sample, counts=True)
+                return float(cnt[0]) / sample.shape[0], float(cnt[1]) / sample.shape[0]
+            nb, tbytes = {tb.LAYOUT_CWBVH: (80, 48), tb.LAYOUT_BVH4_GPU: (64, 48), tb.LAYOUT_BVH_GPU: (64, 52)}[a.layout]
+            # VALU instructions per node visit (test + stack / group bookkeeping), per triangle test, per ray (fetch, octant,
+            # write-back): counted in the gfx950 ISA of the shipped kernels (hipcc -S; DESIGN.md §5 lists the blocks)
+            valu_node, valu_tri, valu_ray = {tb.LAYOUT_CWBVH: (235, 65, 70), tb.LAYOUT_BVH4_GPU: (150, 65, 70), tb.LAYOUT_BVH_GPU: (60, 65, 70)}[a.layout]
+            valu_peak = 256 * 4 * 16 * 2.4   # G lane-ops/s
+            copy_gbps = None
+            try:
+                copy_gbps = ctx.copy_bandwidth_gbps(1 << 30, 3)
+            except Exception as e:
+                log(f"[bench] copy bandwidth measurement failed: {e!r}")
+            traffic, traffic_src = live_pmc_traffic(a, log) if (world == 1 and not a.no_pmc) else (None, None)
+            if traffic is None:
+                pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+                if os.path.exists(pmc):
+                    try:
+                        j = json.load(open(pmc))
+                        traffic = {"diffuse": j.get("diffuse_kernel_hbm_bytes_per_launch"), "primary": j.get("primary_kernel_hbm_bytes_per_launch")}
+                        traffic_src = "profiles/pmc_traffic.json (committed rocprofv3 --pmc run of this command)"
+                    except Exception:
+                        traffic = None
+            lines = {}
+            for kind, dptr in (("diffuse", d_diff), ("primary", d_prim)):
+                S, T = counts(dptr)
+                bpr = 64 + 16 + nb * S + tbytes * T
+                ach = bpr * n / (mean[kind] * 1e-3) / 1e9
+                lane_ops = (S * valu_node + T * valu_tri + valu_ray) * n / (mean[kind] * 1e-3) / 1e9
+                lines[kind] = {"achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
+                               "frac_of_measured_copy": (ach / copy_gbps) if copy_gbps else None,
+                               "traffic": (traffic or {}).get(kind), "algorithmic_bytes_per_ray": bpr, "nodes_per_ray": S, "tris_per_ray": T,
+                               "avg_launch_ms": mean[kind],
+                               "valu_issue": {"achieved": lane_ops, "peak": valu_peak, "unit": "G lane-ops/s", "frac": lane_ops / valu_peak}}
+            kname = {tb.LAYOUT_CWBVH: "k_cwbvh<false>", tb.LAYOUT_BVH4_GPU: "k_bvh4_w8<false>", tb.LAYOUT_BVH_GPU: "k_bvh2<false>"}[a.layout]
+            d_ = lines["diffuse"]
+            roof = {"bound": "hbm", "kernel": kname + " (diffuse batch)", "achieved": d_["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": d_["frac"],
+                    "traffic": d_["traffic"], "traffic_source": traffic_src,
+                    "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": d_["frac_of_measured_copy"],
+                    "algorithmic_bytes_per_ray": d_["algorithmic_bytes_per_ray"], "nodes_per_ray": d_["nodes_per_ray"], "tris_per_ray": d_["tris_per_ray"],
+                    "avg_launch_ms": d_["avg_launch_ms"], "valu_issue": d_["valu_issue"],
+                    "valu_issue_model": {"lane_ops_per_node_visit": valu_node, "lane_ops_per_triangle_test": valu_tri, "lane_ops_per_ray": valu_ray,
+                                         "peak": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz"},
+                    "limiter": "VALU issue and the per-CU L1 miss path, not HBM: the tree lives in the 256 MB Infinity Cache (DESIGN.md §5); "
+                               "`frac` is algorithmic bytes over the HBM peak as the contract defines it",
+                    "primary": lines["primary"]}
         except Exception as e:  # the checker is optional for the number itself
             log(f"[bench] roofline sample failed: {e!r}")
 
@@ -317,7 +409,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}; BVH8_CWBVH; per GPU per step {n} primary + {n} diffuse (depth 1-3) Intersect; + {n} shadow IsOccluded timed separately",
                        "scene_tris": n_tris, "layout": {5: "BVH_GPU", 8: "BVH4_GPU", 10: "BVH8_CWBVH"}[a.layout],
-                       "rays_per_gpu_per_step": 2 * n, "shadow_rays_per_gpu": n, "sharding": f"rays x{world}, BVH replicated, no collective"},
+                       "rays_per_gpu_per_step": 2 * n, "shadow_rays_per_gpu": n, "sharding": f"value: weak — every rank its own {2 * n}-ray step, BVH replicated, no collective; detail.config4_strong: one 64 M-ray batch in {world} contiguous shard(s)"},
             "detail": detail, "roofline": roof, "cpu_baseline": cpu,
         }
         flush_c_stdio()
@@ -344,9 +436,55 @@ def usable_cores():
     return max(1, n)
 
 
+def live_pmc_traffic(a, log):
+    """Fabric-side bytes per launch of the two timed kernels, measured now: this script is run again as a short child
+    (--pmc-child: same scene, same batches, three (primary, diffuse) launch pairs) under `rocprofv3 --pmc FETCH_SIZE` and,
+    separately, `--pmc WRITE_SIZE` (TCC counters do not fit one pass; --kernel-trace only).  FETCH_SIZE is in KB and
+    tallies 64 of every 128 bytes on gfx950 (MI355X_MICROARCH.md), hence x 1024 x 2; WRITE_SIZE x 1024 taken as is.
+    Infinity-Cache hits are counted, so this is an upper bound on HBM bytes.  Returns ({"primary": bytes, "diffuse": bytes}, source)
+    or (None, None)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, None
+    out = {"primary": 0.0, "diffuse": 0.0}
+    for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+        d = tempfile.mkdtemp(prefix="tbvh_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--output-format", "csv", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--pmc-child", "--scene", a.scene, "--side", str(a.side), "--layout", str(a.layout),
+               "--variant", str(a.variant)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST"):
+            env.pop(k, None)
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    kn = r["Kernel_Name"]
+                    if r["Counter_Name"] == counter and ("k_cwbvh<false" in kn or "k_bvh4_w8<false" in kn or "k_bvh4<false" in kn or "k_bvh2<false" in kn):
+                        rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
+            rows.sort()
+            vals = [v for _, v in rows][-6:]          # (primary, diffuse) x 3; the first pair warms the caches
+            if len(vals) != 6:
+                raise RuntimeError(f"{len(rows)} traversal dispatches in the {counter} pass, expected at least 6")
+            out["primary"] += (vals[2] + vals[4]) / 2 * scale
+            out["diffuse"] += (vals[3] + vals[5]) / 2 * scale
+        except Exception as e:
+            log(f"[bench] rocprofv3 --pmc {counter} child failed: {e!r}")
+            return None, None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (FETCH_SIZE x 2, guide correction); includes Infinity-Cache hits"
+
+
 def cpu_baseline(tb, ctx, verts, d_prim, d_diff, n):
-    """Reference BVH8_CPU (AVX2) on all host cores over a bounded sample of the same rays
-    (oracle/_ref, kind 'reference'); falls back to the single-threaded C oracle ('port')."""
+    """Reference BVH8_CPU (AVX2) on all host cores over a bounded sample of the same rays (oracle/_ref, kind 'reference'),
+    plus — SURVEY.md §8(d) — the same on ONE thread and BVH::Intersect (the oracle's own traversal) on all cores and on
+    one; falls back to the single-threaded C restatement ('port') where oracle/_ref is absent."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle, Reference, have_reference
     ns = min(1 << 23, n)  # 8 M primary + 8 M diffuse: a bounded sample, seconds of CPU work
@@ -364,8 +502,18 @@ def cpu_baseline(tb, ctx, verts, d_prim, d_diff, n):
         rs.time_mt(8, batches[0][:1024], threads=1)  # builds BVH8_CPU
         log(f"[bench] reference BVH + BVH8_CPU build {time.time() - t0:.1f}s")
         sec = sum(rs.time_mt(8, b, threads=cores)[0] for b in batches)
+
+        def rate(layout, threads, k):   # k rays of each batch, strided over the sample
+            sub = [np.ascontiguousarray(b[:: max(ns // k, 1)][:k]) for b in batches]
+            return sum(x.shape[0] for x in sub) / sum(rs.time_mt(layout, x, threads=threads)[0] for x in sub) / 1e6, sub[0].shape[0]
+        r8_1, k8 = rate(8, 1, 1 << 20)
+        r1_mt, k1m = rate(1, cores, 1 << 21)
+        r1_1, k11 = rate(1, 1, 1 << 18)
         return {"value": 2 * ns / sec / 1e6, "unit": "MRays/s", "cores": cores, "kind": "reference",
-                "sample": f"tinybvh BVH8_CPU::Intersect (AVX2), {cores} threads, {ns} primary + {ns} diffuse rays of the GPU batches"}
+                "sample": f"tinybvh BVH8_CPU::Intersect (AVX2), {cores} threads, {ns} primary + {ns} diffuse rays of the GPU batches",
+                "threads_1": {"value": r8_1, "unit": "MRays/s", "cores": 1, "sample": f"BVH8_CPU::Intersect, 1 thread, {k8} + {k8} rays"},
+                "bvh_intersect": {"value": r1_mt, "unit": "MRays/s", "cores": cores, "sample": f"BVH::Intersect (the parity oracle's traversal), {cores} threads, {k1m} + {k1m} rays",
+                                  "threads_1": {"value": r1_1, "unit": "MRays/s", "cores": 1, "sample": f"BVH::Intersect, 1 thread, {k11} + {k11} rays"}}}
     orc = Oracle()
     h = tb.HostBVH(verts, tb.LAYOUT_BVH2_WALD)
     ns2 = 100_000

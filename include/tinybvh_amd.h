@@ -232,6 +232,11 @@ int tbvh_reset_hits_device(tbvh_context* ctx, void* d_rays64, uint64_t n_rays, f
  * Synchronizes the stream. */
 float tbvh_time_last_ms(tbvh_context* ctx);
 
+/* Measured device copy bandwidth (GB/s, read + written bytes of a streaming 16-bytes-per-lane copy kernel over `bytes`,
+ * best of `reps` launches; MI355X: ~8 TB/s HBM3E peak, ~6 TB/s achievable): the second denominator for "fraction of the
+ * memory roofline" figures, next to the data-sheet peak. */
+int tbvh_measure_copy_bandwidth(tbvh_context* ctx, uint64_t bytes, uint32_t reps, double* gbps);
+
 /* Lane-utilisation counters of the instrumented kernel variants (development aid):
  * out[0] wave iterations, [1] sum of active lanes, [2] sum of lanes in the node step,
  * [3] triangle-loop iterations, [4] sum of lanes in them, [5] refill events, [6] rays handed out. */
@@ -288,8 +293,16 @@ typedef struct tbvh_wf_params {
     float light_size[2];  /* extent of the rectangular light along x and z, centred at light_pos, facing down
                              (wavefront.cl:208: 9 x 5); 0, 0 = point light                   */
     uint32_t flags;       /* TBVH_WF_*                                                      */
+    uint32_t sample_index; /* the demo's spp - 1 (tiny_bvh_gpu.cpp:147): frames 0..3 take the random numbers of a path's first
+                             vertex from the blue-noise table, if one is set (wavefront.cl:183-189)  */
 } tbvh_wf_params;
 #define TBVH_WF_ONE_DIFFUSE_BOUNCE 1u /* a path ends at its second diffuse vertex, as in wavefront.cl:233 */
+#define TBVH_WF_REFERENCE_LETTER   2u /* follow wavefront.cl to the letter in the three places where Shade otherwise follows its
+                                         intent: a path leaving the scene adds T * sky BEFORE the postponed pdf is divided out
+                                         (wavefront.cl:151-156 vs :180), a light reached by a BSDF sample is weighted with
+                                         LightPDF( D.w = 1e30 ) (:174: the weight vanishes), and bounces use tools.cl:34-39's
+                                         CosWeightedDiffReflection (a world-space half sphere added to N).  For comparing images
+                                         with the reference's own kernels (tests/test_wavefront_reference.py). */
 #define TBVH_MATERIAL_DIFFUSE  0u     /* v0.w of a triangle's first vertex: type << 24 | 0xRRGGBB (wavefront.cl:12-13, 160) */
 #define TBVH_MATERIAL_LIGHT    1u
 #define TBVH_MATERIAL_SPECULAR 2u
@@ -308,6 +321,10 @@ int  tbvh_wavefront_render(tbvh_wavefront* wf, tbvh_scene* scene, const void* d_
  * (wavefront2.cl:183 picks bistroVerts / dragonVerts by instance); tbvh_wavefront_render then takes the TLAS scene and
  * ignores d_verts16.  Normals go to world space through the instance's inverse transform. */
 int  tbvh_wavefront_set_blas_vertices(tbvh_wavefront* wf, const void* const* d_verts16_per_blas, uint64_t n_blas);
+/* The blue-noise table of the demos (tiny_bvh_gpu.cpp:61-66: testdata/blue_noise_128x128x8_2d.raw, 128 x 128 x 8 32-bit words,
+ * two 8-bit channels per word; wavefront.cl:24-31).  With a table set, frames with sample_index < 4 draw the four random numbers of
+ * every path's first vertex from it.  table = NULL removes it.  The data is copied. */
+int  tbvh_wavefront_set_blue_noise(tbvh_wavefront* wf, const uint32_t* table, uint64_t n_words);
 /* copy the float RGBA accumulator (width * height * 4 floats, row-major) to the host */
 int  tbvh_wavefront_read(tbvh_wavefront* wf, float* rgba);
 /* Finalize (wavefront.cl:275-286): accumulator * scale, square root, 8 bits per channel: width * height x 0x00RRGGBB */

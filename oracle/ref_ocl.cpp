@@ -16,13 +16,20 @@
 #include <CL/cl.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 static const char* kSource =
 #include "_ref/ref_cl_source.inc"
+    ;
+// wavefront.cl with all its #includes expanded (tools.cl, traverse.cl and the per-layout files): the path tracer of
+// tiny_bvh_gpu.cpp, run here frame by frame exactly as that demo's Tick() does (tiny_bvh_gpu.cpp:128-158)
+static const char* kWavefrontSource =
+#include "_ref/ref_wavefront_source.inc"
     ;
 
 namespace {
@@ -130,6 +137,123 @@ double refocl_run(int layout, const void* buf0, uint64_t bytes0, const void* buf
     for (int i = 0; i <= nb; i++) clReleaseMemObject(mem[i]);
     clReleaseKernel(k);
     return total / (passes > 0 ? passes : 1);
+}
+
+// ---- the reference's wavefront path tracer (wavefront.cl), frame loop of tiny_bvh_gpu.cpp:128-158 --------------------
+// nodes / tris: BVH8_CWBVH blobs; verts: the vertex array (3 float4 per triangle, material in v0.w); noise: the 128 x 128 x 8
+// blue-noise table; eye, p0, p1, p2: camera (float4 each); renders `frames` frames into one accumulator (spp = 1 .. frames,
+// frame seeds as the demo's) and returns accumulator / frames as width * height float4.  Returns 0 or a negative error.
+namespace { cl_program g_wprog = nullptr; std::string g_wpatch; }
+// patch: "old text=>new text;;old2=>new2" edits applied to the source before it is compiled (NULL or "" = the reference's text as
+// it is).  tests/test_wavefront_reference.py uses it for ONE documented purpose: Connect adds a shadow ray's contribution with a
+// plain read-modify-write (wavefront.cl:265), which loses contributions when two shadow rays of one pixel are in flight; the
+// test's patch makes that addition atomic.  tools/wf_debug.py uses it to switch terms off while bisecting.
+int refocl_wavefront(const void* nodes, uint64_t nodeBytes, const void* tris, uint64_t triBytes, const void* verts, uint64_t vertBytes,
+                     const uint32_t* noise, const float* eye, const float* p0, const float* p1, const float* p2, uint32_t width, uint32_t height,
+                     uint32_t frames, uint32_t iterations, const char* patch, float* out) {
+    if (refocl_init()) return -1;
+    if (iterations == 0 || iterations > 3) iterations = 3;   // the demo runs 3 (tiny_bvh_gpu.cpp:143); fewer isolates the first vertices for debugging
+    cl_int e;
+    const std::string wantPatch = patch ? patch : "";
+    if (!g_wprog || wantPatch != g_wpatch) {
+        if (g_wprog) { clReleaseProgram(g_wprog); g_wprog = nullptr; }
+        std::string src = std::string("#define ISAMD\n") + kWavefrontSource;
+        for (size_t at = 0; at < wantPatch.size();) {
+            size_t end = wantPatch.find(";;", at); if (end == std::string::npos) end = wantPatch.size();
+            const std::string one = wantPatch.substr(at, end - at);
+            const size_t arrow = one.find("=>");
+            if (arrow != std::string::npos) {
+                const std::string from = one.substr(0, arrow), to = one.substr(arrow + 2);
+                size_t pos = src.find(from), cnt = 0;
+                while (pos != std::string::npos && !from.empty()) { src.replace(pos, from.size(), to); pos = src.find(from, pos + to.size()); cnt++; }
+                if (cnt == 0) { snprintf(g_err, sizeof g_err, "wavefront: patch text not found: %s", from.c_str()); return -11; }
+            }
+            at = end + 2;
+        }
+        const char* s = src.c_str();
+        size_t len = src.size();
+        g_wprog = clCreateProgramWithSource(g_ctx, 1, &s, &len, &e);
+        if (e != CL_SUCCESS) { snprintf(g_err, sizeof g_err, "wavefront: clCreateProgramWithSource %d", e); return -5; }
+        e = clBuildProgram(g_wprog, 0, nullptr, "-cl-std=CL2.0 -cl-strict-aliasing -cl-fast-relaxed-math -cl-single-precision-constant ", nullptr, nullptr);
+        if (e != CL_SUCCESS) {
+            size_t n = 0;
+            clGetProgramBuildInfo(g_wprog, g_dev, CL_PROGRAM_BUILD_LOG, sizeof g_err - 64, g_err + 32, &n);
+            memcpy(g_err, "wavefront clBuildProgram failed:", 32);
+            g_wprog = nullptr;
+            return -6;
+        }
+        g_wpatch = wantPatch;
+    }
+    const char* names[9] = {"SetRenderData", "Clear", "Generate", "Extend", "Shade", "UpdateCounters1", "UpdateCounters2", "Connect", "Finalize"};
+    cl_kernel k[9];
+    for (int i = 0; i < 9; i++) {
+        k[i] = clCreateKernel(g_wprog, names[i], &e);
+        if (e != CL_SUCCESS) { snprintf(g_err, sizeof g_err, "wavefront: clCreateKernel(%s) %d", names[i], e); return -7; }
+    }
+    cl_uint cus = 0;
+    clGetDeviceInfo(g_dev, CL_DEVICE_MAX_COMPUTE_UNITS, sizeof cus, &cus, nullptr);
+    const size_t N = (size_t)width * height;
+    auto mk = [&](size_t bytes, const void* host, cl_mem_flags fl) {
+        cl_int ee;
+        cl_mem m = clCreateBuffer(g_ctx, fl | (host ? CL_MEM_COPY_HOST_PTR : 0), bytes ? bytes : 16, (void*)host, &ee);
+        if (ee != CL_SUCCESS) { snprintf(g_err, sizeof g_err, "wavefront: clCreateBuffer(%zu) %d", bytes, ee); return (cl_mem) nullptr; }
+        return m;
+    };
+    cl_mem mNodes = mk(nodeBytes, nodes, CL_MEM_READ_ONLY), mTris = mk(triBytes, tris, CL_MEM_READ_ONLY), mVerts = mk(vertBytes, verts, CL_MEM_READ_ONLY);
+    cl_mem mNoise = mk(128 * 128 * 8 * 4, noise, CL_MEM_READ_ONLY);
+    cl_mem mIn = mk(N * 64, nullptr, CL_MEM_READ_WRITE), mOut = mk(N * 64, nullptr, CL_MEM_READ_WRITE);
+    cl_mem mConn = mk(N * 3 * 48, nullptr, CL_MEM_READ_WRITE), mAcc = mk(N * 16, nullptr, CL_MEM_READ_WRITE);
+    if (!mNodes || !mTris || !mVerts || !mNoise || !mIn || !mOut || !mConn || !mAcc) return -8;
+    auto run1 = [&](cl_kernel kk, size_t global, size_t local) {
+        const cl_int ee = clEnqueueNDRangeKernel(g_q, kk, 1, nullptr, &global, local ? &local : nullptr, 0, nullptr, nullptr);
+        if (ee != CL_SUCCESS) snprintf(g_err, sizeof g_err, "wavefront: clEnqueueNDRangeKernel %d", ee);
+        return ee;
+    };
+    auto run2 = [&](cl_kernel kk) {
+        const size_t g[2] = {width, height};
+        const cl_int ee = clEnqueueNDRangeKernel(g_q, kk, 2, nullptr, g, nullptr, 0, nullptr, nullptr);
+        if (ee != CL_SUCCESS) snprintf(g_err, sizeof g_err, "wavefront: clEnqueueNDRangeKernel 2D %d", ee);
+        return ee;
+    };
+    // Clear (tiny_bvh_gpu.cpp:133-137)
+    clSetKernelArg(k[1], 0, sizeof(cl_mem), &mAcc);
+    if (run1(k[1], N, 0)) return -9;
+    cl_uint frameIdx = 1;
+    const cl_int nPrimary = (cl_int)N;
+    const cl_uint W = width, H = height;
+    for (cl_uint spp = 1; spp <= frames; spp++, frameIdx++) {
+        // SetRenderData( N, eye, p0, p1, p2, frameIdx, W, H, nodes, tris, noise )  (:139-140)
+        clSetKernelArg(k[0], 0, sizeof(cl_int), &nPrimary);
+        clSetKernelArg(k[0], 1, 16, eye); clSetKernelArg(k[0], 2, 16, p0); clSetKernelArg(k[0], 3, 16, p1); clSetKernelArg(k[0], 4, 16, p2);
+        clSetKernelArg(k[0], 5, sizeof(cl_uint), &frameIdx); clSetKernelArg(k[0], 6, sizeof(cl_uint), &W); clSetKernelArg(k[0], 7, sizeof(cl_uint), &H);
+        clSetKernelArg(k[0], 8, sizeof(cl_mem), &mNodes); clSetKernelArg(k[0], 9, sizeof(cl_mem), &mTris); clSetKernelArg(k[0], 10, sizeof(cl_mem), &mNoise);
+        if (run1(k[0], 1, 0)) return -9;
+        // Generate( raysOut, spp * 19191 )  (:141-142)
+        const cl_uint seed = spp * 19191u;
+        clSetKernelArg(k[2], 0, sizeof(cl_mem), &mOut); clSetKernelArg(k[2], 1, sizeof(cl_uint), &seed);
+        if (run2(k[2])) return -9;
+        for (uint32_t i = 0; i < iterations; i++) {   // (:143-152)
+            std::swap(mIn, mOut);
+            clSetKernelArg(k[3], 0, sizeof(cl_mem), &mIn);
+            if (run1(k[3], (size_t)cus * 64 * 16, 64)) return -9;
+            if (run1(k[5], 1, 0)) return -9;
+            const cl_uint sampleIdx = spp - 1;
+            clSetKernelArg(k[4], 0, sizeof(cl_mem), &mAcc); clSetKernelArg(k[4], 1, sizeof(cl_mem), &mIn); clSetKernelArg(k[4], 2, sizeof(cl_mem), &mOut);
+            clSetKernelArg(k[4], 3, sizeof(cl_mem), &mConn); clSetKernelArg(k[4], 4, sizeof(cl_mem), &mVerts); clSetKernelArg(k[4], 5, sizeof(cl_uint), &sampleIdx);
+            if (run1(k[4], (size_t)cus * 64 * 16, 64)) return -9;
+            if (run1(k[6], 1, 0)) return -9;
+        }
+        // Connect( accumulator, connections )  (:153-154)
+        clSetKernelArg(k[7], 0, sizeof(cl_mem), &mAcc); clSetKernelArg(k[7], 1, sizeof(cl_mem), &mConn);
+        if (run1(k[7], (size_t)cus * 64 * 8, 64)) return -9;
+    }
+    e = clEnqueueReadBuffer(g_q, mAcc, CL_TRUE, 0, N * 16, out, 0, nullptr, nullptr);
+    if (e != CL_SUCCESS) { snprintf(g_err, sizeof g_err, "wavefront: clEnqueueReadBuffer %d", e); return -10; }
+    const float inv = 1.0f / (float)frames;
+    for (size_t i = 0; i < N * 4; i++) out[i] *= inv;
+    for (cl_mem m : {mNodes, mTris, mVerts, mNoise, mIn, mOut, mConn, mAcc}) clReleaseMemObject(m);
+    for (int i = 0; i < 9; i++) clReleaseKernel(k[i]);
+    return 0;
 }
 
 }  // extern "C"

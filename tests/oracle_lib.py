@@ -264,9 +264,25 @@ class ReferenceOpenCL:
         L.refocl_device.restype = C.c_char_p
         L.refocl_run.restype = C.c_double
         L.refocl_run.argtypes = [C.c_int, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64, C.c_int]
+        L.refocl_wavefront.restype = C.c_int
+        L.refocl_wavefront.argtypes = [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, _vp]
         if L.refocl_init() != 0:
             raise RuntimeError("reference OpenCL kernels unavailable: " + L.refocl_error().decode(errors="replace")[:2000])
         self.device = L.refocl_device().decode()
+
+    def wavefront(self, nodes, tris, verts, noise, eye, p0, p1, p2, width, height, frames, iterations=3, patch=""):
+        """The reference's wavefront.cl path tracer, driven like tiny_bvh_gpu.cpp:128-158 for `frames` frames; returns the
+        averaged accumulator as (height, width, 4) float32."""
+        nodes, tris, verts = (np.ascontiguousarray(x) for x in (nodes, tris, verts))
+        noise = np.ascontiguousarray(noise, np.uint32).reshape(-1)
+        assert noise.size == 128 * 128 * 8
+        v4 = [np.ascontiguousarray(list(x) + [0.0], np.float32) for x in (eye, p0, p1, p2)]
+        out = np.zeros((height, width, 4), np.float32)
+        r = self.lib.refocl_wavefront(_p(nodes), nodes.nbytes, _p(tris), tris.nbytes, _p(verts), verts.nbytes, _p(noise), _p(v4[0]), _p(v4[1]), _p(v4[2]), _p(v4[3]),
+                                      width, height, frames, iterations, patch.encode(), _p(out))
+        if r != 0:
+            raise RuntimeError(f"refocl_wavefront: {r}: " + self.lib.refocl_error().decode(errors="replace")[:3000])
+        return out
 
     def run(self, layout, blobs, rays, passes=3):
         """blobs: list of numpy arrays in kernel-argument order.  Returns (rays_out, mean_ms)."""

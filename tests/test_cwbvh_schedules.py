@@ -11,7 +11,7 @@ from oracle_lib import compare_hits
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [51, 52, 53, 54, 55, 56, 57, 58, 62, 63, 64, 65, 66, 67, 68, 69])
+@pytest.mark.parametrize("variant", [51, 52, 53, 54, 55, 56, 57, 58, 62, 63, 64, 65, 66, 67, 68, 69, 70, 71])
 def test_schedule_variant_matches_the_oracle(ctx, oracle, variant):
     verts = scenes.soup(20_000, seed=5)
     sc = tb.BVH8_CWBVH(ctx).Build(verts)

@@ -92,6 +92,12 @@ class Context:
     def set_stream(self, hip_stream: Optional[int]):
         check(lib.tbvh_set_stream(self._h, C.c_void_p(hip_stream or 0)), "tbvh_set_stream")
 
+    def copy_bandwidth_gbps(self, nbytes: int = 1 << 30, reps: int = 3) -> float:
+        """Measured streaming-copy bandwidth of this device (tbvh_measure_copy_bandwidth), GB/s read + written."""
+        g = C.c_double(0)
+        check(lib.tbvh_measure_copy_bandwidth(self._h, nbytes, reps, C.byref(g)), "tbvh_measure_copy_bandwidth")
+        return float(g.value)
+
     def time_last_ms(self) -> float:
         return float(lib.tbvh_time_last_ms(self._h))
 
@@ -503,12 +509,13 @@ class Wavefront:
 
     def render(self, scene: _Scene, d_verts: int, cam: Camera, light_pos, light_color=(1.0, 1.0, 1.0), sky_lo=(0.6, 0.7, 0.8), sky_hi=(0.2, 0.4, 0.9),
                eps: float = 1e-3, max_depth: int = 3, seed: int = 1, clear: bool = True, stats: bool = True,
-               light_size=(0.0, 0.0), one_diffuse_bounce: bool = False):
+               light_size=(0.0, 0.0), one_diffuse_bounce: bool = False, reference_letter: bool = False, sample_index: int = 0xFFFFFFFF):
         p = _capi.WfParams()
         p.light_pos[:] = [float(x) for x in light_pos]; p.light_color[:] = [float(x) for x in light_color]
         p.sky_lo[:] = [float(x) for x in sky_lo]; p.sky_hi[:] = [float(x) for x in sky_hi]
         p.eps, p.max_depth, p.seed, p.clear = float(eps), int(max_depth), int(seed), int(clear)
-        p.light_size[:] = [float(x) for x in light_size]; p.flags = 1 if one_diffuse_bounce else 0
+        p.light_size[:] = [float(x) for x in light_size]; p.flags = (1 if one_diffuse_bounce else 0) | (2 if reference_letter else 0)
+        p.sample_index = int(sample_index) & 0xFFFFFFFF
         st = _capi.WfStats()
         check(lib.tbvh_wavefront_render(self._h, scene._h, C.c_void_p(d_verts) if d_verts else None, C.byref(cam), C.byref(p), C.byref(st) if stats else None), "tbvh_wavefront_render")
         if not stats:
@@ -519,6 +526,14 @@ class Wavefront:
         img = np.zeros((self.height, self.width, 4), np.float32)
         check(lib.tbvh_wavefront_read(self._h, _ptr(img)), "tbvh_wavefront_read")
         return img
+
+    def set_blue_noise(self, table) -> None:
+        """The demos' 128 x 128 x 8 blue-noise table (uint32 words), or None to remove it (tbvh_wavefront_set_blue_noise)."""
+        if table is None:
+            check(lib.tbvh_wavefront_set_blue_noise(self._h, None, 0), "tbvh_wavefront_set_blue_noise")
+            return
+        t = np.ascontiguousarray(table, np.uint32).reshape(-1)
+        check(lib.tbvh_wavefront_set_blue_noise(self._h, _ptr(t), t.size), "tbvh_wavefront_set_blue_noise")
 
     def set_blas_vertices(self, d_verts_per_blas: list) -> None:
         """TLAS scenes: the device vertex array of every BLAS, in blasIdx order (tbvh_wavefront_set_blas_vertices)."""

@@ -28,7 +28,7 @@ class Camera(C.Structure):
 
 class WfParams(C.Structure):
     _fields_ = [("light_pos", C.c_float * 3), ("light_color", C.c_float * 3), ("sky_lo", C.c_float * 3), ("sky_hi", C.c_float * 3),
-                ("eps", C.c_float), ("max_depth", _u32), ("seed", _u32), ("clear", _u32), ("light_size", C.c_float * 2), ("flags", _u32)]
+                ("eps", C.c_float), ("max_depth", _u32), ("seed", _u32), ("clear", _u32), ("light_size", C.c_float * 2), ("flags", _u32), ("sample_index", _u32)]
 
 
 class WfStats(C.Structure):
@@ -42,6 +42,7 @@ SYMBOLS = {
     "tbvh_wavefront_read": (_i, [_vp, _vp]),
     "tbvh_wavefront_set_blas_vertices": (_i, [_vp, _vp, _u64]),
     "tbvh_wavefront_finalize": (_i, [_vp, C.c_float, _vp]),
+    "tbvh_wavefront_set_blue_noise": (_i, [_vp, _vp, _u64]),
     "tbvh_abi_version": (_i, []),
     "tbvh_last_error": (C.c_char_p, []),
     "tbvh_device_count": (_i, []),
@@ -74,6 +75,7 @@ SYMBOLS = {
     "tbvh_intersect_device_fresh": (_i, [_vp, _vp, _u64, C.c_float]),
     "tbvh_reset_hits_device": (_i, [_vp, _vp, _u64, C.c_float]),
     "tbvh_time_last_ms": (C.c_float, [_vp]),
+    "tbvh_measure_copy_bandwidth": (_i, [_vp, _u64, _u32, C.POINTER(C.c_double)]),
     "tbvh_set_variant": (_i, [_vp, _i]),
     "tbvh_debug_stats": (_i, [_vp, _vp, _i]),
     "tbvh_generate_primary_device": (_i, [_vp, C.POINTER(Camera), _vp, _u64, _u64]),

@@ -85,6 +85,7 @@ struct tbvh_scene {
     float4* tris = nullptr;    // BVH_GPU gathered tris / CWBVH tris
     char* nodesH = nullptr;    // CWBVH: 128-byte re-laid-out nodes (kernels_cwbvh_h.hip)
     float4* nodes128 = nullptr; // CWBVH: the same nodes padded to 128 bytes (variant 47)
+    float4* tris64 = nullptr;   // CWBVH: triangle records padded to 64 bytes
     float4* nodesP = nullptr;  // CWBVH: nodes renumbered in surface-area priority order (kernels_cwbvh_c.hip)
     uint32_t nNodes = 0;
     uint64_t nNodeBlocks = 0, nTriBlocks = 0;
@@ -341,7 +342,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         else if (s->variant >= 20 && s->variant < 30) launch_cwbvh_h(any, s->variant, s->nodesH, s->tris, q, c->status, blocks, c->stream);
         else
 #endif
-        launch_cwbvh(any, s->variant, cwbvh_variant_padded(s->variant) ? s->nodes128 : s->nodes, s->tris, q, c->status, blocks, c->stream);
+        launch_cwbvh(any, s->variant, cwbvh_variant_padded(s->variant) ? s->nodes128 : s->nodes, cwbvh_variant_tri64(s->variant) ? s->tris64 : s->tris, q, c->status, blocks, c->stream);
         break;
     default:
         return fail(TBVH_E_INVALID, "scene layout %d has no query kernel", s->layout);
@@ -816,7 +817,8 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
     c->timed = true;
     // derived node layouts of the experiment kernels would be stale now
     if (s->nodesH) { hipStreamSynchronize(c->stream); hipFree(s->nodesH); s->nodesH = nullptr; }
-    if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copy current
+    if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copies current
+    if (s->tris64) launch_cwbvh_pad_tris(s->tris, s->tris64, s->nTriBlocks / 3, c->stream);
     if (s->nodesP) { hipStreamSynchronize(c->stream); hipFree(s->nodesP); s->nodesP = nullptr; }
     if (s->variant >= 20 && s->variant < 40) s->variant = 0;
     return 0;
@@ -901,6 +903,7 @@ void tbvh_free_scene(tbvh_scene* s) {
     if (s->tris) hipFree(s->tris);
     if (s->nodesH) hipFree(s->nodesH);
     if (s->nodes128) hipFree(s->nodes128);
+    if (s->tris64) hipFree(s->tris64);
     if (s->nodesP) hipFree(s->nodesP);
     if (s->tlasIdx) hipFree(s->tlasIdx);
     if (s->instances) hipFree(s->instances);
@@ -933,6 +936,14 @@ int tbvh_set_variant(tbvh_scene* s, int v) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(c->stream));
         s->bytes += (uint64_t)s->nNodes * 128;
+    }
+    if (cw && cwbvh_variant_tri64(v) && !s->tris64) {
+        const uint64_t nT = s->nTriBlocks / 3;
+        HIP_TRY(hipMalloc((void**)&s->tris64, (nT ? nT : 1) * 64));
+        launch_cwbvh_pad_tris(s->tris, s->tris64, nT, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        s->bytes += nT * 64;
     }
 #if TBVH_EXPERIMENTS
     if (cw && v >= 20 && v < 30 && !s->nodesH) {
@@ -1136,6 +1147,7 @@ struct tbvh_wavefront {
     uint8_t* occ = nullptr;
     float* accum = nullptr;
     const float4** blasVerts = nullptr;        // device array: vertex array of every BLAS (TLAS scenes)
+    uint32_t* blueNoise = nullptr;             // device copy of the 128 x 128 x 8 table (optional)
     uint64_t nBlasVerts = 0;
     unsigned long long* counters = nullptr;   // [0],[1] path queues, [2] shadow queue, [8..] per-depth history
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1176,6 +1188,7 @@ void tbvh_wavefront_destroy(tbvh_wavefront* w) {
     if (w->accum) hipFree(w->accum);
     if (w->counters) hipFree(w->counters);
     if (w->blasVerts) hipFree((void*)w->blasVerts);
+    if (w->blueNoise) hipFree(w->blueNoise);
     if (w->e0) hipEventDestroy(w->e0);
     if (w->e1) hipEventDestroy(w->e1);
     delete w;
@@ -1228,6 +1241,7 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
         a.shadow = w->shadow; a.shadowAux = w->shadowAux; a.nShadow = QC(2);
         a.verts = (const float4*)dVerts; a.accum = w->accum;
         a.blasVerts = scene->isTlas ? w->blasVerts : nullptr; a.instances = scene->isTlas ? scene->instances : nullptr;
+        a.blueNoise = w->blueNoise; a.sampleIdx = p->sample_index; a.width = w->width; a.height = w->height;
         memcpy(a.lightPos, p->light_pos, 12); memcpy(a.lightColor, p->light_color, 12); memcpy(a.skyLo, p->sky_lo, 12); memcpy(a.skyHi, p->sky_hi, 12);
         a.lightSize[0] = p->light_size[0]; a.lightSize[1] = p->light_size[1]; a.flags = p->flags;
         a.eps = p->eps; a.depth = d; a.maxDepth = maxDepth; a.seed = p->seed;
@@ -1250,6 +1264,18 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
         HIP_TRY(hipEventElapsedTime(&stats->frame_ms, w->e0, w->e1));
         if (int r = checkStatus(c)) return r;
     }
+    return 0;
+}
+
+int tbvh_wavefront_set_blue_noise(tbvh_wavefront* w, const uint32_t* table, uint64_t nWords) {
+    if (!w) return fail(TBVH_E_INVALID, "tbvh_wavefront_set_blue_noise: null wavefront");
+    if (table && nWords != 128ull * 128 * 8) return fail(TBVH_E_INVALID, "tbvh_wavefront_set_blue_noise: the table is 128 x 128 x 8 = 131072 words (got %llu)", (unsigned long long)nWords);
+    if (int r = setDevice(w->ctx)) return r;
+    HIP_TRY(hipStreamSynchronize(w->ctx->stream));
+    if (w->blueNoise) { hipFree(w->blueNoise); w->blueNoise = nullptr; }
+    if (!table) return 0;
+    HIP_TRY(hipMalloc((void**)&w->blueNoise, nWords * 4));
+    HIP_TRY(hipMemcpy(w->blueNoise, table, nWords * 4, hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -1300,6 +1326,31 @@ int tbvh_copy_from_device(tbvh_context* c, void* dst, const void* d, uint64_t by
     if (int r = setDevice(c)) return r;
     HIP_TRY(hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// Device copy bandwidth as this GPU delivers it today: a plain 16-bytes-per-lane streaming copy kernel over `bytes` (read +
+// written bytes counted), best of `reps` launches.  The second denominator of the roofline lines in bench.py.
+int tbvh_measure_copy_bandwidth(tbvh_context* c, uint64_t bytes, uint32_t reps, double* gbps) {
+    if (!c || !gbps || bytes < (1u << 20)) return fail(TBVH_E_INVALID, "tbvh_measure_copy_bandwidth: null argument or under 1 MB");
+    if (int r = setDevice(c)) return r;
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { if (a) hipFree(a); return fail(TBVH_E_NOMEM, "tbvh_measure_copy_bandwidth: cannot allocate 2 x %llu bytes", (unsigned long long)bytes); }
+    hipMemsetAsync(a, 1, bytes, c->stream);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    double best = 0;
+    const uint32_t nrep = reps ? reps : 3;
+    for (uint32_t i = 0; i <= 3 * nrep; i++) {   // the first launch warms up; three grid shapes, the best one counts
+        const uint32_t perCU = i <= nrep ? 8u : i <= 2 * nrep ? 16u : 32u;
+        hipEventRecord(e0, c->stream);
+        launch_stream_copy((const float4*)a, (float4*)b, bytes / 16, (uint32_t)c->numCUs * perCU, c->stream);
+        hipEventRecord(e1, c->stream);
+        hipEventSynchronize(e1);
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        if (i && ms > 0) { const double g = 2.0 * (double)bytes / (ms * 1e-3) / 1e9; if (g > best) best = g; }
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(a); hipFree(b);
+    *gbps = best;
     return 0;
 }
 

@@ -21,6 +21,8 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
                   uint32_t blocks, hipStream_t s);
 bool cwbvh_variant_valid(int variant);
 bool cwbvh_variant_padded(int variant);   // runs on the 128-byte padded node copy
+bool cwbvh_variant_tri64(int variant);    // runs on the 64-byte padded triangle copy
+void launch_cwbvh_pad_tris(const float4* src, float4* dst, uint64_t nTris, hipStream_t s);
 bool bvh_variant_valid(int variant);       // BVH_GPU / BVH4_GPU kernels
 bool tlas_variant_valid(int variant);
 void launch_cwbvh_exp(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
@@ -55,6 +57,7 @@ hipError_t run_refit_bvh4(float4* blocks, uint64_t nBlocks, const float4* verts,
 size_t refit_scratch_bytes(int layout, uint32_t nNodes);
 hipError_t launch_refit(int layout, float4* nodes, uint32_t nNodes, float4* tris, uint64_t nTriRecords, const float4* verts, uint64_t nTris,
                         void* scratch, uint32_t* status, hipStream_t s);
+void launch_stream_copy(const float4* src, float4* dst, uint64_t n16, uint32_t blocks, hipStream_t s);
 void launch_pack_hits(const RayRec* rays, uint32_t* out, uint64_t n, hipStream_t s);
 void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris,
                         hipStream_t s);
@@ -84,7 +87,8 @@ struct ShadeArgs {
     const float4* const* blasVerts; const float4* instances;   // TLAS scenes: vertex array per BLAS, BLASInstance records (else nullptr)
     float lightPos[3], lightColor[3], skyLo[3], skyHi[3];
     float lightSize[2];   // extent of the rectangular light along x and z (0, 0 = point light)
-    float eps; uint32_t depth, maxDepth, seed, flags;   // flags bit 0: at most one diffuse bounce per path (wavefront.cl:233)
+    float eps; uint32_t depth, maxDepth, seed, flags;   // flags bit 0: at most one diffuse bounce per path (wavefront.cl:233); bit 1: wavefront.cl to the letter
+    const uint32_t* blueNoise; uint32_t sampleIdx, width, height;   // 128 x 128 x 8 table (or nullptr), the frame's sample index, image size
 };
 void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint64_t n, uint32_t seed, hipStream_t s);
 void launch_wf_shade(const ShadeArgs& a, uint64_t capacity, hipStream_t s);

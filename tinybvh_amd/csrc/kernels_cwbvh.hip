@@ -33,8 +33,11 @@ namespace {
 constexpr int WG = 64;
 
 // STATS (experiment builds): q.stats[0] wave iterations, [1] sum of active lanes, [2] sum of lanes visiting a node,
-// [3] triangle-phase iterations, [4] sum of lanes in them, [5] refill events, [6] rays handed out, [7] node-phase iterations
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, bool STATS = false, int NSTRIDE = 5>
+// [3] triangle-phase iterations, [4] sum of lanes in them, [5] node phases whose lanes all visit ONE node with ONE octant,
+// [6] sum of lanes in those, [7] node-phase iterations
+// TSTRIDE: float4s between consecutive triangle records (3 = the reference's packed array; 4 = padded to 64 bytes so that no
+// record straddles a 128-byte line)
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, bool STATS = false, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false>
 __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -63,7 +66,6 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
             if (!pool.dry()) {
                 uint64_t nri = 0;
                 const bool got = pool.acquire(!active, q.counter, nRaysTotal, nri);
-                if (STATS) { sRefill++; sRefilled += __popcll(__ballot(got)); }
                 if (got) {
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
@@ -85,17 +87,21 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
         bool done = false;
         // ---- triangle phase: runs when enough lanes have a triangle pending, or when no lane could use a node
         // phase instead (so a waiting lane always makes progress) --------------------------------------------
+        // COH_ONLY: deferral and the gate apply only while the wave runs in lockstep (coherent rays: VALU-bound, the gate
+        // saves triangle phases); once the governor has switched to per-lane replacement (incoherent rays: bound by the
+        // cache-miss path, where nodes visited ahead of their turn are extra traffic) the strict schedule applies
+        const bool spec = SPEC && (!COH_ONLY || gov.lockstep);
         bool triPhase = true;
-        if (TRI_MIN > 1) {
+        if (TRI_MIN > 1 && (!COH_ONLY || gov.lockstep)) {
             const uint32_t nPend = (uint32_t)__popcll(__ballot(tg.y != 0));
-            const bool canNode = SPEC ? (tg2.y == 0 && (cw_has_child(ng) || !st.empty())) : tg.y == 0;
+            const bool canNode = spec ? (tg2.y == 0 && (cw_has_child(ng) || !st.empty())) : tg.y == 0;
             triPhase = nPend >= (uint32_t)TRI_MIN || __ballot(canNode) == 0;
         }
         if (triPhase && tg.y != 0) {
             if (STATS) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sTriIter++; sTri += __popcll(m); } }
             const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
             tg.y &= ~(1u << ti);
-            const uint32_t ta = tg.x + ti * 3u;
+            const uint32_t ta = TSTRIDE == 3 ? tg.x + ti * 3u : (__umulhi(tg.x, 0xAAAAAAABu) >> 1) * 4u + ti * 4u;   // tg.x counts float4s of the packed array
             const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
             TriHit h;
             if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w))) {
@@ -106,20 +112,24 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
             if (SPEC && tg.y == 0) { tg = tg2; tg2 = make_uint2(0u, 0u); }
         }
         // ---- node phase ---------------------------------------------------------------------------------------
-        if (!done && (SPEC ? tg2.y == 0 : tg.y == 0)) {
+        if (!done && (spec ? tg2.y == 0 : tg.y == 0)) {
             bool have = cw_has_child(ng);
             if (!have) {
                 if (!st.empty()) { ng = st.pop(); have = true; }   // only node groups with children pending are ever pushed
-                else if (!SPEC || tg.y == 0) done = true;
+                else if (tg.y == 0) done = true;
             }
             if (have) {
-                if (STATS) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sNodeIter++; sNode += __popcll(m); } }
                 const uint32_t ci = cw_next_child(ng, oct);
+                if (STATS) {
+                    const unsigned long long m = __ballot(true);
+                    const bool uni = __ballot(ci != (uint32_t)__builtin_amdgcn_readfirstlane(ci) || oct != (uint32_t)__builtin_amdgcn_readfirstlane(oct)) == 0;
+                    if (lane_rank(m) == 0) { sNodeIter++; sNode += __popcll(m); if (uni) { sRefill++; sRefilled += __popcll(m); } }   // [5], [6]: uniform node phases, lanes in them
+                }
                 if (cw_has_child(ng)) st.push(ng);
                 const CwNodeHits r = cw_test_node(cw_load_node<NSTRIDE>(nodes, ci), O, rD, hit.x, octinv4);
                 ng = make_uint2(r.childBase, (r.hitmask & 0xFF000000u) | r.imask);
                 const uint2 nt = make_uint2(r.triBase, r.hitmask & 0x00FFFFFFu);
-                if (!SPEC || tg.y == 0) tg = nt;
+                if (tg.y == 0) tg = nt;
                 else tg2 = nt;
             }
         }
@@ -134,6 +144,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
         // the per-phase counters were kept by the first lane of each phase: reduce over the wave
         for (int o = 32; o > 0; o >>= 1) {
             sTriIter += __shfl_xor(sTriIter, o); sTri += __shfl_xor(sTri, o); sNodeIter += __shfl_xor(sNodeIter, o); sNode += __shfl_xor(sNode, o);
+            sRefill += __shfl_xor(sRefill, o); sRefilled += __shfl_xor(sRefilled, o);
         }
         if (threadIdx.x == 0) {
             atomicAdd(q.stats + 0, sIter); atomicAdd(q.stats + 1, sActive); atomicAdd(q.stats + 2, sNode); atomicAdd(q.stats + 3, sTriIter);
@@ -142,11 +153,11 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     }
 }
 
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool STATS = false, int NSTRIDE = 5>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool STATS = false, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false>
 void launch_k(const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
     // without opacity micromaps on the scene the check is compiled out (+1-2 %)
-    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
-    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE, TSTRIDE, COH_ONLY>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE, TSTRIDE, COH_ONLY>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
 }
 
 __global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__ dst, uint32_t nNodes) {
@@ -181,6 +192,14 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     case 61: launch_k<false, 8, 16, 16, true, true>(nodes, tris, q, status, blocks, s); return;    // statistics, deferred + gate 16
     case 62: TBVH_K(8, 16, 1, false, false, 8); return;    // strict schedule on nodes padded to 128 bytes
     case 63: TBVH_K(8, 16, 16, true, false, 8); return;    // deferred + gate 16 on padded nodes
+    case 64: TBVH_K(8, 16, 1, false, false, 5, 4); return; // strict schedule, triangle records padded to 64 bytes
+    case 65: TBVH_K(8, 16, 1, true, false, 5, 4); return;  // deferred, padded triangles
+    case 66: TBVH_K(8, 16, 1, true, false, 8, 4); return;  // deferred, padded triangles and nodes
+    case 67: TBVH_K(8, 16, 8, true, false, 5, 4); return;  // deferred + gate 8, padded triangles
+    case 68: TBVH_K(8, 16, 8, true, false, 5, 3, true); return;   // deferred + gate 8 while in lockstep, strict after
+    case 69: TBVH_K(8, 16, 16, true, false, 5, 3, true); return;
+    case 70: TBVH_K(8, 16, 12, true, false, 5, 3, true); return;
+    case 71: TBVH_K(8, 16, 1, true, false, 5, 3, true); return;   // deferred (no gate) while in lockstep
     default: launch_cwbvh_exp(anyhit, variant, nodes, tris, q, status, blocks, s); return;
     }
 #endif
@@ -188,16 +207,30 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
 #undef TBVH_K
 }
 
+namespace {
+__global__ void k_pad_tris(const float4* __restrict__ src, float4* __restrict__ dst, uint64_t nTris) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per float4 of the padded array
+    if (i >= nTris * 4u) return;
+    const uint64_t t = i >> 2; const uint32_t k = (uint32_t)i & 3u;
+    dst[i] = k < 3u ? src[t * 3u + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+}  // namespace
+// 48-byte triangle records straddle a 128-byte line 3 times out of 8; at 64 bytes none does (+33 % triangle memory)
+void launch_cwbvh_pad_tris(const float4* src, float4* dst, uint64_t nTris, hipStream_t s) {
+    hipLaunchKernelGGL(k_pad_tris, dim3((uint32_t)((nTris * 4u + 255u) / 256u)), dim3(256), 0, s, src, dst, nTris);
+}
+
 // 80-byte nodes straddle 128-byte lines (1.6 lines per node on average); the padded copy costs 60 % more node memory
 void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream_t s) {
     hipLaunchKernelGGL(k_pad_nodes, dim3((nNodes * 8u + 255u) / 256u), dim3(256), 0, s, src, dst, nNodes);
 }
 
-bool cwbvh_variant_padded(int v) { return TBVH_EXPERIMENTS && (v == 47 || v == 62 || v == 63); }
+bool cwbvh_variant_padded(int v) { return TBVH_EXPERIMENTS && (v == 47 || v == 62 || v == 63 || v == 66); }
+bool cwbvh_variant_tri64(int v) { return TBVH_EXPERIMENTS && v >= 64 && v <= 67; }
 
 bool cwbvh_variant_valid(int v) {
 #if TBVH_EXPERIMENTS
-    return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43) || (v >= 50 && v <= 63);
+    return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43) || (v >= 50 && v <= 71);
 #else
     return v == 0;
 #endif

@@ -124,6 +124,25 @@ __global__ void k_pack_hits(const RayRec* __restrict__ rays, uint32_t* __restric
     o[0] = w[11]; o[1] = w[12]; o[2] = w[13]; o[3] = w[14]; o[4] = w[15];
 }
 }  // namespace
+// streaming copy (16 bytes per lane, grid-stride): the denominator of "fraction of the measured copy bandwidth"
+namespace {
+__global__ __launch_bounds__(256) void k_stream_copy(const float4* __restrict__ src4, float4* __restrict__ dst4, uint64_t n16) {
+    // four independent 16-byte loads in flight per lane before the first store
+    const tbvh_f4* src = (const tbvh_f4*)src4;
+    tbvh_f4* dst = (tbvh_f4*)dst4;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const tbvh_f4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride), c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride); __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+}  // namespace
+void launch_stream_copy(const float4* src, float4* dst, uint64_t n16, uint32_t blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, s, src, dst, n16);
+}
+
 void launch_pack_hits(const RayRec* rays, uint32_t* out, uint64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_hits, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, rays, out, n);
 }

@@ -111,12 +111,14 @@ __global__ __launch_bounds__(kShadeBlock) void k_wf_shade(ShadeArgs a) {
         const float ipdf = brdfPdf > 0 ? 1.0f / brdfPdf : 0.f;
         const float3 O = xyz(r.O), D = xyz(r.D);
         const bool areaLight = a.lightSize[0] > 0 && a.lightSize[1] > 0;
+        const bool letter = (a.flags & 2u) != 0;
         const float lightArea = a.lightSize[0] * a.lightSize[1];
         if (!(r.hit.x < kFar)) {
             // end path on sky (wavefront.cl:151-156): lerp(horizon, zenith) by D.y
             const float k = 0.5f * (D.y + 1.0f);
             const float3 sky = make_float3(a.skyLo[0] + k * (a.skyHi[0] - a.skyLo[0]), a.skyLo[1] + k * (a.skyHi[1] - a.skyLo[1]), a.skyLo[2] + k * (a.skyHi[2] - a.skyLo[2]));
-            atomicAdd(&a.accum[pixel * 4 + 0], T.x * ipdf * sky.x); atomicAdd(&a.accum[pixel * 4 + 1], T.y * ipdf * sky.y); atomicAdd(&a.accum[pixel * 4 + 2], T.z * ipdf * sky.z);
+            const float ws = letter ? 1.0f : ipdf;   // wavefront.cl:151-156 adds the sky before :180 divides the postponed pdf out
+            atomicAdd(&a.accum[pixel * 4 + 0], T.x * ws * sky.x); atomicAdd(&a.accum[pixel * 4 + 1], T.y * ws * sky.y); atomicAdd(&a.accum[pixel * 4 + 2], T.z * ws * sky.z);
         } else {
             const uint32_t prim = as_u32(r.hit.w);
             // geometry at the hit: a TLAS hit names the instance in byte 44 of the record (wavefront2.cl:180-186 unpacks
@@ -136,6 +138,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_wf_shade(ShadeArgs a) {
                     const float solid = __builtin_fminf(6.2831853f, lightArea / (r.hit.x * r.hit.x) * fabsf(D.y));
                     const float lightPdf = solid > 0 ? 1.0f / solid : kFar;
                     w = 1.0f / (lightPdf + brdfPdf);
+                    if (letter) w = 0.f;   // wavefront.cl:174 evaluates LightPDF( D4.w ) with D4.w = 1e30 (nothing writes a distance there): 1 / (inf + pdf)
                 }
                 atomicAdd(&a.accum[pixel * 4 + 0], T.x * w * a.lightColor[0]); atomicAdd(&a.accum[pixel * 4 + 1], T.y * w * a.lightColor[1]);
                 atomicAdd(&a.accum[pixel * 4 + 2], T.z * w * a.lightColor[2]);
@@ -156,7 +159,14 @@ __global__ __launch_bounds__(kShadeBlock) void k_wf_shade(ShadeArgs a) {
                                          : make_float3(0.7f, 0.7f, 0.7f);
                 uint32_t s = wang(a.seed * 7919u + pixel * 2699u + a.depth * 104729u + 17u);
                 if (!s) s = 1;
-                const float r0 = rnd(s), r1 = rnd(s), r2 = rnd(s), r3 = rnd(s);
+                float r0 = rnd(s), r1 = rnd(s), r2 = rnd(s), r3 = rnd(s);   // r0, r1: bounce; r2, r3: light sample
+                if (a.blueNoise && a.depth == 0 && a.sampleIdx < 4u) {
+                    // blue-noise first samples (wavefront.cl:183-189; Noise() of :24-31, with its x = pixel % height, y = pixel / height)
+                    const uint32_t nx = (pixel % a.height) & 127u, ny = (pixel / a.height) & 127u;
+                    const uint32_t w0 = a.blueNoise[((a.sampleIdx * 2u) << 14) + (ny << 7) + nx], w1 = a.blueNoise[((a.sampleIdx * 2u + 1u) << 14) + (ny << 7) + nx];
+                    r2 = (float)(w0 >> 16) * 0.00392f; r3 = (float)((w0 >> 8) & 255u) * 0.00392f;   // noise0 -> the light sample
+                    r0 = (float)(w1 >> 16) * 0.00392f; r1 = (float)((w1 >> 8) & 255u) * 0.00392f;   // noise1 -> the bounce
+                }
                 if (materialType != kMaterialSpecular) {
                     // direct illumination: next event estimation (wavefront.cl:205-222)
                     const float3 Pl = areaLight ? make_float3(a.lightPos[0] + (r2 - 0.5f) * a.lightSize[0], a.lightPos[1], a.lightPos[2] + (r3 - 0.5f) * a.lightSize[1])
@@ -187,12 +197,17 @@ __global__ __launch_bounds__(kShadeBlock) void k_wf_shade(ShadeArgs a) {
                         wantBounce = true;
                     } else if (!((a.flags & 1u) && (flags & kPathViaDiffuse))) {   // wavefront.cl:233-242
                         // cosine-weighted bounce about N (Malley): pdf = cos / pi, postponed to the next vertex
+                        if (letter) {   // tools.cl:34-39: a half sphere about the WORLD z axis added to N
+                            const float rl = sqrtf(__builtin_fmaxf(1.0f - r1 * r1, 0.f)), pl = 12.566371f * r0;
+                            R = norm3(make_float3(N.x + cosf(pl) * rl, N.y + sinf(pl) * rl, N.z + r1));
+                        } else {
                         const float rr = sqrtf(r1), cz = sqrtf(1.0f - r1), phi = 6.2831853f * r0;
                         const float3 t1 = fabsf(N.x) > 0.9f ? make_float3(0, 1, 0) : make_float3(1, 0, 0);
                         const float3 bx = norm3(make_float3(t1.y * N.z - t1.z * N.y, t1.z * N.x - t1.x * N.z, t1.x * N.y - t1.y * N.x));
                         const float3 by = make_float3(N.y * bx.z - N.z * bx.y, N.z * bx.x - N.x * bx.z, N.x * bx.y - N.y * bx.x);
                         const float cx = cosf(phi) * rr, cy = sinf(phi) * rr;
                         R = norm3(make_float3(cz * N.x + cx * bx.x + cy * by.x, cz * N.y + cx * bx.y + cy * by.y, cz * N.z + cx * bx.z + cy * by.z));
+                        }
                         const float ndr = __builtin_fmaxf(N.x * R.x + N.y * R.y + N.z * R.z, 1e-6f);
                         newPdf = ndr * 0.31830988f;
                         const float k3 = ndr * 0.31830988f;   // T *= dot(N, R) * BRDF, BRDF = color / pi

@@ -112,7 +112,7 @@ def main():
             print(f"stats {v} [{kind}] {ms:.2f} ms: wave-iterations {it}  per ray {it * 64 / n:.1f}  active/64 {act / it / 64:.3f}  "
                   f"node phases/iter {niter / it:.3f} at {node / max(niter, 1) / 64:.3f} lanes  ({node / n:.2f} node visits/ray)  "
                   f"tri phases/iter {titer / it:.3f} at {tri / max(titer, 1) / 64:.3f} lanes ({tri / n:.2f} tri tests/ray)  "
-                  f"refills {rf} ({rfd / max(rf, 1):.1f} rays each)", flush=True)
+                  f"uniform node phases (one node, one octant) {rf / max(niter, 1):.3f} of all, holding {rfd / max(node, 1):.3f} of the node visits", flush=True)
             res[f"stats{v}_{kind}"] = dict(ms=ms, iters=it, active=act, node_lanes=node, node_iters=niter, tri_iters=titer, tri_lanes=tri, refills=rf)
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
