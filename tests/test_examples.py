@@ -30,3 +30,15 @@ def test_speedtest_gpu_section_with_real_tinybvh():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all layouts agree with BVH::Intersect" in out.stdout
+
+
+@pytest.mark.gpu
+def test_wavefront_demos_with_real_tinybvh():
+    """tiny_bvh_gpu.cpp:128-158 and tiny_bvh_gpu2.cpp:187-198 re-hosted on tbvh_wavefront_* with real tinybvh objects (BVH8_CWBVH::Build /
+    BuildHQ, BVH_GPU TLAS over BLASInstance records rebuilt per frame); the program checks convergence and agreement with the CPU library."""
+    exe = os.path.join(BUILD, "wavefront_demos")
+    if not os.path.exists(exe):
+        pytest.skip("needs the reference header at build time")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "wavefront demos ok" in out.stdout
