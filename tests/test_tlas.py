@@ -120,7 +120,12 @@ def test_every_tlas_kernel_gives_the_same_records(ctx, oracle, layout, variant, 
         got = tlas.Intersect(rays.copy())
         c = check(got, want)
         assert c["hits"] > 1000, (name, c)
-        assert np.array_equal(got.view(np.uint8), base.view(np.uint8)), name                 # and bit for bit what the default returns
+        # and what the default kernel returns: bit for bit, except among hits at exactly equal t when the two kernels visit instances in
+        # another order (the default for BVH4_GPU BLASes walks a 4-wide TLAS nearest child first, kernels_tlas4.hip)
+        differ = np.flatnonzero((got["prim"] != base["prim"]) | (got["inst"] != base["inst"]))
+        assert differ.size <= max(2, c["hits"] // 2000) and np.array_equal(got["t"][differ], base["t"][differ]), (name, differ.size)
+        same = np.ones(got.shape[0], bool); same[differ] = False
+        assert np.array_equal(got[same].view(np.uint8), base[same].view(np.uint8)), name
         occ = tlas.IsOccluded(rays.copy())
         assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2, name
 

@@ -97,7 +97,13 @@ struct tbvh_scene {
     BlasDesc* blasDesc = nullptr;
     int blasLayout = 0;
     uint64_t capNodes = 0, capIdx = 0, capInst = 0;
-    uint64_t nInst = 0, nBlas = 0, nTlasNodes = 0;
+    uint64_t nInst = 0, nBlas = 0, nTlasNodes = 0, nTlasIdx = 0;
+    // the same TLAS collapsed 4-wide in the BVH4_GPU node format (kernels_tlas4.hip), kept current by every upload / update / device rebuild;
+    // only for TLASes whose BLASes are all BVH4_GPU
+    float4* tlas4 = nullptr;
+    uint64_t tlas4Cap = 0;            // blocks
+    void* tlas4Scratch = nullptr;
+    size_t tlas4ScratchBytes = 0;
     // device-side TLAS rebuild (kernels_tlasbuild.hip)
     float* blasBounds = nullptr;      // 6 floats per BLAS
     float* xformStage = nullptr;      // staged transforms (16 floats per instance) when the caller passes host memory
@@ -319,6 +325,15 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     const uint32_t blocks = (uint32_t)(want < lo ? lo : (want > cap ? cap : want));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     if (s->isTlas) {
+        const int tv = s->variant ? s->variant : c->tlasVariant;
+        if (s->tlas4 && s->blasLayout == TBVH_LAYOUT_BVH4_GPU && (tv == 0 || (tv >= 21 && tv <= 31))) {   // BVH4_GPU BLASes: the unified 4-wide kernel
+            q.spillStride = c->spillEntries;   // 32-bit stack entries
+            launch_tlas4(any, tv, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            c->timed = true;
+            return 0;
+        }
         q.spillStride = c->spillEntries / 2;
         launch_tlas(any, s->blasLayout, s->variant ? s->variant : c->tlasVariant, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
         HIP_TRY(hipGetLastError());
@@ -536,6 +551,31 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
 }
 
 namespace {
+// (re)build the 4-wide TLAS from the BVH_GPU nodes on the device; asynchronous on the context's stream
+int buildTlas4(tbvh_scene* s) {
+    if (s->blasLayout != TBVH_LAYOUT_BVH4_GPU) return 0;
+    tbvh_context* c = s->ctx;
+    const uint64_t cap = tlas4_cap_blocks(s->nTlasNodes, s->nInst);
+    if (cap > 0x7fffffffull) return 0;   // beyond 31-bit block offsets: the BVH_GPU TLAS kernels serve this TLAS
+    if (cap > s->tlas4Cap) {
+        if (s->tlas4) hipFree(s->tlas4);
+        s->tlas4 = nullptr; s->tlas4Cap = 0;
+        HIP_TRY(hipMalloc((void**)&s->tlas4, cap * 16));
+        s->tlas4Cap = cap;
+    }
+    const size_t sb = tlas4_scratch_bytes(s->nTlasNodes, s->nInst);
+    if (sb > s->tlas4ScratchBytes) {
+        if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
+        s->tlas4Scratch = nullptr; s->tlas4ScratchBytes = 0;
+        HIP_TRY(hipMalloc(&s->tlas4Scratch, sb));
+        s->tlas4ScratchBytes = sb;
+    }
+    launch_tlas4_build(s->nodes, (uint32_t)s->nTlasNodes, s->tlasIdx, (uint32_t)s->nTlasIdx, s->instances, (uint32_t)s->nInst, s->tlas4, (uint32_t)s->tlas4Cap, s->tlas4Scratch, c->stream);
+    HIP_TRY(hipGetLastError());
+    s->bytes += cap * 16;
+    return 0;
+}
+
 int tlasCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* idx, uint64_t nIdx, const void* inst, uint64_t nInst) {
     tbvh_context* c = s->ctx;
     // same hardening as the BLAS uploads: the TLAS kernels index instances[idx[]] and blas[blasIdx] unguarded
@@ -551,8 +591,8 @@ int tlasCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t
     HIP_TRY(hipMemcpyAsync(s->instances, inst, nInst * 192, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));  // the caller may reuse its host arrays right away
     s->bytes = nNodes * 64 + nIdx * 4 + nInst * 192;
-    s->nInst = nInst; s->nTlasNodes = nNodes;
-    return 0;
+    s->nInst = nInst; s->nTlasNodes = nNodes; s->nTlasIdx = nIdx;
+    return buildTlas4(s);
 }
 }  // namespace
 
@@ -854,6 +894,8 @@ int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice
         else {
             if (s->xformStageCap < n) {   // tbvh_update_tlas may have grown the instance array since the last rebuild
                 if (s->xformStage) hipFree(s->xformStage);
+    if (s->tlas4) hipFree(s->tlas4);
+    if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
                 s->xformStage = nullptr; s->xformStageCap = 0;
                 HIP_TRY(hipMalloc((void**)&s->xformStage, n * 64));
                 s->xformStageCap = n;
@@ -864,10 +906,11 @@ int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice
     }
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(launch_tlas_rebuild(s->nodes, s->tlasIdx, s->instances, xf, s->blasBounds, (uint32_t)n, (uint32_t)s->nBlas, s->buildScratch, s->sortTempBytes, c->stream));
+    s->bytes = nNodes * 64 + n * 4 + n * 192;
+    s->nTlasNodes = nNodes; s->nTlasIdx = n;
+    if (int r = buildTlas4(s)) return r;
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
-    s->bytes = nNodes * 64 + n * 4 + n * 192;
-    s->nTlasNodes = nNodes;
     return 0;
 }
 

@@ -36,6 +36,13 @@ void launch_cwbvh_c(bool anyhit, int variant, const float4* nodes, const float4*
 struct BlasDesc { const float4* nodes; const float4* tris; const uint32_t* opmap; uint32_t opmapN; uint32_t layout; };  // one per BLAS of a TLAS (layout: TBVH_LAYOUT_*)
 void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances,
                  const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
+// 4-wide TLAS in the BVH4_GPU node format + the unified two-level kernel for BVH4_GPU BLASes (kernels_tlas4.hip)
+size_t tlas4_scratch_bytes(uint64_t nAL, uint64_t nInst);
+uint64_t tlas4_cap_blocks(uint64_t nAL, uint64_t nInst);
+void launch_tlas4_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* blocks, uint32_t capBlocks,
+                        void* scratch, hipStream_t s);
+void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* instances, const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks,
+                  hipStream_t s);
 // device TLAS rebuild (kernels_tlasbuild.hip)
 size_t tlas_build_scratch_bytes(uint32_t n, size_t* sortTempBytes);
 hipError_t launch_tlas_rebuild(float4* tlasNodes, uint32_t* tlasIdx, float4* instances, const float* transformsDev, const float* blasBoundsDev,

@@ -18,6 +18,7 @@
 // Input contract = the reference's: leaves hold at most 3 triangles (BVH::SplitLeafs(3), as
 // BVH8_CWBVH::ConvertFrom does at tiny_bvh.h:5893-5899); a larger leaf is reported, not guessed at.
 #include "cwbvh_encode.h"
+#include "bvh4_encode.h"
 #include "device_common.h"
 #include "kernels.h"
 
@@ -180,33 +181,13 @@ __global__ void k_convert4_level(const float4* __restrict__ nodes2, uint32_t nNo
     const uint32_t outFirst = nInner ? atomicAdd(counters + 2, nInner) : 0u;
     if ((uint64_t)base + 4u + 3u * nT > capBlocks) { atomicOr(status, 4u); return; }
     if (item.y != 0xffffffffu) ((uint32_t*)blocks)[item.y] = base;
-    // quantisation frame (reference: scale 254.999 / extent, decode bmin + (extent / 255) * q; the decode step is
-    // nudged up until 255 steps really reach the far face, and every plane is verified against the decode)
-    const float bmn[3] = {self.mn.x, self.mn.y, self.mn.z}, bmx[3] = {self.mx.x, self.mx.y, self.mx.z};
-    float ext[3], scale[3], e255[3], guard[3];
-    for (int a = 0; a < 3; a++) {
-        ext[a] = bmx[a] - bmn[a];
-        scale[a] = ext[a] > 1e-10f ? 254.999f / ext[a] : 0.f;
-        e255[a] = ext[a] * (1.0f / 255.0f);
-        guard[a] = 4e-7f * fmaxf(fmaxf(fabsf(bmn[a]), fabsf(bmx[a])), ext[a]);
-        if (ext[a] > 0) {   // the decode step must carry 255 steps past the far face: jump there, then settle ulp by ulp
-            const float need = ((bmx[a] + guard[a]) - bmn[a]) * (1.0f / 255.0f);
-            if (need > e255[a]) e255[a] = need;
-            while (bmn[a] + e255[a] * 255.0f < bmx[a] + guard[a]) e255[a] = nextafterf(e255[a], 1e30f);
-        }
-    }
+    // quantisation frame and conservative child planes: bvh4_encode.h (shared with the 4-wide TLAS builder)
+    const Bvh4Frame frame = bvh4_frame(self.mn, self.mx);
     uint32_t info[4] = {0, 0, 0, 0}, q[6] = {0, 0, 0, 0, 0, 0};   // q: xmin, xmax, ymin, ymax, zmin, zmax; byte i = child i
     uint32_t rel = 4, inner = 0;
     for (uint32_t i = 0; i < nk; i++) {
         const N2& c = kid[i];
-        const float cmn[3] = {c.mn.x, c.mn.y, c.mn.z}, cmx[3] = {c.mx.x, c.mx.y, c.mx.z};
-        for (int a = 0; a < 3; a++) {
-            int lo = (int)floorf((cmn[a] - bmn[a]) * scale[a]), hi = (int)ceilf((cmx[a] - bmn[a]) * scale[a]);
-            lo = lo < 0 ? 0 : (lo > 255 ? 255 : lo); hi = hi < 0 ? 0 : (hi > 255 ? 255 : hi);
-            while (lo > 0 && bmn[a] + e255[a] * (float)lo > cmn[a] - guard[a]) lo--;
-            while (hi < 255 && bmn[a] + e255[a] * (float)hi < cmx[a] + guard[a]) hi++;
-            q[2 * a] |= (uint32_t)lo << (8 * i); q[2 * a + 1] |= (uint32_t)hi << (8 * i);
-        }
+        bvh4_quantize_child(frame, c.mn, c.mx, i, q);
         if (c.triCount) {
             info[i] = 0x80000000u | (c.triCount << 16) | rel;
             for (uint32_t j = 0; j < c.triCount; j++) {
@@ -225,11 +206,7 @@ __global__ void k_convert4_level(const float4* __restrict__ nodes2, uint32_t nNo
             inner++;
         }
     }
-    float4* nb = blocks + (size_t)base;
-    nb[0] = make_float4(bmn[0], bmn[1], bmn[2], as_f32(q[0]));
-    nb[1] = make_float4(e255[0], e255[1], e255[2], as_f32(q[1]));
-    nb[2] = make_float4(as_f32(q[2]), as_f32(q[3]), as_f32(q[4]), as_f32(q[5]));
-    nb[3] = make_float4(as_f32(info[0]), as_f32(info[1]), as_f32(info[2]), as_f32(info[3]));   // interior entries are patched by the children
+    bvh4_write_node(blocks + (size_t)base, frame, q, info);   // interior entries are patched by the children
 }
 
 }  // namespace

@@ -18,6 +18,7 @@
 #include "lane_stack.h"
 #include "ray_pool.h"
 #include "kernels.h"
+#include "cwbvh_node.h"
 
 namespace tbvh {
 
@@ -26,45 +27,11 @@ namespace {
 constexpr int WAVES = 16;
 constexpr int WGC = WAVES * 64;
 
-__device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
-__device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-__device__ __forceinline__ uint32_t sext_s8x4(uint32_t i) { return ((i >> 7) & 0x01010101u) * 0xffu; }
-
-struct NodeOut { uint32_t childBase, triBase, hitmask, imask; };
-
+typedef CwNodeHits NodeOut;
+// the node test is the shared one (cwbvh_node.h); here the five float4s may come from the LDS cache
 __device__ __forceinline__ NodeOut test_children(float4 n0, float4 n1, float4 n2, float4 n3, float4 n4, float3 O, float3 rD,
                                                  float tmax, uint32_t octinv4) {
-    const uint32_t ew = as_u32(n0.w);
-    const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
-    const float ox = (n0.x - O.x) * rD.x, oy = (n0.y - O.y) * rD.y, oz = (n0.z - O.z) * rD.z;
-    uint32_t hitmask = 0;
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const uint32_t meta4 = half ? as_u32(n1.w) : as_u32(n1.z);
-        const uint32_t inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-        const uint32_t imask4 = sext_s8x4(inner4 << 3);
-        const uint32_t bitidx4 = (meta4 ^ (octinv4 & imask4)) & 0x1F1F1F1Fu;
-        const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;
-        const uint32_t qlx = half ? as_u32(n2.y) : as_u32(n2.x), qhx = half ? as_u32(n3.w) : as_u32(n3.z);
-        const uint32_t qly = half ? as_u32(n2.w) : as_u32(n2.z), qhy = half ? as_u32(n4.y) : as_u32(n4.x);
-        const uint32_t qlz = half ? as_u32(n3.y) : as_u32(n3.x), qhz = half ? as_u32(n4.w) : as_u32(n4.z);
-        const uint32_t lox = rD.x < 0 ? qhx : qlx, hix = rD.x < 0 ? qlx : qhx;
-        const uint32_t loy = rD.y < 0 ? qhy : qly, hiy = rD.y < 0 ? qly : qhy;
-        const uint32_t loz = rD.z < 0 ? qhz : qlz, hiz = rD.z < 0 ? qlz : qhz;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int sh = 8 * i;
-            const float tnx = __builtin_fmaf((float)((lox >> sh) & 255), ax, ox), tfx = __builtin_fmaf((float)((hix >> sh) & 255), ax, ox);
-            const float tny = __builtin_fmaf((float)((loy >> sh) & 255), ay, oy), tfy = __builtin_fmaf((float)((hiy >> sh) & 255), ay, oy);
-            const float tnz = __builtin_fmaf((float)((loz >> sh) & 255), az, oz), tfz = __builtin_fmaf((float)((hiz >> sh) & 255), az, oz);
-            const float cmin = __builtin_fmaxf(fmax3(tnx, tny, tnz), 0.0f);
-            const float cmax = __builtin_fminf(fmin3(tfx, tfy, tfz), tmax);
-            if (cmin <= cmax) hitmask |= ((bits4 >> sh) & 255u) << ((bitidx4 >> sh) & 255u);
-        }
-    }
-    NodeOut r;
-    r.childBase = as_u32(n1.x); r.triBase = as_u32(n1.y); r.hitmask = hitmask; r.imask = ew >> 24;
-    return r;
+    return cw_test_node(CwNode{n0, n1, n2, n3, n4}, O, rD, tmax, octinv4);
 }
 
 template <bool ANYHIT, int LDS_N, int KMAX, int REFILL_MIN>

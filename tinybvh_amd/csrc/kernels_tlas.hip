@@ -29,6 +29,7 @@
 #include "lane_stack.h"
 #include "ray_pool.h"
 #include "kernels.h"
+#include "cwbvh_node.h"
 
 namespace tbvh {
 
@@ -38,7 +39,6 @@ constexpr int WG = 64;
 
 __device__ __forceinline__ float fmin3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
 __device__ __forceinline__ float fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-__device__ __forceinline__ uint32_t sext_s8x4(uint32_t i) { return ((i >> 7) & 0x01010101u) * 0xffu; }
 __device__ __forceinline__ float safercp(float x) {
     if (x > 1e-12f || x < -1e-12f) return 1.0f / x;
     return x >= 0 ? kFar : -kFar;
@@ -87,39 +87,10 @@ __device__ __forceinline__ void blas_cwbvh(const GlobalF4 nodes, const GlobalF4 
             ng.y &= ~(1u << bit);
             if (ng.y > 0x00FFFFFFu) st.push(ng);
             const uint32_t slot = (bit - 24u) ^ oct;
-            const uint32_t ci = (cbase + __popc(imask & ~(0xFFFFFFFFu << slot))) * 5u;
-            const float4 n0 = nodes[ci], n1 = nodes[ci + 1], n2 = nodes[ci + 2], n3 = nodes[ci + 3], n4 = nodes[ci + 4];
-            const uint32_t ew = as_u32(n0.w);
-            const float ax = ldexpf(r.rD.x, (int)(int8_t)(ew)), ay = ldexpf(r.rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(r.rD.z, (int)(int8_t)(ew >> 16));
-            const float ox = (n0.x - r.O.x) * r.rD.x, oy = (n0.y - r.O.y) * r.rD.y, oz = (n0.z - r.O.z) * r.rD.z;
-            uint32_t hitmask = 0;
-#pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const uint32_t meta4 = half ? as_u32(n1.w) : as_u32(n1.z);
-                const uint32_t inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-                const uint32_t imask4 = sext_s8x4(inner4 << 3);
-                const uint32_t bitidx4 = (meta4 ^ (octinv4 & imask4)) & 0x1F1F1F1Fu;
-                const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;
-                const uint32_t qlx = half ? as_u32(n2.y) : as_u32(n2.x), qhx = half ? as_u32(n3.w) : as_u32(n3.z);
-                const uint32_t qly = half ? as_u32(n2.w) : as_u32(n2.z), qhy = half ? as_u32(n4.y) : as_u32(n4.x);
-                const uint32_t qlz = half ? as_u32(n3.y) : as_u32(n3.x), qhz = half ? as_u32(n4.w) : as_u32(n4.z);
-                const uint32_t lox = r.rD.x < 0 ? qhx : qlx, hix = r.rD.x < 0 ? qlx : qhx;
-                const uint32_t loy = r.rD.y < 0 ? qhy : qly, hiy = r.rD.y < 0 ? qly : qhy;
-                const uint32_t loz = r.rD.z < 0 ? qhz : qlz, hiz = r.rD.z < 0 ? qlz : qhz;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int sh = 8 * i;
-                    const float tnx = __builtin_fmaf((float)((lox >> sh) & 255), ax, ox), tfx = __builtin_fmaf((float)((hix >> sh) & 255), ax, ox);
-                    const float tny = __builtin_fmaf((float)((loy >> sh) & 255), ay, oy), tfy = __builtin_fmaf((float)((hiy >> sh) & 255), ay, oy);
-                    const float tnz = __builtin_fmaf((float)((loz >> sh) & 255), az, oz), tfz = __builtin_fmaf((float)((hiz >> sh) & 255), az, oz);
-                    const float cmin = __builtin_fmaxf(fmax3(tnx, tny, tnz), 0.0f);
-                    const float cmax = __builtin_fminf(fmin3(tfx, tfy, tfz), r.hit.x);
-                    if (cmin <= cmax) hitmask |= ((bits4 >> sh) & 255u) << ((bitidx4 >> sh) & 255u);
-                }
-            }
-            ng.x = as_u32(n1.x); tg.x = as_u32(n1.y);
-            ng.y = (hitmask & 0xFF000000u) | (ew >> 24);
-            tg.y = hitmask & 0x00FFFFFFu;
+            const CwNodeHits nh = cw_test_node(cw_load_node(nodes, cbase + __popc(imask & ~(0xFFFFFFFFu << slot))), r.O, r.rD, r.hit.x, octinv4);
+            ng.x = nh.childBase; tg.x = nh.triBase;
+            ng.y = (nh.hitmask & 0xFF000000u) | nh.imask;
+            tg.y = nh.hitmask & 0x00FFFFFFu;
         } else {
             tg = ng;
             ng = make_uint2(0u, 0u);
@@ -324,7 +295,7 @@ __device__ __forceinline__ bool tlas_body(const float4* __restrict__ tlasNodes, 
 // is what the nested loops of tlas_body cost (three levels of "everybody waits for the slowest").  Idle lanes take new
 // rays as in the other kernels.  Per ray the order of instances, nodes and triangles is the nested version's.
 // ---------------------------------------------------------------------------------------------------------------
-template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N, int REFILL_MIN, int PHASE_MIN, bool ADAPT>
+template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N, int REFILL_MIN, int PHASE_MIN, bool ADAPT, bool STATS = false>
 __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
                                                const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, const QueryArgs& q,
                                                StackT<LDS_N>& st, RayPool<64>& pool, const uint64_t nRaysTotal) {
@@ -347,6 +318,7 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
 
     LockstepGovernor gov;   // ADAPT only: lockstep (whole-wave generations) while the rays are coherent, per-lane replacement otherwise
     gov.init();
+    unsigned long long sIter = 0, sAct = 0, sA = 0, sLA = 0, sB = 0, sLB = 0, sC = 0, sLC = 0;   // STATS: phases run and the lanes in them
     for (;;) {
         const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
         if ((ADAPT ? gov.want_refill(nIdle, (uint32_t)REFILL_MIN) : nIdle >= (uint32_t)REFILL_MIN) || nIdle == (uint32_t)WG) {
@@ -373,6 +345,7 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
         const uint32_t nMax = nA > nB ? (nA > nC ? nA : nC) : (nB > nC ? nB : nC);
         const bool runA = PHASE_MIN <= 1 || nA >= (uint32_t)PHASE_MIN || nA == nMax, runB = PHASE_MIN <= 1 || nB >= (uint32_t)PHASE_MIN || nB == nMax,
                    runC = PHASE_MIN <= 1 || nC >= (uint32_t)PHASE_MIN || nC == nMax;
+        if (STATS) { sIter++; sAct += nA + nB + nC; if (runA && nA) { sA++; sLA += nA; } if (runB && nB) { sB++; sLB += nB; } if (runC && nC) { sC++; sLC += nC; } }
         if (!active) continue;
         bool done = false;
 
@@ -404,40 +377,10 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
                         ng.y &= ~(1u << bit);
                         if (ng.y > 0x00FFFFFFu) st.push(ng);
                         const uint32_t slot = (bit - 24u) ^ oct;
-                        const uint32_t octinv4 = oct * 0x01010101u;
-                        const uint32_t ci = (cbase + __popc(imask & ~(0xFFFFFFFFu << slot))) * 5u;
-                        const float4 n0 = bnodes[ci], n1 = bnodes[ci + 1], n2 = bnodes[ci + 2], n3 = bnodes[ci + 3], n4 = bnodes[ci + 4];
-                        const uint32_t ew = as_u32(n0.w);
-                        const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
-                        const float ox = (n0.x - O.x) * rD.x, oy = (n0.y - O.y) * rD.y, oz = (n0.z - O.z) * rD.z;
-                        uint32_t hitmask = 0;
-#pragma unroll
-                        for (int half = 0; half < 2; half++) {
-                            const uint32_t meta4 = half ? as_u32(n1.w) : as_u32(n1.z);
-                            const uint32_t inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-                            const uint32_t imask4 = sext_s8x4(inner4 << 3);
-                            const uint32_t bitidx4 = (meta4 ^ (octinv4 & imask4)) & 0x1F1F1F1Fu;
-                            const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;
-                            const uint32_t qlx = half ? as_u32(n2.y) : as_u32(n2.x), qhx = half ? as_u32(n3.w) : as_u32(n3.z);
-                            const uint32_t qly = half ? as_u32(n2.w) : as_u32(n2.z), qhy = half ? as_u32(n4.y) : as_u32(n4.x);
-                            const uint32_t qlz = half ? as_u32(n3.y) : as_u32(n3.x), qhz = half ? as_u32(n4.w) : as_u32(n4.z);
-                            const uint32_t lox = rD.x < 0 ? qhx : qlx, hix = rD.x < 0 ? qlx : qhx;
-                            const uint32_t loy = rD.y < 0 ? qhy : qly, hiy = rD.y < 0 ? qly : qhy;
-                            const uint32_t loz = rD.z < 0 ? qhz : qlz, hiz = rD.z < 0 ? qlz : qhz;
-#pragma unroll
-                            for (int i = 0; i < 4; i++) {
-                                const int sh = 8 * i;
-                                const float tnx = __builtin_fmaf((float)((lox >> sh) & 255), ax, ox), tfx = __builtin_fmaf((float)((hix >> sh) & 255), ax, ox);
-                                const float tny = __builtin_fmaf((float)((loy >> sh) & 255), ay, oy), tfy = __builtin_fmaf((float)((hiy >> sh) & 255), ay, oy);
-                                const float tnz = __builtin_fmaf((float)((loz >> sh) & 255), az, oz), tfz = __builtin_fmaf((float)((hiz >> sh) & 255), az, oz);
-                                const float cmin = __builtin_fmaxf(fmax3(tnx, tny, tnz), 0.0f);
-                                const float cmax = __builtin_fminf(fmin3(tfx, tfy, tfz), hit.x);
-                                if (cmin <= cmax) hitmask |= ((bits4 >> sh) & 255u) << ((bitidx4 >> sh) & 255u);
-                            }
-                        }
-                        ng.x = as_u32(n1.x); tg.x = as_u32(n1.y);
-                        ng.y = (hitmask & 0xFF000000u) | (ew >> 24);
-                        tg.y = hitmask & 0x00FFFFFFu;
+                        const CwNodeHits nh = cw_test_node(cw_load_node(bnodes, cbase + __popc(imask & ~(0xFFFFFFFFu << slot))), O, rD, hit.x, oct * 0x01010101u);
+                        ng.x = nh.childBase; tg.x = nh.triBase;
+                        ng.y = (nh.hitmask & 0xFF000000u) | nh.imask;
+                        tg.y = nh.hitmask & 0x00FFFFFFu;
                         if (tg.y == 0 && ng.y <= 0x00FFFFFFu) pop = true;
                     }
                 }
@@ -631,6 +574,10 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
             active = false;
         }
     }
+    if (STATS && (threadIdx.x & 63u) == 0) {
+        atomicAdd(q.stats + 0, sIter); atomicAdd(q.stats + 1, sAct); atomicAdd(q.stats + 2, sA); atomicAdd(q.stats + 3, sLA);
+        atomicAdd(q.stats + 4, sB); atomicAdd(q.stats + 5, sLB); atomicAdd(q.stats + 6, sC); atomicAdd(q.stats + 7, sLC);
+    }
 }
 
 // kernel prologue shared by all TLAS kernels: LDS stack top, spill area, ray pool
@@ -643,6 +590,15 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays; /* batch size may live on the device (wavefront queues) */      \
     pool.init(q.poolParts);
 
+template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N = 12, int REFILL_MIN = 16, int PHASE_MIN = 16, bool ADAPT = false>
+__global__ __launch_bounds__(WG) void k_tlas_flat_stats(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
+                                                  const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, QueryArgs q,
+                                                  uint32_t* __restrict__ status) {
+    TBVH_TLAS_PROLOGUE
+    (void)ldsTrips;
+    tlas_flat_body<ANYHIT, BLAS_LAYOUT, LDS_N, REFILL_MIN, PHASE_MIN, ADAPT, true>(tlasNodes, tlasIdx, instances, blas, q, st, pool, nRaysTotal);
+    if (st.overflow) atomicOr(status, 1u);
+}
 template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N = 12, int REFILL_MIN = 16, int PHASE_MIN = 16, bool ADAPT = false>
 __global__ __launch_bounds__(WG) void k_tlas_flat(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
                                                   const float4* __restrict__ instances, const BlasDesc* __restrict__ blas, QueryArgs q,
@@ -736,7 +692,8 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
         return;
     }
 #if TBVH_EXPERIMENTS
-    if (variant == 6) TBVH_LT(k_tlas_flat_w6, 12, 16, 32, true);   // flat loop under the lockstep governor
+    if (variant == 15) TBVH_LT(k_tlas_flat_stats, 12, 16, 32);   // statistics of the flat loop: phases run, lanes per phase
+    else if (variant == 6) TBVH_LT(k_tlas_flat_w6, 12, 16, 32, true);   // flat loop under the lockstep governor
     else if (variant == 7) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);         // flat loop, per-lane replacement throughout
     else if (variant == 9) TBVH_LT(k_tlas_flat_w6, 12, 64, 16);         // flat loop, lockstep throughout
     // flat-loop parameters swept without effect beyond +-3 %: phase threshold 24 / 40 / 48, refill threshold 8 / 24 / 32 (8: incoherent
@@ -751,13 +708,12 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
     else if (variant != 0) TBVH_LT(k_tlas_w5, 12);       // 3: nested loops at 5 waves per SIMD, 12-entry LDS stack top
     else
 #endif
-    {
-        if (blasLayout == kLayoutCwbvh) TBVH_LT(k_tlas_flat_w6, 12, 16, 32);
-        else TBVH_LT(k_tlas_adaptive, 12, 140);
-    }
+    // CWBVH BLASes: the flat loop.  BVH4_GPU BLASes are served by the unified 4-wide kernel (kernels_tlas4.hip, launch_tlas4); this
+    // path only sees them when that TLAS could not be built (more than 2^31 blocks), and then the flat loop is the safe choice
+    TBVH_LT(k_tlas_flat_w6, 12, 16, 32);
 #undef TBVH_LT
 }
 
-bool tlas_variant_valid(int v) { return TBVH_EXPERIMENTS ? (v >= 0 && v <= 14) : v == 0; }
+bool tlas_variant_valid(int v) { return TBVH_EXPERIMENTS ? ((v >= 0 && v <= 15) || (v >= 21 && v <= 31)) : v == 0; }
 
 }  // namespace tbvh

@@ -99,6 +99,16 @@ def main():
             tb.lib.tbvh_debug_stats(ctx._h, st, 1)
             tot = max(sum(int(x) for x in st), 1)
             print("   incoherent: generation cohesion histogram (<.25 -.375 -.5 -.6 -.7 -.8 -.9 >=.9): " + " ".join(f"{int(x) / tot:.3f}" for x in st), flush=True)
+        if a.variant in (15, 26):
+            import ctypes as C
+            st = (C.c_uint64 * 8)()
+            tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+            tlas.intersect_device_fresh(d_rr, m, 1e30); ctx.synchronize()
+            tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+            it, act, pa, la, pb, lb, pc, lc = [int(x) for x in st]
+            print(f"   incoherent flat-loop statistics: wave iterations {it} ({it * 64 / m:.1f} per ray), active lanes/64 {act / max(it, 1) / 64:.3f}; "
+                  f"TLAS (26: node) phases {pa / it:.3f}/iter at {la / max(pa, 1):.1f} lanes ({la / m:.1f} steps/ray); instance phases {pb / it:.3f}/iter at {lb / max(pb, 1):.1f} lanes ({lb / m:.1f}/ray); "
+                  f"BLAS phases {pc / it:.3f}/iter at {lc / max(pc, 1):.1f} lanes ({lc / m:.1f} steps/ray)", flush=True)
         print(f"incoherent: {m} random rays: Intersect {np.mean(ms):.3f} ms = {m / np.mean(ms) / 1e3:.1f} MRays/s, IsOccluded {np.mean(mo):.3f} ms = {m / np.mean(mo) / 1e3:.1f} MRays/s", flush=True)
     hits = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(hits, d_rays)
     print("hit fraction", float((hits["t"] < 1e30).mean()), "distinct instances hit", len(np.unique(hits["inst"][hits["t"] < 1e30])))
