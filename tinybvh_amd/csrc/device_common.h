@@ -99,6 +99,10 @@ struct QueryArgs {
     Omm omm;               // opacity micromaps of the scene (map == nullptr: none)
     uint32_t fresh;        // 1: ignore the stored hit, start every ray from {freshTmax,0,0,0} and always write the record
     float freshTmax;
+    // coherence probe of this batch (kernels_raygen.hip: k_coherence_probe): probe[0] = sampled neighbour pairs whose directions agree, probe[1] = pairs
+    // sampled; nullptr = no probe ran (small batches).  baseBlocks: workgroups beyond this index only take part when the batch is coherent.
+    const uint32_t* probe;
+    uint32_t baseBlocks;
 };
 
 // A float4 array known to live in global memory.  Pointers that were themselves loaded from

@@ -37,7 +37,7 @@ constexpr int WG = 64;
 // [6] sum of lanes in those, [7] node-phase iterations
 // TSTRIDE: float4s between consecutive triangle records (3 = the reference's packed array; 4 = padded to 64 bytes so that no
 // record straddles a 128-byte line)
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, bool STATS = false, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, bool STATS = false, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false, bool PROBED = false>
 __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -49,6 +49,15 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     pool.init(q.poolParts);
     LockstepGovernor gov;
     gov.init();
+    // PROBED: the batch's coherence probe (QueryArgs::probe) picks the schedule for the whole launch: coherent batches (camera rays, shadow
+    // rays towards one light) are VALU-bound and run deferred triangles + a gated triangle phase on a third more waves; incoherent ones are
+    // bound by the cache-miss path, keep the strict schedule, and the surplus waves leave at once
+    bool coh = false;
+    if (PROBED && q.probe) {
+        const uint32_t agree = q.probe[0], pairs = q.probe[1];
+        coh = pairs != 0 && agree * 10u >= pairs * 6u;
+        if (!coh && blockIdx.x >= q.baseBlocks) return;
+    }
 
     bool active = false;
     uint64_t ri = 0;
@@ -90,9 +99,9 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
         // COH_ONLY: deferral and the gate apply only while the wave runs in lockstep (coherent rays: VALU-bound, the gate
         // saves triangle phases); once the governor has switched to per-lane replacement (incoherent rays: bound by the
         // cache-miss path, where nodes visited ahead of their turn are extra traffic) the strict schedule applies
-        const bool spec = SPEC && (!COH_ONLY || gov.lockstep);
+        const bool spec = PROBED ? coh : (SPEC && (!COH_ONLY || gov.lockstep));
         bool triPhase = true;
-        if (TRI_MIN > 1 && (!COH_ONLY || gov.lockstep)) {
+        if (TRI_MIN > 1 && (PROBED ? coh : (!COH_ONLY || gov.lockstep))) {
             const uint32_t nPend = (uint32_t)__popcll(__ballot(tg.y != 0));
             const bool canNode = spec ? (tg2.y == 0 && (cw_has_child(ng) || !st.empty())) : tg.y == 0;
             triPhase = nPend >= (uint32_t)TRI_MIN || __ballot(canNode) == 0;
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
             }
-            if (SPEC && tg.y == 0) { tg = tg2; tg2 = make_uint2(0u, 0u); }
+            if ((SPEC || PROBED) && tg.y == 0) { tg = tg2; tg2 = make_uint2(0u, 0u); }
         }
         // ---- node phase ---------------------------------------------------------------------------------------
         if (!done && (spec ? tg2.y == 0 : tg.y == 0)) {
@@ -153,11 +162,11 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     }
 }
 
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool STATS = false, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool STATS = false, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false, bool PROBED = false>
 void launch_k(const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
     // without opacity micromaps on the scene the check is compiled out (+1-2 %)
-    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE, TSTRIDE, COH_ONLY>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
-    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE, TSTRIDE, COH_ONLY>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE, TSTRIDE, COH_ONLY, PROBED>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE, TSTRIDE, COH_ONLY, PROBED>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
 }
 
 __global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__ dst, uint32_t nNodes) {
@@ -200,10 +209,13 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     case 69: TBVH_K(8, 16, 16, true, false, 5, 3, true); return;
     case 70: TBVH_K(8, 16, 12, true, false, 5, 3, true); return;
     case 71: TBVH_K(8, 16, 1, true, false, 5, 3, true); return;   // deferred (no gate) while in lockstep
+    case 72: TBVH_K(8, 16, 1, false); return;                     // the strict schedule throughout, whatever the probe says
     default: launch_cwbvh_exp(anyhit, variant, nodes, tris, q, status, blocks, s); return;
     }
 #endif
-    TBVH_K(8, 16, 1, false);
+    // with a coherence probe of the batch (capi.hip: launchQuery) the schedule is chosen per launch; without one, the strict schedule
+    if (q.probe) TBVH_K(8, 16, 8, true, false, 5, 3, false, true);
+    else TBVH_K(8, 16, 1, false);
 #undef TBVH_K
 }
 
@@ -230,7 +242,7 @@ bool cwbvh_variant_tri64(int v) { return TBVH_EXPERIMENTS && v >= 64 && v <= 67;
 
 bool cwbvh_variant_valid(int v) {
 #if TBVH_EXPERIMENTS
-    return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43) || (v >= 50 && v <= 71);
+    return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43) || (v >= 50 && v <= 72);
 #else
     return v == 0;
 #endif
