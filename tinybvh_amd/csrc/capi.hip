@@ -104,6 +104,10 @@ struct tbvh_scene {
     uint64_t tlas4Cap = 0;            // blocks
     void* tlas4Scratch = nullptr;
     size_t tlas4ScratchBytes = 0;
+    // ... or 8-wide in the BVH8_CWBVH node format (kernels_tlas8.hip) for TLASes whose BLASes are all BVH8_CWBVH; same scratch
+    float4* tlas8 = nullptr;
+    uint32_t* tlas8Refs = nullptr;
+    uint64_t tlas8Cap = 0;            // nodes; instance references: the same number
     // device-side TLAS rebuild (kernels_tlasbuild.hip)
     float* blasBounds = nullptr;      // 6 floats per BLAS
     float* xformStage = nullptr;      // staged transforms (16 floats per instance) when the caller passes host memory
@@ -346,6 +350,14 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             c->timed = true;
             return 0;
         }
+        if (s->tlas8 && s->blasLayout == TBVH_LAYOUT_CWBVH && (tv == 0 || (tv >= 21 && tv <= 31))) {   // BVH8_CWBVH BLASes: the unified 8-wide kernel
+            q.spillStride = c->spillEntries / 2;   // 8-byte stack entries
+            launch_tlas8(any, tv, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            c->timed = true;
+            return 0;
+        }
         q.spillStride = c->spillEntries / 2;
         launch_tlas(any, s->blasLayout, s->variant ? s->variant : c->tlasVariant, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
         HIP_TRY(hipGetLastError());
@@ -565,8 +577,32 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
 namespace {
 // (re)build the 4-wide TLAS from the BVH_GPU nodes on the device; asynchronous on the context's stream
 int buildTlas4(tbvh_scene* s) {
-    if (s->blasLayout != TBVH_LAYOUT_BVH4_GPU) return 0;
     tbvh_context* c = s->ctx;
+    if (s->blasLayout == TBVH_LAYOUT_CWBVH) {
+        const uint64_t cap = tlas8_cap_nodes(s->nTlasNodes, s->nInst);
+        if (cap > 0x00ffffffull) return 0;   // wide-node indices share a word with 8 flag bits in places: the flat loop serves larger TLASes
+        if (cap > s->tlas8Cap) {
+            if (s->tlas8) hipFree(s->tlas8);
+            if (s->tlas8Refs) hipFree(s->tlas8Refs);
+            s->tlas8 = nullptr; s->tlas8Refs = nullptr; s->tlas8Cap = 0;
+            HIP_TRY(hipMalloc((void**)&s->tlas8, cap * 80));
+            HIP_TRY(hipMalloc((void**)&s->tlas8Refs, cap * 4));
+            s->tlas8Cap = cap;
+        }
+        const size_t sb = tlas8_scratch_bytes(s->nTlasNodes, s->nInst);
+        if (sb > s->tlas4ScratchBytes) {
+            if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
+            s->tlas4Scratch = nullptr; s->tlas4ScratchBytes = 0;
+            HIP_TRY(hipMalloc(&s->tlas4Scratch, sb));
+            s->tlas4ScratchBytes = sb;
+        }
+        launch_tlas8_build(s->nodes, (uint32_t)s->nTlasNodes, s->tlasIdx, (uint32_t)s->nTlasIdx, s->instances, (uint32_t)s->nInst, s->tlas8, (uint32_t)s->tlas8Cap, s->tlas8Refs,
+                           (uint32_t)s->tlas8Cap, s->tlas4Scratch, c->stream);
+        HIP_TRY(hipGetLastError());
+        s->bytes += cap * 84;
+        return 0;
+    }
+    if (s->blasLayout != TBVH_LAYOUT_BVH4_GPU) return 0;
     const uint64_t cap = tlas4_cap_blocks(s->nTlasNodes, s->nInst);
     if (cap > 0x7fffffffull) return 0;   // beyond 31-bit block offsets: the BVH_GPU TLAS kernels serve this TLAS
     if (cap > s->tlas4Cap) {
@@ -906,8 +942,6 @@ int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice
         else {
             if (s->xformStageCap < n) {   // tbvh_update_tlas may have grown the instance array since the last rebuild
                 if (s->xformStage) hipFree(s->xformStage);
-    if (s->tlas4) hipFree(s->tlas4);
-    if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
                 s->xformStage = nullptr; s->xformStageCap = 0;
                 HIP_TRY(hipMalloc((void**)&s->xformStage, n * 64));
                 s->xformStageCap = n;
@@ -966,6 +1000,10 @@ void tbvh_free_scene(tbvh_scene* s) {
     if (s->blasBounds) hipFree(s->blasBounds);
     if (s->xformStage) hipFree(s->xformStage);
     if (s->buildScratch) hipFree(s->buildScratch);
+    if (s->tlas4) hipFree(s->tlas4);
+    if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
+    if (s->tlas8) hipFree(s->tlas8);
+    if (s->tlas8Refs) hipFree(s->tlas8Refs);
     if (s->refitScratch) hipFree(s->refitScratch);
     if (s->opmap) hipFree(s->opmap);
     if (s->vertStage) hipFree(s->vertStage);

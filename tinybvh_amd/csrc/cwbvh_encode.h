@@ -11,6 +11,25 @@ namespace tbvh {
 __device__ __forceinline__ float3 min3(float3 a, float3 b) { return make_float3(fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)); }
 __device__ __forceinline__ float3 max3(float3 a, float3 b) { return make_float3(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)); }
 
+// Octant slots of the up to 8 children of a node: greedy on cost[s][i] = dot(centroid_i - centroid_node, dir_s), the assignment of
+// BVH8_CWBVH::ConvertFrom (tiny_bvh.h:5906-5938) and of the host encoder.  slotOf[i] = slot of child i, childIn[s] = child in slot s or -1.
+__device__ inline void cw_assign_slots(uint32_t nk, float3 mn, float3 mx, const float3* cmn, const float3* cmx, int* slotOf, int* childIn) {
+    const float3 nc = make_float3(0.5f * (mn.x + mx.x), 0.5f * (mn.y + mx.y), 0.5f * (mn.z + mx.z));
+    float cost[8][8];
+    for (int s = 0; s < 8; s++) { childIn[s] = -1; slotOf[s] = -1; }
+    for (uint32_t i = 0; i < nk; i++) {
+        const float dx = 0.5f * (cmn[i].x + cmx[i].x) - nc.x, dy = 0.5f * (cmn[i].y + cmx[i].y) - nc.y, dz = 0.5f * (cmn[i].z + cmx[i].z) - nc.z;
+        for (int s = 0; s < 8; s++) cost[s][i] = ((s & 4) ? -dx : dx) + ((s & 2) ? -dy : dy) + ((s & 1) ? -dz : dz);
+    }
+    for (uint32_t k = 0; k < nk; k++) {
+        float best = 1e30f; int bs = -1, bi = -1;
+        for (int s = 0; s < 8; s++) if (childIn[s] < 0)
+            for (uint32_t i = 0; i < nk; i++) if (slotOf[i] < 0 && cost[s][i] < best) { best = cost[s][i]; bs = s; bi = (int)i; }
+        if (bs < 0) { for (int s = 0; s < 8 && bs < 0; s++) if (childIn[s] < 0) for (uint32_t i = 0; i < nk; i++) if (slotOf[i] < 0) { bs = s; bi = (int)i; break; } }   // NaN boxes: any free pair
+        slotOf[bi] = bs; childIn[bs] = bi;
+    }
+}
+
 // Writes the five float4 of one node.  cmn/cmx/used: the child boxes per slot; triBase in float4 blocks.
 __device__ inline void cw_quantize_write(float4* __restrict__ np, float3 mn, float3 mx, const float3* cmn, const float3* cmx, const bool* used,
                                          uint32_t imask, uint32_t childBase, uint32_t triBase, uint32_t meta0, uint32_t meta1) {

@@ -70,20 +70,11 @@ __global__ void k_convert_level(const float4* __restrict__ nodes2, uint32_t nNod
     // ---- octant slots: greedy on cost[s][i] = dot(centroid_i - centroid_node, dir_s) (host encoder / tiny_bvh.h:5906-5938)
     N2 kid[8];
     for (uint32_t i = 0; i < nk; i++) kid[i] = load_n2(nodes2, kids[i]);
-    const float3 nc = make_float3(0.5f * (self.mn.x + self.mx.x), 0.5f * (self.mn.y + self.mx.y), 0.5f * (self.mn.z + self.mx.z));
-    float cost[8][8];
     int slotOf[8], childIn[8];
-    for (int s = 0; s < 8; s++) { childIn[s] = -1; slotOf[s] = -1; }
-    for (uint32_t i = 0; i < nk; i++) {
-        const float dx = 0.5f * (kid[i].mn.x + kid[i].mx.x) - nc.x, dy = 0.5f * (kid[i].mn.y + kid[i].mx.y) - nc.y, dz = 0.5f * (kid[i].mn.z + kid[i].mx.z) - nc.z;
-        for (int s = 0; s < 8; s++) cost[s][i] = ((s & 4) ? -dx : dx) + ((s & 2) ? -dy : dy) + ((s & 1) ? -dz : dz);
-    }
-    for (uint32_t k = 0; k < nk; k++) {
-        float best = 1e30f; int bs = -1, bi = -1;
-        for (int s = 0; s < 8; s++) if (childIn[s] < 0)
-            for (uint32_t i = 0; i < nk; i++) if (slotOf[i] < 0 && cost[s][i] < best) { best = cost[s][i]; bs = s; bi = (int)i; }
-        if (bs < 0) { for (int s = 0; s < 8 && bs < 0; s++) if (childIn[s] < 0) for (uint32_t i = 0; i < nk; i++) if (slotOf[i] < 0) { bs = s; bi = (int)i; break; } }   // NaN boxes: any free pair
-        slotOf[bi] = bs; childIn[bs] = bi;
+    {
+        float3 cmnA[8], cmxA[8];
+        for (uint32_t i = 0; i < nk; i++) { cmnA[i] = kid[i].mn; cmxA[i] = kid[i].mx; }
+        cw_assign_slots(nk, self.mn, self.mx, cmnA, cmxA, slotOf, childIn);
     }
     // ---- allocation
     uint32_t nInner = 0, nT = 0;

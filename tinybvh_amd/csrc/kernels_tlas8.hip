@@ -1,0 +1,314 @@
+// kernels_tlas8.hip — two-level Intersect / IsOccluded over BVH8_CWBVH BLASes with the TLAS held in the CWBVH node format: the
+// configuration of the reference's instancing demo (tiny_bvh_gpu2.cpp: CWBVH BLASes under a BVH_GPU TLAS, traverse_tlas.cl:13-107).
+//
+// Same idea as kernels_tlas4.hip (which see for the measurements that motivate it): the caller's TLAS is collapsed at every upload /
+// update / device rebuild into an 8-wide compressed tree in the BVH8_CWBVH node format (cwbvh_node.h) whose leaf children stand for
+// ONE instance each (a "triangle" slot of the node: meta = 0b001 << 5 | slot offset, the node's triangle base indexes a list of
+// instance indices), so that a TLAS node step and a BLAS node step are the same code — cw_test_node on different base pointers — and
+// the node phase of the loop serves every lane that has a node to visit, whatever its level.  The triangle phase exists twice: a
+// BLAS-level lane tests a triangle, a TLAS-level lane enters an instance.
+//
+// Traversal state is Ylitie's (node group / triangle group, kernels_cwbvh.hip); entering an instance parks the TLAS-level groups on
+// the stack below the BLAS traversal (a parked instance group is recognised by hits == 0 in its upper byte, like the postponed triangle
+// groups of the reference kernel).  Within a TLAS node the hit instances are entered before its interior children, children in octant
+// order: not the order of the nested reference loop, so among hits at exactly equal t the winner may differ (the tie class).
+#include "device_common.h"
+#include "lane_stack.h"
+#include "ray_pool.h"
+#include "kernels.h"
+#include "cwbvh_node.h"
+#include "cwbvh_encode.h"
+#include "tlas_collapse.h"
+
+namespace tbvh {
+
+namespace {
+
+constexpr int WG = 64;
+
+__device__ __forceinline__ float safercp(float x) {
+    if (x > 1e-12f || x < -1e-12f) return 1.0f / x;
+    return x >= 0 ? kFar : -kFar;
+}
+
+// =====================================================================================================================
+// TLAS (BVH_GPU nodes) -> 8-wide CWBVH-format TLAS; one workgroup, level by level (see kernels_tlas4.hip: k_tlas4_build)
+// items: uint4 {ref, cnt (0xffffffff = AL node), index of the wide node this item becomes, -}
+// =====================================================================================================================
+constexpr int kBuildThreads = 1024;
+__global__ __launch_bounds__(kBuildThreads) void k_tlas8_build(const float4* __restrict__ al, uint32_t nAL, const uint32_t* __restrict__ idx, uint32_t nIdx,
+                                                               const float4* __restrict__ inst, float4* __restrict__ nodes, uint32_t capNodes,
+                                                               uint32_t* __restrict__ instRef, uint32_t capRefs, uint4* __restrict__ itemsA, uint4* __restrict__ itemsB) {
+    __shared__ uint32_t sIn, sOut, sNodes, sRefs;
+    if (threadIdx.x == 0) {
+        const uint32_t rootCnt = as_u32(al[2].w);
+        itemsA[0] = rootCnt ? make_uint4(as_u32(al[3].w), rootCnt, 0u, 0u) : make_uint4(0u, 0xffffffffu, 0u, 0u);
+        sIn = 1; sOut = 0; sNodes = 1; sRefs = 0;
+    }
+    __syncthreads();
+    uint4 *in = itemsA, *out = itemsB;
+    for (uint32_t level = 0; level < 4096u; level++) {
+        const uint32_t n = sIn;
+        if (n == 0) break;
+        for (uint32_t t = threadIdx.x; t < n; t += kBuildThreads) {
+            const uint4 item = in[t];
+            Kid kid[8];
+            uint32_t nk = 0;
+            if (item.y == 0xffffffffu) { al_children(al, nAL, item.x, kid[0], kid[1]); nk = 2; }
+            else if (item.y <= 1u) { kid[0] = range_kid(idx, inst, item.x, item.y); nk = 1; }
+            else { const uint32_t h = item.y / 2u; kid[0] = range_kid(idx, inst, item.x, h); kid[1] = range_kid(idx, inst, item.x + h, item.y - h); nk = 2; }
+            while (nk < 8u) {   // open the largest child that can be opened
+                int best = -1; float bestSA = -1.f;
+                for (uint32_t i = 0; i < nk; i++) {
+                    if (kid[i].cnt <= 1u) continue;
+                    const float sa = kid_area(kid[i]);
+                    if (sa > bestSA) { bestSA = sa; best = (int)i; }
+                }
+                if (best < 0) break;
+                Kid a, b;
+                if (kid[best].cnt == 0xffffffffu) al_children(al, nAL, kid[best].ref, a, b);
+                else { const uint32_t h = kid[best].cnt / 2u; a = range_kid(idx, inst, kid[best].ref, h); b = range_kid(idx, inst, kid[best].ref + h, kid[best].cnt - h); }
+                kid[best] = a; kid[nk++] = b;
+            }
+            // drop empty kids (malformed input), then octant slots as for any CWBVH node
+            uint32_t m = 0;
+            for (uint32_t i = 0; i < nk; i++) if (kid[i].cnt != 0u) kid[m++] = kid[i];
+            nk = m;
+            float3 mn = make_float3(1e30f, 1e30f, 1e30f), mx = make_float3(-1e30f, -1e30f, -1e30f), kmn[8], kmx[8];
+            uint32_t nInner = 0, nLeaf = 0;
+            for (uint32_t i = 0; i < nk; i++) {
+                kmn[i] = kid[i].mn; kmx[i] = kid[i].mx;
+                mn = min3(mn, kmn[i]); mx = max3(mx, kmx[i]);
+                if (kid[i].cnt == 1u) nLeaf++; else nInner++;
+            }
+            int slotOf[8], childIn[8];
+            cw_assign_slots(nk, mn, mx, kmn, kmx, slotOf, childIn);
+            const uint32_t childBase = nInner ? atomicAdd(&sNodes, nInner) : 0u;
+            const uint32_t refBase = nLeaf ? atomicAdd(&sRefs, nLeaf) : 0u;
+            const uint32_t outFirst = nInner ? atomicAdd(&sOut, nInner) : 0u;
+            if (childBase + nInner > capNodes || refBase + nLeaf > capRefs || item.z >= capNodes) continue;   // cannot happen with tbvh's capacities
+            float3 cmn[8], cmx[8];
+            bool used[8];
+            uint8_t meta[8];
+            uint32_t imask = 0, inner = 0, leaves = 0;
+            for (int s = 0; s < 8; s++) {
+                used[s] = childIn[s] >= 0; meta[s] = 0;
+                if (!used[s]) continue;
+                const Kid& c = kid[childIn[s]];
+                cmn[s] = c.mn; cmx[s] = c.mx;
+                if (c.cnt == 1u) {
+                    meta[s] = (uint8_t)((1u << 5) | leaves);             // one "triangle" (= instance) at offset `leaves`
+                    instRef[refBase + leaves] = c.ref < nIdx ? idx[c.ref] : 0u;
+                    leaves++;
+                } else {
+                    imask |= 1u << s;
+                    meta[s] = (uint8_t)((1u << 5) | (24 + s));
+                    out[outFirst + inner] = make_uint4(c.ref, c.cnt, childBase + inner, 0u);
+                    inner++;
+                }
+            }
+            const uint32_t m0 = meta[0] | (meta[1] << 8) | (meta[2] << 16) | ((uint32_t)meta[3] << 24);
+            const uint32_t m1 = meta[4] | (meta[5] << 8) | (meta[6] << 16) | ((uint32_t)meta[7] << 24);
+            cw_quantize_write(nodes + (size_t)item.z * 5, mn, mx, cmn, cmx, used, imask, childBase, refBase, m0, m1);
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x == 0) { sIn = sOut; sOut = 0; }
+        __syncthreads();
+        uint4* tmp = in; in = out; out = tmp;
+    }
+}
+
+// =====================================================================================================================
+// traversal
+// =====================================================================================================================
+enum : uint32_t { S_NODE = 0, S_TRI = 1, S_INST = 2 };
+
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, bool STATS>
+__device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ instRef, const float4* __restrict__ instances,
+                                           const BlasDesc* __restrict__ blas, const QueryArgs& q, uint32_t* __restrict__ status) {
+    __shared__ uint2 stk[LDS_N][WG];
+    LaneStack<uint2, LDS_N, WG> st;
+    st.init(&stk[0][threadIdx.x], (uint2*)q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
+    RayPool<64> pool;
+    const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;
+    pool.init(q.poolParts);
+
+    bool active = false, found = false, inBlas = false;
+    uint64_t ri = 0;
+    float3 O = make_float3(0, 0, 0), D = O, rD = O;   // the ray in the CURRENT space
+    float4 hit = make_float4(0, 0, 0, 0);
+    uint32_t hitInst = 0, rayMask = 0, state = S_NODE, curInst = 0, blasIdx = 0, oct = 0;
+    int base = 0;
+    GlobalF4 cur(tlasNodes), btris;                   // node stream being walked (TLAS or the instance's BLAS); the BLAS's triangle records
+    uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    unsigned long long sIter = 0, sAct = 0, sN = 0, sLN = 0, sT = 0, sLT = 0, sI = 0, sLI = 0;   // STATS
+
+    for (;;) {
+        const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
+        if (nIdle >= (uint32_t)REFILL_MIN) {
+            if (!pool.dry()) {
+                uint64_t nri = 0;
+                if (pool.acquire(!active, q.counter, nRaysTotal, nri)) {
+                    ri = nri;
+                    const RayRec* rp = q.rays + ri;
+                    O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
+                    rayMask = as_u32(rp->O.w);
+                    hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
+                    hitInst = as_u32(rp->rD.w);
+                    found = false; inBlas = false; state = S_NODE; st.sp = 0;
+                    oct = cw_oct(D);
+                    ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
+                    cur = GlobalF4(tlasNodes);
+                    active = true;
+                }
+            }
+            if (__ballot(active) == 0) break;
+        }
+        const uint32_t nN = (uint32_t)__popcll(__ballot(active && state == S_NODE)), nT = (uint32_t)__popcll(__ballot(active && state == S_TRI)),
+                       nI = (uint32_t)__popcll(__ballot(active && state == S_INST));
+        const uint32_t nMax = nN > nT ? (nN > nI ? nN : nI) : (nT > nI ? nT : nI);
+        const bool runN = nN >= (uint32_t)PN || nN == nMax, runT = nT >= (uint32_t)PT || nT == nMax, runI = nI >= (uint32_t)PI || nI == nMax;
+        if (STATS) { sIter++; sAct += nN + nT + nI; if (runN && nN) { sN++; sLN += nN; } if (runT && nT) { sT++; sLT += nT; } if (runI && nI) { sI++; sLI += nI; } }
+        if (!active) continue;
+        bool done = false, next = false;   // next: this lane's step is over, decide what it does in the following iteration
+
+        if (state == S_TRI) { if (runT) {
+            // ---- one triangle of the BLAS node's triangle group ------------------------------------------------------------
+            const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
+            tg.y &= ~(1u << ti);
+            const uint32_t ta = tg.x + ti * 3u;
+            const float4 e2 = btris[ta], e1 = btris[ta + 1], v0 = btris[ta + 2];
+            TriHit h;
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                const BlasDesc bd = blas[blasIdx];   // opacity micromaps are per BLAS: looked up only for a candidate hit
+                if (!bd.opmap || omm_opaque(Omm{bd.opmap, bd.opmapN}, as_u32(v0.w), h.u, h.v)) {
+                    found = true; hitInst = curInst;
+                    if (ANYHIT) done = true;
+                    else hit = make_float4(h.t, h.u, h.v, v0.w);
+                }
+            }
+            next = !done;
+        } } else if (state == S_INST) { if (runI) {
+            // ---- enter one instance of the TLAS node's instance group (tiny_bvh.h:3326-3333) ----------------------------------
+            const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
+            tg.y &= ~(1u << ti);
+            const uint32_t ii = instRef[tg.x + ti];
+            const float4* ip = instances + (size_t)ii * 12;
+            const float4 b0 = ip[8], b1 = ip[9];                      // aabbMin|blasIdx, aabbMax|mask
+            if (as_u32(b1.w) & rayMask) {
+                // park what is left at this TLAS node below the BLAS traversal: its other hit instances, then its interior children
+                if (cw_has_child(ng)) st.push(ng);
+                if (tg.y != 0) st.push(tg);
+                const float4 r0 = ip[4], r1 = ip[5], r2 = ip[6], r3 = ip[7];   // invTransform rows
+                // tinybvh_transform_point / _vector with the reference build's contraction (kernels_tlas.hip: tlas_body)
+                const float px = __builtin_fmaf(r0.z, O.z, __builtin_fmaf(r0.x, O.x, r0.y * O.y)) + r0.w;
+                const float py = __builtin_fmaf(r1.z, O.z, __builtin_fmaf(r1.x, O.x, r1.y * O.y)) + r1.w;
+                const float pz = __builtin_fmaf(r2.z, O.z, __builtin_fmaf(r2.x, O.x, r2.y * O.y)) + r2.w;
+                const float w = __builtin_fmaf(r3.z, O.z, __builtin_fmaf(r3.x, O.x, r3.y * O.y)) + r3.w;
+                const float3 lD = make_float3(__builtin_fmaf(r0.z, D.z, __builtin_fmaf(r0.x, D.x, r0.y * D.y)), __builtin_fmaf(r1.z, D.z, __builtin_fmaf(r1.x, D.x, r1.y * D.y)),
+                                              __builtin_fmaf(r2.z, D.z, __builtin_fmaf(r2.x, D.x, r2.y * D.y)));
+                if (w == 1) O = make_float3(px, py, pz);
+                else { const float iw = 1.f / w; O = make_float3(px * iw, py * iw, pz * iw); }
+                D = lD;
+                rD = make_float3(safercp(D.x), safercp(D.y), safercp(D.z));
+                blasIdx = as_u32(b0.w);
+                const BlasDesc bd = blas[blasIdx];
+                cur = GlobalF4(bd.nodes); btris = GlobalF4(bd.tris);
+                curInst = ii; base = st.sp; inBlas = true;
+                oct = cw_oct(D);
+                ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
+                state = S_NODE;
+            } else next = true;
+        } } else if (runN) {
+            // ---- one node of the TLAS or of the instance's BLAS: same format, same code ------------------------------------------
+            if (cw_has_child(ng)) {
+                const uint32_t ci = cw_next_child(ng, oct);
+                if (cw_has_child(ng)) st.push(ng);
+                const CwNodeHits r = cw_test_node(cw_load_node(cur, ci), O, rD, hit.x, oct * 0x01010101u);
+                ng = make_uint2(r.childBase, (r.hitmask & 0xFF000000u) | r.imask);
+                tg = make_uint2(r.triBase, r.hitmask & 0x00FFFFFFu);
+            }
+            next = true;
+        }
+        if (next) {
+            // ---- what next: the group in hand, else the stack; a BLAS traversal back at its base returns to the TLAS with the world ray ----
+            if (tg.y != 0) state = inBlas ? S_TRI : S_INST;
+            else if (cw_has_child(ng)) state = S_NODE;
+            else {
+                if (inBlas && st.sp == base) {
+                    inBlas = false; cur = GlobalF4(tlasNodes);
+                    const RayRec* rp = q.rays + ri;
+                    O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
+                    oct = cw_oct(D);
+                }
+                if (st.sp == 0) done = true;
+                else {
+                    const uint2 e = st.pop();
+                    if (e.y > 0x00FFFFFFu) { ng = e; tg = make_uint2(0u, 0u); state = S_NODE; }
+                    else { tg = e; ng = make_uint2(0u, 0u); state = inBlas ? S_TRI : S_INST; }   // a parked instance group (TLAS level)
+                }
+            }
+        }
+        if (done) {
+            RayRec* rp = q.rays + ri;
+            if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+            else if (found) { rp->hit = hit; ((uint32_t*)rp)[11] = hitInst; }   // byte 44 = hit.inst
+            else if (q.fresh) rp->hit = hit;
+            active = false;
+        }
+    }
+    if (st.overflow) atomicOr(status, 1u);
+    if (STATS && (threadIdx.x & 63u) == 0) {
+        atomicAdd(q.stats + 0, sIter); atomicAdd(q.stats + 1, sAct); atomicAdd(q.stats + 2, sN); atomicAdd(q.stats + 3, sLN);
+        atomicAdd(q.stats + 4, sI); atomicAdd(q.stats + 5, sLI); atomicAdd(q.stats + 6, sT); atomicAdd(q.stats + 7, sLT);
+    }
+}
+
+template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool STATS = false>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_tlas8(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ instRef,
+                                                                                           const float4* __restrict__ instances, const BlasDesc* __restrict__ blas,
+                                                                                           QueryArgs q, uint32_t* __restrict__ status) {
+    tlas8_body<ANYHIT, LDS_N, REFILL_MIN, PN, PT, PI, STATS>(tlasNodes, instRef, instances, blas, q, status);
+}
+
+}  // namespace
+
+// capacities: wide nodes <= AL nodes + instances + 2, instance references <= instances (+ ranges of malformed input: + AL nodes)
+uint64_t tlas8_cap_nodes(uint64_t nAL, uint64_t nInst) { return nAL + nInst + 2; }
+size_t tlas8_scratch_bytes(uint64_t nAL, uint64_t nInst) { return (size_t)(nAL + nInst + 2) * 16 * 2; }
+
+void launch_tlas8_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* nodes, uint32_t capNodes,
+                        uint32_t* instRef, uint32_t capRefs, void* scratch, hipStream_t s) {
+    uint4* itemsA = (uint4*)scratch;
+    uint4* itemsB = itemsA + (size_t)(nAL + nInst + 2);
+    hipLaunchKernelGGL(k_tlas8_build, dim3(1), dim3(kBuildThreads), 0, s, al, nAL, idx, nIdx, inst, nodes, capNodes, instRef, capRefs, itemsA, itemsB);
+}
+
+void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* instRef, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
+                  uint32_t* status, uint32_t blocks, hipStream_t s) {
+#define TBVH_T8(...)                                                                                                                                \
+    do {                                                                                                                                            \
+        if (anyhit) hipLaunchKernelGGL((k_tlas8<true, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, instRef, instances, blas, q, status);  \
+        else hipLaunchKernelGGL((k_tlas8<false, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, instRef, instances, blas, q, status);        \
+    } while (0)
+#if TBVH_EXPERIMENTS
+    switch (variant) {
+    case 21: TBVH_T8(12, 16, 32, 32, 32); return;
+    case 22: TBVH_T8(12, 16, 16, 8, 8); return;
+    case 23: TBVH_T8(12, 16, 8, 8, 8); return;
+    case 24: TBVH_T8(12, 16, 24, 16, 16); return;
+    case 25: TBVH_T8(12, 16, 16, 4, 4); return;
+    case 26: TBVH_T8(12, 16, 24, 8, 8, true); return;   // statistics
+    case 29: TBVH_T8(12, 8, 24, 8, 8); return;
+    case 30: TBVH_T8(12, 16, 32, 8, 8); return;
+    case 31: TBVH_T8(8, 16, 24, 8, 8); return;
+    default: break;
+    }
+#endif
+    (void)variant;
+    TBVH_T8(12, 16, 24, 8, 8);
+#undef TBVH_T8
+}
+
+}  // namespace tbvh

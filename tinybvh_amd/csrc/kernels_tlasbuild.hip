@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <cstdio>
+
 #include "device_common.h"
 #include "kernels.h"
 
@@ -275,12 +277,18 @@ hipError_t launch_tlas_rebuild(float4* tlasNodes, uint32_t* tlasIdx, float4* ins
     if ((e = hipMemsetAsync(bounds + 3, 0x00, 12, s)) != hipSuccess) return e;    // centre maxima
     if ((e = hipMemsetAsync(flags, 0, (size_t)n * 4, s)) != hipSuccess) return e;
     const uint32_t bs = 128, nb = (n + bs - 1) / bs;
+#define TBVH_STEP(what) do { if ((e = hipGetLastError()) != hipSuccess) { fprintf(stderr, "[tinybvh_amd] TLAS rebuild: %s: %s\n", what, hipGetErrorString(e)); return e; } } while (0)
     hipLaunchKernelGGL(k_instance_update, dim3(nb), dim3(bs), 0, s, instances, transformsDev, blasBoundsDev, n, nBlas, instMin, instMax, bounds);
+    TBVH_STEP("instance update");
     hipLaunchKernelGGL(k_morton, dim3(nb), dim3(bs), 0, s, instMin, instMax, bounds, n, keysA, valsA);
+    TBVH_STEP("morton codes");
     size_t tmp = sortTempBytes;
-    if ((e = hipcub::DeviceRadixSort::SortPairs(sortTemp, tmp, keysA, keysB, valsA, valsB, (int)n, 0, 30, s)) != hipSuccess) return e;
+    if ((e = hipcub::DeviceRadixSort::SortPairs(sortTemp, tmp, keysA, keysB, valsA, valsB, (int)n, 0, 30, s)) != hipSuccess) { fprintf(stderr, "[tinybvh_amd] TLAS rebuild: radix sort (%zu temp bytes): %s\n", sortTempBytes, hipGetErrorString(e)); return e; }
     if (n > 1) hipLaunchKernelGGL(k_lbvh_topology, dim3(nb), dim3(bs), 0, s, keysB, n, parent, children);
+    TBVH_STEP("topology");
     hipLaunchKernelGGL(k_lbvh_nodes, dim3(nb), dim3(bs), 0, s, valsB, instMin, instMax, parent, children, flags, boxMin, boxMax, n, tlasNodes, tlasIdx);
+    TBVH_STEP("nodes");
+#undef TBVH_STEP
     return hipGetLastError();
 }
 
