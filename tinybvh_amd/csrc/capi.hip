@@ -589,7 +589,7 @@ int buildTlas4(tbvh_scene* s) {
             HIP_TRY(hipMalloc((void**)&s->tlas8Refs, cap * 4));
             s->tlas8Cap = cap;
         }
-        const size_t sb = tlas8_scratch_bytes(s->nTlasNodes, s->nInst);
+        const size_t sb = tlas_wide_scratch_bytes(s->nTlasNodes, s->nInst);
         if (sb > s->tlas4ScratchBytes) {
             if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
             s->tlas4Scratch = nullptr; s->tlas4ScratchBytes = 0;
@@ -611,7 +611,7 @@ int buildTlas4(tbvh_scene* s) {
         HIP_TRY(hipMalloc((void**)&s->tlas4, cap * 16));
         s->tlas4Cap = cap;
     }
-    const size_t sb = tlas4_scratch_bytes(s->nTlasNodes, s->nInst);
+    const size_t sb = tlas_wide_scratch_bytes(s->nTlasNodes, s->nInst);
     if (sb > s->tlas4ScratchBytes) {
         if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
         s->tlas4Scratch = nullptr; s->tlas4ScratchBytes = 0;

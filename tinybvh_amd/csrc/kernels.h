@@ -37,7 +37,7 @@ struct BlasDesc { const float4* nodes; const float4* tris; const uint32_t* opmap
 void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances,
                  const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
 // 4-wide TLAS in the BVH4_GPU node format + the unified two-level kernel for BVH4_GPU BLASes (kernels_tlas4.hip)
-size_t tlas4_scratch_bytes(uint64_t nAL, uint64_t nInst);
+size_t tlas_wide_scratch_bytes(uint64_t nAL, uint64_t nInst);   // kernels_tlaswide.hip builds both wide TLAS formats
 uint64_t tlas4_cap_blocks(uint64_t nAL, uint64_t nInst);
 void launch_tlas4_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* blocks, uint32_t capBlocks,
                         void* scratch, hipStream_t s);
@@ -45,7 +45,6 @@ void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* i
                   hipStream_t s);
 // 8-wide TLAS in the BVH8_CWBVH node format + the unified two-level kernel for BVH8_CWBVH BLASes (kernels_tlas8.hip)
 uint64_t tlas8_cap_nodes(uint64_t nAL, uint64_t nInst);
-size_t tlas8_scratch_bytes(uint64_t nAL, uint64_t nInst);
 void launch_tlas8_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* nodes, uint32_t capNodes,
                         uint32_t* instRef, uint32_t capRefs, void* scratch, hipStream_t s);
 void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* instRef, const float4* instances, const BlasDesc* blas, const QueryArgs& q,

@@ -6,7 +6,7 @@
 // 4.2 M random rays: 94 wave-iterations per ray for 37.5 steps, 23 k issued lane-operations per ray of which 16 % are useful,
 // VALU 80 % busy: profiles/r02_tlas_flat_counters.txt).  The two big modes differ only in the node format they decode.
 // So the TLAS the caller uploads (BVH_GPU nodes over BLASInstance records, tiny_bvh.h:4575-4581, or the device-built
-// LBVH of kernels_tlasbuild.hip) is collapsed once per upload / rebuild into a 4-wide quantised tree in the BVH4_GPU node
+// LBVH of kernels_tlasbuild.hip) is collapsed once per upload / rebuild (kernels_tlaswide.hip) into a 4-wide quantised tree in the BVH4_GPU node
 // format (4 blocks: bmin | qxmin, ext/255 | qxmax, qymin qymax qzmin qzmax, childInfo[4]; tiny_bvh.h:1248-1266), whose leaf
 // children name an instance (childInfo = 1 << 31 | instance index) instead of an inline triangle run.  A TLAS node
 // step and a BLAS node step are then THE SAME CODE on different base pointers, all lanes that have a node to visit take it
@@ -20,8 +20,6 @@
 #include "lane_stack.h"
 #include "ray_pool.h"
 #include "kernels.h"
-#include "bvh4_encode.h"
-#include "tlas_collapse.h"
 
 namespace tbvh {
 
@@ -34,81 +32,6 @@ __device__ __forceinline__ float fmax3(float a, float b, float c) { return __bui
 __device__ __forceinline__ float safercp(float x) {
     if (x > 1e-12f || x < -1e-12f) return 1.0f / x;
     return x >= 0 ? kFar : -kFar;
-}
-
-// =====================================================================================================================
-// TLAS (BVH_GPU / Aila-Laine nodes) -> 4-wide quantised TLAS.  ONE workgroup walks the wide tree level by level (a
-// TLAS has thousands of nodes, not millions; one launch, no host round trip, so tbvh_rebuild_tlas_device stays
-// asynchronous).  A work item is a subtree that becomes one wide node: an interior AL node, or a range of the instance
-// index list (an AL leaf with more than one instance — the reference's builder may leave up to 4 — is split in halves).
-// =====================================================================================================================
-constexpr int kBuildThreads = 1024;
-// items: uint4 {ref, cnt (0xffffffff = AL node), word index of the parent's childInfo entry to patch (0xffffffff: root), -}
-__global__ __launch_bounds__(kBuildThreads) void k_tlas4_build(const float4* __restrict__ al, uint32_t nAL, const uint32_t* __restrict__ idx, uint32_t nIdx,
-                                                               const float4* __restrict__ inst, uint32_t nInst, float4* __restrict__ blocks, uint32_t capBlocks,
-                                                               uint4* __restrict__ itemsA, uint4* __restrict__ itemsB, uint32_t* __restrict__ nBlocksOut) {
-    __shared__ uint32_t sIn, sOut, sBlocks;
-    if (threadIdx.x == 0) {
-        const uint32_t rootCnt = as_u32(al[2].w);
-        itemsA[0] = rootCnt ? make_uint4(as_u32(al[3].w), rootCnt, 0xffffffffu, 0u) : make_uint4(0u, 0xffffffffu, 0xffffffffu, 0u);
-        sIn = 1; sOut = 0; sBlocks = 0;
-    }
-    __syncthreads();
-    uint4 *in = itemsA, *out = itemsB;
-    for (uint32_t level = 0; level < 4096u; level++) {
-        const uint32_t n = sIn;
-        if (n == 0) break;
-        for (uint32_t t = threadIdx.x; t < n; t += kBuildThreads) {
-            const uint4 item = in[t];
-            Kid kid[4];
-            uint32_t nk = 0;
-            if (item.y == 0xffffffffu) { al_children(al, nAL, item.x, kid[0], kid[1]); nk = 2; }
-            else if (item.y <= 1u) { kid[0] = range_kid(idx, inst, item.x, item.y); nk = 1; }
-            else { const uint32_t h = item.y / 2u; kid[0] = range_kid(idx, inst, item.x, h); kid[1] = range_kid(idx, inst, item.x + h, item.y - h); nk = 2; }
-            while (nk < 4u) {   // open the largest child that can be opened
-                int best = -1; float bestSA = -1.f;
-                for (uint32_t i = 0; i < nk; i++) {
-                    if (kid[i].cnt <= 1u) continue;   // one instance (or empty): final
-                    const float sa = kid_area(kid[i]);
-                    if (sa > bestSA) { bestSA = sa; best = (int)i; }
-                }
-                if (best < 0) break;
-                Kid a, b;
-                if (kid[best].cnt == 0xffffffffu) al_children(al, nAL, kid[best].ref, a, b);
-                else { const uint32_t h = kid[best].cnt / 2u; a = range_kid(idx, inst, kid[best].ref, h); b = range_kid(idx, inst, kid[best].ref + h, kid[best].cnt - h); }
-                kid[best] = a; kid[nk++] = b;
-            }
-            const uint32_t base = atomicAdd(&sBlocks, 4u);
-            if (base + 4u > capBlocks) continue;   // cannot happen with the capacity tbvh sizes (4 blocks per AL node + instance)
-            if (item.z != 0xffffffffu) ((uint32_t*)blocks)[item.z] = base;
-            float3 mn = make_float3(1e30f, 1e30f, 1e30f), mx = make_float3(-1e30f, -1e30f, -1e30f);
-            float3 cmn[4], cmx[4];
-            uint32_t info[4] = {0u, 0u, 0u, 0u};
-            bool used[4] = {false, false, false, false};
-            uint32_t nInner = 0;
-            for (uint32_t i = 0; i < nk; i++) {
-                if (kid[i].cnt == 0u) continue;
-                used[i] = true; cmn[i] = kid[i].mn; cmx[i] = kid[i].mx;
-                mn = make_float3(fminf(mn.x, cmn[i].x), fminf(mn.y, cmn[i].y), fminf(mn.z, cmn[i].z));
-                mx = make_float3(fmaxf(mx.x, cmx[i].x), fmaxf(mx.y, cmx[i].y), fmaxf(mx.z, cmx[i].z));
-                if (kid[i].cnt == 1u) info[i] = 0x80000000u | (kid[i].ref < nIdx ? idx[kid[i].ref] : 0u);
-                else nInner++;
-            }
-            if (nInner) {
-                uint32_t o = atomicAdd(&sOut, nInner);
-                for (uint32_t i = 0; i < nk; i++)
-                    if (used[i] && kid[i].cnt > 1u) out[o++] = make_uint4(kid[i].ref, kid[i].cnt, (base + 3u) * 4u + i, 0u);   // the child patches info[i]
-            }
-            bvh4_quantize_write(blocks + base, mn, mx, cmn, cmx, used, info);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { sIn = sOut; sOut = 0; }
-        __threadfence_block();
-        __syncthreads();
-        uint4* tmp = in; in = out; out = tmp;
-    }
-    if (threadIdx.x == 0 && nBlocksOut) *nBlocksOut = sBlocks;
-    (void)nInst;
 }
 
 // =====================================================================================================================
@@ -290,18 +213,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 }
 
 }  // namespace
-
-size_t tlas4_scratch_bytes(uint64_t nAL, uint64_t nInst) { return (size_t)(nAL + nInst + 2) * 16 * 2 + 64; }
-uint64_t tlas4_cap_blocks(uint64_t nAL, uint64_t nInst) { return 4 * (nAL + nInst + 2); }
-
-// al: BVH_GPU (Aila-Laine) TLAS nodes; idx: instance index list; inst: BLASInstance records (192 bytes).  One launch.
-void launch_tlas4_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* blocks, uint32_t capBlocks,
-                        void* scratch, hipStream_t s) {
-    uint4* itemsA = (uint4*)scratch;
-    uint4* itemsB = itemsA + (size_t)(nAL + nInst + 2);
-    uint32_t* nOut = (uint32_t*)(itemsB + (size_t)(nAL + nInst + 2));
-    hipLaunchKernelGGL(k_tlas4_build, dim3(1), dim3(kBuildThreads), 0, s, al, nAL, idx, nIdx, inst, nInst, blocks, capBlocks, itemsA, itemsB, nOut);
-}
 
 void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* instances, const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks,
                   hipStream_t s) {

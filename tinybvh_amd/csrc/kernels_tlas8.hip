@@ -2,7 +2,7 @@
 // configuration of the reference's instancing demo (tiny_bvh_gpu2.cpp: CWBVH BLASes under a BVH_GPU TLAS, traverse_tlas.cl:13-107).
 //
 // Same idea as kernels_tlas4.hip (which see for the measurements that motivate it): the caller's TLAS is collapsed at every upload /
-// update / device rebuild into an 8-wide compressed tree in the BVH8_CWBVH node format (cwbvh_node.h) whose leaf children stand for
+// update / device rebuild (kernels_tlaswide.hip) into an 8-wide compressed tree in the BVH8_CWBVH node format (cwbvh_node.h) whose leaf children stand for
 // ONE instance each (a "triangle" slot of the node: meta = 0b001 << 5 | slot offset, the node's triangle base indexes a list of
 // instance indices), so that a TLAS node step and a BLAS node step are the same code — cw_test_node on different base pointers — and
 // the node phase of the loop serves every lane that has a node to visit, whatever its level.  The triangle phase exists twice: a
@@ -17,8 +17,6 @@
 #include "ray_pool.h"
 #include "kernels.h"
 #include "cwbvh_node.h"
-#include "cwbvh_encode.h"
-#include "tlas_collapse.h"
 
 namespace tbvh {
 
@@ -29,94 +27,6 @@ constexpr int WG = 64;
 __device__ __forceinline__ float safercp(float x) {
     if (x > 1e-12f || x < -1e-12f) return 1.0f / x;
     return x >= 0 ? kFar : -kFar;
-}
-
-// =====================================================================================================================
-// TLAS (BVH_GPU nodes) -> 8-wide CWBVH-format TLAS; one workgroup, level by level (see kernels_tlas4.hip: k_tlas4_build)
-// items: uint4 {ref, cnt (0xffffffff = AL node), index of the wide node this item becomes, -}
-// =====================================================================================================================
-constexpr int kBuildThreads = 1024;
-__global__ __launch_bounds__(kBuildThreads) void k_tlas8_build(const float4* __restrict__ al, uint32_t nAL, const uint32_t* __restrict__ idx, uint32_t nIdx,
-                                                               const float4* __restrict__ inst, float4* __restrict__ nodes, uint32_t capNodes,
-                                                               uint32_t* __restrict__ instRef, uint32_t capRefs, uint4* __restrict__ itemsA, uint4* __restrict__ itemsB) {
-    __shared__ uint32_t sIn, sOut, sNodes, sRefs;
-    if (threadIdx.x == 0) {
-        const uint32_t rootCnt = as_u32(al[2].w);
-        itemsA[0] = rootCnt ? make_uint4(as_u32(al[3].w), rootCnt, 0u, 0u) : make_uint4(0u, 0xffffffffu, 0u, 0u);
-        sIn = 1; sOut = 0; sNodes = 1; sRefs = 0;
-    }
-    __syncthreads();
-    uint4 *in = itemsA, *out = itemsB;
-    for (uint32_t level = 0; level < 4096u; level++) {
-        const uint32_t n = sIn;
-        if (n == 0) break;
-        for (uint32_t t = threadIdx.x; t < n; t += kBuildThreads) {
-            const uint4 item = in[t];
-            Kid kid[8];
-            uint32_t nk = 0;
-            if (item.y == 0xffffffffu) { al_children(al, nAL, item.x, kid[0], kid[1]); nk = 2; }
-            else if (item.y <= 1u) { kid[0] = range_kid(idx, inst, item.x, item.y); nk = 1; }
-            else { const uint32_t h = item.y / 2u; kid[0] = range_kid(idx, inst, item.x, h); kid[1] = range_kid(idx, inst, item.x + h, item.y - h); nk = 2; }
-            while (nk < 8u) {   // open the largest child that can be opened
-                int best = -1; float bestSA = -1.f;
-                for (uint32_t i = 0; i < nk; i++) {
-                    if (kid[i].cnt <= 1u) continue;
-                    const float sa = kid_area(kid[i]);
-                    if (sa > bestSA) { bestSA = sa; best = (int)i; }
-                }
-                if (best < 0) break;
-                Kid a, b;
-                if (kid[best].cnt == 0xffffffffu) al_children(al, nAL, kid[best].ref, a, b);
-                else { const uint32_t h = kid[best].cnt / 2u; a = range_kid(idx, inst, kid[best].ref, h); b = range_kid(idx, inst, kid[best].ref + h, kid[best].cnt - h); }
-                kid[best] = a; kid[nk++] = b;
-            }
-            // drop empty kids (malformed input), then octant slots as for any CWBVH node
-            uint32_t m = 0;
-            for (uint32_t i = 0; i < nk; i++) if (kid[i].cnt != 0u) kid[m++] = kid[i];
-            nk = m;
-            float3 mn = make_float3(1e30f, 1e30f, 1e30f), mx = make_float3(-1e30f, -1e30f, -1e30f), kmn[8], kmx[8];
-            uint32_t nInner = 0, nLeaf = 0;
-            for (uint32_t i = 0; i < nk; i++) {
-                kmn[i] = kid[i].mn; kmx[i] = kid[i].mx;
-                mn = min3(mn, kmn[i]); mx = max3(mx, kmx[i]);
-                if (kid[i].cnt == 1u) nLeaf++; else nInner++;
-            }
-            int slotOf[8], childIn[8];
-            cw_assign_slots(nk, mn, mx, kmn, kmx, slotOf, childIn);
-            const uint32_t childBase = nInner ? atomicAdd(&sNodes, nInner) : 0u;
-            const uint32_t refBase = nLeaf ? atomicAdd(&sRefs, nLeaf) : 0u;
-            const uint32_t outFirst = nInner ? atomicAdd(&sOut, nInner) : 0u;
-            if (childBase + nInner > capNodes || refBase + nLeaf > capRefs || item.z >= capNodes) continue;   // cannot happen with tbvh's capacities
-            float3 cmn[8], cmx[8];
-            bool used[8];
-            uint8_t meta[8];
-            uint32_t imask = 0, inner = 0, leaves = 0;
-            for (int s = 0; s < 8; s++) {
-                used[s] = childIn[s] >= 0; meta[s] = 0;
-                if (!used[s]) continue;
-                const Kid& c = kid[childIn[s]];
-                cmn[s] = c.mn; cmx[s] = c.mx;
-                if (c.cnt == 1u) {
-                    meta[s] = (uint8_t)((1u << 5) | leaves);             // one "triangle" (= instance) at offset `leaves`
-                    instRef[refBase + leaves] = c.ref < nIdx ? idx[c.ref] : 0u;
-                    leaves++;
-                } else {
-                    imask |= 1u << s;
-                    meta[s] = (uint8_t)((1u << 5) | (24 + s));
-                    out[outFirst + inner] = make_uint4(c.ref, c.cnt, childBase + inner, 0u);
-                    inner++;
-                }
-            }
-            const uint32_t m0 = meta[0] | (meta[1] << 8) | (meta[2] << 16) | ((uint32_t)meta[3] << 24);
-            const uint32_t m1 = meta[4] | (meta[5] << 8) | (meta[6] << 16) | ((uint32_t)meta[7] << 24);
-            cw_quantize_write(nodes + (size_t)item.z * 5, mn, mx, cmn, cmx, used, imask, childBase, refBase, m0, m1);
-        }
-        __threadfence_block();
-        __syncthreads();
-        if (threadIdx.x == 0) { sIn = sOut; sOut = 0; }
-        __syncthreads();
-        uint4* tmp = in; in = out; out = tmp;
-    }
 }
 
 // =====================================================================================================================
@@ -273,17 +183,6 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 }
 
 }  // namespace
-
-// capacities: wide nodes <= AL nodes + instances + 2, instance references <= instances (+ ranges of malformed input: + AL nodes)
-uint64_t tlas8_cap_nodes(uint64_t nAL, uint64_t nInst) { return nAL + nInst + 2; }
-size_t tlas8_scratch_bytes(uint64_t nAL, uint64_t nInst) { return (size_t)(nAL + nInst + 2) * 16 * 2; }
-
-void launch_tlas8_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* nodes, uint32_t capNodes,
-                        uint32_t* instRef, uint32_t capRefs, void* scratch, hipStream_t s) {
-    uint4* itemsA = (uint4*)scratch;
-    uint4* itemsB = itemsA + (size_t)(nAL + nInst + 2);
-    hipLaunchKernelGGL(k_tlas8_build, dim3(1), dim3(kBuildThreads), 0, s, al, nAL, idx, nIdx, inst, nodes, capNodes, instRef, capRefs, itemsA, itemsB);
-}
 
 void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* instRef, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
                   uint32_t* status, uint32_t blocks, hipStream_t s) {
