@@ -329,11 +329,12 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     const uint32_t lo = (uint32_t)c->numCUs * 4u;
     uint32_t blocks = (uint32_t)(want < lo ? lo : (want > cap ? cap : want));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));   // the probe below is part of the query's time
-    // BVH8_CWBVH scenes beyond the L2s (the `small` class runs dense triangle phases, where the gated schedule loses 15 %), batches of 2 M
+    // BVH8_CWBVH scenes beyond the L2s (the `small` class runs dense triangle phases, where the gated schedule loses 15 %) but within reach
+    // of the Infinity Cache (beyond it camera rays are bound by memory too: 30 M / 60 M triangles lose 11 / 19 % under the gate), batches of 2 M
     // rays and more (the probe costs ~10 us, 3-4 % of a 1 M-ray launch): a 16-workgroup probe of the batch's coherence (4096 neighbour pairs)
     // lets the traversal kernel pick its schedule for the launch; a coherent batch also gets a third more waves (the surplus leaves at once
     // otherwise).  Bistro stand-in, 16.7 M rays: camera rays +4.5 %, shadow rays +6 %, bounce rays unchanged.
-    if (!s->isTlas && !small && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && s->variant == 0) {
+    if (!s->isTlas && !small && s->bytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && s->variant == 0) {
         uint32_t* probe = (uint32_t*)c->pool + (size_t)kPoolParts * kPoolCounterStride;
         launch_coherence_probe(d_rays, n, nDev, probe, c->stream);
         HIP_TRY(hipGetLastError());
@@ -381,7 +382,11 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         else if (s->variant >= 20 && s->variant < 30) launch_cwbvh_h(any, s->variant, s->nodesH, s->tris, q, c->status, blocks, c->stream);
         else
 #endif
-        launch_cwbvh(any, s->variant, cwbvh_variant_padded(s->variant) ? s->nodes128 : s->nodes, cwbvh_variant_tri64(s->variant) ? s->tris64 : s->tris, q, c->status, blocks, c->stream);
+        {
+            const bool autoPad = s->variant == 0 && s->nodes128 != nullptr;   // nodes beyond the Infinity Cache: the padded copy (padCwbvhIfLarge)
+            launch_cwbvh(any, s->variant, (autoPad || cwbvh_variant_padded(s->variant)) ? s->nodes128 : s->nodes, cwbvh_variant_tri64(s->variant) ? s->tris64 : s->tris, q, c->status, blocks,
+                         c->stream, autoPad);
+        }
         break;
     default:
         return fail(TBVH_E_INVALID, "scene layout %d has no query kernel", s->layout);
@@ -404,6 +409,20 @@ int checkStatus(tbvh_context* c) {
         hipMemsetAsync(c->status, 0, 4, c->stream);
         return fail(TBVH_E_FORMAT, "refit: a triangle record refers to a primitive beyond the vertex array");
     }
+    return 0;
+}
+
+// A BVH8_CWBVH scene whose node array is larger than twice the 256 MB Infinity Cache is traversed through a copy with one node per
+// 128-byte line: an 80-byte node straddles 1.6 lines on average, and once the lines come from HBM that is 17 % more traffic than the
+// 60 % larger array costs (tools/size_sweep.py, 60 M triangles: bounce rays +6 %; below that size the smaller footprint wins).
+int padCwbvhIfLarge(tbvh_scene* s) {
+    if (s->layout != TBVH_LAYOUT_CWBVH || s->isTlas || s->nodes128 || (uint64_t)s->nNodes * 80 < (512ull << 20)) return 0;
+    tbvh_context* c = s->ctx;
+    if (hipMalloc((void**)&s->nodes128, (size_t)s->nNodes * 128) != hipSuccess) { s->nodes128 = nullptr; (void)hipGetLastError(); return 0; }   // no memory to spare: the packed array serves
+    launch_cwbvh_pad(s->nodes, s->nodes128, s->nNodes, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    s->bytes += (uint64_t)s->nNodes * 128;
     return 0;
 }
 
@@ -570,6 +589,7 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "CWBVH upload failed: %s", hipGetErrorString(e)); }
     s->nNodeBlocks = nNodeBlocks; s->nTriBlocks = nTriBlocks;
     s->bytes = (nNodeBlocks + nTriBlocks) * 16;
+    if (int r = padCwbvhIfLarge(s)) { tbvh_free_scene(s); return r; }
     *out = s;
     return 0;
 }
@@ -741,6 +761,7 @@ int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t n
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH2 -> CWBVH: %s", hipGetErrorString(e)); }
     s->nNodes = nWide; s->nNodeBlocks = (uint64_t)nWide * 5; s->nTriBlocks = nWideTris * 3;
     s->bytes = (s->nNodeBlocks + s->nTriBlocks) * 16;
+    if (int r = padCwbvhIfLarge(s)) { tbvh_free_scene(s); return r; }
     *out = s;
     return 0;
 }

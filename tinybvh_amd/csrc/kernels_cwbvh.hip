@@ -179,7 +179,7 @@ __global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__
 }  // namespace
 
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
-                  uint32_t blocks, hipStream_t s) {
+                  uint32_t blocks, hipStream_t s, bool paddedNodes) {
 #define TBVH_K(...)                                                                     \
     do {                                                                                \
         if (anyhit) launch_k<true, __VA_ARGS__>(nodes, tris, q, status, blocks, s);     \
@@ -214,6 +214,11 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     }
 #endif
     // with a coherence probe of the batch (capi.hip: launchQuery) the schedule is chosen per launch; without one, the strict schedule
+    if (paddedNodes) {   // one node per cache line (capi.hip: scenes whose node array is beyond the Infinity Cache; DESIGN.md §5: -17 % bytes, +6 % at 60 M triangles)
+        if (q.probe) TBVH_K(8, 16, 8, true, false, 8, 3, false, true);
+        else TBVH_K(8, 16, 1, false, false, 8);
+        return;
+    }
     if (q.probe) TBVH_K(8, 16, 8, true, false, 5, 3, false, true);
     else TBVH_K(8, 16, 1, false);
 #undef TBVH_K
