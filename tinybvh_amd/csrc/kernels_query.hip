@@ -146,7 +146,9 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
 // sorted order.  The hit leaves of a node (at most 4) are queued in registers and their
 // triangles tested one per iteration.
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT, int NODE_REPS, bool SIGNSEL, uint32_t GOV_KEEP, bool HAS_OMM>
+// TIMELINE (experiment build): when the waves start, see the ray pool run dry and end, in 10 ns ticks of the constant
+// clock, folded into q.stats as {~min start, max start, sum start, ~min end, max end, sum end, sum dry, waves}
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT, int NODE_REPS, bool SIGNSEL, uint32_t GOV_KEEP, bool HAS_OMM, bool TIMELINE = false>
 __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const QueryArgs& q, uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
     Stack32<LDS_N> st;
@@ -154,6 +156,8 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
     RayPool<64> pool;
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
     pool.init(q.poolParts);
+    const unsigned long long tStart = TIMELINE ? wall_clock64() : 0ull;
+    unsigned long long tDry = 0ull;
 
     bool active = false;
     uint64_t ri = 0;
@@ -183,6 +187,7 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
                     active = true;
                 }
             }
+            if (TIMELINE && !tDry && pool.dry()) tDry = wall_clock64();
             if (__ballot(active) == 0) break;
         }
         if (!active) continue;
@@ -274,6 +279,12 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
         }
     }
     if (st.overflow) atomicOr(status, 1u);
+    if (TIMELINE && threadIdx.x == 0 && (blockIdx.x % 31u) == 0) {   // every 31st wave (all XCDs): 8192 waves on eight addresses would serialise for longer than the kernel runs
+        const unsigned long long tEnd = wall_clock64();
+        atomicMax(q.stats + 0, ~tStart); atomicMax(q.stats + 1, tStart); atomicAdd(q.stats + 2, tStart);
+        atomicMax(q.stats + 3, ~tEnd); atomicMax(q.stats + 4, tEnd); atomicAdd(q.stats + 5, tEnd);
+        atomicAdd(q.stats + 6, tDry ? tDry : tEnd); atomicAdd(q.stats + 7, 1ull);
+    }
 }
 
 template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, bool SIGNSEL = false, uint32_t GOV_KEEP = kLockstepKeep, bool HAS_OMM = true>
@@ -281,9 +292,9 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
     bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP, HAS_OMM>(data, q, status);
 }
 // the same with the register budget of 8 waves per SIMD (<= 64 VGPRs; left alone the compiler takes 65-68)
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, bool SIGNSEL = false, uint32_t GOV_KEEP = kLockstepKeep, bool HAS_OMM = true>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, bool SIGNSEL = false, uint32_t GOV_KEEP = kLockstepKeep, bool HAS_OMM = true, bool TIMELINE = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh4_w8(const float4* __restrict__ data, QueryArgs q, uint32_t* __restrict__ status) {
-    bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP, HAS_OMM>(data, q, status);
+    bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP, HAS_OMM, TIMELINE>(data, q, status);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -363,6 +374,7 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
     case 11: TBVH_L4W(8, true, 1, true); break;    // + governor
     case 4: TBVH_L4(8, true); break;   // adaptive (LockstepGovernor, ray_pool.h): +6 % on coherent camera rays, -2..8 % elsewhere: not the default
     case 12: TBVH_L4(8); break;        // the former default: min / max pairs per plane, compiler's register budget (65-68 VGPRs)
+    case 13: TBVH_L4W(8, false, 1, true, kLockstepKeep, false, true); break;   // the default kernel with the wave timeline (q.stats)
 #endif
     default:   // per-lane replacement throughout, sign-selected planes, 8 waves per SIMD
         if (q.omm.map) TBVH_L4W(8, false, 1, true);

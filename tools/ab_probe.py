@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--layout", type=int, default=10)
     ap.add_argument("--variants", default="0")
     ap.add_argument("--stats", default="", help="statistics variants (lane utilisation counters)")
+    ap.add_argument("--timeline", default="", help="wave timeline variants (layout 8: 13)")
     ap.add_argument("--passes", type=int, default=4)
     ap.add_argument("--out", default="")
     ap.add_argument("--device-build", action="store_true")
@@ -114,6 +115,26 @@ def main():
                   f"tri phases/iter {titer / it:.3f} at {tri / max(titer, 1) / 64:.3f} lanes ({tri / n:.2f} tri tests/ray)  "
                   f"uniform node phases (one node, one octant) {rf / max(niter, 1):.3f} of all, holding {rfd / max(node, 1):.3f} of the node visits", flush=True)
             res[f"stats{v}_{kind}"] = dict(ms=ms, iters=it, active=act, node_lanes=node, node_iters=niter, tri_iters=titer, tri_lanes=tri, refills=rf)
+    for v in [int(x) for x in a.timeline.split(",") if x]:
+        # wave timeline variants (k_bvh4 variant 13): 10 ns ticks of the constant clock
+        try:
+            sc.set_variant(v)
+        except tb.TbvhError as e:
+            print(f"timeline variant {v}: {e}", flush=True)
+            continue
+        for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
+            st = (C.c_uint64 * 8)()
+            for _ in range(3):
+                tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+                sc.intersect_device_fresh(d, n, 1e30)
+                ms = ctx.time_last_ms()
+                tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+            nmin0, max0, sum0, nmin1, max1, sum1, sumdry, cnt = [int(x) for x in st]
+            min0 = (~nmin0) & (2**64 - 1); min1 = (~nmin1) & (2**64 - 1)
+            us = lambda t: t / 100.0
+            print(f"timeline {v} [{kind}] kernel {ms * 1e3:.0f} us, {cnt} waves: starts {us(max0 - min0):.1f} us apart (mean +{us(sum0 / cnt - min0):.1f}); "
+                  f"pool dry at mean +{us(sumdry / cnt - min0):.1f} us; ends first +{us(min1 - min0):.1f}, mean +{us(sum1 / cnt - min0):.1f}, last +{us(max1 - min0):.1f} us; "
+                  f"mean wave life {us((sum1 - sum0) / cnt):.1f} us", flush=True)
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
     sc.free(); ctx.close()
