@@ -334,7 +334,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     // rays and more (the probe costs ~10 us, 3-4 % of a 1 M-ray launch): a 16-workgroup probe of the batch's coherence (4096 neighbour pairs)
     // lets the traversal kernel pick its schedule for the launch; a coherent batch also gets a third more waves (the surplus leaves at once
     // otherwise).  Bistro stand-in, 16.7 M rays: camera rays +4.5 %, shadow rays +6 %, bounce rays unchanged.
-    if (!s->isTlas && !small && s->bytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && s->variant == 0) {
+    if (!s->isTlas && !small && s->bytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || (TBVH_EXPERIMENTS && s->variant == 88))) {
         uint32_t* probe = (uint32_t*)c->pool + (size_t)kPoolParts * kPoolCounterStride;
         launch_coherence_probe(d_rays, n, nDev, probe, c->stream);
         HIP_TRY(hipGetLastError());

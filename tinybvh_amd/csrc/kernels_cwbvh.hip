@@ -25,6 +25,7 @@
 #include "ray_pool.h"
 #include "kernels.h"
 #include "cwbvh_node.h"
+#include "ray_split.h"
 
 namespace tbvh {
 
@@ -37,8 +38,8 @@ constexpr int WG = 64;
 // [6] sum of lanes in those, [7] node-phase iterations
 // TSTRIDE: float4s between consecutive triangle records (3 = the reference's packed array; 4 = padded to 64 bytes so that no
 // record straddles a 128-byte line)
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, bool STATS = false, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false, bool PROBED = false>
-__global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, int STATS = 0, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false, bool PROBED = false, int STEAL = 0>
+__global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
     const uint32_t glane = blockIdx.x * WG + threadIdx.x;
@@ -66,7 +67,12 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     bool found = false;
     uint32_t oct = 0, octinv4 = 0;
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u), tg2 = make_uint2(0u, 0u);
+    // STEAL > 0 (idle lanes needed): once the ray pool is dry, idle lanes take pending subtrees off the lanes that still traverse (ray_split.h)
+    __shared__ SplitLds<STEAL ? WG : 1> split;
+    int grp = -1;
     unsigned long long sIter = 0, sActive = 0, sNodeIter = 0, sNode = 0, sTriIter = 0, sTri = 0, sRefill = 0, sRefilled = 0;  // STATS only
+    const unsigned long long tStart = STATS >= 2 ? wall_clock64() : 0ull;   // STATS == 2: wave timeline, as in kernels_query.hip (bvh4_body)
+    unsigned long long tDry = 0ull;
 
     for (;;) {
         // ---- ray replacement -------------------------------------------------------------
@@ -86,14 +92,48 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
                     ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u); tg2 = make_uint2(0u, 0u);
                     st.reset();
                     active = true;
+                    if (STEAL) grp = -1;
                 }
             }
+            if (STATS >= 2 && !tDry && pool.dry()) tDry = wall_clock64();
             if (__ballot(active) == 0) break;
         }
-        if (STATS) { sIter++; sActive += __popcll(__ballot(active)); }
+        if (STEAL && nIdle >= (uint32_t)STEAL && pool.dry()) {
+            const uint32_t nKids = (uint32_t)__popc(ng.y >> 24);
+            SplitMatch m;
+            if (split_match(active && (!st.empty() || nKids >= 2u), !active, m)) {
+                uint2 part = make_uint2(0u, 0u);
+                if (m.gives) {
+                    // the NEAREST pending subtree — the one the donor would have entered next, so the chain of dependent steps to the closest
+                    // hit gets shorter (the farthest is mostly work a closer hit would have culled) —, or, with an empty stack, every second
+                    // pending child of the current node, front to back (the front-most is the highest bit, cw_next_child)
+                    if (!st.empty()) part = st.pop();
+                    else {
+                        uint32_t bits = ng.y >> 24, give = 0u, odd = 0u;
+                        while (bits) { const uint32_t hb = 0x80000000u >> __clz(bits); give |= hb & (0u - odd); odd ^= 1u; bits ^= hb; }
+                        part = make_uint2(ng.x, (give << 24) | (ng.y & 0x00FFFFFFu));
+                        ng.y &= ~(give << 24);
+                    }
+                    split_give<ANYHIT>(split, m, grp, found, hit);
+                }
+                const int src = split_take_ray(split, m, O, D, rD, hit, ri, grp);
+                part.x = __shfl(part.x, src); part.y = __shfl(part.y, src);
+                if (STATS == 5) sRefill += __popcll(__ballot(m.takes));
+                if (m.takes) {
+                    found = false;
+                    oct = cw_oct(D); octinv4 = oct * 0x01010101u;
+                    ng = part; tg = make_uint2(0u, 0u); tg2 = make_uint2(0u, 0u);
+                    st.reset();
+                    active = true;
+                }
+            }
+        }
+        if (STATS == 1) { sIter++; sActive += __popcll(__ballot(active)); }
+        if (STATS == 5 && pool.dry()) { sIter++; sActive += __popcll(__ballot(active)); }   // the wave's tail: passes after the pool ran dry, lanes still busy in them
         if (!active) continue;
 
         bool done = false;
+        if (STEAL && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
         // ---- triangle phase: runs when enough lanes have a triangle pending, or when no lane could use a node
         // phase instead (so a waiting lane always makes progress) --------------------------------------------
         // COH_ONLY: deferral and the gate apply only while the wave runs in lockstep (coherent rays: VALU-bound, the gate
@@ -106,8 +146,8 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
             const bool canNode = spec ? (tg2.y == 0 && (cw_has_child(ng) || !st.empty())) : tg.y == 0;
             triPhase = nPend >= (uint32_t)TRI_MIN || __ballot(canNode) == 0;
         }
-        if (triPhase && tg.y != 0) {
-            if (STATS) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sTriIter++; sTri += __popcll(m); } }
+        if (triPhase && tg.y != 0 && !(STEAL && ANYHIT && done)) {
+            if (STATS == 1) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sTriIter++; sTri += __popcll(m); } }
             const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
             tg.y &= ~(1u << ti);
             const uint32_t ta = TSTRIDE == 3 ? tg.x + ti * 3u : (__umulhi(tg.x, 0xAAAAAAABu) >> 1) * 4u + ti * 4u;   // tg.x counts float4s of the packed array
@@ -117,6 +157,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
+                if (STEAL && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
             }
             if ((SPEC || PROBED) && tg.y == 0) { tg = tg2; tg2 = make_uint2(0u, 0u); }
         }
@@ -129,7 +170,7 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
             }
             if (have) {
                 const uint32_t ci = cw_next_child(ng, oct);
-                if (STATS) {
+                if (STATS == 1) {
                     const unsigned long long m = __ballot(true);
                     const bool uni = __ballot(ci != (uint32_t)__builtin_amdgcn_readfirstlane(ci) || oct != (uint32_t)__builtin_amdgcn_readfirstlane(oct)) == 0;
                     if (lane_rank(m) == 0) { sNodeIter++; sNode += __popcll(m); if (uni) { sRefill++; sRefilled += __popcll(m); } }   // [5], [6]: uniform node phases, lanes in them
@@ -143,13 +184,29 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
             }
         }
         if (done) {
-            if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+            if (STEAL && grp >= 0) split_finish<ANYHIT>(split, grp, q, ri);
+            else if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
             else if (found || q.fresh) q.rays[ri].hit = hit;
             active = false;
         }
     }
     if (st.overflow) atomicOr(status, 1u);
-    if (STATS) {
+    if (STATS == 2 && threadIdx.x == 0 && (blockIdx.x % 31u) == 0) {
+        const unsigned long long tEnd = wall_clock64();
+        atomicMax(q.stats + 0, ~tStart); atomicMax(q.stats + 1, tStart); atomicAdd(q.stats + 2, tStart);
+        atomicMax(q.stats + 3, ~tEnd); atomicMax(q.stats + 4, tEnd); atomicAdd(q.stats + 5, tEnd);
+        atomicAdd(q.stats + 6, tDry ? tDry : tEnd); atomicAdd(q.stats + 7, 1ull);
+    }
+    if (STATS == 5 && threadIdx.x == 0) {   // [0] the longest tail: passes << 32 | busy lane-passes, [1] passes, [2] busy lane-passes, [3] waves, [4] subtrees taken over
+        atomicMax(q.stats + 0, (sIter << 32) | (sActive & 0xFFFFFFFFull)); atomicAdd(q.stats + 1, sIter); atomicAdd(q.stats + 2, sActive);
+        atomicAdd(q.stats + 3, 1ull); atomicAdd(q.stats + 4, sRefill);
+    }
+    if ((STATS == 3 || STATS == 4) && threadIdx.x == 0 && (blockIdx.x & 3u) == 1u) {   // histograms over every 4th wave, 64 us bins: 3 = wave ends, 4 = pool dry
+        const unsigned long long t = (STATS == 3 ? wall_clock64() : (tDry ? tDry : wall_clock64())) - tStart;
+        const unsigned long long b = t / 6400ull;
+        atomicAdd(q.stats + (b < 7ull ? b : 7ull), 1ull);
+    }
+    if (STATS == 1) {
         // the per-phase counters were kept by the first lane of each phase: reduce over the wave
         for (int o = 32; o > 0; o >>= 1) {
             sTriIter += __shfl_xor(sTriIter, o); sTri += __shfl_xor(sTri, o); sNodeIter += __shfl_xor(sNodeIter, o); sNode += __shfl_xor(sNode, o);
@@ -162,11 +219,11 @@ __global__ __launch_bounds__(WG) void k_cwbvh(const float4* __restrict__ nodes, 
     }
 }
 
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool STATS = false, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false, bool PROBED = false>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, int STATS = 0, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false, bool PROBED = false, int STEAL = 0>
 void launch_k(const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
     // without opacity micromaps on the scene the check is compiled out (+1-2 %)
-    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE, TSTRIDE, COH_ONLY, PROBED>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
-    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE, TSTRIDE, COH_ONLY, PROBED>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE, TSTRIDE, COH_ONLY, PROBED, STEAL>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE, TSTRIDE, COH_ONLY, PROBED, STEAL>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
 }
 
 __global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__ dst, uint32_t nNodes) {
@@ -210,16 +267,33 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     case 70: TBVH_K(8, 16, 12, true, false, 5, 3, true); return;
     case 71: TBVH_K(8, 16, 1, true, false, 5, 3, true); return;   // deferred (no gate) while in lockstep
     case 72: TBVH_K(8, 16, 1, false); return;                     // the strict schedule throughout, whatever the probe says
+    case 73: launch_k<false, 8, 16, 1, false, 2>(nodes, tris, q, status, blocks, s); return;       // wave timeline of the strict schedule (q.stats)
+    case 74: TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 32); return;   // strict schedule + stack stealing once the pool is dry and 32 lanes idle
+    case 75: TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 16); return;
+    case 76: TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 8); return;
+    case 77: TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 48); return;
+    case 78: launch_k<false, 8, 16, 1, false, 2, 5, 3, false, false, 32>(nodes, tris, q, status, blocks, s); return;   // timeline of 74
+    case 79: launch_k<false, 8, 16, 1, false, 3>(nodes, tris, q, status, blocks, s); return;       // histogram of wave ends, strict schedule
+    case 80: launch_k<false, 8, 16, 1, false, 4>(nodes, tris, q, status, blocks, s); return;       // histogram of pool-dry times
+    case 88: if (q.probe) TBVH_K(8, 16, 8, true, 0, 5, 3, false, true, 16); else TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 16); return;   // the probed schedule + stealing
+    case 82: launch_k<false, 8, 16, 1, false, 5>(nodes, tris, q, status, blocks, s); return;       // tail statistics, strict schedule
+    case 83: launch_k<false, 8, 16, 1, false, 5, 5, 3, false, false, 16>(nodes, tris, q, status, blocks, s); return;   // tail statistics with stealing
+    case 81: launch_k<false, 8, 16, 1, false, 3, 5, 3, false, false, 16>(nodes, tris, q, status, blocks, s); return;   // wave ends with stealing
     default: launch_cwbvh_exp(anyhit, variant, nodes, tris, q, status, blocks, s); return;
     }
 #endif
-    // with a coherence probe of the batch (capi.hip: launchQuery) the schedule is chosen per launch; without one, the strict schedule
+    // with a coherence probe of the batch (capi.hip: launchQuery) the schedule is chosen per launch; without one, the strict schedule.
+    // Batches below 12 M rays (and the wavefront stages, whose ray count only the device knows) also split their last rays over idle
+    // lanes (ray_split.h): Bistro stand-in 0.26 / 1 / 4 / 8 M rays: camera +7 / +20 / +6 / +4 %, bounce +26 / +23 / +8 / +4 %, shadow
+    // +20 / +18 / +6 / +4 %; at 16.7 M rays the tail is 5 % of the launch and the kernel's register cap costs as much as it gains
+    const bool tail = q.nRaysDev != nullptr || q.nRays < (12ull << 20);
     if (paddedNodes) {   // one node per cache line (capi.hip: scenes whose node array is beyond the Infinity Cache; DESIGN.md §5: -17 % bytes, +6 % at 60 M triangles)
-        if (q.probe) TBVH_K(8, 16, 8, true, false, 8, 3, false, true);
-        else TBVH_K(8, 16, 1, false, false, 8);
-        return;
-    }
-    if (q.probe) TBVH_K(8, 16, 8, true, false, 5, 3, false, true);
+        if (tail) TBVH_K(8, 16, 1, false, 0, 8, 3, false, false, 16);
+        else TBVH_K(8, 16, 1, false, 0, 8);
+    } else if (q.probe) {
+        if (tail) TBVH_K(8, 16, 8, true, 0, 5, 3, false, true, 16);
+        else TBVH_K(8, 16, 8, true, 0, 5, 3, false, true);
+    } else if (tail) TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 16);
     else TBVH_K(8, 16, 1, false);
 #undef TBVH_K
 }
@@ -247,7 +321,7 @@ bool cwbvh_variant_tri64(int v) { return TBVH_EXPERIMENTS && v >= 64 && v <= 67;
 
 bool cwbvh_variant_valid(int v) {
 #if TBVH_EXPERIMENTS
-    return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43) || (v >= 50 && v <= 72);
+    return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43) || (v >= 50 && v <= 88 && v != 84 && v != 85 && v != 86 && v != 87);
 #else
     return v == 0;
 #endif

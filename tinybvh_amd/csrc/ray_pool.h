@@ -9,11 +9,10 @@
 // whole GPU at about 80 M chunk fetches per second (measured on MI355X: same-address device-scope
 // atomics are serialised memory-side at ~12 ns each; with 64-ray chunks that is a hard 5.1 GRays/s
 // ceiling, reached on the Sponza stand-in).  The chunks of a batch are therefore dealt round-robin
-// to 2^partsLog2 STRIPES, each with its own counter on its own 256-byte line: stripe p owns chunks
-// p, p + P, p + 2P, ...  A wave draws from stripe blockIdx % P for its whole life.  Every stripe
-// is a uniform sample of the batch, so the stripes run dry within about one chunk of each other
-// and no stealing is needed; the batch is still consumed as ONE front (good for the L2s), and
-// consecutive chunks go to different XCDs just as consecutive workgroups of a plain launch would.
+// to 2^partsLog2 STRIPES, each with its own counter on its own 256-byte line: a stripe owns
+// one chunk of every row of P chunks (acquire).  A wave draws from stripe blockIdx % P for its whole
+// life.  The batch is still consumed as ONE front (good for the L2s), and consecutive chunks go to
+// different XCDs just as consecutive workgroups of a plain launch would.
 #pragma once
 #include "device_common.h"
 
@@ -64,7 +63,7 @@ typedef LockstepGovernorT<> LockstepGovernor;
 template <int CHUNK> struct RayPool {
     static_assert(CHUNK % 64 == 0, "chunks are whole 64-ray groups");
     uint64_t next, end;   // wave-uniform: rays in hand
-    uint32_t stripe;      // wave-uniform: this wave's stripe
+    uint32_t stripe;      // wave-uniform: the stripe this wave draws from
     uint32_t partsLog2;   // the batch's chunks are dealt to 2^partsLog2 stripes
     bool exhausted;       // wave-uniform: the stripe ran past the end of the batch
 
@@ -77,6 +76,10 @@ template <int CHUNK> struct RayPool {
     // Hands out ray indices to the lanes whose `idle` is set.  Returns true for lanes that
     // received one (in `ri`).  Must be called by the whole wave (convergent).
     // counters: one 32-bit count per stripe (rays of that stripe already handed out), kPoolCounterStride apart.
+    // The stripe's k-th chunk is chunk k * P + (stripe + 5 k) mod P of the batch: with a fixed position in every row of P chunks a
+    // stripe would be a set of pixel columns for rays in image order, and columns are not equally expensive (the waves of the cheapest
+    // stripe left 130 us into a 1 M-ray launch whose last stripe ran dry at 380 us); rotating the position makes every stripe a sample
+    // of all columns.
     __device__ __forceinline__ bool acquire(bool idle, uint32_t* counters, uint64_t nRays, uint64_t& ri) {
         const uint64_t idleMask = __ballot(idle);
         uint32_t need = (uint32_t)__popcll(idleMask);
@@ -89,10 +92,11 @@ template <int CHUNK> struct RayPool {
                 uint32_t base = 0;
                 if ((threadIdx.x & 63u) == 0)  // the whole wave is here (convergent call)
                     base = atomicAdd(counters + (size_t)stripe * kPoolCounterStride, (uint32_t)CHUNK);
-                // the stripe's k-th chunk is chunk k * P + stripe of the batch
-                next = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(base) << partsLog2) + (uint64_t)stripe * CHUNK;
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane(base) / (uint32_t)CHUNK;
+                const uint32_t pos = (stripe + 5u * k) & ((1u << partsLog2) - 1u);
+                next = (((uint64_t)k << partsLog2) + pos) * (uint64_t)CHUNK;
                 end = next + CHUNK;
-                if (end >= nRays) { end = nRays; exhausted = true; }
+                if (end >= nRays) { end = nRays; exhausted = true; }   // the later rows lie beyond the batch altogether
                 if (next >= nRays) { next = end = 0; exhausted = true; break; }
             }
             const uint32_t avail = (uint32_t)(end - next);

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--layout", type=int, default=10)
     ap.add_argument("--variants", default="0")
     ap.add_argument("--stats", default="", help="statistics variants (lane utilisation counters)")
+    ap.add_argument("--hist", default="", help="histogram variants (layout 10: 79 wave ends, 80 pool dry, 81 wave ends with stealing)")
     ap.add_argument("--timeline", default="", help="wave timeline variants (layout 8: 13)")
     ap.add_argument("--passes", type=int, default=4)
     ap.add_argument("--out", default="")
@@ -135,6 +136,25 @@ def main():
             print(f"timeline {v} [{kind}] kernel {ms * 1e3:.0f} us, {cnt} waves: starts {us(max0 - min0):.1f} us apart (mean +{us(sum0 / cnt - min0):.1f}); "
                   f"pool dry at mean +{us(sumdry / cnt - min0):.1f} us; ends first +{us(min1 - min0):.1f}, mean +{us(sum1 / cnt - min0):.1f}, last +{us(max1 - min0):.1f} us; "
                   f"mean wave life {us((sum1 - sum0) / cnt):.1f} us", flush=True)
+    for v in [int(x) for x in a.hist.split(",") if x]:
+        try:
+            sc.set_variant(v)
+        except tb.TbvhError as e:
+            print(f"histogram variant {v}: {e}", flush=True)
+            continue
+        for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
+            st = (C.c_uint64 * 8)()
+            for _ in range(2):
+                tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+                sc.intersect_device_fresh(d, n, 1e30)
+                ms = ctx.time_last_ms()
+                tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+            if v in (82, 83, 86):
+                mx, it, act, waves, steals = [int(x) for x in st][:5]
+                print(f"tail {v} [{kind}] kernel {ms * 1e3:.0f} us: after the pool ran dry the waves ran {it / max(waves, 1):.0f} passes on average with {act / max(it, 1):.1f} lanes busy; "
+                      f"the longest tail ran {mx >> 32} passes with {(mx & 0xFFFFFFFF) / max(mx >> 32, 1):.1f} lanes busy; subtrees taken over: {steals}", flush=True)
+                continue
+            print(f"histogram {v} [{kind}] kernel {ms * 1e3:.0f} us; waves per 64 us bin (last = 448 us and later): {[int(x) for x in st]}", flush=True)
     if a.out:
         json.dump(res, open(a.out, "w"), indent=1)
     sc.free(); ctx.close()
