@@ -1,0 +1,86 @@
+"""Split rays (tinybvh_amd/csrc/ray_split.h): once the ray pool of a launch is dry, idle lanes take pending subtrees off
+the lanes that are still traversing.  Batches of fewer rays than the launch has lanes are all tail: every ray is split
+as far as its traversal branches, so these are the cases where a wrong merge of the members' results would show.
+The records must be the oracle's (reference: BVH::Intersect / IsOccluded, tiny_bvh.h:3222-3304, 3382-3453)."""
+import numpy as np
+import pytest
+
+import tinybvh_amd as tb
+from tinybvh_amd import rays as R
+from tinybvh_amd import scenes
+from oracle_lib import compare_hits
+
+LAYOUTS = [tb.BVH_GPU, tb.BVH4_GPU, tb.BVH8_CWBVH]
+
+
+def _check(got, want, what):
+    c = compare_hits(got, want)
+    assert c["hits"] > 100 and c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, (what, c)
+    assert c["tie"] <= max(4, c["hits"] // 1500) and c["onsurf"] <= max(4, c["n"] // 5000), (what, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", LAYOUTS)
+@pytest.mark.parametrize("n", [64, 1000, 40_000])
+def test_batches_that_are_all_tail_match_the_oracle(ctx, oracle, cls, n):
+    verts = scenes.soup(30_000, seed=11)
+    sc = cls(ctx).Build(verts)
+    h = sc.host
+    # long rays through the whole soup (many nodes each) and short ones from inside it
+    rays = R.random_rays(n, (0, 0, 0), (10, 10, 10), seed=n)
+    want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
+    for rep in range(3):   # which lanes help which ray depends on timing: the records must not
+        got = sc.Intersect(rays.copy())
+        if n >= 1000:
+            _check(got, want, (cls.__name__, n, rep))
+        else:
+            c = compare_hits(got, want)
+            assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
+        occ = sc.IsOccluded(rays.copy())
+        assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+    sc.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", LAYOUTS)
+def test_a_closer_hit_already_in_the_record_survives_a_split_ray(ctx, oracle, cls):
+    """Intersect only ever shortens hit.t (tiny_bvh.h:8515-8530): rays that arrive with a hit closer than anything in the
+    scene keep their record bit for bit, rays that arrive with a farther one get the scene's — also when the ray was split."""
+    verts = scenes.soup(30_000, seed=12)
+    sc = cls(ctx).Build(verts)
+    h = sc.host
+    rays = R.random_rays(3000, (0, 0, 0), (10, 10, 10), seed=5)
+    want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
+    pre = rays.copy()
+    pre["t"][::2] = 1e-4; pre["u"][::2] = 0.25; pre["v"][::2] = 0.5; pre["prim"][::2] = 123456   # closer than any triangle
+    pre["t"][1::2] = 1e29                                                                          # farther than all of them
+    got = sc.Intersect(pre.copy())
+    for f in ("t", "u", "v", "prim"):
+        assert np.array_equal(got[f][::2].view(np.uint32), pre[f][::2].view(np.uint32)), f
+    odd_want = want[1::2].copy()
+    miss = odd_want["t"] >= 1e29
+    odd_want["t"][miss] = 1e29
+    c = compare_hits(got[1::2][~miss], odd_want[~miss])
+    assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
+    assert np.all(got["t"][1::2][miss] == np.float32(1e29))
+    sc.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls,plain", [(tb.BVH_GPU, 12), (tb.BVH4_GPU, 14), (tb.BVH8_CWBVH, 72)])
+def test_split_and_unsplit_kernels_agree_up_to_ties(ctx, cls, plain):
+    """Experiment builds: the same kernel without split rays returns the same records, except among hits at (nearly) equal t."""
+    verts, _ = scenes.get("sponza")
+    sc = cls(ctx).Build(verts)
+    try:
+        sc.set_variant(plain)
+    except tb.TbvhError:
+        pytest.skip("experiment build only")
+    cam = R.primary(R.camera(*scenes.SPONZA_CAMERAS[0], 512, 512, 1, 1))
+    base = sc.Intersect(cam.copy())
+    sc.set_variant(0)
+    got = sc.Intersect(cam.copy())
+    c = compare_hits(got, base)
+    assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
+    assert c["tie"] <= max(4, c["hits"] // 1500), c
+    sc.free()

@@ -343,7 +343,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     }
     if (s->isTlas) {
         const int tv = s->variant ? s->variant : c->tlasVariant;
-        if (s->tlas4 && s->blasLayout == TBVH_LAYOUT_BVH4_GPU && (tv == 0 || (tv >= 21 && tv <= 31))) {   // BVH4_GPU BLASes: the unified 4-wide kernel
+        if (s->tlas4 && s->blasLayout == TBVH_LAYOUT_BVH4_GPU && (tv == 0 || (tv >= 21 && tv <= 36))) {   // BVH4_GPU BLASes: the unified 4-wide kernel
             q.spillStride = c->spillEntries;   // 32-bit stack entries
             launch_tlas4(any, tv, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
             HIP_TRY(hipGetLastError());
@@ -351,7 +351,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             c->timed = true;
             return 0;
         }
-        if (s->tlas8 && s->blasLayout == TBVH_LAYOUT_CWBVH && (tv == 0 || (tv >= 21 && tv <= 31))) {   // BVH8_CWBVH BLASes: the unified 8-wide kernel
+        if (s->tlas8 && s->blasLayout == TBVH_LAYOUT_CWBVH && (tv == 0 || (tv >= 21 && tv <= 36))) {   // BVH8_CWBVH BLASes: the unified 8-wide kernel
             q.spillStride = c->spillEntries / 2;   // 8-byte stack entries
             launch_tlas8(any, tv, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
             HIP_TRY(hipGetLastError());

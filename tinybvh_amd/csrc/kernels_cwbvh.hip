@@ -275,7 +275,8 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     case 78: launch_k<false, 8, 16, 1, false, 2, 5, 3, false, false, 32>(nodes, tris, q, status, blocks, s); return;   // timeline of 74
     case 79: launch_k<false, 8, 16, 1, false, 3>(nodes, tris, q, status, blocks, s); return;       // histogram of wave ends, strict schedule
     case 80: launch_k<false, 8, 16, 1, false, 4>(nodes, tris, q, status, blocks, s); return;       // histogram of pool-dry times
-    case 88: if (q.probe) TBVH_K(8, 16, 8, true, 0, 5, 3, false, true, 16); else TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 16); return;   // the probed schedule + stealing
+    case 89: TBVH_K(6, 16, 1, false, 0, 5, 3, false, false, 16); return;   // 75 with 6 stack entries in LDS (32 waves per CU fit)
+    case 88: if (q.probe) TBVH_K(6, 16, 8, true, 0, 5, 3, false, true, 16); else TBVH_K(6, 16, 1, false, 0, 5, 3, false, false, 16); return;   // the probed schedule + stealing, whatever the batch size
     case 82: launch_k<false, 8, 16, 1, false, 5>(nodes, tris, q, status, blocks, s); return;       // tail statistics, strict schedule
     case 83: launch_k<false, 8, 16, 1, false, 5, 5, 3, false, false, 16>(nodes, tris, q, status, blocks, s); return;   // tail statistics with stealing
     case 81: launch_k<false, 8, 16, 1, false, 3, 5, 3, false, false, 16>(nodes, tris, q, status, blocks, s); return;   // wave ends with stealing
@@ -288,12 +289,12 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     // +20 / +18 / +6 / +4 %; at 16.7 M rays the tail is 5 % of the launch and the kernel's register cap costs as much as it gains
     const bool tail = q.nRaysDev != nullptr || q.nRays < (12ull << 20);
     if (paddedNodes) {   // one node per cache line (capi.hip: scenes whose node array is beyond the Infinity Cache; DESIGN.md §5: -17 % bytes, +6 % at 60 M triangles)
-        if (tail) TBVH_K(8, 16, 1, false, 0, 8, 3, false, false, 16);
+        if (tail) TBVH_K(6, 16, 1, false, 0, 8, 3, false, false, 16);   // (6 stack entries in LDS: with the split groups next to them 32 waves per CU still fit; 6 or 8 measure the same)
         else TBVH_K(8, 16, 1, false, 0, 8);
     } else if (q.probe) {
-        if (tail) TBVH_K(8, 16, 8, true, 0, 5, 3, false, true, 16);
+        if (tail) TBVH_K(6, 16, 8, true, 0, 5, 3, false, true, 16);
         else TBVH_K(8, 16, 8, true, 0, 5, 3, false, true);
-    } else if (tail) TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 16);
+    } else if (tail) TBVH_K(6, 16, 1, false, 0, 5, 3, false, false, 16);
     else TBVH_K(8, 16, 1, false);
 #undef TBVH_K
 }
@@ -321,7 +322,7 @@ bool cwbvh_variant_tri64(int v) { return TBVH_EXPERIMENTS && v >= 64 && v <= 67;
 
 bool cwbvh_variant_valid(int v) {
 #if TBVH_EXPERIMENTS
-    return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43) || (v >= 50 && v <= 88 && v != 84 && v != 85 && v != 86 && v != 87);
+    return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43) || (v >= 50 && v <= 89 && v != 84 && v != 85 && v != 86 && v != 87);
 #else
     return v == 0;
 #endif

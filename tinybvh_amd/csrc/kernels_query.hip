@@ -19,6 +19,7 @@
 #include "device_common.h"
 #include "lane_stack.h"
 #include "ray_pool.h"
+#include "ray_split.h"
 #include "kernels.h"
 
 namespace tbvh {
@@ -38,7 +39,9 @@ template <int LDS_N> using Stack32 = LaneStack<uint32_t, LDS_N, WG>;
 // tris: 3 x float4 per primIdx entry {v0.xyz|prim, e1, e2}, gathered at upload so a leaf
 // reads one contiguous run instead of primIdx -> verts (two dependent gathers).
 // ---------------------------------------------------------------------------------------
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, uint32_t GOV_KEEP = kLockstepKeep, bool HAS_OMM = true>
+// STEAL > 0 (idle lanes needed): once the ray pool is dry, idle lanes take the nearest pending subtree (the top of the stack) off a lane
+// that is still traversing (ray_split.h)
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, uint32_t GOV_KEEP = kLockstepKeep, bool HAS_OMM = true, int STEAL = 0>
 __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, const float4* __restrict__ tris, QueryArgs q,
                                              uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
@@ -54,6 +57,8 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
     float4 hit = make_float4(0, 0, 0, 0);
     bool found = false;
     uint32_t node = 0, triLeft = 0, triPtr = 0;   // triLeft > 0: a leaf's triangles are pending
+    __shared__ SplitLds<STEAL ? WG : 1> split;
+    int grp = -1;
 
     LockstepGovernorT<GOV_KEEP, GOV_KEEP - 5u> gov;   // ADAPT only
     gov.init();
@@ -70,17 +75,33 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
                     ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z);
                     found = false; node = 0; triLeft = 0; st.sp = 0;
                     active = true;
+                    if (STEAL) grp = -1;
                 }
             }
             if (__ballot(active) == 0) break;
         }
+        if (STEAL && nIdle >= (uint32_t)STEAL && pool.dry()) {
+            SplitMatch m;
+            if (split_match(active && st.sp != 0, !active, m)) {
+                uint32_t part = 0;
+                if (m.gives) { part = st.pop(); split_give<ANYHIT>(split, m, grp, found, hit); }
+                const int src = split_take_ray(split, m, O, D, rD, hit, ri, grp);
+                part = __shfl(part, src);
+                if (m.takes) {
+                    ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z);
+                    found = false; node = part; triLeft = 0; st.sp = 0;
+                    active = true;
+                }
+            }
+        }
         if (!active) continue;
 
         bool done = false;
+        if (STEAL && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
         // ---- triangle phase -------------------------------------------------------------------
         const uint32_t nPend = (uint32_t)__popcll(__ballot(triLeft != 0));
         const bool triPhase = nPend >= (uint32_t)TRI_MIN || nPend == (uint32_t)__popcll(__ballot(true));
-        if (triPhase && triLeft != 0) {
+        if (triPhase && triLeft != 0 && !done) {
             const float4 v0 = tris[triPtr], e1 = tris[triPtr + 1], e2 = tris[triPtr + 2];
             triPtr += 3; triLeft--;
             TriHit h;
@@ -88,6 +109,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
+                if (STEAL && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
             }
             if (!done && triLeft == 0) {  // leaf finished: continue with the stack
                 if (st.sp == 0) done = true;
@@ -131,7 +153,8 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
             }
         }
         if (done) {
-            if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+            if (STEAL && grp >= 0) split_finish<ANYHIT>(split, grp, q, ri);
+            else if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
             else if (found || q.fresh) q.rays[ri].hit = hit;
             active = false;
         }
@@ -148,7 +171,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
 // ---------------------------------------------------------------------------------------
 // TIMELINE (experiment build): when the waves start, see the ray pool run dry and end, in 10 ns ticks of the constant
 // clock, folded into q.stats as {~min start, max start, sum start, ~min end, max end, sum end, sum dry, waves}
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT, int NODE_REPS, bool SIGNSEL, uint32_t GOV_KEEP, bool HAS_OMM, bool TIMELINE = false>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT, int NODE_REPS, bool SIGNSEL, uint32_t GOV_KEEP, bool HAS_OMM, bool TIMELINE = false, int STEAL = 0>
 __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const QueryArgs& q, uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
     Stack32<LDS_N> st;
@@ -170,6 +193,8 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
     // format's count is 15 bits): slots 0, 1 in leafCnt (slot 0 low), slots 2, 3 in leafCntB.
     // The queue is kept compacted towards slot 0, so leafCnt == 0 means no leaf is pending.
     uint32_t leafQ0 = 0, leafQ1 = 0, leafQ2 = 0, leafQ3 = 0, leafCnt = 0, leafCntB = 0;
+    __shared__ SplitLds<STEAL ? WG : 1> split;   // STEAL as in k_bvh2
+    int grp = -1;
 
     LockstepGovernorT<GOV_KEEP, GOV_KEEP - 5u> gov;   // ADAPT only
     gov.init();
@@ -185,17 +210,32 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
                     hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
                     found = false; offset = 0; leafCnt = 0; leafCntB = 0; st.sp = 0;
                     active = true;
+                    if (STEAL) grp = -1;
                 }
             }
             if (TIMELINE && !tDry && pool.dry()) tDry = wall_clock64();
             if (__ballot(active) == 0) break;
         }
+        if (STEAL && nIdle >= (uint32_t)STEAL && pool.dry()) {
+            SplitMatch m;
+            if (split_match(active && st.sp != 0, !active, m)) {
+                uint32_t part = 0;
+                if (m.gives) { part = st.pop(); split_give<ANYHIT>(split, m, grp, found, hit); }
+                const int src = split_take_ray(split, m, O, D, rD, hit, ri, grp);
+                part = __shfl(part, src);
+                if (m.takes) {
+                    found = false; offset = part; leafCnt = 0; leafCntB = 0; st.sp = 0;
+                    active = true;
+                }
+            }
+        }
         if (!active) continue;
 
         bool done = false;
+        if (STEAL && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
         const uint32_t nPend = (uint32_t)__popcll(__ballot(leafCnt != 0));
         const bool triPhase = nPend >= (uint32_t)TRI_MIN || nPend == (uint32_t)__popcll(__ballot(true));
-        if (triPhase && leafCnt != 0) {
+        if (triPhase && leafCnt != 0 && !done) {
             const uint32_t ta = leafQ0;
             const float4 v0 = data[ta], e1 = data[ta + 1], e2 = data[ta + 2];
             leafQ0 += 3u; leafCnt -= 1u;                      // next triangle, one fewer left in slot 0
@@ -208,6 +248,7 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
+                if (STEAL && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
             }
             if (!done && leafCnt == 0) {
                 if (st.sp == 0) done = true;
@@ -273,7 +314,8 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
             }
         }
         if (done) {
-            if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+            if (STEAL && grp >= 0) split_finish<ANYHIT>(split, grp, q, ri);
+            else if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
             else if (found || q.fresh) q.rays[ri].hit = hit;
             active = false;
         }
@@ -292,9 +334,9 @@ __global__ __launch_bounds__(WG) void k_bvh4(const float4* __restrict__ data, Qu
     bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP, HAS_OMM>(data, q, status);
 }
 // the same with the register budget of 8 waves per SIMD (<= 64 VGPRs; left alone the compiler takes 65-68)
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, bool SIGNSEL = false, uint32_t GOV_KEEP = kLockstepKeep, bool HAS_OMM = true, bool TIMELINE = false>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool ADAPT = false, int NODE_REPS = 1, bool SIGNSEL = false, uint32_t GOV_KEEP = kLockstepKeep, bool HAS_OMM = true, bool TIMELINE = false, int STEAL = 0>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_bvh4_w8(const float4* __restrict__ data, QueryArgs q, uint32_t* __restrict__ status) {
-    bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP, HAS_OMM, TIMELINE>(data, q, status);
+    bvh4_body<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, ADAPT, NODE_REPS, SIGNSEL, GOV_KEEP, HAS_OMM, TIMELINE, STEAL>(data, q, status);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -341,9 +383,17 @@ void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tr
     case 10: TBVH_L2(16, true, 3, 218); break;
     case 11: TBVH_L2(16, true, 3, 230); break;
     case 8: TBVH_L2(16, false, 3); break;      // per-lane replacement throughout, three node visits per iteration (+5..14 % over one)
+    case 12: TBVH_L2(16, true, 3, kLockstepKeep, false); break;           // the default kernel without split rays
+    case 13: TBVH_L2(16, true, 3, kLockstepKeep, false, 16); break;       // ... with, whatever the batch size
+    case 14: TBVH_L2(16, true, 3, kLockstepKeep, false, 32); break;
+    case 15: TBVH_L2(16, true, 3, kLockstepKeep, false, 8); break;
 #endif
     default:   // + the lockstep governor (ray_pool.h): Sponza camera rays +9 %, shadow +6 %; small incoherent batches -3..5 %
-        if (q.omm.map) TBVH_L2(16, true, 3);
+        // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
+        if (q.nRaysDev != nullptr || q.nRays < (12ull << 20)) {
+            if (q.omm.map) TBVH_L2(16, true, 3, kLockstepKeep, true, 16);
+            else TBVH_L2(16, true, 3, kLockstepKeep, false, 16);
+        } else if (q.omm.map) TBVH_L2(16, true, 3);
         else TBVH_L2(16, true, 3, kLockstepKeep, false);   // no opacity micromaps: the check is compiled out
         break;
     }
@@ -375,9 +425,15 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
     case 4: TBVH_L4(8, true); break;   // adaptive (LockstepGovernor, ray_pool.h): +6 % on coherent camera rays, -2..8 % elsewhere: not the default
     case 12: TBVH_L4(8); break;        // the former default: min / max pairs per plane, compiler's register budget (65-68 VGPRs)
     case 13: TBVH_L4W(8, false, 1, true, kLockstepKeep, false, true); break;   // the default kernel with the wave timeline (q.stats)
+    case 14: TBVH_L4W(8, false, 1, true, kLockstepKeep, false); break;            // the default kernel without split rays
+    case 15: TBVH_L4W(8, false, 1, true, kLockstepKeep, false, false, 16); break; // ... with, whatever the batch size
+    case 16: TBVH_L4W(8, false, 1, true, kLockstepKeep, false, false, 32); break;
 #endif
     default:   // per-lane replacement throughout, sign-selected planes, 8 waves per SIMD
-        if (q.omm.map) TBVH_L4W(8, false, 1, true);
+        if (q.nRaysDev != nullptr || q.nRays < (12ull << 20)) {   // split rays, as in launch_bvh2
+            if (q.omm.map) TBVH_L4W(8, false, 1, true, kLockstepKeep, true, false, 16);
+            else TBVH_L4W(8, false, 1, true, kLockstepKeep, false, false, 16);
+        } else if (q.omm.map) TBVH_L4W(8, false, 1, true);
         else TBVH_L4W(8, false, 1, true, kLockstepKeep, false);   // no opacity micromaps: the check is compiled out
         break;
     }

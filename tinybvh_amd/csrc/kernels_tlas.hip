@@ -714,6 +714,6 @@ void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNod
 #undef TBVH_LT
 }
 
-bool tlas_variant_valid(int v) { return TBVH_EXPERIMENTS ? ((v >= 0 && v <= 15) || (v >= 21 && v <= 31)) : v == 0; }
+bool tlas_variant_valid(int v) { return TBVH_EXPERIMENTS ? ((v >= 0 && v <= 15) || (v >= 21 && v <= 36)) : v == 0; }
 
 }  // namespace tbvh

@@ -19,6 +19,7 @@
 #include "device_common.h"
 #include "lane_stack.h"
 #include "ray_pool.h"
+#include "ray_split.h"
 #include "kernels.h"
 
 namespace tbvh {
@@ -44,7 +45,9 @@ enum : uint32_t { S_NODE = 0, S_TRI = 1, S_INST = 2 };
 
 // PN / PT / PI: a state's code runs in an iteration if at least that many lanes are in the state, or it holds the most lanes.
 // ADAPT: rays are taken under the lockstep governor (ray_pool.h): whole 64-ray generations while the wave's rays stay together
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, bool ADAPT, bool STATS>
+// STEAL > 0 (idle lanes needed): once the ray pool is dry, idle lanes take the top stack entry — a BLAS subtree, a TLAS subtree or an instance —
+// off a lane that is still traversing (ray_split.h)
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, bool ADAPT, bool STATS, int STEAL = 0>
 __device__ __forceinline__ void tlas4_body(const float4* __restrict__ tlas4, const float4* __restrict__ instances, const BlasDesc* __restrict__ blas,
                                            const QueryArgs& q, uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
@@ -64,6 +67,8 @@ __device__ __forceinline__ void tlas4_body(const float4* __restrict__ tlas4, con
     // pending leaves of the current BLAS node (kernels_query.hip: bvh4_body)
     uint32_t leafQ0 = 0, leafQ1 = 0, leafQ2 = 0, leafQ3 = 0, leafCnt = 0, leafCntB = 0;
     unsigned long long sIter = 0, sAct = 0, sN = 0, sLN = 0, sT = 0, sLT = 0, sI = 0, sLI = 0;   // STATS
+    __shared__ SplitLds<STEAL ? WG : 1> split;
+    int grp = -1;
     LockstepGovernor gov;   // ADAPT only
     gov.init();
 
@@ -82,9 +87,38 @@ __device__ __forceinline__ void tlas4_body(const float4* __restrict__ tlas4, con
                     found = false; inBlas = false; state = S_NODE; offset = 0; leafCnt = 0; leafCntB = 0; st.sp = 0;
                     cur = GlobalF4(tlas4);
                     active = true;
+                    if (STEAL) grp = -1;
                 }
             }
             if (__ballot(active) == 0) break;
+        }
+        if (STEAL && nIdle >= (uint32_t)STEAL && pool.dry()) {
+            SplitMatch m;
+            if (split_match(active && st.sp != 0, !active, m)) {
+                uint32_t part = 0;
+                int lvl = 0;   // the entry belongs to the donor's BLAS traversal (else to the TLAS level, in world space)
+                if (m.gives) {
+                    lvl = inBlas && st.sp > base;
+                    part = st.pop();
+                    if (inBlas && !lvl) base = st.sp;   // the donor's BLAS part of the stack was empty: it now begins one entry lower
+                    split_give<ANYHIT>(split, m, grp, found, hit, hitInst);
+                }
+                const int src = split_take_ray(split, m, O, D, rD, hit, ri, grp);
+                part = __shfl(part, src); lvl = __shfl(lvl, src);
+                const int donorInBlas = __shfl((int)inBlas, src);
+                rayMask = __shfl(rayMask, src); curInst = __shfl(curInst, src); blasIdx = __shfl(blasIdx, src);
+                if (m.takes) {
+                    found = false; leafCnt = 0; leafCntB = 0; st.sp = 0; base = 0;
+                    if (lvl) { inBlas = true; cur = GlobalF4(blas[blasIdx].nodes); state = S_NODE; offset = part; }   // (back at its empty stack the lane "returns" to a TLAS level with nothing left: done)
+                    else {
+                        inBlas = false; cur = GlobalF4(tlas4);
+                        if (donorInBlas) { const RayRec* rp = q.rays + ri; O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD); }   // the donor's registers hold the instance-space ray
+                        if (part & 0x80000000u) { state = S_INST; offset = part & 0x7fffffffu; }
+                        else { state = S_NODE; offset = part; }
+                    }
+                    active = true;
+                }
+            }
         }
         // Phase gating (PN / PT / PI above)
         const uint32_t nN = (uint32_t)__popcll(__ballot(active && state == S_NODE)), nT = (uint32_t)__popcll(__ballot(active && state == S_TRI)),
@@ -94,8 +128,10 @@ __device__ __forceinline__ void tlas4_body(const float4* __restrict__ tlas4, con
         if (STATS) { sIter++; sAct += nN + nT + nI; if (runN && nN) { sN++; sLN += nN; } if (runT && nT) { sT++; sLT += nT; } if (runI && nI) { sI++; sLI += nI; } }
         if (!active) continue;
         bool done = false, advance = false;   // advance: nothing pending at this level, take the next stack entry
+        if (STEAL && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
 
-        if (state == S_TRI) { if (runT) {
+        if (STEAL && ANYHIT && done) {
+        } else if (state == S_TRI) { if (runT) {
             // ---- one triangle of the pending leaves of a BLAS node ---------------------------------------------------
             const uint32_t ta = leafQ0;
             const float4 v0 = cur[ta], e1 = cur[ta + 1], e2 = cur[ta + 2];
@@ -111,6 +147,7 @@ __device__ __forceinline__ void tlas4_body(const float4* __restrict__ tlas4, con
                     found = true; hitInst = curInst;
                     if (ANYHIT) done = true;
                     else hit = make_float4(h.t, h.u, h.v, v0.w);
+                    if (STEAL && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
                 }
             }
             if (!done && leafCnt == 0) advance = true;
@@ -193,7 +230,8 @@ __device__ __forceinline__ void tlas4_body(const float4* __restrict__ tlas4, con
         }
         if (done) {
             RayRec* rp = q.rays + ri;
-            if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+            if (STEAL && grp >= 0) split_finish<ANYHIT, true>(split, grp, q, ri);
+            else if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
             else if (found) { rp->hit = hit; ((uint32_t*)rp)[11] = hitInst; }   // byte 44 = hit.inst
             else if (q.fresh) rp->hit = hit;
             active = false;
@@ -206,10 +244,10 @@ __device__ __forceinline__ void tlas4_body(const float4* __restrict__ tlas4, con
     }
 }
 
-template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool ADAPT = false, bool STATS = false>
+template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool ADAPT = false, bool STATS = false, int STEAL = 0>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_tlas4(const float4* __restrict__ tlas4, const float4* __restrict__ instances,
                                                                                            const BlasDesc* __restrict__ blas, QueryArgs q, uint32_t* __restrict__ status) {
-    tlas4_body<ANYHIT, LDS_N, REFILL_MIN, PN, PT, PI, ADAPT, STATS>(tlas4, instances, blas, q, status);
+    tlas4_body<ANYHIT, LDS_N, REFILL_MIN, PN, PT, PI, ADAPT, STATS, STEAL>(tlas4, instances, blas, q, status);
 }
 
 }  // namespace
@@ -234,6 +272,10 @@ void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* i
     case 29: TBVH_T4(12, 8, 24, 8, 8); return;
     case 30: TBVH_T4(12, 16, 12, 12, 12); return;
     case 31: TBVH_T4(8, 16, 16, 16, 16); return;
+    case 32: TBVH_T4(12, 16, 24, 8, 8); return;                      // the default thresholds without split rays
+    case 33: TBVH_T4(12, 16, 24, 8, 8, false, false, 16); return;    // ... with, whatever the batch size
+    case 34: TBVH_T4(12, 16, 24, 8, 8, false, false, 32); return;
+    case 35: TBVH_T4(12, 16, 24, 8, 8, false, false, 8); return;
     default: break;
     }
 #endif
@@ -242,7 +284,9 @@ void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* i
     // random rays): 32/32/32 3570 / 2100 (2730); 16/16/16 4010 / 2340 (2910); 16/8/8 4350 / 2480 (3060); 24/8/8 4400 / 2480 (3120);
     // 8/8/8 4200 / 2490 (3050); 16/4/4 4130 / 2380 (2930); under the lockstep governor -2 %; 8-entry LDS stack top -6 %.
     // Before (nested-then-flat over the 2-wide TLAS, kernels_tlas.hip): 4170 / 1220 (1490).
-    TBVH_T4(12, 16, 24, 8, 8);
+    // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
+    if (q.nRaysDev != nullptr || q.nRays < (12ull << 20)) TBVH_T4(12, 16, 24, 8, 8, false, false, 16);
+    else TBVH_T4(12, 16, 24, 8, 8);
 #undef TBVH_T4
 }
 

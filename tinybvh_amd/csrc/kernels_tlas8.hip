@@ -15,6 +15,7 @@
 #include "device_common.h"
 #include "lane_stack.h"
 #include "ray_pool.h"
+#include "ray_split.h"
 #include "kernels.h"
 #include "cwbvh_node.h"
 
@@ -34,7 +35,9 @@ __device__ __forceinline__ float safercp(float x) {
 // =====================================================================================================================
 enum : uint32_t { S_NODE = 0, S_TRI = 1, S_INST = 2 };
 
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, bool STATS>
+// STEAL > 0 (idle lanes needed): once the ray pool is dry, idle lanes take the top stack entry — a node group of the BLAS or of the TLAS, or a
+// parked instance group — off a lane that is still traversing (ray_split.h)
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, bool STATS, int STEAL = 0>
 __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ instRef, const float4* __restrict__ instances,
                                            const BlasDesc* __restrict__ blas, const QueryArgs& q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -53,6 +56,8 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
     GlobalF4 cur(tlasNodes), btris;                   // node stream being walked (TLAS or the instance's BLAS); the BLAS's triangle records
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
     unsigned long long sIter = 0, sAct = 0, sN = 0, sLN = 0, sT = 0, sLT = 0, sI = 0, sLI = 0;   // STATS
+    __shared__ SplitLds<STEAL ? WG : 1> split;
+    int grp = -1;
 
     for (;;) {
         const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
@@ -71,9 +76,41 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
                     ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
                     cur = GlobalF4(tlasNodes);
                     active = true;
+                    if (STEAL) grp = -1;
                 }
             }
             if (__ballot(active) == 0) break;
+        }
+        if (STEAL && nIdle >= (uint32_t)STEAL && pool.dry()) {
+            SplitMatch m;
+            if (split_match(active && st.sp != 0, !active, m)) {
+                uint2 part = make_uint2(0u, 0u);
+                int lvl = 0;   // the entry belongs to the donor's BLAS traversal (else to the TLAS level, in world space)
+                if (m.gives) {
+                    lvl = inBlas && st.sp > base;
+                    part = st.pop();
+                    if (inBlas && !lvl) base = st.sp;   // the donor's BLAS part of the stack was empty: it now begins one entry lower
+                    split_give<ANYHIT>(split, m, grp, found, hit, hitInst);
+                }
+                const int src = split_take_ray(split, m, O, D, rD, hit, ri, grp);
+                part.x = __shfl(part.x, src); part.y = __shfl(part.y, src); lvl = __shfl(lvl, src);
+                const int donorInBlas = __shfl((int)inBlas, src);
+                rayMask = __shfl(rayMask, src); curInst = __shfl(curInst, src); blasIdx = __shfl(blasIdx, src);
+                if (m.takes) {
+                    found = false; st.sp = 0; base = 0;
+                    if (lvl) {   // (back at its empty stack the lane "returns" to a TLAS level with nothing left: done)
+                        const BlasDesc bd = blas[blasIdx];
+                        inBlas = true; cur = GlobalF4(bd.nodes); btris = GlobalF4(bd.tris);
+                    } else {
+                        inBlas = false; cur = GlobalF4(tlasNodes);
+                        if (donorInBlas) { const RayRec* rp = q.rays + ri; O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD); }   // the donor's registers hold the instance-space ray
+                    }
+                    oct = cw_oct(D);
+                    if (part.y > 0x00FFFFFFu) { ng = part; tg = make_uint2(0u, 0u); state = S_NODE; }
+                    else { tg = part; ng = make_uint2(0u, 0u); state = S_INST; }   // a parked instance group (TLAS level only)
+                    active = true;
+                }
+            }
         }
         const uint32_t nN = (uint32_t)__popcll(__ballot(active && state == S_NODE)), nT = (uint32_t)__popcll(__ballot(active && state == S_TRI)),
                        nI = (uint32_t)__popcll(__ballot(active && state == S_INST));
@@ -82,8 +119,10 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
         if (STATS) { sIter++; sAct += nN + nT + nI; if (runN && nN) { sN++; sLN += nN; } if (runT && nT) { sT++; sLT += nT; } if (runI && nI) { sI++; sLI += nI; } }
         if (!active) continue;
         bool done = false, next = false;   // next: this lane's step is over, decide what it does in the following iteration
+        if (STEAL && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
 
-        if (state == S_TRI) { if (runT) {
+        if (STEAL && ANYHIT && done) {
+        } else if (state == S_TRI) { if (runT) {
             // ---- one triangle of the BLAS node's triangle group ------------------------------------------------------------
             const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
             tg.y &= ~(1u << ti);
@@ -96,6 +135,7 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
                     found = true; hitInst = curInst;
                     if (ANYHIT) done = true;
                     else hit = make_float4(h.t, h.u, h.v, v0.w);
+                    if (STEAL && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
                 }
             }
             next = !done;
@@ -162,7 +202,8 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
         }
         if (done) {
             RayRec* rp = q.rays + ri;
-            if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
+            if (STEAL && grp >= 0) split_finish<ANYHIT, true>(split, grp, q, ri);
+            else if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
             else if (found) { rp->hit = hit; ((uint32_t*)rp)[11] = hitInst; }   // byte 44 = hit.inst
             else if (q.fresh) rp->hit = hit;
             active = false;
@@ -175,11 +216,11 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
     }
 }
 
-template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool STATS = false>
+template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool STATS = false, int STEAL = 0>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_tlas8(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ instRef,
                                                                                            const float4* __restrict__ instances, const BlasDesc* __restrict__ blas,
                                                                                            QueryArgs q, uint32_t* __restrict__ status) {
-    tlas8_body<ANYHIT, LDS_N, REFILL_MIN, PN, PT, PI, STATS>(tlasNodes, instRef, instances, blas, q, status);
+    tlas8_body<ANYHIT, LDS_N, REFILL_MIN, PN, PT, PI, STATS, STEAL>(tlasNodes, instRef, instances, blas, q, status);
 }
 
 }  // namespace
@@ -202,11 +243,18 @@ void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint3
     case 29: TBVH_T8(12, 8, 24, 8, 8); return;
     case 30: TBVH_T8(12, 16, 32, 8, 8); return;
     case 31: TBVH_T8(8, 16, 24, 8, 8); return;
+    case 32: TBVH_T8(12, 16, 24, 8, 8); return;                // the default thresholds without split rays
+    case 33: TBVH_T8(10, 16, 24, 8, 8, false, 16); return;     // ... with, whatever the batch size (LDS: 10 stack entries + the split groups still fit 24 waves per CU)
+    case 34: TBVH_T8(10, 16, 24, 8, 8, false, 32); return;
+    case 35: TBVH_T8(8, 16, 24, 8, 8, false, 16); return;
+    case 36: TBVH_T8(10, 16, 24, 8, 8); return;
     default: break;
     }
 #endif
     (void)variant;
-    TBVH_T8(12, 16, 24, 8, 8);
+    // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
+    if (q.nRaysDev != nullptr || q.nRays < (12ull << 20)) TBVH_T8(8, 16, 24, 8, 8, false, 16);   // (8 stack entries in LDS: with 12 and the split groups next to them only 20 waves per CU fit; 8.3 M camera rays +7 % over 10)
+    else TBVH_T8(12, 16, 24, 8, 8);
 #undef TBVH_T8
 }
 

@@ -20,8 +20,9 @@ namespace tbvh {
 template <int N> struct SplitLds {
     unsigned long long best[N];
     float2 uv[N];
+    uint32_t aux[N];       // two-level kernels: the instance of that hit
     uint32_t pending[N];
-    uint32_t donorOf[N];
+    uint8_t donorOf[N];    // scratch of one pairing step: the lane of the donor of each rank
 };
 
 // t as an integer that orders like the float (a hit at t = -0.0 must not lose against positive ones), then prim
@@ -54,12 +55,13 @@ __device__ __forceinline__ bool split_match(bool canGive, bool idle, SplitMatch&
 }
 
 // A donor enters (or opens) its ray's group and announces itself to the taker of its rank.
-template <bool ANYHIT, int N> __device__ __forceinline__ void split_give(SplitLds<N>& L, const SplitMatch& m, int& grp, bool found, float4 hit) {
-    L.donorOf[m.dRank] = threadIdx.x;
+template <bool ANYHIT, int N> __device__ __forceinline__ void split_give(SplitLds<N>& L, const SplitMatch& m, int& grp, bool found, float4 hit, uint32_t aux = 0u) {
+    L.donorOf[m.dRank] = (uint8_t)threadIdx.x;
     if (grp < 0) {   // a new group: the donor's closest hit so far is its first entry
         grp = (int)threadIdx.x;
         L.best[grp] = found ? split_key<ANYHIT>(hit) : ~0ull;
         L.uv[grp] = make_float2(hit.y, hit.z);
+        L.aux[grp] = aux;
         L.pending[grp] = 2u;
     } else atomicAdd(&L.pending[grp], 1u);
 }
@@ -86,20 +88,21 @@ template <bool ANYHIT, int N> __device__ __forceinline__ void split_poll(SplitLd
 }
 
 // A member found a hit: the others cull against it from their next pass on.
-template <bool ANYHIT, int N> __device__ __forceinline__ void split_publish(SplitLds<N>& L, int grp, float4 hit) {
+template <bool ANYHIT, int N> __device__ __forceinline__ void split_publish(SplitLds<N>& L, int grp, float4 hit, uint32_t aux = 0u) {
     const unsigned long long key = split_key<ANYHIT>(hit);
     atomicMin(&L.best[grp], key);
-    if (!ANYHIT && atomicAdd(&L.best[grp], 0ull) == key) L.uv[grp] = make_float2(hit.y, hit.z);   // (read back: of two members finding hits in one pass only the better one writes)
+    if (!ANYHIT && atomicAdd(&L.best[grp], 0ull) == key) { L.uv[grp] = make_float2(hit.y, hit.z); L.aux[grp] = aux; }   // (read back: of two members finding hits in one pass only the better one writes)
 }
 
-// A member is done; the last one writes the record.
-template <bool ANYHIT, int N> __device__ __forceinline__ void split_finish(SplitLds<N>& L, int& grp, const QueryArgs& q, uint64_t ri) {
+// A member is done; the last one writes the record (INST: two-level kernels, hit.inst at byte 44 of the record).
+template <bool ANYHIT, bool INST = false, int N> __device__ __forceinline__ void split_finish(SplitLds<N>& L, int& grp, const QueryArgs& q, uint64_t ri) {
     if (atomicSub(&L.pending[grp], 1u) == 1u) {
         const unsigned long long best = atomicAdd(&L.best[grp], 0ull);
         if (ANYHIT) q.occluded[ri] = best != ~0ull ? 1 : 0;
         else if (best != ~0ull) {
             const float2 uv = L.uv[grp];
             q.rays[ri].hit = make_float4(split_key_t(best), uv.x, uv.y, as_f32((uint32_t)best));
+            if (INST) ((uint32_t*)(q.rays + ri))[11] = L.aux[grp];
         } else if (q.fresh) q.rays[ri].hit = make_float4(q.freshTmax, 0.f, 0.f, 0.f);
     }
     grp = -1;

@@ -31,12 +31,14 @@ def main():
     ap.add_argument("--side", type=int, default=10)
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--random", type=int, default=0, help="also trace this many incoherent rays (random origins and directions inside the grid)")
     a = ap.parse_args()
     verts, label = scenes.get("dragon")
     ctx = tb.Context(0)
     blas = tb.LAYOUT_CLASSES[a.layout](ctx).Build(verts)
-    W, H = 3840, 2160
+    W, H = a.width, a.height
     n = W * H
     ext = 2.0 * a.side
     cam = R.camera((-0.6 * ext, 0.8 * ext, -0.9 * ext), (0.62, -0.38, 0.68), W, H, 1, 1)
