@@ -62,7 +62,7 @@ struct tbvh_context {
     uint32_t poolParts = 5;   // log2: 32 partitions
     int tlasVariant = 0;           // TBVH_TLAS_VARIANT: kernel variant of TLAS scenes that did not pick one (experiment knob)
     bool gridOverride = false;     // TBVH_BLOCKS_PER_CU / TBVH_RAYS_PER_BLOCK given: no per-scene adjustment
-    uint32_t raysPerBlock = 192;   // small batches: one workgroup per this many rays (measured best of 128..384 on 1 M-ray batches)
+    uint32_t raysPerBlock = 128;   // small batches: one workgroup per this many rays (with split rays, profiles/r02_grid_sweep.txt: 96-128 best on 1 M-ray batches, +5 % over 192; flat at 4 M)
     unsigned long long* pool = nullptr;     // ray-fetch counters: kPoolParts of them, 256 bytes apart (ray_pool.h)
     uint32_t* status = nullptr;
     RayRec* stageRays = nullptr;  // staging for host-array queries
@@ -316,14 +316,14 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.omm = Omm{s->opmap, s->opmapN};
     q.probe = nullptr; q.baseBlocks = 0;
     // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
-    // (about one workgroup per 192 rays, measured best for 1 M-ray launches) so every wave still
+    // (about one workgroup per 128 rays, measured best for 1 M-ray launches) so every wave still
     // has a few ray replacements' worth of work
     // A scene that (nearly) lives in the L2s — the Sponza class: < 48 MB of nodes and triangles against 8 x 4 MB of L2
     // plus the Infinity Cache — is latency-bound, not cache-bound: it runs best with a third more waves (32 per CU) of
     // fewer rays each (measured +1..20 % on the Sponza stand-in from 0.26 M to 16.7 M rays; the same shape costs the
     // 196 MB Bistro stand-in 5-10 % on bounce and shadow rays, which thrash the caches more with more waves).
     const bool small = !s->isTlas && !c->gridOverride && s->bytes < (48ull << 20);
-    const uint32_t perBlock = small ? (c->raysPerBlock * 2u) / 3u : c->raysPerBlock;
+    const uint32_t perBlock = c->raysPerBlock;
     const uint32_t cap = small ? c->blocks + c->blocks / 3u : c->blocks;
     uint64_t want = (n + perBlock - 1) / perBlock;
     const uint32_t lo = (uint32_t)c->numCUs * 4u;
