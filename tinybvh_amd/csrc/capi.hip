@@ -359,6 +359,14 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             c->timed = true;
             return 0;
         }
+        if (s->blasLayout == TBVH_LAYOUT_BVH_GPU && (tv == 0 || (tv >= 21 && tv <= 36))) {   // BVH_GPU BLASes: the TLAS already has their node format (kernels_tlas2.hip)
+            q.spillStride = c->spillEntries;   // 32-bit stack entries
+            launch_tlas2(any, tv, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            c->timed = true;
+            return 0;
+        }
         q.spillStride = c->spillEntries / 2;
         launch_tlas(any, s->blasLayout, s->variant ? s->variant : c->tlasVariant, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
         HIP_TRY(hipGetLastError());

@@ -50,6 +50,8 @@ void launch_tlas8_build(const float4* al, uint32_t nAL, const uint32_t* idx, uin
                         uint32_t* instRef, uint32_t capRefs, void* scratch, hipStream_t s);
 void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* instRef, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
                   uint32_t* status, uint32_t blocks, hipStream_t s);
+void launch_tlas2(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
+                  uint32_t* status, uint32_t blocks, hipStream_t s);   // BVH_GPU BLASes (kernels_tlas2.hip)
 // device TLAS rebuild (kernels_tlasbuild.hip)
 size_t tlas_build_scratch_bytes(uint32_t n, size_t* sortTempBytes);
 hipError_t launch_tlas_rebuild(float4* tlasNodes, uint32_t* tlasIdx, float4* instances, const float* transformsDev, const float* blasBoundsDev,
