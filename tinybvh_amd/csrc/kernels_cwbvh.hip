@@ -92,13 +92,13 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
                     ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u); tg2 = make_uint2(0u, 0u);
                     st.reset();
                     active = true;
-                    if (STEAL) grp = -1;
                 }
             }
             if (STATS >= 2 && !tDry && pool.dry()) tDry = wall_clock64();
             if (__ballot(active) == 0) break;
         }
-        if (STEAL && nIdle >= (uint32_t)STEAL && pool.dry()) {
+        const bool tail = STEAL && pool.dry();   // wave-uniform: nothing of the split-ray code costs a vector instruction before the pool is dry
+        if (tail && nIdle >= (uint32_t)STEAL) {
             const uint32_t nKids = (uint32_t)__popc(ng.y >> 24);
             SplitMatch m;
             if (split_match(active && (!st.empty() || nKids >= 2u), !active, m)) {
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
         if (!active) continue;
 
         bool done = false;
-        if (STEAL && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
+        if (tail && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
         // ---- triangle phase: runs when enough lanes have a triangle pending, or when no lane could use a node
         // phase instead (so a waiting lane always makes progress) --------------------------------------------
         // COH_ONLY: deferral and the gate apply only while the wave runs in lockstep (coherent rays: VALU-bound, the gate
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
-                if (STEAL && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
+                if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
             }
             if ((SPEC || PROBED) && tg.y == 0) { tg = tg2; tg2 = make_uint2(0u, 0u); }
         }
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
             }
         }
         if (done) {
-            if (STEAL && grp >= 0) split_finish<ANYHIT>(split, grp, q, ri);
+            if (tail && grp >= 0) split_finish<ANYHIT>(split, grp, q, ri);
             else if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
             else if (found || q.fresh) q.rays[ri].hit = hit;
             active = false;

@@ -75,12 +75,12 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
                     ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z);
                     found = false; node = 0; triLeft = 0; st.sp = 0;
                     active = true;
-                    if (STEAL) grp = -1;
                 }
             }
             if (__ballot(active) == 0) break;
         }
-        if (STEAL && nIdle >= (uint32_t)STEAL && pool.dry()) {
+        const bool tail = STEAL && pool.dry();   // wave-uniform: nothing of the split-ray code costs a vector instruction before the pool is dry
+        if (tail && nIdle >= (uint32_t)STEAL) {
             SplitMatch m;
             if (split_match(active && st.sp != 0, !active, m)) {
                 uint32_t part = 0;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
         if (!active) continue;
 
         bool done = false;
-        if (STEAL && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
+        if (tail && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
         // ---- triangle phase -------------------------------------------------------------------
         const uint32_t nPend = (uint32_t)__popcll(__ballot(triLeft != 0));
         const bool triPhase = nPend >= (uint32_t)TRI_MIN || nPend == (uint32_t)__popcll(__ballot(true));
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
-                if (STEAL && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
+                if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
             }
             if (!done && triLeft == 0) {  // leaf finished: continue with the stack
                 if (st.sp == 0) done = true;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
             }
         }
         if (done) {
-            if (STEAL && grp >= 0) split_finish<ANYHIT>(split, grp, q, ri);
+            if (tail && grp >= 0) split_finish<ANYHIT>(split, grp, q, ri);
             else if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
             else if (found || q.fresh) q.rays[ri].hit = hit;
             active = false;
@@ -210,13 +210,13 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
                     hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
                     found = false; offset = 0; leafCnt = 0; leafCntB = 0; st.sp = 0;
                     active = true;
-                    if (STEAL) grp = -1;
                 }
             }
             if (TIMELINE && !tDry && pool.dry()) tDry = wall_clock64();
             if (__ballot(active) == 0) break;
         }
-        if (STEAL && nIdle >= (uint32_t)STEAL && pool.dry()) {
+        const bool tail = STEAL && pool.dry();   // wave-uniform: nothing of the split-ray code costs a vector instruction before the pool is dry
+        if (tail && nIdle >= (uint32_t)STEAL) {
             SplitMatch m;
             if (split_match(active && st.sp != 0, !active, m)) {
                 uint32_t part = 0;
@@ -232,7 +232,7 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
         if (!active) continue;
 
         bool done = false;
-        if (STEAL && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
+        if (tail && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
         const uint32_t nPend = (uint32_t)__popcll(__ballot(leafCnt != 0));
         const bool triPhase = nPend >= (uint32_t)TRI_MIN || nPend == (uint32_t)__popcll(__ballot(true));
         if (triPhase && leafCnt != 0 && !done) {
@@ -248,7 +248,7 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
-                if (STEAL && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
+                if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
             }
             if (!done && leafCnt == 0) {
                 if (st.sp == 0) done = true;
@@ -314,7 +314,7 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
             }
         }
         if (done) {
-            if (STEAL && grp >= 0) split_finish<ANYHIT>(split, grp, q, ri);
+            if (tail && grp >= 0) split_finish<ANYHIT>(split, grp, q, ri);
             else if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
             else if (found || q.fresh) q.rays[ri].hit = hit;
             active = false;

@@ -73,12 +73,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     found = false; inBlas = false; state = S_NODE; node = 0; triLeft = 0; instNext = instEnd = 0; st.sp = 0;
                     cur = GlobalF4(tlasNodes);
                     active = true;
-                    if (STEAL) grp = -1;
                 }
             }
             if (__ballot(active) == 0) break;
         }
-        if (STEAL && nIdle >= (uint32_t)STEAL && pool.dry()) {
+        const bool tail = STEAL && pool.dry();   // wave-uniform: nothing of the split-ray code costs a vector instruction before the pool is dry
+        if (tail && nIdle >= (uint32_t)STEAL) {
             SplitMatch m;
             if (split_match(active && st.sp != 0, !active, m)) {
                 uint32_t part = 0;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         const bool runN = nN >= (uint32_t)PN || nN == nMax, runT = nT >= (uint32_t)PT || nT == nMax, runI = nI >= (uint32_t)PI || nI == nMax;
         if (!active) continue;
         bool done = false, advance = false;   // advance: nothing pending here, take what comes next at this level
-        if (STEAL && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
+        if (tail && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
 
         if (STEAL && ANYHIT && done) {
         } else if (state == S_TRI) { if (runT) {
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                     found = true; hitInst = curInst;
                     if (ANYHIT) done = true;
                     else hit = make_float4(h.t, h.u, h.v, v0.w);
-                    if (STEAL && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
+                    if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
                 }
             }
             if (!done && triLeft == 0) advance = true;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         }
         if (done) {
             RayRec* rp = q.rays + ri;
-            if (STEAL && grp >= 0) split_finish<ANYHIT, true>(split, grp, q, ri);
+            if (tail && grp >= 0) split_finish<ANYHIT, true>(split, grp, q, ri);
             else if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
             else if (found) { rp->hit = hit; ((uint32_t*)rp)[11] = hitInst; }   // byte 44 = hit.inst
             else if (q.fresh) rp->hit = hit;

@@ -76,12 +76,12 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
                     ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
                     cur = GlobalF4(tlasNodes);
                     active = true;
-                    if (STEAL) grp = -1;
                 }
             }
             if (__ballot(active) == 0) break;
         }
-        if (STEAL && nIdle >= (uint32_t)STEAL && pool.dry()) {
+        const bool tail = STEAL && pool.dry();   // wave-uniform: nothing of the split-ray code costs a vector instruction before the pool is dry
+        if (tail && nIdle >= (uint32_t)STEAL) {
             SplitMatch m;
             if (split_match(active && st.sp != 0, !active, m)) {
                 uint2 part = make_uint2(0u, 0u);
@@ -119,7 +119,7 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
         if (STATS) { sIter++; sAct += nN + nT + nI; if (runN && nN) { sN++; sLN += nN; } if (runT && nT) { sT++; sLT += nT; } if (runI && nI) { sI++; sLI += nI; } }
         if (!active) continue;
         bool done = false, next = false;   // next: this lane's step is over, decide what it does in the following iteration
-        if (STEAL && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
+        if (tail && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
 
         if (STEAL && ANYHIT && done) {
         } else if (state == S_TRI) { if (runT) {
@@ -135,7 +135,7 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
                     found = true; hitInst = curInst;
                     if (ANYHIT) done = true;
                     else hit = make_float4(h.t, h.u, h.v, v0.w);
-                    if (STEAL && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
+                    if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
                 }
             }
             next = !done;
@@ -202,7 +202,7 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
         }
         if (done) {
             RayRec* rp = q.rays + ri;
-            if (STEAL && grp >= 0) split_finish<ANYHIT, true>(split, grp, q, ri);
+            if (tail && grp >= 0) split_finish<ANYHIT, true>(split, grp, q, ri);
             else if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
             else if (found) { rp->hit = hit; ((uint32_t*)rp)[11] = hitInst; }   // byte 44 = hit.inst
             else if (q.fresh) rp->hit = hit;
