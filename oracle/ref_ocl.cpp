@@ -32,6 +32,12 @@ static const char* kWavefrontSource =
 #include "_ref/ref_wavefront_source.inc"
     ;
 
+// wavefront2.cl (tiny_bvh_gpu2.cpp: TLAS over instanced BVH8_CWBVH BLASes) with its #includes expanded: only its SetRenderData and
+// Extend kernels are run here, to time traverse_tlas (traverse_tlas.cl:13-107) next to this library's two-level kernels
+static const char* kWavefront2Source =
+#include "_ref/ref_wavefront2_source.inc"
+    ;
+
 namespace {
 cl_context g_ctx = nullptr;
 cl_device_id g_dev = nullptr;
@@ -254,6 +260,95 @@ int refocl_wavefront(const void* nodes, uint64_t nodeBytes, const void* tris, ui
     for (cl_mem m : {mNodes, mTris, mVerts, mNoise, mIn, mOut, mConn, mAcc}) clReleaseMemObject(m);
     for (int i = 0; i < 9; i++) clReleaseKernel(k[i]);
     return 0;
+}
+
+// ---- the reference's TLAS traversal (traverse_tlas.cl) through wavefront2.cl's Extend kernel, as tiny_bvh_gpu2.cpp:184-191 launches it -----
+// The file as shipped does not compile on its own (traverse_tlas.cl's general path reads blasDesc / blasCWNodes, which only raytracer.cl
+// declares); its DEPRECATED_TLAS_PATH branch — "instance 0 is the Bistro, all others the dragon", the branch tiny_bvh_gpu2.cpp was written
+// against — does, and with the same BLAS passed for both it is a TLAS over instances of one BVH8_CWBVH BLAS.
+// rays: n 64-byte ray records (O, D read; the kernel derives rD with native_recip as the demo does); out: n float4 hits
+// (t, u, v, prim + (instance << 24)).  Extend runs `passes` + 1 times with the demo's launch shape (compute units * 64 * 16 work-items of 64);
+// returns the mean kernel time in milliseconds or a negative error.
+namespace { cl_program g_w2prog = nullptr; }
+double refocl_tlas_extend(const void* tlasNodes, uint64_t tlasNodeBytes, const uint32_t* tlasIdx, uint64_t nIdx, const void* instances, uint64_t nInst,
+                          const void* blasNodes, uint64_t blasNodeBytes, const void* blasTris, uint64_t blasTriBytes, const void* rays, uint64_t n, int passes,
+                          float* out) {
+    if (refocl_init()) return -1.0;
+    cl_int e;
+    if (!g_w2prog) {
+        const std::string src = std::string("#define ISAMD\n#define DEPRECATED_TLAS_PATH\n") + kWavefront2Source;
+        const char* s = src.c_str();
+        size_t len = src.size();
+        g_w2prog = clCreateProgramWithSource(g_ctx, 1, &s, &len, &e);
+        if (e != CL_SUCCESS) { snprintf(g_err, sizeof g_err, "tlas: clCreateProgramWithSource %d", e); return -5.0; }
+        e = clBuildProgram(g_w2prog, 0, nullptr, "-cl-std=CL2.0 -cl-strict-aliasing -cl-fast-relaxed-math -cl-single-precision-constant ", nullptr, nullptr);
+        if (e != CL_SUCCESS) {
+            size_t m = 0;
+            clGetProgramBuildInfo(g_w2prog, g_dev, CL_PROGRAM_BUILD_LOG, sizeof g_err - 64, g_err + 32, &m);
+            memcpy(g_err, "wavefront2 clBuildProgram failed", 32);
+            g_w2prog = nullptr;
+            return -6.0;
+        }
+    }
+    cl_kernel kSet = clCreateKernel(g_w2prog, "SetRenderData", &e);
+    if (e != CL_SUCCESS) { snprintf(g_err, sizeof g_err, "tlas: clCreateKernel(SetRenderData) %d", e); return -7.0; }
+    cl_kernel kExt = clCreateKernel(g_w2prog, "Extend", &e);
+    if (e != CL_SUCCESS) { snprintf(g_err, sizeof g_err, "tlas: clCreateKernel(Extend) %d", e); return -7.0; }
+    auto buf = [&](const void* p, uint64_t bytes, cl_mem_flags f) {
+        cl_int ee;
+        cl_mem m = clCreateBuffer(g_ctx, f | CL_MEM_COPY_HOST_PTR, bytes ? bytes : 16, (void*)p, &ee);
+        if (ee != CL_SUCCESS) snprintf(g_err, sizeof g_err, "tlas: clCreateBuffer(%llu bytes) %d", (unsigned long long)bytes, ee);
+        return m;
+    };
+    // PathState { float4 T, O (w: pixel index << 8 | flags), D (w: t), hit } per ray (wavefront2.cl:53-59, Generate :106-119)
+    std::vector<float> ps((size_t)n * 16);
+    const float* r = (const float*)rays;
+    for (uint64_t i = 0; i < n; i++) {
+        float* p = ps.data() + i * 16;
+        p[0] = p[1] = p[2] = p[3] = 1.f;
+        p[4] = r[i * 16 + 0]; p[5] = r[i * 16 + 1]; p[6] = r[i * 16 + 2];
+        const uint32_t w = ((uint32_t)i << 8) + 1u; memcpy(p + 7, &w, 4);
+        p[8] = r[i * 16 + 4]; p[9] = r[i * 16 + 5]; p[10] = r[i * 16 + 6]; p[11] = 1e30f;
+        p[12] = 1e30f; p[13] = p[14] = p[15] = 0.f;
+    }
+    const uint32_t dummy[4] = {0, 0, 0, 0};
+    cl_mem mTlas = buf(tlasNodes, tlasNodeBytes, CL_MEM_READ_ONLY), mIdx = buf(tlasIdx, nIdx * 4, CL_MEM_READ_ONLY), mInst = buf(instances, nInst * 192, CL_MEM_READ_ONLY);
+    cl_mem mNodes = buf(blasNodes, blasNodeBytes, CL_MEM_READ_ONLY), mTris = buf(blasTris, blasTriBytes, CL_MEM_READ_ONLY), mDummy = buf(dummy, 16, CL_MEM_READ_ONLY);
+    cl_mem mRays = buf(ps.data(), n * 64, CL_MEM_READ_WRITE);
+    if (!mTlas || !mIdx || !mInst || !mNodes || !mTris || !mDummy || !mRays) return -8.0;
+    cl_uint cus = 0;
+    clGetDeviceInfo(g_dev, CL_DEVICE_MAX_COMPUTE_UNITS, sizeof cus, &cus, nullptr);
+    const cl_int count = (cl_int)n;
+    const float z4[4] = {0, 0, 0, 0};
+    const cl_uint one = 1, w = 1024, h = 1024;
+    // SetRenderData( N, eye, p0, p1, p2, frameIdx, W, H, bistroNodes, bistroTris, bistroVerts, dragonNodes, dragonTris, dragonVerts, tlasNodes, tlasIdx, instances, blueNoise )
+    clSetKernelArg(kSet, 0, sizeof count, &count);
+    for (int i = 1; i <= 4; i++) clSetKernelArg(kSet, i, 16, z4);
+    clSetKernelArg(kSet, 5, sizeof one, &one); clSetKernelArg(kSet, 6, sizeof w, &w); clSetKernelArg(kSet, 7, sizeof h, &h);
+    cl_mem args[10] = {mNodes, mTris, mDummy, mNodes, mTris, mDummy, mTlas, mIdx, mInst, mDummy};
+    for (int i = 0; i < 10; i++) clSetKernelArg(kSet, 8 + i, sizeof(cl_mem), &args[i]);
+    clSetKernelArg(kExt, 0, sizeof(cl_mem), &mRays);
+    const size_t gOne = 1, gExt = (size_t)cus * 64 * 16, local = 64;
+    double total = 0;
+    for (int p = 0; p <= passes; p++) {
+        e = clEnqueueNDRangeKernel(g_q, kSet, 1, nullptr, &gOne, nullptr, 0, nullptr, nullptr);   // resets extendTasks to N
+        if (e != CL_SUCCESS) { snprintf(g_err, sizeof g_err, "tlas: SetRenderData %d", e); return -9.0; }
+        cl_event ev;
+        e = clEnqueueNDRangeKernel(g_q, kExt, 1, nullptr, &gExt, &local, 0, nullptr, &ev);
+        if (e != CL_SUCCESS) { snprintf(g_err, sizeof g_err, "tlas: Extend %d", e); return -9.0; }
+        clWaitForEvents(1, &ev);
+        cl_ulong t0 = 0, t1 = 0;
+        clGetEventProfilingInfo(ev, CL_PROFILING_COMMAND_START, sizeof t0, &t0, nullptr);
+        clGetEventProfilingInfo(ev, CL_PROFILING_COMMAND_END, sizeof t1, &t1, nullptr);
+        if (p) total += (double)(t1 - t0) * 1e-6;
+        clReleaseEvent(ev);
+    }
+    e = clEnqueueReadBuffer(g_q, mRays, CL_TRUE, 0, n * 64, ps.data(), 0, nullptr, nullptr);
+    if (e != CL_SUCCESS) { snprintf(g_err, sizeof g_err, "tlas: clEnqueueReadBuffer %d", e); return -10.0; }
+    for (uint64_t i = 0; i < n; i++) memcpy(out + i * 4, ps.data() + i * 16 + 12, 16);
+    for (cl_mem m : {mTlas, mIdx, mInst, mNodes, mTris, mDummy, mRays}) clReleaseMemObject(m);
+    clReleaseKernel(kSet); clReleaseKernel(kExt);
+    return total / (passes > 0 ? passes : 1);
 }
 
 }  // extern "C"

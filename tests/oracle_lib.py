@@ -266,6 +266,8 @@ class ReferenceOpenCL:
         L.refocl_run.argtypes = [C.c_int, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64, C.c_int]
         L.refocl_wavefront.restype = C.c_int
         L.refocl_wavefront.argtypes = [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_char_p, _vp]
+        L.refocl_tlas_extend.restype = C.c_double
+        L.refocl_tlas_extend.argtypes = [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _u64, C.c_int, _vp]
         if L.refocl_init() != 0:
             raise RuntimeError("reference OpenCL kernels unavailable: " + L.refocl_error().decode(errors="replace")[:2000])
         self.device = L.refocl_device().decode()
@@ -283,6 +285,20 @@ class ReferenceOpenCL:
         if r != 0:
             raise RuntimeError(f"refocl_wavefront: {r}: " + self.lib.refocl_error().decode(errors="replace")[:3000])
         return out
+
+    def tlas_extend(self, tlas_nodes, tlas_idx, instances, blas_nodes, blas_tris, rays, passes=3):
+        """The reference's traverse_tlas (TLAS in BVH_GPU format over instances of ONE BVH8_CWBVH BLAS) through wavefront2.cl's Extend
+        kernel, launched as tiny_bvh_gpu2.cpp:191 does.  Returns ((n, 4) float32 hits: t, u, v, prim + (inst << 24) as bits; mean kernel ms)."""
+        tlas_nodes, instances, blas_nodes, blas_tris = (np.ascontiguousarray(x) for x in (tlas_nodes, instances, blas_nodes, blas_tris))
+        tlas_idx = np.ascontiguousarray(tlas_idx, np.uint32)
+        r = np.ascontiguousarray(rays)
+        n = r.shape[0]
+        out = np.zeros((n, 4), np.float32)
+        ms = self.lib.refocl_tlas_extend(_p(tlas_nodes), tlas_nodes.nbytes, _p(tlas_idx), tlas_idx.size, _p(instances), instances.shape[0], _p(blas_nodes), blas_nodes.nbytes,
+                                         _p(blas_tris), blas_tris.nbytes, _p(r), n, passes, _p(out))
+        if ms < 0:
+            raise RuntimeError("refocl_tlas_extend: " + self.lib.refocl_error().decode(errors="replace")[:3000])
+        return out, ms
 
     def run(self, layout, blobs, rays, passes=3):
         """blobs: list of numpy arrays in kernel-argument order.  Returns (rays_out, mean_ms)."""
