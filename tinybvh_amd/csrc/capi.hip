@@ -393,7 +393,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         {
             const bool autoPad = s->variant == 0 && s->nodes128 != nullptr;   // nodes beyond the Infinity Cache: the padded copy (padCwbvhIfLarge)
             launch_cwbvh(any, s->variant, (autoPad || cwbvh_variant_padded(s->variant)) ? s->nodes128 : s->nodes, cwbvh_variant_tri64(s->variant) ? s->tris64 : s->tris, q, c->status, blocks,
-                         c->stream, autoPad);
+                         c->stream, autoPad, small);
         }
         break;
     default:

@@ -19,7 +19,7 @@ void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tr
 void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
 // paddedNodes: `nodes` is the copy with one node per 128-byte line (8 float4 apart; scenes whose nodes outgrow the Infinity Cache)
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
-                  uint32_t blocks, hipStream_t s, bool paddedNodes = false);
+                  uint32_t blocks, hipStream_t s, bool paddedNodes = false, bool shallow = false);
 bool cwbvh_variant_valid(int variant);
 bool cwbvh_variant_padded(int variant);   // runs on the 128-byte padded node copy
 bool cwbvh_variant_tri64(int variant);    // runs on the 64-byte padded triangle copy

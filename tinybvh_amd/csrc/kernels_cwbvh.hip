@@ -236,7 +236,7 @@ __global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__
 }  // namespace
 
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
-                  uint32_t blocks, hipStream_t s, bool paddedNodes) {
+                  uint32_t blocks, hipStream_t s, bool paddedNodes, bool shallow) {
 #define TBVH_K(...)                                                                     \
     do {                                                                                \
         if (anyhit) launch_k<true, __VA_ARGS__>(nodes, tris, q, status, blocks, s);     \
@@ -276,6 +276,8 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     case 79: launch_k<false, 8, 16, 1, false, 3>(nodes, tris, q, status, blocks, s); return;       // histogram of wave ends, strict schedule
     case 80: launch_k<false, 8, 16, 1, false, 4>(nodes, tris, q, status, blocks, s); return;       // histogram of pool-dry times
     case 89: TBVH_K(6, 16, 1, false, 0, 5, 3, false, false, 16); return;   // 75 with 6 stack entries in LDS (32 waves per CU fit)
+    case 91: TBVH_K(8, 16, 1, false, 0, 8, 3, false, false, 16); return;   // padded nodes + split rays, 8 stack entries in LDS
+    case 92: TBVH_K(6, 16, 1, false, 0, 8, 3, false, false, 16); return;   // ... 6
     case 88: if (q.probe) TBVH_K(6, 16, 8, true, 0, 5, 3, false, true, 16); else TBVH_K(6, 16, 1, false, 0, 5, 3, false, false, 16); return;   // the probed schedule + stealing, whatever the batch size
     case 82: launch_k<false, 8, 16, 1, false, 5>(nodes, tris, q, status, blocks, s); return;       // tail statistics, strict schedule
     case 83: launch_k<false, 8, 16, 1, false, 5, 5, 3, false, false, 16>(nodes, tris, q, status, blocks, s); return;   // tail statistics with stealing
@@ -288,14 +290,18 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     // lanes (ray_split.h): Bistro stand-in 0.26 / 1 / 4 / 8 M rays: camera +7 / +20 / +6 / +4 %, bounce +26 / +23 / +8 / +4 %, shadow
     // +20 / +18 / +6 / +4 %; at 16.7 M rays the tail is 5 % of the launch and the kernel's register cap costs as much as it gains
     const bool tail = q.nRaysDev != nullptr || q.nRays < (12ull << 20);
+    // Stack entries in LDS next to the split groups: 6 let 32 waves per CU fit (what scenes under 48 MB and coherent probed batches are
+    // launched with; Bistro-size trees measure the same with 6 or 8), deep trees want 8 (30 M triangles: 6 costs 7 % on camera rays, 13 % on bounce rays)
     if (paddedNodes) {   // one node per cache line (capi.hip: scenes whose node array is beyond the Infinity Cache; DESIGN.md §5: -17 % bytes, +6 % at 60 M triangles)
-        if (tail) TBVH_K(6, 16, 1, false, 0, 8, 3, false, false, 16);   // (6 stack entries in LDS: with the split groups next to them 32 waves per CU still fit; 6 or 8 measure the same)
+        if (tail) TBVH_K(8, 16, 1, false, 0, 8, 3, false, false, 16);
         else TBVH_K(8, 16, 1, false, 0, 8);
     } else if (q.probe) {
         if (tail) TBVH_K(6, 16, 8, true, 0, 5, 3, false, true, 16);
         else TBVH_K(8, 16, 8, true, 0, 5, 3, false, true);
-    } else if (tail) TBVH_K(6, 16, 1, false, 0, 5, 3, false, false, 16);
-    else TBVH_K(8, 16, 1, false);
+    } else if (tail) {
+        if (shallow) TBVH_K(6, 16, 1, false, 0, 5, 3, false, false, 16);
+        else TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 16);
+    } else TBVH_K(8, 16, 1, false);
 #undef TBVH_K
 }
 
@@ -317,12 +323,12 @@ void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream
     hipLaunchKernelGGL(k_pad_nodes, dim3((nNodes * 8u + 255u) / 256u), dim3(256), 0, s, src, dst, nNodes);
 }
 
-bool cwbvh_variant_padded(int v) { return TBVH_EXPERIMENTS && (v == 47 || v == 62 || v == 63 || v == 66); }
+bool cwbvh_variant_padded(int v) { return TBVH_EXPERIMENTS && (v == 47 || v == 62 || v == 63 || v == 66 || v == 91 || v == 92); }
 bool cwbvh_variant_tri64(int v) { return TBVH_EXPERIMENTS && v >= 64 && v <= 67; }
 
 bool cwbvh_variant_valid(int v) {
 #if TBVH_EXPERIMENTS
-    return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43) || (v >= 50 && v <= 89 && v != 84 && v != 85 && v != 86 && v != 87);
+    return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43) || (v >= 50 && v <= 92 && v != 90 && v != 84 && v != 85 && v != 86 && v != 87);
 #else
     return v == 0;
 #endif
