@@ -1,8 +1,9 @@
 // Split rays: the end of a launch.  Once the ray pool is dry a persistent wave only finishes what its lanes hold, and what
 // is left in the end are the longest rays — each a chain of dependent steps — on a few lanes while the others idle: a
 // 1 M-ray launch on the Bistro stand-in has handed out its last ray after 250 us and ends after 500 us (wave timeline,
-// tools/ab_probe.py --timeline / --hist).  From then on idle lanes take pending subtrees off the lanes that are still
-// traversing and walk them for the same ray.
+// tools/ab_probe.py --timeline / --hist).  From then on idle lanes take pending subtrees — the NEWEST stack entry, i.e.
+// the nearest one: the chain of dependent steps to the closest hit is what has to get shorter — off the lanes that are
+// still traversing and walk them for the same ray; takers give away in turn.
 //
 // The lanes working on one ray form a GROUP, named after the lane that gave work away first (a lane owns at most one
 // ray after the pool is dry, so the slot is used once).  In LDS per group: the closest hit so far as one 64-bit key
@@ -35,9 +36,11 @@ __device__ __forceinline__ float split_key_t(unsigned long long key) {   // (no 
     return as_f32((tk & 0x80000000u) ? (tk & 0x7FFFFFFFu) : ~tk);
 }
 
-// Pairs idle lanes with lanes that can give work away, one to one by rank.  Whole wave, wave-uniform control flow.
-// Returns false when there is nothing to pair.  gives / takes: this lane's role; after split_publish_donors() and a
-// barrier, split_source() names the lane a taker copies from.
+// One pairing step, whole wave, wave-uniform control flow:
+//   split_match     pairs idle lanes with lanes that can give work away, one to one by rank (false: nothing to pair);
+//   split_give      (donors) enter or open the ray's group, leave the own lane id for the taker of the same rank;
+//   split_take_ray  (all lanes) the donor's ray lands in the taker's registers; returns the lane a taker copies from, so the
+//                   kernel can fetch its own state (the stack entry given away, the instance, ...) the same way.
 struct SplitMatch {
     bool gives, takes;
     uint32_t dRank, iRank;
