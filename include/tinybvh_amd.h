@@ -200,7 +200,11 @@ int tbvh_occluded(tbvh_scene* scene, const void* rays, uint64_t n_rays,
                   uint32_t stride_bytes, uint8_t* occluded);
 
 /* Device-resident packed rays (64-byte stride, 16-byte aligned).  Asynchronous on the
- * context's stream; no host copies.  This is the timed path. */
+ * context's stream; no host copies.  This is the timed path.
+ * Records are the reference's (BVH::Intersect: prim exact, t / u / v bit-identical) except among triangles a ray
+ * hits at (nearly) the same t, where — as between the reference's own layouts — the winner depends on the order of
+ * the tests; batches below 12 M rays split their last rays over idle lanes (DESIGN.md par. 3), so which of two such
+ * triangles is reported may differ from run to run. */
 int tbvh_intersect_device(tbvh_scene* scene, void* d_rays64, uint64_t n_rays);
 int tbvh_occluded_device(tbvh_scene* scene, const void* d_rays64, uint64_t n_rays,
                          uint8_t* d_occluded);
