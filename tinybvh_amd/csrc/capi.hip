@@ -62,6 +62,7 @@ struct tbvh_context {
     uint32_t poolParts = 5;   // log2: 32 partitions
     int tlasVariant = 0;           // TBVH_TLAS_VARIANT: kernel variant of TLAS scenes that did not pick one (experiment knob)
     bool gridOverride = false;     // TBVH_BLOCKS_PER_CU / TBVH_RAYS_PER_BLOCK given: no per-scene adjustment
+    uint64_t splitBelow = 12ull << 20;   // batches of fewer rays split their last rays over idle lanes; TBVH_SPLIT_RAYS=0 turns that off (tie order then reproducible run to run)
     uint32_t raysPerBlock = 128;   // small batches: one workgroup per this many rays (with split rays, profiles/r02_grid_sweep.txt: 96-128 best on 1 M-ray batches, +5 % over 192; flat at 4 M)
     unsigned long long* pool = nullptr;     // ray-fetch counters: kPoolParts of them, 256 bytes apart (ray_pool.h)
     uint32_t* status = nullptr;
@@ -315,6 +316,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     q.stats = c->counter + 8;
     q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.omm = Omm{s->opmap, s->opmapN};
     q.probe = nullptr; q.baseBlocks = 0;
+    q.splitBelow = c->splitBelow;
     // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
     // (about one workgroup per 128 rays, measured best for 1 M-ray launches) so every wave still
     // has a few ray replacements' worth of work
@@ -485,6 +487,7 @@ int tbvh_init(int device, tbvh_context** out) {
         if (b >= 64 && b <= 4096) { c->raysPerBlock = (uint32_t)b; c->gridOverride = true; }
     }
     if (const char* e = getenv("TBVH_TLAS_VARIANT")) c->tlasVariant = atoi(e);   // experiment knob
+    if (const char* e = getenv("TBVH_SPLIT_RAYS")) { if (atoi(e) == 0) c->splitBelow = 0; }
     if (const char* e = getenv("TBVH_POOL_PARTS")) {  // experiment knob
         const int b = atoi(e);
         if (b >= 0 && (1 << b) <= kPoolParts) c->poolParts = (uint32_t)b;   // log2 of the partition count

@@ -96,6 +96,7 @@ struct QueryArgs {
     uint32_t poolParts;    // log2 of the number of partitions of the batch, each with its own counter (ray_pool.h)
     unsigned long long* stats;  // instrumented variants: lane-utilisation counters
     const unsigned long long* nRaysDev;  // if non-null the batch size is read from device memory (on-device queues)
+    uint64_t splitBelow;   // batches of fewer rays split their last rays over idle lanes (ray_split.h); 0: never (TBVH_SPLIT_RAYS=0)
     Omm omm;               // opacity micromaps of the scene (map == nullptr: none)
     uint32_t fresh;        // 1: ignore the stored hit, start every ray from {freshTmax,0,0,0} and always write the record
     float freshTmax;
@@ -104,6 +105,11 @@ struct QueryArgs {
     const uint32_t* probe;
     uint32_t baseBlocks;
 };
+
+// Host side: does this launch use the kernels with split rays?  Batches below the threshold, and the wavefront stages (ray count
+// known to the device only); at 16.7 M rays the tail is 5 % of a launch and those kernels' register cap costs as much as it gains.
+inline bool split_rays_wanted(const QueryArgs& q) { return q.splitBelow != 0 && (q.nRaysDev != nullptr || q.nRays < q.splitBelow); }
+
 
 // A float4 array known to live in global memory.  Pointers that were themselves loaded from
 // memory (per-BLAS node / triangle bases) are generic to the compiler, and loads through them

@@ -289,7 +289,7 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     // Batches below 12 M rays (and the wavefront stages, whose ray count only the device knows) also split their last rays over idle
     // lanes (ray_split.h): Bistro stand-in 0.26 / 1 / 4 / 8 M rays: camera +7 / +20 / +6 / +4 %, bounce +26 / +23 / +8 / +4 %, shadow
     // +20 / +18 / +6 / +4 %; at 16.7 M rays the tail is 5 % of the launch and the kernel's register cap costs as much as it gains
-    const bool tail = q.nRaysDev != nullptr || q.nRays < (12ull << 20);
+    const bool tail = split_rays_wanted(q);
     // Stack entries in LDS next to the split groups: 6 let 32 waves per CU fit (what scenes under 48 MB and coherent probed batches are
     // launched with; Bistro-size trees measure the same with 6 or 8), deep trees want 8 (30 M triangles: 6 costs 7 % on camera rays, 13 % on bounce rays)
     if (paddedNodes) {   // one node per cache line (capi.hip: scenes whose node array is beyond the Infinity Cache; DESIGN.md §5: -17 % bytes, +6 % at 60 M triangles)

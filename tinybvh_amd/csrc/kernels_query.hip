@@ -390,7 +390,7 @@ void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tr
 #endif
     default:   // + the lockstep governor (ray_pool.h): Sponza camera rays +9 %, shadow +6 %; small incoherent batches -3..5 %
         // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
-        if (q.nRaysDev != nullptr || q.nRays < (12ull << 20)) {
+        if (split_rays_wanted(q)) {
             if (q.omm.map) TBVH_L2(16, true, 3, kLockstepKeep, true, 16);
             else TBVH_L2(16, true, 3, kLockstepKeep, false, 16);
         } else if (q.omm.map) TBVH_L2(16, true, 3);
@@ -430,7 +430,7 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
     case 16: TBVH_L4W(8, false, 1, true, kLockstepKeep, false, false, 32); break;
 #endif
     default:   // per-lane replacement throughout, sign-selected planes, 8 waves per SIMD
-        if (q.nRaysDev != nullptr || q.nRays < (12ull << 20)) {   // split rays, as in launch_bvh2
+        if (split_rays_wanted(q)) {   // split rays, as in launch_bvh2
             if (q.omm.map) TBVH_L4W(8, false, 1, true, kLockstepKeep, true, false, 16);
             else TBVH_L4W(8, false, 1, true, kLockstepKeep, false, false, 16);
         } else if (q.omm.map) TBVH_L4W(8, false, 1, true);

@@ -240,7 +240,7 @@ void launch_tlas2(bool anyhit, int variant, const float4* tlasNodes, const uint3
 #endif
     (void)variant;
     // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
-    if (q.nRaysDev != nullptr || q.nRays < (12ull << 20)) TBVH_T2(16, 16, 24, 8, 8, 16);
+    if (split_rays_wanted(q)) TBVH_T2(16, 16, 24, 8, 8, 16);
     else TBVH_T2(16, 16, 24, 8, 8, 0);
 #undef TBVH_T2
 }

@@ -285,7 +285,7 @@ void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* i
     // 8/8/8 4200 / 2490 (3050); 16/4/4 4130 / 2380 (2930); under the lockstep governor -2 %; 8-entry LDS stack top -6 %.
     // Before (nested-then-flat over the 2-wide TLAS, kernels_tlas.hip): 4170 / 1220 (1490).
     // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
-    if (q.nRaysDev != nullptr || q.nRays < (12ull << 20)) TBVH_T4(12, 16, 24, 8, 8, false, false, 16);
+    if (split_rays_wanted(q)) TBVH_T4(12, 16, 24, 8, 8, false, false, 16);
     else TBVH_T4(12, 16, 24, 8, 8);
 #undef TBVH_T4
 }

@@ -253,7 +253,7 @@ void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint3
 #endif
     (void)variant;
     // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
-    if (q.nRaysDev != nullptr || q.nRays < (12ull << 20)) TBVH_T8(8, 16, 24, 8, 8, false, 16);   // (8 stack entries in LDS: with 12 and the split groups next to them only 20 waves per CU fit; 8.3 M camera rays +7 % over 10)
+    if (split_rays_wanted(q)) TBVH_T8(8, 16, 24, 8, 8, false, 16);   // (8 stack entries in LDS: with 12 and the split groups next to them only 20 waves per CU fit; 8.3 M camera rays +7 % over 10)
     else TBVH_T8(12, 16, 24, 8, 8);
 #undef TBVH_T8
 }
