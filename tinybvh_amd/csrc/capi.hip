@@ -345,9 +345,10 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     }
     if (s->isTlas) {
         const int tv = s->variant ? s->variant : c->tlasVariant;
+        const uint32_t blocks7 = (!c->gridOverride && blocks == c->blocks) ? (uint32_t)c->numCUs * 28u : blocks;   // the full grid of the kernels built for 7 waves per SIMD
         if (s->tlas4 && s->blasLayout == TBVH_LAYOUT_BVH4_GPU && (tv == 0 || (tv >= 21 && tv <= 36))) {   // BVH4_GPU BLASes: the unified 4-wide kernel
             q.spillStride = c->spillEntries;   // 32-bit stack entries
-            launch_tlas4(any, tv, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+            launch_tlas4(any, tv, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
             c->timed = true;
@@ -355,7 +356,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         }
         if (s->tlas8 && s->blasLayout == TBVH_LAYOUT_CWBVH && (tv == 0 || (tv >= 21 && tv <= 36))) {   // BVH8_CWBVH BLASes: the unified 8-wide kernel
             q.spillStride = c->spillEntries / 2;   // 8-byte stack entries
-            launch_tlas8(any, tv, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+            launch_tlas8(any, tv, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
             c->timed = true;
@@ -363,7 +364,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         }
         if (s->blasLayout == TBVH_LAYOUT_BVH_GPU && (tv == 0 || (tv >= 21 && tv <= 36))) {   // BVH_GPU BLASes: the TLAS already has their node format (kernels_tlas2.hip)
             q.spillStride = c->spillEntries;   // 32-bit stack entries
-            launch_tlas2(any, tv, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+            launch_tlas2(any, tv, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
             c->timed = true;

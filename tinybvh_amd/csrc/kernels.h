@@ -43,15 +43,15 @@ uint64_t tlas4_cap_blocks(uint64_t nAL, uint64_t nInst);
 void launch_tlas4_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* blocks, uint32_t capBlocks,
                         void* scratch, hipStream_t s);
 void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* instances, const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks,
-                  hipStream_t s);
+                  hipStream_t s, uint32_t blocks7);
 // 8-wide TLAS in the BVH8_CWBVH node format + the unified two-level kernel for BVH8_CWBVH BLASes (kernels_tlas8.hip)
 uint64_t tlas8_cap_nodes(uint64_t nAL, uint64_t nInst);
 void launch_tlas8_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* nodes, uint32_t capNodes,
                         uint32_t* instRef, uint32_t capRefs, void* scratch, hipStream_t s);
 void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* instRef, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
-                  uint32_t* status, uint32_t blocks, hipStream_t s);
+                  uint32_t* status, uint32_t blocks, hipStream_t s, uint32_t blocks7);
 void launch_tlas2(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
-                  uint32_t* status, uint32_t blocks, hipStream_t s);   // BVH_GPU BLASes (kernels_tlas2.hip)
+                  uint32_t* status, uint32_t blocks, hipStream_t s, uint32_t blocks7);   // BVH_GPU BLASes (kernels_tlas2.hip)
 // device TLAS rebuild (kernels_tlasbuild.hip)
 size_t tlas_build_scratch_bytes(uint32_t n, size_t* sortTempBytes);
 hipError_t launch_tlas_rebuild(float4* tlasNodes, uint32_t* tlasIdx, float4* instances, const float* transformsDev, const float* blasBoundsDev,

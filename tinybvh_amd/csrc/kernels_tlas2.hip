@@ -36,8 +36,8 @@ enum : uint32_t { S_NODE = 0, S_TRI = 1, S_INST = 2 };
 // PN / PT / PI: a state's code runs in a pass if at least that many lanes are in the state, or it holds the most lanes.
 // STEAL > 0 (idle lanes needed): once the ray pool is dry, idle lanes take the top stack entry — a BLAS or a TLAS subtree — off a lane
 // that is still traversing.
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, int STEAL>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_tlas2(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, int STEAL, int WAVES = 6>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_tlas2(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
                                                                                            const float4* __restrict__ instances, const BlasDesc* __restrict__ blas,
                                                                                            QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint32_t stk[LDS_N][WG];
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 }  // namespace
 
 void launch_tlas2(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
-                  uint32_t* status, uint32_t blocks, hipStream_t s) {
+                  uint32_t* status, uint32_t blocks, hipStream_t s, uint32_t blocks7) {
 #define TBVH_T2(...)                                                                                                                                \
     do {                                                                                                                                            \
         if (anyhit) hipLaunchKernelGGL((k_tlas2<true, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);  \
@@ -235,13 +235,17 @@ void launch_tlas2(bool anyhit, int variant, const float4* tlasNodes, const uint3
     case 32: TBVH_T2(16, 16, 24, 8, 8, 0); return;     // the default thresholds without split rays
     case 33: TBVH_T2(16, 16, 24, 8, 8, 16); return;    // ... with, whatever the batch size
     case 34: TBVH_T2(12, 16, 24, 8, 8, 16); return;
+    case 29: TBVH_T2(16, 16, 24, 8, 8, 0, 7); return;      // register budget of 7 waves per SIMD (use with TBVH_BLOCKS_PER_CU=28)
+    case 30: TBVH_T2(16, 16, 24, 8, 8, 16, 7); return;
+    case 31: TBVH_T2(12, 16, 24, 8, 8, 16, 8); return;     // ... of 8 (32 per CU)
     default: break;
     }
 #endif
     (void)variant;
     // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
+    // without the split code the kernel fits the register budget of 7 waves per SIMD (28 workgroups per CU: +4…6 %); with it five dwords spill and it loses
     if (split_rays_wanted(q)) TBVH_T2(16, 16, 24, 8, 8, 16);
-    else TBVH_T2(16, 16, 24, 8, 8, 0);
+    else { blocks = blocks7; TBVH_T2(16, 16, 24, 8, 8, 0, 7); }
 #undef TBVH_T2
 }
 

@@ -244,8 +244,8 @@ __device__ __forceinline__ void tlas4_body(const float4* __restrict__ tlas4, con
     }
 }
 
-template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool ADAPT = false, bool STATS = false, int STEAL = 0>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_tlas4(const float4* __restrict__ tlas4, const float4* __restrict__ instances,
+template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool ADAPT = false, bool STATS = false, int STEAL = 0, int WAVES = 6>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_tlas4(const float4* __restrict__ tlas4, const float4* __restrict__ instances,
                                                                                            const BlasDesc* __restrict__ blas, QueryArgs q, uint32_t* __restrict__ status) {
     tlas4_body<ANYHIT, LDS_N, REFILL_MIN, PN, PT, PI, ADAPT, STATS, STEAL>(tlas4, instances, blas, q, status);
 }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 }  // namespace
 
 void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* instances, const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks,
-                  hipStream_t s) {
+                  hipStream_t s, uint32_t blocks7) {
 #define TBVH_T4(...)                                                                                                                     \
     do {                                                                                                                                 \
         if (anyhit) hipLaunchKernelGGL((k_tlas4<true, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlas4, instances, blas, q, status);  \
@@ -269,13 +269,14 @@ void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* i
     case 26: TBVH_T4(12, 16, 24, 8, 8, false, true); return;   // statistics: phases run and lanes per phase (q.stats)
     case 27: TBVH_T4(12, 16, 16, 16, 16, true); return;          // under the lockstep governor
     case 28: TBVH_T4(12, 16, 16, 8, 8, true); return;
-    case 29: TBVH_T4(12, 8, 24, 8, 8); return;
-    case 30: TBVH_T4(12, 16, 12, 12, 12); return;
+    case 29: TBVH_T4(12, 16, 24, 8, 8, false, false, 0, 7); return;   // 32 with the register budget of 7 waves per SIMD
     case 31: TBVH_T4(8, 16, 16, 16, 16); return;
     case 32: TBVH_T4(12, 16, 24, 8, 8); return;                      // the default thresholds without split rays
     case 33: TBVH_T4(12, 16, 24, 8, 8, false, false, 16); return;    // ... with, whatever the batch size
     case 34: TBVH_T4(12, 16, 24, 8, 8, false, false, 32); return;
     case 35: TBVH_T4(12, 16, 24, 8, 8, false, false, 8); return;
+    case 36: TBVH_T4(12, 16, 24, 8, 8, false, false, 16, 8); return;   // 33 with the register budget of 8 waves per SIMD (use with TBVH_BLOCKS_PER_CU=32)
+    case 30: TBVH_T4(12, 16, 24, 8, 8, false, false, 16, 7); return;   // ... of 7 (28 per CU)
     default: break;
     }
 #endif
@@ -285,8 +286,11 @@ void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* i
     // 8/8/8 4200 / 2490 (3050); 16/4/4 4130 / 2380 (2930); under the lockstep governor -2 %; 8-entry LDS stack top -6 %.
     // Before (nested-then-flat over the 2-wide TLAS, kernels_tlas.hip): 4170 / 1220 (1490).
     // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
-    if (split_rays_wanted(q)) TBVH_T4(12, 16, 24, 8, 8, false, false, 16);
-    else TBVH_T4(12, 16, 24, 8, 8);
+    // Register budget of 7 waves per SIMD (72 VGPRs, three spilled dwords) on 28 workgroups per CU: the BLASes of an instanced scene live in the L2s,
+    // the loop is latency-bound — 8.3 M camera rays +4 %, 33 M +8 %, random rays +2…5 % over 6 waves; 8 waves (64 VGPRs, eight spilled) lose
+    blocks = blocks7;
+    if (split_rays_wanted(q)) TBVH_T4(12, 16, 24, 8, 8, false, false, 16, 7);
+    else TBVH_T4(12, 16, 24, 8, 8, false, false, 0, 7);
 #undef TBVH_T4
 }
 

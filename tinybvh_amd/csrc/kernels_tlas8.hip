@@ -216,8 +216,8 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
     }
 }
 
-template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool STATS = false, int STEAL = 0>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_tlas8(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ instRef,
+template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool STATS = false, int STEAL = 0, int WAVES = 6>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_tlas8(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ instRef,
                                                                                            const float4* __restrict__ instances, const BlasDesc* __restrict__ blas,
                                                                                            QueryArgs q, uint32_t* __restrict__ status) {
     tlas8_body<ANYHIT, LDS_N, REFILL_MIN, PN, PT, PI, STATS, STEAL>(tlasNodes, instRef, instances, blas, q, status);
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 }  // namespace
 
 void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* instRef, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
-                  uint32_t* status, uint32_t blocks, hipStream_t s) {
+                  uint32_t* status, uint32_t blocks, hipStream_t s, uint32_t blocks7) {
 #define TBVH_T8(...)                                                                                                                                \
     do {                                                                                                                                            \
         if (anyhit) hipLaunchKernelGGL((k_tlas8<true, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, instRef, instances, blas, q, status);  \
@@ -240,21 +240,24 @@ void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint3
     case 24: TBVH_T8(12, 16, 24, 16, 16); return;
     case 25: TBVH_T8(12, 16, 16, 4, 4); return;
     case 26: TBVH_T8(12, 16, 24, 8, 8, true); return;   // statistics
-    case 29: TBVH_T8(12, 8, 24, 8, 8); return;
-    case 30: TBVH_T8(12, 16, 32, 8, 8); return;
     case 31: TBVH_T8(8, 16, 24, 8, 8); return;
     case 32: TBVH_T8(12, 16, 24, 8, 8); return;                // the default thresholds without split rays
     case 33: TBVH_T8(10, 16, 24, 8, 8, false, 16); return;     // ... with, whatever the batch size (LDS: 10 stack entries + the split groups still fit 24 waves per CU)
     case 34: TBVH_T8(10, 16, 24, 8, 8, false, 32); return;
     case 35: TBVH_T8(8, 16, 24, 8, 8, false, 16); return;
     case 36: TBVH_T8(10, 16, 24, 8, 8); return;
+    case 29: TBVH_T8(10, 16, 24, 8, 8, false, 0, 7); return;     // register budget of 7 waves per SIMD (use with TBVH_BLOCKS_PER_CU=28)
+    case 30: TBVH_T8(8, 16, 24, 8, 8, false, 16, 7); return;     // ... with split rays
     default: break;
     }
 #endif
     (void)variant;
     // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
-    if (split_rays_wanted(q)) TBVH_T8(8, 16, 24, 8, 8, false, 16);   // (8 stack entries in LDS: with 12 and the split groups next to them only 20 waves per CU fit; 8.3 M camera rays +7 % over 10)
-    else TBVH_T8(12, 16, 24, 8, 8);
+    // 7 waves per SIMD on 28 workgroups per CU (kernels_tlas4.hip): +4…5 %.  LDS sets the stack entries kept there: 8 next to the split groups
+    // (with 12 only 20 waves per CU fit; 8.3 M camera rays +7 % over 10), 10 without them
+    blocks = blocks7;
+    if (split_rays_wanted(q)) TBVH_T8(8, 16, 24, 8, 8, false, 16, 7);
+    else TBVH_T8(10, 16, 24, 8, 8, false, 0, 7);
 #undef TBVH_T8
 }
 
