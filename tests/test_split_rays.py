@@ -84,3 +84,43 @@ def test_split_and_unsplit_kernels_agree_up_to_ties(ctx, cls, plain):
     assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
     assert c["tie"] <= max(4, c["hits"] // 1500), c
     sc.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", LAYOUTS)
+def test_large_batches_run_the_unsplit_kernels_and_agree(ctx, cls):
+    """Batches of 12 M rays and more run the kernels WITHOUT split rays (the tail is 5 % of such a launch): the same rays traced as part of a
+    12.8 M-ray launch and as a 1 M-ray launch of their own give the same records, ties aside."""
+    verts, _ = scenes.get("sponza")
+    sc = cls(ctx).Build(verts)
+    side = 3584                                   # 12.8 M rays
+    n, m = side * side, 1 << 20
+    cam = R.camera(*scenes.SPONZA_CAMERAS[0], side, side, 1, 1)
+    d = ctx.malloc(n * 64)
+    ctx.generate_primary(cam, d, 0, n)
+    sc.intersect_device_fresh(d, n, 1e30)
+    big = np.zeros(m, tb.RAY_DTYPE); ctx.from_device(big, d)
+    sc.intersect_device_fresh(d, m, 1e30)
+    small = np.zeros(m, tb.RAY_DTYPE); ctx.from_device(small, d)
+    ctx.free(d)
+    c = compare_hits(small, big)
+    assert c["hits"] > m // 2 and c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
+    assert c["tie"] <= max(4, c["hits"] // 1500), c
+    sc.free()
+
+
+@pytest.mark.gpu
+def test_split_rays_can_be_switched_off(oracle, monkeypatch):
+    """TBVH_SPLIT_RAYS=0 (read at tbvh_init): small batches run the kernels without split rays; same records."""
+    monkeypatch.setenv("TBVH_SPLIT_RAYS", "0")
+    c2 = tb.Context(0)
+    try:
+        verts = scenes.soup(20_000, seed=13)
+        for cls in LAYOUTS:
+            sc = cls(c2).Build(verts)
+            rays = R.random_rays(30_000, (0, 0, 0), (10, 10, 10), seed=2)
+            want = oracle.bvh2_intersect(sc.host.bvh2_nodes(), sc.host.bvh2_prim_idx(), verts, rays)
+            _check(sc.Intersect(rays.copy()), want, cls.__name__)
+            sc.free()
+    finally:
+        c2.close()
