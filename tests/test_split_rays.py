@@ -154,3 +154,53 @@ def test_large_two_level_batches_agree_with_small_ones(ctx, cls):
     same = (small["prim"] == big["prim"]) & (small["t"] < 1e30)
     assert np.array_equal(small["inst"][same], big["inst"][same])
     tlas.free(); blas.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", LAYOUTS)
+def test_every_hit_a_tie(ctx, oracle, cls):
+    """A scene in which every triangle exists twice: every hit is a tie between two prims, the case in which the members of a split ray
+    disagree about the winner all the time.  t, u, v must be the oracle's bit for bit, prim one of the two copies."""
+    base = scenes.soup(8_000, seed=17)
+    verts = np.ascontiguousarray(np.concatenate([base, base]))
+    ntri = base.shape[0] // 3
+    sc = cls(ctx).Build(verts)
+    h = sc.host
+    rays = R.random_rays(20_000, (0, 0, 0), (10, 10, 10), seed=4)
+    want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
+    for rep in range(3):
+        got = sc.Intersect(rays.copy())
+        hit = want["t"] < 1e30
+        assert np.array_equal(got["t"] < 1e30, hit)
+        for f in ("t", "u", "v"):
+            assert np.array_equal(got[f][hit].view(np.uint32), want[f][hit].view(np.uint32)), (cls.__name__, f, rep)
+        assert np.array_equal(got["prim"][hit] % ntri, want["prim"][hit] % ntri), (cls.__name__, rep)
+    sc.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cls", LAYOUTS)
+def test_every_instance_twice(ctx, cls):
+    """Two-level: every instance exists twice with the same transform, so every hit is a tie between two instances.  The record must be the
+    one of the scene with each instance once — t, u, v, prim bit for bit — with hit.inst naming either copy."""
+    verts = scenes.blob(5_000, seed=8)
+    blas = cls(ctx).Build(verts)
+    g = np.stack(np.meshgrid(np.arange(3), np.arange(3), np.arange(3), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    k = g.shape[0]
+    ang = (0.5 + np.arange(k) * 0.29).astype(np.float32)
+    T = np.zeros((k, 4, 4), np.float32)
+    T[:, 0, 0] = np.cos(ang) * 0.8; T[:, 0, 2] = np.sin(ang) * 0.8; T[:, 1, 1] = 0.8; T[:, 2, 0] = -np.sin(ang) * 0.8; T[:, 2, 2] = np.cos(ang) * 0.8; T[:, 3, 3] = 1
+    T[:, :3, 3] = g * 2.2
+    once = tb.TLAS(ctx).Build(tb.make_instances(T, np.zeros(k, np.uint32)), [blas])
+    twice = tb.TLAS(ctx).Build(tb.make_instances(np.concatenate([T, T]), np.zeros(2 * k, np.uint32)), [blas])
+    rays = R.random_rays(40_000, (-1.0, -1.0, -1.0), (6.0, 6.0, 6.0), seed=6)
+    want = once.Intersect(rays.copy())
+    hit = want["t"] < 1e30
+    assert hit.sum() > 5000
+    for rep in range(3):
+        got = twice.Intersect(rays.copy())
+        assert np.array_equal(got["t"] < 1e30, hit)
+        for f in ("t", "u", "v", "prim"):
+            assert np.array_equal(got[f][hit].view(np.uint32), want[f][hit].view(np.uint32)), (cls.__name__, f, rep)
+        assert np.array_equal(got["inst"][hit] % k, want["inst"][hit]), (cls.__name__, rep)
+    once.free(); twice.free(); blas.free()
