@@ -101,7 +101,7 @@ def main():
             tb.lib.tbvh_debug_stats(ctx._h, st, 1)
             tot = max(sum(int(x) for x in st), 1)
             print("   incoherent: generation cohesion histogram (<.25 -.375 -.5 -.6 -.7 -.8 -.9 >=.9): " + " ".join(f"{int(x) / tot:.3f}" for x in st), flush=True)
-        if a.variant in (15, 26):
+        if a.variant in (15, 26) and a.layout != 5:   # statistics variants of the flat loop (15) and of k_tlas4 / k_tlas8 (26)
             import ctypes as C
             st = (C.c_uint64 * 8)()
             tb.lib.tbvh_debug_stats(ctx._h, st, 1)
