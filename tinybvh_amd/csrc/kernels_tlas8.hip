@@ -37,7 +37,7 @@ enum : uint32_t { S_NODE = 0, S_TRI = 1, S_INST = 2 };
 
 // STEAL > 0 (idle lanes needed): once the ray pool is dry, idle lanes take the top stack entry — a node group of the BLAS or of the TLAS, or a
 // parked instance group — off a lane that is still traversing (ray_split.h)
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, bool STATS, int STEAL = 0>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, bool STATS, int STEAL = 0, bool FUSE = false>
 __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ instRef, const float4* __restrict__ instances,
                                            const BlasDesc* __restrict__ blas, const QueryArgs& q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -121,6 +121,9 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
         bool done = false, next = false;   // next: this lane's step is over, decide what it does in the following iteration
         if (tail && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
 
+        // FUSE: a lane whose triangle group is finished, or that has just entered an instance, takes its node step in the same pass (the
+        // single-level kernel's schedule: one triangle AND one node per pass) instead of waiting for the next one
+        bool cont = false;
         if (STEAL && ANYHIT && done) {
         } else if (state == S_TRI) { if (runT) {
             // ---- one triangle of the BLAS node's triangle group ------------------------------------------------------------
@@ -139,6 +142,7 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
                 }
             }
             next = !done;
+            if (FUSE && !done && tg.y == 0 && cw_has_child(ng)) { state = S_NODE; next = false; cont = true; }
         } } else if (state == S_INST) { if (runI) {
             // ---- enter one instance of the TLAS node's instance group (tiny_bvh.h:3326-3333) ----------------------------------
             const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
@@ -168,9 +172,10 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
                 curInst = ii; base = st.sp; inBlas = true;
                 oct = cw_oct(D);
                 ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
-                state = S_NODE;
+                state = S_NODE; cont = FUSE;
             } else next = true;
-        } } else if (runN) {
+        } } else if (runN) cont = true;
+        if (cont && runN && state == S_NODE && !done) {
             // ---- one node of the TLAS or of the instance's BLAS: same format, same code ------------------------------------------
             if (cw_has_child(ng)) {
                 const uint32_t ci = cw_next_child(ng, oct);
@@ -216,11 +221,11 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
     }
 }
 
-template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool STATS = false, int STEAL = 0, int WAVES = 6>
+template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool STATS = false, int STEAL = 0, int WAVES = 6, bool FUSE = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_tlas8(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ instRef,
                                                                                            const float4* __restrict__ instances, const BlasDesc* __restrict__ blas,
                                                                                            QueryArgs q, uint32_t* __restrict__ status) {
-    tlas8_body<ANYHIT, LDS_N, REFILL_MIN, PN, PT, PI, STATS, STEAL>(tlasNodes, instRef, instances, blas, q, status);
+    tlas8_body<ANYHIT, LDS_N, REFILL_MIN, PN, PT, PI, STATS, STEAL, FUSE>(tlasNodes, instRef, instances, blas, q, status);
 }
 
 }  // namespace
@@ -248,6 +253,8 @@ void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint3
     case 36: TBVH_T8(10, 16, 24, 8, 8); return;
     case 29: TBVH_T8(10, 16, 24, 8, 8, false, 0, 7); return;     // register budget of 7 waves per SIMD (use with TBVH_BLOCKS_PER_CU=28)
     case 30: TBVH_T8(8, 16, 24, 8, 8, false, 16, 7); return;     // ... with split rays
+    case 27: TBVH_T8(8, 16, 24, 8, 8, false, 16, 7, true); return;   // 30 with fused triangle / instance -> node steps
+    case 28: TBVH_T8(8, 16, 24, 8, 8, true, 16, 7, true); return;    // ... statistics
     default: break;
     }
 #endif
@@ -256,8 +263,9 @@ void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint3
     // 7 waves per SIMD on 28 workgroups per CU (kernels_tlas4.hip): +4…5 %.  LDS sets the stack entries kept there: 8 next to the split groups
     // (with 12 only 20 waves per CU fit; 8.3 M camera rays +7 % over 10), 10 without them
     blocks = blocks7;
-    if (split_rays_wanted(q)) TBVH_T8(8, 16, 24, 8, 8, false, 16, 7);
-    else TBVH_T8(10, 16, 24, 8, 8, false, 0, 7);
+    // fused steps (a lane done with its triangles, or entering an instance, takes a node step in the same pass): camera rays +4 %, IsOccluded +5 %
+    if (split_rays_wanted(q)) TBVH_T8(8, 16, 24, 8, 8, false, 16, 7, true);
+    else TBVH_T8(10, 16, 24, 8, 8, false, 0, 7, true);
 #undef TBVH_T8
 }
 
