@@ -127,18 +127,20 @@ def test_split_rays_can_be_switched_off(oracle, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cls", LAYOUTS)
+@pytest.mark.parametrize("cls", LAYOUTS + ["mixed"])
 def test_large_two_level_batches_agree_with_small_ones(ctx, cls):
-    """The two-level kernels: 12.8 M rays (kernels without split rays) against the first 1 M of them as a launch of their own."""
+    """The two-level kernels: 12.8 M rays (kernels without split rays) against the first 1 M of them as a launch of their own.
+    "mixed": BVH8_CWBVH and BVH_GPU BLASes under one TLAS, instance by instance."""
     verts = scenes.blob(6_000, seed=6)
-    blas = cls(ctx).Build(verts)
+    blases = [tb.BVH8_CWBVH(ctx).Build(verts), tb.BVH_GPU(ctx).Build(verts)] if cls == "mixed" else [cls(ctx).Build(verts)]
+    blas = blases[0]
     g = np.stack(np.meshgrid(np.arange(5), np.arange(5), np.arange(5), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
     k = g.shape[0]
     ang = (0.2 + np.arange(k) * 0.41).astype(np.float32)
     T = np.zeros((k, 4, 4), np.float32)
     T[:, 0, 0] = np.cos(ang) * 0.7; T[:, 0, 2] = np.sin(ang) * 0.7; T[:, 1, 1] = 0.7; T[:, 2, 0] = -np.sin(ang) * 0.7; T[:, 2, 2] = np.cos(ang) * 0.7; T[:, 3, 3] = 1
     T[:, :3, 3] = g * 2.0
-    tlas = tb.TLAS(ctx).Build(tb.make_instances(T, np.zeros(k, np.uint32)), [blas])
+    tlas = tb.TLAS(ctx).Build(tb.make_instances(T, (np.arange(k) % len(blases)).astype(np.uint32)), blases)
     side = 3584
     n, m = side * side, 1 << 20
     cam = R.camera((-6.0, 8.0, -9.0), (0.62, -0.38, 0.68), side, side, 1, 1)
@@ -153,7 +155,9 @@ def test_large_two_level_batches_agree_with_small_ones(ctx, cls):
     assert c["hits"] > 1000 and c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
     same = (small["prim"] == big["prim"]) & (small["t"] < 1e30)
     assert np.array_equal(small["inst"][same], big["inst"][same])
-    tlas.free(); blas.free()
+    tlas.free()
+    for x in blases:
+        x.free()
 
 
 @pytest.mark.gpu

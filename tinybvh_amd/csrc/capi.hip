@@ -97,6 +97,7 @@ struct tbvh_scene {
     float4* instances = nullptr;
     BlasDesc* blasDesc = nullptr;
     int blasLayout = 0;
+    bool blasMixCw2 = false;          // blasLayout == 0 and every BLAS is BVH8_CWBVH or BVH_GPU: the reference's two BLAS types (traverse_tlas.cl:50-72)
     uint64_t capNodes = 0, capIdx = 0, capInst = 0;
     uint64_t nInst = 0, nBlas = 0, nTlasNodes = 0, nTlasIdx = 0;
     // the same TLAS collapsed 4-wide in the BVH4_GPU node format (kernels_tlas4.hip), kept current by every upload / update / device rebuild;
@@ -354,9 +355,9 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             c->timed = true;
             return 0;
         }
-        if (s->tlas8 && s->blasLayout == TBVH_LAYOUT_CWBVH && (tv == 0 || (tv >= 21 && tv <= 36))) {   // BVH8_CWBVH BLASes: the unified 8-wide kernel
+        if (s->tlas8 && (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2) && (tv == 0 || (tv >= 21 && tv <= 36))) {   // BVH8_CWBVH BLASes (or those and BVH_GPU ones): the unified 8-wide kernel
             q.spillStride = c->spillEntries / 2;   // 8-byte stack entries
-            launch_tlas8(any, tv, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
+            launch_tlas8(any, tv, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7, s->blasMixCw2);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
             c->timed = true;
@@ -610,7 +611,7 @@ namespace {
 // (re)build the 4-wide TLAS from the BVH_GPU nodes on the device; asynchronous on the context's stream
 int buildTlas4(tbvh_scene* s) {
     tbvh_context* c = s->ctx;
-    if (s->blasLayout == TBVH_LAYOUT_CWBVH) {
+    if (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2) {
         const uint64_t cap = tlas8_cap_nodes(s->nTlasNodes, s->nInst);
         if (cap > 0x00ffffffull) return 0;   // wide-node indices share a word with 8 flag bits in places: the flat loop serves larger TLASes
         if (cap > s->tlas8Cap) {
@@ -693,6 +694,8 @@ int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, cons
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
     s->isTlas = true; s->blasLayout = layout; s->nBlas = nBlas;
+    s->blasMixCw2 = layout == 0;
+    for (uint64_t i = 0; i < nBlas; i++) if (blas[i]->layout == TBVH_LAYOUT_BVH4_GPU) s->blasMixCw2 = false;
     for (uint64_t i = 0; i < nBlas; i++) { s->blasList.push_back(blas[i]); blas[i]->usedBy.push_back(s); }
     hipError_t e = hipMalloc((void**)&s->blasDesc, nBlas * sizeof(BlasDesc));
     if (e == hipSuccess) e = hipMemcpy(s->blasDesc, desc.data(), nBlas * sizeof(BlasDesc), hipMemcpyHostToDevice);

@@ -49,7 +49,7 @@ uint64_t tlas8_cap_nodes(uint64_t nAL, uint64_t nInst);
 void launch_tlas8_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* nodes, uint32_t capNodes,
                         uint32_t* instRef, uint32_t capRefs, void* scratch, hipStream_t s);
 void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* instRef, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
-                  uint32_t* status, uint32_t blocks, hipStream_t s, uint32_t blocks7);
+                  uint32_t* status, uint32_t blocks, hipStream_t s, uint32_t blocks7, bool mixed = false);
 void launch_tlas2(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
                   uint32_t* status, uint32_t blocks, hipStream_t s, uint32_t blocks7);   // BVH_GPU BLASes (kernels_tlas2.hip)
 // device TLAS rebuild (kernels_tlasbuild.hip)

@@ -33,11 +33,14 @@ __device__ __forceinline__ float safercp(float x) {
 // =====================================================================================================================
 // traversal
 // =====================================================================================================================
-enum : uint32_t { S_NODE = 0, S_TRI = 1, S_INST = 2 };
+enum : uint32_t { S_NODE = 0, S_TRI = 1, S_INST = 2, S_NODE2 = 3, S_TRI2 = 4 };   // S_NODE2 / S_TRI2: a BVH_GPU BLAS under the 8-wide TLAS (MIXED)
 
 // STEAL > 0 (idle lanes needed): once the ray pool is dry, idle lanes take the top stack entry — a node group of the BLAS or of the TLAS, or a
 // parked instance group — off a lane that is still traversing (ray_split.h)
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, bool STATS, int STEAL = 0, bool FUSE = false>
+// MIXED: the BLASes are BVH8_CWBVH or BVH_GPU, instance by instance (BlasDesc::layout) — the two BLAS types of the reference's traverse_tlas
+// (traverse_tlas.cl:50-72: blasType 4 = compressed-wide static geometry, 2 / 3 = Aila-Laine nodes for geometry that is refitted or rebuilt).
+// The TLAS is the 8-wide one; a BVH_GPU BLAS adds two lane states with the k_bvh2 node step and leaf loop; its stack entries are node indices.
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, bool STATS, int STEAL = 0, bool FUSE = false, bool MIXED = false>
 __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ instRef, const float4* __restrict__ instances,
                                            const BlasDesc* __restrict__ blas, const QueryArgs& q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -55,6 +58,9 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
     int base = 0;
     GlobalF4 cur(tlasNodes), btris;                   // node stream being walked (TLAS or the instance's BLAS); the BLAS's triangle records
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u);
+    float3 ro = make_float3(0, 0, 0);                 // MIXED, inside a BVH_GPU BLAS: O * rD (SLAB_TEST_TWO_NODES form); its node, pending leaf
+    uint32_t node2 = 0, triLeft = 0, triPtr = 0;
+    bool blas2 = false;                               // the current BLAS is a BVH_GPU one
     unsigned long long sIter = 0, sAct = 0, sN = 0, sLN = 0, sT = 0, sLT = 0, sI = 0, sLI = 0;   // STATS
     __shared__ SplitLds<STEAL ? WG : 1> split;
     int grp = -1;
@@ -71,7 +77,7 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
                     rayMask = as_u32(rp->O.w);
                     hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
                     hitInst = as_u32(rp->rD.w);
-                    found = false; inBlas = false; state = S_NODE; st.sp = 0;
+                    found = false; inBlas = false; blas2 = false; state = S_NODE; st.sp = 0;
                     oct = cw_oct(D);
                     ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
                     cur = GlobalF4(tlasNodes);
@@ -96,17 +102,20 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
                 part.x = __shfl(part.x, src); part.y = __shfl(part.y, src); lvl = __shfl(lvl, src);
                 const int donorInBlas = __shfl((int)inBlas, src);
                 rayMask = __shfl(rayMask, src); curInst = __shfl(curInst, src); blasIdx = __shfl(blasIdx, src);
+                const int donor2 = MIXED ? __shfl((int)blas2, src) : 0;
                 if (m.takes) {
-                    found = false; st.sp = 0; base = 0;
+                    found = false; st.sp = 0; base = 0; blas2 = false; triLeft = 0;
                     if (lvl) {   // (back at its empty stack the lane "returns" to a TLAS level with nothing left: done)
                         const BlasDesc bd = blas[blasIdx];
                         inBlas = true; cur = GlobalF4(bd.nodes); btris = GlobalF4(bd.tris);
+                        blas2 = MIXED && donor2;
                     } else {
                         inBlas = false; cur = GlobalF4(tlasNodes);
                         if (donorInBlas) { const RayRec* rp = q.rays + ri; O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD); }   // the donor's registers hold the instance-space ray
                     }
                     oct = cw_oct(D);
-                    if (part.y > 0x00FFFFFFu) { ng = part; tg = make_uint2(0u, 0u); state = S_NODE; }
+                    if (MIXED && blas2) { ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z); node2 = part.x; ng = make_uint2(0u, 0u); tg = make_uint2(0u, 0u); state = S_NODE2; }
+                    else if (part.y > 0x00FFFFFFu) { ng = part; tg = make_uint2(0u, 0u); state = S_NODE; }
                     else { tg = part; ng = make_uint2(0u, 0u); state = S_INST; }   // a parked instance group (TLAS level only)
                     active = true;
                 }
@@ -114,8 +123,11 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
         }
         const uint32_t nN = (uint32_t)__popcll(__ballot(active && state == S_NODE)), nT = (uint32_t)__popcll(__ballot(active && state == S_TRI)),
                        nI = (uint32_t)__popcll(__ballot(active && state == S_INST));
-        const uint32_t nMax = nN > nT ? (nN > nI ? nN : nI) : (nT > nI ? nT : nI);
+        const uint32_t nN2 = MIXED ? (uint32_t)__popcll(__ballot(active && state == S_NODE2)) : 0u, nT2 = MIXED ? (uint32_t)__popcll(__ballot(active && state == S_TRI2)) : 0u;
+        uint32_t nMax = nN > nT ? (nN > nI ? nN : nI) : (nT > nI ? nT : nI);
+        if (MIXED) { nMax = nN2 > nMax ? nN2 : nMax; nMax = nT2 > nMax ? nT2 : nMax; }
         const bool runN = nN >= (uint32_t)PN || nN == nMax, runT = nT >= (uint32_t)PT || nT == nMax, runI = nI >= (uint32_t)PI || nI == nMax;
+        const bool runN2 = MIXED && (nN2 >= (uint32_t)PN || nN2 == nMax), runT2 = MIXED && (nT2 >= (uint32_t)PT || nT2 == nMax);
         if (STATS) { sIter++; sAct += nN + nT + nI; if (runN && nN) { sN++; sLN += nN; } if (runT && nT) { sT++; sLT += nT; } if (runI && nI) { sI++; sLI += nI; } }
         if (!active) continue;
         bool done = false, next = false;   // next: this lane's step is over, decide what it does in the following iteration
@@ -124,8 +136,50 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
         // FUSE: a lane whose triangle group is finished, or that has just entered an instance, takes its node step in the same pass (the
         // single-level kernel's schedule: one triangle AND one node per pass) instead of waiting for the next one
         bool cont = false;
+        bool pop2 = false;   // MIXED: this lane's BVH_GPU step ended with nothing pending
         if (STEAL && ANYHIT && done) {
-        } else if (state == S_TRI) { if (runT) {
+        } else if (MIXED && state == S_TRI2) { if (runT2) {
+            // ---- one triangle of the current leaf of a BVH_GPU BLAS (records {v0|prim, e1, e2}, kernels_query.hip: k_bvh2) -------------------
+            const float4 v0 = btris[triPtr], e1 = btris[triPtr + 1], e2 = btris[triPtr + 2];
+            triPtr += 3u; triLeft--;
+            TriHit h;
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+                const BlasDesc bd = blas[blasIdx];
+                if (!bd.opmap || omm_opaque(Omm{bd.opmap, bd.opmapN}, as_u32(v0.w), h.u, h.v)) {
+                    found = true; hitInst = curInst;
+                    if (ANYHIT) done = true;
+                    else hit = make_float4(h.t, h.u, h.v, v0.w);
+                    if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
+                }
+            }
+            if (!done && triLeft == 0) pop2 = true;
+        } } else if (MIXED && state == S_NODE2) { if (runN2) {
+            // ---- one node of a BVH_GPU BLAS: SLAB_TEST_TWO_NODES (tiny_bvh.h:3202-3220), as k_bvh2 / k_tlas2 -----------------------------------
+            const float4 n0 = cur[node2 * 4], n1 = cur[node2 * 4 + 1], n2 = cur[node2 * 4 + 2], n3 = cur[node2 * 4 + 3];
+            const uint32_t cnt = as_u32(n2.w);
+            if (cnt) { triLeft = cnt; triPtr = as_u32(n3.w) * 3u; state = S_TRI2; }
+            else {
+                const float lx1 = __builtin_fmaf(n0.x, rD.x, -ro.x), lx2 = __builtin_fmaf(n1.x, rD.x, -ro.x);
+                const float ly1 = __builtin_fmaf(n0.y, rD.y, -ro.y), ly2 = __builtin_fmaf(n1.y, rD.y, -ro.y);
+                const float lz1 = __builtin_fmaf(n0.z, rD.z, -ro.z), lz2 = __builtin_fmaf(n1.z, rD.z, -ro.z);
+                const float rx1 = __builtin_fmaf(n2.x, rD.x, -ro.x), rx2 = __builtin_fmaf(n3.x, rD.x, -ro.x);
+                const float ry1 = __builtin_fmaf(n2.y, rD.y, -ro.y), ry2 = __builtin_fmaf(n3.y, rD.y, -ro.y);
+                const float rz1 = __builtin_fmaf(n2.z, rD.z, -ro.z), rz2 = __builtin_fmaf(n3.z, rD.z, -ro.z);
+                const float tminL = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx1, lx2), __builtin_fminf(ly1, ly2)), __builtin_fminf(lz1, lz2)), 0.0f);
+                const float tmaxL = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2)), __builtin_fmaxf(lz1, lz2)), hit.x);
+                const float tminR = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(rx1, rx2), __builtin_fminf(ry1, ry2)), __builtin_fminf(rz1, rz2)), 0.0f);
+                const float tmaxR = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2)), __builtin_fmaxf(rz1, rz2)), hit.x);
+                const bool hL = tmaxL >= tminL, hR = tmaxR >= tminR;
+                uint32_t l = as_u32(n0.w), r = as_u32(n1.w);
+                if (hL && hR) {
+                    if (tminL > tminR) { const uint32_t t = l; l = r; r = t; }
+                    st.push(make_uint2(r, 0u));
+                    node2 = l;
+                } else if (hL) node2 = l;
+                else if (hR) node2 = r;
+                else pop2 = true;
+            }
+        } } else if (state == S_TRI) { if (runT) {
             // ---- one triangle of the BLAS node's triangle group ------------------------------------------------------------
             const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
             tg.y &= ~(1u << ti);
@@ -171,8 +225,14 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
                 cur = GlobalF4(bd.nodes); btris = GlobalF4(bd.tris);
                 curInst = ii; base = st.sp; inBlas = true;
                 oct = cw_oct(D);
-                ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
-                state = S_NODE; cont = FUSE;
+                if (MIXED && bd.layout == (uint32_t)kLayoutBvhGpu) {
+                    blas2 = true; ro = make_float3(O.x * rD.x, O.y * rD.y, O.z * rD.z);
+                    ng = make_uint2(0u, 0u); tg = make_uint2(0u, 0u); node2 = 0; triLeft = 0;
+                    state = S_NODE2;
+                } else {
+                    ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u);
+                    state = S_NODE; cont = FUSE;
+                }
             } else next = true;
         } } else if (runN) cont = true;
         if (cont && runN && state == S_NODE && !done) {
@@ -185,6 +245,10 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
                 tg = make_uint2(r.triBase, r.hitmask & 0x00FFFFFFu);
             }
             next = true;
+        }
+        if (MIXED && pop2) {
+            if (st.sp == base) { blas2 = false; next = true; }   // the BVH_GPU BLAS is done: back to the TLAS below (ng and tg are empty, so `next` goes to the stack)
+            else { node2 = st.pop().x; state = S_NODE2; }
         }
         if (next) {
             // ---- what next: the group in hand, else the stack; a BLAS traversal back at its base returns to the TLAS with the world ray ----
@@ -221,24 +285,34 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
     }
 }
 
-template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool STATS = false, int STEAL = 0, int WAVES = 6, bool FUSE = false>
+template <bool ANYHIT, int LDS_N = 12, int REFILL_MIN = 16, int PN = 24, int PT = 8, int PI = 8, bool STATS = false, int STEAL = 0, int WAVES = 6, bool FUSE = false, bool MIXED = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_tlas8(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ instRef,
                                                                                            const float4* __restrict__ instances, const BlasDesc* __restrict__ blas,
                                                                                            QueryArgs q, uint32_t* __restrict__ status) {
-    tlas8_body<ANYHIT, LDS_N, REFILL_MIN, PN, PT, PI, STATS, STEAL, FUSE>(tlasNodes, instRef, instances, blas, q, status);
+    tlas8_body<ANYHIT, LDS_N, REFILL_MIN, PN, PT, PI, STATS, STEAL, FUSE, MIXED>(tlasNodes, instRef, instances, blas, q, status);
 }
 
 }  // namespace
 
 void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* instRef, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
-                  uint32_t* status, uint32_t blocks, hipStream_t s, uint32_t blocks7) {
+                  uint32_t* status, uint32_t blocks, hipStream_t s, uint32_t blocks7, bool mixed) {
 #define TBVH_T8(...)                                                                                                                                \
     do {                                                                                                                                            \
         if (anyhit) hipLaunchKernelGGL((k_tlas8<true, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, instRef, instances, blas, q, status);  \
         else hipLaunchKernelGGL((k_tlas8<false, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, instRef, instances, blas, q, status);        \
     } while (0)
 #if TBVH_EXPERIMENTS
-    switch (variant) {
+    if (mixed) switch (variant) {   // phase thresholds of the mixed-layout kernel
+    case 21: TBVH_T8(8, 16, 32, 32, 32, false, 16, 6, true, true); return;
+    case 22: TBVH_T8(8, 16, 16, 8, 8, false, 16, 6, true, true); return;
+    case 23: TBVH_T8(8, 16, 8, 8, 8, false, 16, 6, true, true); return;
+    case 24: TBVH_T8(8, 16, 24, 16, 16, false, 16, 6, true, true); return;
+    case 25: TBVH_T8(8, 16, 16, 4, 4, false, 16, 6, true, true); return;
+    case 29: TBVH_T8(8, 16, 12, 8, 8, false, 16, 6, true, true); return;
+    case 30: TBVH_T8(8, 16, 24, 8, 8, false, 16, 7, true, true); return;   // register budget of 7 waves per SIMD
+    default: break;
+    }
+    else switch (variant) {
     case 21: TBVH_T8(12, 16, 32, 32, 32); return;
     case 22: TBVH_T8(12, 16, 16, 8, 8); return;
     case 23: TBVH_T8(12, 16, 8, 8, 8); return;
@@ -262,8 +336,15 @@ void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint3
     // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
     // 7 waves per SIMD on 28 workgroups per CU (kernels_tlas4.hip): +4…5 %.  LDS sets the stack entries kept there: 8 next to the split groups
     // (with 12 only 20 waves per CU fit; 8.3 M camera rays +7 % over 10), 10 without them
-    blocks = blocks7;
     // fused steps (a lane done with its triangles, or entering an instance, takes a node step in the same pass): camera rays +4 %, IsOccluded +5 %
+    if (mixed) {   // BVH8_CWBVH and BVH_GPU BLASes under one TLAS: five lane states, so a state's code runs from 8 lanes on (1000 instances, half of each
+        // kind: thresholds 32/32/32 2100 / 1080, 24/8/8 2540 / 1320, 16/8/8 2630 / 1440, 8/8/8 2790 / 1490 MRays/s camera / random rays; the three-mode
+        // loop of kernels_tlas.hip 2350 / 870); the two more states need the registers of 6 waves per SIMD (7: -4 %)
+        if (split_rays_wanted(q)) TBVH_T8(8, 16, 8, 8, 8, false, 16, 6, true, true);
+        else TBVH_T8(12, 16, 8, 8, 8, false, 0, 6, true, true);
+        return;
+    }
+    blocks = blocks7;
     if (split_rays_wanted(q)) TBVH_T8(8, 16, 24, 8, 8, false, 16, 7, true);
     else TBVH_T8(10, 16, 24, 8, 8, false, 0, 7, true);
 #undef TBVH_T8

@@ -14,7 +14,7 @@ from tinybvh_amd import rays as R  # noqa: E402
 from tinybvh_amd import scenes  # noqa: E402
 
 
-def instances(n_side, t, scale=0.07 * 10):
+def instances(n_side, t, scale=0.07 * 10, n_blas=1):
     g = np.stack(np.meshgrid(np.arange(n_side), np.arange(n_side), np.arange(n_side), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
     k = g.shape[0]
     ang = (t * 0.5 + np.arange(k) * 0.37).astype(np.float32)
@@ -22,7 +22,7 @@ def instances(n_side, t, scale=0.07 * 10):
     T = np.zeros((k, 4, 4), np.float32)
     T[:, 0, 0] = c * scale; T[:, 0, 2] = s * scale; T[:, 1, 1] = scale; T[:, 2, 0] = -s * scale; T[:, 2, 2] = c * scale; T[:, 3, 3] = 1
     T[:, :3, 3] = g * 2.0
-    return tb.make_instances(T, np.zeros(k, np.uint32))
+    return tb.make_instances(T, (np.arange(k) % n_blas).astype(np.uint32))
 
 
 def main():
@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--side", type=int, default=10)
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--layout2", type=int, default=0, help="a second BLAS of this layout: every other instance uses it (mixed BLAS layouts under one TLAS)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--random", type=int, default=0, help="also trace this many incoherent rays (random origins and directions inside the grid)")
@@ -38,6 +39,7 @@ def main():
     verts, label = scenes.get("dragon")
     ctx = tb.Context(0)
     blas = tb.LAYOUT_CLASSES[a.layout](ctx).Build(verts)
+    blases = [blas] + ([tb.LAYOUT_CLASSES[a.layout2](ctx).Build(verts)] if a.layout2 else [])
     W, H = a.width, a.height
     n = W * H
     ext = 2.0 * a.side
@@ -46,9 +48,9 @@ def main():
     ctx.generate_primary(cam, d_rays, 0, n)
     tlas = tb.TLAS(ctx)
     for f in range(a.frames):
-        inst = instances(a.side, float(f))
+        inst = instances(a.side, float(f), n_blas=len(blases))
         t0 = time.perf_counter()
-        tlas.Build(inst, [blas])          # host: BLASInstance update + TLAS build + upload/update
+        tlas.Build(inst, blases)          # host: BLASInstance update + TLAS build + upload/update
         t_host = time.perf_counter() - t0
         if a.variant:
             tlas.set_variant(a.variant)
@@ -59,7 +61,7 @@ def main():
     # the same frames with the TLAS rebuilt on the device (tbvh_rebuild_tlas_device): transforms go up (64 B per
     # instance), instance update + LBVH build run on the GPU
     for f in range(a.frames):
-        inst = instances(a.side, float(f))
+        inst = instances(a.side, float(f), n_blas=len(blases))
         xf = np.ascontiguousarray(inst["transform"])
         ctx.synchronize()
         t0 = time.perf_counter()
