@@ -36,7 +36,7 @@ enum : uint32_t { S_NODE = 0, S_TRI = 1, S_INST = 2 };
 // PN / PT / PI: a state's code runs in a pass if at least that many lanes are in the state, or it holds the most lanes.
 // STEAL > 0 (idle lanes needed): once the ray pool is dry, idle lanes take the top stack entry — a BLAS or a TLAS subtree — off a lane
 // that is still traversing.
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, int STEAL, int WAVES = 6, int NODE_REPS = 1>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int PN, int PT, int PI, int STEAL, int WAVES = 6, int NODE_REPS = 1, bool FUSE = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void k_tlas2(const float4* __restrict__ tlasNodes, const uint32_t* __restrict__ tlasIdx,
                                                                                            const float4* __restrict__ instances, const BlasDesc* __restrict__ blas,
                                                                                            QueryArgs q, uint32_t* __restrict__ status) {
@@ -116,6 +116,8 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
         bool done = false, advance = false;   // advance: nothing pending here, take what comes next at this level
         if (tail && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
 
+        // FUSE: a lane whose leaf is finished with more of the BLAS on its stack, or that has just entered an instance, takes its node step(s) in the same pass
+        bool cont = false;
         if (STEAL && ANYHIT && done) {
         } else if (state == S_TRI) { if (runT) {
             // ---- one triangle of the current BLAS leaf -----------------------------------------------------------------------
@@ -131,7 +133,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
                 }
             }
-            if (!done && triLeft == 0) advance = true;
+            if (!done && triLeft == 0) {
+                if (FUSE && st.sp > base) { node = st.pop(); state = S_NODE; cont = true; }
+                else advance = true;
+            }
         } } else if (state == S_INST) { if (runI) {
             // ---- the next instance of the current TLAS leaf (tiny_bvh.h:3326-3333) -------------------------------------------------
             if (instNext == instEnd) advance = true;
@@ -157,10 +162,11 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
                     const BlasDesc bd = blas[blasIdx];
                     cur = GlobalF4(bd.nodes); btris = GlobalF4(bd.tris);
                     curInst = ii; base = st.sp; inBlas = true;
-                    state = S_NODE; node = 0;
+                    state = S_NODE; node = 0; cont = FUSE;
                 }
             }
-        } } else if (runN) {
+        } } else if (runN) cont = true;
+        if (cont && runN && state == S_NODE && !done) {
             // ---- NODE_REPS nodes of the TLAS or of the instance's BLAS (the per-pass bookkeeping is a sizeable part of a 2-wide step, as in
             // k_bvh2): same format, same code at both levels; a lane stops early at a leaf or when nothing was hit ----------------------------
 #pragma unroll
@@ -245,6 +251,8 @@ void launch_tlas2(bool anyhit, int variant, const float4* tlasNodes, const uint3
     case 26: TBVH_T2(16, 16, 24, 8, 8, 16, 6, 2); return;  // 33 with two node visits per pass
     case 27: TBVH_T2(16, 16, 24, 8, 8, 16, 6, 3); return;  // ... three
     case 28: TBVH_T2(16, 16, 24, 8, 8, 0, 7, 3); return;   // 29 with three
+    case 35: TBVH_T2(16, 16, 24, 8, 8, 16, 6, 3, true); return;   // 27 with fused leaf / instance -> node steps
+    case 36: TBVH_T2(16, 16, 24, 8, 8, 0, 7, 3, true); return;    // 28 with them
     default: break;
     }
 #endif
@@ -252,8 +260,9 @@ void launch_tlas2(bool anyhit, int variant, const float4* tlasNodes, const uint3
     // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
     // without the split code the kernel fits the register budget of 7 waves per SIMD (28 workgroups per CU: +4…6 %); with it five dwords spill and it loses
     // three node visits per pass: camera rays +11 %, random rays +11 %, IsOccluded +16 % over one (8.3 M / 4.2 M rays); 33 M rays +5…8 %
-    if (split_rays_wanted(q)) TBVH_T2(16, 16, 24, 8, 8, 16, 6, 3);
-    else { blocks = blocks7; TBVH_T2(16, 16, 24, 8, 8, 0, 7, 3); }
+    // fused steps (a lane done with a leaf, or entering an instance, goes on to its node visits in the same pass): camera rays +9 %, random rays +5 %
+    if (split_rays_wanted(q)) TBVH_T2(16, 16, 24, 8, 8, 16, 6, 3, true);
+    else { blocks = blocks7; TBVH_T2(16, 16, 24, 8, 8, 0, 7, 3, true); }
 #undef TBVH_T2
 }
 
