@@ -268,10 +268,10 @@ void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* i
 #if TBVH_EXPERIMENTS
     switch (variant) {
     case 21: TBVH_T4(12, 16, 32, 32, 32); return;
-    case 22: TBVH_T4(12, 16, 16, 8, 8); return;
-    case 23: TBVH_T4(12, 16, 8, 8, 8); return;
-    case 24: TBVH_T4(12, 16, 24, 8, 8); return;
-    case 25: TBVH_T4(12, 16, 16, 4, 4); return;
+    case 22: TBVH_T4(12, 16, 16, 8, 8, false, false, 16, 7, true); return;     // thresholds around the shipped kernel (24 / 8 / 8)
+    case 23: TBVH_T4(12, 16, 8, 8, 8, false, false, 16, 7, true); return;
+    case 24: TBVH_T4(12, 16, 32, 8, 8, false, false, 16, 7, true); return;
+    case 25: TBVH_T4(12, 16, 24, 4, 4, false, false, 16, 7, true); return;
     case 26: TBVH_T4(12, 16, 24, 8, 8, false, true); return;   // statistics: phases run and lanes per phase (q.stats)
     case 27: TBVH_T4(12, 16, 16, 16, 16, true); return;          // under the lockstep governor
     case 28: TBVH_T4(12, 16, 16, 8, 8, true); return;
