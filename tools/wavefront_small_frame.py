@@ -1,6 +1,8 @@
-"""Frame time of the path tracer at the reference demo resolution (1280 x 720, 3 bounces): wall clock of back-to-back frames against the GPU events of\nsingle frames (are the ~13 launches of a frame launch-bound?  no: 0.91 ms either way)."""
+"""Frame time of the path tracer at the reference demo resolution (1280 x 720, 3 bounces): wall clock of back-to-back frames against the GPU events of
+single frames (are the ~13 launches of a frame launch-bound?  no: 0.91 ms either way)."""
 import sys, time, numpy as np
-sys.path.insert(0,'/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import tinybvh_amd as tb
 from tinybvh_amd import rays as R, scenes
 verts,_=scenes.get("sponza")
