@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define TBVH_ABI_VERSION 2
+#define TBVH_ABI_VERSION 3   /* 3: deterministic ties, tbvh_bin_rays_device, tbvh_cwbvh_set_hybrid, device-resident multi-device calls */
 
 /* error codes */
 #define TBVH_OK            0
@@ -201,10 +201,12 @@ int tbvh_occluded(tbvh_scene* scene, const void* rays, uint64_t n_rays,
 
 /* Device-resident packed rays (64-byte stride, 16-byte aligned).  Asynchronous on the
  * context's stream; no host copies.  This is the timed path.
- * Records are the reference's (BVH::Intersect: prim exact, t / u / v bit-identical) except among triangles a ray
- * hits at (nearly) the same t, where — as between the reference's own layouts — the winner depends on the order of
- * the tests; batches below 12 M rays split their last rays over idle lanes (DESIGN.md par. 3), so which of two such
- * triangles is reported may differ from run to run. */
+ * Records are the reference's (BVH::Intersect: prim exact, t / u / v bit-identical) with ONE deliberate difference: among
+ * triangles a ray hits at exactly the same t the reference reports whichever it tested last (tiny_bvh.h:1656 accepts
+ * t <= hit.t), so its answer depends on the traversal order and its own layouts disagree with each other there; this
+ * library reports the one with the smaller primitive index (TLAS: then the smaller instance index), whatever the layout,
+ * the schedule or the batch size — the same bytes from run to run.  (Residual, shared with every BVH traversal including
+ * the reference's: a triangle lying exactly IN a face of its leaf box can be culled by a hit within a few ulps of it.) */
 int tbvh_intersect_device(tbvh_scene* scene, void* d_rays64, uint64_t n_rays);
 int tbvh_occluded_device(tbvh_scene* scene, const void* d_rays64, uint64_t n_rays,
                          uint8_t* d_occluded);
@@ -246,8 +248,23 @@ int tbvh_measure_copy_bandwidth(tbvh_context* ctx, uint64_t bytes, uint32_t reps
  * [3] triangle-loop iterations, [4] sum of lanes in them, [5] refill events, [6] rays handed out. */
 int tbvh_debug_stats(tbvh_context* ctx, uint64_t out[8], int reset);
 
-/* Kernel variant selection for experiments (0 = default).  Returns TBVH_E_INVALID for an
- * unknown variant of the scene's layout. */
+/* BVH8_CWBVH node placement (the blob the caller uploaded is unchanged; "the library may keep a re-laid-out copy"): nodes in
+ * surface-area priority order — the nodes a ray is most likely to visit first —, the first packed_nodes of them (rounded down to a
+ * multiple of 8) packed 80 bytes apart, all later ones one per 128-byte line.  The top of the tree is served by the L2s, where the
+ * packed form moves 40 % more nodes per second; deep nodes come from beyond them, where a cache line is the unit and a packed node
+ * straddles 1.6 lines (tools/ubench/gather_lanes.hip).  packed_nodes >= the node count: priority order, all packed; 0: all padded;
+ * < 0: back to the uploaded array.  Hit records do not depend on the placement.  Kept current by tbvh_refit. */
+int tbvh_cwbvh_set_hybrid(tbvh_scene* scene, int64_t packed_nodes);
+
+/* The per-launch coherence probe of the most recent query on this context (development aid; DESIGN.md par. 3): out[0] = sampled
+ * neighbouring ray pairs whose directions agree, out[1] = pairs sampled, out[2] = 0 no probe ran (small batches, small or very
+ * large scenes, other layouts), 1 the batch was classified incoherent (strict schedule), 2 coherent (deferred triangles, gated
+ * triangle phase, a third more waves).  Synchronizes the stream. */
+int tbvh_debug_last_probe(tbvh_context* ctx, uint32_t out[3]);
+
+/* Diagnostic kernel variants of BVH8_CWBVH scenes (0 = default): 72 / 52 force the strict / the coherent schedule whatever
+ * the probe says, 75 / 88 split the last rays whatever the batch size, 59 / 61 / 73 / 78 / 82 / 83 are the instrumented
+ * kernels behind tbvh_debug_stats.  Returns TBVH_E_INVALID for anything else. */
 int tbvh_set_variant(tbvh_scene* scene, int variant);
 
 /* ------------------------------------------------------------------------------------
@@ -276,6 +293,16 @@ int tbvh_generate_bounce_device(tbvh_context* ctx, const void* d_verts16,
 int tbvh_generate_shadow_device(tbvh_context* ctx, const void* d_in_rays64,
                                 void* d_out_rays64, uint64_t n_rays,
                                 const float light_pos[3], float eps);
+
+/* Reorder a resident ray batch into bins of (origin cell, direction octant): d_out[slot] = d_in[i], all rays of a bin adjacent, bins
+ * in Morton order of the cell (2^cell_bits cells per axis over bounds6 = min.xyz, max.xyz; cell_bits 0..6).  flags: 0 = cell only,
+ * 1 = the direction's sign octant as the minor part of the key, 2 = as the major part.  For incoherent batches — bounce rays from
+ * depth 2 on — ahead of tbvh_intersect_device: the launch consumes a batch front to back, so the whole GPU then works on one
+ * region of space at a time (DESIGN.md par. 5).  d_perm (optional, n x u32): d_perm[slot] = i, for callers that need the results
+ * back in the original order.  A counting sort: three launches, asynchronous on the context's stream; tbvh_time_last_ms() reports
+ * its device time.  No counterpart in the reference (wavefront.cl:236-245 appends extension rays in completion order). */
+int tbvh_bin_rays_device(tbvh_context* ctx, const void* d_in_rays64, void* d_out_rays64, uint64_t n_rays, const float bounds6[6],
+                         uint32_t cell_bits, uint32_t flags, uint32_t* d_perm);
 
 /* ------------------------------------------------------------------------------------
  * device-resident wavefront path tracer — the frame loop of tiny_bvh_gpu.cpp:128-158 over

@@ -34,8 +34,24 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session")
 def oracle():
+    """The restated oracle under the LIBRARY's tie rule (at exactly equal t the smaller prim, then the smaller instance, wins;
+    oracle/tbvh_oracle.c: orc_set_tie_rule; tinybvh_amd/csrc/device_common.h: hit_wins): against it the GPU kernels must report
+    the exact prim, ties included.  Everything else is BVH::Intersect restated."""
     from oracle_lib import Oracle
-    return Oracle()
+    return Oracle(tie_rule=1)
+
+
+@pytest.fixture(scope="session")
+def oracle_ties(oracle):
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def oracle_ref():
+    """The restated oracle under the REFERENCE's tie rule (the later test wins, tiny_bvh.h:1656): what the bit-for-bit comparisons
+    with oracle/_ref (the real tiny_bvh.h) and with the golden vectors generated from it need."""
+    from oracle_lib import Oracle
+    return Oracle(tie_rule=0)
 
 
 @pytest.fixture(scope="session")

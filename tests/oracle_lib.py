@@ -30,10 +30,16 @@ def build_oracle():
 class Oracle:
     """The C restatement.  All functions take/return numpy arrays of RAY_DTYPE records."""
 
-    def __init__(self):
+    def __init__(self, tie_rule: int = 1):
+        """tie_rule 1 (default): the library's (at exactly equal t the smaller prim, then the smaller instance, wins:
+        order-independent; under it the GPU parity tests demand the exact prim); 0: the reference's (the later test wins;
+        what the pinned comparisons against oracle/_ref and the golden vectors need).  The rule is process-wide state of
+        liborc, so every call sets it."""
         build_oracle()
         self.lib = C.CDLL(ORC_PATH)
+        self.tie_rule = int(tie_rule)
         L = self.lib
+        assert L.orc_abi_version() >= 2, "oracle/liborc.so is stale: make -C oracle"
         L.orc_bvh2_intersect.argtypes = [_vp, _vp, _vp, _vp, _u64, _u32, _vp]
         L.orc_bvh2_occluded.argtypes = [_vp, _vp, _vp, _vp, _u64, _u32, _vp]
         L.orc_bvhgpu_intersect.argtypes = [_vp, _vp, _vp, _vp, _u64, _u32, _vp]
@@ -56,6 +62,7 @@ class Oracle:
     def bvh2_intersect(self, nodes32, prim_idx, verts, rays, counts=False):
         r = self._prep(rays)
         c = np.zeros(2, np.uint64) if counts else None
+        self.lib.orc_set_tie_rule(self.tie_rule)
         self.lib.orc_bvh2_intersect(_p(nodes32), _p(prim_idx), _p(verts), _p(r), r.shape[0], r.strides[0], _p(c))
         return (r, c) if counts else r
 
@@ -68,18 +75,21 @@ class Oracle:
     def bvhgpu_intersect(self, nodes64, prim_idx, verts, rays, counts=False):
         r = self._prep(rays)
         c = np.zeros(2, np.uint64) if counts else None
+        self.lib.orc_set_tie_rule(self.tie_rule)
         self.lib.orc_bvhgpu_intersect(_p(nodes64), _p(prim_idx), _p(verts), _p(r), r.shape[0], r.strides[0], _p(c))
         return (r, c) if counts else r
 
     def bvh4_intersect(self, blocks16, rays, counts=False):
         r = self._prep(rays)
         c = np.zeros(2, np.uint64) if counts else None
+        self.lib.orc_set_tie_rule(self.tie_rule)
         self.lib.orc_bvh4_intersect(_p(blocks16), _p(r), r.shape[0], r.strides[0], _p(c))
         return (r, c) if counts else r
 
     def cwbvh_intersect(self, nodes16, tris16, rays, counts=False):
         r = self._prep(rays)
         c = np.zeros(2, np.uint64) if counts else None
+        self.lib.orc_set_tie_rule(self.tie_rule)
         self.lib.orc_cwbvh_intersect(_p(nodes16), _p(tris16), _p(r), r.shape[0], r.strides[0], _p(c))
         return (r, c) if counts else r
 
@@ -99,6 +109,7 @@ def tlas_intersect(orc: "Oracle", tlas_nodes32, tlas_idx, instances, blas_list, 
         arr[i] = OrcBlas(n.ctypes.data, p.ctypes.data, v.ctypes.data)
     r = np.ascontiguousarray(rays).copy()
     tn = np.ascontiguousarray(tlas_nodes32); ti = np.ascontiguousarray(tlas_idx, np.uint32); inst = np.ascontiguousarray(instances)
+    orc.lib.orc_set_tie_rule(orc.tie_rule)
     orc.lib.orc_tlas_intersect(_p(tn), _p(ti), _p(inst), C.cast(arr, C.c_void_p), _p(r), r.shape[0], r.strides[0])
     return r
 

@@ -1,0 +1,96 @@
+"""The kernels bench.py TIMES, checked against the oracle in the default build (round-2 review, "parity hole"): BVH8_CWBVH scenes of 48-384 MB
+get a per-launch coherence probe for batches of 2 M rays and more (tinybvh_amd/csrc/capi.hip: launchQuery), and a coherent batch — camera
+rays, shadow rays towards one light — then runs ANOTHER schedule (deferred triangles, gated triangle phase, a third more waves;
+kernels_cwbvh.hip) than the strict one the small-scene tests exercise; batches of 2-12 M rays run the probed kernel WITH split rays.  Here:
+the Bistro stand-in at the bench's sizes, the probe's verdict asserted (tbvh_debug_last_probe), a strided 65 k sample of every batch
+compared with BVH::Intersect / IsOccluded restated (tiny_bvh.h:3222-3304, 3382-3453) — exact prim, bit-identical t, u, v."""
+import numpy as np
+import pytest
+
+import tinybvh_amd as tb
+from tinybvh_amd import rays as R
+from tinybvh_amd import scenes
+from oracle_lib import compare_hits
+
+pytestmark = pytest.mark.gpu
+
+
+def sample_check(oracle, sc, verts, before, after, n, what, ns=65536):
+    idx = np.arange(0, n, max(n // ns, 1))[:ns]
+    h = sc.host
+    want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, before[idx])
+    c = compare_hits(after[idx], want)
+    assert c["hits"] > ns // 4, (what, c)
+    assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] == 0, (what, c)
+    assert c["onsurf"] <= 8 and c["bit_identical"] == c["same_prim"], (what, c)
+    return c
+
+
+def test_probed_schedules_on_the_bench_scene(ctx, oracle):
+    verts, _ = scenes.get("bistro")
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    assert (48 << 20) < sc.device_bytes <= (384 << 20), sc.device_bytes      # the size class that gets the probe
+    side = 4096
+    n = side * side
+    cam = R.camera(*scenes.STREET_CAMERAS[0], side, side, 1, 1)              # bench.py's camera
+    d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
+    d_a, d_b = ctx.malloc(n * 64), ctx.malloc(n * 64)
+    d_occ = ctx.malloc(n)
+    before = np.zeros(n, tb.RAY_DTYPE); after = np.zeros(n, tb.RAY_DTYPE)
+
+    # 16.7 M camera rays: coherent -> deferred triangles + gated triangle phase on 32 waves per CU, no split rays
+    ctx.generate_primary(cam, d_a, 0, n)
+    ctx.from_device(before, d_a)
+    sc.intersect_device_fresh(d_a, n, 1e30)
+    agree, pairs, verdict = ctx.last_probe()
+    assert verdict == 2 and pairs >= 1024, (agree, pairs, verdict)
+    ctx.from_device(after, d_a)
+    sample_check(oracle, sc, verts, before, after, n, "16.7 M camera rays, coherent schedule")
+    prim_hits = after.copy()
+
+    # 16.7 M shadow rays towards one light: coherent any-hit
+    ext = float((verts[:, :3].max(0) - verts[:, :3].min(0)).max())
+    light = (0.0, 0.9 * float(verts[:, 1].max()), 0.0)
+    ctx.generate_shadow(d_a, d_b, n, light, ext * 5e-7)
+    sc.occluded_device(d_b, n, d_occ)
+    assert ctx.last_probe()[2] == 2
+    occ = np.zeros(n, np.uint8); ctx.from_device(occ, d_occ)
+    ctx.from_device(before, d_b)
+    idx = np.arange(0, n, n // 65536)[:65536]
+    h = sc.host
+    want_occ = oracle.bvh2_occluded(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, before[idx])
+    assert 1000 < int(want_occ.sum()) < idx.size - 1000
+    assert np.array_equal(occ[idx], want_occ), int((occ[idx] != want_occ).sum())
+
+    # 4.2 M camera rays (2 - 12 M rays): the probed kernel WITH split rays
+    m = 2048 * 2048
+    cam4 = R.camera(*scenes.STREET_CAMERAS[0], 2048, 2048, 1, 1)
+    ctx.generate_primary(cam4, d_b, 0, m)
+    ctx.from_device(before[:m], d_b)
+    sc.intersect_device_fresh(d_b, m, 1e30)
+    assert ctx.last_probe()[2] == 2
+    ctx.from_device(after[:m], d_b)
+    sample_check(oracle, sc, verts, before[:m], after[:m], m, "4.2 M camera rays, coherent schedule + split rays")
+    runs = []
+    for _ in range(2):        # and the same bytes run to run (which rays are split depends on timing)
+        sc.intersect_device_fresh(d_b, m, 1e30)
+        again = np.zeros(m, tb.RAY_DTYPE); ctx.from_device(again, d_b)
+        runs.append(again)
+    assert np.array_equal(runs[0].view(np.uint8), after[:m].view(np.uint8)) and np.array_equal(runs[1].view(np.uint8), after[:m].view(np.uint8))
+
+    # 16.7 M bounce rays: incoherent -> the probe says so, strict schedule
+    ctx.to_device(d_a, prim_hits)
+    ctx.generate_bounce(d_verts, d_a, d_b, n, 4711)
+    ctx.from_device(before, d_b)
+    sc.intersect_device_fresh(d_b, n, 1e30)
+    assert ctx.last_probe()[2] == 1
+    ctx.from_device(after, d_b)
+    sample_check(oracle, sc, verts, before, after, n, "16.7 M bounce rays, strict schedule")
+    # 4.2 M of them: strict + split rays
+    sc.intersect_device_fresh(d_b, m, 1e30)
+    assert ctx.last_probe()[2] == 1
+    ctx.from_device(after[:m], d_b)
+    sample_check(oracle, sc, verts, before[:m], after[:m], m, "4.2 M bounce rays, strict schedule + split rays")
+    for p in (d_verts, d_a, d_b, d_occ):
+        ctx.free(p)
+    sc.free()

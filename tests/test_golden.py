@@ -26,7 +26,7 @@ def test_fixtures_exist():
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
-def test_oracle_on_reference_split_leaf_bvh2(oracle, path):
+def test_oracle_on_reference_split_leaf_bvh2(oracle_ref, path):
     """The BVH2 the reference converts its CWBVH from (leaves of at most 3 triangles; the device conversion's input
     fixture) is a valid BVH2: the restated BVH::Intersect on it returns the reference's hit records."""
     g = np.load(path)
@@ -34,32 +34,32 @@ def test_oracle_on_reference_split_leaf_bvh2(oracle, path):
     for k in (0, 1):
         n2, pi = g[f"bvh2s3_nodes_{k}"], g[f"bvh2s3_idx_{k}"].reshape(-1)
         assert int(n2[:, 7].max()) <= 3
-        got = oracle.bvh2_intersect(n2, pi, verts, rays)
+        got = oracle_ref.bvh2_intersect(n2, pi, verts, rays)
         c = compare_hits(got, hits)
         assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["tie"] <= 4, c
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
-def test_oracle_reproduces_reference_hits(oracle, path):
+def test_oracle_reproduces_reference_hits(oracle_ref, path):
     g = np.load(path)
     verts, rays, hits = g["verts"], g["rays"], hitrec(g["hits"])
     h = tb.HostBVH(verts, tb.LAYOUT_BVH2_WALD)
-    got = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
+    got = oracle_ref.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
     c = compare_hits(got, hits)
     assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] <= 1, c
     assert c["bit_identical"] == c["same_prim"], c
-    occ = oracle.bvh2_occluded(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, g["shadow_rays"])
+    occ = oracle_ref.bvh2_occluded(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, g["shadow_rays"])
     assert np.array_equal(occ, g["occluded"])
 
 
 @pytest.mark.parametrize("path", GOLDEN, ids=[os.path.basename(p) for p in GOLDEN])
 @pytest.mark.parametrize("hq", [0, 1])
-def test_oracle_mirrors_reproduce_reference_mirrors_on_reference_blobs(oracle, path, hq):
+def test_oracle_mirrors_reproduce_reference_mirrors_on_reference_blobs(oracle_ref, path, hq):
     g = np.load(path)
     verts, rays = g["verts"], g["rays"]
-    got4 = oracle.bvhgpu_intersect(g[f"bvhgpu_nodes_{hq}"], g[f"bvhgpu_idx_{hq}"], verts, rays)
-    got6 = oracle.bvh4_intersect(g[f"bvh4_{hq}"], rays)
-    got9 = oracle.cwbvh_intersect(g[f"cwbvh_nodes_{hq}"], g[f"cwbvh_tris_{hq}"], rays)
+    got4 = oracle_ref.bvhgpu_intersect(g[f"bvhgpu_nodes_{hq}"], g[f"bvhgpu_idx_{hq}"], verts, rays)
+    got6 = oracle_ref.bvh4_intersect(g[f"bvh4_{hq}"], rays)
+    got9 = oracle_ref.cwbvh_intersect(g[f"cwbvh_nodes_{hq}"], g[f"cwbvh_tris_{hq}"], rays)
     for got, key in ((got4, f"mirror4_{hq}"), (got6, f"mirror6_{hq}")):
         for f in ("t", "u", "v", "prim"):
             assert np.array_equal(got[f].view(np.uint32), hitrec(g[key])[f].view(np.uint32)), (key, f)

@@ -43,47 +43,47 @@ def get_scene(name):
 
 @pytest.mark.parametrize("scene", SCENES)
 @pytest.mark.parametrize("hq", [False, True])
-def test_restated_traversals_equal_the_reference(oracle, reference, scene, hq):
+def test_restated_traversals_equal_the_reference(oracle_ref, reference, scene, hq):
     verts = get_scene(scene)
     rs = reference.build(verts, hq=hq)
     n2, pi = rs.blob(1, 0, np.uint32, 8), rs.blob(1, 1, np.uint32, 1)
     for rays in batches(verts):
         want = rs.intersect(1, rays)
         assert (want["t"] < 1e30).sum() > 100
-        exact(oracle.bvh2_intersect(n2, pi, verts, rays), want)                       # BVH::Intersect
-        exact(oracle.bvhgpu_intersect(rs.blob(4, 0, np.uint32, 16), rs.blob(4, 1, np.uint32, 1), verts, rays), rs.intersect(4, rays))
-        exact(oracle.bvh4_intersect(rs.blob(6, 0, np.uint32, 4), rays), rs.intersect(6, rays))
+        exact(oracle_ref.bvh2_intersect(n2, pi, verts, rays), want)                       # BVH::Intersect
+        exact(oracle_ref.bvhgpu_intersect(rs.blob(4, 0, np.uint32, 16), rs.blob(4, 1, np.uint32, 1), verts, rays), rs.intersect(4, rays))
+        exact(oracle_ref.bvh4_intersect(rs.blob(6, 0, np.uint32, 4), rays), rs.intersect(6, rays))
         # the CWBVH mirror zeroes u,v,prim of missed finite-tmax rays (tiny_bvh.h:7148); tmax is
         # 1e30 here so records are comparable field by field
-        got = oracle.cwbvh_intersect(rs.blob(9, 0, np.uint32, 4), rs.blob(9, 1, np.uint32, 4), rays)
+        got = oracle_ref.cwbvh_intersect(rs.blob(9, 0, np.uint32, 4), rs.blob(9, 1, np.uint32, 4), rays)
         ref9 = rs.intersect(9, rays)
         for f in ("t", "u", "v", "prim"):
             assert np.array_equal(got[f].view(np.uint32), ref9[f].view(np.uint32)), f
         # shadow rays
         sh = R.shadow(want, verts[:, :3].max(0) * 1.1, 1e-4)
-        assert np.array_equal(oracle.bvh2_occluded(n2, pi, verts, sh), rs.occluded(1, sh))
+        assert np.array_equal(oracle_ref.bvh2_occluded(n2, pi, verts, sh), rs.occluded(1, sh))
 
 
-def test_own_builder_gives_the_reference_hits(oracle, reference):
+def test_own_builder_gives_the_reference_hits(oracle_ref, reference):
     """Hit records are builder independent (up to ties): the library's own BVH and the
     reference's BVH::Build agree ray by ray."""
     verts = scenes.atrium(25_000, seed=1)
     rs = reference.build(verts)
     h = tb.HostBVH(verts, tb.LAYOUT_BVH2_WALD)
     for rays in batches(verts):
-        got = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
+        got = oracle_ref.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
         c = compare_hits(got, rs.intersect(1, rays))
         assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["tie"] <= 2, c
         assert c["bit_identical"] == c["same_prim"], c
 
 
-def test_reference_counts_match_oracle_counts(oracle, reference):
+def test_reference_counts_match_oracle_counts(oracle_ref, reference):
     verts = scenes.atrium(25_000, seed=1)
     rs = reference.build(verts)
     rays = batches(verts)[0]
-    for layout, fn in ((1, lambda: oracle.bvh2_intersect(rs.blob(1, 0, np.uint32, 8), rs.blob(1, 1, np.uint32, 1), verts, rays, counts=True)),
-                       (4, lambda: oracle.bvhgpu_intersect(rs.blob(4, 0, np.uint32, 16), rs.blob(4, 1, np.uint32, 1), verts, rays, counts=True)),
-                       (6, lambda: oracle.bvh4_intersect(rs.blob(6, 0, np.uint32, 4), rays, counts=True))):
+    for layout, fn in ((1, lambda: oracle_ref.bvh2_intersect(rs.blob(1, 0, np.uint32, 8), rs.blob(1, 1, np.uint32, 1), verts, rays, counts=True)),
+                       (4, lambda: oracle_ref.bvhgpu_intersect(rs.blob(4, 0, np.uint32, 16), rs.blob(4, 1, np.uint32, 1), verts, rays, counts=True)),
+                       (6, lambda: oracle_ref.bvh4_intersect(rs.blob(6, 0, np.uint32, 4), rays, counts=True))):
         s, t = rs.counts(layout, rays)
         _, c = fn()
         assert (int(c[0]), int(c[1])) == (s, t), layout
@@ -121,7 +121,7 @@ def test_instance_update_is_bit_identical_to_the_reference(reference):
         assert np.array_equal(mine[f].view(np.uint32), theirs[f].view(np.uint32)), f
 
 
-def test_restated_tlas_traversal_equals_the_reference(oracle, reference):
+def test_restated_tlas_traversal_equals_the_reference(oracle_ref, reference):
     """BVH::IntersectTLAS restated (orc_tlas_intersect) on the reference's own TLAS and instance records."""
     import ctypes as C
     from oracle_lib import tlas_intersect
@@ -139,7 +139,7 @@ def test_restated_tlas_traversal_equals_the_reference(oracle, reference):
     nn = reference.lib.ref_tlas_blob(t, 2, C.byref(p)); nodes = np.frombuffer((C.c_char * (nn * 32)).from_address(p.value), np.uint32).reshape(-1, 8).copy()
     ni = reference.lib.ref_tlas_blob(t, 1, C.byref(p)); idx = np.frombuffer((C.c_char * (ni * 4)).from_address(p.value), np.uint32).copy()
     bl = [(r.blob(1, 0, np.uint32, 8), r.blob(1, 1, np.uint32, 1).reshape(-1), v) for r, v in ((r0, v0), (r1, v1))]
-    got = tlas_intersect(oracle, nodes, idx, inst, bl, rays)
+    got = tlas_intersect(oracle_ref, nodes, idx, inst, bl, rays)
     reference.lib.ref_tlas_free(t)
     assert int((want["t"] < 1e30).sum()) > 1000
     c = compare_hits(got, want)
@@ -160,7 +160,7 @@ def random_opmap(n_tris, N, seed, density=0.6):
 
 
 @pytest.mark.parametrize("N", [4, 8, 32])
-def test_opacity_micromaps_equal_the_reference(oracle, reference, N):
+def test_opacity_micromaps_equal_the_reference(oracle_ref, reference, N):
     """IntersectTri / TriOccludes with opacity micromaps (tiny_bvh.h:8514-8522, 8562-8570): restated index arithmetic
     against the real BVH::Intersect / IsOccluded with SetOpacityMicroMaps."""
     import ctypes as C
@@ -176,11 +176,11 @@ def test_opacity_micromaps_equal_the_reference(oracle, reference, N):
     want_occ = rs.occluded(1, sh)
     reference.lib.ref_set_opmap(rs.h, None, 0)
     assert int((want["prim"] != plain["prim"]).sum()) > 500          # the maps really cut holes
-    oracle.set_opmap(om, N)
+    oracle_ref.set_opmap(om, N)
     try:
-        got = oracle.bvh2_intersect(rs.blob(1, 0, np.uint32, 8), rs.blob(1, 1, np.uint32, 1).reshape(-1), verts, rays)
-        got_occ = oracle.bvh2_occluded(rs.blob(1, 0, np.uint32, 8), rs.blob(1, 1, np.uint32, 1).reshape(-1), verts, sh)
+        got = oracle_ref.bvh2_intersect(rs.blob(1, 0, np.uint32, 8), rs.blob(1, 1, np.uint32, 1).reshape(-1), verts, rays)
+        got_occ = oracle_ref.bvh2_occluded(rs.blob(1, 0, np.uint32, 8), rs.blob(1, 1, np.uint32, 1).reshape(-1), verts, sh)
     finally:
-        oracle.set_opmap(None, 0)
+        oracle_ref.set_opmap(None, 0)
     exact(got, want)
     assert np.array_equal(got_occ, want_occ)

@@ -1,7 +1,9 @@
 """Split rays (tinybvh_amd/csrc/ray_split.h): once the ray pool of a launch is dry, idle lanes take pending subtrees off
 the lanes that are still traversing.  Batches of fewer rays than the launch has lanes are all tail: every ray is split
 as far as its traversal branches, so these are the cases where a wrong merge of the members' results would show.
-The records must be the oracle's (reference: BVH::Intersect / IsOccluded, tiny_bvh.h:3222-3304, 3382-3453)."""
+The records must be the oracle's (reference: BVH::Intersect / IsOccluded, tiny_bvh.h:3222-3304, 3382-3453) — exactly, and the same
+from run to run: the members of a split ray merge their hits under the library's tie rule (smaller prim at exactly equal t), which is
+also what one lane alone applies, so which rays get split (timing) cannot show in a record."""
 import numpy as np
 import pytest
 
@@ -16,7 +18,13 @@ LAYOUTS = [tb.BVH_GPU, tb.BVH4_GPU, tb.BVH8_CWBVH]
 def _check(got, want, what):
     c = compare_hits(got, want)
     assert c["hits"] > 100 and c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, (what, c)
-    assert c["tie"] <= max(4, c["hits"] // 1500) and c["onsurf"] <= max(4, c["n"] // 5000), (what, c)
+    assert c["tie"] == 0 and c["onsurf"] <= max(4, c["n"] // 5000), (what, c)
+
+
+@pytest.fixture(scope="module")
+def oracle(oracle_ties):
+    """In this module the restated oracle runs under the library's tie rule."""
+    return oracle_ties
 
 
 @pytest.mark.gpu
@@ -29,8 +37,12 @@ def test_batches_that_are_all_tail_match_the_oracle(ctx, oracle, cls, n):
     # long rays through the whole soup (many nodes each) and short ones from inside it
     rays = R.random_rays(n, (0, 0, 0), (10, 10, 10), seed=n)
     want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
+    first = None
     for rep in range(3):   # which lanes help which ray depends on timing: the records must not
         got = sc.Intersect(rays.copy())
+        if first is None:
+            first = got.copy()
+        assert np.array_equal(got.view(np.uint8), first.view(np.uint8)), (cls.__name__, n, rep)   # byte-identical run to run
         if n >= 1000:
             _check(got, want, (cls.__name__, n, rep))
         else:
@@ -67,30 +79,32 @@ def test_a_closer_hit_already_in_the_record_survives_a_split_ray(ctx, oracle, cl
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cls,plain", [(tb.BVH_GPU, 12), (tb.BVH4_GPU, 14), (tb.BVH8_CWBVH, 72)])
-def test_split_and_unsplit_kernels_agree_up_to_ties(ctx, cls, plain):
-    """Experiment builds: the same kernel without split rays returns the same records, except among hits at (nearly) equal t."""
+def test_split_and_unsplit_kernels_agree_byte_for_byte(ctx, monkeypatch):
+    """The kernels WITHOUT split rays (a context created under TBVH_SPLIT_RAYS=0) return the same bytes as the default ones, in every layout."""
     verts, _ = scenes.get("sponza")
-    sc = cls(ctx).Build(verts)
-    try:
-        sc.set_variant(plain)
-    except tb.TbvhError:
-        pytest.skip("experiment build only")
     cam = R.primary(R.camera(*scenes.SPONZA_CAMERAS[0], 512, 512, 1, 1))
-    base = sc.Intersect(cam.copy())
-    sc.set_variant(0)
-    got = sc.Intersect(cam.copy())
-    c = compare_hits(got, base)
-    assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
-    assert c["tie"] <= max(4, c["hits"] // 1500), c
-    sc.free()
+    rnd = R.random_rays(200_000, verts[:, :3].min(0), verts[:, :3].max(0), seed=12)
+    monkeypatch.setenv("TBVH_SPLIT_RAYS", "0")
+    plain_ctx = tb.Context(0)
+    monkeypatch.delenv("TBVH_SPLIT_RAYS")
+    try:
+        for cls in LAYOUTS:
+            a, b = cls(ctx).Build(verts), cls(plain_ctx).Build(verts)
+            for rays in (cam, rnd):
+                ga, gb = a.Intersect(rays.copy()), b.Intersect(rays.copy())
+                assert int((ga["t"] < 1e30).sum()) > rays.shape[0] // 4
+                assert np.array_equal(ga.view(np.uint8), gb.view(np.uint8)), cls.__name__
+                assert np.array_equal(a.IsOccluded(rays.copy()), b.IsOccluded(rays.copy())), cls.__name__
+            a.free(); b.free()
+    finally:
+        plain_ctx.close()
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cls", LAYOUTS)
 def test_large_batches_run_the_unsplit_kernels_and_agree(ctx, cls):
     """Batches of 12 M rays and more run the kernels WITHOUT split rays (the tail is 5 % of such a launch): the same rays traced as part of a
-    12.8 M-ray launch and as a 1 M-ray launch of their own give the same records, ties aside."""
+    12.8 M-ray launch and as a 1 M-ray launch of their own give the same records, byte for byte."""
     verts, _ = scenes.get("sponza")
     sc = cls(ctx).Build(verts)
     side = 3584                                   # 12.8 M rays
@@ -105,7 +119,7 @@ def test_large_batches_run_the_unsplit_kernels_and_agree(ctx, cls):
     ctx.free(d)
     c = compare_hits(small, big)
     assert c["hits"] > m // 2 and c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
-    assert c["tie"] <= max(4, c["hits"] // 1500), c
+    assert np.array_equal(small.view(np.uint8), big.view(np.uint8))
     sc.free()
 
 
@@ -153,40 +167,50 @@ def test_large_two_level_batches_agree_with_small_ones(ctx, cls):
     ctx.free(d)
     c = compare_hits(small, big)
     assert c["hits"] > 1000 and c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
-    same = (small["prim"] == big["prim"]) & (small["t"] < 1e30)
-    assert np.array_equal(small["inst"][same], big["inst"][same])
+    assert np.array_equal(small.view(np.uint8), big.view(np.uint8))
     tlas.free()
     for x in blases:
         x.free()
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cls", LAYOUTS)
-def test_every_hit_a_tie(ctx, oracle, cls):
-    """A scene in which every triangle exists twice: every hit is a tie between two prims, the case in which the members of a split ray
-    disagree about the winner all the time.  t, u, v must be the oracle's bit for bit, prim one of the two copies."""
+def test_every_hit_a_tie(ctx, oracle):
+    """A scene in which every triangle exists twice: every hit is a tie between two prims, the case in which the members of a split ray — and
+    the three layouts, and the schedules — disagree about the winner all the time under "the later test wins".  Under the library's rule the
+    record is the same everywhere: t, u, v the oracle's bit for bit, prim the SMALLER copy; three runs of a 1 M-ray batch byte-identical, in
+    every layout (1 M rays: the split-ray kernels; small batches are all tail)."""
     base = scenes.soup(8_000, seed=17)
     verts = np.ascontiguousarray(np.concatenate([base, base]))
     ntri = base.shape[0] // 3
-    sc = cls(ctx).Build(verts)
-    h = sc.host
-    rays = R.random_rays(20_000, (0, 0, 0), (10, 10, 10), seed=4)
-    want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
-    for rep in range(3):
-        got = sc.Intersect(rays.copy())
+    rays = R.random_rays(1 << 20, (0, 0, 0), (10, 10, 10), seed=4)
+    small = rays[:20_000]
+    records = {}
+    for cls in LAYOUTS:
+        sc = cls(ctx).Build(verts)
+        h = sc.host
+        want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, small)
         hit = want["t"] < 1e30
-        assert np.array_equal(got["t"] < 1e30, hit)
-        for f in ("t", "u", "v"):
-            assert np.array_equal(got[f][hit].view(np.uint32), want[f][hit].view(np.uint32)), (cls.__name__, f, rep)
-        assert np.array_equal(got["prim"][hit] % ntri, want["prim"][hit] % ntri), (cls.__name__, rep)
-    sc.free()
+        assert hit.sum() > 5000 and np.all(want["prim"][hit] < ntri)          # the oracle under the same rule reports the smaller copy
+        for rep in range(3):
+            got = sc.Intersect(small.copy())
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (cls.__name__, rep)
+        runs = [sc.Intersect(rays.copy()) for _ in range(3)]
+        assert np.array_equal(runs[0].view(np.uint8), runs[1].view(np.uint8)) and np.array_equal(runs[0].view(np.uint8), runs[2].view(np.uint8)), cls.__name__
+        h1 = runs[0]["t"] < 1e30
+        assert np.all(runs[0]["prim"][h1] < ntri), cls.__name__
+        records[cls.__name__] = runs[0]
+        sc.free()
+    names = list(records)
+    for nm in names[1:]:   # and across layouts
+        assert np.array_equal(records[nm].view(np.uint8), records[names[0]].view(np.uint8)), nm
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("cls", LAYOUTS)
 def test_every_instance_twice(ctx, cls):
     """Two-level: every instance exists twice with the same transform, so every hit is a tie between two instances.  The record must be the
-    one of the scene with each instance once — t, u, v, prim bit for bit — with hit.inst naming either copy."""
+    one of the scene with each instance once — t, u, v, prim bit for bit — with hit.inst naming the FIRST copy (the smaller instance index),
+    the same in three runs of a batch large enough for split rays."""
     verts = scenes.blob(5_000, seed=8)
     blas = cls(ctx).Build(verts)
     g = np.stack(np.meshgrid(np.arange(3), np.arange(3), np.arange(3), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
@@ -197,14 +221,11 @@ def test_every_instance_twice(ctx, cls):
     T[:, :3, 3] = g * 2.2
     once = tb.TLAS(ctx).Build(tb.make_instances(T, np.zeros(k, np.uint32)), [blas])
     twice = tb.TLAS(ctx).Build(tb.make_instances(np.concatenate([T, T]), np.zeros(2 * k, np.uint32)), [blas])
-    rays = R.random_rays(40_000, (-1.0, -1.0, -1.0), (6.0, 6.0, 6.0), seed=6)
+    rays = R.random_rays(400_000, (-1.0, -1.0, -1.0), (6.0, 6.0, 6.0), seed=6)
     want = once.Intersect(rays.copy())
     hit = want["t"] < 1e30
-    assert hit.sum() > 5000
+    assert hit.sum() > 50_000
     for rep in range(3):
         got = twice.Intersect(rays.copy())
-        assert np.array_equal(got["t"] < 1e30, hit)
-        for f in ("t", "u", "v", "prim"):
-            assert np.array_equal(got[f][hit].view(np.uint32), want[f][hit].view(np.uint32)), (cls.__name__, f, rep)
-        assert np.array_equal(got["inst"][hit] % k, want["inst"][hit]), (cls.__name__, rep)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (cls.__name__, rep)
     once.free(); twice.free(); blas.free()

@@ -37,7 +37,8 @@ def oracle_tlas(oracle, tlas, blas_list, rays):
 def check(got, want):
     c = compare_hits(got, want)
     assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0, c
-    assert c["tie"] <= 2 and c["onsurf"] <= 4, c
+    # the oracle runs under the library's tie rule (smaller prim, then smaller instance, at exactly equal t): no tie class left
+    assert c["tie"] == 0 and c["onsurf"] <= 4, c
     assert c["bit_identical"] == c["same_prim"], c
     same = (got["t"] < 1e30) & (got["prim"] == want["prim"]) & (got["t"] == want["t"])
     assert np.array_equal(got["inst"][same], want["inst"][same])
@@ -63,7 +64,8 @@ def test_host_tlas_build_updates_instances():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("layout", [tb.LAYOUT_CWBVH, tb.LAYOUT_BVH4_GPU])
-def test_tlas_parity(ctx, oracle, layout):
+def test_tlas_parity(ctx, oracle_ties, layout):
+    oracle = oracle_ties
     verts = scenes.blob(6000, seed=3)
     verts2 = scenes.soup(2000, seed=9, extent=1.6, size=0.25); verts2[:, :3] -= 0.8
     blas = [tb.LAYOUT_CLASSES[layout](ctx).Build(verts), tb.LAYOUT_CLASSES[layout](ctx).Build(verts2)]
@@ -95,47 +97,12 @@ def test_tlas_parity(ctx, oracle, layout):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("layout", [tb.LAYOUT_CWBVH, tb.LAYOUT_BVH4_GPU])
-@pytest.mark.parametrize("variant,name", [(3, "nested loops"), (7, "flat loop, per-lane replacement"), (6, "flat loop, lockstep governor"),
-                                          (9, "flat loop, lockstep"), (13, "nested then flat"), (5, "round-1 kernel")])
-def test_every_tlas_kernel_gives_the_same_records(ctx, oracle, layout, variant, name):
-    """The TLAS query exists as nested loops (whole-wave batches), as one flat loop with per-lane ray replacement, and as
-    the adaptive pair; the default picks by BLAS layout.  All of them must return the oracle's records — the same
-    instances, nodes and triangles are visited in the same per-ray order."""
-    verts = scenes.blob(5000, seed=11)
-    blas = [tb.LAYOUT_CLASSES[layout](ctx).Build(verts)]
-    inst = grid_instances(5, 0.5, 3)
-    tlas = tb.TLAS(ctx).Build(inst, blas)
-    rng_rays = R.random_rays(40_000, (-2, -2, -2), (9, 9, 9), seed=31)                       # incoherent
-    cam = R.camera((-4.0, 9.0, -6.0), (0.55, -0.45, 0.7), 256, 128, 1, 1)
-    cam_rays = R.primary(cam)                                                                # coherent
-    for rays in (rng_rays, cam_rays):
-        want = oracle_tlas(oracle, tlas, blas, rays)
-        tlas.set_variant(0)
-        base = tlas.Intersect(rays.copy())
-        try:
-            tlas.set_variant(variant)
-        except tb.TbvhError:
-            pytest.skip("kernel variants other than the default exist in experiment builds only (make EXPERIMENTS=1)")
-        got = tlas.Intersect(rays.copy())
-        c = check(got, want)
-        assert c["hits"] > 1000, (name, c)
-        # and what the default kernel returns: bit for bit, except among hits at exactly equal t when the two kernels visit instances in
-        # another order (the default for BVH4_GPU BLASes walks a 4-wide TLAS nearest child first, kernels_tlas4.hip)
-        differ = np.flatnonzero((got["prim"] != base["prim"]) | (got["inst"] != base["inst"]))
-        assert differ.size <= max(2, c["hits"] // 2000) and np.array_equal(got["t"][differ], base["t"][differ]), (name, differ.size)
-        same = np.ones(got.shape[0], bool); same[differ] = False
-        assert np.array_equal(got[same].view(np.uint8), base[same].view(np.uint8)), name
-        occ = tlas.IsOccluded(rays.copy())
-        assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2, name
-
-
-@pytest.mark.gpu
 @pytest.mark.parametrize("layouts", [(tb.LAYOUT_BVH_GPU,), (tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH_GPU), (tb.LAYOUT_CWBVH, tb.LAYOUT_BVH_GPU),
                                      (tb.LAYOUT_BVH4_GPU, tb.LAYOUT_CWBVH, tb.LAYOUT_BVH_GPU)])
-def test_bvh_gpu_blases_and_mixed_blas_layouts(ctx, oracle, layouts):
+def test_bvh_gpu_blases_and_mixed_blas_layouts(ctx, oracle_ties, layouts):
     """traverse_tlas.cl:50-72 picks the BLAS traversal per instance (blasDesc[].blasType: CWBVH for static geometry,
     Aila-Laine BVH_GPU for dynamic / rigid meshes).  Same here: a TLAS may mix BVH8_CWBVH, BVH4_GPU and BVH_GPU BLASes."""
+    oracle = oracle_ties
     meshes = [scenes.blob(4000, seed=3), scenes.soup(1500, seed=9, extent=1.6, size=0.25), scenes.blob(2500, seed=8)]
     meshes[1][:, :3] -= 0.8
     blas = [tb.LAYOUT_CLASSES[l](ctx).Build(meshes[i]) for i, l in enumerate(layouts)]

@@ -101,6 +101,13 @@ class Context:
     def time_last_ms(self) -> float:
         return float(lib.tbvh_time_last_ms(self._h))
 
+    def last_probe(self):
+        """(agreeing pairs, pairs, verdict) of the coherence probe of the most recent query: verdict 0 = no probe ran,
+        1 = incoherent (strict schedule), 2 = coherent (tbvh_debug_last_probe)."""
+        out = (C.c_uint32 * 3)()
+        check(lib.tbvh_debug_last_probe(self._h, out), "tbvh_debug_last_probe")
+        return int(out[0]), int(out[1]), int(out[2])
+
     # device buffers (replace tinyocl::Buffer for resident rays)
     def malloc(self, nbytes: int) -> int:
         p = C.c_void_p()
@@ -127,6 +134,11 @@ class Context:
 
     def generate_bounce(self, d_verts: int, d_in: int, d_out: int, n: int, seed: int):
         check(lib.tbvh_generate_bounce_device(self._h, C.c_void_p(d_verts), C.c_void_p(d_in), C.c_void_p(d_out), n, seed), "tbvh_generate_bounce_device")
+
+    def bin_rays(self, d_in: int, d_out: int, n: int, bounds6, cell_bits: int = 5, flags: int = 1, d_perm: int = 0):
+        """Counting sort of a resident batch by (Morton code of the origin's cell, direction octant): tbvh_bin_rays_device."""
+        b = (C.c_float * 6)(*[float(x) for x in bounds6])
+        check(lib.tbvh_bin_rays_device(self._h, C.c_void_p(d_in), C.c_void_p(d_out), n, b, cell_bits, flags, C.c_void_p(d_perm or 0)), "tbvh_bin_rays_device")
 
     def generate_shadow(self, d_in: int, d_out: int, n: int, light, eps: float):
         l = (C.c_float * 3)(*[float(x) for x in light])
@@ -253,6 +265,11 @@ class _Scene:
 
     def set_variant(self, v: int):
         check(lib.tbvh_set_variant(self._h, v), "tbvh_set_variant")
+
+    def set_hybrid(self, packed_nodes: int):
+        """BVH8_CWBVH: traverse a priority-ordered copy of the nodes whose first `packed_nodes` are packed and the others
+        one per 128-byte line (tbvh_cwbvh_set_hybrid); < 0: back to the uploaded array."""
+        check(lib.tbvh_cwbvh_set_hybrid(self._h, int(packed_nodes)), "tbvh_cwbvh_set_hybrid")
 
     def Intersect(self, rays: np.ndarray) -> np.ndarray:
         """rays: structured RAY_DTYPE array (64-byte records) or a (n, 128)-byte host Ray[] view;

@@ -60,7 +60,7 @@ struct tbvh_context {
     uint32_t spillEntries = 0;    // 32-bit entries per lane
     unsigned long long* counter = nullptr;  // status word, instrumentation counters
     uint32_t poolParts = 5;   // log2: 32 partitions
-    int tlasVariant = 0;           // TBVH_TLAS_VARIANT: kernel variant of TLAS scenes that did not pick one (experiment knob)
+    bool lastProbed = false;   // the most recent query launch ran the coherence probe (tbvh_debug_last_probe)
     bool gridOverride = false;     // TBVH_BLOCKS_PER_CU / TBVH_RAYS_PER_BLOCK given: no per-scene adjustment
     uint64_t splitBelow = 12ull << 20;   // batches of fewer rays split their last rays over idle lanes; TBVH_SPLIT_RAYS=0 turns that off (tie order then reproducible run to run)
     uint32_t raysPerBlock = 128;   // small batches: one workgroup per this many rays (with split rays, profiles/r02_grid_sweep.txt: 96-128 best on 1 M-ray batches, +5 % over 192; flat at 4 M)
@@ -75,6 +75,8 @@ struct tbvh_context {
     // hipMemcpy2D moves ~9 GB/s because one CPU thread does the staging copy), and the 20 result bytes per ray come back
     // packed (k_pack_hits) and are scattered by the same workers
     struct HostPipe* pipe = nullptr;
+    void* binScratch = nullptr;   // tbvh_bin_rays_device
+    size_t binScratchBytes = 0;
     std::vector<tbvh_scene*> scenes;
 };
 
@@ -84,10 +86,10 @@ struct tbvh_scene {
     int variant = 0;
     float4* nodes = nullptr;   // BVH_GPU nodes / BVH4 stream / CWBVH nodes
     float4* tris = nullptr;    // BVH_GPU gathered tris / CWBVH tris
-    char* nodesH = nullptr;    // CWBVH: 128-byte re-laid-out nodes (kernels_cwbvh_h.hip)
-    float4* nodes128 = nullptr; // CWBVH: the same nodes padded to 128 bytes (variant 47)
-    float4* tris64 = nullptr;   // CWBVH: triangle records padded to 64 bytes
-    float4* nodesP = nullptr;  // CWBVH: nodes renumbered in surface-area priority order (kernels_cwbvh_c.hip)
+    float4* nodes128 = nullptr; // CWBVH: the same nodes padded to one 128-byte line each (padCwbvhIfLarge: node arrays beyond the Infinity Cache)
+    float4* nodesHy = nullptr;  // CWBVH: the same nodes in surface-area priority order, the first hybridK packed, the others one per line (cwbvh_node.h: kNodeHybrid)
+    uint32_t* hyPerm = nullptr; // device: position of node i in nodesHy
+    uint32_t hybridK = 0;
     uint32_t nNodes = 0;
     uint64_t nNodeBlocks = 0, nTriBlocks = 0;
     uint64_t bytes = 0;
@@ -130,6 +132,7 @@ struct tbvh_scene {
     // opacity micromaps (BVHBase::SetOpacityMicroMaps)
     uint32_t* opmap = nullptr;
     uint32_t opmapN = 0;
+    uint64_t opmapBytes = 0;
     uint64_t vertStageTris = 0;
 };
 
@@ -316,7 +319,8 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     q.spill = c->spill; q.counter = (uint32_t*)c->pool; q.poolParts = c->poolParts;
     q.stats = c->counter + 8;
     q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.omm = Omm{s->opmap, s->opmapN};
-    q.probe = nullptr; q.baseBlocks = 0;
+    q.probe = nullptr; q.baseBlocks = 0; q.hybridK = s->hybridK;
+    c->lastProbed = false;
     q.splitBelow = c->splitBelow;
     // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
     // (about one workgroup per 128 rays, measured best for 1 M-ray launches) so every wave still
@@ -337,42 +341,42 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     // rays and more (the probe costs ~10 us, 3-4 % of a 1 M-ray launch): a 16-workgroup probe of the batch's coherence (4096 neighbour pairs)
     // lets the traversal kernel pick its schedule for the launch; a coherent batch also gets a third more waves (the surplus leaves at once
     // otherwise).  Bistro stand-in, 16.7 M rays: camera rays +4.5 %, shadow rays +6 %, bounce rays unchanged.
-    if (!s->isTlas && !small && s->bytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || (TBVH_EXPERIMENTS && s->variant == 88))) {
+    if (!s->isTlas && !small && s->bytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || s->variant == 88)) {
         uint32_t* probe = (uint32_t*)c->pool + (size_t)kPoolParts * kPoolCounterStride;
         launch_coherence_probe(d_rays, n, nDev, probe, c->stream);
         HIP_TRY(hipGetLastError());
         q.probe = probe; q.baseBlocks = blocks;
+        c->lastProbed = true;
         if (!c->gridOverride && blocks == c->blocks) blocks = c->blocks + c->blocks / 3u;   // 24 -> 32 one-wave workgroups per CU
     }
     if (s->isTlas) {
-        const int tv = s->variant ? s->variant : c->tlasVariant;
         const uint32_t blocks7 = (!c->gridOverride && blocks == c->blocks) ? (uint32_t)c->numCUs * 28u : blocks;   // the full grid of the kernels built for 7 waves per SIMD
-        if (s->tlas4 && s->blasLayout == TBVH_LAYOUT_BVH4_GPU && (tv == 0 || (tv >= 21 && tv <= 36))) {   // BVH4_GPU BLASes: the unified 4-wide kernel
+        if (s->tlas4 && s->blasLayout == TBVH_LAYOUT_BVH4_GPU) {   // BVH4_GPU BLASes: the unified 4-wide kernel
             q.spillStride = c->spillEntries;   // 32-bit stack entries
-            launch_tlas4(any, tv, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
+            launch_tlas4(any, 0, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
             c->timed = true;
             return 0;
         }
-        if (s->tlas8 && (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2) && (tv == 0 || (tv >= 21 && tv <= 36))) {   // BVH8_CWBVH BLASes (or those and BVH_GPU ones): the unified 8-wide kernel
+        if (s->tlas8 && (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2)) {   // BVH8_CWBVH BLASes (or those and BVH_GPU ones): the unified 8-wide kernel
             q.spillStride = c->spillEntries / 2;   // 8-byte stack entries
-            launch_tlas8(any, tv, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7, s->blasMixCw2);
+            launch_tlas8(any, 0, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7, s->blasMixCw2);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
             c->timed = true;
             return 0;
         }
-        if (s->blasLayout == TBVH_LAYOUT_BVH_GPU && (tv == 0 || (tv >= 21 && tv <= 36))) {   // BVH_GPU BLASes: the TLAS already has their node format (kernels_tlas2.hip)
+        if (s->blasLayout == TBVH_LAYOUT_BVH_GPU) {   // BVH_GPU BLASes: the TLAS already has their node format (kernels_tlas2.hip)
             q.spillStride = c->spillEntries;   // 32-bit stack entries
-            launch_tlas2(any, tv, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
+            launch_tlas2(any, 0, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
             c->timed = true;
             return 0;
         }
         q.spillStride = c->spillEntries / 2;
-        launch_tlas(any, s->blasLayout, s->variant ? s->variant : c->tlasVariant, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+        launch_tlas(any, s->blasLayout, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         c->timed = true;
@@ -389,15 +393,10 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         break;
     case TBVH_LAYOUT_CWBVH:
         q.spillStride = c->spillEntries / 2;  // 8-byte entries
-#if TBVH_EXPERIMENTS
-        if (s->variant >= 30 && s->variant < 40) launch_cwbvh_c(any, s->variant, s->nodesP, s->tris, s->nNodes, q, c->status, (uint32_t)c->numCUs, c->stream);
-        else if (s->variant >= 20 && s->variant < 30) launch_cwbvh_h(any, s->variant, s->nodesH, s->tris, q, c->status, blocks, c->stream);
-        else
-#endif
         {
             const bool autoPad = s->variant == 0 && s->nodes128 != nullptr;   // nodes beyond the Infinity Cache: the padded copy (padCwbvhIfLarge)
-            launch_cwbvh(any, s->variant, (autoPad || cwbvh_variant_padded(s->variant)) ? s->nodes128 : s->nodes, cwbvh_variant_tri64(s->variant) ? s->tris64 : s->tris, q, c->status, blocks,
-                         c->stream, autoPad, small);
+            const bool hybrid = s->variant == 0 && !autoPad && s->nodesHy != nullptr;
+            launch_cwbvh(any, s->variant, autoPad ? s->nodes128 : hybrid ? s->nodesHy : s->nodes, s->tris, q, c->status, blocks, c->stream, autoPad ? 8 : hybrid ? 13 : 5, small);
         }
         break;
     default:
@@ -421,6 +420,10 @@ int checkStatus(tbvh_context* c) {
         hipMemsetAsync(c->status, 0, 4, c->stream);
         return fail(TBVH_E_FORMAT, "refit: a triangle record refers to a primitive beyond the vertex array");
     }
+    if (st & 4u) {
+        hipMemsetAsync(c->status, 0, 4, c->stream);
+        return fail(TBVH_E_FORMAT, "wide TLAS build: the node capacity did not hold the collapsed tree");
+    }
     return 0;
 }
 
@@ -437,6 +440,8 @@ int padCwbvhIfLarge(tbvh_scene* s) {
     s->bytes += (uint64_t)s->nNodes * 128;
     return 0;
 }
+
+size_t hybridBytes(uint32_t nNodes, uint32_t K) { return ((size_t)K * 5 + (size_t)(nNodes - K) * 8) * 16; }
 
 tbvh_scene* newScene(tbvh_context* c, int layout) {
     tbvh_scene* s = new (std::nothrow) tbvh_scene;
@@ -488,7 +493,6 @@ int tbvh_init(int device, tbvh_context** out) {
         const int b = atoi(e);
         if (b >= 64 && b <= 4096) { c->raysPerBlock = (uint32_t)b; c->gridOverride = true; }
     }
-    if (const char* e = getenv("TBVH_TLAS_VARIANT")) c->tlasVariant = atoi(e);   // experiment knob
     if (const char* e = getenv("TBVH_SPLIT_RAYS")) { if (atoi(e) == 0) c->splitBelow = 0; }
     if (const char* e = getenv("TBVH_POOL_PARTS")) {  // experiment knob
         const int b = atoi(e);
@@ -522,6 +526,7 @@ void tbvh_shutdown(tbvh_context* c) {
     if (c->pool) hipFree(c->pool);
     if (c->stageRays) hipFree(c->stageRays);
     if (c->stageOcc) hipFree(c->stageOcc);
+    if (c->binScratch) hipFree(c->binScratch);
     delete c->pipe;
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
@@ -613,7 +618,13 @@ int buildTlas4(tbvh_scene* s) {
     tbvh_context* c = s->ctx;
     if (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2) {
         const uint64_t cap = tlas8_cap_nodes(s->nTlasNodes, s->nInst);
-        if (cap > 0x00ffffffull) return 0;   // wide-node indices share a word with 8 flag bits in places: the flat loop serves larger TLASes
+        if (cap > 0x00ffffffull) {   // wide-node indices share a word with 8 flag bits in places: the flat loop serves larger TLASes — and a wide
+            // TLAS left from an earlier, smaller upload must not be traversed in its place (launchQuery keys on the pointer)
+            if (s->tlas8) hipFree(s->tlas8);
+            if (s->tlas8Refs) hipFree(s->tlas8Refs);
+            s->tlas8 = nullptr; s->tlas8Refs = nullptr; s->tlas8Cap = 0;
+            return 0;
+        }
         if (cap > s->tlas8Cap) {
             if (s->tlas8) hipFree(s->tlas8);
             if (s->tlas8Refs) hipFree(s->tlas8Refs);
@@ -621,6 +632,7 @@ int buildTlas4(tbvh_scene* s) {
             HIP_TRY(hipMalloc((void**)&s->tlas8, cap * 80));
             HIP_TRY(hipMalloc((void**)&s->tlas8Refs, cap * 4));
             s->tlas8Cap = cap;
+            s->bytes += cap * 84;
         }
         const size_t sb = tlas_wide_scratch_bytes(s->nTlasNodes, s->nInst);
         if (sb > s->tlas4ScratchBytes) {
@@ -630,19 +642,23 @@ int buildTlas4(tbvh_scene* s) {
             s->tlas4ScratchBytes = sb;
         }
         launch_tlas8_build(s->nodes, (uint32_t)s->nTlasNodes, s->tlasIdx, (uint32_t)s->nTlasIdx, s->instances, (uint32_t)s->nInst, s->tlas8, (uint32_t)s->tlas8Cap, s->tlas8Refs,
-                           (uint32_t)s->tlas8Cap, s->tlas4Scratch, c->stream);
+                           (uint32_t)s->tlas8Cap, s->tlas4Scratch, c->status, c->stream);
         HIP_TRY(hipGetLastError());
-        s->bytes += cap * 84;
         return 0;
     }
     if (s->blasLayout != TBVH_LAYOUT_BVH4_GPU) return 0;
     const uint64_t cap = tlas4_cap_blocks(s->nTlasNodes, s->nInst);
-    if (cap > 0x7fffffffull) return 0;   // beyond 31-bit block offsets: the BVH_GPU TLAS kernels serve this TLAS
+    if (cap > 0x7fffffffull) {   // beyond 31-bit block offsets: the flat loop serves this TLAS; drop a 4-wide TLAS of an earlier, smaller upload
+        if (s->tlas4) hipFree(s->tlas4);
+        s->tlas4 = nullptr; s->tlas4Cap = 0;
+        return 0;
+    }
     if (cap > s->tlas4Cap) {
         if (s->tlas4) hipFree(s->tlas4);
         s->tlas4 = nullptr; s->tlas4Cap = 0;
         HIP_TRY(hipMalloc((void**)&s->tlas4, cap * 16));
         s->tlas4Cap = cap;
+        s->bytes += cap * 16;
     }
     const size_t sb = tlas_wide_scratch_bytes(s->nTlasNodes, s->nInst);
     if (sb > s->tlas4ScratchBytes) {
@@ -651,9 +667,8 @@ int buildTlas4(tbvh_scene* s) {
         HIP_TRY(hipMalloc(&s->tlas4Scratch, sb));
         s->tlas4ScratchBytes = sb;
     }
-    launch_tlas4_build(s->nodes, (uint32_t)s->nTlasNodes, s->tlasIdx, (uint32_t)s->nTlasIdx, s->instances, (uint32_t)s->nInst, s->tlas4, (uint32_t)s->tlas4Cap, s->tlas4Scratch, c->stream);
+    launch_tlas4_build(s->nodes, (uint32_t)s->nTlasNodes, s->tlasIdx, (uint32_t)s->nTlasIdx, s->instances, (uint32_t)s->nInst, s->tlas4, (uint32_t)s->tlas4Cap, s->tlas4Scratch, c->status, c->stream);
     HIP_TRY(hipGetLastError());
-    s->bytes += cap * 16;
     return 0;
 }
 
@@ -857,21 +872,31 @@ int tbvh_set_opacity_micromaps(tbvh_scene* s, const uint32_t* mapData, uint32_t 
     if (!s || s->isTlas) return fail(TBVH_E_INVALID, "tbvh_set_opacity_micromaps: not a BLAS scene (set the maps on the BLASes before uploading their TLAS)");
     tbvh_context* c = s->ctx;
     if (int r = setDevice(c)) return r;
+    // validate first, build the new map next, and only then swap it in: every exit leaves the scene and the TLASes over it (their BlasDesc
+    // snapshots) pointing at live memory — the old maps on a failure, the new ones on success
+    const bool clear = !mapData || N == 0;
+    if (!clear && (N > 1024 || nTris == 0)) return fail(TBVH_E_INVALID, "tbvh_set_opacity_micromaps: N = %u, %llu triangles", N, (unsigned long long)nTris);
+    uint32_t* fresh = nullptr;
+    uint64_t freshBytes = 0;
+    if (!clear) {
+        const uint64_t wordsPerTri = ((uint64_t)N * N + 31) >> 5, words = wordsPerTri * nTris;
+        // the reference's index can run one row past the map when u + v == 1 exactly (tiny_bvh.h:8518-8519): keep that read inside the allocation
+        const uint64_t pad = (((uint64_t)N + 1) * (N + 1) + 63) >> 5;
+        freshBytes = (words + pad) * 4;
+        if (hipMalloc((void**)&fresh, freshBytes) != hipSuccess) { (void)hipGetLastError(); return fail(TBVH_E_NOMEM, "tbvh_set_opacity_micromaps: %llu bytes of device memory", (unsigned long long)freshBytes); }
+        hipError_t e = hipMemsetAsync(fresh + words, 0, pad * 4, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(fresh, mapData, words * 4, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(fresh); return fail(TBVH_E_HIP, "tbvh_set_opacity_micromaps: copying the maps failed: %s", hipGetErrorString(e)); }
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));   // no query may still read the old maps
-    if (s->opmap) { hipFree(s->opmap); s->opmap = nullptr; }
-    s->opmapN = 0;
-    if (!mapData || N == 0) return refreshBlasDescs(s);            // cleared
-    if (N > 1024 || nTris == 0) return fail(TBVH_E_INVALID, "tbvh_set_opacity_micromaps: N = %u, %llu triangles", N, (unsigned long long)nTris);
-    const uint64_t wordsPerTri = ((uint64_t)N * N + 31) >> 5, words = wordsPerTri * nTris;
-    // the reference's index can run one row past the map when u + v == 1 exactly (tiny_bvh.h:8518-8519): keep that read inside the allocation
-    const uint64_t pad = (((uint64_t)N + 1) * (N + 1) + 63) >> 5;
-    HIP_TRY(hipMalloc((void**)&s->opmap, (words + pad) * 4));
-    HIP_TRY(hipMemsetAsync(s->opmap + words, 0, pad * 4, c->stream));
-    HIP_TRY(hipMemcpyAsync(s->opmap, mapData, words * 4, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    s->opmapN = N;
-    s->bytes += (words + pad) * 4;
-    return refreshBlasDescs(s);
+    uint32_t* old = s->opmap;
+    const uint64_t oldBytes = s->opmapBytes;
+    s->opmap = fresh; s->opmapN = clear ? 0u : N; s->opmapBytes = freshBytes;
+    s->bytes += freshBytes; s->bytes -= oldBytes;
+    const int r = refreshBlasDescs(s);   // the descriptors are rewritten before the old maps go
+    if (old && r == 0) hipFree(old);   // (a failed refresh may have left a descriptor on the old maps: leak them rather than dangle)
+    return r;
 }
 
 int tbvh_scene_download(tbvh_scene* s, int which, void* dst, uint64_t capBytes, uint64_t* bytesOut) {
@@ -940,11 +965,8 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     // derived node layouts of the experiment kernels would be stale now
-    if (s->nodesH) { hipStreamSynchronize(c->stream); hipFree(s->nodesH); s->nodesH = nullptr; }
-    if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copies current
-    if (s->tris64) launch_cwbvh_pad_tris(s->tris, s->tris64, s->nTriBlocks / 3, c->stream);
-    if (s->nodesP) { hipStreamSynchronize(c->stream); hipFree(s->nodesP); s->nodesP = nullptr; }
-    if (s->variant >= 20 && s->variant < 40) s->variant = 0;
+    if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copy current
+    if (s->nodesHy) launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, nNodes, s->hybridK, c->stream);
     return 0;
 }
 
@@ -1026,10 +1048,9 @@ void tbvh_free_scene(tbvh_scene* s) {
     }
     if (s->nodes) hipFree(s->nodes);
     if (s->tris) hipFree(s->tris);
-    if (s->nodesH) hipFree(s->nodesH);
     if (s->nodes128) hipFree(s->nodes128);
-    if (s->tris64) hipFree(s->tris64);
-    if (s->nodesP) hipFree(s->nodesP);
+    if (s->nodesHy) hipFree(s->nodesHy);
+    if (s->hyPerm) hipFree(s->hyPerm);
     if (s->tlasIdx) hipFree(s->tlasIdx);
     if (s->instances) hipFree(s->instances);
     if (s->blasDesc) hipFree(s->blasDesc);
@@ -1052,45 +1073,9 @@ uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0;
 
 int tbvh_set_variant(tbvh_scene* s, int v) {
     if (!s) return fail(TBVH_E_INVALID, "null scene");
-    const bool ok = s->isTlas ? tlas_variant_valid(v)
-                  : s->layout == TBVH_LAYOUT_CWBVH ? (cwbvh_variant_valid(v) || (TBVH_EXPERIMENTS && v >= 20 && v <= 39)) : bvh_variant_valid(v);
-    if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d%s", v, s->layout, TBVH_EXPERIMENTS ? "" : " (experiment variants need a library built with make EXPERIMENTS=1)");
-    tbvh_context* c = s->ctx;
-    if (int r = setDevice(c)) return r;
-    // experimental kernels run on derived node layouts, built on first use
-    const bool cw = s->layout == TBVH_LAYOUT_CWBVH && !s->isTlas;
-    if (cw && cwbvh_variant_padded(v) && !s->nodes128) {
-        HIP_TRY(hipMalloc((void**)&s->nodes128, (size_t)s->nNodes * 128));
-        launch_cwbvh_pad(s->nodes, s->nodes128, s->nNodes, c->stream);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        s->bytes += (uint64_t)s->nNodes * 128;
-    }
-    if (cw && cwbvh_variant_tri64(v) && !s->tris64) {
-        const uint64_t nT = s->nTriBlocks / 3;
-        HIP_TRY(hipMalloc((void**)&s->tris64, (nT ? nT : 1) * 64));
-        launch_cwbvh_pad_tris(s->tris, s->tris64, nT, c->stream);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        s->bytes += nT * 64;
-    }
-#if TBVH_EXPERIMENTS
-    if (cw && v >= 20 && v < 30 && !s->nodesH) {
-        HIP_TRY(hipMalloc((void**)&s->nodesH, (size_t)s->nNodes * 128));
-        launch_cwbvh_relayout(s->nodes, s->nodesH, s->nNodes, c->stream);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        s->bytes += (uint64_t)s->nNodes * 128;
-    }
-    if (cw && v >= 30 && v < 40 && !s->nodesP) {
-        std::vector<Vec4> in((size_t)s->nNodes * 5), pr;
-        HIP_TRY(hipMemcpy(in.data(), s->nodes, in.size() * 16, hipMemcpyDeviceToHost));
-        reorder_cwbvh_priority(in.data(), s->nNodes, pr);
-        HIP_TRY(hipMalloc((void**)&s->nodesP, pr.size() * 16));
-        HIP_TRY(hipMemcpy(s->nodesP, pr.data(), pr.size() * 16, hipMemcpyHostToDevice));
-        s->bytes += pr.size() * 16;
-    }
-#endif
+    // only the BVH8_CWBVH kernel keeps diagnostic variants (kernels_cwbvh.hip: forced schedules, instrumented kernels)
+    const bool ok = v == 0 || (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH && cwbvh_variant_valid(v));
+    if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
     s->variant = v;
     return 0;
 }
@@ -1217,6 +1202,73 @@ int tbvh_debug_stats(tbvh_context* c, uint64_t out[8], int reset) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, c->counter + 8, 64, hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(c->counter + 8, 0, 64));
+    return 0;
+}
+
+int tbvh_bin_rays_device(tbvh_context* c, const void* dIn, void* dOut, uint64_t n, const float bounds6[6], uint32_t cellBits, uint32_t flags, uint32_t* dPerm) {
+    if (!c || !bounds6 || ((!dIn || !dOut) && n)) return fail(TBVH_E_INVALID, "tbvh_bin_rays_device: null argument");
+    if (dIn == dOut) return fail(TBVH_E_INVALID, "tbvh_bin_rays_device: the batch cannot be binned in place");
+    if (cellBits > 6 || (flags & ~3u) || (flags & 3u) == 3u) return fail(TBVH_E_INVALID, "tbvh_bin_rays_device: cell_bits 0..6, flags 0, 1 or 2");
+    if (n > 0xffffffffull) return fail(TBVH_E_INVALID, "tbvh_bin_rays_device: at most 2^32 - 1 rays per call");
+    if (int r = setDevice(c)) return r;
+    if (!n) return 0;
+    size_t scanTemp = 0;
+    const size_t need = ray_bin_scratch_bytes(n, cellBits, flags, &scanTemp);
+    if (need > c->binScratchBytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->binScratch) hipFree(c->binScratch);
+        c->binScratch = nullptr; c->binScratchBytes = 0;
+        HIP_TRY(hipMalloc(&c->binScratch, need));
+        c->binScratchBytes = need;
+    }
+    RayBinArgs a;
+    for (int k = 0; k < 3; k++) {
+        a.lo[k] = bounds6[k];
+        const float ext = bounds6[3 + k] - bounds6[k];
+        a.scale[k] = ext > 0 ? (float)(1u << cellBits) / ext : 0.f;
+    }
+    a.cellBits = cellBits; a.flags = flags;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(launch_ray_bin((const RayRec*)dIn, (RayRec*)dOut, dPerm, n, nullptr, a, c->binScratch, scanTemp, (uint32_t)c->numCUs * 16u, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return 0;
+}
+
+int tbvh_cwbvh_set_hybrid(tbvh_scene* s, int64_t packedNodes) {
+    if (!s || s->isTlas || s->layout != TBVH_LAYOUT_CWBVH) return fail(TBVH_E_INVALID, "tbvh_cwbvh_set_hybrid: not a BVH8_CWBVH scene");
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (s->nodesHy) { s->bytes -= hybridBytes(s->nNodes, s->hybridK); hipFree(s->nodesHy); s->nodesHy = nullptr; }
+    if (packedNodes < 0) return 0;
+    const uint32_t K = (uint32_t)std::min<uint64_t>((uint64_t)packedNodes, s->nNodes) & ~7u;   // the padded part starts on a 128-byte line
+    if (!s->hyPerm) {
+        std::vector<Vec4> host((size_t)s->nNodes * 5);
+        HIP_TRY(hipMemcpy(host.data(), s->nodes, host.size() * 16, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> perm;
+        cwbvh_priority_order(host.data(), s->nNodes, perm);
+        HIP_TRY(hipMalloc((void**)&s->hyPerm, (size_t)s->nNodes * 4));
+        HIP_TRY(hipMemcpy(s->hyPerm, perm.data(), (size_t)s->nNodes * 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc((void**)&s->nodesHy, hybridBytes(s->nNodes, K)));
+    HIP_TRY(hipMemsetAsync(s->nodesHy, 0, hybridBytes(s->nNodes, K), c->stream));
+    s->hybridK = K;
+    launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, s->nNodes, K, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    s->bytes += hybridBytes(s->nNodes, K);
+    return 0;
+}
+
+int tbvh_debug_last_probe(tbvh_context* c, uint32_t out[3]) {
+    if (!c || !out) return fail(TBVH_E_INVALID, "tbvh_debug_last_probe: null argument");
+    if (int r = setDevice(c)) return r;
+    out[0] = out[1] = out[2] = 0;
+    if (!c->lastProbed) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, (uint32_t*)c->pool + (size_t)kPoolParts * kPoolCounterStride, 8, hipMemcpyDeviceToHost));
+    out[2] = (out[1] != 0 && out[0] * 10u >= out[1] * 6u) ? 2u : 1u;   // the rule of k_cwbvh (kernels_cwbvh.hip)
     return 0;
 }
 

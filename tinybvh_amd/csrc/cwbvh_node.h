@@ -27,10 +27,15 @@ __device__ __forceinline__ uint32_t cw_sext_s8x4(uint32_t i) {
 struct CwNode { float4 n0, n1, n2, n3, n4; };   // one node as fetched
 struct CwNodeHits { uint32_t childBase, triBase, hitmask, imask; };
 
-// NSTRIDE: float4s between consecutive nodes (5 = the reference's packed array; 8 = padded to one 128-byte line)
+// NSTRIDE: float4s between consecutive nodes: 5 = the reference's packed array; 8 = one node per 128-byte line; kNodeHybrid = the first
+// hybridK nodes (surface-area priority order: the top of the tree, which lives in the L2s — there the packed form moves 40 % more nodes
+// per second) packed, all later ones (fetched from beyond the L2s, where a line is the unit and a packed node straddles 1.6 of them) one
+// per line.  hybridK is a multiple of 8, so the padded part starts on a line.
+constexpr int kNodeHybrid = 13;
 template <int NSTRIDE = 5>
-__device__ __forceinline__ CwNode cw_load_node(const float4* __restrict__ nodes, uint32_t nodeIdx) {
-    const float4* np = nodes + (size_t)nodeIdx * (uint32_t)NSTRIDE;
+__device__ __forceinline__ CwNode cw_load_node(const float4* __restrict__ nodes, uint32_t nodeIdx, uint32_t hybridK = 0u) {
+    const size_t off = NSTRIDE == kNodeHybrid ? (size_t)nodeIdx * 8u - (size_t)(nodeIdx < hybridK ? nodeIdx : hybridK) * 3u : (size_t)nodeIdx * (uint32_t)NSTRIDE;
+    const float4* np = nodes + off;
     return CwNode{np[0], np[1], np[2], np[3], np[4]};
 }
 __device__ __forceinline__ CwNode cw_load_node(const GlobalF4 nodes, uint32_t nodeIdx) {

@@ -85,6 +85,19 @@ __device__ __forceinline__ bool tri_test(float3 O, float3 D, float3 v0, float3 e
 
 __device__ __forceinline__ float3 xyz(float4 v) { return make_float3(v.x, v.y, v.z); }
 
+// The library's tie rule.  tri_test has established t <= best.x; the candidate replaces the closest hit so far iff it is the
+// first hit of this traversal, strictly closer, or equally far with the smaller primitive index (two-level kernels: then the smaller
+// instance).  Every candidate at the final distance is tested whatever the visit order (nodes at tmin == best are visited: inclusive slab
+// test), so the reported triangle does not depend on the schedule, on split rays or on the layout's child order.  The reference lets the
+// LATER test win (tiny_bvh.h:1656: t <= ray.hit.t is accepted), i.e. its result among exactly equal t depends on the traversal order, and
+// its own layouts disagree with each other there; oracle/tbvh_oracle.c restates both rules (orc_set_tie_rule).
+__device__ __forceinline__ bool hit_wins(float t, uint32_t prim, bool found, float4 best) {
+    return !found || t < best.x || prim < as_u32(best.w);
+}
+__device__ __forceinline__ bool hit_wins(float t, uint32_t prim, uint32_t inst, bool found, float4 best, uint32_t bestInst) {
+    return !found || t < best.x || prim < as_u32(best.w) || (prim == as_u32(best.w) && inst < bestInst);
+}
+
 // Kernel launch parameters common to the query kernels.
 struct QueryArgs {
     RayRec* rays;          // device, 64-byte stride
@@ -104,6 +117,7 @@ struct QueryArgs {
     // sampled; nullptr = no probe ran (small batches).  baseBlocks: workgroups beyond this index only take part when the batch is coherent.
     const uint32_t* probe;
     uint32_t baseBlocks;
+    uint32_t hybridK;      // BVH8_CWBVH, hybrid node array (cwbvh_node.h: kNodeHybrid): nodes below this index are packed, the others one per line
 };
 
 // Host side: does this launch use the kernels with split rays?  Batches below the threshold, and the wavefront stages (ray count

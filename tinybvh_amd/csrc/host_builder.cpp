@@ -797,7 +797,7 @@ void update_instance(Instance192& inst, const float* bb) {
 
 }  // namespace tbvh
 
-// ---- CWBVH node renumbering for the LDS-resident top of the tree (kernels_cwbvh_c.hip) --------
+// ---- CWBVH node renumbering: the nodes a ray is most likely to visit first -----------------------
 #include <queue>
 namespace tbvh {
 
@@ -805,11 +805,9 @@ namespace tbvh {
 // area and give its interior children the next consecutive indices (slot order, so
 // childBaseIndex + popc(...) addressing still works).  The first K nodes of the result are
 // (to first order) the K nodes a random ray is most likely to visit.  Works on any valid
-// CWBVH blob, reference-built or ours; only childBaseIndex fields change.
-void reorder_cwbvh_priority(const Vec4* in, uint32_t nNodes, std::vector<Vec4>& out) {
-    out.assign((size_t)nNodes * 5, Vec4{0, 0, 0, 0});
+// CWBVH blob, reference-built or ours.  newIdx[old] = new; unreachable nodes keep 0xffffffff.
+void cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>& newIdx) {
     auto u32 = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-    auto f32 = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
     auto area = [&](uint32_t n) {
         const Vec4* p = in + (size_t)n * 5;
         const uint32_t ew = u32(p[0].w);
@@ -822,7 +820,7 @@ void reorder_cwbvh_priority(const Vec4* in, uint32_t nNodes, std::vector<Vec4>& 
         }
         return ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0];
     };
-    std::vector<uint32_t> newIdx(nNodes, 0xffffffffu);
+    newIdx.assign(nNodes, 0xffffffffu);
     std::priority_queue<std::pair<float, uint32_t>> pq;
     newIdx[0] = 0;
     uint32_t next = 1;
@@ -832,9 +830,6 @@ void reorder_cwbvh_priority(const Vec4* in, uint32_t nNodes, std::vector<Vec4>& 
         const Vec4* p = in + (size_t)n * 5;
         const uint32_t imask = u32(p[0].w) >> 24, base = u32(p[1].x);
         const uint32_t cnt = (uint32_t)__builtin_popcount(imask);
-        Vec4* o = out.data() + (size_t)newIdx[n] * 5;
-        for (int k = 0; k < 5; k++) o[k] = p[k];
-        o[1].x = f32(cnt ? next : 0u);
         for (uint32_t j = 0; j < cnt; j++) {
             const uint32_t c = base + j;
             if (c >= nNodes || newIdx[c] != 0xffffffffu) continue;  // malformed blob: leave as is
@@ -843,6 +838,7 @@ void reorder_cwbvh_priority(const Vec4* in, uint32_t nNodes, std::vector<Vec4>& 
         }
         next += cnt;
     }
+    for (uint32_t i = 0; i < nNodes; i++) if (newIdx[i] == 0xffffffffu) newIdx[i] = next++;   // unreachable nodes go last
 }
 
 }  // namespace tbvh

@@ -61,8 +61,8 @@ void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, const BuildParams& p, s
 void encode_cwbvh(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std::vector<Vec4>& nodeBlocks,
                   std::vector<Vec4>& triBlocks);
 
-// Renumber CWBVH nodes (5 x Vec4 each) in surface-area priority order; see host_builder.cpp.
-void reorder_cwbvh_priority(const Vec4* in, uint32_t nNodes, std::vector<Vec4>& out);
+// CWBVH nodes (5 x Vec4 each) in surface-area priority order: newIdx[old] = new; see host_builder.cpp.
+void cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>& newIdx);
 
 // Structural validation of caller-supplied blobs (returns nullptr when fine, else a message).
 const char* validate_bvh_gpu(const NodeAL* nodes, uint64_t nNodes, uint64_t nIdx);

@@ -3,12 +3,6 @@
 #include <vector>
 #include "device_common.h"
 
-// TBVH_EXPERIMENTS = 1 (make EXPERIMENTS=1) also builds the measured-and-rejected kernel variants reachable through
-// tbvh_set_variant; the default build holds only the kernels the dispatchers pick.
-#ifndef TBVH_EXPERIMENTS
-#define TBVH_EXPERIMENTS 0
-#endif
-
 namespace tbvh {
 
 // layout codes as in include/tinybvh_amd.h (= BVHBase::BVHType, tiny_bvh.h:773-791); capi.hip checks they agree
@@ -17,37 +11,27 @@ constexpr int kLayoutBvhGpu = 5, kLayoutBvh4Gpu = 8, kLayoutCwbvh = 10;
 void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                  uint32_t blocks, hipStream_t s);
 void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
-// paddedNodes: `nodes` is the copy with one node per 128-byte line (8 float4 apart; scenes whose nodes outgrow the Infinity Cache)
+// nodeStride: 5 = `nodes` is the packed array; 8 = the copy with one node per 128-byte line (scenes whose nodes outgrow the Infinity
+// Cache); 13 (cwbvh_node.h: kNodeHybrid) = the priority-ordered copy whose first q.hybridK nodes are packed and the others one per line
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
-                  uint32_t blocks, hipStream_t s, bool paddedNodes = false, bool shallow = false);
-bool cwbvh_variant_valid(int variant);
-bool cwbvh_variant_padded(int variant);   // runs on the 128-byte padded node copy
-bool cwbvh_variant_tri64(int variant);    // runs on the 64-byte padded triangle copy
-void launch_cwbvh_pad_tris(const float4* src, float4* dst, uint64_t nTris, hipStream_t s);
-bool bvh_variant_valid(int variant);       // BVH_GPU / BVH4_GPU kernels
-bool tlas_variant_valid(int variant);
-void launch_cwbvh_exp(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
-                      uint32_t blocks, hipStream_t s);   // experiment builds only
+                  uint32_t blocks, hipStream_t s, int nodeStride = 5, bool shallow = false);
+void launch_cwbvh_derive_hybrid(const float4* src, const uint32_t* perm, float4* dst, uint32_t nNodes, uint32_t hybridK, hipStream_t s);
+bool cwbvh_variant_valid(int variant);     // diagnostic variants of the BVH8_CWBVH kernel (tbvh_set_variant); the other layouts have none
 void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream_t s);
-void launch_cwbvh_h(bool anyhit, int variant, const char* nodesH, const float4* tris, const QueryArgs& q, uint32_t* status,
-                    uint32_t blocks, hipStream_t s);
-void launch_cwbvh_relayout(const float4* src, char* dst, uint32_t nNodes, hipStream_t s);
-void launch_cwbvh_c(bool anyhit, int variant, const float4* nodes, const float4* tris, uint32_t nNodes, const QueryArgs& q,
-                    uint32_t* status, uint32_t blocks, hipStream_t s);
 struct BlasDesc { const float4* nodes; const float4* tris; const uint32_t* opmap; uint32_t opmapN; uint32_t layout; };  // one per BLAS of a TLAS (layout: TBVH_LAYOUT_*)
-void launch_tlas(bool anyhit, int blasLayout, int variant, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances,
+void launch_tlas(bool anyhit, int blasLayout, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances,
                  const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
 // 4-wide TLAS in the BVH4_GPU node format + the unified two-level kernel for BVH4_GPU BLASes (kernels_tlas4.hip)
 size_t tlas_wide_scratch_bytes(uint64_t nAL, uint64_t nInst);   // kernels_tlaswide.hip builds both wide TLAS formats
 uint64_t tlas4_cap_blocks(uint64_t nAL, uint64_t nInst);
 void launch_tlas4_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* blocks, uint32_t capBlocks,
-                        void* scratch, hipStream_t s);
+                        void* scratch, uint32_t* status, hipStream_t s);   // status |= 4 when the capacity does not hold the tree
 void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* instances, const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks,
                   hipStream_t s, uint32_t blocks7);
 // 8-wide TLAS in the BVH8_CWBVH node format + the unified two-level kernel for BVH8_CWBVH BLASes (kernels_tlas8.hip)
 uint64_t tlas8_cap_nodes(uint64_t nAL, uint64_t nInst);
 void launch_tlas8_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* nodes, uint32_t capNodes,
-                        uint32_t* instRef, uint32_t capRefs, void* scratch, hipStream_t s);
+                        uint32_t* instRef, uint32_t capRefs, void* scratch, uint32_t* status, hipStream_t s);
 void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* instRef, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
                   uint32_t* status, uint32_t blocks, hipStream_t s, uint32_t blocks7, bool mixed = false);
 void launch_tlas2(bool anyhit, int variant, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances, const BlasDesc* blas, const QueryArgs& q,
@@ -94,6 +78,17 @@ struct TriSource {
 void launch_gen_bounce(const TriSource& src, const RayRec* in, RayRec* out, uint64_t n, uint32_t seed, hipStream_t s);
 void launch_reset_hits(RayRec* rays, uint64_t n, float tmax, hipStream_t s);
 void launch_gen_shadow(const RayRec* in, RayRec* out, uint64_t n, float lx, float ly, float lz, float eps, hipStream_t s);
+
+// ray binning (kernels_raybin.hip): counting sort of a batch by (Morton code of the origin's cell, direction octant)
+struct RayBinArgs {
+    float lo[3], scale[3];   // cell = (O - lo) * scale, clamped to [0, 2^cellBits)
+    uint32_t cellBits;       // 0..6 bits per axis
+    uint32_t flags;          // 1: octant as the minor part of the key, 2: as the major part, 0: cell only
+};
+uint32_t ray_bin_count(uint32_t cellBits, uint32_t flags);
+size_t ray_bin_scratch_bytes(uint64_t n, uint32_t cellBits, uint32_t flags, size_t* scanTempBytes);
+hipError_t launch_ray_bin(const RayRec* in, RayRec* out, uint32_t* perm, uint64_t n, const unsigned long long* nDev, const RayBinArgs& a, void* scratch,
+                          size_t scanTempBytes, uint32_t blocks, hipStream_t s);
 
 // wavefront path tracer stages (kernels_wavefront.hip)
 struct PathAux { float T[3]; uint32_t pixel; };   // throughput + pixel << 8 | depth << 4 | path flags (paths), or pending contribution + pixel (shadow rays); 16 bytes

@@ -36,9 +36,7 @@ constexpr int WG = 64;
 // STATS (experiment builds): q.stats[0] wave iterations, [1] sum of active lanes, [2] sum of lanes visiting a node,
 // [3] triangle-phase iterations, [4] sum of lanes in them, [5] node phases whose lanes all visit ONE node with ONE octant,
 // [6] sum of lanes in those, [7] node-phase iterations
-// TSTRIDE: float4s between consecutive triangle records (3 = the reference's packed array; 4 = padded to 64 bytes so that no
-// record straddles a 128-byte line)
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, int STATS = 0, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false, bool PROBED = false, int STEAL = 0>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, int STATS = 0, int NSTRIDE = 5, bool PROBED = false, int STEAL = 0>
 __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
@@ -136,12 +134,9 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
         if (tail && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
         // ---- triangle phase: runs when enough lanes have a triangle pending, or when no lane could use a node
         // phase instead (so a waiting lane always makes progress) --------------------------------------------
-        // COH_ONLY: deferral and the gate apply only while the wave runs in lockstep (coherent rays: VALU-bound, the gate
-        // saves triangle phases); once the governor has switched to per-lane replacement (incoherent rays: bound by the
-        // cache-miss path, where nodes visited ahead of their turn are extra traffic) the strict schedule applies
-        const bool spec = PROBED ? coh : (SPEC && (!COH_ONLY || gov.lockstep));
+        const bool spec = PROBED ? coh : SPEC;
         bool triPhase = true;
-        if (TRI_MIN > 1 && (PROBED ? coh : (!COH_ONLY || gov.lockstep))) {
+        if (TRI_MIN > 1 && (PROBED ? coh : true)) {
             const uint32_t nPend = (uint32_t)__popcll(__ballot(tg.y != 0));
             const bool canNode = spec ? (tg2.y == 0 && (cw_has_child(ng) || !st.empty())) : tg.y == 0;
             triPhase = nPend >= (uint32_t)TRI_MIN || __ballot(canNode) == 0;
@@ -150,10 +145,11 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
             if (STATS == 1) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sTriIter++; sTri += __popcll(m); } }
             const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
             tg.y &= ~(1u << ti);
-            const uint32_t ta = TSTRIDE == 3 ? tg.x + ti * 3u : (__umulhi(tg.x, 0xAAAAAAABu) >> 1) * 4u + ti * 4u;   // tg.x counts float4s of the packed array
+            const uint32_t ta = tg.x + ti * 3u;
             const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w))) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w)) &&
+                (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), found, hit))) {   // (a split ray's group arbitrates: split_publish)
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -176,7 +172,7 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
                     if (lane_rank(m) == 0) { sNodeIter++; sNode += __popcll(m); if (uni) { sRefill++; sRefilled += __popcll(m); } }   // [5], [6]: uniform node phases, lanes in them
                 }
                 if (cw_has_child(ng)) st.push(ng);
-                const CwNodeHits r = cw_test_node(cw_load_node<NSTRIDE>(nodes, ci), O, rD, hit.x, octinv4);
+                const CwNodeHits r = cw_test_node(cw_load_node<NSTRIDE>(nodes, ci, q.hybridK), O, rD, hit.x, octinv4);
                 ng = make_uint2(r.childBase, (r.hitmask & 0xFF000000u) | r.imask);
                 const uint2 nt = make_uint2(r.triBase, r.hitmask & 0x00FFFFFFu);
                 if (tg.y == 0) tg = nt;
@@ -219,11 +215,11 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
     }
 }
 
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, int STATS = 0, int NSTRIDE = 5, int TSTRIDE = 3, bool COH_ONLY = false, bool PROBED = false, int STEAL = 0>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, int STATS = 0, int NSTRIDE = 5, bool PROBED = false, int STEAL = 0>
 void launch_k(const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
     // without opacity micromaps on the scene the check is compiled out (+1-2 %)
-    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE, TSTRIDE, COH_ONLY, PROBED, STEAL>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
-    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE, TSTRIDE, COH_ONLY, PROBED, STEAL>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE, PROBED, STEAL>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE, PROBED, STEAL>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
 }
 
 __global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__ dst, uint32_t nNodes) {
@@ -233,58 +229,47 @@ __global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__
     dst[i] = k < 5u ? src[n * 5u + k] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// the hybrid node array (cwbvh_node.h: kNodeHybrid) from the packed one: node i goes to position perm[i], its childBaseIndex follows its
+// first child (children stay consecutive in slot order under the priority order)
+__global__ void k_derive_hybrid(const float4* __restrict__ src, const uint32_t* __restrict__ perm, float4* __restrict__ dst, uint32_t nNodes, uint32_t hybridK) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nNodes) return;
+    const uint32_t ni = perm[i];
+    float4* o = dst + ((size_t)ni * 8u - (size_t)(ni < hybridK ? ni : hybridK) * 3u);
+    const float4* p = src + (size_t)i * 5u;
+    float4 n1 = p[1];
+    if (as_u32(p[0].w) >> 24) { const uint32_t cb = as_u32(n1.x); n1.x = as_f32(cb < nNodes ? perm[cb] : 0u); }
+    o[0] = p[0]; o[1] = n1; o[2] = p[2]; o[3] = p[3]; o[4] = p[4];
+}
+
 }  // namespace
 
+void launch_cwbvh_derive_hybrid(const float4* src, const uint32_t* perm, float4* dst, uint32_t nNodes, uint32_t hybridK, hipStream_t s) {
+    hipLaunchKernelGGL(k_derive_hybrid, dim3((nNodes + 255u) / 256u), dim3(256), 0, s, src, perm, dst, nNodes, hybridK);
+}
+
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
-                  uint32_t blocks, hipStream_t s, bool paddedNodes, bool shallow) {
+                  uint32_t blocks, hipStream_t s, int nodeStride, bool shallow) {
 #define TBVH_K(...)                                                                     \
     do {                                                                                \
         if (anyhit) launch_k<true, __VA_ARGS__>(nodes, tris, q, status, blocks, s);     \
         else launch_k<false, __VA_ARGS__>(nodes, tris, q, status, blocks, s);           \
     } while (0)
-#if TBVH_EXPERIMENTS
+    // diagnostic variants (tbvh_set_variant; tools/ab_probe.py, tests/test_cwbvh_schedules.py): a schedule forced whatever the probe says, and the
+    // instrumented kernels behind the counters of DESIGN.md §5 (profiles/r02_schedule_variants.txt, r02_counters_*.txt)
     switch (variant) {
-    case 0: case 50: break;
-    case 51: TBVH_K(8, 16, 1, true); return;     // deferred triangles, triangle phase every iteration
-    case 52: TBVH_K(8, 16, 8, true); return;     // ... once 8 lanes wait
-    case 53: TBVH_K(8, 16, 16, true); return;
-    case 54: TBVH_K(8, 16, 24, true); return;
-    case 55: TBVH_K(8, 16, 32, true); return;
-    case 56: TBVH_K(8, 8, 16, true); return;     // refill at 8 idle lanes
-    case 57: TBVH_K(8, 24, 16, true); return;
-    case 58: TBVH_K(8, 16, 8, false); return;    // gated triangle phase without deferral (lanes wait)
-    case 59: launch_k<false, 8, 16, 1, false, true>(nodes, tris, q, status, blocks, s); return;    // statistics of the strict schedule
-    case 60: launch_k<false, 8, 16, 1, true, true>(nodes, tris, q, status, blocks, s); return;     // statistics, deferred
-    case 61: launch_k<false, 8, 16, 16, true, true>(nodes, tris, q, status, blocks, s); return;    // statistics, deferred + gate 16
-    case 62: TBVH_K(8, 16, 1, false, false, 8); return;    // strict schedule on nodes padded to 128 bytes
-    case 63: TBVH_K(8, 16, 16, true, false, 8); return;    // deferred + gate 16 on padded nodes
-    case 64: TBVH_K(8, 16, 1, false, false, 5, 4); return; // strict schedule, triangle records padded to 64 bytes
-    case 65: TBVH_K(8, 16, 1, true, false, 5, 4); return;  // deferred, padded triangles
-    case 66: TBVH_K(8, 16, 1, true, false, 8, 4); return;  // deferred, padded triangles and nodes
-    case 67: TBVH_K(8, 16, 8, true, false, 5, 4); return;  // deferred + gate 8, padded triangles
-    case 68: TBVH_K(8, 16, 8, true, false, 5, 3, true); return;   // deferred + gate 8 while in lockstep, strict after
-    case 69: TBVH_K(8, 16, 16, true, false, 5, 3, true); return;
-    case 70: TBVH_K(8, 16, 12, true, false, 5, 3, true); return;
-    case 71: TBVH_K(8, 16, 1, true, false, 5, 3, true); return;   // deferred (no gate) while in lockstep
-    case 72: TBVH_K(8, 16, 1, false); return;                     // the strict schedule throughout, whatever the probe says
-    case 73: launch_k<false, 8, 16, 1, false, 2>(nodes, tris, q, status, blocks, s); return;       // wave timeline of the strict schedule (q.stats)
-    case 74: TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 32); return;   // strict schedule + stack stealing once the pool is dry and 32 lanes idle
-    case 75: TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 16); return;
-    case 76: TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 8); return;
-    case 77: TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 48); return;
-    case 78: launch_k<false, 8, 16, 1, false, 2, 5, 3, false, false, 32>(nodes, tris, q, status, blocks, s); return;   // timeline of 74
-    case 79: launch_k<false, 8, 16, 1, false, 3>(nodes, tris, q, status, blocks, s); return;       // histogram of wave ends, strict schedule
-    case 80: launch_k<false, 8, 16, 1, false, 4>(nodes, tris, q, status, blocks, s); return;       // histogram of pool-dry times
-    case 89: TBVH_K(6, 16, 1, false, 0, 5, 3, false, false, 16); return;   // 75 with 6 stack entries in LDS (32 waves per CU fit)
-    case 91: TBVH_K(8, 16, 1, false, 0, 8, 3, false, false, 16); return;   // padded nodes + split rays, 8 stack entries in LDS
-    case 92: TBVH_K(6, 16, 1, false, 0, 8, 3, false, false, 16); return;   // ... 6
-    case 88: if (q.probe) TBVH_K(6, 16, 8, true, 0, 5, 3, false, true, 16); else TBVH_K(6, 16, 1, false, 0, 5, 3, false, false, 16); return;   // the probed schedule + stealing, whatever the batch size
-    case 82: launch_k<false, 8, 16, 1, false, 5>(nodes, tris, q, status, blocks, s); return;       // tail statistics, strict schedule
-    case 83: launch_k<false, 8, 16, 1, false, 5, 5, 3, false, false, 16>(nodes, tris, q, status, blocks, s); return;   // tail statistics with stealing
-    case 81: launch_k<false, 8, 16, 1, false, 3, 5, 3, false, false, 16>(nodes, tris, q, status, blocks, s); return;   // wave ends with stealing
-    default: launch_cwbvh_exp(anyhit, variant, nodes, tris, q, status, blocks, s); return;
+    case 52: TBVH_K(8, 16, 8, true); return;      // the coherent schedule: deferred triangles, triangle phase once 8 lanes wait
+    case 72: TBVH_K(8, 16, 1, false); return;     // the strict schedule
+    case 75: TBVH_K(8, 16, 1, false, 0, 5, false, 16); return;   // strict + split rays whatever the batch size
+    case 88: if (q.probe) TBVH_K(6, 16, 8, true, 0, 5, true, 16); else TBVH_K(6, 16, 1, false, 0, 5, false, 16); return;   // the probed schedule + split rays whatever the batch size
+    case 59: launch_k<false, 8, 16, 1, false, 1>(nodes, tris, q, status, blocks, s); return;    // lane statistics of the strict schedule (q.stats)
+    case 61: launch_k<false, 8, 16, 8, true, 1>(nodes, tris, q, status, blocks, s); return;     // ... of the coherent schedule
+    case 73: launch_k<false, 8, 16, 1, false, 2>(nodes, tris, q, status, blocks, s); return;    // wave timeline of the strict schedule
+    case 78: launch_k<false, 8, 16, 1, false, 2, 5, false, 16>(nodes, tris, q, status, blocks, s); return;   // ... with split rays
+    case 82: launch_k<false, 8, 16, 1, false, 5>(nodes, tris, q, status, blocks, s); return;    // tail statistics, strict schedule
+    case 83: launch_k<false, 8, 16, 1, false, 5, 5, false, 16>(nodes, tris, q, status, blocks, s); return;   // ... with split rays
+    default: break;
     }
-#endif
     // with a coherence probe of the batch (capi.hip: launchQuery) the schedule is chosen per launch; without one, the strict schedule.
     // Batches below 12 M rays (and the wavefront stages, whose ray count only the device knows) also split their last rays over idle
     // lanes (ray_split.h): Bistro stand-in 0.26 / 1 / 4 / 8 M rays: camera +7 / +20 / +6 / +4 %, bounce +26 / +23 / +8 / +4 %, shadow
@@ -292,30 +277,23 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     const bool tail = split_rays_wanted(q);
     // Stack entries in LDS next to the split groups: 6 let 32 waves per CU fit (what scenes under 48 MB and coherent probed batches are
     // launched with; Bistro-size trees measure the same with 6 or 8), deep trees want 8 (30 M triangles: 6 costs 7 % on camera rays, 13 % on bounce rays)
-    if (paddedNodes) {   // one node per cache line (capi.hip: scenes whose node array is beyond the Infinity Cache; DESIGN.md §5: -17 % bytes, +6 % at 60 M triangles)
-        if (tail) TBVH_K(8, 16, 1, false, 0, 8, 3, false, false, 16);
+    if (nodeStride == 8) {   // one node per cache line (capi.hip: scenes whose node array is beyond the Infinity Cache; DESIGN.md §5: -17 % bytes, +6 % at 60 M triangles)
+        if (tail) TBVH_K(8, 16, 1, false, 0, 8, false, 16);
         else TBVH_K(8, 16, 1, false, 0, 8);
+    } else if (nodeStride == kNodeHybrid) {   // priority-ordered nodes, the first q.hybridK packed, the others one per line (cwbvh_node.h)
+        if (q.probe) {
+            if (tail) TBVH_K(6, 16, 8, true, 0, kNodeHybrid, true, 16);
+            else TBVH_K(8, 16, 8, true, 0, kNodeHybrid, true);
+        } else if (tail) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, false, 16);
+        else TBVH_K(8, 16, 1, false, 0, kNodeHybrid);
     } else if (q.probe) {
-        if (tail) TBVH_K(6, 16, 8, true, 0, 5, 3, false, true, 16);
-        else TBVH_K(8, 16, 8, true, 0, 5, 3, false, true);
+        if (tail) TBVH_K(6, 16, 8, true, 0, 5, true, 16);
+        else TBVH_K(8, 16, 8, true, 0, 5, true);
     } else if (tail) {
-        if (shallow) TBVH_K(6, 16, 1, false, 0, 5, 3, false, false, 16);
-        else TBVH_K(8, 16, 1, false, 0, 5, 3, false, false, 16);
+        if (shallow) TBVH_K(6, 16, 1, false, 0, 5, false, 16);
+        else TBVH_K(8, 16, 1, false, 0, 5, false, 16);
     } else TBVH_K(8, 16, 1, false);
 #undef TBVH_K
-}
-
-namespace {
-__global__ void k_pad_tris(const float4* __restrict__ src, float4* __restrict__ dst, uint64_t nTris) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per float4 of the padded array
-    if (i >= nTris * 4u) return;
-    const uint64_t t = i >> 2; const uint32_t k = (uint32_t)i & 3u;
-    dst[i] = k < 3u ? src[t * 3u + k] : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-}  // namespace
-// 48-byte triangle records straddle a 128-byte line 3 times out of 8; at 64 bytes none does (+33 % triangle memory)
-void launch_cwbvh_pad_tris(const float4* src, float4* dst, uint64_t nTris, hipStream_t s) {
-    hipLaunchKernelGGL(k_pad_tris, dim3((uint32_t)((nTris * 4u + 255u) / 256u)), dim3(256), 0, s, src, dst, nTris);
 }
 
 // 80-byte nodes straddle 128-byte lines (1.6 lines per node on average); the padded copy costs 60 % more node memory
@@ -323,15 +301,6 @@ void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream
     hipLaunchKernelGGL(k_pad_nodes, dim3((nNodes * 8u + 255u) / 256u), dim3(256), 0, s, src, dst, nNodes);
 }
 
-bool cwbvh_variant_padded(int v) { return TBVH_EXPERIMENTS && (v == 47 || v == 62 || v == 63 || v == 66 || v == 91 || v == 92); }
-bool cwbvh_variant_tri64(int v) { return TBVH_EXPERIMENTS && v >= 64 && v <= 67; }
-
-bool cwbvh_variant_valid(int v) {
-#if TBVH_EXPERIMENTS
-    return (v >= 0 && v <= 19) || (v >= 40 && v <= 48 && v != 42 && v != 43) || (v >= 50 && v <= 92 && v != 90 && v != 84 && v != 85 && v != 86 && v != 87);
-#else
-    return v == 0;
-#endif
-}
+bool cwbvh_variant_valid(int v) { return v == 0 || v == 52 || v == 72 || v == 75 || v == 88 || v == 59 || v == 61 || v == 73 || v == 78 || v == 82 || v == 83; }
 
 }  // namespace tbvh

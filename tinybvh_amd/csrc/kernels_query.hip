@@ -105,7 +105,8 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
             const float4 v0 = tris[triPtr], e1 = tris[triPtr + 1], e2 = tris[triPtr + 2];
             triPtr += 3; triLeft--;
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w))) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w)) &&
+                (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), found, hit))) {   // (a split ray's group arbitrates: split_publish)
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -244,7 +245,8 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
                 leafCnt = __builtin_amdgcn_alignbit(leafCntB, leafCnt, 16); leafCntB >>= 16;
             }
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w))) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w)) &&
+                (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), found, hit))) {   // (a split ray's group arbitrates: split_publish)
                 found = true;
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
@@ -371,23 +373,6 @@ void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tr
         else hipLaunchKernelGGL((k_bvh2<false, 16, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);       \
     } while (0)
     switch (variant) {
-#if TBVH_EXPERIMENTS
-    case 1: TBVH_L2(1); break;
-    case 2: TBVH_L2(8); break;
-    case 3: TBVH_L2(32); break;
-    case 5: TBVH_L2(16, false, 2); break;   // two node visits per iteration
-    case 6: TBVH_L2(16, false, 3); break;
-    case 4: TBVH_L2(16, true); break;   // adaptive, one node visit per iteration
-    case 7: TBVH_L2(16); break;                // one node visit per iteration (the former default)
-    case 9: TBVH_L2(16, true, 3, 205); break;
-    case 10: TBVH_L2(16, true, 3, 218); break;
-    case 11: TBVH_L2(16, true, 3, 230); break;
-    case 8: TBVH_L2(16, false, 3); break;      // per-lane replacement throughout, three node visits per iteration (+5..14 % over one)
-    case 12: TBVH_L2(16, true, 3, kLockstepKeep, false); break;           // the default kernel without split rays
-    case 13: TBVH_L2(16, true, 3, kLockstepKeep, false, 16); break;       // ... with, whatever the batch size
-    case 14: TBVH_L2(16, true, 3, kLockstepKeep, false, 32); break;
-    case 15: TBVH_L2(16, true, 3, kLockstepKeep, false, 8); break;
-#endif
     default:   // + the lockstep governor (ray_pool.h): Sponza camera rays +9 %, shadow +6 %; small incoherent batches -3..5 %
         // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
         if (split_rays_wanted(q)) {
@@ -412,23 +397,6 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
         else hipLaunchKernelGGL((k_bvh4_w8<false, 12, 16, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, data, q, status);        \
     } while (0)
     switch (variant) {
-#if TBVH_EXPERIMENTS
-    case 1: TBVH_L4(1); break;
-    case 2: TBVH_L4(16); break;
-    case 5: TBVH_L4(8, false, 2); break;   // two node visits per iteration
-    case 6: TBVH_L4(8, false, 3); break;
-    case 7: TBVH_L4(8, false, 1, true); break;   // sign-selected near / far planes
-    case 8: TBVH_L4(8, true, 1, true); break;    // + governor
-    case 9: TBVH_L4W(8, false, 1, true); break;    // sign-selected planes, <= 64 VGPRs
-    case 10: TBVH_L4W(8, false, 1, false); break;
-    case 11: TBVH_L4W(8, true, 1, true); break;    // + governor
-    case 4: TBVH_L4(8, true); break;   // adaptive (LockstepGovernor, ray_pool.h): +6 % on coherent camera rays, -2..8 % elsewhere: not the default
-    case 12: TBVH_L4(8); break;        // the former default: min / max pairs per plane, compiler's register budget (65-68 VGPRs)
-    case 13: TBVH_L4W(8, false, 1, true, kLockstepKeep, false, true); break;   // the default kernel with the wave timeline (q.stats)
-    case 14: TBVH_L4W(8, false, 1, true, kLockstepKeep, false); break;            // the default kernel without split rays
-    case 15: TBVH_L4W(8, false, 1, true, kLockstepKeep, false, false, 16); break; // ... with, whatever the batch size
-    case 16: TBVH_L4W(8, false, 1, true, kLockstepKeep, false, false, 32); break;
-#endif
     default:   // per-lane replacement throughout, sign-selected planes, 8 waves per SIMD
         if (split_rays_wanted(q)) {   // split rays, as in launch_bvh2
             if (q.omm.map) TBVH_L4W(8, false, 1, true, kLockstepKeep, true, false, 16);
@@ -440,8 +408,6 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
 #undef TBVH_L4
 #undef TBVH_L4W
 }
-
-bool bvh_variant_valid(int v) { return TBVH_EXPERIMENTS ? (v >= 0 && v <= 16) : v == 0; }
 
 void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris, hipStream_t s) {
     const uint32_t bs = 256;

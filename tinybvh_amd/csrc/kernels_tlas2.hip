@@ -124,13 +124,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
             const float4 v0 = btris[triPtr], e1 = btris[triPtr + 1], e2 = btris[triPtr + 2];
             triPtr += 3u; triLeft--;
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h) && (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), curInst, found, hit, hitInst))) {
                 const BlasDesc bd = blas[blasIdx];   // opacity micromaps are per BLAS: looked up only for a candidate hit
                 if (!bd.opmap || omm_opaque(Omm{bd.opmap, bd.opmapN}, as_u32(v0.w), h.u, h.v)) {
                     found = true; hitInst = curInst;
                     if (ANYHIT) done = true;
                     else hit = make_float4(h.t, h.u, h.v, v0.w);
-                    if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
+                    if (tail && grp >= 0) split_publish<ANYHIT, true>(split, grp, hit, hitInst);
                 }
             }
             if (!done && triLeft == 0) {
@@ -235,27 +235,6 @@ void launch_tlas2(bool anyhit, int variant, const float4* tlasNodes, const uint3
         if (anyhit) hipLaunchKernelGGL((k_tlas2<true, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);  \
         else hipLaunchKernelGGL((k_tlas2<false, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, tlasIdx, instances, blas, q, status);        \
     } while (0)
-#if TBVH_EXPERIMENTS
-    switch (variant) {
-    case 21: TBVH_T2(16, 16, 32, 32, 32, 0); return;
-    case 22: TBVH_T2(16, 16, 16, 8, 8, 0); return;
-    case 23: TBVH_T2(16, 16, 8, 8, 8, 0); return;
-    case 24: TBVH_T2(16, 16, 24, 16, 16, 0); return;
-    case 25: TBVH_T2(16, 16, 16, 16, 16, 0); return;
-    case 32: TBVH_T2(16, 16, 24, 8, 8, 0); return;     // the default thresholds without split rays
-    case 33: TBVH_T2(16, 16, 24, 8, 8, 16); return;    // ... with, whatever the batch size
-    case 34: TBVH_T2(12, 16, 24, 8, 8, 16); return;
-    case 29: TBVH_T2(16, 16, 24, 8, 8, 0, 7); return;      // register budget of 7 waves per SIMD (use with TBVH_BLOCKS_PER_CU=28)
-    case 30: TBVH_T2(16, 16, 24, 8, 8, 16, 7); return;
-    case 31: TBVH_T2(12, 16, 24, 8, 8, 16, 8); return;     // ... of 8 (32 per CU)
-    case 26: TBVH_T2(16, 16, 24, 8, 8, 16, 6, 2); return;  // 33 with two node visits per pass
-    case 27: TBVH_T2(16, 16, 24, 8, 8, 16, 6, 3); return;  // ... three
-    case 28: TBVH_T2(16, 16, 24, 8, 8, 0, 7, 3); return;   // 29 with three
-    case 35: TBVH_T2(16, 16, 24, 8, 8, 16, 6, 3, true); return;   // 27 with fused leaf / instance -> node steps
-    case 36: TBVH_T2(16, 16, 24, 8, 8, 0, 7, 3, true); return;    // 28 with them
-    default: break;
-    }
-#endif
     (void)variant;
     // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
     // without the split code the kernel fits the register budget of 7 waves per SIMD (28 workgroups per CU: +4…6 %); with it five dwords spill and it loses

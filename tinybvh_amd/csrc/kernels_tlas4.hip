@@ -143,13 +143,13 @@ __device__ __forceinline__ void tlas4_body(const float4* __restrict__ tlas4, con
                 leafCnt = __builtin_amdgcn_alignbit(leafCntB, leafCnt, 16); leafCntB >>= 16;
             }
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h) && (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), curInst, found, hit, hitInst))) {
                 const BlasDesc bd = blas[blasIdx];   // opacity micromaps are per BLAS: looked up only for a candidate hit
                 if (!bd.opmap || omm_opaque(Omm{bd.opmap, bd.opmapN}, as_u32(v0.w), h.u, h.v)) {
                     found = true; hitInst = curInst;
                     if (ANYHIT) done = true;
                     else hit = make_float4(h.t, h.u, h.v, v0.w);
-                    if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
+                    if (tail && grp >= 0) split_publish<ANYHIT, true>(split, grp, hit, hitInst);
                 }
             }
             if (!done && leafCnt == 0) {
@@ -265,27 +265,6 @@ void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* i
         if (anyhit) hipLaunchKernelGGL((k_tlas4<true, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlas4, instances, blas, q, status);  \
         else hipLaunchKernelGGL((k_tlas4<false, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlas4, instances, blas, q, status);        \
     } while (0)
-#if TBVH_EXPERIMENTS
-    switch (variant) {
-    case 21: TBVH_T4(12, 16, 32, 32, 32); return;
-    case 22: TBVH_T4(12, 16, 16, 8, 8, false, false, 16, 7, true); return;     // thresholds around the shipped kernel (24 / 8 / 8)
-    case 23: TBVH_T4(12, 16, 8, 8, 8, false, false, 16, 7, true); return;
-    case 24: TBVH_T4(12, 16, 32, 8, 8, false, false, 16, 7, true); return;
-    case 25: TBVH_T4(12, 16, 24, 4, 4, false, false, 16, 7, true); return;
-    case 26: TBVH_T4(12, 16, 24, 8, 8, false, true); return;   // statistics: phases run and lanes per phase (q.stats)
-    case 27: TBVH_T4(12, 16, 16, 16, 16, true); return;          // under the lockstep governor
-    case 28: TBVH_T4(12, 16, 16, 8, 8, true); return;
-    case 29: TBVH_T4(12, 16, 24, 8, 8, false, false, 0, 7); return;   // 32 with the register budget of 7 waves per SIMD
-    case 32: TBVH_T4(12, 16, 24, 8, 8); return;                      // the default thresholds without split rays
-    case 33: TBVH_T4(12, 16, 24, 8, 8, false, false, 16); return;    // ... with, whatever the batch size
-    case 34: TBVH_T4(12, 16, 24, 8, 8, false, false, 32); return;
-    case 35: TBVH_T4(12, 16, 24, 8, 8, false, false, 8); return;
-    case 31: TBVH_T4(12, 16, 24, 8, 8, false, false, 16, 7, true); return;  // the default with fused leaf / instance -> node steps
-    case 36: TBVH_T4(12, 16, 24, 8, 8, false, false, 16, 8); return;   // 33 with the register budget of 8 waves per SIMD (use with TBVH_BLOCKS_PER_CU=32)
-    case 30: TBVH_T4(12, 16, 24, 8, 8, false, false, 16, 7); return;   // ... of 7 (28 per CU)
-    default: break;
-    }
-#endif
     (void)variant;
     // thresholds measured on 1000 instances of a 100 k-triangle BLAS, 8.3 M camera / 4.2 M random rays, Intersect MRays/s (IsOccluded on the
     // random rays): 32/32/32 3570 / 2100 (2730); 16/16/16 4010 / 2340 (2910); 16/8/8 4350 / 2480 (3060); 24/8/8 4400 / 2480 (3120);

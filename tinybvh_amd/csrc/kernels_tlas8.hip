@@ -143,13 +143,13 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
             const float4 v0 = btris[triPtr], e1 = btris[triPtr + 1], e2 = btris[triPtr + 2];
             triPtr += 3u; triLeft--;
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h) && (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), curInst, found, hit, hitInst))) {
                 const BlasDesc bd = blas[blasIdx];
                 if (!bd.opmap || omm_opaque(Omm{bd.opmap, bd.opmapN}, as_u32(v0.w), h.u, h.v)) {
                     found = true; hitInst = curInst;
                     if (ANYHIT) done = true;
                     else hit = make_float4(h.t, h.u, h.v, v0.w);
-                    if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
+                    if (tail && grp >= 0) split_publish<ANYHIT, true>(split, grp, hit, hitInst);
                 }
             }
             if (!done && triLeft == 0) pop2 = true;
@@ -186,13 +186,13 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
             const uint32_t ta = tg.x + ti * 3u;
             const float4 e2 = btris[ta], e1 = btris[ta + 1], v0 = btris[ta + 2];
             TriHit h;
-            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h)) {
+            if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h) && (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), curInst, found, hit, hitInst))) {
                 const BlasDesc bd = blas[blasIdx];   // opacity micromaps are per BLAS: looked up only for a candidate hit
                 if (!bd.opmap || omm_opaque(Omm{bd.opmap, bd.opmapN}, as_u32(v0.w), h.u, h.v)) {
                     found = true; hitInst = curInst;
                     if (ANYHIT) done = true;
                     else hit = make_float4(h.t, h.u, h.v, v0.w);
-                    if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit, hitInst);
+                    if (tail && grp >= 0) split_publish<ANYHIT, true>(split, grp, hit, hitInst);
                 }
             }
             next = !done;
@@ -301,37 +301,6 @@ void launch_tlas8(bool anyhit, int variant, const float4* tlasNodes, const uint3
         if (anyhit) hipLaunchKernelGGL((k_tlas8<true, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, instRef, instances, blas, q, status);  \
         else hipLaunchKernelGGL((k_tlas8<false, __VA_ARGS__>), dim3(blocks), dim3(WG), 0, s, tlasNodes, instRef, instances, blas, q, status);        \
     } while (0)
-#if TBVH_EXPERIMENTS
-    if (mixed) switch (variant) {   // phase thresholds of the mixed-layout kernel
-    case 21: TBVH_T8(8, 16, 32, 32, 32, false, 16, 6, true, true); return;
-    case 22: TBVH_T8(8, 16, 16, 8, 8, false, 16, 6, true, true); return;
-    case 23: TBVH_T8(8, 16, 8, 8, 8, false, 16, 6, true, true); return;
-    case 24: TBVH_T8(8, 16, 24, 16, 16, false, 16, 6, true, true); return;
-    case 25: TBVH_T8(8, 16, 16, 4, 4, false, 16, 6, true, true); return;
-    case 29: TBVH_T8(8, 16, 12, 8, 8, false, 16, 6, true, true); return;
-    case 30: TBVH_T8(8, 16, 24, 8, 8, false, 16, 7, true, true); return;   // register budget of 7 waves per SIMD
-    default: break;
-    }
-    else switch (variant) {
-    case 21: TBVH_T8(12, 16, 32, 32, 32); return;
-    case 22: TBVH_T8(12, 16, 16, 8, 8); return;
-    case 23: TBVH_T8(12, 16, 8, 8, 8); return;
-    case 24: TBVH_T8(12, 16, 24, 16, 16); return;
-    case 25: TBVH_T8(12, 16, 16, 4, 4); return;
-    case 26: TBVH_T8(12, 16, 24, 8, 8, true); return;   // statistics
-    case 31: TBVH_T8(8, 16, 24, 8, 8); return;
-    case 32: TBVH_T8(12, 16, 24, 8, 8); return;                // the default thresholds without split rays
-    case 33: TBVH_T8(10, 16, 24, 8, 8, false, 16); return;     // ... with, whatever the batch size (LDS: 10 stack entries + the split groups still fit 24 waves per CU)
-    case 34: TBVH_T8(10, 16, 24, 8, 8, false, 32); return;
-    case 35: TBVH_T8(8, 16, 24, 8, 8, false, 16); return;
-    case 36: TBVH_T8(10, 16, 24, 8, 8); return;
-    case 29: TBVH_T8(10, 16, 24, 8, 8, false, 0, 7); return;     // register budget of 7 waves per SIMD (use with TBVH_BLOCKS_PER_CU=28)
-    case 30: TBVH_T8(8, 16, 24, 8, 8, false, 16, 7); return;     // ... with split rays
-    case 27: TBVH_T8(8, 16, 24, 8, 8, false, 16, 7, true); return;   // 30 with fused triangle / instance -> node steps
-    case 28: TBVH_T8(8, 16, 24, 8, 8, true, 16, 7, true); return;    // ... statistics
-    default: break;
-    }
-#endif
     (void)variant;
     // batches below 12 M rays, and the wavefront stages (ray count known to the device only), split their last rays over idle lanes (ray_split.h)
     // 7 waves per SIMD on 28 workgroups per CU (kernels_tlas4.hip): +4…5 %.  LDS sets the stack entries kept there: 8 next to the split groups

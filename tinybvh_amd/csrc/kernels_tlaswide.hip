@@ -42,7 +42,8 @@ __device__ __forceinline__ void open_kid(const float4* __restrict__ al, uint32_t
 template <int W>
 __global__ __launch_bounds__(kBuildThreads) void k_tlas_wide_build(const float4* __restrict__ al, uint32_t nAL, const uint32_t* __restrict__ idx, uint32_t nIdx,
                                                                    const float4* __restrict__ inst, float4* __restrict__ nodes, uint32_t capNodes,
-                                                                   uint32_t* __restrict__ instRef, uint32_t capRefs, uint4* __restrict__ itemsA, uint4* __restrict__ itemsB) {
+                                                                   uint32_t* __restrict__ instRef, uint32_t capRefs, uint4* __restrict__ itemsA, uint4* __restrict__ itemsB,
+                                                                   uint32_t* __restrict__ status) {
     __shared__ uint32_t sIn, sOut, sNodes, sRefs;
     if (threadIdx.x == 0) {
         const uint32_t rootCnt = as_u32(al[2].w);
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_tlas_wide_build(const float4*
                 if (live && j == 0) { base = atomicAdd(&sNodes, 4u); outFirst = nInner ? atomicAdd(&sOut, nInner) : 0u; }
                 base = grp_get<W>(base, 0); outFirst = grp_get<W>(outFirst, 0);
                 const bool fits = live && base + 4u <= capNodes;
+                if (live && !fits && j == 0) atomicOr(status, 4u);   // capacity miscount: reported (TBVH_E_FORMAT), never a silently wrong tree
                 const Bvh4Frame f = bvh4_frame(mn, mx);
                 uint32_t q[6] = {0, 0, 0, 0, 0, 0};
                 if (valid) bvh4_quantize_child(f, mine.mn, mine.mx, j, q);
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(kBuildThreads) void k_tlas_wide_build(const float4*
                 }
                 childBase = grp_get<W>(childBase, 0); refBase = grp_get<W>(refBase, 0); outFirst = grp_get<W>(outFirst, 0);
                 const bool fits = live && childBase + nInner <= capNodes && refBase + nLeaf <= capRefs && item.z < capNodes;
+                if (live && !fits && j == 0) atomicOr(status, 4u);   // capacity miscount: reported (TBVH_E_FORMAT), never a silently wrong tree
                 // per-axis exponent: the smallest e with every child plane within 255 steps of 2^e and the far face reached (cwbvh_encode.h)
                 const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z};
                 const float cl[3] = {mine.mn.x, mine.mn.y, mine.mn.z}, ch[3] = {mine.mx.x, mine.mx.y, mine.mx.z};
@@ -228,16 +231,16 @@ uint64_t tlas4_cap_blocks(uint64_t nAL, uint64_t nInst) { return 4 * (nAL + nIns
 uint64_t tlas8_cap_nodes(uint64_t nAL, uint64_t nInst) { return nAL + nInst + 2; }
 
 void launch_tlas4_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* blocks, uint32_t capBlocks,
-                        void* scratch, hipStream_t s) {
+                        void* scratch, uint32_t* status, hipStream_t s) {
     uint4* itemsA = (uint4*)scratch;
     uint4* itemsB = itemsA + (size_t)(nAL + nInst + 2);
-    hipLaunchKernelGGL(k_tlas_wide_build<4>, dim3(1), dim3(kBuildThreads), 0, s, al, nAL, idx, nIdx, inst, blocks, capBlocks, (uint32_t*)nullptr, 0u, itemsA, itemsB);
+    hipLaunchKernelGGL(k_tlas_wide_build<4>, dim3(1), dim3(kBuildThreads), 0, s, al, nAL, idx, nIdx, inst, blocks, capBlocks, (uint32_t*)nullptr, 0u, itemsA, itemsB, status);
 }
 void launch_tlas8_build(const float4* al, uint32_t nAL, const uint32_t* idx, uint32_t nIdx, const float4* inst, uint32_t nInst, float4* nodes, uint32_t capNodes,
-                        uint32_t* instRef, uint32_t capRefs, void* scratch, hipStream_t s) {
+                        uint32_t* instRef, uint32_t capRefs, void* scratch, uint32_t* status, hipStream_t s) {
     uint4* itemsA = (uint4*)scratch;
     uint4* itemsB = itemsA + (size_t)(nAL + nInst + 2);
-    hipLaunchKernelGGL(k_tlas_wide_build<8>, dim3(1), dim3(kBuildThreads), 0, s, al, nAL, idx, nIdx, inst, nodes, capNodes, instRef, capRefs, itemsA, itemsB);
+    hipLaunchKernelGGL(k_tlas_wide_build<8>, dim3(1), dim3(kBuildThreads), 0, s, al, nAL, idx, nIdx, inst, nodes, capNodes, instRef, capRefs, itemsA, itemsB, status);
 }
 
 }  // namespace tbvh

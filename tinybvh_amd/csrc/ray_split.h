@@ -10,8 +10,8 @@
 // (t as an integer that orders like the float | prim), (u, v) of that hit, and the number of members still traversing.
 // A member publishes a hit when it finds it; every member bounds its traversal by the group's key (closest hit) or
 // stops when the key says "found" (any-hit); the last member to finish writes the ray's record.  Among hits at
-// exactly equal t the smaller prim wins instead of the later test (the tie class of DESIGN.md §4); everything else
-// is what one lane would have found.
+// exactly equal t the smaller prim wins — the rule every lane applies on its own as well (device_common.h: hit_wins), so
+// a split ray reports what one lane would have found.
 #pragma once
 #include "device_common.h"
 #include "ray_pool.h"
@@ -19,6 +19,7 @@
 namespace tbvh {
 
 template <int N> struct SplitLds {
+    static_assert(N == 64 || N == 1, "split groups assume ONE 64-lane wave per workgroup: threadIdx.x is the lane id, __syncthreads a wave barrier");
     unsigned long long best[N];
     float2 uv[N];
     uint32_t aux[N];       // two-level kernels: the instance of that hit
@@ -90,11 +91,21 @@ template <bool ANYHIT, int N> __device__ __forceinline__ void split_poll(SplitLd
     else hit.x = __builtin_fminf(hit.x, split_key_t(gb));   // (fminf keeps hit.x against the NaN of "no hit yet")
 }
 
-// A member found a hit: the others cull against it from their next pass on.
-template <bool ANYHIT, int N> __device__ __forceinline__ void split_publish(SplitLds<N>& L, int grp, float4 hit, uint32_t aux = 0u) {
+// A member found a hit: the others cull against it from their next pass on.  The key orders candidates by (t, prim) — the library's tie
+// rule (device_common.h: hit_wins) — so the group's result does not depend on which member found what first.  INST (two-level kernels): the
+// same triangle can be reached through several instances at the same t; then the smaller instance wins.  All members of a group are lanes of
+// ONE wave, LDS operations of a wave execute in program order, and the atomics of one instruction are serialised: exactly one of the lanes
+// that publish a new best key sees an older (larger) key come back and resets the instance word before the holders of the best key take
+// its minimum.
+template <bool ANYHIT, bool INST = false, int N> __device__ __forceinline__ void split_publish(SplitLds<N>& L, int grp, float4 hit, uint32_t aux = 0u) {
     const unsigned long long key = split_key<ANYHIT>(hit);
-    atomicMin(&L.best[grp], key);
-    if (!ANYHIT && atomicAdd(&L.best[grp], 0ull) == key) { L.uv[grp] = make_float2(hit.y, hit.z); L.aux[grp] = aux; }   // (read back: of two members finding hits in one pass only the better one writes)
+    const unsigned long long old = atomicMin(&L.best[grp], key);
+    if (ANYHIT) return;
+    const bool best = atomicAdd(&L.best[grp], 0ull) == key;   // (read back: of two members finding hits in one pass only the better one writes)
+    if (!INST) { if (best) L.uv[grp] = make_float2(hit.y, hit.z); return; }
+    if (best && old > key) L.aux[grp] = 0xFFFFFFFFu;
+    if (best) atomicMin(&L.aux[grp], aux);
+    if (best && atomicAdd(&L.aux[grp], 0u) == aux) L.uv[grp] = make_float2(hit.y, hit.z);
 }
 
 // A member is done; the last one writes the record (INST: two-level kernels, hit.inst at byte 44 of the record).
