@@ -499,14 +499,14 @@ def cpu_baseline(tb, ctx, verts, d_prim, d_diff, n):
         ref = Reference()
         t0 = time.time()
         rs = ref.build(verts, hq=False, threaded=True)
-        rs.time_mt(8, batches[0][:1024], threads=1)  # builds BVH8_CPU
+        rs.time_mt(11, batches[0][:1024], threads=1)  # builds BVH8_CPU
         log(f"[bench] reference BVH + BVH8_CPU build {time.time() - t0:.1f}s")
-        sec = sum(rs.time_mt(8, b, threads=cores)[0] for b in batches)
+        sec = sum(rs.time_mt(11, b, threads=cores)[0] for b in batches)
 
         def rate(layout, threads, k):   # k rays of each batch, strided over the sample
             sub = [np.ascontiguousarray(b[:: max(ns // k, 1)][:k]) for b in batches]
             return sum(x.shape[0] for x in sub) / sum(rs.time_mt(layout, x, threads=threads)[0] for x in sub) / 1e6, sub[0].shape[0]
-        r8_1, k8 = rate(8, 1, 1 << 20)
+        r8_1, k8 = rate(11, 1, 1 << 20)
         r1_mt, k1m = rate(1, cores, 1 << 21)
         r1_1, k11 = rate(1, 1, 1 << 18)
         return {"value": 2 * ns / sec / 1e6, "unit": "MRays/s", "cores": cores, "kind": "reference",

@@ -248,13 +248,21 @@ int tbvh_measure_copy_bandwidth(tbvh_context* ctx, uint64_t bytes, uint32_t reps
  * [3] triangle-loop iterations, [4] sum of lanes in them, [5] refill events, [6] rays handed out. */
 int tbvh_debug_stats(tbvh_context* ctx, uint64_t out[8], int reset);
 
-/* BVH8_CWBVH node placement (the blob the caller uploaded is unchanged; "the library may keep a re-laid-out copy"): nodes in
- * surface-area priority order — the nodes a ray is most likely to visit first —, the first packed_nodes of them (rounded down to a
- * multiple of 8) packed 80 bytes apart, all later ones one per 128-byte line.  The top of the tree is served by the L2s, where the
- * packed form moves 40 % more nodes per second; deep nodes come from beyond them, where a cache line is the unit and a packed node
- * straddles 1.6 lines (tools/ubench/gather_lanes.hip).  packed_nodes >= the node count: priority order, all packed; 0: all padded;
- * < 0: back to the uploaded array.  Hit records do not depend on the placement.  Kept current by tbvh_refit. */
+/* BVH8_CWBVH placement for INCOHERENT batches (the blob the caller uploaded is unchanged; "the library may keep a re-laid-out copy"):
+ * a copy of the nodes in surface-area priority order — the nodes a ray is most likely to visit first —, the first packed_nodes of them
+ * (rounded down to a multiple of 8) packed 80 bytes apart, all later ones one per 128-byte line, plus the triangle records padded to 64
+ * bytes.  The top of the tree is served by the L2s, where the packed form moves 40 % more nodes per second; deep nodes and triangles come
+ * from beyond them, where a cache line is the unit and a packed node straddles 1.6 lines, a 48-byte record 1.4 (tools/ubench/
+ * gather_lanes.hip).  Scenes of 48 - 384 MB get these copies at upload with packed_nodes = 8192, and batches of 2 M rays and more whose
+ * coherence probe says "incoherent" are traced on them (DESIGN.md par. 5; TBVH_INCOHERENT_COPIES=0 turns that off); this call (re)builds
+ * them with another split for any BVH8_CWBVH scene — tbvh_set_variant(scene, 90) then traces every batch on them.  packed_nodes >= the
+ * node count: priority order, all packed; 0: all padded; < 0: drop the node copy.  Hit records do not depend on the placement.  Kept
+ * current by tbvh_refit. */
 int tbvh_cwbvh_set_hybrid(tbvh_scene* scene, int64_t packed_nodes);
+
+/* Experiment switches for the BVH8_CWBVH kernel of the next launches on this context (development aid; 0 = as shipped):
+ * 1 = non-temporal ray loads / hit stores, 2 = triangle records padded to 64 bytes (a padded copy is built on first use). */
+int tbvh_debug_set_flags(tbvh_context* ctx, uint32_t flags);
 
 /* The per-launch coherence probe of the most recent query on this context (development aid; DESIGN.md par. 3): out[0] = sampled
  * neighbouring ray pairs whose directions agree, out[1] = pairs sampled, out[2] = 0 no probe ran (small batches, small or very
@@ -263,7 +271,7 @@ int tbvh_cwbvh_set_hybrid(tbvh_scene* scene, int64_t packed_nodes);
 int tbvh_debug_last_probe(tbvh_context* ctx, uint32_t out[3]);
 
 /* Diagnostic kernel variants of BVH8_CWBVH scenes (0 = default): 72 / 52 force the strict / the coherent schedule whatever
- * the probe says, 75 / 88 split the last rays whatever the batch size, 59 / 61 / 73 / 78 / 82 / 83 are the instrumented
+ * the probe says, 90 the incoherent flavor on the copies of tbvh_cwbvh_set_hybrid, 75 / 88 split the last rays whatever the batch size, 59 / 61 / 73 / 78 / 82 / 83 are the instrumented
  * kernels behind tbvh_debug_stats.  Returns TBVH_E_INVALID for anything else. */
 int tbvh_set_variant(tbvh_scene* scene, int variant);
 

@@ -41,12 +41,12 @@ def fixture(name, verts, ref):
             out["occluded"] = rs.occluded(1, sh)
         else:
             out["hits_hq_tree"] = hits  # same records up to ties; kept to show builder independence
-        out[f"bvhgpu_nodes_{hq}"] = rs.blob(4, 0, np.uint32, 16); out[f"bvhgpu_idx_{hq}"] = rs.blob(4, 1, np.uint32, 1)
-        out[f"bvh4_{hq}"] = rs.blob(6, 0, np.uint32, 4)
-        out[f"cwbvh_nodes_{hq}"] = rs.blob(9, 0, np.uint32, 4); out[f"cwbvh_tris_{hq}"] = rs.blob(9, 1, np.uint32, 4)
+        out[f"bvhgpu_nodes_{hq}"] = rs.blob(5, 0, np.uint32, 16); out[f"bvhgpu_idx_{hq}"] = rs.blob(5, 1, np.uint32, 1)
+        out[f"bvh4_{hq}"] = rs.blob(8, 0, np.uint32, 4)
+        out[f"cwbvh_nodes_{hq}"] = rs.blob(10, 0, np.uint32, 4); out[f"cwbvh_tris_{hq}"] = rs.blob(10, 1, np.uint32, 4)
         # the BVH2 (leaves of at most 3 triangles) the reference converted that CWBVH from: input of the device-side conversion
-        out[f"bvh2s3_nodes_{hq}"] = rs.blob(19, 0, np.uint32, 8); out[f"bvh2s3_idx_{hq}"] = rs.blob(19, 1, np.uint32, 1)
-        out[f"mirror4_{hq}"] = rs.intersect(4, rays); out[f"mirror6_{hq}"] = rs.intersect(6, rays); out[f"mirror9_{hq}"] = rs.intersect(9, rays)
+        out[f"bvh2s3_nodes_{hq}"] = rs.blob(110, 0, np.uint32, 8); out[f"bvh2s3_idx_{hq}"] = rs.blob(110, 1, np.uint32, 1)
+        out[f"mirror4_{hq}"] = rs.intersect(5, rays); out[f"mirror6_{hq}"] = rs.intersect(8, rays); out[f"mirror9_{hq}"] = rs.intersect(10, rays)
     # hit records are stored as their last 16 bytes (t, u, v, prim) to keep the fixtures small
     for k in list(out):
         if k.startswith(("hits", "mirror")):

@@ -101,22 +101,22 @@ int refocl_dump_binary(const char* path) {
     return (int)sz;
 }
 
-// layout: 4 = batch_ailalaine(nodes, idx, verts, rays); 6 = batch_gpu4way(blocks, rays);
-//         9 = batch_cwbvh(nodes, tris, rays).  bufN / bytesN are the layout's blobs in that order.
+// layout (BVHBase::BVHType, as in include/tinybvh_amd.h): 5 = batch_ailalaine(nodes, idx, verts, rays); 8 = batch_gpu4way(blocks, rays);
+//         10 = batch_cwbvh(nodes, tris, rays).  bufN / bytesN are the layout's blobs in that order.
 // rays: n packed 64-byte records (in/out).  Runs 1 warm-up + `passes` timed launches with global
 // size n and local size 64 (tiny_bvh_speedtest.cpp:1122-1131); returns the mean kernel time in
 // milliseconds from the profiling events, or a negative error.
 double refocl_run(int layout, const void* buf0, uint64_t bytes0, const void* buf1, uint64_t bytes1, const void* buf2, uint64_t bytes2,
                   void* rays, uint64_t n, int passes) {
     if (refocl_init()) return -1.0;
-    const char* name = layout == 4 ? "batch_ailalaine" : layout == 6 ? "batch_gpu4way" : layout == 9 ? "batch_cwbvh" : nullptr;
+    const char* name = layout == 5 ? "batch_ailalaine" : layout == 8 ? "batch_gpu4way" : layout == 10 ? "batch_cwbvh" : nullptr;
     if (!name) { snprintf(g_err, sizeof g_err, "bad layout"); return -2.0; }
     cl_int e;
     cl_kernel k = clCreateKernel(g_prog, name, &e);
     if (e != CL_SUCCESS) { snprintf(g_err, sizeof g_err, "clCreateKernel(%s) %d", name, e); return -3.0; }
     const void* bufs[3] = {buf0, buf1, buf2};
     const uint64_t bytes[3] = {bytes0, bytes1, bytes2};
-    const int nb = layout == 4 ? 3 : layout == 6 ? 1 : 2;
+    const int nb = layout == 5 ? 3 : layout == 8 ? 1 : 2;
     cl_mem mem[4] = {nullptr, nullptr, nullptr, nullptr};
     for (int i = 0; i < nb; i++) {
         mem[i] = clCreateBuffer(g_ctx, CL_MEM_READ_ONLY | CL_MEM_COPY_HOST_PTR, bytes[i] ? bytes[i] : 16, (void*)bufs[i], &e);

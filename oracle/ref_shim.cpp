@@ -96,34 +96,40 @@ void ref_free(void* h) {
 // Convert to a GPU layout with the reference's own converter.  Each layout object builds
 // its own tree with the same builder (Build/BuildHQ) the way tiny_bvh_speedtest.cpp does
 // (:1098-1099, 1149-1150, 1196-1197).
-static void ensureLayout(RefScene* s, int layout) {
-    if (layout == 4 && !s->gpu2) { s->gpu2 = new BVH_GPU(); if (s->hq) s->gpu2->BuildHQ(s->verts, s->triCount); else s->gpu2->Build(s->verts, s->triCount); }
-    if (layout == 6 && !s->gpu4) { s->gpu4 = new BVH4_GPU(); if (s->hq) s->gpu4->BuildHQ(s->verts, s->triCount); else s->gpu4->Build(s->verts, s->triCount); }
-    if (layout == 9 && !s->cw) { s->cw = new BVH8_CWBVH(); if (s->hq) s->cw->BuildHQ(s->verts, s->triCount); else s->cw->Build(s->verts, s->triCount); }
-    if (layout == 8 && !s->cpu8) { s->cpu8 = new BVH8_CPU(); if (s->hq) s->cpu8->BuildHQ(s->verts, s->triCount); else s->cpu8->Build(s->verts, s->triCount); }
+// Layout codes are BVHBase::BVHType (tiny_bvh.h:773-791), the same values include/tinybvh_amd.h uses: 1 LAYOUT_BVH, 5 LAYOUT_BVH_GPU,
+// 8 LAYOUT_BVH4_GPU, 10 LAYOUT_CWBVH, 11 LAYOUT_BVH8_AVX2 (BVH8_CPU); 110 = the BVH2 behind the CWBVH (ref_blob only).  Anything else is an error.
+enum { L_BVH = 1, L_BVH_GPU = 5, L_BVH4_GPU = 8, L_CWBVH = 10, L_BVH8_CPU = 11, L_CWBVH_BVH2 = 110 };
+static bool ensureLayout(RefScene* s, int layout) {
+    if (layout != L_BVH && layout != L_BVH_GPU && layout != L_BVH4_GPU && layout != L_CWBVH && layout != L_BVH8_CPU) return false;
+    if (layout == L_BVH_GPU && !s->gpu2) { s->gpu2 = new BVH_GPU(); if (s->hq) s->gpu2->BuildHQ(s->verts, s->triCount); else s->gpu2->Build(s->verts, s->triCount); }
+    if (layout == L_BVH4_GPU && !s->gpu4) { s->gpu4 = new BVH4_GPU(); if (s->hq) s->gpu4->BuildHQ(s->verts, s->triCount); else s->gpu4->Build(s->verts, s->triCount); }
+    if (layout == L_CWBVH && !s->cw) { s->cw = new BVH8_CWBVH(); if (s->hq) s->cw->BuildHQ(s->verts, s->triCount); else s->cw->Build(s->verts, s->triCount); }
+    if (layout == L_BVH8_CPU && !s->cpu8) { s->cpu8 = new BVH8_CPU(); if (s->hq) s->cpu8->BuildHQ(s->verts, s->triCount); else s->cpu8->Build(s->verts, s->triCount); }
+    return true;
 }
 
-// Blob access.  layout: 1 = BVH (Wald), 4 = BVH_GPU, 6 = BVH4_GPU, 9 = CWBVH, 19 = the BVH2 the CWBVH was
+// Blob access.  layout: 1 = BVH (Wald), 5 = BVH_GPU, 8 = BVH4_GPU, 10 = CWBVH, 110 = the BVH2 the CWBVH was
 // converted from (bvh8.bvh after Compact + SplitLeafs(3), tiny_bvh.h:5829-5835): the input a device-side
 // ConvertFrom replacement gets from a tinybvh user.
-// which: 0 = nodes / blocks, 1 = primIdx (layouts 1, 4) or triangle blocks (layout 9).
+// which: 0 = nodes / blocks, 1 = primIdx (layouts 1, 5) or triangle blocks (layout 10).  Unknown layout: 0 elements, null pointer.
 // Returns element count; *out receives the pointer (owned by the scene).
 uint64_t ref_blob(void* h, int layout, int which, const void** out) {
     RefScene* s = (RefScene*)h;
-    ensureLayout(s, layout == 19 ? 9 : layout);
+    *out = nullptr;
+    if (!ensureLayout(s, layout == L_CWBVH_BVH2 ? (int)L_CWBVH : layout)) return 0;
     switch (layout) {
-    case 1:
+    case L_BVH:
         if (which == 0) { *out = s->bvh.bvhNode; return s->bvh.usedNodes; }
         *out = s->bvh.primIdx; return s->bvh.idxCount;
-    case 4:
+    case L_BVH_GPU:
         if (which == 0) { *out = s->gpu2->bvhNode; return s->gpu2->usedNodes; }
         *out = s->gpu2->bvh.primIdx; return s->gpu2->bvh.idxCount;
-    case 6:
+    case L_BVH4_GPU:
         *out = s->gpu4->bvh4Data; return s->gpu4->usedBlocks;
-    case 9:
+    case L_CWBVH:
         if (which == 0) { *out = s->cw->bvh8Data; return s->cw->usedBlocks; }
         *out = s->cw->bvh8Tris; return (uint64_t)s->cw->bvh8.idxCount * 3;
-    case 19:
+    case L_CWBVH_BVH2:
         if (which == 0) { *out = s->cw->bvh8.bvh.bvhNode; return s->cw->bvh8.bvh.usedNodes; }
         *out = s->cw->bvh8.bvh.primIdx; return s->cw->bvh8.bvh.idxCount;
     }
@@ -134,49 +140,47 @@ const void* ref_verts(void* h) { return ((RefScene*)h)->verts; }
 void ref_set_opmap(void* h, uint32_t* mapData, uint32_t N) { ((RefScene*)h)->bvh.SetOpacityMicroMaps(mapData, N); }
 
 // Per-ray queries through the reference's own traversal code.
-// layout 1: BVH::Intersect (THE oracle, tiny_bvh.h:3222); 4/6/9: the CPU mirrors of the GPU
-// layouts (4657 / 5252 / 7046); 8: BVH8_CPU::Intersect (7188).
+// layout 1: BVH::Intersect (THE oracle, tiny_bvh.h:3222); 5 / 8 / 10: the CPU mirrors of the GPU
+// layouts (4657 / 5252 / 7046); 11: BVH8_CPU::Intersect (7188).  -1: unknown layout.
 int ref_intersect(void* h, int layout, void* rays, uint64_t n, uint32_t stride) {
     RefScene* s = (RefScene*)h;
-    ensureLayout(s, layout);
+    if (!ensureLayout(s, layout)) return -1;
     switch (layout) {
-    case 1: forRays(rays, n, stride, [&](Ray& r) { s->bvh.Intersect(r); }); return 0;
-    case 4: forRays(rays, n, stride, [&](Ray& r) { s->gpu2->Intersect(r); }); return 0;
-    case 6: forRays(rays, n, stride, [&](Ray& r) { s->gpu4->Intersect(r); }); return 0;
-    case 9: forRays(rays, n, stride, [&](Ray& r) { s->cw->Intersect(r); }); return 0;
-    case 8: forRays(rays, n, stride, [&](Ray& r) { s->cpu8->Intersect(r); }); return 0;
+    case L_BVH: forRays(rays, n, stride, [&](Ray& r) { s->bvh.Intersect(r); }); return 0;
+    case L_BVH_GPU: forRays(rays, n, stride, [&](Ray& r) { s->gpu2->Intersect(r); }); return 0;
+    case L_BVH4_GPU: forRays(rays, n, stride, [&](Ray& r) { s->gpu4->Intersect(r); }); return 0;
+    case L_CWBVH: forRays(rays, n, stride, [&](Ray& r) { s->cw->Intersect(r); }); return 0;
+    case L_BVH8_CPU: forRays(rays, n, stride, [&](Ray& r) { s->cpu8->Intersect(r); }); return 0;
     }
     return -1;
 }
 int ref_occluded(void* h, int layout, const void* rays, uint64_t n, uint32_t stride, uint8_t* out) {
     RefScene* s = (RefScene*)h;
-    ensureLayout(s, layout);
+    if ((layout != L_BVH && layout != L_BVH8_CPU) || !ensureLayout(s, layout)) return -1;
     const char* p = (const char*)rays;
     for (uint64_t i = 0; i < n; i++, p += stride) {
         Ray r; load(r, p);
         bool o;
-        if (layout == 1) o = s->bvh.IsOccluded(r);
-        else if (layout == 8) o = s->cpu8->IsOccluded(r);
-        else return -1;
+        if (layout == L_BVH) o = s->bvh.IsOccluded(r);
+        else o = s->cpu8->IsOccluded(r);
         out[i] = o ? 1 : 0;
     }
     return 0;
 }
 
 // Node / triangle visit counts from the reference CPU mirrors: c_trav = 1024, c_int = 1
-// (SURVEY.md §5 trick).  layouts 1, 4, 6 only (the CWBVH mirror returns 0).
+// (SURVEY.md §5 trick).  layouts 1, 5, 8 only (the CWBVH mirror returns 0); -1 otherwise.
 int ref_counts(void* h, int layout, const void* rays, uint64_t n, uint32_t stride, uint64_t* steps, uint64_t* tris) {
     RefScene* s = (RefScene*)h;
-    ensureLayout(s, layout);
-    BVHBase* b = layout == 1 ? (BVHBase*)&s->bvh : layout == 4 ? (BVHBase*)s->gpu2 : layout == 6 ? (BVHBase*)s->gpu4 : nullptr;
-    if (!b) return -1;
+    if ((layout != L_BVH && layout != L_BVH_GPU && layout != L_BVH4_GPU) || !ensureLayout(s, layout)) return -1;
+    BVHBase* b = layout == L_BVH ? (BVHBase*)&s->bvh : layout == L_BVH_GPU ? (BVHBase*)s->gpu2 : (BVHBase*)s->gpu4;
     const float ct = b->c_trav, ci = b->c_int;
     b->c_trav = 65536.0f; b->c_int = 1.0f;
     uint64_t S = 0, T = 0;
     const char* p = (const char*)rays;
     for (uint64_t i = 0; i < n; i++, p += stride) {
         Ray r; load(r, p);
-        int32_t c = layout == 1 ? s->bvh.Intersect(r) : layout == 4 ? s->gpu2->Intersect(r) : s->gpu4->Intersect(r);
+        int32_t c = layout == L_BVH ? s->bvh.Intersect(r) : layout == L_BVH_GPU ? s->gpu2->Intersect(r) : s->gpu4->Intersect(r);
         S += (uint32_t)c >> 16; T += (uint32_t)c & 65535;
     }
     b->c_trav = ct; b->c_int = ci;
@@ -186,13 +190,13 @@ int ref_counts(void* h, int layout, const void* rays, uint64_t n, uint32_t strid
 
 // Timed multi-threaded baseline with the speedtest's dynamic batch scheme: 10 000-ray
 // batches handed out through an atomic counter (tiny_bvh_speedtest.cpp:392-401,
-// 1077-1083).  layout 8 = BVH8_CPU (AVX2), 1 = BVH::Intersect.  shadow != 0 times
+// 1077-1083).  layout 11 = BVH8_CPU (AVX2), 1 = BVH::Intersect (anything else: returns -1).  shadow != 0 times
 // IsOccluded.  Rays are 64-byte records; each thread expands them to host Rays in
 // batches *outside* nothing — the expansion is part of what a caller holding packed rays
 // would pay, but it is small (64-byte copy) next to traversal.  Returns seconds.
 double ref_time_mt(void* h, int layout, const void* rays, uint64_t n, uint32_t stride, int threads, int shadow, uint64_t* hits) {
     RefScene* s = (RefScene*)h;
-    ensureLayout(s, layout);
+    if ((layout != L_BVH && layout != L_BVH8_CPU) || !ensureLayout(s, layout)) return -1.0;
     if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
     // expand once, untimed (the speedtest times traversal over pre-built Ray arrays)
     Ray* R = (Ray*)malloc64(n * sizeof(Ray));
@@ -206,10 +210,10 @@ double ref_time_mt(void* h, int layout, const void* rays, uint64_t n, uint32_t s
             if (b >= n) break;
             const uint64_t e = b + 10000 < n ? b + 10000 : n;
             if (shadow) {
-                if (layout == 8) for (uint64_t i = b; i < e; i++) local += s->cpu8->IsOccluded(R[i]);
+                if (layout == L_BVH8_CPU) for (uint64_t i = b; i < e; i++) local += s->cpu8->IsOccluded(R[i]);
                 else for (uint64_t i = b; i < e; i++) local += s->bvh.IsOccluded(R[i]);
             } else {
-                if (layout == 8) for (uint64_t i = b; i < e; i++) s->cpu8->Intersect(R[i]);
+                if (layout == L_BVH8_CPU) for (uint64_t i = b; i < e; i++) s->cpu8->Intersect(R[i]);
                 else for (uint64_t i = b; i < e; i++) s->bvh.Intersect(R[i]);
                 for (uint64_t i = b; i < e; i++) local += R[i].hit.t < BVH_FAR;
             }
@@ -277,7 +281,7 @@ void ref_cwbvh_default_image(void* out, uint32_t bytes) {
 }
 int ref_cwbvh_save(void* h, const char* path) {
     RefScene* s = (RefScene*)h;
-    ensureLayout(s, 9);
+    ensureLayout(s, L_CWBVH);
     s->cw->Save(path);
     return 0;
 }

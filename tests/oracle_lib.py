@@ -178,6 +178,8 @@ class RefScene:
             pass
 
     def blob(self, layout, which, dtype, width):
+        """layout: BVHBase::BVHType as everywhere (1 BVH, 5 BVH_GPU, 8 BVH4_GPU, 10 CWBVH; 110 = the BVH2 behind the CWBVH)."""
+        assert layout in (1, 5, 8, 10, 110), layout
         p = _vp()
         n = self.ref.lib.ref_blob(self.h, layout, which, C.byref(p))
         nbytes = n * np.dtype(dtype).itemsize * width
@@ -209,6 +211,7 @@ class RefScene:
         r = np.ascontiguousarray(rays)
         hits = _u64()
         sec = self.ref.lib.ref_time_mt(self.h, layout, _p(r), r.shape[0], r.strides[0], threads, int(shadow), C.byref(hits))
+        assert sec >= 0, f"ref_time_mt: layout {layout} is not timed (1 = BVH, 11 = BVH8_CPU)"
         return sec, hits.value
 
 

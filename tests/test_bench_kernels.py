@@ -29,7 +29,9 @@ def sample_check(oracle, sc, verts, before, after, n, what, ns=65536):
 def test_probed_schedules_on_the_bench_scene(ctx, oracle):
     verts, _ = scenes.get("bistro")
     sc = tb.BVH8_CWBVH(ctx).Build(verts)
-    assert (48 << 20) < sc.device_bytes <= (384 << 20), sc.device_bytes      # the size class that gets the probe
+    blob_bytes = sc.host.blob(0, np.uint32, 4).nbytes + sc.host.blob(1, np.uint32, 4).nbytes
+    assert (48 << 20) < blob_bytes <= (384 << 20), blob_bytes      # the size class that gets the probe (and the incoherent-batch copies)
+    assert sc.device_bytes > blob_bytes * 2                         # ... which are there: hybrid node copy + 64-byte triangle records
     side = 4096
     n = side * side
     cam = R.camera(*scenes.STREET_CAMERAS[0], side, side, 1, 1)              # bench.py's camera

@@ -78,8 +78,8 @@ def test_reads_files_saved_by_the_reference(tmp_path, reference, verts, hq):
     path = str(tmp_path / "ref.cwbvh")
     rs.cwbvh_save(path)
     back = tb.HostBVH.from_cwbvh_file(path, expected_tris=verts.shape[0] // 3)
-    assert np.array_equal(back.blob(0, np.uint32, 4), rs.blob(9, 0, np.uint32, 4))
-    assert np.array_equal(back.blob(1, np.uint32, 4), rs.blob(9, 1, np.uint32, 4))
+    assert np.array_equal(back.blob(0, np.uint32, 4), rs.blob(10, 0, np.uint32, 4))
+    assert np.array_equal(back.blob(1, np.uint32, 4), rs.blob(10, 1, np.uint32, 4))
 
 
 def test_reference_loads_and_traces_files_written_here(tmp_path, reference, oracle, verts):

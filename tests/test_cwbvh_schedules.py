@@ -32,8 +32,9 @@ def test_schedule_variant_matches_the_oracle(ctx, oracle_ties, variant):
         assert c["tie"] == 0 and c["onsurf"] <= max(4, c["n"] // 5000), (variant, c)
         assert c["bit_identical"] == c["same_prim"], (variant, c)
         assert np.array_equal(got.view(np.uint8), base.view(np.uint8)), variant          # and the default kernel's, byte for byte
-        occ = sc.IsOccluded(rays.copy())
-        assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+        if variant not in (59, 61):                     # (the instrumented kernels exist for Intersect only)
+            occ = sc.IsOccluded(rays.copy())
+            assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
     sc.free()
 
 
@@ -51,8 +52,8 @@ def test_unknown_variants_are_refused(ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("packed", [0, 64, 1024, 10**9])
 def test_node_placement_does_not_change_a_record(ctx, oracle_ties, packed):
-    """tbvh_cwbvh_set_hybrid: priority-ordered nodes, the first `packed` at 80 bytes, the others one per 128-byte line.  Same records, byte for
-    byte; a refit keeps the placed copy current."""
+    """tbvh_cwbvh_set_hybrid: priority-ordered nodes, the first `packed` at 80 bytes, the others one per 128-byte line, triangle records at 64
+    bytes; the incoherent flavor of the kernel (non-temporal ray records).  Same records, byte for byte; a refit keeps the copies current."""
     verts = scenes.atrium(60_000, seed=3)
     sc = tb.BVH8_CWBVH(ctx).Build(verts)
     rays = np.concatenate([R.random_rays(60_000, (-20, 0, -10), (20, 15, 10), seed=8), R.primary(R.camera(*scenes.SPONZA_CAMERAS[0], 256, 128, 1, 1))])
@@ -62,12 +63,14 @@ def test_node_placement_does_not_change_a_record(ctx, oracle_ties, packed):
     c = compare_hits(base, want)
     assert c["hits"] > 10_000 and c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["tie"] == 0, c
     sc.set_hybrid(packed)
+    sc.set_variant(90)                      # the incoherent flavor on the placed copies (hybrid nodes, 64-byte triangle records), whatever the batch
     got = sc.Intersect(rays.copy())
     assert np.array_equal(got.view(np.uint8), base.view(np.uint8))
     assert np.array_equal(sc.IsOccluded(rays.copy()), occ0)
     moved = verts.copy(); moved[:, 1] += np.float32(0.01) * np.sin(verts[:, 0]).astype(np.float32)
     sc.Refit(moved)
     got2 = sc.Intersect(rays.copy())
+    sc.set_variant(0)
     sc.set_hybrid(-1)
     base2 = sc.Intersect(rays.copy())
     assert np.array_equal(got2.view(np.uint8), base2.view(np.uint8))

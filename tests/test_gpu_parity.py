@@ -21,12 +21,6 @@ pytestmark = pytest.mark.gpu
 LAYOUTS = [tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU, tb.LAYOUT_CWBVH]
 
 
-@pytest.fixture(scope="module")
-def oracle(oracle_ties):
-    """In this module the restated oracle runs under the library's tie rule."""
-    return oracle_ties
-
-
 def upload(ctx, layout, verts):
     return tb.LAYOUT_CLASSES[layout](ctx).Build(verts)
 
@@ -192,11 +186,11 @@ def test_reference_built_blobs(ctx, oracle, reference, atrium_small, layout, hq)
     rs = reference.build(verts, hq=hq)
     cls = tb.LAYOUT_CLASSES[layout]
     if layout == tb.LAYOUT_BVH_GPU:
-        sc = cls(ctx).Upload(rs.blob(4, 0, np.uint32, 16), rs.blob(4, 1, np.uint32, 1), verts)
+        sc = cls(ctx).Upload(rs.blob(5, 0, np.uint32, 16), rs.blob(5, 1, np.uint32, 1), verts)
     elif layout == tb.LAYOUT_BVH4_GPU:
-        sc = cls(ctx).Upload(rs.blob(6, 0, np.uint32, 4))
+        sc = cls(ctx).Upload(rs.blob(8, 0, np.uint32, 4))
     else:
-        sc = cls(ctx).Upload(rs.blob(9, 0, np.uint32, 4), rs.blob(9, 1, np.uint32, 4))
+        sc = cls(ctx).Upload(rs.blob(10, 0, np.uint32, 4), rs.blob(10, 1, np.uint32, 4))
     eye, view = scenes.SPONZA_CAMERAS[2]
     rays = R.primary(R.camera(eye, view, 160, 96, 2, 2))
     want = rs.intersect(1, rays)  # BVH::Intersect of the reference itself

@@ -51,12 +51,12 @@ def test_restated_traversals_equal_the_reference(oracle_ref, reference, scene, h
         want = rs.intersect(1, rays)
         assert (want["t"] < 1e30).sum() > 100
         exact(oracle_ref.bvh2_intersect(n2, pi, verts, rays), want)                       # BVH::Intersect
-        exact(oracle_ref.bvhgpu_intersect(rs.blob(4, 0, np.uint32, 16), rs.blob(4, 1, np.uint32, 1), verts, rays), rs.intersect(4, rays))
-        exact(oracle_ref.bvh4_intersect(rs.blob(6, 0, np.uint32, 4), rays), rs.intersect(6, rays))
+        exact(oracle_ref.bvhgpu_intersect(rs.blob(5, 0, np.uint32, 16), rs.blob(5, 1, np.uint32, 1), verts, rays), rs.intersect(5, rays))
+        exact(oracle_ref.bvh4_intersect(rs.blob(8, 0, np.uint32, 4), rays), rs.intersect(8, rays))
         # the CWBVH mirror zeroes u,v,prim of missed finite-tmax rays (tiny_bvh.h:7148); tmax is
         # 1e30 here so records are comparable field by field
-        got = oracle_ref.cwbvh_intersect(rs.blob(9, 0, np.uint32, 4), rs.blob(9, 1, np.uint32, 4), rays)
-        ref9 = rs.intersect(9, rays)
+        got = oracle_ref.cwbvh_intersect(rs.blob(10, 0, np.uint32, 4), rs.blob(10, 1, np.uint32, 4), rays)
+        ref9 = rs.intersect(10, rays)
         for f in ("t", "u", "v", "prim"):
             assert np.array_equal(got[f].view(np.uint32), ref9[f].view(np.uint32)), f
         # shadow rays
@@ -82,8 +82,8 @@ def test_reference_counts_match_oracle_counts(oracle_ref, reference):
     rs = reference.build(verts)
     rays = batches(verts)[0]
     for layout, fn in ((1, lambda: oracle_ref.bvh2_intersect(rs.blob(1, 0, np.uint32, 8), rs.blob(1, 1, np.uint32, 1), verts, rays, counts=True)),
-                       (4, lambda: oracle_ref.bvhgpu_intersect(rs.blob(4, 0, np.uint32, 16), rs.blob(4, 1, np.uint32, 1), verts, rays, counts=True)),
-                       (6, lambda: oracle_ref.bvh4_intersect(rs.blob(6, 0, np.uint32, 4), rays, counts=True))):
+                       (5, lambda: oracle_ref.bvhgpu_intersect(rs.blob(5, 0, np.uint32, 16), rs.blob(5, 1, np.uint32, 1), verts, rays, counts=True)),
+                       (8, lambda: oracle_ref.bvh4_intersect(rs.blob(8, 0, np.uint32, 4), rays, counts=True))):
         s, t = rs.counts(layout, rays)
         _, c = fn()
         assert (int(c[0]), int(c[1])) == (s, t), layout

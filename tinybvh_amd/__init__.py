@@ -101,6 +101,9 @@ class Context:
     def time_last_ms(self) -> float:
         return float(lib.tbvh_time_last_ms(self._h))
 
+    def set_debug_flags(self, flags: int):
+        check(lib.tbvh_debug_set_flags(self._h, int(flags)), "tbvh_debug_set_flags")
+
     def last_probe(self):
         """(agreeing pairs, pairs, verdict) of the coherence probe of the most recent query: verdict 0 = no probe ran,
         1 = incoherent (strict schedule), 2 = coherent (tbvh_debug_last_probe)."""

@@ -79,6 +79,7 @@ SYMBOLS = {
     "tbvh_set_variant": (_i, [_vp, _i]),
     "tbvh_debug_stats": (_i, [_vp, _vp, _i]),
     "tbvh_debug_last_probe": (_i, [_vp, _vp]),
+    "tbvh_debug_set_flags": (_i, [_vp, _u32]),
     "tbvh_cwbvh_set_hybrid": (_i, [_vp, C.c_int64]),
     "tbvh_bin_rays_device": (_i, [_vp, _vp, _vp, _u64, C.POINTER(C.c_float), _u32, _u32, _vp]),
     "tbvh_generate_primary_device": (_i, [_vp, C.POINTER(Camera), _vp, _u64, _u64]),

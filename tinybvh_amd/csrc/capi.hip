@@ -60,6 +60,8 @@ struct tbvh_context {
     uint32_t spillEntries = 0;    // 32-bit entries per lane
     unsigned long long* counter = nullptr;  // status word, instrumentation counters
     uint32_t poolParts = 5;   // log2: 32 partitions
+    bool incoherentCopies = true;   // TBVH_INCOHERENT_COPIES=0: no hybrid node copy / 64-byte triangle records (prepareIncoherentCopies)
+    uint32_t expFlags = 0;     // tbvh_debug_set_flags: QueryArgs::flags of the next launches (experiments)
     bool lastProbed = false;   // the most recent query launch ran the coherence probe (tbvh_debug_last_probe)
     bool gridOverride = false;     // TBVH_BLOCKS_PER_CU / TBVH_RAYS_PER_BLOCK given: no per-scene adjustment
     uint64_t splitBelow = 12ull << 20;   // batches of fewer rays split their last rays over idle lanes; TBVH_SPLIT_RAYS=0 turns that off (tie order then reproducible run to run)
@@ -89,6 +91,7 @@ struct tbvh_scene {
     float4* nodes128 = nullptr; // CWBVH: the same nodes padded to one 128-byte line each (padCwbvhIfLarge: node arrays beyond the Infinity Cache)
     float4* nodesHy = nullptr;  // CWBVH: the same nodes in surface-area priority order, the first hybridK packed, the others one per line (cwbvh_node.h: kNodeHybrid)
     uint32_t* hyPerm = nullptr; // device: position of node i in nodesHy
+    float4* tris64 = nullptr;   // CWBVH (experiment flag 2): triangle records padded to 64 bytes
     uint32_t hybridK = 0;
     uint32_t nNodes = 0;
     uint64_t nNodeBlocks = 0, nTriBlocks = 0;
@@ -319,7 +322,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     q.spill = c->spill; q.counter = (uint32_t*)c->pool; q.poolParts = c->poolParts;
     q.stats = c->counter + 8;
     q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.omm = Omm{s->opmap, s->opmapN};
-    q.probe = nullptr; q.baseBlocks = 0; q.hybridK = s->hybridK;
+    q.probe = nullptr; q.baseBlocks = 0; q.hybridK = s->hybridK; q.flags = c->expFlags & 1u;
     c->lastProbed = false;
     q.splitBelow = c->splitBelow;
     // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
@@ -329,7 +332,8 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     // plus the Infinity Cache — is latency-bound, not cache-bound: it runs best with a third more waves (32 per CU) of
     // fewer rays each (measured +1..20 % on the Sponza stand-in from 0.26 M to 16.7 M rays; the same shape costs the
     // 196 MB Bistro stand-in 5-10 % on bounce and shadow rays, which thrash the caches more with more waves).
-    const bool small = !s->isTlas && !c->gridOverride && s->bytes < (48ull << 20);
+    const uint64_t blobBytes = (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH) ? (s->nNodeBlocks + s->nTriBlocks) * 16 : s->bytes;   // (without the library's own re-laid-out copies)
+    const bool small = !s->isTlas && !c->gridOverride && blobBytes < (48ull << 20);
     const uint32_t perBlock = c->raysPerBlock;
     const uint32_t cap = small ? c->blocks + c->blocks / 3u : c->blocks;
     uint64_t want = (n + perBlock - 1) / perBlock;
@@ -341,7 +345,8 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     // rays and more (the probe costs ~10 us, 3-4 % of a 1 M-ray launch): a 16-workgroup probe of the batch's coherence (4096 neighbour pairs)
     // lets the traversal kernel pick its schedule for the launch; a coherent batch also gets a third more waves (the surplus leaves at once
     // otherwise).  Bistro stand-in, 16.7 M rays: camera rays +4.5 %, shadow rays +6 %, bounce rays unchanged.
-    if (!s->isTlas && !small && s->bytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || s->variant == 88)) {
+    uint32_t blocksBase = blocks;
+    if (!s->isTlas && !small && blobBytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || s->variant == 88)) {
         uint32_t* probe = (uint32_t*)c->pool + (size_t)kPoolParts * kPoolCounterStride;
         launch_coherence_probe(d_rays, n, nDev, probe, c->stream);
         HIP_TRY(hipGetLastError());
@@ -395,8 +400,25 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         q.spillStride = c->spillEntries / 2;  // 8-byte entries
         {
             const bool autoPad = s->variant == 0 && s->nodes128 != nullptr;   // nodes beyond the Infinity Cache: the padded copy (padCwbvhIfLarge)
-            const bool hybrid = s->variant == 0 && !autoPad && s->nodesHy != nullptr;
-            launch_cwbvh(any, s->variant, autoPad ? s->nodes128 : hybrid ? s->nodesHy : s->nodes, s->tris, q, c->status, blocks, c->stream, autoPad ? 8 : hybrid ? 13 : 5, small);
+            const uint32_t blocks7 = c->gridOverride ? 0xFFFFFFFFu : (uint32_t)c->numCUs * 28u;
+            const float4* tris = s->tris;
+            if ((c->expFlags & 2u) && s->tris64) { tris = s->tris64; q.flags |= 2u; }   // experiment: 64-byte triangle records in the ordinary kernels too
+            // A probed launch on a scene with the incoherent-batch copies (prepareIncoherentCopies) is TWO kernels back to back, each for one
+            // verdict of the probe; the one the verdict is not for leaves at once (~10 us).  The coherent flavor keeps the packed arrays as
+            // uploaded (its working set lives in the L2s); the incoherent one walks the hybrid node copy and the 64-byte triangle records.
+            // Bistro stand-in, 16.7 M rays, interleaved medians (profiles/r03_ab_16m.txt): bounce rays +10 %, camera and shadow rays unchanged.
+            const bool twoFlavors = q.probe && s->variant == 0 && !autoPad && s->nodesHy && s->tris64 && !(c->expFlags & 4u);
+            if (s->variant == 90 && s->nodesHy && s->tris64)   // diagnostic: the incoherent flavor whatever the batch (tests, tools/ab_configs.py)
+                launch_cwbvh(any, 0, s->nodesHy, s->tris64, q, c->status, blocksBase, c->stream, 13, small, blocks7);
+            else if (twoFlavors) {
+                QueryArgs qa = q;
+                qa.baseBlocks = 0;   // every wave of the coherent flavor leaves unless the batch is coherent
+                launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, blocks, c->stream, 5, small, blocks7);
+                HIP_TRY(hipGetLastError());
+                QueryArgs qb = q;
+                launch_cwbvh(any, 0, s->nodesHy, s->tris64, qb, c->status, blocksBase, c->stream, 13, small, blocks7);
+            } else
+                launch_cwbvh(any, s->variant, autoPad ? s->nodes128 : s->nodes, tris, q, c->status, blocks, c->stream, autoPad ? 8 : 5, small, blocks7);
         }
         break;
     default:
@@ -442,6 +464,38 @@ int padCwbvhIfLarge(tbvh_scene* s) {
 }
 
 size_t hybridBytes(uint32_t nNodes, uint32_t K) { return ((size_t)K * 5 + (size_t)(nNodes - K) * 8) * 16; }
+
+// BVH8_CWBVH scenes of the class that gets the per-launch coherence probe (48 - 384 MB of blobs: beyond the L2s, within reach of the Infinity
+// Cache) keep two derived copies for INCOHERENT batches (kernels_cwbvh.hip: PROBED == 2): the nodes in surface-area priority order with the
+// first kHybridPacked packed and the others one per 128-byte line, and the triangle records padded to 64 bytes.  hostNodes: the blob as
+// uploaded (priority order computed on the host, ~0.1 s for 600 k nodes), or nullptr for trees made on the device (tbvh_convert_bvh2_device,
+// tbvh_build_device emit level order, which already is close to priority order: no renumbering).  Failure to allocate is not an error: the
+// scene then runs the one-kernel path.  TBVH_INCOHERENT_COPIES=0 turns the copies off.
+constexpr uint32_t kHybridPacked = 8192;
+int prepareIncoherentCopies(tbvh_scene* s, const Vec4* hostNodes) {
+    tbvh_context* c = s->ctx;
+    const uint64_t blobBytes = (s->nNodeBlocks + s->nTriBlocks) * 16;
+    if (s->layout != TBVH_LAYOUT_CWBVH || s->isTlas || !c->incoherentCopies || blobBytes < (48ull << 20) || blobBytes > (384ull << 20) || s->nNodes <= kHybridPacked || !s->nTriBlocks) return 0;
+    const uint32_t K = kHybridPacked;
+    const uint64_t nT = s->nTriBlocks / 3;
+    if (!s->nodesHy && hipMalloc((void**)&s->nodesHy, hybridBytes(s->nNodes, K)) != hipSuccess) { s->nodesHy = nullptr; (void)hipGetLastError(); return 0; }
+    if (!s->tris64 && hipMalloc((void**)&s->tris64, nT * 64) != hipSuccess) { s->tris64 = nullptr; (void)hipGetLastError(); hipFree(s->nodesHy); s->nodesHy = nullptr; return 0; }
+    if (hostNodes && !s->hyPerm) {
+        std::vector<uint32_t> perm;
+        cwbvh_priority_order(hostNodes, s->nNodes, perm);
+        if (hipMalloc((void**)&s->hyPerm, (size_t)s->nNodes * 4) == hipSuccess) HIP_TRY(hipMemcpyAsync(s->hyPerm, perm.data(), (size_t)s->nNodes * 4, hipMemcpyHostToDevice, c->stream));
+        else { s->hyPerm = nullptr; (void)hipGetLastError(); }
+        HIP_TRY(hipStreamSynchronize(c->stream));   // perm goes out of scope
+    }
+    s->hybridK = K;
+    HIP_TRY(hipMemsetAsync(s->nodesHy, 0, hybridBytes(s->nNodes, K), c->stream));
+    launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, s->nNodes, K, c->stream);
+    launch_cwbvh_pad_tris(s->tris, s->tris64, nT, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    s->bytes += hybridBytes(s->nNodes, K) + nT * 64;
+    return 0;
+}
 
 tbvh_scene* newScene(tbvh_context* c, int layout) {
     tbvh_scene* s = new (std::nothrow) tbvh_scene;
@@ -494,6 +548,7 @@ int tbvh_init(int device, tbvh_context** out) {
         if (b >= 64 && b <= 4096) { c->raysPerBlock = (uint32_t)b; c->gridOverride = true; }
     }
     if (const char* e = getenv("TBVH_SPLIT_RAYS")) { if (atoi(e) == 0) c->splitBelow = 0; }
+    if (const char* e = getenv("TBVH_INCOHERENT_COPIES")) { if (atoi(e) == 0) c->incoherentCopies = false; }
     if (const char* e = getenv("TBVH_POOL_PARTS")) {  // experiment knob
         const int b = atoi(e);
         if (b >= 0 && (1 << b) <= kPoolParts) c->poolParts = (uint32_t)b;   // log2 of the partition count
@@ -608,6 +663,7 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
     s->nNodeBlocks = nNodeBlocks; s->nTriBlocks = nTriBlocks;
     s->bytes = (nNodeBlocks + nTriBlocks) * 16;
     if (int r = padCwbvhIfLarge(s)) { tbvh_free_scene(s); return r; }
+    if (int r = prepareIncoherentCopies(s, (const Vec4*)nodes16)) { tbvh_free_scene(s); return r; }
     *out = s;
     return 0;
 }
@@ -792,6 +848,7 @@ int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t n
     s->nNodes = nWide; s->nNodeBlocks = (uint64_t)nWide * 5; s->nTriBlocks = nWideTris * 3;
     s->bytes = (s->nNodeBlocks + s->nTriBlocks) * 16;
     if (int r = padCwbvhIfLarge(s)) { tbvh_free_scene(s); return r; }
+    if (int r = prepareIncoherentCopies(s, nullptr)) { tbvh_free_scene(s); return r; }
     *out = s;
     return 0;
 }
@@ -967,6 +1024,7 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
     // derived node layouts of the experiment kernels would be stale now
     if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copy current
     if (s->nodesHy) launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, nNodes, s->hybridK, c->stream);
+    if (s->tris64) launch_cwbvh_pad_tris(s->tris, s->tris64, s->nTriBlocks / 3, c->stream);
     return 0;
 }
 
@@ -1050,6 +1108,7 @@ void tbvh_free_scene(tbvh_scene* s) {
     if (s->tris) hipFree(s->tris);
     if (s->nodes128) hipFree(s->nodes128);
     if (s->nodesHy) hipFree(s->nodesHy);
+    if (s->tris64) hipFree(s->tris64);
     if (s->hyPerm) hipFree(s->hyPerm);
     if (s->tlasIdx) hipFree(s->tlasIdx);
     if (s->instances) hipFree(s->instances);
@@ -1256,8 +1315,21 @@ int tbvh_cwbvh_set_hybrid(tbvh_scene* s, int64_t packedNodes) {
     s->hybridK = K;
     launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, s->nNodes, K, c->stream);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
     s->bytes += hybridBytes(s->nNodes, K);
+    if (!s->tris64 && s->nTriBlocks) {
+        const uint64_t nT = s->nTriBlocks / 3;
+        HIP_TRY(hipMalloc((void**)&s->tris64, nT * 64));
+        launch_cwbvh_pad_tris(s->tris, s->tris64, nT, c->stream);
+        HIP_TRY(hipGetLastError());
+        s->bytes += nT * 64;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int tbvh_debug_set_flags(tbvh_context* c, uint32_t flags) {
+    if (!c) return fail(TBVH_E_INVALID, "tbvh_debug_set_flags: null context");
+    c->expFlags = flags;
     return 0;
 }
 

@@ -91,6 +91,14 @@ __device__ __forceinline__ float3 xyz(float4 v) { return make_float3(v.x, v.y, v
 // test), so the reported triangle does not depend on the schedule, on split rays or on the layout's child order.  The reference lets the
 // LATER test win (tiny_bvh.h:1656: t <= ray.hit.t is accepted), i.e. its result among exactly equal t depends on the traversal order, and
 // its own layouts disagree with each other there; oracle/tbvh_oracle.c restates both rules (orc_set_tie_rule).
+// Box tests cull against a bound 2^-20 (eight ulps) beyond the closest hit so far.  A triangle lying IN a face of its leaf box — every
+// axis-aligned wall — has its distance computed twice, by the slab test and by the triangle test, and the two round differently: with the
+// exact bound, whether such a triangle is still tested once a hit within an ulp or two of it has been found depends on which was found
+// first, i.e. on the traversal order (in the reference as well: tests/test_full_size.py).  With the slack every candidate within a few ulps of
+// the closest hit is tested and the tie rule below picks the same one whatever the order; tri_test still rejects t > hit.t exactly, so no
+// record gets farther, and a record can only get CLOSER (by ulps) than one the exact bound would have produced.
+__device__ __forceinline__ float cull_bound(float t) { return t * 1.00000095367431640625f; }
+
 __device__ __forceinline__ bool hit_wins(float t, uint32_t prim, bool found, float4 best) {
     return !found || t < best.x || prim < as_u32(best.w);
 }
@@ -117,6 +125,8 @@ struct QueryArgs {
     // sampled; nullptr = no probe ran (small batches).  baseBlocks: workgroups beyond this index only take part when the batch is coherent.
     const uint32_t* probe;
     uint32_t baseBlocks;
+    const float4* nodesPacked;   // BVH8_CWBVH with a hybrid node array: the packed array as uploaded (coherent probed batches stay on it)
+    uint32_t flags;        // experiments: 1 = non-temporal ray loads / hit stores, 2 = triangle records padded to 64 bytes
     uint32_t hybridK;      // BVH8_CWBVH, hybrid node array (cwbvh_node.h: kNodeHybrid): nodes below this index are packed, the others one per line
 };
 

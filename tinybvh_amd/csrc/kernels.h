@@ -14,10 +14,11 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
 // nodeStride: 5 = `nodes` is the packed array; 8 = the copy with one node per 128-byte line (scenes whose nodes outgrow the Infinity
 // Cache); 13 (cwbvh_node.h: kNodeHybrid) = the priority-ordered copy whose first q.hybridK nodes are packed and the others one per line
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
-                  uint32_t blocks, hipStream_t s, int nodeStride = 5, bool shallow = false);
+                  uint32_t blocks, hipStream_t s, int nodeStride = 5, bool shallow = false, uint32_t blocks7 = 0xFFFFFFFFu);   // blocks7: grid of the kernels built for 7 waves per SIMD
 void launch_cwbvh_derive_hybrid(const float4* src, const uint32_t* perm, float4* dst, uint32_t nNodes, uint32_t hybridK, hipStream_t s);
 bool cwbvh_variant_valid(int variant);     // diagnostic variants of the BVH8_CWBVH kernel (tbvh_set_variant); the other layouts have none
 void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream_t s);
+void launch_cwbvh_pad_tris(const float4* src, float4* dst, uint64_t nTris, hipStream_t s);
 struct BlasDesc { const float4* nodes; const float4* tris; const uint32_t* opmap; uint32_t opmapN; uint32_t layout; };  // one per BLAS of a TLAS (layout: TBVH_LAYOUT_*)
 void launch_tlas(bool anyhit, int blasLayout, const float4* tlasNodes, const uint32_t* tlasIdx, const float4* instances,
                  const BlasDesc* blas, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);

@@ -36,8 +36,8 @@ constexpr int WG = 64;
 // STATS (experiment builds): q.stats[0] wave iterations, [1] sum of active lanes, [2] sum of lanes visiting a node,
 // [3] triangle-phase iterations, [4] sum of lanes in them, [5] node phases whose lanes all visit ONE node with ONE octant,
 // [6] sum of lanes in those, [7] node-phase iterations
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, int STATS = 0, int NSTRIDE = 5, bool PROBED = false, int STEAL = 0>
-__global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, int STATS = 0, int NSTRIDE = 5, int PROBED = 0, int STEAL = 0, int MINW = 8>
+__global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
     const uint32_t glane = blockIdx.x * WG + threadIdx.x;
@@ -48,15 +48,23 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
     pool.init(q.poolParts);
     LockstepGovernor gov;
     gov.init();
-    // PROBED: the batch's coherence probe (QueryArgs::probe) picks the schedule for the whole launch: coherent batches (camera rays, shadow
-    // rays towards one light) are VALU-bound and run deferred triangles + a gated triangle phase on a third more waves; incoherent ones are
-    // bound by the cache-miss path, keep the strict schedule, and the surplus waves leave at once
+    // PROBED: the batch's coherence probe (QueryArgs::probe) picks the schedule for the whole launch: coherent batches (camera rays, shadow rays
+    // towards one light) are VALU-bound and run deferred triangles + a gated triangle phase on a third more waves; incoherent ones are bound by
+    // the cache-miss path and keep the strict schedule.  PROBED == 1: this kernel holds both schedules (waves beyond q.baseBlocks leave at once
+    // when the batch is incoherent; with baseBlocks == 0 the kernel serves coherent batches only).  PROBED == 2: the INCOHERENT flavor of a probed
+    // launch (capi.hip launches the two back to back, the one the verdict is not for costs ~10 us): strict schedule, leaves at once when the batch
+    // is coherent, and reads what an incoherent batch is bound by in its cheapest form — the priority-ordered node copy whose deep nodes have a
+    // line each (NSTRIDE = kNodeHybrid), triangle records padded to 64 bytes (none straddles a line), ray records with the non-temporal hint
+    // (read once by one CU: they should not displace tree lines in the L2s).
     bool coh = false;
     if (PROBED && q.probe) {
         const uint32_t agree = q.probe[0], pairs = q.probe[1];
         coh = pairs != 0 && agree * 10u >= pairs * 6u;
-        if (!coh && blockIdx.x >= q.baseBlocks) return;
+        if (PROBED == 2) { if (coh) return; }
+        else if (!coh && blockIdx.x >= q.baseBlocks) return;
     }
+    const uint32_t hybridK = q.hybridK;
+    const bool ntRays = PROBED == 2 || (q.flags & 1u) != 0, tri64 = PROBED == 2 || (q.flags & 2u) != 0;
 
     bool active = false;
     uint64_t ri = 0;
@@ -82,7 +90,11 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
                 if (got) {
                     ri = nri;
                     const RayRec* rp = q.rays + ri;
-                    O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD);
+                    if (ntRays) {   // (experiment) a ray record is read once by one CU: keep it from displacing tree lines in the L2
+                        const tbvh_f4* r4 = (const tbvh_f4*)rp;
+                        const tbvh_f4 a = __builtin_nontemporal_load(r4), b = __builtin_nontemporal_load(r4 + 1), c = __builtin_nontemporal_load(r4 + 2);
+                        O = make_float3(a.x, a.y, a.z); D = make_float3(b.x, b.y, b.z); rD = make_float3(c.x, c.y, c.z);
+                    } else { O = xyz(rp->O); D = xyz(rp->D); rD = xyz(rp->rD); }
                     hit = q.fresh ? make_float4(q.freshTmax, 0.f, 0.f, 0.f) : rp->hit;
                     found = false;
                     oct = cw_oct(D);
@@ -134,9 +146,9 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
         if (tail && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
         // ---- triangle phase: runs when enough lanes have a triangle pending, or when no lane could use a node
         // phase instead (so a waiting lane always makes progress) --------------------------------------------
-        const bool spec = PROBED ? coh : SPEC;
+        const bool spec = PROBED == 1 ? coh : SPEC;
         bool triPhase = true;
-        if (TRI_MIN > 1 && (PROBED ? coh : true)) {
+        if (TRI_MIN > 1 && (PROBED == 1 ? coh : true)) {
             const uint32_t nPend = (uint32_t)__popcll(__ballot(tg.y != 0));
             const bool canNode = spec ? (tg2.y == 0 && (cw_has_child(ng) || !st.empty())) : tg.y == 0;
             triPhase = nPend >= (uint32_t)TRI_MIN || __ballot(canNode) == 0;
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
             if (STATS == 1) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sTriIter++; sTri += __popcll(m); } }
             const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
             tg.y &= ~(1u << ti);
-            const uint32_t ta = tg.x + ti * 3u;
+            const uint32_t ta = tri64 ? (__umulhi(tg.x, 0xAAAAAAABu) >> 1) * 4u + ti * 4u : tg.x + ti * 3u;   // (experiment) records padded to 64 bytes: tg.x counts float4s of the packed array
             const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
             TriHit h;
             if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w)) &&
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
                 if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
             }
-            if ((SPEC || PROBED) && tg.y == 0) { tg = tg2; tg2 = make_uint2(0u, 0u); }
+            if ((SPEC || PROBED == 1) && tg.y == 0) { tg = tg2; tg2 = make_uint2(0u, 0u); }
         }
         // ---- node phase ---------------------------------------------------------------------------------------
         if (!done && (spec ? tg2.y == 0 : tg.y == 0)) {
@@ -172,7 +184,7 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
                     if (lane_rank(m) == 0) { sNodeIter++; sNode += __popcll(m); if (uni) { sRefill++; sRefilled += __popcll(m); } }   // [5], [6]: uniform node phases, lanes in them
                 }
                 if (cw_has_child(ng)) st.push(ng);
-                const CwNodeHits r = cw_test_node(cw_load_node<NSTRIDE>(nodes, ci, q.hybridK), O, rD, hit.x, octinv4);
+                const CwNodeHits r = cw_test_node(cw_load_node<NSTRIDE>(nodes, ci, hybridK), O, rD, cull_bound(hit.x), octinv4);
                 ng = make_uint2(r.childBase, (r.hitmask & 0xFF000000u) | r.imask);
                 const uint2 nt = make_uint2(r.triBase, r.hitmask & 0x00FFFFFFu);
                 if (tg.y == 0) tg = nt;
@@ -182,7 +194,10 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
         if (done) {
             if (tail && grp >= 0) split_finish<ANYHIT>(split, grp, q, ri);
             else if (ANYHIT) q.occluded[ri] = found ? 1 : 0;
-            else if (found || q.fresh) q.rays[ri].hit = hit;
+            else if (found || q.fresh) {
+                if (ntRays) { tbvh_f4 hv; hv.x = hit.x; hv.y = hit.y; hv.z = hit.z; hv.w = hit.w; __builtin_nontemporal_store(hv, (tbvh_f4*)&q.rays[ri].hit); }
+                else q.rays[ri].hit = hit;
+            }
             active = false;
         }
     }
@@ -215,11 +230,11 @@ __global__ __launch_bounds__(WG, STEAL ? 8 : 1) void k_cwbvh(const float4* __res
     }
 }
 
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, int STATS = 0, int NSTRIDE = 5, bool PROBED = false, int STEAL = 0>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, int STATS = 0, int NSTRIDE = 5, int PROBED = 0, int STEAL = 0, int MINW = 8>
 void launch_k(const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
     // without opacity micromaps on the scene the check is compiled out (+1-2 %)
-    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE, PROBED, STEAL>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
-    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE, PROBED, STEAL>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE, PROBED, STEAL, MINW>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE, PROBED, STEAL, MINW>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
 }
 
 __global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__ dst, uint32_t nNodes) {
@@ -234,11 +249,11 @@ __global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__
 __global__ void k_derive_hybrid(const float4* __restrict__ src, const uint32_t* __restrict__ perm, float4* __restrict__ dst, uint32_t nNodes, uint32_t hybridK) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nNodes) return;
-    const uint32_t ni = perm[i];
+    const uint32_t ni = perm ? perm[i] : i;   // (no permutation: trees made on the device are in level order already)
     float4* o = dst + ((size_t)ni * 8u - (size_t)(ni < hybridK ? ni : hybridK) * 3u);
     const float4* p = src + (size_t)i * 5u;
     float4 n1 = p[1];
-    if (as_u32(p[0].w) >> 24) { const uint32_t cb = as_u32(n1.x); n1.x = as_f32(cb < nNodes ? perm[cb] : 0u); }
+    if (as_u32(p[0].w) >> 24) { const uint32_t cb = as_u32(n1.x); n1.x = as_f32(cb < nNodes ? (perm ? perm[cb] : cb) : 0u); }
     o[0] = p[0]; o[1] = n1; o[2] = p[2]; o[3] = p[3]; o[4] = p[4];
 }
 
@@ -249,7 +264,7 @@ void launch_cwbvh_derive_hybrid(const float4* src, const uint32_t* perm, float4*
 }
 
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
-                  uint32_t blocks, hipStream_t s, int nodeStride, bool shallow) {
+                  uint32_t blocks, hipStream_t s, int nodeStride, bool shallow, uint32_t blocks7) {
 #define TBVH_K(...)                                                                     \
     do {                                                                                \
         if (anyhit) launch_k<true, __VA_ARGS__>(nodes, tris, q, status, blocks, s);     \
@@ -260,14 +275,15 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     switch (variant) {
     case 52: TBVH_K(8, 16, 8, true); return;      // the coherent schedule: deferred triangles, triangle phase once 8 lanes wait
     case 72: TBVH_K(8, 16, 1, false); return;     // the strict schedule
-    case 75: TBVH_K(8, 16, 1, false, 0, 5, false, 16); return;   // strict + split rays whatever the batch size
-    case 88: if (q.probe) TBVH_K(6, 16, 8, true, 0, 5, true, 16); else TBVH_K(6, 16, 1, false, 0, 5, false, 16); return;   // the probed schedule + split rays whatever the batch size
-    case 59: launch_k<false, 8, 16, 1, false, 1>(nodes, tris, q, status, blocks, s); return;    // lane statistics of the strict schedule (q.stats)
-    case 61: launch_k<false, 8, 16, 8, true, 1>(nodes, tris, q, status, blocks, s); return;     // ... of the coherent schedule
-    case 73: launch_k<false, 8, 16, 1, false, 2>(nodes, tris, q, status, blocks, s); return;    // wave timeline of the strict schedule
-    case 78: launch_k<false, 8, 16, 1, false, 2, 5, false, 16>(nodes, tris, q, status, blocks, s); return;   // ... with split rays
-    case 82: launch_k<false, 8, 16, 1, false, 5>(nodes, tris, q, status, blocks, s); return;    // tail statistics, strict schedule
-    case 83: launch_k<false, 8, 16, 1, false, 5, 5, false, 16>(nodes, tris, q, status, blocks, s); return;   // ... with split rays
+    case 75: TBVH_K(8, 16, 1, false, 0, 5, 0, 16); return;   // strict + split rays whatever the batch size
+    case 88: if (blocks > blocks7) blocks = blocks7; if (q.probe) TBVH_K(6, 16, 8, true, 0, 5, 1, 16, 7); else TBVH_K(6, 16, 1, false, 0, 5, 0, 16, 7); return;   // the probed schedule + split rays whatever the batch size
+    case 89: if (q.probe) TBVH_K(6, 16, 8, true, 0, 5, 1, 16, 8); else break; return;   // round 2's shipped form of the probed schedule + split rays: 64 VGPRs, 20 bytes of scratch per lane
+    case 59: if (anyhit) break; launch_k<false, 8, 16, 1, false, 1>(nodes, tris, q, status, blocks, s); return;    // lane statistics of the strict schedule (q.stats)
+    case 61: if (anyhit) break; launch_k<false, 8, 16, 8, true, 1>(nodes, tris, q, status, blocks, s); return;     // ... of the coherent schedule
+    case 73: if (anyhit) break; launch_k<false, 8, 16, 1, false, 2>(nodes, tris, q, status, blocks, s); return;    // wave timeline of the strict schedule
+    case 78: if (anyhit) break; launch_k<false, 8, 16, 1, false, 2, 5, 0, 16>(nodes, tris, q, status, blocks, s); return;   // ... with split rays
+    case 82: if (anyhit) break; launch_k<false, 8, 16, 1, false, 5>(nodes, tris, q, status, blocks, s); return;    // tail statistics, strict schedule
+    case 83: if (anyhit) break; launch_k<false, 8, 16, 1, false, 5, 5, 0, 16>(nodes, tris, q, status, blocks, s); return;   // ... with split rays
     default: break;
     }
     // with a coherence probe of the batch (capi.hip: launchQuery) the schedule is chosen per launch; without one, the strict schedule.
@@ -275,25 +291,37 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     // lanes (ray_split.h): Bistro stand-in 0.26 / 1 / 4 / 8 M rays: camera +7 / +20 / +6 / +4 %, bounce +26 / +23 / +8 / +4 %, shadow
     // +20 / +18 / +6 / +4 %; at 16.7 M rays the tail is 5 % of the launch and the kernel's register cap costs as much as it gains
     const bool tail = split_rays_wanted(q);
-    // Stack entries in LDS next to the split groups: 6 let 32 waves per CU fit (what scenes under 48 MB and coherent probed batches are
-    // launched with; Bistro-size trees measure the same with 6 or 8), deep trees want 8 (30 M triangles: 6 costs 7 % on camera rays, 13 % on bounce rays)
+    // Stack entries in LDS next to the split groups: 6 let more than 24 waves per CU fit (what scenes under 48 MB and coherent probed batches are
+    // launched with; Bistro-size trees measure the same with 6 or 8), deep trees want 8 (30 M triangles: 6 costs 7 % on camera rays, 13 % on bounce rays).
+    // Those 6-entry kernels with split rays are built for 7 waves per SIMD (72 VGPRs) and launched 28 per CU: under the budget of 8 (64 VGPRs) they
+    // spill 12-24 bytes per lane inside the loop (round 2 shipped that: 4 M bounce rays 2420 -> 2810 MRays/s without the spill)
     if (nodeStride == 8) {   // one node per cache line (capi.hip: scenes whose node array is beyond the Infinity Cache; DESIGN.md §5: -17 % bytes, +6 % at 60 M triangles)
-        if (tail) TBVH_K(8, 16, 1, false, 0, 8, false, 16);
+        if (tail) TBVH_K(8, 16, 1, false, 0, 8, 0, 16);
         else TBVH_K(8, 16, 1, false, 0, 8);
-    } else if (nodeStride == kNodeHybrid) {   // priority-ordered nodes, the first q.hybridK packed, the others one per line (cwbvh_node.h)
-        if (q.probe) {
-            if (tail) TBVH_K(6, 16, 8, true, 0, kNodeHybrid, true, 16);
-            else TBVH_K(8, 16, 8, true, 0, kNodeHybrid, true);
-        } else if (tail) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, false, 16);
-        else TBVH_K(8, 16, 1, false, 0, kNodeHybrid);
+    } else if (nodeStride == kNodeHybrid) {   // the incoherent flavor of a probed launch: `nodes` = the hybrid copy, `tris` = the 64-byte records (cwbvh_node.h, capi.hip)
+        if (tail) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 16);
+        else TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2);
     } else if (q.probe) {
-        if (tail) TBVH_K(6, 16, 8, true, 0, 5, true, 16);
-        else TBVH_K(8, 16, 8, true, 0, 5, true);
+        if (tail) { if (blocks > blocks7) blocks = blocks7; TBVH_K(6, 16, 8, true, 0, 5, 1, 16, 7); }
+        else TBVH_K(8, 16, 8, true, 0, 5, 1);
     } else if (tail) {
-        if (shallow) TBVH_K(6, 16, 1, false, 0, 5, false, 16);
-        else TBVH_K(8, 16, 1, false, 0, 5, false, 16);
+        if (shallow) { if (blocks > blocks7) blocks = blocks7; TBVH_K(6, 16, 1, false, 0, 5, 0, 16, 7); }
+        else TBVH_K(8, 16, 1, false, 0, 5, 0, 16);
     } else TBVH_K(8, 16, 1, false);
 #undef TBVH_K
+}
+
+namespace {
+__global__ void k_pad_tris(const float4* __restrict__ src, float4* __restrict__ dst, uint64_t nTris) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per float4 of the padded array
+    if (i >= nTris * 4u) return;
+    const uint64_t t = i >> 2; const uint32_t k = (uint32_t)i & 3u;
+    dst[i] = k < 3u ? src[t * 3u + k] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+}  // namespace
+// 48-byte triangle records straddle a 128-byte line 3 times out of 8; at 64 bytes none does (+33 % triangle memory)
+void launch_cwbvh_pad_tris(const float4* src, float4* dst, uint64_t nTris, hipStream_t s) {
+    hipLaunchKernelGGL(k_pad_tris, dim3((uint32_t)((nTris * 4u + 255u) / 256u)), dim3(256), 0, s, src, dst, nTris);
 }
 
 // 80-byte nodes straddle 128-byte lines (1.6 lines per node on average); the padded copy costs 60 % more node memory
@@ -301,6 +329,6 @@ void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream
     hipLaunchKernelGGL(k_pad_nodes, dim3((nNodes * 8u + 255u) / 256u), dim3(256), 0, s, src, dst, nNodes);
 }
 
-bool cwbvh_variant_valid(int v) { return v == 0 || v == 52 || v == 72 || v == 75 || v == 88 || v == 59 || v == 61 || v == 73 || v == 78 || v == 82 || v == 83; }
+bool cwbvh_variant_valid(int v) { return v == 0 || v == 90 || v == 52 || v == 72 || v == 75 || v == 88 || v == 89 || v == 59 || v == 61 || v == 73 || v == 78 || v == 82 || v == 83; }
 
 }  // namespace tbvh

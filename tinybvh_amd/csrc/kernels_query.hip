@@ -136,9 +136,9 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
                 const float ry1 = __builtin_fmaf(n2.y, rD.y, -ro.y), ry2 = __builtin_fmaf(n3.y, rD.y, -ro.y);
                 const float rz1 = __builtin_fmaf(n2.z, rD.z, -ro.z), rz2 = __builtin_fmaf(n3.z, rD.z, -ro.z);
                 const float tminL = __builtin_fmaxf(fmax3(__builtin_fminf(lx1, lx2), __builtin_fminf(ly1, ly2), __builtin_fminf(lz1, lz2)), 0.0f);
-                const float tmaxL = __builtin_fminf(fmin3(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2), __builtin_fmaxf(lz1, lz2)), hit.x);
+                const float tmaxL = __builtin_fminf(fmin3(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2), __builtin_fmaxf(lz1, lz2)), cull_bound(hit.x));
                 const float tminR = __builtin_fmaxf(fmax3(__builtin_fminf(rx1, rx2), __builtin_fminf(ry1, ry2), __builtin_fminf(rz1, rz2)), 0.0f);
-                const float tmaxR = __builtin_fminf(fmin3(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2), __builtin_fmaxf(rz1, rz2)), hit.x);
+                const float tmaxR = __builtin_fminf(fmin3(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2), __builtin_fmaxf(rz1, rz2)), cull_bound(hit.x));
                 const bool hL = tmaxL >= tminL, hR = tmaxR >= tminR;
                 uint32_t l = as_u32(n0.w), r = as_u32(n1.w);
                 if (hL && hR) {
@@ -283,7 +283,7 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
                     const float y1 = __builtin_fmaf((float)((ny >> sh) & 255), sy, by), y2 = __builtin_fmaf((float)((fy >> sh) & 255), sy, by);
                     const float z1 = __builtin_fmaf((float)((nz >> sh) & 255), sz, bz), z2 = __builtin_fmaf((float)((fz >> sh) & 255), sz, bz);
                     const float tmin = __builtin_fmaxf(fmax3(x1, y1, z1), 0.0f);
-                    const float tmax = __builtin_fminf(fmin3(x2, y2, z2), hit.x);
+                    const float tmax = __builtin_fminf(fmin3(x2, y2, z2), cull_bound(hit.x));
                     dist[i] = (tmin > tmax || info[i] == 0) ? kFar : tmin;
                     continue;
                 }
@@ -291,7 +291,7 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
                 const float y1 = __builtin_fmaf((float)((qy0 >> sh) & 255), sy, by), y2 = __builtin_fmaf((float)((qy1 >> sh) & 255), sy, by);
                 const float z1 = __builtin_fmaf((float)((qz0 >> sh) & 255), sz, bz), z2 = __builtin_fmaf((float)((qz1 >> sh) & 255), sz, bz);
                 const float tmin = __builtin_fmaxf(fmax3(__builtin_fminf(x1, x2), __builtin_fminf(y1, y2), __builtin_fminf(z1, z2)), 0.0f);
-                const float tmax = __builtin_fminf(fmin3(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2), __builtin_fmaxf(z1, z2)), hit.x);
+                const float tmax = __builtin_fminf(fmin3(__builtin_fmaxf(x1, x2), __builtin_fmaxf(y1, y2), __builtin_fmaxf(z1, z2)), cull_bound(hit.x));
                 dist[i] = (tmin > tmax || info[i] == 0) ? kFar : tmin;
             }
             // 5-comparator network, descending (farthest first)

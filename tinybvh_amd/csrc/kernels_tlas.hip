@@ -141,7 +141,7 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
                         ng.y &= ~(1u << bit);
                         if (ng.y > 0x00FFFFFFu) st.push(ng);
                         const uint32_t slot = (bit - 24u) ^ oct;
-                        const CwNodeHits nh = cw_test_node(cw_load_node(bnodes, cbase + __popc(imask & ~(0xFFFFFFFFu << slot))), O, rD, hit.x, oct * 0x01010101u);
+                        const CwNodeHits nh = cw_test_node(cw_load_node(bnodes, cbase + __popc(imask & ~(0xFFFFFFFFu << slot))), O, rD, cull_bound(hit.x), oct * 0x01010101u);
                         ng.x = nh.childBase; tg.x = nh.triBase;
                         ng.y = (nh.hitmask & 0xFF000000u) | nh.imask;
                         tg.y = nh.hitmask & 0x00FFFFFFu;
@@ -193,7 +193,7 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
                         const float y1 = __builtin_fmaf((float)((ny >> sh) & 255), sy, by), y2 = __builtin_fmaf((float)((fy >> sh) & 255), sy, by);
                         const float z1 = __builtin_fmaf((float)((nz >> sh) & 255), sz, bz), z2 = __builtin_fmaf((float)((fz >> sh) & 255), sz, bz);
                         const float tmin = __builtin_fmaxf(fmax3(x1, y1, z1), 0.0f);
-                        const float tmax = __builtin_fminf(fmin3(x2, y2, z2), hit.x);
+                        const float tmax = __builtin_fminf(fmin3(x2, y2, z2), cull_bound(hit.x));
                         dist[i] = (tmin > tmax || info[i] == 0) ? kFar : tmin;
                     }
 #define TBVH_CSWAP(a, b) if (dist[a] < dist[b]) { const float tf = dist[a]; dist[a] = dist[b]; dist[b] = tf; const uint32_t tu = info[a]; info[a] = info[b]; info[b] = tu; }
@@ -244,9 +244,9 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
                         const float ry1 = __builtin_fmaf(n2.y, rD.y, -ro.y), ry2 = __builtin_fmaf(n3.y, rD.y, -ro.y);
                         const float rz1 = __builtin_fmaf(n2.z, rD.z, -ro.z), rz2 = __builtin_fmaf(n3.z, rD.z, -ro.z);
                         const float tminL = __builtin_fmaxf(fmax3(__builtin_fminf(lx1, lx2), __builtin_fminf(ly1, ly2), __builtin_fminf(lz1, lz2)), 0.0f);
-                        const float tmaxL = __builtin_fminf(fmin3(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2), __builtin_fmaxf(lz1, lz2)), hit.x);
+                        const float tmaxL = __builtin_fminf(fmin3(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2), __builtin_fmaxf(lz1, lz2)), cull_bound(hit.x));
                         const float tminR = __builtin_fmaxf(fmax3(__builtin_fminf(rx1, rx2), __builtin_fminf(ry1, ry2), __builtin_fminf(rz1, rz2)), 0.0f);
-                        const float tmaxR = __builtin_fminf(fmin3(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2), __builtin_fmaxf(rz1, rz2)), hit.x);
+                        const float tmaxR = __builtin_fminf(fmin3(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2), __builtin_fmaxf(rz1, rz2)), cull_bound(hit.x));
                         const bool hL = tmaxL >= tminL, hR = tmaxR >= tminR;
                         uint32_t l = as_u32(n0.w), r = as_u32(n1.w);
                         if (hL && hR) {
@@ -313,9 +313,9 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
                 const float ry1 = __builtin_fmaf(n2.y, rD.y, -ro.y), ry2 = __builtin_fmaf(n3.y, rD.y, -ro.y);
                 const float rz1 = __builtin_fmaf(n2.z, rD.z, -ro.z), rz2 = __builtin_fmaf(n3.z, rD.z, -ro.z);
                 const float tminL = __builtin_fmaxf(fmax3(__builtin_fminf(lx1, lx2), __builtin_fminf(ly1, ly2), __builtin_fminf(lz1, lz2)), 0.0f);
-                const float tmaxL = __builtin_fminf(fmin3(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2), __builtin_fmaxf(lz1, lz2)), hit.x);
+                const float tmaxL = __builtin_fminf(fmin3(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2), __builtin_fmaxf(lz1, lz2)), cull_bound(hit.x));
                 const float tminR = __builtin_fmaxf(fmax3(__builtin_fminf(rx1, rx2), __builtin_fminf(ry1, ry2), __builtin_fminf(rz1, rz2)), 0.0f);
-                const float tmaxR = __builtin_fminf(fmin3(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2), __builtin_fmaxf(rz1, rz2)), hit.x);
+                const float tmaxR = __builtin_fminf(fmin3(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2), __builtin_fmaxf(rz1, rz2)), cull_bound(hit.x));
                 const bool hL = tmaxL >= tminL, hR = tmaxR >= tminR;
                 uint32_t l = as_u32(n0.w), r = as_u32(n1.w);
                 if (hL && hR) {

@@ -200,7 +200,7 @@ __device__ __forceinline__ void tlas4_body(const float4* __restrict__ tlas4, con
                 const float y1 = __builtin_fmaf((float)((ny >> sh) & 255), sy, by), y2 = __builtin_fmaf((float)((fy >> sh) & 255), sy, by);
                 const float z1 = __builtin_fmaf((float)((nz >> sh) & 255), sz, bz), z2 = __builtin_fmaf((float)((fz >> sh) & 255), sz, bz);
                 const float tmin = __builtin_fmaxf(fmax3(x1, y1, z1), 0.0f);
-                const float tmax = __builtin_fminf(fmin3(x2, y2, z2), hit.x);
+                const float tmax = __builtin_fminf(fmin3(x2, y2, z2), cull_bound(hit.x));
                 dist[i] = (tmin > tmax || info[i] == 0) ? kFar : tmin;
             }
 #define TBVH_CSWAP(a, b) if (dist[a] < dist[b]) { const float tf = dist[a]; dist[a] = dist[b]; dist[b] = tf; const uint32_t tu = info[a]; info[a] = info[b]; info[b] = tu; }

@@ -166,9 +166,9 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
                 const float ry1 = __builtin_fmaf(n2.y, rD.y, -ro.y), ry2 = __builtin_fmaf(n3.y, rD.y, -ro.y);
                 const float rz1 = __builtin_fmaf(n2.z, rD.z, -ro.z), rz2 = __builtin_fmaf(n3.z, rD.z, -ro.z);
                 const float tminL = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(lx1, lx2), __builtin_fminf(ly1, ly2)), __builtin_fminf(lz1, lz2)), 0.0f);
-                const float tmaxL = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2)), __builtin_fmaxf(lz1, lz2)), hit.x);
+                const float tmaxL = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(lx1, lx2), __builtin_fmaxf(ly1, ly2)), __builtin_fmaxf(lz1, lz2)), cull_bound(hit.x));
                 const float tminR = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(rx1, rx2), __builtin_fminf(ry1, ry2)), __builtin_fminf(rz1, rz2)), 0.0f);
-                const float tmaxR = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2)), __builtin_fmaxf(rz1, rz2)), hit.x);
+                const float tmaxR = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(rx1, rx2), __builtin_fmaxf(ry1, ry2)), __builtin_fmaxf(rz1, rz2)), cull_bound(hit.x));
                 const bool hL = tmaxL >= tminL, hR = tmaxR >= tminR;
                 uint32_t l = as_u32(n0.w), r = as_u32(n1.w);
                 if (hL && hR) {
@@ -240,7 +240,7 @@ __device__ __forceinline__ void tlas8_body(const float4* __restrict__ tlasNodes,
             if (cw_has_child(ng)) {
                 const uint32_t ci = cw_next_child(ng, oct);
                 if (cw_has_child(ng)) st.push(ng);
-                const CwNodeHits r = cw_test_node(cw_load_node(cur, ci), O, rD, hit.x, oct * 0x01010101u);
+                const CwNodeHits r = cw_test_node(cw_load_node(cur, ci), O, rD, cull_bound(hit.x), oct * 0x01010101u);
                 ng = make_uint2(r.childBase, (r.hitmask & 0xFF000000u) | r.imask);
                 tg = make_uint2(r.triBase, r.hitmask & 0x00FFFFFFu);
             }

@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--hybrid", default="all,0,8192,32768,131072")
     ap.add_argument("--bins", default="4:0,5:0,5:1,5:2,6:0,6:1")
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--flags", default="", help="experiment flag sets to A/B on the default placement and on the best hybrid, e.g. 1,2,3")
+    ap.add_argument("--no-bins", action="store_true")
     a = ap.parse_args()
     verts, label = scenes.get(a.scene)
     ctx = tb.Context(0)
@@ -85,6 +87,19 @@ def main():
         same = all(np.array_equal(gp[f].view(np.uint32), ref_p[f].view(np.uint32)) and np.array_equal(gd[f].view(np.uint32), ref_d[f].view(np.uint32)) for f in ("t", "u", "v", "prim"))
         print(f"    records identical to the default's: {same}; occlusion flags identical: {bool(np.array_equal(occ, occ0))}; set_hybrid {dt * 1e3:.0f} ms; {sc.device_bytes / 1e6:.0f} MB", flush=True)
     sc.set_hybrid(-1)
+    for fl in [int(x) for x in a.flags.split(",") if x]:
+        ctx.set_debug_flags(fl)
+        measure(f"flags {fl}, uploaded array")
+        gp, gd = records(d_prim), records(d_diff)
+        same = all(np.array_equal(gp[f].view(np.uint32), ref_p[f].view(np.uint32)) and np.array_equal(gd[f].view(np.uint32), ref_d[f].view(np.uint32)) for f in ("t", "u", "v", "prim"))
+        sc.set_hybrid(8192)
+        measure(f"flags {fl}, hybrid 8192")
+        sc.set_hybrid(-1)
+        print(f"    records identical to the default's: {same}", flush=True)
+    ctx.set_debug_flags(0)
+    if a.no_bins:
+        ctx.close()
+        return
 
     # ---- ray order --------------------------------------------------------------------------------------------------------------
     d_sorted = ctx.malloc(n * 64)

@@ -88,11 +88,11 @@ def main():
             for L in own:
                 t1 = time.time()
                 if L == 5:
-                    sc = tb.BVH_GPU(ctx).Upload(rs.blob(4, 0, np.uint32, 16), rs.blob(4, 1, np.uint32, 1), verts)
+                    sc = tb.BVH_GPU(ctx).Upload(rs.blob(5, 0, np.uint32, 16), rs.blob(5, 1, np.uint32, 1), verts)
                 elif L == 8:
-                    sc = tb.BVH4_GPU(ctx).Upload(rs.blob(6, 0, np.uint32, 4))
+                    sc = tb.BVH4_GPU(ctx).Upload(rs.blob(8, 0, np.uint32, 4))
                 else:
-                    nodes, tris = rs.blob(9, 0, np.uint32, 4), rs.blob(9, 1, np.uint32, 4)
+                    nodes, tris = rs.blob(10, 0, np.uint32, 4), rs.blob(10, 1, np.uint32, 4)
                     sc = tb.BVH8_CWBVH(ctx).Upload(nodes, tris)
                 r = time_scene(ctx, sc, batches, n)
                 r.update(layout=L, tree=tag, mb=sc.device_bytes / 1e6, build_s=time.time() - t1)
