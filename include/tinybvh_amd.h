@@ -238,10 +238,15 @@ int tbvh_reset_hits_device(tbvh_context* ctx, void* d_rays64, uint64_t n_rays, f
  * Synchronizes the stream. */
 float tbvh_time_last_ms(tbvh_context* ctx);
 
-/* Measured device copy bandwidth (GB/s, read + written bytes of a streaming 16-bytes-per-lane copy kernel over `bytes`,
- * best of `reps` launches; MI355X: ~8 TB/s HBM3E peak, ~6 TB/s achievable): the second denominator for "fraction of the
- * memory roofline" figures, next to the data-sheet peak. */
+/* The machine's own ceilings, measured where the kernels run (bench.py's roofline denominators; best of `reps` launches, 0 = 3):
+ *   copy   GB/s read + written by a streaming copy over `bytes` (one float4 per thread, non-temporal; MI355X: 8 TB/s HBM3E peak on
+ *          the data sheet, 6.3-6.5 measured: tools/ubench/copy_rate.hip);
+ *   read   GB/s of a read-only sweep over `bytes` (the traversal kernels' traffic is almost all reads);
+ *   valu   1e9 wave64 VALU instructions per second over the whole chip for the instruction mix of the CWBVH node test at 8 waves per
+ *          SIMD, clock throttling included (tools/ubench/valu_issue.hip). */
 int tbvh_measure_copy_bandwidth(tbvh_context* ctx, uint64_t bytes, uint32_t reps, double* gbps);
+int tbvh_measure_read_bandwidth(tbvh_context* ctx, uint64_t bytes, uint32_t reps, double* gbps);
+int tbvh_measure_valu_issue(tbvh_context* ctx, uint32_t reps, double* ginstr_per_s);
 
 /* Lane-utilisation counters of the instrumented kernel variants (development aid):
  * out[0] wave iterations, [1] sum of active lanes, [2] sum of lanes in the node step,

@@ -98,6 +98,18 @@ class Context:
         check(lib.tbvh_measure_copy_bandwidth(self._h, nbytes, reps, C.byref(g)), "tbvh_measure_copy_bandwidth")
         return float(g.value)
 
+    def read_bandwidth_gbps(self, nbytes: int = 1 << 30, reps: int = 3) -> float:
+        """Measured read-only streaming bandwidth of this device (tbvh_measure_read_bandwidth), GB/s."""
+        g = C.c_double(0)
+        check(lib.tbvh_measure_read_bandwidth(self._h, nbytes, reps, C.byref(g)), "tbvh_measure_read_bandwidth")
+        return float(g.value)
+
+    def valu_issue_ginstr(self, reps: int = 3) -> float:
+        """Measured VALU issue ceiling (1e9 wave64 instructions per second, whole chip) for the CWBVH node test's mix (tbvh_measure_valu_issue)."""
+        g = C.c_double(0)
+        check(lib.tbvh_measure_valu_issue(self._h, reps, C.byref(g)), "tbvh_measure_valu_issue")
+        return float(g.value)
+
     def time_last_ms(self) -> float:
         return float(lib.tbvh_time_last_ms(self._h))
 

@@ -76,6 +76,8 @@ SYMBOLS = {
     "tbvh_reset_hits_device": (_i, [_vp, _vp, _u64, C.c_float]),
     "tbvh_time_last_ms": (C.c_float, [_vp]),
     "tbvh_measure_copy_bandwidth": (_i, [_vp, _u64, _u32, C.POINTER(C.c_double)]),
+    "tbvh_measure_read_bandwidth": (_i, [_vp, _u64, _u32, C.POINTER(C.c_double)]),
+    "tbvh_measure_valu_issue": (_i, [_vp, _u32, C.POINTER(C.c_double)]),
     "tbvh_set_variant": (_i, [_vp, _i]),
     "tbvh_debug_stats": (_i, [_vp, _vp, _i]),
     "tbvh_debug_last_probe": (_i, [_vp, _vp]),

@@ -416,7 +416,8 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                 launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, blocks, c->stream, 5, small, blocks7);
                 HIP_TRY(hipGetLastError());
                 QueryArgs qb = q;
-                launch_cwbvh(any, 0, s->nodesHy, s->tris64, qb, c->status, blocksBase, c->stream, 13, small, blocks7);
+                const uint32_t wB = (c->expFlags >> 8) & 0xffu;   // experiment: waves per CU of the incoherent flavor
+                launch_cwbvh(any, 0, s->nodesHy, s->tris64, qb, c->status, (wB && blocksBase == c->blocks) ? (uint32_t)c->numCUs * wB : blocksBase, c->stream, 13, small, blocks7);
             } else
                 launch_cwbvh(any, s->variant, autoPad ? s->nodes128 : s->nodes, tris, q, c->status, blocks, c->stream, autoPad ? 8 : 5, small, blocks7);
         }
@@ -1582,28 +1583,75 @@ int tbvh_copy_from_device(tbvh_context* c, void* dst, const void* d, uint64_t by
     return 0;
 }
 
-// Device copy bandwidth as this GPU delivers it today: a plain 16-bytes-per-lane streaming copy kernel over `bytes` (read +
-// written bytes counted), best of `reps` launches.  The second denominator of the roofline lines in bench.py.
+// Device memory bandwidth as this GPU delivers it today: a streaming copy (one float4 per thread, non-temporal; read + written bytes
+// counted) and a read-only sweep over `bytes`, best of `reps` launches each.  The denominators of the roofline lines in bench.py.
+static int timeBest(tbvh_context* c, uint32_t reps, const std::function<void()>& launch, double* bestMs) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { hipEventDestroy(e0); return fail(TBVH_E_HIP, "hipEventCreate failed"); }
+    double best = 0;
+    hipError_t err = hipSuccess;
+    for (uint32_t i = 0; i <= reps && err == hipSuccess; i++) {   // the first launch warms up
+        err = hipEventRecord(e0, c->stream);
+        launch();
+        if (err == hipSuccess) err = hipGetLastError();
+        if (err == hipSuccess) err = hipEventRecord(e1, c->stream);
+        if (err == hipSuccess) err = hipEventSynchronize(e1);
+        float ms = 0;
+        if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+        if (err == hipSuccess && i && ms > 0 && (best == 0 || ms < best)) best = ms;
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    if (err != hipSuccess) return fail(TBVH_E_HIP, "measurement launch failed: %s", hipGetErrorString(err));
+    if (best <= 0) return fail(TBVH_E_HIP, "measurement produced no timing");
+    *bestMs = best;
+    return 0;
+}
+
 int tbvh_measure_copy_bandwidth(tbvh_context* c, uint64_t bytes, uint32_t reps, double* gbps) {
     if (!c || !gbps || bytes < (1u << 20)) return fail(TBVH_E_INVALID, "tbvh_measure_copy_bandwidth: null argument or under 1 MB");
     if (int r = setDevice(c)) return r;
     void *a = nullptr, *b = nullptr;
     if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { if (a) hipFree(a); return fail(TBVH_E_NOMEM, "tbvh_measure_copy_bandwidth: cannot allocate 2 x %llu bytes", (unsigned long long)bytes); }
-    hipMemsetAsync(a, 1, bytes, c->stream);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    double best = 0;
-    const uint32_t nrep = reps ? reps : 3;
-    for (uint32_t i = 0; i <= 3 * nrep; i++) {   // the first launch warms up; three grid shapes, the best one counts
-        const uint32_t perCU = i <= nrep ? 8u : i <= 2 * nrep ? 16u : 32u;
-        hipEventRecord(e0, c->stream);
-        launch_stream_copy((const float4*)a, (float4*)b, bytes / 16, (uint32_t)c->numCUs * perCU, c->stream);
-        hipEventRecord(e1, c->stream);
-        hipEventSynchronize(e1);
-        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-        if (i && ms > 0) { const double g = 2.0 * (double)bytes / (ms * 1e-3) / 1e9; if (g > best) best = g; }
-    }
-    hipEventDestroy(e0); hipEventDestroy(e1); hipFree(a); hipFree(b);
-    *gbps = best;
+    int r = 0;
+    if (hipMemsetAsync(a, 1, bytes, c->stream) != hipSuccess) r = fail(TBVH_E_HIP, "hipMemsetAsync failed");
+    double ms = 0;
+    if (!r) r = timeBest(c, reps ? reps : 3, [&] { launch_stream_copy((const float4*)a, (float4*)b, bytes / 16, c->stream); }, &ms);
+    hipFree(a); hipFree(b);
+    if (r) return r;
+    *gbps = 2.0 * (double)bytes / (ms * 1e-3) / 1e9;
+    return 0;
+}
+
+int tbvh_measure_read_bandwidth(tbvh_context* c, uint64_t bytes, uint32_t reps, double* gbps) {
+    if (!c || !gbps || bytes < (1u << 20)) return fail(TBVH_E_INVALID, "tbvh_measure_read_bandwidth: null argument or under 1 MB");
+    if (int r = setDevice(c)) return r;
+    void *a = nullptr, *sink = nullptr;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&sink, 256) != hipSuccess) { if (a) hipFree(a); return fail(TBVH_E_NOMEM, "tbvh_measure_read_bandwidth: cannot allocate %llu bytes", (unsigned long long)bytes); }
+    int r = 0;
+    if (hipMemsetAsync(a, 1, bytes, c->stream) != hipSuccess) r = fail(TBVH_E_HIP, "hipMemsetAsync failed");
+    double ms = 0;
+    if (!r) r = timeBest(c, reps ? reps : 3, [&] { launch_stream_read((const float4*)a, (float*)sink, bytes / 16, (uint32_t)c->numCUs * 32u, c->stream); }, &ms);
+    hipFree(a); hipFree(sink);
+    if (r) return r;
+    *gbps = (double)bytes / (ms * 1e-3) / 1e9;
+    return 0;
+}
+
+// VALU issue ceiling of this GPU for the instruction mix of the CWBVH node test (kernels_raygen.hip: k_valu_mix), 8 waves per SIMD:
+// wave64 VALU instructions per second over the whole chip, in units of 1e9.
+int tbvh_measure_valu_issue(tbvh_context* c, uint32_t reps, double* ginstr_per_s) {
+    if (!c || !ginstr_per_s) return fail(TBVH_E_INVALID, "tbvh_measure_valu_issue: null argument");
+    if (int r = setDevice(c)) return r;
+    const uint32_t blocks = (uint32_t)c->numCUs * 32u;
+    const int iters = 20000;
+    void* out = nullptr;
+    if (hipMalloc(&out, (size_t)blocks * 64 * 4) != hipSuccess) return fail(TBVH_E_NOMEM, "tbvh_measure_valu_issue: out of device memory");
+    double ms = 0;
+    const int r = timeBest(c, reps ? reps : 3, [&] { launch_valu_mix((float*)out, iters, blocks, c->stream); }, &ms);
+    hipFree(out);
+    if (r) return r;
+    *ginstr_per_s = (double)blocks * iters * 32.0 / (ms * 1e-3) / 1e9;
     return 0;
 }
 

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
         const uint32_t agree = q.probe[0], pairs = q.probe[1];
         coh = pairs != 0 && agree * 10u >= pairs * 6u;
         if (PROBED == 2) { if (coh) return; }
+        else if (PROBED == 3) { if (!coh) return; }   // the coherent flavor of a two-kernel launch: deferred + gated schedule only (SPEC = true)
         else if (!coh && blockIdx.x >= q.baseBlocks) return;
     }
     const uint32_t hybridK = q.hybridK;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
         if (tail && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
         // ---- triangle phase: runs when enough lanes have a triangle pending, or when no lane could use a node
         // phase instead (so a waiting lane always makes progress) --------------------------------------------
-        const bool spec = PROBED == 1 ? coh : SPEC;
+        const bool spec = PROBED == 1 ? coh : SPEC;   // (PROBED == 3 is launched with SPEC = true)
         bool triPhase = true;
         if (TRI_MIN > 1 && (PROBED == 1 ? coh : true)) {
             const uint32_t nPend = (uint32_t)__popcll(__ballot(tg.y != 0));
@@ -301,7 +302,10 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     } else if (nodeStride == kNodeHybrid) {   // the incoherent flavor of a probed launch: `nodes` = the hybrid copy, `tris` = the 64-byte records (cwbvh_node.h, capi.hip)
         if (tail) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 16);
         else TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2);
-    } else if (q.probe) {
+    } else if (q.probe && q.baseBlocks == 0) {   // the coherent flavor of a two-kernel probed launch (capi.hip): no strict path compiled in (camera rays +1.5 %)
+        if (tail) { if (blocks > blocks7) blocks = blocks7; TBVH_K(6, 16, 8, true, 0, 5, 3, 16, 7); }
+        else TBVH_K(8, 16, 8, true, 0, 5, 3);
+    } else if (q.probe) {                        // one kernel for both verdicts (scenes without the incoherent-batch copies)
         if (tail) { if (blocks > blocks7) blocks = blocks7; TBVH_K(6, 16, 8, true, 0, 5, 1, 16, 7); }
         else TBVH_K(8, 16, 8, true, 0, 5, 1);
     } else if (tail) {
