@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic from profiles/)")
     ap.add_argument("--no-strong", action="store_true", help="skip the 64 M-ray strong-scaling batch of config 4")
     ap.add_argument("--no-configs", action="store_true", help="skip detail.config1 / config2 / reference_blob")
+    ap.add_argument("--one-process-devices", type=int, default=0, help="also trace config 4's 64 M-ray batch from THIS process over K contexts (device i mod the visible devices) through tbvh_intersect_sharded_device")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
@@ -202,13 +203,15 @@ def main():
                 ctx.generate_bounce(d_verts, d_b + t3 * 64, d_b + t3 * 64, m4 - t3, 4002)
                 sc.intersect_device(d_b + 2 * t3 * 64, m4 - 2 * t3)
                 ctx.generate_bounce(d_verts, d_b + 2 * t3 * 64, d_b + 2 * t3 * 64, m4 - 2 * t3, 4003)
-                sc.intersect_device_fresh(d_b, m4, 1e30)      # warm-up
+                tb.intersect_sharded_device([sc], [d_b], [m4], fresh=True, tmax=1e30)      # warm-up
             sync_all()
             t0 = time.perf_counter()
             reps4 = 3
+            km4, dm4 = [], []
             for _ in range(reps4):
-                if m4:
-                    sc.intersect_device_fresh(d_b, m4, 1e30)
+                if m4:   # through the C ABI's device-resident multi-device entry point (this process owns one device: a 1-device call)
+                    km, dm = tb.intersect_sharded_device([sc], [d_b], [m4], fresh=True, tmax=1e30)
+                    km4.append(km[0]); dm4.append(dm[0])
             sync_all()
             el4 = time.perf_counter() - t0
             if use_dist:
@@ -218,10 +221,20 @@ def main():
                 el4 = float(t.item())
             strong = {"workload": f"one {n4}-ray diffuse batch (depth 1-3), {world} contiguous wave-aligned shard(s), BVH replicated, no collective",
                       "rays": n4, "ms_per_batch": el4 / reps4 * 1e3, "mrays": n4 / (el4 / reps4) / 1e6, "scaling": "strong",
-                      "rank0_shard": [b4, e4]}
+                      "rank0_shard": [b4, e4], "entry_point": "tbvh_intersect_sharded_device (one device per process)",
+                      "rank0_kernel_ms": float(np.mean(km4)) if km4 else None, "rank0_host_dispatch_ms": float(np.mean(dm4)) if dm4 else None}
             ctx.free(d_a); ctx.free(d_b)
         except Exception as e:
             log(f"[bench] config 4 strong-scaling batch failed: {e!r}")
+    # the same batch from ONE process over K devices through the C ABI (tbvh_intersect_sharded_device): K = --one-process-devices, or every
+    # visible device when this is a single-process run that sees more than one
+    one_proc = None
+    kdev = a.one_process_devices if a.one_process_devices else (tb.device_count() if (world == 1 and tb.device_count() > 1 and a.gpus > 1) else 0)
+    if rank == 0 and world == 1 and kdev >= 2 and not a.no_strong:
+        try:
+            one_proc = strong_one_process(tb, R, sc, verts, eye, view, 8192 if a.side >= 4096 else 2 * a.side, kdev, log)
+        except Exception as e:
+            log(f"[bench] one-process multi-device batch failed: {e!r}")
 
     # whole wavefront path-traced frames (Generate, {Extend, Shade} x 3, Connect; all queues on the
     # device) — config 4's pipeline end to end, reported in `detail` (outside the timed steps)
@@ -343,6 +356,8 @@ def main():
         detail["device_side_ops"] = dev_ops
         detail["tlas_1000_instances"] = tlas_detail
         detail["config4_strong"] = strong
+        if one_proc:
+            detail["config4_strong_one_process"] = one_proc
         if cfg12:
             detail["config1"] = cfg12.get("config1")
             detail["config2"] = cfg12.get("config2")
@@ -490,6 +505,50 @@ def main():
     if rank == 0 and not parity.get("ok", False) and "error" not in parity:
         log(f"[bench] PARITY MISMATCH on the timed kernels: {parity}")
         sys.exit(3)
+
+
+def strong_one_process(tb, R, sc0, verts, eye, view, side4, k, log):
+    """Config 4's batch (side4 x side4 camera rays, bounced to depths 1-3 in thirds) from ONE process over k contexts — context i on device
+    i mod (visible devices) — through tbvh_intersect_sharded_device: the BVH uploaded once per context, every shard generated, traced and kept
+    on its device, one host thread enqueueing all launches.  Reports the batch rate, per-device kernel ms and the host dispatch gap."""
+    from tinybvh_amd.sharding import shard_range
+    n_dev = tb.device_count()
+    n4 = side4 * side4
+    cam4 = R.camera(eye, view, side4, side4, 1, 1)
+    ctxs = [tb.Context(i % n_dev) for i in range(k)]
+    try:
+        h = sc0.host
+        reps = [tb.BVH8_CWBVH(c).Upload(h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4)) for c in ctxs]
+        d_rays, counts = [], []
+        for i, (c, r) in enumerate(zip(ctxs, reps)):
+            b, e = shard_range(n4, i, k)
+            m = e - b
+            dv = c.malloc(verts.nbytes); c.to_device(dv, verts)
+            d_a, d_b = c.malloc(max(m, 1) * 64), c.malloc(max(m, 1) * 64)
+            c.generate_primary(cam4, d_a, b, m)
+            r.intersect_device(d_a, m)
+            t3 = m // 3
+            c.generate_bounce(dv, d_a, d_b, m, 4001)
+            r.intersect_device(d_b + t3 * 64, m - t3)
+            c.generate_bounce(dv, d_b + t3 * 64, d_b + t3 * 64, m - t3, 4002)
+            r.intersect_device(d_b + 2 * t3 * 64, m - 2 * t3)
+            c.generate_bounce(dv, d_b + 2 * t3 * 64, d_b + 2 * t3 * 64, m - 2 * t3, 4003)
+            c.synchronize()
+            c.free(d_a); c.free(dv)
+            d_rays.append(d_b); counts.append(m)
+        tb.intersect_sharded_device(reps, d_rays, counts, fresh=True)     # warm-up
+        wall, kms, dms = [], [], []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            km, dm = tb.intersect_sharded_device(reps, d_rays, counts, fresh=True)
+            wall.append(time.perf_counter() - t0); kms.append(km); dms.append(dm)
+        w = float(np.mean(wall))
+        return {"workload": f"one {n4}-ray diffuse batch (depth 1-3) from ONE process over {k} contexts on {min(k, n_dev)} device(s), BVH replicated, no collective",
+                "entry_point": "tbvh_intersect_sharded_device", "contexts": k, "devices": min(k, n_dev), "rays": n4, "ms_per_batch": w * 1e3, "mrays": n4 / w / 1e6,
+                "kernel_ms_per_device": [float(x) for x in np.mean(np.array(kms), 0)], "host_dispatch_ms_per_device": [float(x) for x in np.mean(np.array(dms), 0)]}
+    finally:
+        for c in ctxs:
+            c.close()
 
 
 def configs_1_and_2(tb, ctx, R, scenes):

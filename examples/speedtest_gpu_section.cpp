@@ -16,7 +16,7 @@
 #include <fstream>
 #include <vector>
 
-#include "tinybvh_amd.h"
+#include "tiny_hip.h"   // the binding a tinybvh maintainer adds (include/tiny_hip.h over the C ABI of tinybvh_amd.h)
 
 using namespace tinybvh;
 
@@ -78,40 +78,42 @@ int main(int argc, char** argv) {
     memcpy((void*)ref, (void*)rays, N * sizeof(Ray));
     for (unsigned i = 0; i < N; i++) refbvh.Intersect(ref[i]);
 
-    tbvh_context* ctx = nullptr;
-    CHECK(tbvh_init(0, &ctx));
+    tbvh_context* ctx = tinyhip::Context(0);   // the binding's context of device 0 (the blocks below that use the C ABI directly share it)
     int bad = 0;
     Ray* work = (Ray*)malloc64(N * sizeof(Ray));
     printf("%u triangles, %u rays, layouts built by tiny_bvh.h %d.%d.%d BuildHQ, traced by the HIP engine:\n", triCount, N, TINY_BVH_VERSION_MAJOR, TINY_BVH_VERSION_MINOR, TINY_BVH_VERSION_SUB);
+    // the three GPU blocks of the speedtest through tinyhip::Scene (tiny_hip.h): what was two or three tinyocl::Buffers + CopyToDevice + SetArguments +
+    // Run + clWaitForEvents + CopyFromDevice per layout is a constructor and a call
     {   // BVH_GPU (:1098-1141)
         BVH_GPU bvh; bvh.BuildHQ(tris.data(), triCount);
-        tbvh_scene* s = nullptr;
-        CHECK(tbvh_upload_bvh_gpu(ctx, bvh.bvhNode, bvh.usedNodes, bvh.bvh.primIdx, bvh.bvh.idxCount, tris.data(), triCount, &s));
+        tinyhip::Scene gpu(bvh, tris.data());
         memcpy((void*)work, (void*)rays, N * sizeof(Ray));
-        CHECK(tbvh_intersect(s, work, N, sizeof(Ray)));
-        printf("  BVH_GPU      %.1f MRays/s (kernel %.3f ms)\n", N / (tbvh_time_last_ms(ctx) * 1e3), tbvh_time_last_ms(ctx));
+        gpu.Intersect(work, N);
+        printf("  BVH_GPU      %.1f MRays/s (kernel %.3f ms)\n", N / (gpu.LastKernelMs() * 1e3), gpu.LastKernelMs());
         bad += validate("BVH_GPU", work, ref, N);
-        tbvh_free_scene(s);
     }
     {   // BVH4_GPU (:1149-1188)
         BVH4_GPU bvh; bvh.BuildHQ(tris.data(), triCount);
-        tbvh_scene* s = nullptr;
-        CHECK(tbvh_upload_bvh4_gpu(ctx, bvh.bvh4Data, bvh.usedBlocks, &s));
+        tinyhip::Scene gpu(bvh);
         memcpy((void*)work, (void*)rays, N * sizeof(Ray));
-        CHECK(tbvh_intersect(s, work, N, sizeof(Ray)));
-        printf("  BVH4_GPU     %.1f MRays/s (kernel %.3f ms)\n", N / (tbvh_time_last_ms(ctx) * 1e3), tbvh_time_last_ms(ctx));
+        gpu.Intersect(work, N);
+        printf("  BVH4_GPU     %.1f MRays/s (kernel %.3f ms)\n", N / (gpu.LastKernelMs() * 1e3), gpu.LastKernelMs());
         bad += validate("BVH4_GPU", work, ref, N);
-        tbvh_free_scene(s);
     }
     {   // BVH8_CWBVH (:1196-1241)
         BVH8_CWBVH bvh; bvh.BuildHQ(tris.data(), triCount);
-        tbvh_scene* s = nullptr;
-        CHECK(tbvh_upload_cwbvh(ctx, bvh.bvh8Data, bvh.usedBlocks, bvh.bvh8Tris, (uint64_t)bvh.bvh8.idxCount * 3, &s));
+        tinyhip::Scene gpu(bvh);
         memcpy((void*)work, (void*)rays, N * sizeof(Ray));
-        CHECK(tbvh_intersect(s, work, N, sizeof(Ray)));
-        printf("  BVH8_CWBVH   %.1f MRays/s (kernel %.3f ms)\n", N / (tbvh_time_last_ms(ctx) * 1e3), tbvh_time_last_ms(ctx));
+        gpu.Intersect(work, N);
+        printf("  BVH8_CWBVH   %.1f MRays/s (kernel %.3f ms)\n", N / (gpu.LastKernelMs() * 1e3), gpu.LastKernelMs());
         bad += validate("BVH8_CWBVH", work, ref, N);
-        tbvh_free_scene(s);
+        // any-hit through the binding: a ray is occluded iff BVH::IsOccluded says so
+        std::vector<uint8_t> occ(N);
+        gpu.IsOccluded(rays, N, occ.data());
+        unsigned occBad = 0;
+        for (unsigned i = 0; i < N; i++) occBad += (occ[i] != 0) != refbvh.IsOccluded(rays[i]);
+        printf("  %-12s IsOccluded mismatches %u\n", "BVH8_CWBVH", occBad);
+        bad += occBad > 2;
     }
     // ---- beyond the speedtest: the per-frame / build-time host work of a tinybvh user, moved to the GPU -------------
     {   // BVH8_CWBVH::ConvertFrom on the device: tinybvh builds the BVH2 (Build + Compact + SplitLeafs(3), what
@@ -194,7 +196,7 @@ int main(int argc, char** argv) {
         free64(ref3);
         tbvh_free_scene(ts); tbvh_free_scene(bs);
     }
-    tbvh_shutdown(ctx);
+    tbvh_shutdown(ctx);   // (every tinyhip::Scene above is out of scope)
     printf(bad ? "VALIDATION FAILED\n" : "all layouts agree with BVH::Intersect\n");
     return bad ? 1 : 0;
 }

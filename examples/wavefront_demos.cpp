@@ -22,7 +22,7 @@
 #include <cstring>
 #include <vector>
 
-#include "tinybvh_amd.h"
+#include "tiny_hip.h"   // tinyhip::Scene / tinyhip::PathTracer (include/tiny_hip.h) over the C ABI of tinybvh_amd.h
 
 using namespace tinybvh;
 
@@ -134,6 +134,65 @@ int main() {
         bvh.bvh8.bvh.Intersect(r);                        // the demo's mouse-pick ray (:163-165)
         CHECK(tbvh_intersect(scene, &viaEngine, 1, sizeof(Ray)));
         if (r.hit.prim != viaEngine.hit.prim || r.hit.t != viaEngine.hit.t) { printf("  part 1: pick ray differs: t %f prim %u vs t %f prim %u\n", r.hit.t, r.hit.prim, viaEngine.hit.t, viaEngine.hit.prim); bad++; }
+        // ---- part 1b: the same frame loop over SEVERAL devices (the reference has one process-global OpenCL device, tiny_ocl.h:362-364) ----
+        // tinyhip::PathTracer cuts the image into bands of rows, one per device — every device of the box, and at least two contexts (on a
+        // 1-GPU box both bands live on device 0: the band arithmetic, the per-band queues and the gather run as they do on 8 GPUs) —, each band
+        // generated, traced, shaded and accumulated where it lives.  The bands draw the random numbers the full frame draws for their pixels:
+        // the gathered image must be the single-device image up to the order of the float accumulations.
+        {
+            const int nDev = tinyhip::DeviceCount();
+            const int nBands = nDev > 2 ? nDev : 2;
+            std::vector<tbvh_context*> bandCtx(nBands, nullptr);
+            std::vector<tbvh_scene*> bandScene(nBands, nullptr);
+            std::vector<tbvh_wavefront*> bandWf(nBands, nullptr);
+            std::vector<void*> bandVerts(nBands, nullptr);
+            uint32_t row = 0;
+            for (int i = 0; i < nBands; i++) {
+                CHECK(tbvh_init(i % nDev, &bandCtx[i]));                 // a context of its own per band (device i, or device 0 again)
+                CHECK(tbvh_upload_cwbvh(bandCtx[i], bvh.bvh8Data, bvh.usedBlocks, bvh.bvh8Tris, (uint64_t)bvh.bvh8.idxCount * 3, &bandScene[i]));
+                const uint32_t next = (uint32_t)((uint64_t)(H / 4) * (i + 1) / nBands) * 4;
+                CHECK(tbvh_wavefront_create(bandCtx[i], W, next - row, &bandWf[i]));
+                CHECK(tbvh_wavefront_set_band(bandWf[i], row, H));
+                CHECK(tbvh_device_malloc(bandCtx[i], (uint64_t)triCount * 48, &bandVerts[i]));
+                CHECK(tbvh_copy_to_device(bandCtx[i], bandVerts[i], tris.data(), (uint64_t)triCount * 48));
+                row = next;
+            }
+            std::vector<float> banded((size_t)W * H * 4), dispatch(nBands);
+            std::vector<tbvh_wf_stats> bst(nBands);
+            float slowest = 0;
+            for (unsigned f = 0; f < frames; f++) {
+                const tbvh_wf_params p = demoParams(f);
+                CHECK(tbvh_wavefront_render_sharded(bandWf.data(), bandScene.data(), (const void* const*)bandVerts.data(), (uint32_t)nBands, &cam, &p, bst.data(), dispatch.data()));
+                slowest = 0;
+                for (auto& st : bst) slowest = st.frame_ms > slowest ? st.frame_ms : slowest;
+            }
+            CHECK(tbvh_wavefront_read_sharded(bandWf.data(), (uint32_t)nBands, banded.data()));
+            double diff = 0, ref = 0;
+            for (size_t i = 0; i < img.size(); i++) { diff += fabs((double)banded[i] - (double)img[i]); ref += fabs((double)img[i]); }
+            float gap = 0;
+            for (float d : dispatch) gap += d;
+            printf("  the same %u frames over %d context(s) on %d device(s), %d bands of rows: slowest band %.3f ms per frame, host dispatch %.3f ms per frame; "
+                   "relative difference of the gathered image from the single-device one %.2e\n", frames, nBands, nDev, nBands, slowest, gap, diff / ref);
+            if (!(diff <= 1e-5 * ref)) { printf("  part 1b: the banded image differs\n"); bad++; }
+            for (int i = 0; i < nBands; i++) { tbvh_wavefront_destroy(bandWf[i]); tbvh_device_free(bandCtx[i], bandVerts[i]); tbvh_free_scene(bandScene[i]); tbvh_shutdown(bandCtx[i]); }
+        }
+        // ... and through the binding (include/tiny_hip.h): one tinyhip::Scene per device of the box, tinyhip::PathTracer over them
+        {
+            const int nDev = tinyhip::DeviceCount();
+            std::vector<tinyhip::Scene*> perDevice;
+            for (int d = 0; d < nDev; d++) perDevice.push_back(new tinyhip::Scene(bvh, d));
+            {
+                tinyhip::PathTracer pt(perDevice, tris.data(), tris.size(), W, H);
+                for (unsigned f = 0; f < frames; f++) pt.Render(cam, demoParams(f));
+                std::vector<float> viaBinding((size_t)W * H * 4);
+                pt.Read(viaBinding.data());
+                double diff = 0, ref = 0;
+                for (size_t i = 0; i < img.size(); i++) { diff += fabs((double)viaBinding[i] - (double)img[i]); ref += fabs((double)img[i]); }
+                printf("  tinyhip::PathTracer over the box's %d device(s), %u band(s): relative difference %.2e\n", nDev, pt.Bands(), diff / ref);
+                if (!(diff <= 1e-5 * ref)) { printf("  part 1b: the image rendered through tiny_hip.h differs\n"); bad++; }
+            }
+            for (auto* sPtr : perDevice) delete sPtr;
+        }
         tbvh_device_free(ctx, dVerts);
         tbvh_free_scene(scene);
     }

@@ -226,6 +226,16 @@ int tbvh_intersect_device_fresh(tbvh_scene* scene, void* d_rays64, uint64_t n_ra
 int tbvh_intersect_sharded(tbvh_scene* const* scenes, uint32_t n_devices, void* rays, uint64_t n_rays, uint32_t stride_bytes);
 int tbvh_occluded_sharded(tbvh_scene* const* scenes, uint32_t n_devices, const void* rays, uint64_t n_rays,
                           uint32_t stride_bytes, uint8_t* occluded);
+/* The same with DEVICE-RESIDENT rays — nothing crosses the host: d_rays64[i] / n_rays[i] is the batch resident on the device of
+ * scenes[i] (produced there: a wavefront path tracer per device, or a kernel of the caller's; tbvh_shard_range cuts a global batch).
+ * One host thread enqueues every device's launch (each is asynchronous on its context's stream), then waits for all; records are
+ * written in place as by tbvh_intersect_device (fresh != 0: as by tbvh_intersect_device_fresh with tmax), flags as by
+ * tbvh_occluded_device.  kernel_ms[i] (optional) = device time of device i's launch, dispatch_ms[i] (optional) = host time spent
+ * enqueueing it — the per-device dispatch gap of SURVEY.md par. 8(e). */
+int tbvh_intersect_sharded_device(tbvh_scene* const* scenes, uint32_t n_devices, void* const* d_rays64, const uint64_t* n_rays,
+                                  int fresh, float tmax, float* kernel_ms, float* dispatch_ms);
+int tbvh_occluded_sharded_device(tbvh_scene* const* scenes, uint32_t n_devices, const void* const* d_rays64, const uint64_t* n_rays,
+                                 uint8_t* const* d_occluded, float* kernel_ms, float* dispatch_ms);
 /* shard `rank` of `world` covers rays [*begin, *end) */
 void tbvh_shard_range(uint64_t n_rays, uint32_t rank, uint32_t world, uint64_t* begin, uint64_t* end);
 
@@ -361,6 +371,20 @@ void tbvh_wavefront_destroy(tbvh_wavefront* wf);
  * asynchronous); when given, the call synchronizes and fills it. */
 int  tbvh_wavefront_render(tbvh_wavefront* wf, tbvh_scene* scene, const void* d_verts16, const tbvh_camera* cam,
                            const tbvh_wf_params* params, tbvh_wf_stats* stats);
+/* Several devices, one image (BASELINE config 4: "wavefront path tracer, 3 bounces, ray batch sharded across 8 x MI355X"; the frame loop
+ * of tiny_bvh_gpu.cpp:128-158 with the reference's single device, tiny_ocl.h:362-364, lifted): a wavefront object can stand for a BAND
+ * of rows of a larger image — created with the band's height, then told where the band lies; it is then rendered with the FULL image's
+ * camera and draws exactly the random numbers the full image's frame would draw for its pixels.  tbvh_wavefront_render_sharded renders
+ * one frame with band i on the device of wfs[i] / scenes[i] (the scene uploaded once per device; d_verts16[i] that device's vertex
+ * array, or NULL for TLAS scenes): the frames are enqueued one after the other by the calling thread and run concurrently, rays are
+ * generated, traced, shaded and accumulated on their device, nothing is exchanged.  stats[i] / dispatch_ms[i] (optional, n_devices
+ * entries): per-band ray counts and device time, host time spent enqueueing band i.  tbvh_wavefront_read_sharded gathers the bands'
+ * accumulators into one width x full_height x 4 float image.  The bands must tile the image in order; first_row and the heights are
+ * multiples of 4. */
+int  tbvh_wavefront_set_band(tbvh_wavefront* wf, uint32_t first_row, uint32_t full_height);   /* full_height 0: the whole image again */
+int  tbvh_wavefront_render_sharded(tbvh_wavefront* const* wfs, tbvh_scene* const* scenes, const void* const* d_verts16, uint32_t n_devices,
+                                   const tbvh_camera* cam, const tbvh_wf_params* params, tbvh_wf_stats* stats, float* dispatch_ms);
+int  tbvh_wavefront_read_sharded(tbvh_wavefront* const* wfs, uint32_t n_devices, float* rgba);
 /* TLAS scenes (the path tracer of tiny_bvh_gpu2.cpp / wavefront2.cl): one device vertex array per BLAS, in blasIdx order
  * (wavefront2.cl:183 picks bistroVerts / dragonVerts by instance); tbvh_wavefront_render then takes the TLAS scene and
  * ignores d_verts16.  Normals go to world space through the instance's inverse transform. */

@@ -423,6 +423,56 @@ def occluded_sharded(replicas: list, rays: np.ndarray) -> np.ndarray:
     return occ
 
 
+def intersect_sharded_device(replicas: list, d_rays: list, n_rays: list, fresh: bool = True, tmax: float = 1e30):
+    """Device-resident shards (tbvh_intersect_sharded_device): d_rays[i] / n_rays[i] live on the device of replicas[i]; one host thread
+    enqueues all launches, then waits.  Returns (kernel ms per device, host dispatch ms per device)."""
+    k = len(replicas)
+    sc = (C.c_void_p * k)(*[r._h for r in replicas])
+    dp = (C.c_void_p * k)(*[int(p) for p in d_rays])
+    nn = (C.c_uint64 * k)(*[int(x) for x in n_rays])
+    km, dm = (C.c_float * k)(), (C.c_float * k)()
+    check(lib.tbvh_intersect_sharded_device(sc, k, dp, nn, 1 if fresh else 0, float(tmax), km, dm), "tbvh_intersect_sharded_device")
+    return [float(x) for x in km], [float(x) for x in dm]
+
+
+def occluded_sharded_device(replicas: list, d_rays: list, n_rays: list, d_occ: list):
+    k = len(replicas)
+    sc = (C.c_void_p * k)(*[r._h for r in replicas])
+    dp = (C.c_void_p * k)(*[int(p) for p in d_rays])
+    do = (C.c_void_p * k)(*[int(p) for p in d_occ])
+    nn = (C.c_uint64 * k)(*[int(x) for x in n_rays])
+    km, dm = (C.c_float * k)(), (C.c_float * k)()
+    check(lib.tbvh_occluded_sharded_device(sc, k, dp, nn, do, km, dm), "tbvh_occluded_sharded_device")
+    return [float(x) for x in km], [float(x) for x in dm]
+
+
+def wavefront_render_sharded(wfs: list, scenes_: list, d_verts: list, cam: Camera, light_pos, light_color=(1.0, 1.0, 1.0), sky_lo=(0.6, 0.7, 0.8), sky_hi=(0.2, 0.4, 0.9),
+                             eps: float = 1e-3, max_depth: int = 3, seed: int = 1, clear: bool = True, light_size=(0.0, 0.0)):
+    """One frame over several devices (tbvh_wavefront_render_sharded): wfs[i] is the band of the image (Wavefront.set_band) rendered on
+    the device of scenes_[i].  Returns per band {"extend_rays", "shadow_rays", "frame_ms", "dispatch_ms"}."""
+    k = len(wfs)
+    p = _capi.WfParams()
+    p.light_pos[:] = [float(x) for x in light_pos]; p.light_color[:] = [float(x) for x in light_color]
+    p.sky_lo[:] = [float(x) for x in sky_lo]; p.sky_hi[:] = [float(x) for x in sky_hi]
+    p.eps, p.max_depth, p.seed, p.clear = float(eps), int(max_depth), int(seed), int(clear)
+    p.light_size[:] = [float(x) for x in light_size]; p.flags = 0; p.sample_index = 0xFFFFFFFF
+    wa = (C.c_void_p * k)(*[w._h for w in wfs])
+    sa = (C.c_void_p * k)(*[s._h for s in scenes_])
+    va = (C.c_void_p * k)(*[int(v) if v else None for v in d_verts])
+    st = (_capi.WfStats * k)()
+    dm = (C.c_float * k)()
+    check(lib.tbvh_wavefront_render_sharded(wa, sa, va, k, C.byref(cam), C.byref(p), st, dm), "tbvh_wavefront_render_sharded")
+    return [{"extend_rays": [int(x) for x in st[i].extend_rays[:max_depth]], "shadow_rays": [int(x) for x in st[i].shadow_rays[:max_depth]],
+             "frame_ms": float(st[i].frame_ms), "dispatch_ms": float(dm[i])} for i in range(k)]
+
+
+def wavefront_read_sharded(wfs: list, width: int, full_height: int) -> np.ndarray:
+    img = np.zeros((full_height, width, 4), np.float32)
+    wa = (C.c_void_p * len(wfs))(*[w._h for w in wfs])
+    check(lib.tbvh_wavefront_read_sharded(wa, len(wfs), _ptr(img)), "tbvh_wavefront_read_sharded")
+    return img
+
+
 def device_count() -> int:
     return int(lib.tbvh_device_count())
 
@@ -553,6 +603,11 @@ class Wavefront:
         if not stats:
             return None
         return {"extend_rays": [int(x) for x in st.extend_rays[:max_depth]], "shadow_rays": [int(x) for x in st.shadow_rays[:max_depth]], "frame_ms": float(st.frame_ms)}
+
+    def set_band(self, first_row: int, full_height: int):
+        """This object renders rows [first_row, first_row + height) of an image of full_height rows (tbvh_wavefront_set_band)."""
+        check(lib.tbvh_wavefront_set_band(self._h, int(first_row), int(full_height)), "tbvh_wavefront_set_band")
+        return self
 
     def read(self) -> np.ndarray:
         img = np.zeros((self.height, self.width, 4), np.float32)

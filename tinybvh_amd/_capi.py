@@ -69,6 +69,11 @@ SYMBOLS = {
     "tbvh_occluded": (_i, [_vp, _vp, _u64, _u32, _vp]),
     "tbvh_intersect_sharded": (_i, [_vp, _u32, _vp, _u64, _u32]),
     "tbvh_occluded_sharded": (_i, [_vp, _u32, _vp, _u64, _u32, _vp]),
+    "tbvh_intersect_sharded_device": (_i, [_vp, _u32, _vp, _vp, _i, C.c_float, _vp, _vp]),
+    "tbvh_occluded_sharded_device": (_i, [_vp, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "tbvh_wavefront_set_band": (_i, [_vp, _u32, _u32]),
+    "tbvh_wavefront_render_sharded": (_i, [_vp, _vp, _vp, _u32, C.POINTER(Camera), _vp, _vp, _vp]),
+    "tbvh_wavefront_read_sharded": (_i, [_vp, _u32, _vp]),
     "tbvh_shard_range": (None, [_u64, _u32, _u32, C.POINTER(_u64), C.POINTER(_u64)]),
     "tbvh_intersect_device": (_i, [_vp, _vp, _u64]),
     "tbvh_occluded_device": (_i, [_vp, _vp, _u64, _vp]),

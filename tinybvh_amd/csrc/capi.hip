@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -1247,6 +1248,44 @@ int tbvh_occluded_sharded(tbvh_scene* const* scenes, uint32_t nDev, const void* 
     return shardedQuery(scenes, nDev, (void*)rays, n, stride, occ, "tbvh_occluded_sharded");
 }
 
+// ---- device-resident rays over several devices: nothing crosses the host -------------------------------------------------------------
+// Every device's launch is asynchronous on its context's stream, so ONE host thread enqueues them all (a few tens of microseconds each:
+// dispatch_ms[i] = host time spent enqueueing device i's launch), then waits for all.  With the rays produced and consumed where they are
+// traced — a wavefront path tracer per device (tbvh_wavefront_render_sharded), or rays a kernel of the caller's wrote — the devices run
+// at their device-resident rate; tbvh_intersect_sharded above moves HOST rays and is bound by the host (DESIGN.md par. 7).
+namespace {
+int shardedDeviceQuery(tbvh_scene* const* scenes, uint32_t nDev, void* const* dRays, const uint64_t* nRays, uint8_t* const* dOcc, int fresh, float tmax,
+                       float* kernelMs, float* dispatchMs, const char* who) {
+    if (!scenes || !nDev || !dRays || !nRays) return fail(TBVH_E_INVALID, "%s: null argument", who);
+    for (uint32_t i = 0; i < nDev; i++) {
+        if (!scenes[i]) return fail(TBVH_E_INVALID, "%s: scenes[%u] is null", who, i);
+        if (nRays[i] && (!dRays[i] || (dOcc && !dOcc[i]))) return fail(TBVH_E_INVALID, "%s: null ray / output pointer for device %u", who, i);
+        for (uint32_t k = 0; k < i; k++) if (scenes[k]->ctx == scenes[i]->ctx) return fail(TBVH_E_INVALID, "%s: scenes %u and %u share a context (one scene per context)", who, k, i);
+    }
+    for (uint32_t i = 0; i < nDev; i++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (int r = launchQuery(scenes[i], (RayRec*)dRays[i], nRays[i], dOcc ? dOcc[i] : nullptr, fresh != 0, tmax)) return r;
+        if (dispatchMs) dispatchMs[i] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    for (uint32_t i = 0; i < nDev; i++) {
+        if (!nRays[i]) { if (kernelMs) kernelMs[i] = 0.f; continue; }
+        if (int r = checkStatus(scenes[i]->ctx)) return r;   // synchronizes device i's stream
+        if (kernelMs) kernelMs[i] = tbvh_time_last_ms(scenes[i]->ctx);
+    }
+    return 0;
+}
+}  // namespace
+
+int tbvh_intersect_sharded_device(tbvh_scene* const* scenes, uint32_t nDev, void* const* dRays, const uint64_t* nRays, int fresh, float tmax,
+                                  float* kernelMs, float* dispatchMs) {
+    return shardedDeviceQuery(scenes, nDev, dRays, nRays, nullptr, fresh, tmax, kernelMs, dispatchMs, "tbvh_intersect_sharded_device");
+}
+int tbvh_occluded_sharded_device(tbvh_scene* const* scenes, uint32_t nDev, const void* const* dRays, const uint64_t* nRays, uint8_t* const* dOcc,
+                                 float* kernelMs, float* dispatchMs) {
+    if (!dOcc) return fail(TBVH_E_INVALID, "tbvh_occluded_sharded_device: null output");
+    return shardedDeviceQuery(scenes, nDev, (void* const*)dRays, nRays, dOcc, 0, 1e30f, kernelMs, dispatchMs, "tbvh_occluded_sharded_device");
+}
+
 float tbvh_time_last_ms(tbvh_context* c) {
     if (!c || !c->timed) return -1.0f;
     hipSetDevice(c->device);
@@ -1392,7 +1431,8 @@ int tbvh_reset_hits_device(tbvh_context* c, void* dRays, uint64_t n, float tmax)
 
 struct tbvh_wavefront {
     tbvh_context* ctx = nullptr;
-    uint32_t width = 0, height = 0;
+    uint32_t width = 0, height = 0;   // of this object's accumulator: the image, or a band of it
+    uint32_t firstRow = 0, fullHeight = 0;   // tbvh_wavefront_set_band: rows [firstRow, firstRow + height) of an image of fullHeight rows (0: the whole image)
     uint64_t n = 0;
     RayRec* rays[2] = {nullptr, nullptr};
     PathAux* aux[2] = {nullptr, nullptr};
@@ -1466,7 +1506,8 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
         if (w->nBlasVerts < scene->nBlas) return fail(TBVH_E_INVALID, "tbvh_wavefront_render: a TLAS scene needs tbvh_wavefront_set_blas_vertices (%llu BLASes)", (unsigned long long)scene->nBlas);
     } else if (!dVerts) return fail(TBVH_E_INVALID, "tbvh_wavefront_render: null vertex array");
     if (scene->ctx != w->ctx) return fail(TBVH_E_INVALID, "scene and wavefront belong to different contexts");
-    if (cam->width != w->width || cam->height != w->height) return fail(TBVH_E_INVALID, "camera size differs from the wavefront's");
+    const uint32_t fullH = w->fullHeight ? w->fullHeight : w->height;
+    if (cam->width != w->width || cam->height != fullH) return fail(TBVH_E_INVALID, "camera size differs from the wavefront's (a band takes the FULL image's camera)");
     const uint32_t maxDepth = p->max_depth ? (p->max_depth > 8 ? 8 : p->max_depth) : 3;
     tbvh_context* c = w->ctx;
     if (int r = setDevice(c)) return r;
@@ -1481,7 +1522,7 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
     CameraArgs ca;
     memcpy(ca.eye, cam->eye, 12); memcpy(ca.p1, cam->p1, 12); memcpy(ca.p2, cam->p2, 12); memcpy(ca.p3, cam->p3, 12);
     ca.width = cam->width; ca.height = cam->height; ca.sppX = ca.sppY = 1;
-    launch_wf_generate(ca, w->rays[0], w->aux[0], w->n, p->seed, st);
+    launch_wf_generate(ca, w->rays[0], w->aux[0], w->n, p->seed, w->firstRow, w->height, st);
     int cur = 0;
     for (uint32_t d = 0; d < maxDepth; d++) {
         const int nxt = cur ^ 1;
@@ -1495,7 +1536,7 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
         a.shadow = w->shadow; a.shadowAux = w->shadowAux; a.nShadow = QC(2);
         a.verts = (const float4*)dVerts; a.accum = w->accum;
         a.blasVerts = scene->isTlas ? w->blasVerts : nullptr; a.instances = scene->isTlas ? scene->instances : nullptr;
-        a.blueNoise = w->blueNoise; a.sampleIdx = p->sample_index; a.width = w->width; a.height = w->height;
+        a.blueNoise = w->blueNoise; a.sampleIdx = p->sample_index; a.width = w->width; a.height = fullH; a.pixelOffset = w->firstRow * w->width;
         memcpy(a.lightPos, p->light_pos, 12); memcpy(a.lightColor, p->light_color, 12); memcpy(a.skyLo, p->sky_lo, 12); memcpy(a.skyHi, p->sky_hi, 12);
         a.lightSize[0] = p->light_size[0]; a.lightSize[1] = p->light_size[1]; a.flags = p->flags;
         a.eps = p->eps; a.depth = d; a.maxDepth = maxDepth; a.seed = p->seed;
@@ -1517,6 +1558,61 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
         for (uint32_t d = 0; d < maxDepth; d++) { stats->extend_rays[d] = h[2 * d]; stats->shadow_rays[d] = h[1 + 2 * d]; }
         HIP_TRY(hipEventElapsedTime(&stats->frame_ms, w->e0, w->e1));
         if (int r = checkStatus(c)) return r;
+    }
+    return 0;
+}
+
+int tbvh_wavefront_set_band(tbvh_wavefront* w, uint32_t firstRow, uint32_t fullHeight) {
+    if (!w) return fail(TBVH_E_INVALID, "tbvh_wavefront_set_band: null wavefront");
+    if (fullHeight == 0) { w->firstRow = 0; w->fullHeight = 0; return 0; }
+    if ((firstRow & 3u) || (fullHeight & 3u) || (uint64_t)firstRow + w->height > fullHeight) return fail(TBVH_E_INVALID, "tbvh_wavefront_set_band: rows %u + %u of %u (multiples of 4, inside the image)", firstRow, w->height, fullHeight);
+    w->firstRow = firstRow; w->fullHeight = fullHeight;
+    return 0;
+}
+
+// One frame over several devices: every wavefront object renders its band of the image on its own device with its own copy of the scene; the
+// frames are enqueued by this thread one after the other (each enqueue is asynchronous) and run concurrently.  No exchange between devices:
+// a band's accumulator stays on its device until tbvh_wavefront_read_sharded gathers the image.
+int tbvh_wavefront_render_sharded(tbvh_wavefront* const* wfs, tbvh_scene* const* scenes, const void* const* dVerts, uint32_t nDev, const tbvh_camera* cam,
+                                  const tbvh_wf_params* p, tbvh_wf_stats* stats, float* dispatchMs) {
+    if (!wfs || !scenes || !nDev || !cam || !p) return fail(TBVH_E_INVALID, "tbvh_wavefront_render_sharded: null argument");
+    uint32_t row = 0;
+    for (uint32_t i = 0; i < nDev; i++) {
+        if (!wfs[i] || !scenes[i]) return fail(TBVH_E_INVALID, "tbvh_wavefront_render_sharded: null wavefront / scene %u", i);
+        const uint32_t fullH = wfs[i]->fullHeight ? wfs[i]->fullHeight : wfs[i]->height;
+        if (fullH != cam->height || wfs[i]->firstRow != row) return fail(TBVH_E_INVALID, "tbvh_wavefront_render_sharded: band %u covers rows %u.. of %u, expected rows %u.. of %u (bands in order, tiling the image)", i, wfs[i]->firstRow, fullH, row, cam->height);
+        row += wfs[i]->height;
+        for (uint32_t k = 0; k < i; k++) if (wfs[k]->ctx == wfs[i]->ctx) return fail(TBVH_E_INVALID, "tbvh_wavefront_render_sharded: bands %u and %u share a context", k, i);
+    }
+    if (row != cam->height) return fail(TBVH_E_INVALID, "tbvh_wavefront_render_sharded: the bands cover %u of %u rows", row, cam->height);
+    for (uint32_t i = 0; i < nDev; i++) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (int r = tbvh_wavefront_render(wfs[i], scenes[i], dVerts ? dVerts[i] : nullptr, cam, p, nullptr)) return r;
+        if (dispatchMs) dispatchMs[i] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    for (uint32_t i = 0; i < nDev; i++) {
+        tbvh_wavefront* w = wfs[i];
+        tbvh_context* c = w->ctx;
+        if (int r = setDevice(c)) return r;
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (int r = checkStatus(c)) return r;
+        if (stats) {
+            const uint32_t maxDepth = p->max_depth ? (p->max_depth > 8 ? 8 : p->max_depth) : 3;
+            unsigned long long h[64];
+            HIP_TRY(hipMemcpy(h, &w->counters[96], sizeof h, hipMemcpyDeviceToHost));
+            memset(&stats[i], 0, sizeof stats[i]);
+            for (uint32_t d = 0; d < maxDepth; d++) { stats[i].extend_rays[d] = h[2 * d]; stats[i].shadow_rays[d] = h[1 + 2 * d]; }
+            HIP_TRY(hipEventElapsedTime(&stats[i].frame_ms, w->e0, w->e1));
+        }
+    }
+    return 0;
+}
+
+int tbvh_wavefront_read_sharded(tbvh_wavefront* const* wfs, uint32_t nDev, float* rgba) {
+    if (!wfs || !nDev || !rgba) return fail(TBVH_E_INVALID, "tbvh_wavefront_read_sharded: null argument");
+    for (uint32_t i = 0; i < nDev; i++) {
+        if (!wfs[i]) return fail(TBVH_E_INVALID, "tbvh_wavefront_read_sharded: null wavefront %u", i);
+        if (int r = tbvh_wavefront_read(wfs[i], rgba + (size_t)wfs[i]->firstRow * wfs[i]->width * 4)) return r;
     }
     return 0;
 }

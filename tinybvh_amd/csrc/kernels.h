@@ -104,9 +104,10 @@ struct ShadeArgs {
     float lightPos[3], lightColor[3], skyLo[3], skyHi[3];
     float lightSize[2];   // extent of the rectangular light along x and z (0, 0 = point light)
     float eps; uint32_t depth, maxDepth, seed, flags;   // flags bit 0: at most one diffuse bounce per path (wavefront.cl:233); bit 1: wavefront.cl to the letter
-    const uint32_t* blueNoise; uint32_t sampleIdx, width, height;   // 128 x 128 x 8 table (or nullptr), the frame's sample index, image size
+    const uint32_t* blueNoise; uint32_t sampleIdx, width, height;   // 128 x 128 x 8 table (or nullptr), the frame's sample index, size of the FULL image
+    uint32_t pixelOffset;   // a band of a larger image (tbvh_wavefront_set_band): index of the band's first pixel in the full image (else 0)
 };
-void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint64_t n, uint32_t seed, hipStream_t s);
+void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint64_t n, uint32_t seed, uint32_t firstRow, uint32_t bandRows, hipStream_t s);
 void launch_wf_shade(const ShadeArgs& a, uint64_t capacity, hipStream_t s);
 void launch_wf_finalize(const float* accum, float scale, uint32_t* pixels, uint64_t n, hipStream_t s);
 void launch_wf_connect(const uint8_t* occ, const PathAux* aux, const unsigned long long* nShadow, float* accum, uint64_t capacity, hipStream_t s);

@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t queue_slot(bool want, unsigned long long* co
     return want ? slot : 0xffffffffu;
 }
 
-__global__ void k_wf_generate(CameraArgs cam, RayRec* __restrict__ rays, PathAux* __restrict__ aux, uint64_t n, uint32_t seed) {
+__global__ void k_wf_generate(CameraArgs cam, RayRec* __restrict__ rays, PathAux* __restrict__ aux, uint64_t n, uint32_t seed, uint32_t firstRow, uint32_t bandRows) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // same pixel order as k_gen_primary (4x4 tiles), one jittered sample per pixel
@@ -80,9 +80,13 @@ __global__ void k_wf_generate(CameraArgs cam, RayRec* __restrict__ rays, PathAux
     const uint64_t tile = i >> 4;
     const uint32_t tilesX = cam.width / 4;
     const uint32_t px = (uint32_t)(tile % tilesX) * 4 + (inTile & 3), py = (uint32_t)(tile / tilesX) * 4 + (inTile >> 2);
-    uint32_t s = wang(seed * 9781u + (uint32_t)i * 6271u + 1u);
+    // a band of a larger image (tbvh_wavefront_set_band): cam is the FULL image's camera, this launch covers its rows firstRow ... and draws the
+    // random numbers the full image's launch would draw for these pixels (4 x 4 tiles and firstRow a multiple of 4: global ray index = local +
+    // firstRow * width)
+    (void)bandRows;
+    uint32_t s = wang(seed * 9781u + ((uint32_t)i + firstRow * cam.width) * 6271u + 1u);
     if (!s) s = 1;
-    const float u = ((float)px + rnd(s)) / (float)cam.width, v = ((float)py + rnd(s)) / (float)cam.height;
+    const float u = ((float)px + rnd(s)) / (float)cam.width, v = ((float)(py + firstRow) + rnd(s)) / (float)cam.height;
     const float3 eye = make_float3(cam.eye[0], cam.eye[1], cam.eye[2]);
     const float3 P = make_float3(cam.p1[0] + u * (cam.p2[0] - cam.p1[0]) + v * (cam.p3[0] - cam.p1[0]),
                                  cam.p1[1] + u * (cam.p2[1] - cam.p1[1]) + v * (cam.p3[1] - cam.p1[1]),
@@ -157,12 +161,13 @@ __global__ __launch_bounds__(kShadeBlock) void k_wf_shade(ShadeArgs a) {
                 const uint32_t rgb = c & 0xffffffu;
                 const float3 color = rgb ? make_float3((float)((rgb >> 16) & 255) * 0.00392f, (float)((rgb >> 8) & 255) * 0.00392f, (float)(rgb & 255) * 0.00392f)
                                          : make_float3(0.7f, 0.7f, 0.7f);
-                uint32_t s = wang(a.seed * 7919u + pixel * 2699u + a.depth * 104729u + 17u);
+                const uint32_t gpixel = pixel + a.pixelOffset;   // (a band of a larger image: the pixel's index in the full image)
+                uint32_t s = wang(a.seed * 7919u + gpixel * 2699u + a.depth * 104729u + 17u);
                 if (!s) s = 1;
                 float r0 = rnd(s), r1 = rnd(s), r2 = rnd(s), r3 = rnd(s);   // r0, r1: bounce; r2, r3: light sample
                 if (a.blueNoise && a.depth == 0 && a.sampleIdx < 4u) {
                     // blue-noise first samples (wavefront.cl:183-189; Noise() of :24-31, with its x = pixel % height, y = pixel / height)
-                    const uint32_t nx = (pixel % a.height) & 127u, ny = (pixel / a.height) & 127u;
+                    const uint32_t nx = (gpixel % a.height) & 127u, ny = (gpixel / a.height) & 127u;
                     const uint32_t w0 = a.blueNoise[((a.sampleIdx * 2u) << 14) + (ny << 7) + nx], w1 = a.blueNoise[((a.sampleIdx * 2u + 1u) << 14) + (ny << 7) + nx];
                     r2 = (float)(w0 >> 16) * 0.00392f; r3 = (float)((w0 >> 8) & 255u) * 0.00392f;   // noise0 -> the light sample
                     r0 = (float)(w1 >> 16) * 0.00392f; r1 = (float)((w1 >> 8) & 255u) * 0.00392f;   // noise1 -> the bounce
@@ -254,8 +259,8 @@ __global__ void k_wf_connect(const uint8_t* __restrict__ occluded, const PathAux
 
 }  // namespace
 
-void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint64_t n, uint32_t seed, hipStream_t s) {
-    hipLaunchKernelGGL(k_wf_generate, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, cam, rays, aux, n, seed);
+void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint64_t n, uint32_t seed, uint32_t firstRow, uint32_t bandRows, hipStream_t s) {
+    hipLaunchKernelGGL(k_wf_generate, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, cam, rays, aux, n, seed, firstRow, bandRows);
 }
 void launch_wf_shade(const ShadeArgs& a, uint64_t capacity, hipStream_t s) {
     hipLaunchKernelGGL(k_wf_shade, dim3((uint32_t)((capacity + kShadeBlock - 1) / kShadeBlock)), dim3(kShadeBlock), 0, s, a);
