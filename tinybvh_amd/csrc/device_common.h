@@ -125,7 +125,6 @@ struct QueryArgs {
     // sampled; nullptr = no probe ran (small batches).  baseBlocks: workgroups beyond this index only take part when the batch is coherent.
     const uint32_t* probe;
     uint32_t baseBlocks;
-    const float4* nodesPacked;   // BVH8_CWBVH with a hybrid node array: the packed array as uploaded (coherent probed batches stay on it)
     uint32_t flags;        // experiments: 1 = non-temporal ray loads / hit stores, 2 = triangle records padded to 64 bytes
     uint32_t hybridK;      // BVH8_CWBVH, hybrid node array (cwbvh_node.h: kNodeHybrid): nodes below this index are packed, the others one per line
 };
