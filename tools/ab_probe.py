@@ -1,8 +1,8 @@
 """A/B of kernel variants on the contract bench's own batches (not the contract benchmark — that is bench.py): the scene is
 built once, the primary / diffuse (bounce depths 1-3 in thirds) / shadow batches are generated once exactly as bench.py
-does, then every requested variant traces them PASSES times (tbvh_intersect_device_fresh, HIP events).  Needs a library
-built with `make -C tinybvh_amd/csrc EXPERIMENTS=1` for variants other than 0.
-    python tools/ab_probe.py --variants 0,51,52,53 [--scene bistro --side 4096 --layout 10 --stats 59,60,61]"""
+does, then every requested variant traces them PASSES times (tbvh_intersect_device_fresh, HIP events).  Variants: the
+diagnostic ones the library still holds (kernels_cwbvh.hip: launch_cwbvh; 0 = as shipped).
+    python tools/ab_probe.py --variants 0,52,72 [--scene bistro --side 4096 --layout 10 --stats 59,61]"""
 import argparse
 import ctypes as C
 import json
