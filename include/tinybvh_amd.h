@@ -137,6 +137,15 @@ int tbvh_convert_bvh2_device(tbvh_context* ctx, const void* nodes32, uint64_t n_
 int tbvh_build_device(tbvh_context* ctx, const void* verts16, uint64_t n_tris, int on_device, int layout,
                       uint32_t max_leaf_tris, tbvh_scene** out);
 
+/* The same with the tree built by PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) instead of the LBVH's Morton splits:
+ * bottom-up agglomeration of the Morton-ordered triangles — every cluster merges with the neighbour within `radius` positions whose union
+ * has the smallest surface area, once both agree; one triangle per leaf; about 1.5 x the LBVH's build time.  Lower surface-area cost
+ * than the LBVH (the reference's bar for GPU traversal is BVH::BuildHQ, tiny_bvh.h:2623-3040), but NOT faster to trace on the scenes
+ * this library is measured on (profiles/r03_device_builders.txt: axis-aligned procedural geometry suits Morton splits),
+ * hence an entry point of its own rather than the default.
+ * radius: 1..32 positions to each side, 0 = the default 16.  Everything else as tbvh_build_device. */
+int tbvh_build_device_ploc(tbvh_context* ctx, const void* verts16, uint64_t n_tris, int on_device, int layout, uint32_t radius, tbvh_scene** out);
+
 /* Read a BLAS scene's device blobs back (tests, caching a refitted blob): which = 0 nodes, 1 triangle
  * records (BVH_GPU: the gathered {v0|prim, e1, e2} form; BVH4_GPU has none).  dst = NULL only reports the size. */
 int tbvh_scene_download(tbvh_scene* scene, int which, void* dst, uint64_t cap_bytes, uint64_t* bytes_out);

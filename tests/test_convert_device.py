@@ -105,6 +105,34 @@ def test_build_on_device_parity(ctx, oracle, scene, n, leaf):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scene,n,radius", [("soup", 3000, 8), ("blob", 20000, 16), ("atrium", 0, 0), ("soup", 1, 0), ("soup", 2, 32), ("soup", 700, 32)])
+def test_ploc_build_on_device_parity(ctx, oracle, scene, n, radius):
+    """tbvh_build_device_ploc: agglomerative clustering over the Morton order + collapse + encode on the GPU.  Another tree again, the same hit
+    records; every triangle in exactly one leaf; the blob passes the upload validator."""
+    verts = scenes.soup(n, seed=4) if scene == "soup" else scenes.blob(n, seed=7) if scene == "blob" else scenes.get("sponza")[0]
+    sc = tb.BVH8_CWBVH(ctx).BuildOnDevice(verts, builder="ploc", radius=radius)
+    nodes, tris = sc.download_blobs()
+    n_tris = verts.shape[0] // 3
+    prims = tris.reshape(-1, 3, 4)[:, 2, 3]
+    assert np.array_equal(np.sort(prims), np.arange(n_tris, dtype=np.uint32))
+    tb.BVH8_CWBVH(ctx).Upload(nodes, tris)
+    host = tb.HostBVH(verts, tb.LAYOUT_CWBVH)
+    lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+    pad = 0.05 * (hi - lo) + 0.01
+    rays = R.random_rays(40_000, lo - pad, hi + pad, seed=3)
+    want = oracle.bvh2_intersect(host.bvh2_nodes(), host.bvh2_prim_idx(), verts, rays)
+    c = check(sc.Intersect(rays.copy()), want)
+    if n_tris > 100:
+        assert c["hits"] > 2000
+    occ = sc.IsOccluded(rays.copy())
+    assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+    b4 = tb.BVH4_GPU(ctx).BuildOnDevice(verts, builder="ploc", radius=radius)
+    check(b4.Intersect(rays.copy()), want)
+    with pytest.raises(tb.TbvhError):
+        tb.BVH8_CWBVH(ctx).BuildOnDevice(verts, builder="ploc", radius=33)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scene,n", [("soup", 3000), ("blob", 20000), ("atrium", 0), ("soup", 1)])
 def test_bvh4_gpu_convert_and_build_on_device(ctx, oracle, scene, n):
     """BVH4_GPU as the target: conversion of a host BVH2 and the full device build."""

@@ -336,10 +336,13 @@ class BVH4_GPU(_Scene):
         self.host = HostBVH(verts, LAYOUT_BVH4_GPU, **kw)
         return self.Upload(self.host.blob(0, np.uint32, 4))
 
-    def BuildOnDevice(self, verts: np.ndarray, max_leaf_tris: int = 4) -> "BVH4_GPU":
-        """LBVH build + 4-wide collapse + encode on the GPU (tbvh_build_device)."""
+    def BuildOnDevice(self, verts: np.ndarray, max_leaf_tris: int = 4, builder: str = "lbvh", radius: int = 0) -> "BVH4_GPU":
+        """LBVH (tbvh_build_device) or PLOC (tbvh_build_device_ploc) build + 4-wide collapse + encode on the GPU."""
         verts = np.ascontiguousarray(verts, np.float32)
-        check(lib.tbvh_build_device(self.ctx._h, _ptr(verts), verts.shape[0] // 3, 0, LAYOUT_BVH4_GPU, max_leaf_tris, C.byref(self._h)), "tbvh_build_device")
+        if builder == "ploc":
+            check(lib.tbvh_build_device_ploc(self.ctx._h, _ptr(verts), verts.shape[0] // 3, 0, LAYOUT_BVH4_GPU, radius, C.byref(self._h)), "tbvh_build_device_ploc")
+        else:
+            check(lib.tbvh_build_device(self.ctx._h, _ptr(verts), verts.shape[0] // 3, 0, LAYOUT_BVH4_GPU, max_leaf_tris, C.byref(self._h)), "tbvh_build_device")
         return self
 
     def ConvertFromBVH2(self, nodes32: np.ndarray, prim_idx: np.ndarray, verts: np.ndarray) -> "BVH4_GPU":
@@ -363,10 +366,13 @@ class BVH8_CWBVH(_Scene):
         self.host = HostBVH(verts, LAYOUT_CWBVH, **kw)
         return self.Upload(self.host.blob(0, np.uint32, 4), self.host.blob(1, np.uint32, 4))
 
-    def BuildOnDevice(self, verts: np.ndarray, max_leaf_tris: int = 0) -> "BVH8_CWBVH":
-        """LBVH build + wide collapse + encode on the GPU (tbvh_build_device); nothing is built on the host."""
+    def BuildOnDevice(self, verts: np.ndarray, max_leaf_tris: int = 0, builder: str = "lbvh", radius: int = 0) -> "BVH8_CWBVH":
+        """LBVH (tbvh_build_device) or PLOC (tbvh_build_device_ploc) build + wide collapse + encode on the GPU; nothing is built on the host."""
         verts = np.ascontiguousarray(verts, np.float32)
-        check(lib.tbvh_build_device(self.ctx._h, _ptr(verts), verts.shape[0] // 3, 0, LAYOUT_CWBVH, max_leaf_tris, C.byref(self._h)), "tbvh_build_device")
+        if builder == "ploc":
+            check(lib.tbvh_build_device_ploc(self.ctx._h, _ptr(verts), verts.shape[0] // 3, 0, LAYOUT_CWBVH, radius, C.byref(self._h)), "tbvh_build_device_ploc")
+        else:
+            check(lib.tbvh_build_device(self.ctx._h, _ptr(verts), verts.shape[0] // 3, 0, LAYOUT_CWBVH, max_leaf_tris, C.byref(self._h)), "tbvh_build_device")
         return self
 
     def ConvertFromBVH2(self, nodes32: np.ndarray, prim_idx: np.ndarray, verts: np.ndarray) -> "BVH8_CWBVH":

@@ -60,6 +60,7 @@ SYMBOLS = {
     "tbvh_set_opacity_micromaps": (_i, [_vp, _vp, _u32, _u64, _i]),
     "tbvh_scene_download": (_i, [_vp, _i, _vp, _u64, _vp]),
     "tbvh_build_device": (_i, [_vp, _vp, _u64, _i, _i, _u32, _vp]),
+    "tbvh_build_device_ploc": (_i, [_vp, _vp, _u64, _i, _i, _u32, _vp]),
     "tbvh_convert_bvh2_device": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _i, _i, _vp]),
     "tbvh_tlas_download": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp]),
     "tbvh_free_scene": (None, [_vp]),

@@ -882,16 +882,13 @@ int tbvh_convert_bvh2_device(tbvh_context* c, const void* nodes32, uint64_t nNod
     return r;
 }
 
-int tbvh_build_device(tbvh_context* c, const void* verts16, uint64_t nTris, int onDevice, int layout, uint32_t maxLeafTris, tbvh_scene** out) {
-    if (!c || !verts16 || !out || nTris == 0) return fail(TBVH_E_INVALID, "tbvh_build_device: null/empty argument");
-    if (layout != TBVH_LAYOUT_CWBVH && layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "tbvh_build_device: target layout %d not supported (BVH8_CWBVH and BVH4_GPU are)", layout);
-    if (nTris > 0x3fffffffull) return fail(TBVH_E_INVALID, "tbvh_build_device: too many triangles for 32-bit node indices");
-    const uint32_t leafCap = layout == TBVH_LAYOUT_CWBVH ? 3u : 4u;
-    // default: one triangle per leaf for CWBVH.  Contiguous Morton ranges make poor multi-triangle leaves: measured on the
-    // Bistro stand-in, 1 / 2 / 3 triangles per leaf trace camera rays at 3629 / 3354 / 3125 and bounce rays at 2323 / 2150 /
-    // 1884 MRays/s (the host SAH tree: 3300 / 2480), for 13 instead of 8 ms of build time and 22 % more memory
-    if (maxLeafTris == 0) maxLeafTris = layout == TBVH_LAYOUT_CWBVH ? 1u : leafCap;
-    if (maxLeafTris > leafCap) return fail(TBVH_E_INVALID, "tbvh_build_device: at most %u triangles per leaf for this layout", leafCap);
+namespace {
+// builder: 0 = LBVH (maxLeafTris applies), 1 = PLOC (one triangle per leaf; radius = search window to each side)
+int buildDeviceImpl(const char* who, tbvh_context* c, const void* verts16, uint64_t nTris, int onDevice, int layout, uint32_t maxLeafTris, int builder, uint32_t radius,
+                    tbvh_scene** out) {
+    if (!c || !verts16 || !out || nTris == 0) return fail(TBVH_E_INVALID, "%s: null/empty argument", who);
+    if (layout != TBVH_LAYOUT_CWBVH && layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "%s: target layout %d not supported (BVH8_CWBVH and BVH4_GPU are)", who, layout);
+    if (nTris > 0x3fffffffull) return fail(TBVH_E_INVALID, "%s: too many triangles for 32-bit node indices", who);
     if (int r = setDevice(c)) return r;
     struct Tmp {
         void *v = nullptr, *n2 = nullptr, *idx = nullptr, *scratch = nullptr;
@@ -903,15 +900,33 @@ int tbvh_build_device(tbvh_context* c, const void* verts16, uint64_t nTris, int 
         HIP_TRY(hipMemcpyAsync(t.v, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream));
         dV = (const float4*)t.v;
     }
-    size_t sortTemp = 0;
-    const size_t scratchBytes = lbvh_scratch_bytes((uint32_t)nTris, &sortTemp);
+    size_t sortTemp = 0, scanTemp = 0;
+    const size_t scratchBytes = builder == 1 ? ploc_scratch_bytes((uint32_t)nTris, &sortTemp, &scanTemp) : lbvh_scratch_bytes((uint32_t)nTris, &sortTemp);
     HIP_TRY(hipMalloc(&t.n2, nTris * 2 * 32)); HIP_TRY(hipMalloc(&t.idx, nTris * 4)); HIP_TRY(hipMalloc(&t.scratch, scratchBytes));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(launch_lbvh_build(dV, (uint32_t)nTris, maxLeafTris, (float4*)t.n2, (uint32_t*)t.idx, t.scratch, sortTemp, c->stream));
+    if (builder == 1) HIP_TRY(launch_ploc_build(dV, (uint32_t)nTris, radius, (float4*)t.n2, (uint32_t*)t.idx, t.scratch, sortTemp, scanTemp, c->stream, nullptr));
+    else HIP_TRY(launch_lbvh_build(dV, (uint32_t)nTris, maxLeafTris, (float4*)t.n2, (uint32_t*)t.idx, t.scratch, sortTemp, c->stream));
     const int r = convertDeviceImpl(c, layout, (const float4*)t.n2, nTris * 2, (const uint32_t*)t.idx, nTris, dV, nTris, out);
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     return r;
+}
+}  // namespace
+
+int tbvh_build_device(tbvh_context* c, const void* verts16, uint64_t nTris, int onDevice, int layout, uint32_t maxLeafTris, tbvh_scene** out) {
+    const uint32_t leafCap = layout == TBVH_LAYOUT_CWBVH ? 3u : 4u;
+    // default: one triangle per leaf for CWBVH.  Contiguous Morton ranges make poor multi-triangle leaves: measured on the
+    // Bistro stand-in, 1 / 2 / 3 triangles per leaf trace camera rays at 3629 / 3354 / 3125 and bounce rays at 2323 / 2150 /
+    // 1884 MRays/s (the host SAH tree: 3300 / 2480), for 13 instead of 8 ms of build time and 22 % more memory
+    if (maxLeafTris == 0) maxLeafTris = layout == TBVH_LAYOUT_CWBVH ? 1u : leafCap;
+    if (maxLeafTris > leafCap) return fail(TBVH_E_INVALID, "tbvh_build_device: at most %u triangles per leaf for this layout", leafCap);
+    return buildDeviceImpl("tbvh_build_device", c, verts16, nTris, onDevice, layout, maxLeafTris, 0, 0, out);
+}
+
+int tbvh_build_device_ploc(tbvh_context* c, const void* verts16, uint64_t nTris, int onDevice, int layout, uint32_t radius, tbvh_scene** out) {
+    if (radius == 0) radius = 16;
+    if (radius > 32u) return fail(TBVH_E_INVALID, "tbvh_build_device_ploc: search radius %u (1..32; 0 = the default 16)", radius);
+    return buildDeviceImpl("tbvh_build_device_ploc", c, verts16, nTris, onDevice, layout, 1, 1, radius, out);
 }
 
 namespace {

@@ -43,6 +43,9 @@ hipError_t launch_tlas_rebuild(float4* tlasNodes, uint32_t* tlasIdx, float4* ins
                                uint32_t n, uint32_t nBlas, void* scratch, size_t sortTempBytes, hipStream_t s);
 // LBVH build on the device (kernels_build.hip)
 size_t lbvh_scratch_bytes(uint32_t n, size_t* sortTempBytes);
+size_t ploc_scratch_bytes(uint32_t n, size_t* sortTempBytes, size_t* scanTempBytes);
+hipError_t launch_ploc_build(const float4* verts, uint32_t n, uint32_t radius, float4* nodes32, uint32_t* primIdx, void* scratch, size_t sortTempBytes,
+                             size_t scanTempBytes, hipStream_t s, uint32_t* steps);
 hipError_t launch_lbvh_build(const float4* verts, uint32_t n, uint32_t maxLeaf, float4* nodes32, uint32_t* primIdx, void* scratch, size_t sortTempBytes,
                              hipStream_t s);
 // BVH2 -> CWBVH conversion on the device (kernels_convert.hip)

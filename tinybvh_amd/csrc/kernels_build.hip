@@ -177,6 +177,129 @@ __global__ void k_wald_pass(const uint32_t* __restrict__ parent, const uint2* __
     done[node] = pass;
 }
 
+// ---- PLOC (Meister & Bittner 2018: parallel locally-ordered clustering) ---------------------------------------------------------------
+// The LBVH splits by Morton bits alone; PLOC builds the tree bottom-up by AGGLOMERATION: the clusters (first: the triangles, in Morton order)
+// each look R positions left and right for the neighbour whose union with them has the smallest surface area; clusters that chose EACH OTHER
+// merge into a new node; the array is compacted (order kept) and the step repeats until one cluster is left (~log_1.6 n steps).  Quality is
+// that of a greedy agglomerative build restricted to a Morton window — close to binned SAH, well above LBVH — for a few sorts' worth of time.
+//
+// A cluster IS its future BVHNode record (32 bytes: aabbMin, leftFirst, aabbMax, triCount): a leaf cluster {box, position in primIdx, 1}, a
+// merged one {union, 2 + 2p, 0} where p numbers the merges; the two records of a merged pair are written to out positions 2 + 2p and 3 + 2p at
+// the moment they merge — the adjacent-children format of tiny_bvh.h:1050-1062 falls out, as with the LBVH above.  p and the compacted index come
+// from ONE exclusive scan per step over (keeps, leads) packed into 64 bits: node numbering is deterministic.
+// Ties: among equal areas a cluster picks by a symmetric hash of the pair (below), so of all pairs at the minimal area the one with the
+// smallest hash is mutual: every step merges at least one pair.
+constexpr int kPlocBlock = 256;
+
+// Equal areas are the rule, not the exception, in modelled geometry (rows of identical quads): "the lowest index among equals" makes every
+// cluster of such a row choose its LEFT neighbour — one mutual pair per row and step, chains instead of trees.  The tie is broken by a hash of
+// the PAIR instead (the same value seen from both sides; lower index first, so it is a total order on pairs): along a row of equal areas a
+// pair merges when its hash is below both neighbouring pairs' — a third of them per step.
+__device__ __forceinline__ uint32_t pair_hash(uint32_t i, uint32_t j) {
+    const uint32_t a = i < j ? i : j, b = i < j ? j : i;
+    uint32_t h = a * 0x9E3779B1u ^ (b * 0x85EBCA6Bu + 0x7F4A7C15u);
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    return h;
+}
+
+template <int R>
+__global__ __launch_bounds__(kPlocBlock) void k_ploc_nearest(const float4* __restrict__ cl, const uint32_t* __restrict__ count, uint32_t* __restrict__ nn) {
+    __shared__ float tile[6][kPlocBlock + 2 * R];
+    const uint32_t c = *count;
+    const int base = (int)(blockIdx.x * kPlocBlock) - R;
+    if ((uint32_t)(blockIdx.x * kPlocBlock) >= c) return;
+    for (int t = threadIdx.x; t < kPlocBlock + 2 * R; t += kPlocBlock) {
+        const int g = base + t;
+        float4 mn = make_float4(0.f, 0.f, 0.f, 0.f), mx = mn;
+        if (g >= 0 && (uint32_t)g < c) { mn = cl[2 * (size_t)g]; mx = cl[2 * (size_t)g + 1]; }
+        tile[0][t] = mn.x; tile[1][t] = mn.y; tile[2][t] = mn.z; tile[3][t] = mx.x; tile[4][t] = mx.y; tile[5][t] = mx.z;
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * kPlocBlock + threadIdx.x;
+    if (i >= c) return;
+    const int me = (int)threadIdx.x + R;
+    const float a0 = tile[0][me], a1 = tile[1][me], a2 = tile[2][me], a3 = tile[3][me], a4 = tile[4][me], a5 = tile[5][me];
+    float best = 3.0e38f;
+    uint32_t bestJ = 0xffffffffu, bestH = 0xffffffffu;
+#pragma unroll 4
+    for (int d = -R; d <= R; d++) {
+        const int g = (int)i + d;
+        if (d == 0 || g < 0 || (uint32_t)g >= c) continue;
+        const int t = me + d;
+        const float ex = fmaxf(a3, tile[3][t]) - fminf(a0, tile[0][t]), ey = fmaxf(a4, tile[4][t]) - fminf(a1, tile[1][t]), ez = fmaxf(a5, tile[5][t]) - fminf(a2, tile[2][t]);
+        const float area = ex * ey + ey * ez + ez * ex;
+        const uint32_t h = pair_hash(i, (uint32_t)g);
+        if (area < best || (area == best && h < bestH)) { best = area; bestJ = (uint32_t)g; bestH = h; }
+    }
+    nn[i] = bestJ;
+}
+
+// keeps | leads << 32 per cluster: a cluster whose choice chose it back merges; the lower index of the pair leads (and stays), the other goes
+__global__ void k_ploc_flags(const uint32_t* __restrict__ nn, const uint32_t* __restrict__ count, unsigned long long* __restrict__ flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = *count;
+    if (i >= c) return;
+    const uint32_t j = nn[i];
+    const bool mutual = j < c && nn[j] == i;
+    const unsigned long long keeps = (mutual && j < i) ? 0ull : 1ull, leads = (mutual && i < j) ? 1ull : 0ull;
+    flags[i] = keeps | (leads << 32);
+}
+
+// counters: [0] clusters now, [1] merges so far (= next p), [2] clusters after this step, [3] merges after this step
+__global__ void k_ploc_merge(const float4* __restrict__ cl, const uint32_t* __restrict__ nn, const unsigned long long* __restrict__ flags,
+                             const unsigned long long* __restrict__ scan, uint32_t* __restrict__ counters, float4* __restrict__ clOut, float4* __restrict__ nodes32) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = counters[0], pBase = counters[1];
+    if (i >= c) return;
+    const unsigned long long f = flags[i], sc = scan[i];
+    if (i == c - 1u) { counters[2] = (uint32_t)sc + (uint32_t)(f & 1ull); counters[3] = pBase + (uint32_t)(sc >> 32) + (uint32_t)(f >> 32); }
+    if (!(f & 1ull)) return;
+    const uint32_t to = (uint32_t)sc;
+    const float4 amn = cl[2 * (size_t)i], amx = cl[2 * (size_t)i + 1];
+    if (f >> 32) {
+        const uint32_t j = nn[i], p = pBase + (uint32_t)(sc >> 32);
+        const float4 bmn = cl[2 * (size_t)j], bmx = cl[2 * (size_t)j + 1];
+        float4* o = nodes32 + 2 * (size_t)(2u + 2u * p);
+        o[0] = amn; o[1] = amx; o[2] = bmn; o[3] = bmx;
+        clOut[2 * (size_t)to] = make_float4(fminf(amn.x, bmn.x), fminf(amn.y, bmn.y), fminf(amn.z, bmn.z), as_f32(2u + 2u * p));
+        clOut[2 * (size_t)to + 1] = make_float4(fmaxf(amx.x, bmx.x), fmaxf(amx.y, bmx.y), fmaxf(amx.z, bmx.z), as_f32(0u));
+    } else { clOut[2 * (size_t)to] = amn; clOut[2 * (size_t)to + 1] = amx; }
+}
+__global__ void k_ploc_advance(uint32_t* __restrict__ counters) { counters[0] = counters[2]; counters[1] = counters[3]; }
+
+__global__ void k_ploc_leaves(const uint32_t* __restrict__ sortedTri, const float4* __restrict__ triMin, const float4* __restrict__ triMax, uint32_t n, float4* __restrict__ cl) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t tri = sortedTri[k];
+    const float4 mn = triMin[tri], mx = triMax[tri];
+    cl[2 * (size_t)k] = make_float4(mn.x, mn.y, mn.z, as_f32(k)); cl[2 * (size_t)k + 1] = make_float4(mx.x, mx.y, mx.z, as_f32(1u));
+}
+__global__ void k_ploc_root(const float4* __restrict__ cl, float4* __restrict__ nodes32) {
+    if (threadIdx.x == 0) { nodes32[0] = cl[0]; nodes32[1] = cl[1]; nodes32[2] = make_float4(0.f, 0.f, 0.f, 0.f); nodes32[3] = make_float4(0.f, 0.f, 0.f, 0.f); }
+}
+
+struct PlocScratch {
+    float4 *triMin, *triMax, *clA, *clB;
+    unsigned long long *keysA, *keysB, *flags, *scan;
+    uint32_t *valsA, *nn, *bounds, *counters;
+    void *sortTemp, *scanTemp;
+    size_t total;
+};
+PlocScratch carve_ploc(void* base, uint32_t n, size_t sortTempBytes, size_t scanTempBytes) {
+    char* p = (char*)base;
+    auto take = [&](size_t bytes) { char* r = p; p += (bytes + 255) & ~(size_t)255; return r; };
+    PlocScratch s;
+    s.triMin = (float4*)take((size_t)n * 16); s.triMax = (float4*)take((size_t)n * 16);
+    s.clA = (float4*)take((size_t)n * 32); s.clB = (float4*)take((size_t)n * 32);
+    s.keysA = (unsigned long long*)take((size_t)n * 8); s.keysB = (unsigned long long*)take((size_t)n * 8);
+    s.flags = (unsigned long long*)take((size_t)n * 8); s.scan = (unsigned long long*)take((size_t)n * 8);
+    s.valsA = (uint32_t*)take((size_t)n * 4); s.nn = (uint32_t*)take((size_t)n * 4);
+    s.bounds = (uint32_t*)take(64); s.counters = (uint32_t*)take(64);
+    s.sortTemp = take(sortTempBytes); s.scanTemp = take(scanTempBytes);
+    s.total = (size_t)(p - (char*)base);
+    return s;
+}
+
 struct Scratch {
     float4 *triMin, *triMax, *boxMin, *boxMax;
     unsigned long long *keysA, *keysB;
@@ -237,6 +360,54 @@ hipError_t launch_lbvh_build(const float4* verts, uint32_t n, uint32_t maxLeaf, 
         if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
         if (pass > 2u + 24u * 100000u) return hipErrorUnknown;
     }
+    return hipGetLastError();
+}
+
+size_t ploc_scratch_bytes(uint32_t n, size_t* sortTempBytes, size_t* scanTempBytes) {
+    size_t tmp = 0, tmp2 = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 63);
+    hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, (int)n);
+    *sortTempBytes = tmp; *scanTempBytes = tmp2;
+    return carve_ploc(nullptr, n, tmp, tmp2).total;
+}
+
+// PLOC build (see above).  Out as launch_lbvh_build: nodes32 (2n BVHNode records, [1] unused), primIdx (the triangles in Morton order); one
+// triangle per leaf.  radius: search window to each side (8, 16 or 32).  steps (optional): number of clustering steps taken.
+hipError_t launch_ploc_build(const float4* verts, uint32_t n, uint32_t radius, float4* nodes32, uint32_t* primIdx, void* scratch, size_t sortTempBytes,
+                             size_t scanTempBytes, hipStream_t s, uint32_t* steps) {
+    const PlocScratch sc = carve_ploc(scratch, n, sortTempBytes, scanTempBytes);
+    hipError_t e;
+    if ((e = hipMemsetAsync(sc.bounds, 0xff, 12, s)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(sc.bounds + 3, 0x00, 12, s)) != hipSuccess) return e;
+    const uint32_t bs = 256, nb = (n + bs - 1) / bs;
+    hipLaunchKernelGGL(k_tri_boxes, dim3(nb < 2048u ? nb : 2048u), dim3(bs), 0, s, verts, n, sc.triMin, sc.triMax, sc.bounds);
+    hipLaunchKernelGGL(k_tri_morton, dim3(nb), dim3(bs), 0, s, sc.triMin, sc.triMax, sc.bounds, n, sc.keysA, sc.valsA);
+    size_t tmp = sortTempBytes;
+    if ((e = hipcub::DeviceRadixSort::SortPairs(sc.sortTemp, tmp, sc.keysA, sc.keysB, sc.valsA, primIdx, (int)n, 0, 63, s)) != hipSuccess) return e;
+    float4 *cur = sc.clA, *nxt = sc.clB;
+    hipLaunchKernelGGL(k_ploc_leaves, dim3(nb), dim3(bs), 0, s, primIdx, sc.triMin, sc.triMax, n, cur);
+    uint32_t host[4] = {n, 0u, n, 0u};
+    if ((e = hipMemcpyAsync(sc.counters, host, 16, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    uint32_t c = n, nSteps = 0;
+    while (c > 1u) {
+        const uint32_t g = (c + kPlocBlock - 1) / kPlocBlock;
+        if (radius <= 8u) hipLaunchKernelGGL(k_ploc_nearest<8>, dim3(g), dim3(kPlocBlock), 0, s, cur, sc.counters, sc.nn);
+        else if (radius <= 16u) hipLaunchKernelGGL(k_ploc_nearest<16>, dim3(g), dim3(kPlocBlock), 0, s, cur, sc.counters, sc.nn);
+        else hipLaunchKernelGGL(k_ploc_nearest<32>, dim3(g), dim3(kPlocBlock), 0, s, cur, sc.counters, sc.nn);
+        hipLaunchKernelGGL(k_ploc_flags, dim3(g), dim3(kPlocBlock), 0, s, sc.nn, sc.counters, sc.flags);
+        size_t t2 = scanTempBytes;
+        if ((e = hipcub::DeviceScan::ExclusiveSum(sc.scanTemp, t2, sc.flags, sc.scan, (int)c, s)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_ploc_merge, dim3(g), dim3(kPlocBlock), 0, s, cur, sc.nn, sc.flags, sc.scan, sc.counters, nxt, nodes32);
+        hipLaunchKernelGGL(k_ploc_advance, dim3(1), dim3(1), 0, s, sc.counters);
+        if ((e = hipMemcpyAsync(host, sc.counters, 16, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(s)) != hipSuccess) return e;
+        if (host[0] >= c || host[0] == 0u) return hipErrorUnknown;   // every step merges at least one pair
+        c = host[0];
+        float4* t = cur; cur = nxt; nxt = t;
+        nSteps++;
+    }
+    hipLaunchKernelGGL(k_ploc_root, dim3(1), dim3(64), 0, s, cur, nodes32);
+    if (steps) *steps = nSteps;
     return hipGetLastError();
 }
 
