@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--order", default="")
     ap.add_argument("--host-tree", action="store_true", help="also the host SAH tree at the first size")
+    ap.add_argument("--st", action="store_true", help="node visits / triangle tests per ray of every tree (variant 59)")
     a = ap.parse_args()
     ctx = tb.Context(0)
     n = a.side * a.side
@@ -68,6 +69,20 @@ def main():
                             ms.append(t)
                     row[kind] = n / (float(np.mean(ms)) * 1e-3) / 1e6
                 print(f"   variant {v:3d}: BVH+copies {sc.device_bytes / 1e6:7.0f} MB  primary {row['primary']:7.1f}  diffuse {row['diffuse']:7.1f} MRays/s", flush=True)
+            if a.st:
+                # node visits (S) and triangle tests (T) per ray from the instrumented strict kernel: the algorithmic bytes of SURVEY §8(d)
+                import ctypes as C
+                sc.set_variant(59)
+                for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
+                    st = (C.c_uint64 * 8)()
+                    tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+                    sc.intersect_device_fresh(d, n, 1e30)
+                    order.append(dict(tris=nt, tree=tree, kind="prep", variant=59))
+                    tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+                    S, T = int(st[2]) / n, int(st[4]) / n
+                    alg = S * 80 + T * 48 + 64 + 16
+                    print(f"   S/T {kind:8s}: {S:.2f} node visits, {T:.2f} triangle tests per ray -> algorithmic {alg:.0f} B/ray (80 S + 48 T + 64 + 16)", flush=True)
+                sc.set_variant(0)
             sc.free(); ctx.free(d_prim); ctx.free(d_diff)
         del verts
     if a.order:
