@@ -1277,16 +1277,23 @@ int shardedDeviceQuery(tbvh_scene* const* scenes, uint32_t nDev, void* const* dR
         if (nRays[i] && (!dRays[i] || (dOcc && !dOcc[i]))) return fail(TBVH_E_INVALID, "%s: null ray / output pointer for device %u", who, i);
         for (uint32_t k = 0; k < i; k++) if (scenes[k]->ctx == scenes[i]->ctx) return fail(TBVH_E_INVALID, "%s: scenes %u and %u share a context (one scene per context)", who, k, i);
     }
-    for (uint32_t i = 0; i < nDev; i++) {
+    int rc = 0;
+    uint32_t launched = 0;
+    for (; launched < nDev && !rc; launched++) {
+        const uint32_t i = launched;
         const auto t0 = std::chrono::steady_clock::now();
-        if (int r = launchQuery(scenes[i], (RayRec*)dRays[i], nRays[i], dOcc ? dOcc[i] : nullptr, fresh != 0, tmax)) return r;
+        rc = launchQuery(scenes[i], (RayRec*)dRays[i], nRays[i], dOcc ? dOcc[i] : nullptr, fresh != 0, tmax);
         if (dispatchMs) dispatchMs[i] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    for (uint32_t i = 0; i < nDev; i++) {
+    // wait for everything that was enqueued, also after a failure: the caller gets its buffers back quiescent (the first error is reported)
+    std::string firstErr = rc ? tbvh_last_error() : "";
+    for (uint32_t i = 0; i < launched; i++) {
         if (!nRays[i]) { if (kernelMs) kernelMs[i] = 0.f; continue; }
-        if (int r = checkStatus(scenes[i]->ctx)) return r;   // synchronizes device i's stream
-        if (kernelMs) kernelMs[i] = tbvh_time_last_ms(scenes[i]->ctx);
+        const int r = checkStatus(scenes[i]->ctx);   // synchronizes device i's stream
+        if (r && !rc) { rc = r; firstErr = tbvh_last_error(); }
+        if (kernelMs) kernelMs[i] = r ? -1.f : tbvh_time_last_ms(scenes[i]->ctx);
     }
+    if (rc) return fail(rc, "%s: %s", who, firstErr.c_str());
     return 0;
 }
 }  // namespace
