@@ -67,7 +67,9 @@ struct tbvh_context {
     bool gridOverride = false;     // TBVH_BLOCKS_PER_CU / TBVH_RAYS_PER_BLOCK given: no per-scene adjustment
     uint64_t splitBelow = 12ull << 20;   // batches of fewer rays split their last rays over idle lanes; TBVH_SPLIT_RAYS=0 turns that off (tie order then reproducible run to run)
     uint32_t raysPerBlock = 128;   // small batches: one workgroup per this many rays (with split rays, profiles/r02_grid_sweep.txt: 96-128 best on 1 M-ray batches, +5 % over 192; flat at 4 M)
-    unsigned long long* pool = nullptr;     // ray-fetch counters: kPoolParts of them, 256 bytes apart (ray_pool.h)
+    unsigned long long* pool = nullptr;     // ray-fetch counters: kPoolParts of them, 256 bytes apart (ray_pool.h), + the coherence probe's line; TWO such areas
+    int poolCur = 0;              // the area the next launch draws from; its kernels zero the other one for the launch after (no memset in the stream)
+    bool poolClean = false;       // both areas are known to be as that scheme leaves them (false: the next launch clears them itself)
     uint32_t* status = nullptr;
     RayRec* stageRays = nullptr;  // staging for host-array queries
     uint64_t stageCap = 0;
@@ -317,10 +319,15 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     if (int r = setDevice(c)) return r;
     if (n == 0) return 0;
     const bool any = d_occ != nullptr;
-    HIP_TRY(hipMemsetAsync(c->pool, 0, (size_t)(kPoolParts + 1) * kPoolCounterStride * 4, c->stream));   // + the coherence-probe counters on their own line
+    // ray-fetch counters: two areas alternate; the kernels of this launch zero the other area for the next one.  After anything that went wrong
+    // between two launches (poolClean still false) both are cleared here.
+    const size_t poolWords = (size_t)(kPoolParts + 1) * kPoolCounterStride;   // + the coherence-probe counters on their own line
+    if (!c->poolClean) HIP_TRY(hipMemsetAsync(c->pool, 0, poolWords * 4 * 2, c->stream));
+    c->poolClean = false;
+    uint32_t* const poolArea = (uint32_t*)c->pool + (size_t)c->poolCur * poolWords;
     QueryArgs q;
     q.rays = d_rays; q.nRays = n; q.occluded = d_occ;
-    q.spill = c->spill; q.counter = (uint32_t*)c->pool; q.poolParts = c->poolParts;
+    q.spill = c->spill; q.counter = poolArea; q.counterNext = (uint32_t*)c->pool + (size_t)(c->poolCur ^ 1) * poolWords; q.poolParts = c->poolParts;
     q.stats = c->counter + 8;
     q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.omm = Omm{s->opmap, s->opmapN};
     q.probe = nullptr; q.baseBlocks = 0; q.hybridK = s->hybridK; q.flags = c->expFlags & 1u;
@@ -348,7 +355,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     // otherwise).  Bistro stand-in, 16.7 M rays: camera rays +4.5 %, shadow rays +6 %, bounce rays unchanged.
     uint32_t blocksBase = blocks;
     if (!s->isTlas && !small && blobBytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || s->variant == 88)) {
-        uint32_t* probe = (uint32_t*)c->pool + (size_t)kPoolParts * kPoolCounterStride;
+        uint32_t* probe = poolArea + (size_t)kPoolParts * kPoolCounterStride;
         launch_coherence_probe(d_rays, n, nDev, probe, c->stream);
         HIP_TRY(hipGetLastError());
         q.probe = probe; q.baseBlocks = blocks;
@@ -362,7 +369,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             launch_tlas4(any, 0, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
-            c->timed = true;
+            c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
             return 0;
         }
         if (s->tlas8 && (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2)) {   // BVH8_CWBVH BLASes (or those and BVH_GPU ones): the unified 8-wide kernel
@@ -370,7 +377,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             launch_tlas8(any, 0, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7, s->blasMixCw2);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
-            c->timed = true;
+            c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
             return 0;
         }
         if (s->blasLayout == TBVH_LAYOUT_BVH_GPU) {   // BVH_GPU BLASes: the TLAS already has their node format (kernels_tlas2.hip)
@@ -378,14 +385,14 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             launch_tlas2(any, 0, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipEventRecord(c->ev1, c->stream));
-            c->timed = true;
+            c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
             return 0;
         }
         q.spillStride = c->spillEntries / 2;
         launch_tlas(any, s->blasLayout, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
-        c->timed = true;
+        c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
         return 0;
     }
     switch (s->layout) {
@@ -428,7 +435,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
     return 0;
 }
 
@@ -559,7 +566,7 @@ int tbvh_init(int device, tbvh_context** out) {
     const size_t spillBytes = (size_t)(c->blocks + c->blocks / 3u) * 64 * c->spillEntries * 4;   // the largest grid any launch uses
     e = hipMalloc((void**)&c->spill, spillBytes);
     if (e == hipSuccess) e = hipMalloc((void**)&c->counter, 256);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->pool, (size_t)(kPoolParts + 1) * kPoolCounterStride * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->pool, (size_t)(kPoolParts + 1) * kPoolCounterStride * 4 * 2);
     if (e != hipSuccess) { tbvh_shutdown(c); return fail(TBVH_E_NOMEM, "device allocation failed: %s", hipGetErrorString(e)); }
     c->status = (uint32_t*)(c->counter + 4);
     hipMemset(c->counter, 0, 256);
@@ -1401,7 +1408,8 @@ int tbvh_debug_last_probe(tbvh_context* c, uint32_t out[3]) {
     out[0] = out[1] = out[2] = 0;
     if (!c->lastProbed) return 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, (uint32_t*)c->pool + (size_t)kPoolParts * kPoolCounterStride, 8, hipMemcpyDeviceToHost));
+    // (the area the last launch drew from: the next launch's kernels will zero it)
+    HIP_TRY(hipMemcpy(out, (uint32_t*)c->pool + (size_t)(c->poolCur ^ 1) * ((size_t)(kPoolParts + 1) * kPoolCounterStride) + (size_t)kPoolParts * kPoolCounterStride, 8, hipMemcpyDeviceToHost));
     out[2] = (out[1] != 0 && out[0] * 10u >= out[1] * 6u) ? 2u : 1u;   // the rule of k_cwbvh (kernels_cwbvh.hip)
     return 0;
 }
@@ -1451,6 +1459,8 @@ int tbvh_reset_hits_device(tbvh_context* c, void* dRays, uint64_t n, float tmax)
 
 // ---- wavefront path tracer (device-resident Generate / Extend / Shade / Connect) ----------------
 
+constexpr uint32_t kWfCounterWords = 32u * 18u;   // 9 path-queue + 8 shadow-queue counters (max_depth <= 8), one 256-byte line each, 64-bit words
+
 struct tbvh_wavefront {
     tbvh_context* ctx = nullptr;
     uint32_t width = 0, height = 0;   // of this object's accumulator: the image, or a band of it
@@ -1484,7 +1494,7 @@ int tbvh_wavefront_create(tbvh_context* c, uint32_t width, uint32_t height, tbvh
     if (e == hipSuccess) e = hipMalloc((void**)&w->shadowAux, w->n * sizeof(PathAux));
     if (e == hipSuccess) e = hipMalloc((void**)&w->occ, w->n);
     if (e == hipSuccess) e = hipMalloc((void**)&w->accum, w->n * 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&w->counters, 256 * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&w->counters, (size_t)kWfCounterWords * 8);
     if (e == hipSuccess) e = hipMemset(w->accum, 0, w->n * 16);
     if (e == hipSuccess) e = hipEventCreate(&w->e0);
     if (e == hipSuccess) e = hipEventCreate(&w->e1);
@@ -1536,26 +1546,26 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
     hipStream_t st = c->stream;
     HIP_TRY(hipEventRecord(w->e0, st));
     if (p->clear) HIP_TRY(hipMemsetAsync(w->accum, 0, w->n * 16, st));
-    // the two path-queue counters and the shadow-queue counter sit on their own 256-byte lines (words 0, 32, 64): appends to
-    // different queues hit different lines (same-line atomics are serialised memory-side); per-depth history from word 96 on
-    auto QC = [&](int i) { return &w->counters[i < 8 ? i * 32 : 96 + (i - 8)]; };
-    HIP_TRY(hipMemsetAsync(w->counters, 0, 256 * 8, st));
-    HIP_TRY(hipMemcpyAsync(QC(0), &w->n, 8, hipMemcpyHostToDevice, st));
+    // Queue counters: one per queue AND depth — the path queue that depth d reads (word 32 d; depth 0: the n camera rays) and the shadow queue
+    // depth d fills (word 32 (9 + d)) —, each on its own 256-byte line (appends to different queues hit different lines; same-line atomics are
+    // serialised memory-side).  Nothing is reused within a frame, so nothing has to be cleared or copied between the stages: k_wf_generate sets
+    // them all, and the per-depth history of the statistics IS the counters.  (Until round 3 two path counters and one shadow counter were
+    // recycled: 13 memsets and 7 copies per 3-bounce frame, each a launch of its own — 0.18 of the 0.92 ms of a 1280 x 720 frame.)
+    auto QP = [&](uint32_t d) { return &w->counters[32u * d]; };
+    auto QS = [&](uint32_t d) { return &w->counters[32u * (9u + d)]; };
     CameraArgs ca;
     memcpy(ca.eye, cam->eye, 12); memcpy(ca.p1, cam->p1, 12); memcpy(ca.p2, cam->p2, 12); memcpy(ca.p3, cam->p3, 12);
     ca.width = cam->width; ca.height = cam->height; ca.sppX = ca.sppY = 1;
-    launch_wf_generate(ca, w->rays[0], w->aux[0], w->n, p->seed, w->firstRow, w->height, st);
+    launch_wf_generate(ca, w->rays[0], w->aux[0], w->n, p->seed, w->firstRow, w->height, w->counters, kWfCounterWords, st);
     int cur = 0;
     for (uint32_t d = 0; d < maxDepth; d++) {
         const int nxt = cur ^ 1;
         // Extend: nearest hit of every live path; the batch size lives on the device
-        if (int r = launchQuery(scene, w->rays[cur], w->n, nullptr, false, 1e30f, QC(cur))) return r;
-        HIP_TRY(hipMemsetAsync(QC(nxt), 0, 8, st));
-        HIP_TRY(hipMemsetAsync(QC(2), 0, 8, st));
+        if (int r = launchQuery(scene, w->rays[cur], w->n, nullptr, false, 1e30f, QP(d))) return r;
         ShadeArgs a;
-        a.in = w->rays[cur]; a.auxIn = w->aux[cur]; a.nIn = QC(cur);
-        a.out = w->rays[nxt]; a.auxOut = w->aux[nxt]; a.nOut = QC(nxt);
-        a.shadow = w->shadow; a.shadowAux = w->shadowAux; a.nShadow = QC(2);
+        a.in = w->rays[cur]; a.auxIn = w->aux[cur]; a.nIn = QP(d);
+        a.out = w->rays[nxt]; a.auxOut = w->aux[nxt]; a.nOut = QP(d + 1);
+        a.shadow = w->shadow; a.shadowAux = w->shadowAux; a.nShadow = QS(d);
         a.verts = (const float4*)dVerts; a.accum = w->accum;
         a.blasVerts = scene->isTlas ? w->blasVerts : nullptr; a.instances = scene->isTlas ? scene->instances : nullptr;
         a.blueNoise = w->blueNoise; a.sampleIdx = p->sample_index; a.width = w->width; a.height = fullH; a.pixelOffset = w->firstRow * w->width;
@@ -1564,20 +1574,18 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
         a.eps = p->eps; a.depth = d; a.maxDepth = maxDepth; a.seed = p->seed;
         launch_wf_shade(a, w->n, st);
         // Connect: any-hit over the shadow queue, then add what is unoccluded
-        if (int r = launchQuery(scene, w->shadow, w->n, w->occ, false, 1e30f, QC(2))) return r;
-        launch_wf_connect(w->occ, w->shadowAux, QC(2), w->accum, w->n, st);
-        HIP_TRY(hipMemcpyAsync(QC(8 + 2 * d), QC(cur), 8, hipMemcpyDeviceToDevice, st));
-        HIP_TRY(hipMemcpyAsync(QC(9 + 2 * d), QC(2), 8, hipMemcpyDeviceToDevice, st));
+        if (int r = launchQuery(scene, w->shadow, w->n, w->occ, false, 1e30f, QS(d))) return r;
+        launch_wf_connect(w->occ, w->shadowAux, QS(d), w->accum, w->n, st);
         cur = nxt;
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(w->e1, st));
     if (stats) {
-        unsigned long long h[64];
-        HIP_TRY(hipMemcpyAsync(h, QC(8), sizeof h, hipMemcpyDeviceToHost, st));
+        std::vector<unsigned long long> h(kWfCounterWords);
+        HIP_TRY(hipMemcpyAsync(h.data(), w->counters, (size_t)kWfCounterWords * 8, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         memset(stats, 0, sizeof *stats);
-        for (uint32_t d = 0; d < maxDepth; d++) { stats->extend_rays[d] = h[2 * d]; stats->shadow_rays[d] = h[1 + 2 * d]; }
+        for (uint32_t d = 0; d < maxDepth; d++) { stats->extend_rays[d] = h[32u * d]; stats->shadow_rays[d] = h[32u * (9u + d)]; }
         HIP_TRY(hipEventElapsedTime(&stats->frame_ms, w->e0, w->e1));
         if (int r = checkStatus(c)) return r;
     }
@@ -1620,10 +1628,10 @@ int tbvh_wavefront_render_sharded(tbvh_wavefront* const* wfs, tbvh_scene* const*
         if (int r = checkStatus(c)) return r;
         if (stats) {
             const uint32_t maxDepth = p->max_depth ? (p->max_depth > 8 ? 8 : p->max_depth) : 3;
-            unsigned long long h[64];
-            HIP_TRY(hipMemcpy(h, &w->counters[96], sizeof h, hipMemcpyDeviceToHost));
+            std::vector<unsigned long long> h(kWfCounterWords);
+            HIP_TRY(hipMemcpy(h.data(), w->counters, (size_t)kWfCounterWords * 8, hipMemcpyDeviceToHost));
             memset(&stats[i], 0, sizeof stats[i]);
-            for (uint32_t d = 0; d < maxDepth; d++) { stats[i].extend_rays[d] = h[2 * d]; stats[i].shadow_rays[d] = h[1 + 2 * d]; }
+            for (uint32_t d = 0; d < maxDepth; d++) { stats[i].extend_rays[d] = h[32u * d]; stats[i].shadow_rays[d] = h[32u * (9u + d)]; }
             HIP_TRY(hipEventElapsedTime(&stats[i].frame_ms, w->e0, w->e1));
         }
     }

@@ -114,6 +114,7 @@ struct QueryArgs {
     uint32_t* spill;       // global overflow area for traversal stacks
     uint32_t spillStride;  // entries per lane in `spill`
     uint32_t* counter;     // dynamic ray-fetch counters (persistent kernels): poolParts of them, 256 bytes apart
+    uint32_t* counterNext; // the counter area of the next launch on this context: zeroed by this one (ray_pool.h: RayPool::init); nullptr: no
     uint32_t poolParts;    // log2 of the number of partitions of the batch, each with its own counter (ray_pool.h)
     unsigned long long* stats;  // instrumented variants: lane-utilisation counters
     const unsigned long long* nRaysDev;  // if non-null the batch size is read from device memory (on-device queues)

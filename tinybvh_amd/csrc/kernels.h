@@ -110,7 +110,8 @@ struct ShadeArgs {
     const uint32_t* blueNoise; uint32_t sampleIdx, width, height;   // 128 x 128 x 8 table (or nullptr), the frame's sample index, size of the FULL image
     uint32_t pixelOffset;   // a band of a larger image (tbvh_wavefront_set_band): index of the band's first pixel in the full image (else 0)
 };
-void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint64_t n, uint32_t seed, uint32_t firstRow, uint32_t bandRows, hipStream_t s);
+void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint64_t n, uint32_t seed, uint32_t firstRow, uint32_t bandRows, unsigned long long* queueCounters,
+                        uint32_t nCounterWords, hipStream_t s);
 void launch_wf_shade(const ShadeArgs& a, uint64_t capacity, hipStream_t s);
 void launch_wf_finalize(const float* accum, float scale, uint32_t* pixels, uint64_t n, hipStream_t s);
 void launch_wf_connect(const uint8_t* occ, const PathAux* aux, const unsigned long long* nShadow, float* accum, uint64_t capacity, hipStream_t s);

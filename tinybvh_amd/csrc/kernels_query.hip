@@ -49,7 +49,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
     st.init(&stk[0][threadIdx.x], q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
-    pool.init(q.poolParts);
+    pool.init(q.poolParts, q.counterNext);
 
     bool active = false;
     uint64_t ri = 0;
@@ -179,7 +179,7 @@ __device__ __forceinline__ void bvh4_body(const float4* __restrict__ data, const
     st.init(&stk[0][threadIdx.x], q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;   // batch size may live on the device (wavefront queues)
-    pool.init(q.poolParts);
+    pool.init(q.poolParts, q.counterNext);
     const unsigned long long tStart = TIMELINE ? wall_clock64() : 0ull;
     unsigned long long tDry = 0ull;
 

@@ -351,7 +351,7 @@ __device__ __forceinline__ void tlas_flat_body(const float4* __restrict__ tlasNo
     st.init(&stk[0][threadIdx.x], (uint2*)q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);       \
     RayPool<64> pool;                                                                                                               \
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays; /* batch size may live on the device (wavefront queues) */      \
-    pool.init(q.poolParts);
+    pool.init(q.poolParts, q.counterNext);
 
 // register budgets: 6 waves per SIMD for one BLAS layout, 5 when the layout is picked per instance (three BLAS steps inlined)
 template <bool ANYHIT, int BLAS_LAYOUT, int LDS_N = 12, int REFILL_MIN = 16, int PHASE_MIN = 16>

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
     st.init(&stk[0][threadIdx.x], q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;
-    pool.init(q.poolParts);
+    pool.init(q.poolParts, q.counterNext);
     __shared__ SplitLds<STEAL ? WG : 1> split;
     int grp = -1;
 

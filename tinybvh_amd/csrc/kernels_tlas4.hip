@@ -55,7 +55,7 @@ __device__ __forceinline__ void tlas4_body(const float4* __restrict__ tlas4, con
     st.init(&stk[0][threadIdx.x], q.spill + (blockIdx.x * WG + threadIdx.x), (size_t)gridDim.x * WG, q.spillStride);
     RayPool<64> pool;
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;
-    pool.init(q.poolParts);
+    pool.init(q.poolParts, q.counterNext);
 
     bool active = false, found = false, inBlas = false;
     uint64_t ri = 0;

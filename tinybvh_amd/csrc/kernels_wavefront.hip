@@ -72,7 +72,12 @@ __device__ __forceinline__ uint32_t queue_slot(bool want, unsigned long long* co
     return want ? slot : 0xffffffffu;
 }
 
-__global__ void k_wf_generate(CameraArgs cam, RayRec* __restrict__ rays, PathAux* __restrict__ aux, uint64_t n, uint32_t seed, uint32_t firstRow, uint32_t bandRows) {
+__global__ void k_wf_generate(CameraArgs cam, RayRec* __restrict__ rays, PathAux* __restrict__ aux, uint64_t n, uint32_t seed, uint32_t firstRow, uint32_t bandRows,
+                              unsigned long long* __restrict__ queueCounters, uint32_t nCounterWords) {
+    // the frame's queue counters (one per queue and depth, each on its own 256-byte line: capi.hip) start at zero, the first path queue at n — set
+    // here instead of by a memset and a copy in the stream (each a launch of its own: ~8 us with the gap around it)
+    if (queueCounters && blockIdx.x == 0)
+        for (uint32_t k = threadIdx.x; k < nCounterWords; k += blockDim.x) queueCounters[k] = k == 0u ? n : 0ull;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     // same pixel order as k_gen_primary (4x4 tiles), one jittered sample per pixel
@@ -259,8 +264,9 @@ __global__ void k_wf_connect(const uint8_t* __restrict__ occluded, const PathAux
 
 }  // namespace
 
-void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint64_t n, uint32_t seed, uint32_t firstRow, uint32_t bandRows, hipStream_t s) {
-    hipLaunchKernelGGL(k_wf_generate, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, cam, rays, aux, n, seed, firstRow, bandRows);
+void launch_wf_generate(const CameraArgs& cam, RayRec* rays, PathAux* aux, uint64_t n, uint32_t seed, uint32_t firstRow, uint32_t bandRows, unsigned long long* queueCounters,
+                        uint32_t nCounterWords, hipStream_t s) {
+    hipLaunchKernelGGL(k_wf_generate, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, cam, rays, aux, n, seed, firstRow, bandRows, queueCounters, nCounterWords);
 }
 void launch_wf_shade(const ShadeArgs& a, uint64_t capacity, hipStream_t s) {
     hipLaunchKernelGGL(k_wf_shade, dim3((uint32_t)((capacity + kShadeBlock - 1) / kShadeBlock)), dim3(kShadeBlock), 0, s, a);

@@ -67,9 +67,17 @@ template <int CHUNK> struct RayPool {
     uint32_t partsLog2;   // the batch's chunks are dealt to 2^partsLog2 stripes
     bool exhausted;       // wave-uniform: the stripe ran past the end of the batch
 
-    __device__ __forceinline__ void init(uint32_t log2Parts) {
+    // zeroOther: the counter area of the NEXT launch on this context (two areas alternate, capi.hip: launchQuery) — the launch before this
+    // one drew from it and is over, the one after this one will find it zero without a memset of its own in the stream (a fill kernel and
+    // the gap around it: ~8 us of a 120 us launch; a 1280 x 720 path-traced frame is 6 such launches)
+    __device__ __forceinline__ void init(uint32_t log2Parts, uint32_t* zeroOther = nullptr) {
         next = end = 0; exhausted = false; partsLog2 = log2Parts;
         stripe = blockIdx.x & ((1u << log2Parts) - 1u);
+        if (zeroOther && blockIdx.x == 0)
+            for (uint32_t i = threadIdx.x; i <= (uint32_t)kPoolParts; i += blockDim.x) {
+                zeroOther[(size_t)i * kPoolCounterStride] = 0u;
+                if (i == (uint32_t)kPoolParts) zeroOther[(size_t)i * kPoolCounterStride + 1u] = 0u;   // (the coherence probe's two words)
+            }
     }
     __device__ __forceinline__ bool dry() const { return exhausted && next == end; }
 
