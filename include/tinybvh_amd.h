@@ -215,7 +215,11 @@ int tbvh_occluded(tbvh_scene* scene, const void* rays, uint64_t n_rays,
  * t <= hit.t), so its answer depends on the traversal order and its own layouts disagree with each other there; this
  * library reports the one with the smaller primitive index (TLAS: then the smaller instance index), whatever the layout,
  * the schedule or the batch size — the same bytes from run to run.  (Residual, shared with every BVH traversal including
- * the reference's: a triangle lying exactly IN a face of its leaf box can be culled by a hit within a few ulps of it.) */
+ * the reference's: a triangle lying exactly IN a face of its leaf box can be culled by a hit within a few ulps of it.)
+ * Rays with a zero-length direction (rD = 1e30, tinybvh_safercp) or an infinite origin get the reference's answer; rays with NaN components
+ * or an infinite direction component are traced without fault and without disturbing other rays, but what they report is unspecified
+ * (the reference's own answer for them depends on the order of its comparisons).  Degenerate and duplicate triangles are fine
+ * (tests/test_gpu_parity.py: test_hostile_geometry_and_rays). */
 int tbvh_intersect_device(tbvh_scene* scene, void* d_rays64, uint64_t n_rays);
 int tbvh_occluded_device(tbvh_scene* scene, const void* d_rays64, uint64_t n_rays,
                          uint8_t* d_occluded);

@@ -164,6 +164,55 @@ def test_edge_cases(ctx, oracle, soup, layout):
     assert np.all(wide[:, 1]["t"] == 99.0)
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_hostile_geometry_and_rays(ctx, oracle, layout):
+    """Degenerate triangles (zero area: two or three equal vertices, collinear), exact duplicates (every hit a tie), a triangle a million times
+    the scene's size; rays from inside the geometry, along box faces, with zero-length, infinite and NaN components.  Finite rays: the oracle's
+    records.  The others: the launch returns, and whatever the reference arithmetic does with them (comparisons with NaN are false: a miss) is
+    what the kernels do too for zero-length directions and infinite origins; NaN components and infinite direction components are unspecified
+    (include/tinybvh_amd.h) — the test prints how many differ and requires only that the launch returns and the rays next to them are untouched."""
+    rng = np.random.default_rng(5)
+    base = scenes.soup(3000, seed=11).reshape(-1, 3, 4)
+    degenerate = base[:60].copy()
+    degenerate[:20, 1] = degenerate[:20, 0]                                   # two equal vertices
+    degenerate[20:40, 1] = degenerate[20:40, 0]; degenerate[20:40, 2] = degenerate[20:40, 0]   # a point
+    degenerate[40:, 2] = 2 * degenerate[40:, 1] - degenerate[40:, 0]          # collinear
+    dup = base[100:400].copy()                                                # exact duplicates of triangles already in the scene
+    huge = np.array([[[-1e6, -1e6, 5.0, 0], [1e6, -1e6, 5.0, 0], [0, 1e6, 5.0, 0]]], np.float32)
+    verts = np.ascontiguousarray(np.concatenate([base, degenerate, dup, huge]).reshape(-1, 4), np.float32)
+    sc = upload(ctx, layout, verts)
+    rays = R.random_rays(20_000, (0, 0, 0), (10, 10, 10), seed=3)
+    tri = base[rng.integers(0, base.shape[0], 4000)]
+    inside = R.random_rays(4000, (0, 0, 0), (10, 10, 10), seed=4)
+    inside["O"][:, :3] = tri[:, :, :3].mean(1)                                # origins ON triangles
+    finite = np.concatenate([rays, inside])
+    want = oracle_hits(oracle, sc, verts, finite)
+    got = sc.Intersect(finite.copy())
+    c = compare_hits(got, want, rtol=1e-5)
+    assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] == 0, c
+    assert c["bit_identical"] == c["same_prim"], c
+    assert c["hits"] > 15_000
+    occ = sc.IsOccluded(finite.copy())
+    assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+    # non-finite rays: zero direction, NaN direction, NaN origin, infinite origin, infinite direction component
+    bad = R.random_rays(640, (0, 0, 0), (10, 10, 10), seed=6)
+    bad["D"][0:128, :3] = 0.0; bad["rD"][0:128, :3] = np.float32(1e30)
+    bad["D"][128:256, 0] = np.nan; bad["rD"][128:256, 0] = np.nan
+    bad["O"][256:384, 1] = np.nan
+    bad["O"][384:512, 2] = np.inf
+    bad["D"][512:640, 1] = np.inf; bad["rD"][512:640, 1] = 0.0
+    mixed = np.concatenate([bad, rays[:6400]])
+    with np.errstate(all="ignore"):
+        want_m = oracle_hits(oracle, sc, verts, mixed)
+    got_m = sc.Intersect(mixed.copy())                                        # returns (no hang, no fault)
+    assert np.array_equal(got_m[640:].view(np.uint8), got[:6400].view(np.uint8))   # the finite rays next to them are not disturbed
+    same = (got_m["prim"][:640] == want_m["prim"][:640]) & ((got_m["t"][:640] == want_m["t"][:640]) | (np.isnan(got_m["t"][:640]) & np.isnan(want_m["t"][:640])))
+    per_class = [int((~same[k:k + 128]).sum()) for k in range(0, 640, 128)]
+    print("non-finite rays that differ from the restated reference, per class (zero D, NaN D, NaN O, inf O, inf D):", per_class)
+    assert per_class[0] == 0 and per_class[3] == 0, per_class                 # zero-length directions (rD = 1e30: tinybvh_safercp) and infinite origins: as the reference
+    assert sc.IsOccluded(mixed.copy()).shape[0] == mixed.shape[0]
+
+
 def check_ref(got, want):
     """Reference-encoded BVH4_GPU blobs quantise child boxes with 254.999/extent
     (tiny_bvh.h:5196-5231), which can fall short of the true box by 4e-6 relative: a grazing
