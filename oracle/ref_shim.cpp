@@ -31,6 +31,7 @@ struct RefScene {
     bvhvec4* verts = nullptr;  // owned copy, 64-byte aligned
     uint32_t triCount = 0;
     bool hq = false;
+    int optimize = 0;   // > 0: BVH8_CWBVH::Build followed by ::Optimize(optimize) (the reinsertion optimiser, tiny_bvh.h:4338-4449) — tools/ref_blobs_probe.py only
     BVH bvh;                   // the oracle tree (Build or BuildHQ)
     BVH_GPU* gpu2 = nullptr;
     BVH4_GPU* gpu4 = nullptr;
@@ -79,11 +80,12 @@ const char* ref_version() {
 // threaded = 0 forces single-threaded builds for byte-stable output.
 void* ref_build(const void* verts16, uint32_t triCount, int hq, int threaded) {
     RefScene* s = new RefScene;
-    s->triCount = triCount; s->hq = hq != 0;
+    s->triCount = triCount; s->hq = hq == 1;
+    if (hq >= 100) s->optimize = hq - 100;   // (hq = 100 + iterations: Build + Optimize, CWBVH layout only)
     s->verts = (bvhvec4*)malloc64((size_t)triCount * 48);
     std::memcpy((void*)s->verts, verts16, (size_t)triCount * 48);
     s->bvh.threadedBuild = threaded != 0;
-    if (hq) s->bvh.BuildHQ(s->verts, triCount); else s->bvh.Build(s->verts, triCount);
+    if (hq == 1) s->bvh.BuildHQ(s->verts, triCount); else s->bvh.Build(s->verts, triCount);
     return s;
 }
 void ref_free(void* h) {
@@ -103,7 +105,11 @@ static bool ensureLayout(RefScene* s, int layout) {
     if (layout != L_BVH && layout != L_BVH_GPU && layout != L_BVH4_GPU && layout != L_CWBVH && layout != L_BVH8_CPU) return false;
     if (layout == L_BVH_GPU && !s->gpu2) { s->gpu2 = new BVH_GPU(); if (s->hq) s->gpu2->BuildHQ(s->verts, s->triCount); else s->gpu2->Build(s->verts, s->triCount); }
     if (layout == L_BVH4_GPU && !s->gpu4) { s->gpu4 = new BVH4_GPU(); if (s->hq) s->gpu4->BuildHQ(s->verts, s->triCount); else s->gpu4->Build(s->verts, s->triCount); }
-    if (layout == L_CWBVH && !s->cw) { s->cw = new BVH8_CWBVH(); if (s->hq) s->cw->BuildHQ(s->verts, s->triCount); else s->cw->Build(s->verts, s->triCount); }
+    if (layout == L_CWBVH && !s->cw) {
+        s->cw = new BVH8_CWBVH();
+        if (s->hq) s->cw->BuildHQ(s->verts, s->triCount); else s->cw->Build(s->verts, s->triCount);
+        if (s->optimize > 0) s->cw->Optimize((uint32_t)s->optimize, false);
+    }
     if (layout == L_BVH8_CPU && !s->cpu8) { s->cpu8 = new BVH8_CPU(); if (s->hq) s->cpu8->BuildHQ(s->verts, s->triCount); else s->cpu8->Build(s->verts, s->triCount); }
     return true;
 }

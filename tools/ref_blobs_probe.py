@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--side", type=int, default=2048)
     ap.add_argument("--layouts", default="10,8,5")
     ap.add_argument("--hq", type=int, default=1)
+    ap.add_argument("--optimize", default="", help="also Build + Optimize(n) trees of the reinsertion optimiser (BVH8_CWBVH only), e.g. 25,50")
     a = ap.parse_args()
     assert have_reference(), "oracle/_ref/libtinybvh_ref.so missing (built by oracle/Makefile where /root/reference exists)"
     ref = Reference(); orc = Oracle()
@@ -81,11 +82,13 @@ def main():
         ctx.from_device(full, d_prim); psample = full[::stride][: sample.shape[0]].copy(); psample["t"] = 1e30
         del full
         rows = []
-        for hq in ([0, 1] if a.hq else [0]):
+        for hq in ([0, 1] if a.hq else [0]) + [100 + int(x) for x in a.optimize.split(",") if x]:
             t0 = time.time()
-            rs = ref.build(verts, hq=bool(hq), threaded=True)
-            tag = "tiny_bvh.h BuildHQ" if hq else "tiny_bvh.h Build"
+            rs = ref.build(verts, hq=hq, threaded=True)
+            tag = f"tiny_bvh.h Build+Optimize({hq - 100})" if hq >= 100 else "tiny_bvh.h BuildHQ" if hq else "tiny_bvh.h Build"
             for L in own:
+                if hq >= 100 and L != 10:
+                    continue
                 t1 = time.time()
                 if L == 5:
                     sc = tb.BVH_GPU(ctx).Upload(rs.blob(5, 0, np.uint32, 16), rs.blob(5, 1, np.uint32, 1), verts)
@@ -95,7 +98,7 @@ def main():
                     nodes, tris = rs.blob(10, 0, np.uint32, 4), rs.blob(10, 1, np.uint32, 4)
                     sc = tb.BVH8_CWBVH(ctx).Upload(nodes, tris)
                 r = time_scene(ctx, sc, batches, n)
-                r.update(layout=L, tree=tag, mb=sc.device_bytes / 1e6, build_s=time.time() - t1)
+                r.update(layout=L, tree=tag + f" [{time.time() - t0:.1f} s]", mb=sc.device_bytes / 1e6, build_s=time.time() - t1)
                 if L == 10:
                     for kind, smp in (("primary", psample), ("diffuse", dsample)):
                         _, cnt = orc.cwbvh_intersect(nodes, tris, smp, counts=True)
@@ -116,7 +119,7 @@ def main():
         for L in own:
             for r in [x for x in rows if x["layout"] == L]:
                 extra = f"  S/T primary {r['primary_S']:.1f}/{r['primary_T']:.1f}  diffuse {r['diffuse_S']:.1f}/{r['diffuse_T']:.1f}" if "diffuse_S" in r else ""
-                print(f"  {names[L]:11s} {r['tree']:22s} {r['mb']:7.1f} MB  primary {r['primary']:7.1f}  diffuse {r['diffuse']:7.1f}  shadow {r['shadow']:7.1f} MRays/s{extra}", flush=True)
+                print(f"  {names[L]:11s} {r['tree']:32s} {r['mb']:7.1f} MB  primary {r['primary']:7.1f}  diffuse {r['diffuse']:7.1f}  shadow {r['shadow']:7.1f} MRays/s{extra}", flush=True)
         for d in batches:
             ctx.free(d)
         for sc in own.values():
