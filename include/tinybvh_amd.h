@@ -94,7 +94,8 @@ int tbvh_upload_bvh4_gpu(tbvh_context* ctx, const void* blocks16, uint64_t n_blo
 
 /* BVH8_CWBVH.  nodes16 = bvh8Data, n_node_blocks = usedBlocks (5 per node);
  * tris16 = bvh8Tris, n_tri_blocks = 3 * idxCount (tiny_bvh.h:1356-1359;
- * tiny_bvh_speedtest.cpp:1200-1204). */
+ * tiny_bvh_speedtest.cpp:1200-1204).  The default triangle records only (48 bytes: e2, e1, v0 | prim): blobs built with the reference's
+ * experimental CWBVH_COMPRESSED_TRIS switch (tiny_bvh.h:170-171, off by default; 64-byte records) are refused with TBVH_E_FORMAT. */
 int tbvh_upload_cwbvh(tbvh_context* ctx, const void* nodes16, uint64_t n_node_blocks,
                       const void* tris16, uint64_t n_tri_blocks, tbvh_scene** out);
 

@@ -287,6 +287,12 @@ def test_malformed_blobs_are_rejected_at_upload(ctx, soup):
         tb.BVH8_CWBVH(ctx).Upload(h.blob(0, np.uint32, 4), tris[:30])      # triangle array too short
     with pytest.raises(tb.TbvhError):
         tb.BVH8_CWBVH(ctx).Upload(h.blob(0, np.uint32, 4)[:7], tris)       # not a multiple of 5 blocks
+    # a blob in the reference's experimental CWBVH_COMPRESSED_TRIS form counts triangle records in fours (tiny_bvh.h:5999-6003): refused
+    c4 = h.blob(0, np.uint32, 4).copy().reshape(-1, 5, 4)
+    c4[:, 1, 1] = c4[:, 1, 1] // 3 * 4
+    tris4 = np.zeros((tris.shape[0] // 3 * 4, 4), np.uint32)
+    with pytest.raises(tb.TbvhError, match="COMPRESSED_TRIS"):
+        tb.BVH8_CWBVH(ctx).Upload(c4.reshape(-1, 4), tris4)
     h4 = tb.HostBVH(soup, tb.LAYOUT_BVH4_GPU)
     b = h4.blob(0, np.uint32, 4).copy(); b[3, 0] = 0x7fffff00             # child offset far outside
     with pytest.raises(tb.TbvhError):

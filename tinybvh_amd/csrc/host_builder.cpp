@@ -897,6 +897,9 @@ const char* validate_cwbvh(const Vec4* nodes, uint64_t nNodes, uint64_t nTriBloc
             maxTri = std::max(maxTri, (m & 31) + c);
         }
         if (maxTri > 24) return "CWBVH node: more than 24 triangles";
+        // 48-byte records {e2, e1, v0 | prim}: three float4 each.  A blob made with CWBVH_COMPRESSED_TRIS (tiny_bvh.h:170-171, an experimental
+        // switch: 64-byte Baldwin-Weber records, four float4 each) counts in fours
+        if (maxTri && triBase % 3u != 0u) return "CWBVH node: triangle base is not a multiple of 3 float4 (a CWBVH_COMPRESSED_TRIS blob? that experimental format is not supported)";
         if (maxTri && (uint64_t)triBase + 3ull * maxTri > nTriBlocks) return "CWBVH node: triangle range exceeds the triangle array";
     }
     return nullptr;
