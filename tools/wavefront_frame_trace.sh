@@ -1,6 +1,8 @@
 #!/bin/bash
+# A 1280 x 720 path-traced frame kernel by kernel: rocprofv3 --kernel-trace of tools/wavefront_small_frame.py, then per steady-state frame the
+# wall time, the time inside kernels, the launches by name and the gaps between them (how DESIGN.md par. 10 found the 20 fill / copy launches).
 set -u
-O=$PWD/gpurun_out/r03_14
+O=$PWD/gpurun_out/frame_trace
 mkdir -p $O
 export TMPDIR=/tmp
 HERE=$PWD
@@ -11,7 +13,7 @@ tail -3 $O/run.txt
 python - <<'PY'
 import csv, glob, os
 from collections import defaultdict
-d = "gpurun_out/r03_14/kt"
+d = "gpurun_out/frame_trace/kt"
 tr = []
 for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     tr += list(csv.DictReader(open(f)))
