@@ -424,7 +424,10 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                 launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, blocks, c->stream, 5, small, blocks7);
                 HIP_TRY(hipGetLastError());
                 QueryArgs qb = q;
-                const uint32_t wB = (c->expFlags >> 8) & 0xffu;   // experiment: waves per CU of the incoherent flavor
+                // the incoherent flavor on 28 one-wave workgroups per CU when the batch fills the grid (24 is the persistent grid's size: 20 / 26 / 28 / 30 /
+                // 32 per CU trace bounce rays at -4.4 / +0.6 / +0.9 / +0.5 / +0.5 %, interleaved medians of 13 rounds)
+                const uint32_t wX = (c->expFlags >> 8) & 0xffu;   // experiment: another number of waves per CU
+                const uint32_t wB = wX ? wX : (c->gridOverride ? 0u : 28u);
                 launch_cwbvh(any, 0, s->nodesHy, s->tris64, qb, c->status, (wB && blocksBase == c->blocks) ? (uint32_t)c->numCUs * wB : blocksBase, c->stream, 13, small, blocks7);
             } else
                 launch_cwbvh(any, s->variant, autoPad ? s->nodes128 : s->nodes, tris, q, c->status, blocks, c->stream, autoPad ? 8 : 5, small, blocks7);
