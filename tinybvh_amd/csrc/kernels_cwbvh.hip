@@ -48,6 +48,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
     pool.init(q.poolParts, q.counterNext);
     LockstepGovernor gov;
     gov.init();
+    if (PROBED == 2) gov.lockstep = false;   // the probe has said the batch is incoherent: no lockstep generation to find that out again (4 M bounce rays +1 %)
     // PROBED: the batch's coherence probe (QueryArgs::probe) picks the schedule for the whole launch: coherent batches (camera rays, shadow rays
     // towards one light) are VALU-bound and run deferred triangles + a gated triangle phase on a third more waves; incoherent ones are bound by
     // the cache-miss path and keep the strict schedule.  PROBED == 1: this kernel holds both schedules (waves beyond q.baseBlocks leave at once
