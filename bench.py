@@ -22,7 +22,9 @@ timed with the same barrier / max-over-ranks rule: strong scaling.
 `roofline` carries the contract's algorithmic-HBM line for the dominant kernel (diffuse batch) and for the primary batch,
 the measured device copy bandwidth as a second denominator, the fabric-side traffic measured LIVE by a rocprofv3 --pmc
 child run of this same script (FETCH_SIZE and WRITE_SIZE in separate passes, MI355X_MICROARCH.md corrections), and the
-VALU-issue roofline of both kernels (what actually bounds them: DESIGN.md §5).
+VALU-issue roofline of both kernels (what actually bounds them: DESIGN.md §5).  `detail.hbm_regime` prices the same kernels against HBM where
+they really fetch from it: the street generator at 30 M triangles (3.3 GB of tree), S / T per ray from the instrumented kernel, bytes from two
+more rocprofv3 --pmc children (hbm_regime below).
 
 One process per GPU; launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -59,6 +61,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip detail.config1 / config2 / reference_blob")
     ap.add_argument("--one-process-devices", type=int, default=0, help="also trace config 4's 64 M-ray batch from THIS process over K contexts (device i mod the visible devices) through tbvh_intersect_sharded_device")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--device-build", action="store_true", help="build the layout on the device (tbvh_build_device: LBVH) instead of the host builder")
+    ap.add_argument("--no-hbm-regime", action="store_true", help="skip detail.hbm_regime (the same kernels on a 30 M-triangle scene, beyond the Infinity Cache)")
+    ap.add_argument("--hbm-child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,7 +106,7 @@ def main():
     # N ranks build the same BVH at the same time on one host: give each its share of the cores (the build is deterministic
     # whatever the thread count)
     build_threads = max(1, usable_cores() // world) if world > 1 else 0
-    sc = tb.LAYOUT_CLASSES[a.layout](ctx).Build(verts, threads=build_threads)
+    sc = tb.LAYOUT_CLASSES[a.layout](ctx).BuildOnDevice(verts) if a.device_build else tb.LAYOUT_CLASSES[a.layout](ctx).Build(verts, threads=build_threads)
     if a.variant:
         sc.set_variant(a.variant)
     if rank == 0:
@@ -109,7 +114,7 @@ def main():
 
     # ---- ray batches on the device (untimed) -----------------------------------------------------
     n = a.side * a.side
-    cams = scenes.STREET_CAMERAS if a.scene == "bistro" else scenes.SPONZA_CAMERAS
+    cams = scenes.STREET_CAMERAS if (a.scene == "bistro" or a.scene.startswith("street")) else scenes.SPONZA_CAMERAS
     eye, view = cams[0]   # the same camera on every rank: equal work per GPU, so the N-GPU aggregate measures scaling, not workload differences
     cam = R.camera(eye, view, a.side, a.side, 1, 1)
     d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
@@ -138,6 +143,28 @@ def main():
             sc.intersect_device_fresh(d_prim, n, 1e30)
             sc.intersect_device_fresh(d_diff, n, 1e30)
         ctx.synchronize()
+        ctx.close()
+        return
+
+    if a.hbm_child:   # detail.hbm_regime: the timed kernels on a scene beyond the Infinity Cache; one JSON line, nothing else
+        import ctypes as C
+        out = {"scene": label, "triangles": n_tris, "bvh_mb": sc.device_bytes / 1e6, "rays_per_launch": n, "tree": "device LBVH" if a.device_build else "host SAH"}
+        for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
+            ms = []
+            for p_ in range(4):
+                sc.intersect_device_fresh(d, n, 1e30)
+                if p_:
+                    ms.append(ctx.time_last_ms())
+            out[kind + "_ms"] = float(np.mean(ms)); out[kind + "_mrays"] = n / (out[kind + "_ms"] * 1e-3) / 1e6
+        if a.layout == 10:
+            sc.set_variant(59)   # the instrumented strict kernel: node visits and triangle tests per ray
+            for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
+                st = (C.c_uint64 * 8)()
+                tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+                sc.intersect_device_fresh(d, n, 1e30)
+                tb.lib.tbvh_debug_stats(ctx._h, st, 1)
+                out[kind + "_S"] = int(st[2]) / n; out[kind + "_T"] = int(st[4]) / n
+        print(json.dumps(out), flush=True)
         ctx.close()
         return
 
@@ -362,6 +389,8 @@ def main():
             detail["config1"] = cfg12.get("config1")
             detail["config2"] = cfg12.get("config2")
         detail["reference_blob"] = ref_blob
+        if world == 1 and not a.no_hbm_regime and a.layout == 10:
+            detail["hbm_regime"] = hbm_regime(a, log)
 
         # ---- parity of the timed kernels, in this run (outside the timed region; the oracle is the checker, never the thing measured) -------
         # a strided 65 k sample of the primary and the diffuse batch: the GPU records the timed launches left in HBM against BVH::Intersect
@@ -649,6 +678,46 @@ def usable_cores():
     return max(1, n)
 
 
+def hbm_regime(a, log):
+    """north_star asks for ">= 50 % HBM roofline on the node-fetch loop"; the bench's own scene (184 MB of tree) lives in the L2s and the Infinity
+    Cache, so that bar is measured where the kernel really fetches from HBM: the same street generator at 30 M triangles (3.3 GB of nodes and
+    triangles, built on the device), 4.19 M camera rays and bounce rays (depth 1-3) per launch, the shipped kernels.  A child of this script
+    times the launches and counts node visits S / triangle tests T per ray with the instrumented kernel; two more children under
+    `rocprofv3 --pmc` give the bytes fetched and written per launch.  Reported per ray kind: MRays/s, algorithmic bytes per ray
+    (80 S + 48 T + 64 + 16: SURVEY.md par. 8(d)), fetched bytes per ray, and both as TB/s against the 8 TB/s HBM peak."""
+    import copy
+    import subprocess
+    b = copy.copy(a)
+    b.scene, b.side, b.device_build, b.layout, b.variant = "street30m", 2048, True, 10, 0
+    cmd = [sys.executable, os.path.abspath(__file__), "--hbm-child", "--device-build", "--scene", b.scene, "--side", str(b.side), "--layout", "10"]
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=400, check=True)
+        out = json.loads([l for l in r.stdout.decode().split("\n") if l.startswith("{")][-1])
+    except Exception as e:
+        log(f"[bench] hbm_regime child failed: {e!r}")
+        return {"error": repr(e)}
+    n = out["rays_per_launch"]
+    traffic, src = (live_pmc_traffic(b, log) if not a.no_pmc else (None, None))
+    for kind in ("primary", "diffuse"):
+        alg = 80.0 * out.get(kind + "_S", 0.0) + 48.0 * out.get(kind + "_T", 0.0) + 80.0
+        sec = out[kind + "_ms"] * 1e-3
+        row = {"mrays": out[kind + "_mrays"], "node_visits_per_ray": out.get(kind + "_S"), "triangle_tests_per_ray": out.get(kind + "_T"),
+               "algorithmic_bytes_per_ray": alg, "algorithmic_tb_per_s": alg * n / sec / 1e12}
+        if traffic:
+            row["fabric_bytes_per_ray"] = traffic[kind] / n
+            row["fabric_tb_per_s"] = traffic[kind] / sec / 1e12
+            row["frac_of_hbm_peak"] = traffic[kind] / sec / 8e12
+        out[kind] = row
+    out["traffic_source"] = src
+    out["peak_tb_per_s"] = 8.0
+    for k in [k for k in list(out) if k.endswith(("_ms", "_mrays", "_S", "_T")) and "_" in k and k.split("_")[0] in ("primary", "diffuse")]:
+        out.pop(k)
+    return out
+
+
 def live_pmc_traffic(a, log):
     """Fabric-side bytes per launch of the two timed kernels, measured now: this script is run again as a short child
     (--pmc-child: same scene, same batches, three (primary, diffuse) launch pairs) under `rocprofv3 --pmc FETCH_SIZE` and,
@@ -668,7 +737,7 @@ def live_pmc_traffic(a, log):
         d = tempfile.mkdtemp(prefix="tbvh_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--output-format", "csv", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--scene", a.scene, "--side", str(a.side), "--layout", str(a.layout),
-               "--variant", str(a.variant)]
+               "--variant", str(a.variant)] + (["--device-build"] if getattr(a, "device_build", False) else [])
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST"):
             env.pop(k, None)

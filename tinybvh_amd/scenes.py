@@ -246,6 +246,9 @@ def get(name: str):
         return street(), "procedural street (Bistro-exterior stand-in, 2.83M tris, seed 2)"
     if name == "dragon":
         return blob(), "procedural blob (Dragon stand-in, 100k tris, seed 3)"
+    if name.startswith("street") and name.endswith("m"):   # the street generator at another size, e.g. street30m (scene-size sweeps)
+        m = float(name[6:-1])
+        return street(int(m * 1e6), seed=2), f"procedural street at {m:g} M triangles (seed 2)"
     raise KeyError(name)
 
 
