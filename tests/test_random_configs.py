@@ -1,0 +1,84 @@
+"""Randomised parity: many small (scene, layout, builder option, batch shape, entry point) combinations against the oracle — the cheap way to
+meet a corner no hand-written case names (ragged sizes around the wave and chunk boundaries, tmax classes, 64 / 128-byte strides, fresh and
+in-place entry points, host and device builders, device-resident and host-array calls, closest-hit and any-hit on the same rays)."""
+import numpy as np
+import pytest
+
+import tinybvh_amd as tb
+from tinybvh_amd import rays as R
+from tinybvh_amd import scenes
+from oracle_lib import compare_hits
+
+pytestmark = pytest.mark.gpu
+
+LAYOUTS = [tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU, tb.LAYOUT_CWBVH]
+
+
+def make_scene(rng):
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        return scenes.soup(int(rng.integers(1, 4000)), seed=int(rng.integers(1, 1 << 20)))
+    if kind == 1:
+        return scenes.blob(int(rng.integers(200, 6000)), seed=int(rng.integers(1, 1 << 20)))
+    if kind == 2:
+        return scenes.atrium(int(rng.integers(2000, 20000)), seed=int(rng.integers(1, 1 << 20)))
+    v = scenes.soup(int(rng.integers(50, 1500)), seed=int(rng.integers(1, 1 << 20))).reshape(-1, 3, 4)
+    return np.ascontiguousarray(np.concatenate([v, v[: max(1, v.shape[0] // 3)]]).reshape(-1, 4))   # duplicates: ties everywhere
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_configuration(ctx, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    verts = make_scene(rng)
+    layout = LAYOUTS[int(rng.integers(0, 3))]
+    opts = {}
+    if layout != tb.LAYOUT_BVH_GPU and rng.random() < 0.4:
+        opts["greedy_collapse"] = True
+    if rng.random() < 0.3:
+        opts["bins"] = int(rng.choice([4, 16, 32]))
+    on_device = layout != tb.LAYOUT_BVH_GPU and rng.random() < 0.3
+    cls = tb.LAYOUT_CLASSES[layout]
+    if on_device:
+        ploc = rng.random() < 0.5
+        sc = cls(ctx).BuildOnDevice(verts, builder="ploc", radius=int(rng.choice([0, 8, 32]))) if ploc else cls(ctx).BuildOnDevice(verts)
+        host = tb.HostBVH(verts, layout)
+    else:
+        sc = cls(ctx).Build(verts, **opts)
+        host = sc.host
+    lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+    pad = 0.1 * (hi - lo) + 0.01
+    n = int(rng.choice([1, 63, 64, 65, 127, 129, 4095, 4097, 20000, 33333]))
+    tmax = np.float32(rng.choice([1e30, float(np.linalg.norm(hi - lo)) * 0.3, 0.0]))
+    rays = R.random_rays(n, lo - pad, hi + pad, seed=int(rng.integers(1, 1 << 20)), tmax=tmax)
+    want = oracle.bvh2_intersect(host.bvh2_nodes(), host.bvh2_prim_idx(), verts, rays)
+
+    mode = int(rng.integers(0, 4))
+    if mode == 0:                                   # host array, packed
+        got = sc.Intersect(rays.copy())
+    elif mode == 1:                                 # host array, 128-byte stride in place
+        wide = np.zeros((n, 2), dtype=tb.RAY_DTYPE); wide[:, 0] = rays; wide[:, 1]["t"] = 7.0
+        flat = wide.reshape(-1)
+        import ctypes as C
+        tb.check(tb.lib.tbvh_intersect(sc._h, C.c_void_p(flat.ctypes.data), n, 128), "tbvh_intersect")
+        got = wide[:, 0].copy()
+        assert np.all(wide[:, 1]["t"] == 7.0)
+    elif mode == 2:                                 # device-resident, in place
+        d = ctx.malloc(n * 64); ctx.to_device(d, rays)
+        sc.intersect_device(d, n)
+        got = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(got, d); ctx.free(d)
+    else:                                           # device-resident, fresh entry point: every record written
+        d = ctx.malloc(n * 64); scrambled = rays.copy(); scrambled["t"] = 123.0; scrambled["prim"] = 77
+        ctx.to_device(d, scrambled)
+        sc.intersect_device_fresh(d, n, float(tmax))
+        got = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(got, d); ctx.free(d)
+        miss = want["t"] >= tmax if tmax < 1e30 else want["t"] >= 1e30
+        miss &= want["prim"] == rays["prim"]
+        want = want.copy(); want["u"][miss] = 0; want["v"][miss] = 0; want["prim"][miss] = 0; want["t"][miss] = tmax
+    c = compare_hits(got, want, rtol=1e-5)
+    assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] == 0, (seed, layout, opts, on_device, n, float(tmax), mode, c)
+    assert c["bit_identical"] == c["same_prim"], (seed, c)
+    # any-hit on the same rays: occluded iff the closest-hit oracle changed the record (a hit within [0, tmax])
+    ref = oracle.bvh2_intersect(host.bvh2_nodes(), host.bvh2_prim_idx(), verts, rays)
+    hit = (ref["prim"] != rays["prim"]) | (ref["t"] != rays["t"])
+    occ = sc.IsOccluded(rays.copy())
+    assert int((occ.astype(bool) != hit).sum()) <= max(2, n // 2000), (seed, layout, n, float(tmax), mode)
