@@ -82,3 +82,39 @@ def test_random_configuration(ctx, oracle, seed):
     hit = (ref["prim"] != rays["prim"]) | (ref["t"] != rays["t"])
     occ = sc.IsOccluded(rays.copy())
     assert int((occ.astype(bool) != hit).sum()) <= max(2, n // 2000), (seed, layout, n, float(tmax), mode)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_tlas_configuration(ctx, oracle, seed):
+    """The same for two-level scenes: 1-3 BLASes of random layouts (also mixed under one TLAS), 1-200 instances with random rigid + non-uniform
+    scale transforms and masks, random batch sizes; host TLAS build or the device rebuild; against BVH::IntersectTLAS restated."""
+    from test_tlas import grid_instances, oracle_tlas, check
+    rng = np.random.default_rng(5000 + seed)
+    n_blas = int(rng.integers(1, 4))
+    meshes = []
+    for k in range(n_blas):
+        m = scenes.blob(int(rng.integers(300, 4000)), seed=int(rng.integers(1, 1 << 20))) if rng.random() < 0.5 else scenes.soup(int(rng.integers(50, 1500)), seed=int(rng.integers(1, 1 << 20)), extent=1.6, size=0.25)
+        if m[:, :3].min() >= 0:
+            m = m.copy(); m[:, :3] -= 0.8
+        meshes.append(m)
+    mixed = rng.random() < 0.5
+    if mixed:
+        layouts = [[tb.LAYOUT_CWBVH, tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU][int(rng.integers(0, 3))] for _ in range(n_blas)]
+    else:
+        layouts = [[tb.LAYOUT_CWBVH, tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU][int(rng.integers(0, 3))]] * n_blas
+    blas = [tb.LAYOUT_CLASSES[l](ctx).Build(meshes[i]) for i, l in enumerate(layouts)]
+    side = int(rng.integers(1, 6))
+    inst = grid_instances(side, float(rng.uniform(0.3, 0.7)), int(rng.integers(1, 1 << 20)), n_blas=n_blas)
+    if rng.random() < 0.5:
+        inst["mask"][:: int(rng.integers(2, 6))] = 0x0001
+    tlas = tb.TLAS(ctx).Build(inst, blas)
+    if rng.random() < 0.4:
+        tlas.RebuildOnDevice()
+    n = int(rng.choice([1, 65, 4097, 30000]))
+    rays = R.random_rays(n, (-2, -2, -2), (2.0 * side + 1, 2.0 * side + 1, 2.0 * side + 1), seed=int(rng.integers(1, 1 << 20)))
+    if rng.random() < 0.5:
+        rays["mask"][::3] = 0x00F0
+    want = oracle_tlas(oracle, tlas, blas, rays)
+    check(tlas.Intersect(rays.copy()), want)
+    occ = tlas.IsOccluded(rays.copy())
+    assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
