@@ -1,6 +1,8 @@
 """Randomised parity: many small (scene, layout, builder option, batch shape, entry point) combinations against the oracle — the cheap way to
 meet a corner no hand-written case names (ragged sizes around the wave and chunk boundaries, tmax classes, 64 / 128-byte strides, fresh and
 in-place entry points, host and device builders, device-resident and host-array calls, closest-hit and any-hit on the same rays)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,6 +14,7 @@ from oracle_lib import compare_hits
 pytestmark = pytest.mark.gpu
 
 LAYOUTS = [tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU, tb.LAYOUT_CWBVH]
+N_SEEDS = int(os.environ.get("TBVH_RANDOM_SEEDS", "48"))   # a longer hunt: TBVH_RANDOM_SEEDS=2000 python -m pytest tests/test_random_configs.py -m gpu
 
 
 def make_scene(rng):
@@ -26,7 +29,7 @@ def make_scene(rng):
     return np.ascontiguousarray(np.concatenate([v, v[: max(1, v.shape[0] // 3)]]).reshape(-1, 4))   # duplicates: ties everywhere
 
 
-@pytest.mark.parametrize("seed", range(48))
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_configuration(ctx, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     verts = make_scene(rng)
@@ -84,7 +87,7 @@ def test_random_configuration(ctx, oracle, seed):
     assert int((occ.astype(bool) != hit).sum()) <= max(2, n // 2000), (seed, layout, n, float(tmax), mode)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(max(N_SEEDS // 3, 1)))
 def test_random_tlas_configuration(ctx, oracle, seed):
     """The same for two-level scenes: 1-3 BLASes of random layouts (also mixed under one TLAS), 1-200 instances with random rigid + non-uniform
     scale transforms and masks, random batch sizes; host TLAS build or the device rebuild; against BVH::IntersectTLAS restated."""
