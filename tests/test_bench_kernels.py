@@ -96,3 +96,51 @@ def test_probed_schedules_on_the_bench_scene(ctx, oracle):
     for p in (d_verts, d_a, d_b, d_occ):
         ctx.free(p)
     sc.free()
+
+
+@pytest.mark.parametrize("tris_m", [1.2, 2.832120])
+def test_probed_launches_random_batches(ctx, oracle, tris_m):
+    """The probed, two-flavor launches under batches nobody tuned for: scenes of the probed size class at two sizes, every camera of the
+    generator, ray counts from 2.1 M to 12 M (with and without split rays), camera rays and bounce depths 1-3, closest-hit and any-hit: a strided
+    16 k sample of each against BVH::Intersect / IsOccluded restated; the verdict of the probe is recorded, not prescribed."""
+    rng = np.random.default_rng(int(tris_m * 1000))
+    verts = scenes.street(int(tris_m * 1e6), seed=2)
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    blob_bytes = sc.host.blob(0, np.uint32, 4).nbytes + sc.host.blob(1, np.uint32, 4).nbytes
+    assert (48 << 20) < blob_bytes <= (384 << 20), blob_bytes
+    d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
+    cap = 3600 * 3600
+    d_a, d_b, d_occ = ctx.malloc(cap * 64), ctx.malloc(cap * 64), ctx.malloc(cap)
+    verdicts = []
+    for k in range(6):
+        side = int(rng.integers(1450, 3600)) // 4 * 4
+        n = side * side
+        cam = R.camera(*scenes.STREET_CAMERAS[int(rng.integers(0, len(scenes.STREET_CAMERAS)))], side, side, 1, 1)
+        depth = int(rng.integers(0, 4))
+        ctx.generate_primary(cam, d_a, 0, n)
+        cur, nxt = d_a, d_b
+        for d in range(depth):
+            sc.intersect_device(cur, n)
+            ctx.generate_bounce(d_verts, cur, nxt, n, 77 + 10 * k + d)
+            cur, nxt = nxt, cur
+        before = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(before, cur)
+        sc.intersect_device_fresh(cur, n, 1e30)
+        verdicts.append((side, depth, ctx.last_probe()[2]))
+        after = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(after, cur)
+        rearmed = before.copy(); rearmed["t"] = np.float32(1e30)
+        idx = np.arange(0, n, max(n // 16384, 1))[:16384]
+        h = sc.host
+        want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rearmed[idx])
+        c = compare_hits(after[idx], want)
+        assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] == 0, (side, depth, c)
+        assert c["bit_identical"] == c["same_prim"], (side, depth, c)
+        # any-hit over the same rays with a finite range
+        rays = rearmed.copy(); rays["t"] = np.float32(rng.uniform(5.0, 60.0))
+        ctx.to_device(cur, rays)
+        sc.occluded_device(cur, n, d_occ)
+        occ = np.zeros(n, np.uint8); ctx.from_device(occ, d_occ)
+        want_occ = oracle.bvh2_occluded(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays[idx])
+        assert int((occ[idx] != want_occ).sum()) <= 2, (side, depth)
+    assert any(v == 2 for _, _, v in verdicts) and any(v == 1 for _, _, v in verdicts), verdicts   # both flavors were exercised
+    for p in (d_verts, d_a, d_b, d_occ):
+        ctx.free(p)
