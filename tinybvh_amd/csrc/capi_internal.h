@@ -1,0 +1,215 @@
+// capi_internal.h — what the translation units behind include/tinybvh_amd.h share: the context and scene objects, the error
+// helper, and the few internal entry points that cross files (capi_context / capi_scene / capi_query / capi_wavefront / capi_host).
+// Not installed; nothing outside tinybvh_amd/csrc includes it.
+#pragma once
+#include "../../include/tinybvh_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "host_builder.h"
+#include "kernels.h"
+#include "ray_pool.h"
+
+using namespace tbvh;
+
+static_assert(kLayoutBvhGpu == TBVH_LAYOUT_BVH_GPU && kLayoutBvh4Gpu == TBVH_LAYOUT_BVH4_GPU && kLayoutCwbvh == TBVH_LAYOUT_CWBVH,
+              "kernels.h and the public header agree on the layout codes");
+
+namespace tbvh_capi {
+int fail(int code, const char* fmt, ...);   // sets tbvh_last_error() of the calling thread, returns code
+}  // namespace tbvh_capi
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(TBVH_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct tbvh_context {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int numCUs = 0;
+    uint32_t blocks = 0;          // persistent grid size (64-thread workgroups)
+    uint32_t* spill = nullptr;    // stack spill area
+    uint32_t spillEntries = 0;    // 32-bit entries per lane
+    unsigned long long* counter = nullptr;  // status word, instrumentation counters
+    uint32_t poolParts = 5;   // log2: 32 partitions
+    bool incoherentCopies = true;   // TBVH_INCOHERENT_COPIES=0: no hybrid node copy / 64-byte triangle records (prepareIncoherentCopies)
+    uint32_t expFlags = 0;     // tbvh_debug_set_flags: QueryArgs::flags of the next launches (experiments)
+    bool lastProbed = false;   // the most recent query launch ran the coherence probe (tbvh_debug_last_probe)
+    bool gridOverride = false;     // TBVH_BLOCKS_PER_CU / TBVH_RAYS_PER_BLOCK given: no per-scene adjustment
+    uint64_t splitBelow = 12ull << 20;   // batches of fewer rays split their last rays over idle lanes; TBVH_SPLIT_RAYS=0 turns that off (tie order then reproducible run to run)
+    uint32_t raysPerBlock = 128;   // small batches: one workgroup per this many rays (with split rays, profiles/r02_grid_sweep.txt: 96-128 best on 1 M-ray batches, +5 % over 192; flat at 4 M)
+    unsigned long long* pool = nullptr;     // ray-fetch counters: kPoolParts of them, 256 bytes apart (ray_pool.h), + the coherence probe's line; TWO such areas
+    int poolCur = 0;              // the area the next launch draws from; its kernels zero the other one for the launch after (no memset in the stream)
+    bool poolClean = false;       // both areas are known to be as that scheme leaves them (false: the next launch clears them itself)
+    uint32_t* status = nullptr;
+    RayRec* stageRays = nullptr;  // staging for host-array queries
+    uint64_t stageCap = 0;
+    uint8_t* stageOcc = nullptr;
+    uint64_t stageOccCap = 0;
+    // host-array queries of more than a few 10 k rays go through pinned staging in chunks: worker threads gather the
+    // 64-byte prefixes of the caller's records into a pinned buffer while the previous chunk is in flight (a pageable
+    // hipMemcpy2D moves ~9 GB/s because one CPU thread does the staging copy), and the 20 result bytes per ray come back
+    // packed (k_pack_hits) and are scattered by the same workers
+    struct HostPipe* pipe = nullptr;
+    void* binScratch = nullptr;   // tbvh_bin_rays_device
+    size_t binScratchBytes = 0;
+    std::vector<tbvh_scene*> scenes;
+};
+
+struct tbvh_scene {
+    tbvh_context* ctx = nullptr;
+    int layout = 0;
+    int variant = 0;
+    float4* nodes = nullptr;   // BVH_GPU nodes / BVH4 stream / CWBVH nodes
+    float4* tris = nullptr;    // BVH_GPU gathered tris / CWBVH tris
+    float4* nodes128 = nullptr; // CWBVH: the same nodes padded to one 128-byte line each (padCwbvhIfLarge: node arrays beyond the Infinity Cache)
+    float4* nodesHy = nullptr;  // CWBVH: the same nodes in surface-area priority order, the first hybridK packed, the others one per line (cwbvh_node.h: kNodeHybrid)
+    uint32_t* hyPerm = nullptr; // device: position of node i in nodesHy
+    float4* tris64 = nullptr;   // CWBVH (experiment flag 2): triangle records padded to 64 bytes
+    uint32_t hybridK = 0;
+    uint32_t nNodes = 0;
+    uint64_t nNodeBlocks = 0, nTriBlocks = 0;
+    uint64_t bytes = 0;
+    // TLAS (layout = BVH_GPU nodes in `nodes`)
+    bool isTlas = false;
+    uint32_t* tlasIdx = nullptr;
+    float4* instances = nullptr;
+    BlasDesc* blasDesc = nullptr;
+    int blasLayout = 0;
+    bool blasMixCw2 = false;          // blasLayout == 0 and every BLAS is BVH8_CWBVH or BVH_GPU: the reference's two BLAS types (traverse_tlas.cl:50-72)
+    uint64_t capNodes = 0, capIdx = 0, capInst = 0;
+    uint64_t nInst = 0, nBlas = 0, nTlasNodes = 0, nTlasIdx = 0;
+    // the same TLAS collapsed 4-wide in the BVH4_GPU node format (kernels_tlas4.hip), kept current by every upload / update / device rebuild;
+    // only for TLASes whose BLASes are all BVH4_GPU
+    float4* tlas4 = nullptr;
+    uint64_t tlas4Cap = 0;            // blocks
+    void* tlas4Scratch = nullptr;
+    size_t tlas4ScratchBytes = 0;
+    // ... or 8-wide in the BVH8_CWBVH node format (kernels_tlas8.hip) for TLASes whose BLASes are all BVH8_CWBVH; same scratch
+    float4* tlas8 = nullptr;
+    uint32_t* tlas8Refs = nullptr;
+    uint64_t tlas8Cap = 0;            // nodes; instance references: the same number
+    // device-side TLAS rebuild (kernels_tlasbuild.hip)
+    float* blasBounds = nullptr;      // 6 floats per BLAS
+    float* xformStage = nullptr;      // staged transforms (16 floats per instance) when the caller passes host memory
+    uint64_t xformStageCap = 0;       // instances the staging buffer holds
+    // BLAS <-> TLAS references: a TLAS snapshots its BLASes' device pointers (BlasDesc), so a BLAS knows the TLASes that
+    // use it (their descriptors are refreshed when its opacity maps change) and outlives them (tbvh_free_scene on a BLAS
+    // that is still referenced only marks it; the memory goes when the last TLAS over it is freed)
+    std::vector<tbvh_scene*> blasList;   // TLAS: its BLASes, in blasIdx order
+    std::vector<tbvh_scene*> usedBy;     // BLAS: the TLASes built over it (one entry per reference)
+    bool zombie = false;                 // BLAS: freed by the caller while still referenced
+    void* buildScratch = nullptr;
+    size_t buildScratchBytes = 0, sortTempBytes = 0;
+    uint64_t buildScratchFor = 0;     // instance count the scratch was sized for
+    // device-side BLAS refit (kernels_refit.hip)
+    void* refitScratch = nullptr;
+    std::vector<uint32_t> b4Levels;   // BVH4_GPU: first node of every tree level in the item list (filled by the first refit)
+    float4* vertStage = nullptr;      // staged vertices when the caller passes host memory
+    // opacity micromaps (BVHBase::SetOpacityMicroMaps)
+    uint32_t* opmap = nullptr;
+    uint32_t opmapN = 0;
+    uint64_t opmapBytes = 0;
+    uint64_t vertStageTris = 0;
+};
+
+struct BLASInstanceCheck { float m[32]; float mn[3]; uint32_t blasIdx; float mx[3]; uint32_t mask; uint32_t pad[8]; };
+static_assert(sizeof(BLASInstanceCheck) == 192, "BLASInstance is 192 bytes");
+
+struct tbvh_hostbvh {
+    int layout = 0;
+    BVH2 bvh2;
+    std::vector<NodeAL> al;
+    std::vector<Vec4> blocksA, blocksB;
+};
+
+struct HostPipe {
+    static constexpr uint64_t kChunk = 1ull << 18;   // rays per chunk: 16 MB up, 5 MB down
+    void* pinUp[2] = {nullptr, nullptr};
+    void* pinDown[2] = {nullptr, nullptr};
+    hipEvent_t evUp[2] = {nullptr, nullptr}, evDown[2] = {nullptr, nullptr};
+    uint32_t* packed = nullptr;   // device: 5 dwords per ray (bytes 44..63 of the record)
+    uint64_t packedCap = 0;
+    // a small persistent worker pool: parallel_for(n, fn) runs fn(part, parts) on every worker and the caller
+    std::vector<std::thread> workers;
+    std::mutex m;
+    std::condition_variable cvWork, cvDone;
+    std::function<void(uint32_t, uint32_t)> job;
+    uint64_t generation = 0;
+    uint32_t pending = 0;
+    bool quit = false;
+    void start(uint32_t nThreads) {
+        for (uint32_t t = 0; t < nThreads; t++)
+            workers.emplace_back([this, t, nThreads] {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::function<void(uint32_t, uint32_t)> f;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cvWork.wait(lk, [&] { return quit || generation != seen; });
+                        if (quit) return;
+                        seen = generation; f = job;
+                    }
+                    f(t + 1, nThreads + 1);
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        if (--pending == 0) cvDone.notify_all();
+                    }
+                }
+            });
+    }
+    void parallel_for(const std::function<void(uint32_t, uint32_t)>& f) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = f; pending = (uint32_t)workers.size(); generation++;
+        }
+        cvWork.notify_all();
+        f(0, (uint32_t)workers.size() + 1);
+        std::unique_lock<std::mutex> lk(m);
+        cvDone.wait(lk, [&] { return pending == 0; });
+    }
+    ~HostPipe() {
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cvWork.notify_all();
+        for (auto& w : workers) w.join();
+        for (int i = 0; i < 2; i++) {
+            if (pinUp[i]) hipHostFree(pinUp[i]);
+            if (pinDown[i]) hipHostFree(pinDown[i]);
+            if (evUp[i]) hipEventDestroy(evUp[i]);
+            if (evDown[i]) hipEventDestroy(evDown[i]);
+        }
+        if (packed) hipFree(packed);
+    }
+};
+
+namespace tbvh_capi {
+int setDevice(tbvh_context* c);
+// one query launch (probe-in-kernel + traversal kernel(s)) on the context's stream; asynchronous.  nDev: batch size in device memory (wavefront queues)
+int launchQuery(tbvh_scene* s, tbvh::RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh = false, float freshTmax = 1e30f,
+                const unsigned long long* nDev = nullptr);
+int checkStatus(tbvh_context* c);   // synchronizes the stream, turns the device status word into an error code
+tbvh_scene* newScene(tbvh_context* c, int layout);
+int padCwbvhIfLarge(tbvh_scene* s);
+size_t hybridBytes(uint32_t nNodes, uint32_t K);
+int prepareIncoherentCopies(tbvh_scene* s, const tbvh::Vec4* hostNodes);
+}  // namespace tbvh_capi

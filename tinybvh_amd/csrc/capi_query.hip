@@ -1,0 +1,477 @@
+// capi_query.hip — the query path: launchQuery (grid shape, schedule choice, kernel flavors), host-array staging, multi-device sharding, ray generators.
+#include "capi_internal.h"
+
+using namespace tbvh;
+using namespace tbvh_capi;
+
+namespace tbvh_capi {
+int ensureStage(tbvh_context* c, uint64_t n) {
+    if (c->stageCap >= n) return 0;
+    if (c->stageRays) hipFree(c->stageRays);
+    c->stageRays = nullptr; c->stageCap = 0;
+    HIP_TRY(hipMalloc((void**)&c->stageRays, n * sizeof(RayRec)));
+    c->stageCap = n;
+    return 0;
+}
+int ensureStageOcc(tbvh_context* c, uint64_t n) {
+    if (c->stageOccCap >= n) return 0;
+    if (c->stageOcc) hipFree(c->stageOcc);
+    c->stageOcc = nullptr; c->stageOccCap = 0;
+    HIP_TRY(hipMalloc((void**)&c->stageOcc, n));
+    c->stageOccCap = n;
+    return 0;
+}
+}  // namespace tbvh_capi
+namespace tbvh_capi {
+
+int ensurePipe(tbvh_context* c, uint64_t n) {
+    if (!c->pipe) {
+        HostPipe* p = new (std::nothrow) HostPipe;
+        if (!p) return fail(TBVH_E_NOMEM, "out of host memory");
+        c->pipe = p;
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipHostMalloc(&p->pinUp[i], HostPipe::kChunk * 64, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(&p->pinDown[i], HostPipe::kChunk * 20, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&p->evUp[i], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&p->evDown[i], hipEventDisableTiming));
+        }
+        uint32_t hw = usable_host_threads();
+        uint32_t t = hw >= 32 ? 7 : hw >= 8 ? 3 : hw >= 4 ? 1 : 0;   // + the calling thread
+        if (const char* e = getenv("TBVH_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) t = (uint32_t)v - 1; }
+        p->start(t);
+    }
+    HostPipe* p = c->pipe;
+    if (p->packedCap < n) {
+        if (p->packed) hipFree(p->packed);
+        p->packed = nullptr; p->packedCap = 0;
+        HIP_TRY(hipMalloc((void**)&p->packed, n * 20));
+        p->packedCap = n;
+    }
+    return 0;
+}
+
+// caller records (stride bytes apart) -> device array of 64-byte records
+int pipeUpload(tbvh_context* c, const char* rays, uint64_t n, uint32_t stride, RayRec* dst) {
+    HostPipe* p = c->pipe;
+    for (uint64_t first = 0, k = 0; first < n; first += HostPipe::kChunk, k++) {
+        const uint64_t cnt = n - first < HostPipe::kChunk ? n - first : HostPipe::kChunk;
+        const int b = (int)(k & 1);
+        if (k >= 2) HIP_TRY(hipEventSynchronize(p->evUp[b]));   // the DMA that last read this buffer is done
+        char* pin = (char*)p->pinUp[b];
+        const char* src = rays + first * stride;
+        p->parallel_for([=](uint32_t part, uint32_t parts) {
+            const uint64_t lo = cnt * part / parts, hi = cnt * (part + 1) / parts;
+            if (stride == 64) std::memcpy(pin + lo * 64, src + lo * 64, (hi - lo) * 64);
+            else for (uint64_t i = lo; i < hi; i++) std::memcpy(pin + i * 64, src + i * stride, 64);
+        });
+        HIP_TRY(hipMemcpyAsync(dst + first, pin, cnt * 64, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipEventRecord(p->evUp[b], c->stream));
+    }
+    return 0;
+}
+
+// device records -> bytes 44..63 of the caller's records
+int pipeDownloadHits(tbvh_context* c, char* rays, uint64_t n, uint32_t stride, const RayRec* src) {
+    HostPipe* p = c->pipe;
+    launch_pack_hits(src, p->packed, n, c->stream);
+    HIP_TRY(hipGetLastError());
+    const uint64_t chunks = (n + HostPipe::kChunk - 1) / HostPipe::kChunk;
+    auto issue = [&](uint64_t k) -> int {
+        const uint64_t first = k * HostPipe::kChunk, cnt = n - first < HostPipe::kChunk ? n - first : HostPipe::kChunk;
+        HIP_TRY(hipMemcpyAsync(p->pinDown[k & 1], (const char*)p->packed + first * 20, cnt * 20, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(p->evDown[k & 1], c->stream));
+        return 0;
+    };
+    if (int r = issue(0)) return r;
+    for (uint64_t k = 0; k < chunks; k++) {
+        if (k + 1 < chunks) if (int r = issue(k + 1)) return r;   // next chunk in flight while this one is scattered
+        HIP_TRY(hipEventSynchronize(p->evDown[k & 1]));
+        const uint64_t first = k * HostPipe::kChunk, cnt = n - first < HostPipe::kChunk ? n - first : HostPipe::kChunk;
+        const char* pin = (const char*)p->pinDown[k & 1];
+        char* dstRays = rays + first * stride;
+        p->parallel_for([=](uint32_t part, uint32_t parts) {
+            const uint64_t lo = cnt * part / parts, hi = cnt * (part + 1) / parts;
+            for (uint64_t i = lo; i < hi; i++) std::memcpy(dstRays + i * stride + 44, pin + i * 20, 20);
+        });
+    }
+    return 0;
+}
+
+constexpr uint64_t kPipeMinRays = 1ull << 15;
+
+int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh, float freshTmax, const unsigned long long* nDev) {
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    if (n == 0) return 0;
+    const bool any = d_occ != nullptr;
+    // ray-fetch counters: two areas alternate; the kernels of this launch zero the other area for the next one.  After anything that went wrong
+    // between two launches (poolClean still false) both are cleared here.
+    const size_t poolWords = (size_t)(kPoolParts + 1) * kPoolCounterStride;   // + the coherence-probe counters on their own line
+    if (!c->poolClean) HIP_TRY(hipMemsetAsync(c->pool, 0, poolWords * 4 * 2, c->stream));
+    c->poolClean = false;
+    uint32_t* const poolArea = (uint32_t*)c->pool + (size_t)c->poolCur * poolWords;
+    QueryArgs q;
+    q.rays = d_rays; q.nRays = n; q.occluded = d_occ;
+    q.spill = c->spill; q.counter = poolArea; q.counterNext = (uint32_t*)c->pool + (size_t)(c->poolCur ^ 1) * poolWords; q.poolParts = c->poolParts;
+    q.stats = c->counter + 8;
+    q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.omm = Omm{s->opmap, s->opmapN};
+    q.probe = nullptr; q.baseBlocks = 0; q.hybridK = s->hybridK; q.flags = c->expFlags & 1u;
+    c->lastProbed = false;
+    q.splitBelow = c->splitBelow;
+    // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
+    // (about one workgroup per 128 rays, measured best for 1 M-ray launches) so every wave still
+    // has a few ray replacements' worth of work
+    // A scene that (nearly) lives in the L2s — the Sponza class: < 48 MB of nodes and triangles against 8 x 4 MB of L2
+    // plus the Infinity Cache — is latency-bound, not cache-bound: it runs best with a third more waves (32 per CU) of
+    // fewer rays each (measured +1..20 % on the Sponza stand-in from 0.26 M to 16.7 M rays; the same shape costs the
+    // 196 MB Bistro stand-in 5-10 % on bounce and shadow rays, which thrash the caches more with more waves).
+    const uint64_t blobBytes = (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH) ? (s->nNodeBlocks + s->nTriBlocks) * 16 : s->bytes;   // (without the library's own re-laid-out copies)
+    const bool small = !s->isTlas && !c->gridOverride && blobBytes < (48ull << 20);
+    const uint32_t perBlock = c->raysPerBlock;
+    const uint32_t cap = small ? c->blocks + c->blocks / 3u : c->blocks;
+    uint64_t want = (n + perBlock - 1) / perBlock;
+    const uint32_t lo = (uint32_t)c->numCUs * 4u;
+    uint32_t blocks = (uint32_t)(want < lo ? lo : (want > cap ? cap : want));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));   // the probe below is part of the query's time
+    // BVH8_CWBVH scenes beyond the L2s (the `small` class runs dense triangle phases, where the gated schedule loses 15 %) but within reach
+    // of the Infinity Cache (beyond it camera rays are bound by memory too: 30 M / 60 M triangles lose 11 / 19 % under the gate), batches of 2 M
+    // rays and more (the probe costs ~10 us, 3-4 % of a 1 M-ray launch): a 16-workgroup probe of the batch's coherence (4096 neighbour pairs)
+    // lets the traversal kernel pick its schedule for the launch; a coherent batch also gets a third more waves (the surplus leaves at once
+    // otherwise).  Bistro stand-in, 16.7 M rays: camera rays +4.5 %, shadow rays +6 %, bounce rays unchanged.
+    uint32_t blocksBase = blocks;
+    if (!s->isTlas && !small && blobBytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || s->variant == 88)) {
+        uint32_t* probe = poolArea + (size_t)kPoolParts * kPoolCounterStride;
+        launch_coherence_probe(d_rays, n, nDev, probe, c->stream);
+        HIP_TRY(hipGetLastError());
+        q.probe = probe; q.baseBlocks = blocks;
+        c->lastProbed = true;
+        if (!c->gridOverride && blocks == c->blocks) blocks = c->blocks + c->blocks / 3u;   // 24 -> 32 one-wave workgroups per CU
+    }
+    if (s->isTlas) {
+        const uint32_t blocks7 = (!c->gridOverride && blocks == c->blocks) ? (uint32_t)c->numCUs * 28u : blocks;   // the full grid of the kernels built for 7 waves per SIMD
+        if (s->tlas4 && s->blasLayout == TBVH_LAYOUT_BVH4_GPU) {   // BVH4_GPU BLASes: the unified 4-wide kernel
+            q.spillStride = c->spillEntries;   // 32-bit stack entries
+            launch_tlas4(any, 0, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
+            return 0;
+        }
+        if (s->tlas8 && (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2)) {   // BVH8_CWBVH BLASes (or those and BVH_GPU ones): the unified 8-wide kernel
+            q.spillStride = c->spillEntries / 2;   // 8-byte stack entries
+            launch_tlas8(any, 0, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7, s->blasMixCw2);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
+            return 0;
+        }
+        if (s->blasLayout == TBVH_LAYOUT_BVH_GPU) {   // BVH_GPU BLASes: the TLAS already has their node format (kernels_tlas2.hip)
+            q.spillStride = c->spillEntries;   // 32-bit stack entries
+            launch_tlas2(any, 0, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
+            return 0;
+        }
+        q.spillStride = c->spillEntries / 2;
+        launch_tlas(any, s->blasLayout, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
+        return 0;
+    }
+    switch (s->layout) {
+    case TBVH_LAYOUT_BVH_GPU:
+        q.spillStride = c->spillEntries;
+        launch_bvh2(any, s->variant, s->nodes, s->tris, q, c->status, blocks, c->stream);
+        break;
+    case TBVH_LAYOUT_BVH4_GPU:
+        q.spillStride = c->spillEntries;
+        launch_bvh4(any, s->variant, s->nodes, q, c->status, blocks, c->stream);
+        break;
+    case TBVH_LAYOUT_CWBVH:
+        q.spillStride = c->spillEntries / 2;  // 8-byte entries
+        {
+            const bool autoPad = s->variant == 0 && s->nodes128 != nullptr;   // nodes beyond the Infinity Cache: the padded copy (padCwbvhIfLarge)
+            const uint32_t blocks7 = c->gridOverride ? 0xFFFFFFFFu : (uint32_t)c->numCUs * 28u;
+            const float4* tris = s->tris;
+            if ((c->expFlags & 2u) && s->tris64) { tris = s->tris64; q.flags |= 2u; }   // experiment: 64-byte triangle records in the ordinary kernels too
+            // A probed launch on a scene with the incoherent-batch copies (prepareIncoherentCopies) is TWO kernels back to back, each for one
+            // verdict of the probe; the one the verdict is not for leaves at once (~10 us).  The coherent flavor keeps the packed arrays as
+            // uploaded (its working set lives in the L2s); the incoherent one walks the hybrid node copy and the 64-byte triangle records.
+            // Bistro stand-in, 16.7 M rays, interleaved medians (profiles/r03_ab_16m.txt): bounce rays +10 %, camera and shadow rays unchanged.
+            const bool twoFlavors = q.probe && s->variant == 0 && !autoPad && s->nodesHy && s->tris64 && !(c->expFlags & 4u);
+            if (s->variant == 90 && s->nodesHy && s->tris64)   // diagnostic: the incoherent flavor whatever the batch (tests, tools/ab_configs.py)
+                launch_cwbvh(any, 0, s->nodesHy, s->tris64, q, c->status, blocksBase, c->stream, 13, small, blocks7);
+            else if (twoFlavors) {
+                QueryArgs qa = q;
+                qa.baseBlocks = 0;   // every wave of the coherent flavor leaves unless the batch is coherent
+                launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, blocks, c->stream, 5, small, blocks7);
+                HIP_TRY(hipGetLastError());
+                QueryArgs qb = q;
+                // the incoherent flavor on 28 one-wave workgroups per CU when the batch fills the grid (24 is the persistent grid's size: 20 / 26 / 28 / 30 /
+                // 32 per CU trace bounce rays at -4.4 / +0.6 / +0.9 / +0.5 / +0.5 %, interleaved medians of 13 rounds)
+                const uint32_t wX = (c->expFlags >> 8) & 0xffu;   // experiment: another number of waves per CU
+                const uint32_t wB = wX ? wX : (c->gridOverride ? 0u : 28u);
+                launch_cwbvh(any, 0, s->nodesHy, s->tris64, qb, c->status, (wB && blocksBase == c->blocks) ? (uint32_t)c->numCUs * wB : blocksBase, c->stream, 13, small, blocks7);
+            } else
+                launch_cwbvh(any, s->variant, autoPad ? s->nodes128 : s->nodes, tris, q, c->status, blocks, c->stream, autoPad ? 8 : 5, small, blocks7);
+        }
+        break;
+    default:
+        return fail(TBVH_E_INVALID, "scene layout %d has no query kernel", s->layout);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
+    return 0;
+}
+
+int checkStatus(tbvh_context* c) {
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpyAsync(&st, c->status, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (st & 1u) {
+        hipMemsetAsync(c->status, 0, 4, c->stream);
+        return fail(TBVH_E_FORMAT, "traversal stack overflow (tree deeper than the spill area allows)");
+    }
+    if (st & 2u) {
+        hipMemsetAsync(c->status, 0, 4, c->stream);
+        return fail(TBVH_E_FORMAT, "refit: a triangle record refers to a primitive beyond the vertex array");
+    }
+    if (st & 4u) {
+        hipMemsetAsync(c->status, 0, 4, c->stream);
+        return fail(TBVH_E_FORMAT, "wide TLAS build: the node capacity did not hold the collapsed tree");
+    }
+    return 0;
+}
+}  // namespace tbvh_capi
+
+extern "C" {
+
+// ---- queries ---------------------------------------------------------------------------
+
+int tbvh_intersect_device(tbvh_scene* s, void* dRays, uint64_t n) {
+    if (!s || (!dRays && n)) return fail(TBVH_E_INVALID, "tbvh_intersect_device: null argument");
+    if (((uintptr_t)dRays) & 15) return fail(TBVH_E_INVALID, "ray array must be 16-byte aligned");
+    return launchQuery(s, (RayRec*)dRays, n, nullptr);
+}
+
+int tbvh_intersect_device_fresh(tbvh_scene* s, void* dRays, uint64_t n, float tmax) {
+    if (!s || (!dRays && n)) return fail(TBVH_E_INVALID, "tbvh_intersect_device_fresh: null argument");
+    if (((uintptr_t)dRays) & 15) return fail(TBVH_E_INVALID, "ray array must be 16-byte aligned");
+    return launchQuery(s, (RayRec*)dRays, n, nullptr, true, tmax);
+}
+
+int tbvh_occluded_device(tbvh_scene* s, const void* dRays, uint64_t n, uint8_t* dOcc) {
+    if (!s || ((!dRays || !dOcc) && n)) return fail(TBVH_E_INVALID, "tbvh_occluded_device: null argument");
+    if (((uintptr_t)dRays) & 15) return fail(TBVH_E_INVALID, "ray array must be 16-byte aligned");
+    return launchQuery(s, (RayRec*)dRays, n, dOcc);
+}
+
+int tbvh_intersect(tbvh_scene* s, void* rays, uint64_t n, uint32_t stride) {
+    if (!s || (!rays && n)) return fail(TBVH_E_INVALID, "tbvh_intersect: null argument");
+    if (stride < 64 || (stride & 3)) return fail(TBVH_E_INVALID, "stride must be >= 64 and a multiple of 4 (got %u)", stride);
+    if (n == 0) return 0;
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    if (int r = ensureStage(c, n)) return r;
+    if (n >= kPipeMinRays) {   // pinned, chunked, multi-threaded staging (see HostPipe)
+        if (int r = ensurePipe(c, n)) return r;
+        if (int r = pipeUpload(c, (const char*)rays, n, stride, c->stageRays)) return r;
+        if (int r = launchQuery(s, c->stageRays, n, nullptr)) return r;
+        if (int r = pipeDownloadHits(c, (char*)rays, n, stride, c->stageRays)) return r;
+        return checkStatus(c);
+    }
+    HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
+    if (int r = launchQuery(s, c->stageRays, n, nullptr)) return r;
+    // copy back bytes 44..63 of every record (hit.inst + hit)
+    HIP_TRY(hipMemcpy2DAsync((char*)rays + 44, stride, (char*)c->stageRays + 44, 64, 20, n, hipMemcpyDeviceToHost, c->stream));
+    return checkStatus(c);
+}
+
+int tbvh_occluded(tbvh_scene* s, const void* rays, uint64_t n, uint32_t stride, uint8_t* occ) {
+    if (!s || ((!rays || !occ) && n)) return fail(TBVH_E_INVALID, "tbvh_occluded: null argument");
+    if (stride < 64 || (stride & 3)) return fail(TBVH_E_INVALID, "stride must be >= 64 and a multiple of 4 (got %u)", stride);
+    if (n == 0) return 0;
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    if (int r = ensureStage(c, n)) return r;
+    if (int r = ensureStageOcc(c, n)) return r;
+    if (n >= kPipeMinRays) {
+        if (int r = ensurePipe(c, n)) return r;
+        if (int r = pipeUpload(c, (const char*)rays, n, stride, c->stageRays)) return r;
+    } else HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
+    if (int r = launchQuery(s, c->stageRays, n, c->stageOcc)) return r;
+    HIP_TRY(hipMemcpyAsync(occ, c->stageOcc, n, hipMemcpyDeviceToHost, c->stream));
+    return checkStatus(c);
+}
+
+// ---- one ray array over several devices -----------------------------------------------------------
+// The BVH is replicated (scenes[i] = the same blobs uploaded through context i), the ray array is cut into contiguous,
+// wave-aligned shards (the same arithmetic as tinybvh_amd/sharding.py: shard_range), one host thread per device drives
+// that device's staging + kernel + read-back, results land in the caller's array in place.  No collective.
+void tbvh_shard_range(uint64_t n_rays, uint32_t rank, uint32_t world, uint64_t* begin, uint64_t* end) {
+    const uint64_t align = 64, units = (n_rays + align - 1) / align;
+    const uint64_t base = world ? units / world : 0, extra = world ? units % world : 0;
+    const uint64_t b = (uint64_t)rank * base + (rank < extra ? rank : extra), e = b + base + (rank < extra ? 1 : 0);
+    if (begin) *begin = b * align < n_rays ? b * align : n_rays;
+    if (end) *end = e * align < n_rays ? e * align : n_rays;
+}
+
+namespace {
+int shardedQuery(tbvh_scene* const* scenes, uint32_t nDev, void* rays, uint64_t n, uint32_t stride, uint8_t* occ, const char* who) {
+    if (!scenes || nDev == 0 || (!rays && n)) return fail(TBVH_E_INVALID, "%s: null/empty argument", who);
+    if (stride < 64 || (stride & 3)) return fail(TBVH_E_INVALID, "stride must be >= 64 and a multiple of 4 (got %u)", stride);
+    for (uint32_t i = 0; i < nDev; i++) {
+        if (!scenes[i]) return fail(TBVH_E_INVALID, "%s: scene %u is null", who, i);
+        if (scenes[i]->layout != scenes[0]->layout || scenes[i]->isTlas != scenes[0]->isTlas) return fail(TBVH_E_INVALID, "%s: scene %u is not a replica of scene 0 (layout differs)", who, i);
+        for (uint32_t j = 0; j < i; j++) if (scenes[j]->ctx == scenes[i]->ctx) return fail(TBVH_E_INVALID, "%s: scenes %u and %u share a context (one context, i.e. one stream and staging area, per shard)", who, j, i);
+    }
+    if (n == 0) return 0;
+    std::vector<int> rc(nDev, 0);
+    std::vector<std::string> msg(nDev);
+    auto work = [&](uint32_t i) {
+        uint64_t b, e;
+        tbvh_shard_range(n, i, nDev, &b, &e);
+        if (e == b) return;
+        char* base = (char*)rays + b * stride;
+        rc[i] = occ ? tbvh_occluded(scenes[i], base, e - b, stride, occ + b) : tbvh_intersect(scenes[i], base, e - b, stride);
+        if (rc[i]) msg[i] = tbvh_last_error();   // the worker's thread-local message
+    };
+    std::vector<std::thread> th;
+    for (uint32_t i = 1; i < nDev; i++) th.emplace_back(work, i);
+    work(0);
+    for (auto& t : th) t.join();
+    for (uint32_t i = 0; i < nDev; i++) if (rc[i]) return fail(rc[i], "%s: shard %u (device %d): %s", who, i, scenes[i]->ctx->device, msg[i].c_str());
+    return 0;
+}
+}  // namespace
+
+int tbvh_intersect_sharded(tbvh_scene* const* scenes, uint32_t nDev, void* rays, uint64_t n, uint32_t stride) {
+    return shardedQuery(scenes, nDev, rays, n, stride, nullptr, "tbvh_intersect_sharded");
+}
+int tbvh_occluded_sharded(tbvh_scene* const* scenes, uint32_t nDev, const void* rays, uint64_t n, uint32_t stride, uint8_t* occ) {
+    if (!occ && n) return fail(TBVH_E_INVALID, "tbvh_occluded_sharded: null output");
+    return shardedQuery(scenes, nDev, (void*)rays, n, stride, occ, "tbvh_occluded_sharded");
+}
+
+// ---- device-resident rays over several devices: nothing crosses the host -------------------------------------------------------------
+// Every device's launch is asynchronous on its context's stream, so ONE host thread enqueues them all (a few tens of microseconds each:
+// dispatch_ms[i] = host time spent enqueueing device i's launch), then waits for all.  With the rays produced and consumed where they are
+// traced — a wavefront path tracer per device (tbvh_wavefront_render_sharded), or rays a kernel of the caller's wrote — the devices run
+// at their device-resident rate; tbvh_intersect_sharded above moves HOST rays and is bound by the host (DESIGN.md par. 7).
+namespace {
+int shardedDeviceQuery(tbvh_scene* const* scenes, uint32_t nDev, void* const* dRays, const uint64_t* nRays, uint8_t* const* dOcc, int fresh, float tmax,
+                       float* kernelMs, float* dispatchMs, const char* who) {
+    if (!scenes || !nDev || !dRays || !nRays) return fail(TBVH_E_INVALID, "%s: null argument", who);
+    for (uint32_t i = 0; i < nDev; i++) {
+        if (!scenes[i]) return fail(TBVH_E_INVALID, "%s: scenes[%u] is null", who, i);
+        if (nRays[i] && (!dRays[i] || (dOcc && !dOcc[i]))) return fail(TBVH_E_INVALID, "%s: null ray / output pointer for device %u", who, i);
+        for (uint32_t k = 0; k < i; k++) if (scenes[k]->ctx == scenes[i]->ctx) return fail(TBVH_E_INVALID, "%s: scenes %u and %u share a context (one scene per context)", who, k, i);
+    }
+    int rc = 0;
+    uint32_t launched = 0;
+    for (; launched < nDev && !rc; launched++) {
+        const uint32_t i = launched;
+        const auto t0 = std::chrono::steady_clock::now();
+        rc = launchQuery(scenes[i], (RayRec*)dRays[i], nRays[i], dOcc ? dOcc[i] : nullptr, fresh != 0, tmax);
+        if (dispatchMs) dispatchMs[i] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    // wait for everything that was enqueued, also after a failure: the caller gets its buffers back quiescent (the first error is reported)
+    std::string firstErr = rc ? tbvh_last_error() : "";
+    for (uint32_t i = 0; i < launched; i++) {
+        if (!nRays[i]) { if (kernelMs) kernelMs[i] = 0.f; continue; }
+        const int r = checkStatus(scenes[i]->ctx);   // synchronizes device i's stream
+        if (r && !rc) { rc = r; firstErr = tbvh_last_error(); }
+        if (kernelMs) kernelMs[i] = r ? -1.f : tbvh_time_last_ms(scenes[i]->ctx);
+    }
+    if (rc) return fail(rc, "%s: %s", who, firstErr.c_str());
+    return 0;
+}
+}  // namespace
+
+int tbvh_intersect_sharded_device(tbvh_scene* const* scenes, uint32_t nDev, void* const* dRays, const uint64_t* nRays, int fresh, float tmax,
+                                  float* kernelMs, float* dispatchMs) {
+    return shardedDeviceQuery(scenes, nDev, dRays, nRays, nullptr, fresh, tmax, kernelMs, dispatchMs, "tbvh_intersect_sharded_device");
+}
+int tbvh_occluded_sharded_device(tbvh_scene* const* scenes, uint32_t nDev, const void* const* dRays, const uint64_t* nRays, uint8_t* const* dOcc,
+                                 float* kernelMs, float* dispatchMs) {
+    if (!dOcc) return fail(TBVH_E_INVALID, "tbvh_occluded_sharded_device: null output");
+    return shardedDeviceQuery(scenes, nDev, (void* const*)dRays, nRays, dOcc, 0, 1e30f, kernelMs, dispatchMs, "tbvh_occluded_sharded_device");
+}
+
+int tbvh_bin_rays_device(tbvh_context* c, const void* dIn, void* dOut, uint64_t n, const float bounds6[6], uint32_t cellBits, uint32_t flags, uint32_t* dPerm) {
+    if (!c || !bounds6 || ((!dIn || !dOut) && n)) return fail(TBVH_E_INVALID, "tbvh_bin_rays_device: null argument");
+    if (dIn == dOut) return fail(TBVH_E_INVALID, "tbvh_bin_rays_device: the batch cannot be binned in place");
+    if (cellBits > 6 || (flags & ~3u) || (flags & 3u) == 3u) return fail(TBVH_E_INVALID, "tbvh_bin_rays_device: cell_bits 0..6, flags 0, 1 or 2");
+    if (n > 0xffffffffull) return fail(TBVH_E_INVALID, "tbvh_bin_rays_device: at most 2^32 - 1 rays per call");
+    if (int r = setDevice(c)) return r;
+    if (!n) return 0;
+    size_t scanTemp = 0;
+    const size_t need = ray_bin_scratch_bytes(n, cellBits, flags, &scanTemp);
+    if (need > c->binScratchBytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->binScratch) hipFree(c->binScratch);
+        c->binScratch = nullptr; c->binScratchBytes = 0;
+        HIP_TRY(hipMalloc(&c->binScratch, need));
+        c->binScratchBytes = need;
+    }
+    RayBinArgs a;
+    for (int k = 0; k < 3; k++) {
+        a.lo[k] = bounds6[k];
+        const float ext = bounds6[3 + k] - bounds6[k];
+        a.scale[k] = ext > 0 ? (float)(1u << cellBits) / ext : 0.f;
+    }
+    a.cellBits = cellBits; a.flags = flags;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(launch_ray_bin((const RayRec*)dIn, (RayRec*)dOut, dPerm, n, nullptr, a, c->binScratch, scanTemp, (uint32_t)c->numCUs * 16u, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return 0;
+}
+
+// ---- ray generators ----------------------------------------------------------------------
+
+int tbvh_generate_primary_device(tbvh_context* c, const tbvh_camera* cam, void* dRays, uint64_t first, uint64_t n) {
+    if (!c || !cam || (!dRays && n)) return fail(TBVH_E_INVALID, "tbvh_generate_primary_device: null argument");
+    if (cam->width % 4 || cam->height % 4 || !cam->spp_x || !cam->spp_y) return fail(TBVH_E_INVALID, "camera: width/height must be multiples of 4, spp > 0");
+    if (int r = setDevice(c)) return r;
+    if (!n) return 0;
+    CameraArgs a;
+    memcpy(a.eye, cam->eye, 12); memcpy(a.p1, cam->p1, 12); memcpy(a.p2, cam->p2, 12); memcpy(a.p3, cam->p3, 12);
+    a.width = cam->width; a.height = cam->height; a.sppX = cam->spp_x; a.sppY = cam->spp_y;
+    launch_gen_primary(a, (RayRec*)dRays, first, n, c->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int tbvh_generate_bounce_device(tbvh_context* c, const void* dVerts, const void* dIn, void* dOut, uint64_t n, uint32_t seed) {
+    if (!c || ((!dVerts || !dIn || !dOut) && n)) return fail(TBVH_E_INVALID, "tbvh_generate_bounce_device: null argument");
+    if (int r = setDevice(c)) return r;
+    if (!n) return 0;
+    TriSource src; src.mode = 0; src.verts = (const float4*)dVerts;
+    launch_gen_bounce(src, (const RayRec*)dIn, (RayRec*)dOut, n, seed, c->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int tbvh_generate_shadow_device(tbvh_context* c, const void* dIn, void* dOut, uint64_t n, const float light[3], float eps) {
+    if (!c || !light || ((!dIn || !dOut) && n)) return fail(TBVH_E_INVALID, "tbvh_generate_shadow_device: null argument");
+    if (int r = setDevice(c)) return r;
+    if (!n) return 0;
+    launch_gen_shadow((const RayRec*)dIn, (RayRec*)dOut, n, light[0], light[1], light[2], eps, c->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int tbvh_reset_hits_device(tbvh_context* c, void* dRays, uint64_t n, float tmax) {
+    if (!c || (!dRays && n)) return fail(TBVH_E_INVALID, "tbvh_reset_hits_device: null argument");
+    if (int r = setDevice(c)) return r;
+    if (!n) return 0;
+    launch_reset_hits((RayRec*)dRays, n, tmax, c->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

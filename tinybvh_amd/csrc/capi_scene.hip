@@ -1,0 +1,653 @@
+// capi_scene.hip — scenes: uploads and their validation, derived copies, device conversion / build / refit, TLAS upload and rebuild, opacity maps.
+#include "capi_internal.h"
+
+using namespace tbvh;
+using namespace tbvh_capi;
+
+namespace tbvh_capi {
+// A BVH8_CWBVH scene whose node array is larger than twice the 256 MB Infinity Cache is traversed through a copy with one node per
+// 128-byte line: an 80-byte node straddles 1.6 lines on average, and once the lines come from HBM that is 17 % more traffic than the
+// 60 % larger array costs (tools/size_sweep.py, 60 M triangles: bounce rays +6 %; below that size the smaller footprint wins).
+int padCwbvhIfLarge(tbvh_scene* s) {
+    if (s->layout != TBVH_LAYOUT_CWBVH || s->isTlas || s->nodes128 || (uint64_t)s->nNodes * 80 < (512ull << 20)) return 0;
+    tbvh_context* c = s->ctx;
+    if (hipMalloc((void**)&s->nodes128, (size_t)s->nNodes * 128) != hipSuccess) { s->nodes128 = nullptr; (void)hipGetLastError(); return 0; }   // no memory to spare: the packed array serves
+    launch_cwbvh_pad(s->nodes, s->nodes128, s->nNodes, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    s->bytes += (uint64_t)s->nNodes * 128;
+    return 0;
+}
+
+size_t hybridBytes(uint32_t nNodes, uint32_t K) { return ((size_t)K * 5 + (size_t)(nNodes - K) * 8) * 16; }
+
+// BVH8_CWBVH scenes of the class that gets the per-launch coherence probe (48 - 384 MB of blobs: beyond the L2s, within reach of the Infinity
+// Cache) keep two derived copies for INCOHERENT batches (kernels_cwbvh.hip: PROBED == 2): the nodes in surface-area priority order with the
+// first kHybridPacked packed and the others one per 128-byte line, and the triangle records padded to 64 bytes.  hostNodes: the blob as
+// uploaded (priority order computed on the host, ~0.1 s for 600 k nodes), or nullptr for trees made on the device (tbvh_convert_bvh2_device,
+// tbvh_build_device emit level order, which already is close to priority order: no renumbering).  Failure to allocate is not an error: the
+// scene then runs the one-kernel path.  TBVH_INCOHERENT_COPIES=0 turns the copies off.
+constexpr uint32_t kHybridPacked = 8192;
+int prepareIncoherentCopies(tbvh_scene* s, const Vec4* hostNodes) {
+    tbvh_context* c = s->ctx;
+    const uint64_t blobBytes = (s->nNodeBlocks + s->nTriBlocks) * 16;
+    if (s->layout != TBVH_LAYOUT_CWBVH || s->isTlas || !c->incoherentCopies || blobBytes < (48ull << 20) || blobBytes > (384ull << 20) || s->nNodes <= kHybridPacked || !s->nTriBlocks) return 0;
+    const uint32_t K = kHybridPacked;
+    const uint64_t nT = s->nTriBlocks / 3;
+    if (!s->nodesHy && hipMalloc((void**)&s->nodesHy, hybridBytes(s->nNodes, K)) != hipSuccess) { s->nodesHy = nullptr; (void)hipGetLastError(); return 0; }
+    if (!s->tris64 && hipMalloc((void**)&s->tris64, nT * 64) != hipSuccess) { s->tris64 = nullptr; (void)hipGetLastError(); hipFree(s->nodesHy); s->nodesHy = nullptr; return 0; }
+    if (hostNodes && !s->hyPerm) {
+        std::vector<uint32_t> perm;
+        cwbvh_priority_order(hostNodes, s->nNodes, perm);
+        if (hipMalloc((void**)&s->hyPerm, (size_t)s->nNodes * 4) == hipSuccess) HIP_TRY(hipMemcpyAsync(s->hyPerm, perm.data(), (size_t)s->nNodes * 4, hipMemcpyHostToDevice, c->stream));
+        else { s->hyPerm = nullptr; (void)hipGetLastError(); }
+        HIP_TRY(hipStreamSynchronize(c->stream));   // perm goes out of scope
+    }
+    s->hybridK = K;
+    HIP_TRY(hipMemsetAsync(s->nodesHy, 0, hybridBytes(s->nNodes, K), c->stream));
+    launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, s->nNodes, K, c->stream);
+    launch_cwbvh_pad_tris(s->tris, s->tris64, nT, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    s->bytes += hybridBytes(s->nNodes, K) + nT * 64;
+    return 0;
+}
+
+tbvh_scene* newScene(tbvh_context* c, int layout) {
+    tbvh_scene* s = new (std::nothrow) tbvh_scene;
+    if (!s) return nullptr;
+    s->ctx = c; s->layout = layout;
+    c->scenes.push_back(s);
+    return s;
+}
+
+}  // namespace tbvh_capi
+
+extern "C" {
+
+// ---- uploads ---------------------------------------------------------------------------
+
+int tbvh_upload_bvh_gpu(tbvh_context* c, const void* nodes64, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx,
+                        const void* verts16, uint64_t nTris, tbvh_scene** out) {
+    if (!c || !nodes64 || !primIdx || !verts16 || !out || nNodes == 0) return fail(TBVH_E_INVALID, "tbvh_upload_bvh_gpu: null/empty argument");
+    if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(TBVH_E_FORMAT, "%s", why);
+    if (int r = setDevice(c)) return r;
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    uint32_t* dIdx = nullptr; float4* dVerts = nullptr;
+    hipError_t e = hipMalloc((void**)&s->nodes, nNodes * 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->tris, (nIdx ? nIdx : 1) * 48);
+    if (e == hipSuccess) e = hipMalloc((void**)&dIdx, (nIdx ? nIdx : 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dVerts, (nTris ? nTris : 1) * 48);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, nodes64, nNodes * 64, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dIdx, primIdx, nIdx * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dVerts, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nIdx) { launch_gather_tris(dIdx, dVerts, s->tris, nIdx, nTris, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (dIdx) hipFree(dIdx);
+    if (dVerts) hipFree(dVerts);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH_GPU upload failed: %s", hipGetErrorString(e)); }
+    s->nNodeBlocks = nNodes * 4; s->nTriBlocks = nIdx * 3;
+    s->bytes = nNodes * 64 + nIdx * 48;
+    *out = s;
+    return 0;
+}
+
+int tbvh_upload_bvh4_gpu(tbvh_context* c, const void* blocks16, uint64_t nBlocks, tbvh_scene** out) {
+    if (!c || !blocks16 || !out || nBlocks < 4) return fail(TBVH_E_INVALID, "tbvh_upload_bvh4_gpu: null/empty argument");
+    if (const char* why = validate_bvh4_gpu((const Vec4*)blocks16, nBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
+    if (int r = setDevice(c)) return r;
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH4_GPU);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    hipError_t e = hipMalloc((void**)&s->nodes, nBlocks * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, blocks16, nBlocks * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH4_GPU upload failed: %s", hipGetErrorString(e)); }
+    s->nNodeBlocks = nBlocks; s->bytes = nBlocks * 16;
+    *out = s;
+    return 0;
+}
+
+int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks, const void* tris16, uint64_t nTriBlocks,
+                      tbvh_scene** out) {
+    if (!c || !nodes16 || !out || nNodeBlocks < 5 || (nTriBlocks && !tris16)) return fail(TBVH_E_INVALID, "tbvh_upload_cwbvh: null/empty argument");
+    if (nNodeBlocks % 5) return fail(TBVH_E_FORMAT, "CWBVH node blocks (%llu) not a multiple of 5", (unsigned long long)nNodeBlocks);
+    if (const char* why = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
+    if (int r = setDevice(c)) return r;
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_CWBVH);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    hipError_t e = hipMalloc((void**)&s->nodes, nNodeBlocks * 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->tris, (nTriBlocks ? nTriBlocks : 1) * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, nodes16, nNodeBlocks * 16, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nTriBlocks) e = hipMemcpyAsync(s->tris, tris16, nTriBlocks * 16, hipMemcpyHostToDevice, c->stream);
+    s->nNodes = (uint32_t)(nNodeBlocks / 5);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "CWBVH upload failed: %s", hipGetErrorString(e)); }
+    s->nNodeBlocks = nNodeBlocks; s->nTriBlocks = nTriBlocks;
+    s->bytes = (nNodeBlocks + nTriBlocks) * 16;
+    if (int r = padCwbvhIfLarge(s)) { tbvh_free_scene(s); return r; }
+    if (int r = prepareIncoherentCopies(s, (const Vec4*)nodes16)) { tbvh_free_scene(s); return r; }
+    *out = s;
+    return 0;
+}
+
+namespace {
+// (re)build the 4-wide TLAS from the BVH_GPU nodes on the device; asynchronous on the context's stream
+int buildTlas4(tbvh_scene* s) {
+    tbvh_context* c = s->ctx;
+    if (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2) {
+        const uint64_t cap = tlas8_cap_nodes(s->nTlasNodes, s->nInst);
+        if (cap > 0x00ffffffull) {   // wide-node indices share a word with 8 flag bits in places: the flat loop serves larger TLASes — and a wide
+            // TLAS left from an earlier, smaller upload must not be traversed in its place (launchQuery keys on the pointer)
+            if (s->tlas8) hipFree(s->tlas8);
+            if (s->tlas8Refs) hipFree(s->tlas8Refs);
+            s->tlas8 = nullptr; s->tlas8Refs = nullptr; s->tlas8Cap = 0;
+            return 0;
+        }
+        if (cap > s->tlas8Cap) {
+            if (s->tlas8) hipFree(s->tlas8);
+            if (s->tlas8Refs) hipFree(s->tlas8Refs);
+            s->tlas8 = nullptr; s->tlas8Refs = nullptr; s->tlas8Cap = 0;
+            HIP_TRY(hipMalloc((void**)&s->tlas8, cap * 80));
+            HIP_TRY(hipMalloc((void**)&s->tlas8Refs, cap * 4));
+            s->tlas8Cap = cap;
+            s->bytes += cap * 84;
+        }
+        const size_t sb = tlas_wide_scratch_bytes(s->nTlasNodes, s->nInst);
+        if (sb > s->tlas4ScratchBytes) {
+            if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
+            s->tlas4Scratch = nullptr; s->tlas4ScratchBytes = 0;
+            HIP_TRY(hipMalloc(&s->tlas4Scratch, sb));
+            s->tlas4ScratchBytes = sb;
+        }
+        launch_tlas8_build(s->nodes, (uint32_t)s->nTlasNodes, s->tlasIdx, (uint32_t)s->nTlasIdx, s->instances, (uint32_t)s->nInst, s->tlas8, (uint32_t)s->tlas8Cap, s->tlas8Refs,
+                           (uint32_t)s->tlas8Cap, s->tlas4Scratch, c->status, c->stream);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    if (s->blasLayout != TBVH_LAYOUT_BVH4_GPU) return 0;
+    const uint64_t cap = tlas4_cap_blocks(s->nTlasNodes, s->nInst);
+    if (cap > 0x7fffffffull) {   // beyond 31-bit block offsets: the flat loop serves this TLAS; drop a 4-wide TLAS of an earlier, smaller upload
+        if (s->tlas4) hipFree(s->tlas4);
+        s->tlas4 = nullptr; s->tlas4Cap = 0;
+        return 0;
+    }
+    if (cap > s->tlas4Cap) {
+        if (s->tlas4) hipFree(s->tlas4);
+        s->tlas4 = nullptr; s->tlas4Cap = 0;
+        HIP_TRY(hipMalloc((void**)&s->tlas4, cap * 16));
+        s->tlas4Cap = cap;
+        s->bytes += cap * 16;
+    }
+    const size_t sb = tlas_wide_scratch_bytes(s->nTlasNodes, s->nInst);
+    if (sb > s->tlas4ScratchBytes) {
+        if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
+        s->tlas4Scratch = nullptr; s->tlas4ScratchBytes = 0;
+        HIP_TRY(hipMalloc(&s->tlas4Scratch, sb));
+        s->tlas4ScratchBytes = sb;
+    }
+    launch_tlas4_build(s->nodes, (uint32_t)s->nTlasNodes, s->tlasIdx, (uint32_t)s->nTlasIdx, s->instances, (uint32_t)s->nInst, s->tlas4, (uint32_t)s->tlas4Cap, s->tlas4Scratch, c->status, c->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int tlasCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* idx, uint64_t nIdx, const void* inst, uint64_t nInst) {
+    tbvh_context* c = s->ctx;
+    // same hardening as the BLAS uploads: the TLAS kernels index instances[idx[]] and blas[blasIdx] unguarded
+    if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(TBVH_E_FORMAT, "TLAS: %s", why);
+    for (uint64_t i = 0; i < nIdx; i++) if (idx[i] >= nInst) return fail(TBVH_E_FORMAT, "TLAS: primIdx[%llu] = %u is not an instance (%llu instances)", (unsigned long long)i, idx[i], (unsigned long long)nInst);
+    const BLASInstanceCheck* ic = (const BLASInstanceCheck*)inst;
+    for (uint64_t i = 0; i < nInst; i++) if (ic[i].blasIdx >= s->nBlas) return fail(TBVH_E_FORMAT, "instance %llu: blasIdx %u out of range (%llu BLASes)", (unsigned long long)i, ic[i].blasIdx, (unsigned long long)s->nBlas);
+    if (nNodes > s->capNodes) { if (s->nodes) hipFree(s->nodes); s->nodes = nullptr; HIP_TRY(hipMalloc((void**)&s->nodes, nNodes * 64)); s->capNodes = nNodes; }
+    if (nIdx > s->capIdx) { if (s->tlasIdx) hipFree(s->tlasIdx); s->tlasIdx = nullptr; HIP_TRY(hipMalloc((void**)&s->tlasIdx, nIdx * 4)); s->capIdx = nIdx; }
+    if (nInst > s->capInst) { if (s->instances) hipFree(s->instances); s->instances = nullptr; HIP_TRY(hipMalloc((void**)&s->instances, nInst * 192)); s->capInst = nInst; }
+    HIP_TRY(hipMemcpyAsync(s->nodes, nodes64, nNodes * 64, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(s->tlasIdx, idx, nIdx * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(s->instances, inst, nInst * 192, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));  // the caller may reuse its host arrays right away
+    s->bytes = nNodes * 64 + nIdx * 4 + nInst * 192;
+    s->nInst = nInst; s->nTlasNodes = nNodes; s->nTlasIdx = nIdx;
+    return buildTlas4(s);
+}
+}  // namespace
+
+int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, const uint32_t* idx, uint64_t nIdx, const void* inst,
+                     uint64_t nInst, tbvh_scene* const* blas, uint64_t nBlas, tbvh_scene** out) {
+    if (!c || !nodes64 || !idx || !inst || !blas || !out || !nNodes || !nIdx || !nInst || !nBlas) return fail(TBVH_E_INVALID, "tbvh_upload_tlas: null/empty argument");
+    int layout = 0;
+    std::vector<BlasDesc> desc(nBlas);
+    for (uint64_t i = 0; i < nBlas; i++) {
+        const tbvh_scene* b = blas[i];
+        if (!b || b->ctx != c || b->isTlas || b->zombie) return fail(TBVH_E_INVALID, "BLAS %llu is null, freed, a TLAS, or from another context", (unsigned long long)i);
+        if (b->layout != TBVH_LAYOUT_CWBVH && b->layout != TBVH_LAYOUT_BVH4_GPU && b->layout != TBVH_LAYOUT_BVH_GPU)
+            return fail(TBVH_E_INVALID, "BLAS %llu: layout %d cannot be a BLAS", (unsigned long long)i, b->layout);
+        layout = i == 0 ? b->layout : (layout == b->layout ? layout : 0);   // 0: the BLASes mix layouts (traverse_tlas.cl:50-72)
+        desc[i].nodes = b->nodes; desc[i].tris = b->tris; desc[i].opmap = b->opmap; desc[i].opmapN = b->opmapN; desc[i].layout = (uint32_t)b->layout;
+    }
+    if (int r = setDevice(c)) return r;
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    s->isTlas = true; s->blasLayout = layout; s->nBlas = nBlas;
+    s->blasMixCw2 = layout == 0;
+    for (uint64_t i = 0; i < nBlas; i++) if (blas[i]->layout == TBVH_LAYOUT_BVH4_GPU) s->blasMixCw2 = false;
+    for (uint64_t i = 0; i < nBlas; i++) { s->blasList.push_back(blas[i]); blas[i]->usedBy.push_back(s); }
+    hipError_t e = hipMalloc((void**)&s->blasDesc, nBlas * sizeof(BlasDesc));
+    if (e == hipSuccess) e = hipMemcpy(s->blasDesc, desc.data(), nBlas * sizeof(BlasDesc), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "TLAS upload failed: %s", hipGetErrorString(e)); }
+    if (int r = tlasCopy(s, nodes64, nNodes, idx, nIdx, inst, nInst)) { tbvh_free_scene(s); return r; }
+    *out = s;
+    return 0;
+}
+
+int tbvh_update_tlas(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* idx, uint64_t nIdx, const void* inst, uint64_t nInst) {
+    if (!s || !s->isTlas || !nodes64 || !idx || !inst || !nNodes || !nIdx || !nInst) return fail(TBVH_E_INVALID, "tbvh_update_tlas: not a TLAS or null/empty argument");
+    if (int r = setDevice(s->ctx)) return r;
+    return tlasCopy(s, nodes64, nNodes, idx, nIdx, inst, nInst);
+}
+
+namespace {
+// BVH2 (device arrays) -> CWBVH scene.  msBefore: device time already spent on this request (builder), added to the report.
+int convertDeviceImpl4(tbvh_context* c, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris,
+                       tbvh_scene** out) {
+    struct Tmp {
+        void *blocks = nullptr, *itA = nullptr, *itB = nullptr, *cnt = nullptr;
+        ~Tmp() { for (void* p : {blocks, itA, itB, cnt}) if (p) hipFree(p); }
+    } t;
+    const uint64_t capItems = nNodes2 / 2 + 2, capBlocks = capItems * 4 + nIdx * 3;
+    if (capBlocks > 0xffffffffull) return fail(TBVH_E_INVALID, "BVH2 -> BVH4_GPU: stream would exceed 32-bit block indices");
+    HIP_TRY(hipMalloc(&t.blocks, capBlocks * 16));
+    HIP_TRY(hipMalloc(&t.itA, capItems * 8)); HIP_TRY(hipMalloc(&t.itB, capItems * 8)); HIP_TRY(hipMalloc(&t.cnt, 16));
+    uint64_t nBlocks = 0; uint32_t levels = 0;
+    HIP_TRY(run_convert_bvh4(dN2, (uint32_t)nNodes2, dIdx, nIdx, dV, nTris, (float4*)t.blocks, capBlocks, (uint2*)t.itA, (uint2*)t.itB, (uint32_t*)t.cnt, c->status,
+                             c->stream, &nBlocks, &levels));
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpy(&st, c->status, 4, hipMemcpyDeviceToHost));
+    if (st & 12u) {
+        hipMemset(c->status, 0, 4);
+        return fail(TBVH_E_FORMAT, (st & 8u) ? "BVH2 -> BVH4_GPU: a node's inline triangles exceed the 16-bit relative offset (leaves too large)"
+                                             : "BVH2 -> BVH4_GPU: malformed BVH2 (child, primitive or triangle index out of range)");
+    }
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH4_GPU);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    hipError_t e = hipMalloc((void**)&s->nodes, nBlocks * 16);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, t.blocks, nBlocks * 16, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH2 -> BVH4_GPU: %s", hipGetErrorString(e)); }
+    s->nNodeBlocks = nBlocks; s->bytes = nBlocks * 16;
+    *out = s;
+    return 0;
+}
+
+int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris,
+                      tbvh_scene** out) {
+    if (layout == TBVH_LAYOUT_BVH4_GPU) return convertDeviceImpl4(c, dN2, nNodes2, dIdx, nIdx, dV, nTris, out);
+    struct Tmp {
+        void *nodes = nullptr, *tris = nullptr, *itA = nullptr, *itB = nullptr, *cnt = nullptr;
+        ~Tmp() { for (void* p : {nodes, tris, itA, itB, cnt}) if (p) hipFree(p); }
+    } t;
+    // worst case: every BVH2 interior node becomes a wide node ((n + 1) / 2 of them in a full binary tree, + the root)
+    const uint32_t capNodes = (uint32_t)(nNodes2 / 2 + 2);
+    HIP_TRY(hipMalloc(&t.nodes, (size_t)capNodes * 80)); HIP_TRY(hipMalloc(&t.tris, nIdx * 48));
+    HIP_TRY(hipMalloc(&t.itA, (size_t)capNodes * 8)); HIP_TRY(hipMalloc(&t.itB, (size_t)capNodes * 8)); HIP_TRY(hipMalloc(&t.cnt, 16));
+    uint32_t nWide = 0, levels = 0; uint64_t nWideTris = 0;
+    HIP_TRY(run_convert_cwbvh(dN2, (uint32_t)nNodes2, dIdx, nIdx, dV, nTris, (float4*)t.nodes, capNodes, (float4*)t.tris, nIdx, (uint2*)t.itA, (uint2*)t.itB,
+                              (uint32_t*)t.cnt, c->status, c->stream, &nWide, &nWideTris, &levels));
+    uint32_t st = 0;
+    HIP_TRY(hipMemcpy(&st, c->status, 4, hipMemcpyDeviceToHost));
+    if (st & 12u) {
+        hipMemset(c->status, 0, 4);
+        return fail(TBVH_E_FORMAT, (st & 8u) ? "BVH2 -> CWBVH: a BVH2 leaf holds more than 3 triangles (SplitLeafs(3) first, like BVH8_CWBVH::ConvertFrom)"
+                                             : "BVH2 -> CWBVH: malformed BVH2 (child, primitive or triangle index out of range)");
+    }
+    tbvh_scene* s = newScene(c, TBVH_LAYOUT_CWBVH);
+    if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
+    // keep exactly what was produced
+    hipError_t e = hipMalloc((void**)&s->nodes, (size_t)nWide * 80);
+    if (e == hipSuccess) e = hipMalloc((void**)&s->tris, (nWideTris ? nWideTris : 1) * 48);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, t.nodes, (size_t)nWide * 80, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess && nWideTris) e = hipMemcpyAsync(s->tris, t.tris, nWideTris * 48, hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH2 -> CWBVH: %s", hipGetErrorString(e)); }
+    s->nNodes = nWide; s->nNodeBlocks = (uint64_t)nWide * 5; s->nTriBlocks = nWideTris * 3;
+    s->bytes = (s->nNodeBlocks + s->nTriBlocks) * 16;
+    if (int r = padCwbvhIfLarge(s)) { tbvh_free_scene(s); return r; }
+    if (int r = prepareIncoherentCopies(s, nullptr)) { tbvh_free_scene(s); return r; }
+    *out = s;
+    return 0;
+}
+}  // namespace
+
+int tbvh_convert_bvh2_device(tbvh_context* c, const void* nodes32, uint64_t nNodes2, const uint32_t* primIdx, uint64_t nIdx, const void* verts16,
+                             uint64_t nTris, int onDevice, int layout, tbvh_scene** out) {
+    if (!c || !nodes32 || !primIdx || !verts16 || !out || nNodes2 == 0 || nIdx == 0 || nTris == 0) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: null/empty argument");
+    if (layout != TBVH_LAYOUT_CWBVH && layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: target layout %d not supported (BVH8_CWBVH and BVH4_GPU are)", layout);
+    if (nNodes2 > 0x7fffffffull || nIdx > 0x7fffffffull) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: BVH2 too large for 32-bit node / triangle indices");
+    if (int r = setDevice(c)) return r;
+    struct Tmp {
+        void *n2 = nullptr, *idx = nullptr, *v = nullptr;
+        ~Tmp() { for (void* p : {n2, idx, v}) if (p) hipFree(p); }
+    } t;
+    const float4 *dN2 = (const float4*)nodes32, *dV = (const float4*)verts16;
+    const uint32_t* dIdx = primIdx;
+    if (!onDevice) {
+        HIP_TRY(hipMalloc(&t.n2, nNodes2 * 32)); HIP_TRY(hipMalloc(&t.idx, nIdx * 4)); HIP_TRY(hipMalloc(&t.v, nTris * 48));
+        HIP_TRY(hipMemcpyAsync(t.n2, nodes32, nNodes2 * 32, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(t.idx, primIdx, nIdx * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(t.v, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream));
+        dN2 = (const float4*)t.n2; dIdx = (const uint32_t*)t.idx; dV = (const float4*)t.v;
+    }
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    const int r = convertDeviceImpl(c, layout, dN2, nNodes2, dIdx, nIdx, dV, nTris, out);
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return r;
+}
+
+namespace {
+// builder: 0 = LBVH (maxLeafTris applies), 1 = PLOC (one triangle per leaf; radius = search window to each side)
+int buildDeviceImpl(const char* who, tbvh_context* c, const void* verts16, uint64_t nTris, int onDevice, int layout, uint32_t maxLeafTris, int builder, uint32_t radius,
+                    tbvh_scene** out) {
+    if (!c || !verts16 || !out || nTris == 0) return fail(TBVH_E_INVALID, "%s: null/empty argument", who);
+    if (layout != TBVH_LAYOUT_CWBVH && layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "%s: target layout %d not supported (BVH8_CWBVH and BVH4_GPU are)", who, layout);
+    if (nTris > 0x3fffffffull) return fail(TBVH_E_INVALID, "%s: too many triangles for 32-bit node indices", who);
+    if (int r = setDevice(c)) return r;
+    struct Tmp {
+        void *v = nullptr, *n2 = nullptr, *idx = nullptr, *scratch = nullptr;
+        ~Tmp() { for (void* p : {v, n2, idx, scratch}) if (p) hipFree(p); }
+    } t;
+    const float4* dV = (const float4*)verts16;
+    if (!onDevice) {
+        HIP_TRY(hipMalloc(&t.v, nTris * 48));
+        HIP_TRY(hipMemcpyAsync(t.v, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream));
+        dV = (const float4*)t.v;
+    }
+    size_t sortTemp = 0, scanTemp = 0;
+    const size_t scratchBytes = builder == 1 ? ploc_scratch_bytes((uint32_t)nTris, &sortTemp, &scanTemp) : lbvh_scratch_bytes((uint32_t)nTris, &sortTemp);
+    HIP_TRY(hipMalloc(&t.n2, nTris * 2 * 32)); HIP_TRY(hipMalloc(&t.idx, nTris * 4)); HIP_TRY(hipMalloc(&t.scratch, scratchBytes));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    if (builder == 1) HIP_TRY(launch_ploc_build(dV, (uint32_t)nTris, radius, (float4*)t.n2, (uint32_t*)t.idx, t.scratch, sortTemp, scanTemp, c->stream, nullptr));
+    else HIP_TRY(launch_lbvh_build(dV, (uint32_t)nTris, maxLeafTris, (float4*)t.n2, (uint32_t*)t.idx, t.scratch, sortTemp, c->stream));
+    const int r = convertDeviceImpl(c, layout, (const float4*)t.n2, nTris * 2, (const uint32_t*)t.idx, nTris, dV, nTris, out);
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return r;
+}
+}  // namespace
+
+int tbvh_build_device(tbvh_context* c, const void* verts16, uint64_t nTris, int onDevice, int layout, uint32_t maxLeafTris, tbvh_scene** out) {
+    const uint32_t leafCap = layout == TBVH_LAYOUT_CWBVH ? 3u : 4u;
+    // default: one triangle per leaf for CWBVH.  Contiguous Morton ranges make poor multi-triangle leaves: measured on the
+    // Bistro stand-in, 1 / 2 / 3 triangles per leaf trace camera rays at 3629 / 3354 / 3125 and bounce rays at 2323 / 2150 /
+    // 1884 MRays/s (the host SAH tree: 3300 / 2480), for 13 instead of 8 ms of build time and 22 % more memory
+    if (maxLeafTris == 0) maxLeafTris = layout == TBVH_LAYOUT_CWBVH ? 1u : leafCap;
+    if (maxLeafTris > leafCap) return fail(TBVH_E_INVALID, "tbvh_build_device: at most %u triangles per leaf for this layout", leafCap);
+    return buildDeviceImpl("tbvh_build_device", c, verts16, nTris, onDevice, layout, maxLeafTris, 0, 0, out);
+}
+
+int tbvh_build_device_ploc(tbvh_context* c, const void* verts16, uint64_t nTris, int onDevice, int layout, uint32_t radius, tbvh_scene** out) {
+    if (radius == 0) radius = 16;
+    if (radius > 32u) return fail(TBVH_E_INVALID, "tbvh_build_device_ploc: search radius %u (1..32; 0 = the default 16)", radius);
+    return buildDeviceImpl("tbvh_build_device_ploc", c, verts16, nTris, onDevice, layout, 1, 1, radius, out);
+}
+
+namespace {
+// the TLASes over BLAS b hold a snapshot of its device pointers: rewrite their entries for b
+int refreshBlasDescs(tbvh_scene* b) {
+    for (tbvh_scene* t : b->usedBy)
+        for (size_t i = 0; i < t->blasList.size(); i++)
+            if (t->blasList[i] == b) {
+                BlasDesc d; d.nodes = b->nodes; d.tris = b->tris; d.opmap = b->opmap; d.opmapN = b->opmapN; d.layout = (uint32_t)b->layout;
+                HIP_TRY(hipMemcpy(t->blasDesc + i, &d, sizeof d, hipMemcpyHostToDevice));
+            }
+    return 0;
+}
+}  // namespace
+
+int tbvh_set_opacity_micromaps(tbvh_scene* s, const uint32_t* mapData, uint32_t N, uint64_t nTris, int onDevice) {
+    if (!s || s->isTlas) return fail(TBVH_E_INVALID, "tbvh_set_opacity_micromaps: not a BLAS scene (set the maps on the BLASes before uploading their TLAS)");
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    // validate first, build the new map next, and only then swap it in: every exit leaves the scene and the TLASes over it (their BlasDesc
+    // snapshots) pointing at live memory — the old maps on a failure, the new ones on success
+    const bool clear = !mapData || N == 0;
+    if (!clear && (N > 1024 || nTris == 0)) return fail(TBVH_E_INVALID, "tbvh_set_opacity_micromaps: N = %u, %llu triangles", N, (unsigned long long)nTris);
+    uint32_t* fresh = nullptr;
+    uint64_t freshBytes = 0;
+    if (!clear) {
+        const uint64_t wordsPerTri = ((uint64_t)N * N + 31) >> 5, words = wordsPerTri * nTris;
+        // the reference's index can run one row past the map when u + v == 1 exactly (tiny_bvh.h:8518-8519): keep that read inside the allocation
+        const uint64_t pad = (((uint64_t)N + 1) * (N + 1) + 63) >> 5;
+        freshBytes = (words + pad) * 4;
+        if (hipMalloc((void**)&fresh, freshBytes) != hipSuccess) { (void)hipGetLastError(); return fail(TBVH_E_NOMEM, "tbvh_set_opacity_micromaps: %llu bytes of device memory", (unsigned long long)freshBytes); }
+        hipError_t e = hipMemsetAsync(fresh + words, 0, pad * 4, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(fresh, mapData, words * 4, onDevice ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { hipFree(fresh); return fail(TBVH_E_HIP, "tbvh_set_opacity_micromaps: copying the maps failed: %s", hipGetErrorString(e)); }
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));   // no query may still read the old maps
+    uint32_t* old = s->opmap;
+    const uint64_t oldBytes = s->opmapBytes;
+    s->opmap = fresh; s->opmapN = clear ? 0u : N; s->opmapBytes = freshBytes;
+    s->bytes += freshBytes; s->bytes -= oldBytes;
+    const int r = refreshBlasDescs(s);   // the descriptors are rewritten before the old maps go
+    if (old && r == 0) hipFree(old);   // (a failed refresh may have left a descriptor on the old maps: leak them rather than dangle)
+    return r;
+}
+
+int tbvh_scene_download(tbvh_scene* s, int which, void* dst, uint64_t capBytes, uint64_t* bytesOut) {
+    if (!s || s->isTlas || (which != 0 && which != 1)) return fail(TBVH_E_INVALID, "tbvh_scene_download: not a BLAS scene or bad blob selector");
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    const void* src = which == 0 ? (const void*)s->nodes : (const void*)s->tris;
+    const uint64_t bytes = (which == 0 ? s->nNodeBlocks : s->nTriBlocks) * 16;
+    if (bytesOut) *bytesOut = src ? bytes : 0;
+    if (!dst) return 0;
+    if (!src) return fail(TBVH_E_INVALID, "tbvh_scene_download: this layout has no such blob");
+    if (capBytes < bytes) return fail(TBVH_E_INVALID, "tbvh_scene_download: buffer too small (%llu < %llu bytes)", (unsigned long long)capBytes, (unsigned long long)bytes);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice) {
+    if (!s || !verts16 || !nTris) return fail(TBVH_E_INVALID, "tbvh_refit: null/empty argument");
+    if (s->isTlas) return fail(TBVH_E_INVALID, "tbvh_refit: a TLAS is rebuilt with tbvh_rebuild_tlas_device / tbvh_update_tlas");
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    if (s->layout == TBVH_LAYOUT_BVH4_GPU) {
+        // node list per level, child-box hand-over area: sized for the most nodes the stream can hold (4 blocks each)
+        const uint32_t capNodes = (uint32_t)(s->nNodeBlocks / 4 + 1);
+        if (!s->refitScratch) HIP_TRY(hipMalloc(&s->refitScratch, (size_t)capNodes * (16 + 128) + 256));
+        const float4* dv4 = (const float4*)verts16;
+        if (!onDevice) {
+            if (s->vertStageTris < nTris) {
+                if (s->vertStage) hipFree(s->vertStage);
+                s->vertStage = nullptr; s->vertStageTris = 0;
+                HIP_TRY(hipMalloc((void**)&s->vertStage, nTris * 48));
+                s->vertStageTris = nTris;
+            }
+            HIP_TRY(hipMemcpyAsync(s->vertStage, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream));
+            dv4 = s->vertStage;
+        }
+        char* base = (char*)s->refitScratch;
+        uint32_t* counter = (uint32_t*)base;
+        void* items = base + 256;
+        float4* childBox = (float4*)(base + 256 + (size_t)capNodes * 16);
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        HIP_TRY(run_refit_bvh4(s->nodes, s->nNodeBlocks, dv4, nTris, items, capNodes, counter, childBox, s->b4Levels, c->status, c->stream));
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        c->timed = true;
+        return 0;
+    }
+    if (s->layout != TBVH_LAYOUT_CWBVH && s->layout != TBVH_LAYOUT_BVH_GPU)
+        return fail(TBVH_E_INVALID, "tbvh_refit: layout %d is not refittable", s->layout);
+    const uint32_t nNodes = (uint32_t)(s->layout == TBVH_LAYOUT_CWBVH ? s->nNodeBlocks / 5 : s->nNodeBlocks / 4);
+    const uint64_t nRecords = s->nTriBlocks / 3;
+    if (!s->refitScratch) HIP_TRY(hipMalloc(&s->refitScratch, refit_scratch_bytes(s->layout, nNodes)));
+    const float4* dv = (const float4*)verts16;
+    if (!onDevice) {
+        if (s->vertStageTris < nTris) {
+            if (s->vertStage) hipFree(s->vertStage);
+            s->vertStage = nullptr; s->vertStageTris = 0;
+            HIP_TRY(hipMalloc((void**)&s->vertStage, nTris * 48));
+            s->vertStageTris = nTris;
+        }
+        HIP_TRY(hipMemcpyAsync(s->vertStage, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream));
+        dv = s->vertStage;
+    }
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(launch_refit(s->layout, s->nodes, nNodes, s->tris, nRecords, dv, nTris, s->refitScratch, c->status, c->stream));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    // derived node layouts of the experiment kernels would be stale now
+    if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copy current
+    if (s->nodesHy) launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, nNodes, s->hybridK, c->stream);
+    if (s->tris64) launch_cwbvh_pad_tris(s->tris, s->tris64, s->nTriBlocks / 3, c->stream);
+    return 0;
+}
+
+int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice, const float* blasBounds6, uint64_t nBlas) {
+    if (!s || !s->isTlas) return fail(TBVH_E_INVALID, "tbvh_rebuild_tlas_device: not a TLAS");
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    const uint64_t n = s->nInst;
+    if (n == 0 || n > 0x7fffffffull) return fail(TBVH_E_INVALID, "tbvh_rebuild_tlas_device: %llu instances", (unsigned long long)n);
+    if (blasBounds6) {
+        if (nBlas != s->nBlas) return fail(TBVH_E_INVALID, "tbvh_rebuild_tlas_device: %llu BLAS bounds for a TLAS over %llu BLASes", (unsigned long long)nBlas, (unsigned long long)s->nBlas);
+        if (!s->blasBounds) HIP_TRY(hipMalloc((void**)&s->blasBounds, s->nBlas * 24));
+        HIP_TRY(hipMemcpyAsync(s->blasBounds, blasBounds6, s->nBlas * 24, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // the caller's array may go away
+    }
+    if (!s->blasBounds) return fail(TBVH_E_INVALID, "tbvh_rebuild_tlas_device: the first call needs blas_bounds6");
+    // an LBVH over n leaves has 2n - 1 nodes and n index entries
+    const uint64_t nNodes = 2 * n - 1;
+    if (nNodes > s->capNodes) { if (s->nodes) hipFree(s->nodes); s->nodes = nullptr; s->capNodes = 0; HIP_TRY(hipMalloc((void**)&s->nodes, nNodes * 64)); s->capNodes = nNodes; }
+    if (n > s->capIdx) { if (s->tlasIdx) hipFree(s->tlasIdx); s->tlasIdx = nullptr; s->capIdx = 0; HIP_TRY(hipMalloc((void**)&s->tlasIdx, n * 4)); s->capIdx = n; }
+    if (s->buildScratchFor != n) {
+        if (s->buildScratch) hipFree(s->buildScratch);
+        s->buildScratch = nullptr; s->buildScratchFor = 0;
+        s->buildScratchBytes = tlas_build_scratch_bytes((uint32_t)n, &s->sortTempBytes);
+        HIP_TRY(hipMalloc(&s->buildScratch, s->buildScratchBytes));
+        s->buildScratchFor = n;
+    }
+    const float* xf = nullptr;
+    if (transforms) {
+        if (onDevice) xf = (const float*)transforms;
+        else {
+            if (s->xformStageCap < n) {   // tbvh_update_tlas may have grown the instance array since the last rebuild
+                if (s->xformStage) hipFree(s->xformStage);
+                s->xformStage = nullptr; s->xformStageCap = 0;
+                HIP_TRY(hipMalloc((void**)&s->xformStage, n * 64));
+                s->xformStageCap = n;
+            }
+            HIP_TRY(hipMemcpyAsync(s->xformStage, transforms, n * 64, hipMemcpyHostToDevice, c->stream));
+            xf = s->xformStage;
+        }
+    }
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(launch_tlas_rebuild(s->nodes, s->tlasIdx, s->instances, xf, s->blasBounds, (uint32_t)n, (uint32_t)s->nBlas, s->buildScratch, s->sortTempBytes, c->stream));
+    s->bytes = nNodes * 64 + n * 4 + n * 192;
+    s->nTlasNodes = nNodes; s->nTlasIdx = n;
+    if (int r = buildTlas4(s)) return r;
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    return 0;
+}
+
+int tbvh_tlas_download(tbvh_scene* s, void* nodes64, uint64_t capNodes, uint32_t* idx, uint64_t capIdx, void* instances192, uint64_t capInst,
+                       uint64_t* nNodesOut) {
+    if (!s || !s->isTlas) return fail(TBVH_E_INVALID, "tbvh_tlas_download: not a TLAS");
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const uint64_t n = s->nInst, nNodes = s->nTlasNodes;
+    if (nNodesOut) *nNodesOut = nNodes;
+    if (nodes64) { if (capNodes < nNodes) return fail(TBVH_E_INVALID, "tbvh_tlas_download: node buffer too small"); HIP_TRY(hipMemcpy(nodes64, s->nodes, nNodes * 64, hipMemcpyDeviceToHost)); }
+    if (idx) { if (capIdx < n) return fail(TBVH_E_INVALID, "tbvh_tlas_download: index buffer too small"); HIP_TRY(hipMemcpy(idx, s->tlasIdx, n * 4, hipMemcpyDeviceToHost)); }
+    if (instances192) { if (capInst < n) return fail(TBVH_E_INVALID, "tbvh_tlas_download: instance buffer too small"); HIP_TRY(hipMemcpy(instances192, s->instances, n * 192, hipMemcpyDeviceToHost)); }
+    return 0;
+}
+
+void tbvh_free_scene(tbvh_scene* s) {
+    if (!s) return;
+    tbvh_context* c = s->ctx;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    if (!s->isTlas && !s->usedBy.empty()) { s->zombie = true; return; }   // a TLAS still points at this BLAS's memory: freed with the last such TLAS
+    if (s->isTlas) {
+        std::vector<tbvh_scene*> mine;
+        mine.swap(s->blasList);
+        for (tbvh_scene* b : mine) {
+            for (size_t i = 0; i < b->usedBy.size(); i++) if (b->usedBy[i] == s) { b->usedBy.erase(b->usedBy.begin() + i); break; }
+            if (b->zombie && b->usedBy.empty()) { b->zombie = false; tbvh_free_scene(b); }
+        }
+    }
+    if (s->nodes) hipFree(s->nodes);
+    if (s->tris) hipFree(s->tris);
+    if (s->nodes128) hipFree(s->nodes128);
+    if (s->nodesHy) hipFree(s->nodesHy);
+    if (s->tris64) hipFree(s->tris64);
+    if (s->hyPerm) hipFree(s->hyPerm);
+    if (s->tlasIdx) hipFree(s->tlasIdx);
+    if (s->instances) hipFree(s->instances);
+    if (s->blasDesc) hipFree(s->blasDesc);
+    if (s->blasBounds) hipFree(s->blasBounds);
+    if (s->xformStage) hipFree(s->xformStage);
+    if (s->buildScratch) hipFree(s->buildScratch);
+    if (s->tlas4) hipFree(s->tlas4);
+    if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
+    if (s->tlas8) hipFree(s->tlas8);
+    if (s->tlas8Refs) hipFree(s->tlas8Refs);
+    if (s->refitScratch) hipFree(s->refitScratch);
+    if (s->opmap) hipFree(s->opmap);
+    if (s->vertStage) hipFree(s->vertStage);
+    for (size_t i = 0; i < c->scenes.size(); i++)
+        if (c->scenes[i] == s) { c->scenes.erase(c->scenes.begin() + i); break; }
+    delete s;
+}
+int tbvh_scene_layout(const tbvh_scene* s) { return s ? s->layout : TBVH_E_INVALID; }
+uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0; }
+
+int tbvh_set_variant(tbvh_scene* s, int v) {
+    if (!s) return fail(TBVH_E_INVALID, "null scene");
+    // only the BVH8_CWBVH kernel keeps diagnostic variants (kernels_cwbvh.hip: forced schedules, instrumented kernels)
+    const bool ok = v == 0 || (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH && cwbvh_variant_valid(v));
+    if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
+    s->variant = v;
+    return 0;
+}
+
+int tbvh_cwbvh_set_hybrid(tbvh_scene* s, int64_t packedNodes) {
+    if (!s || s->isTlas || s->layout != TBVH_LAYOUT_CWBVH) return fail(TBVH_E_INVALID, "tbvh_cwbvh_set_hybrid: not a BVH8_CWBVH scene");
+    tbvh_context* c = s->ctx;
+    if (int r = setDevice(c)) return r;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (s->nodesHy) { s->bytes -= hybridBytes(s->nNodes, s->hybridK); hipFree(s->nodesHy); s->nodesHy = nullptr; }
+    if (packedNodes < 0) return 0;
+    const uint32_t K = (uint32_t)std::min<uint64_t>((uint64_t)packedNodes, s->nNodes) & ~7u;   // the padded part starts on a 128-byte line
+    if (!s->hyPerm) {
+        std::vector<Vec4> host((size_t)s->nNodes * 5);
+        HIP_TRY(hipMemcpy(host.data(), s->nodes, host.size() * 16, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> perm;
+        cwbvh_priority_order(host.data(), s->nNodes, perm);
+        HIP_TRY(hipMalloc((void**)&s->hyPerm, (size_t)s->nNodes * 4));
+        HIP_TRY(hipMemcpy(s->hyPerm, perm.data(), (size_t)s->nNodes * 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc((void**)&s->nodesHy, hybridBytes(s->nNodes, K)));
+    HIP_TRY(hipMemsetAsync(s->nodesHy, 0, hybridBytes(s->nNodes, K), c->stream));
+    s->hybridK = K;
+    launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, s->nNodes, K, c->stream);
+    HIP_TRY(hipGetLastError());
+    s->bytes += hybridBytes(s->nNodes, K);
+    if (!s->tris64 && s->nTriBlocks) {
+        const uint64_t nT = s->nTriBlocks / 3;
+        HIP_TRY(hipMalloc((void**)&s->tris64, nT * 64));
+        launch_cwbvh_pad_tris(s->tris, s->tris64, nT, c->stream);
+        HIP_TRY(hipGetLastError());
+        s->bytes += nT * 64;
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+}  // extern "C"
