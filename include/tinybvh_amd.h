@@ -262,6 +262,14 @@ int tbvh_reset_hits_device(tbvh_context* ctx, void* d_rays64, uint64_t n_rays, f
  * Synchronizes the stream. */
 float tbvh_time_last_ms(tbvh_context* ctx);
 
+/* The same without a synchronisation per call: the HIP-event durations (ms) of the most recent timed operations on this
+ * context (queries, refits, builds, rebuilds: everything tbvh_time_last_ms reports), oldest first, at most `cap` and at most
+ * the 256 the context remembers; *count = how many were written.  A renderer (or bench.py's timed loop) enqueues its
+ * launches back to back and reads the durations once at the end — per-launch tbvh_time_last_ms() calls expose every
+ * launch's latency (0.4 ms per two-query step on the round-3 driver box).  Waits for the operations it reports.
+ * An entry is -1 when that operation failed before its end was recorded. */
+int tbvh_time_history(tbvh_context* ctx, float* ms, uint32_t cap, uint32_t* count);
+
 /* The machine's own ceilings, measured where the kernels run (bench.py's roofline denominators; best of `reps` launches, 0 = 3):
  *   copy   GB/s read + written by a streaming copy over `bytes` (one float4 per thread, non-temporal; MI355X: 8 TB/s HBM3E peak on
  *          the data sheet, 6.3-6.5 measured: tools/ubench/copy_rate.hip);

@@ -215,6 +215,32 @@ class RefScene:
         return sec, hits.value
 
 
+class RefTlas:
+    """The real BVH::Build(BLASInstance*, ...) + BVH::IntersectTLAS (tiny_bvh.h:2221-2259, 3306-3380) over RefScene BLASes.
+    `instances` (192-byte BLASInstance records with transform / blasIdx / mask set) are copied; .inst holds them as the
+    reference updated them (BLASInstance::Update)."""
+
+    def __init__(self, ref: Reference, instances, ref_scenes):
+        self.ref = ref
+        self.scenes = list(ref_scenes)        # keep the BLASes alive
+        self.inst = np.ascontiguousarray(instances).copy()
+        arr = (_vp * len(self.scenes))(*[s.h for s in self.scenes])
+        self.h = ref.lib.ref_tlas_build(_p(self.inst), self.inst.shape[0], arr, len(self.scenes))
+
+    def intersect(self, rays):
+        r = np.ascontiguousarray(rays).copy()
+        assert self.ref.lib.ref_tlas_intersect(self.h, _p(r), r.shape[0], r.strides[0]) == 0
+        return r
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ref.lib.ref_tlas_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 # ---- comparison with the parity contract -----------------------------------------------------------
 
 def compare_hits(got: np.ndarray, want: np.ndarray, rtol: float = 1e-5):
@@ -256,6 +282,45 @@ def compare_hits(got: np.ndarray, want: np.ndarray, rtol: float = 1e-5):
         bi &= got[f][both].view(np.uint32) == want[f][both].view(np.uint32)
     res["bit_identical"] = int(bi.sum())
     res["same_prim"] = int(sp.sum())
+    return res
+
+
+def compare_with_real_reference(got: np.ndarray, want: np.ndarray, check_inst: bool = False, ulp_window: int = 64):
+    """GPU hit records against records of the REAL reference (oracle/_ref: BVH::Intersect / IntersectTLAS of tiny_bvh.h, run under ITS
+    tie rule — among exactly equal t the later test wins, tiny_bvh.h:1656).  The library deviates from that rule in two deliberate,
+    documented ways (DESIGN.md par. 4), and this comparison COUNTS each instead of folding them into a tolerance:
+      tie_equal_t      both report a hit at the bit-identical t but name different primitives (or instances): the library's
+                       order-independent rule (smaller prim, then smaller instance) against the reference's traversal-order-dependent one;
+      closer_by_ulps   the library's t is SMALLER by 1..ulp_window ulps (whatever the prim): box tests cull 2^-20 beyond the closest hit
+                       (device_common.h: cull_bound), so a candidate within a few ulps behind a face the reference's exact bound culled
+                       is still tested and may win;
+      farther_by_ulps  the library's t is LARGER by 1..ulp_window ulps (expected 0: tri_test rejects t > hit.t exactly).
+    Real errors: hitmiss, prim_real (different primitive, t apart by more than the window), t_bad (same primitive, t apart by more than
+    the window), uv_differs (same primitive, same t bits, u or v bits differ).  onsurf (one side reports t == +-0: ray origin exactly on a
+    triangle's plane, where the reference's own layouts disagree with each other) is counted and excluded, as in compare_hits."""
+    far = np.float32(1e30)
+    gh, wh = got["t"] < far, want["t"] < far
+    onsurf = ((got["t"] == 0) | (want["t"] == 0)) & ((got["prim"] != want["prim"]) | (gh != wh))
+    both = gh & wh & ~onsurf
+    gt = got["t"][both].view(np.int32).astype(np.int64); wt = want["t"][both].view(np.int32).astype(np.int64)   # positive floats order like their bits
+    ulps = gt - wt
+    same = got["prim"][both] == want["prim"][both]
+    if check_inst:
+        same &= got["inst"][both] == want["inst"][both]
+    uv_same = (got["u"][both].view(np.uint32) == want["u"][both].view(np.uint32)) & (got["v"][both].view(np.uint32) == want["v"][both].view(np.uint32))
+    near = np.abs(ulps) <= ulp_window
+    res = {"n": int(got.shape[0]), "hits": int(wh.sum()), "onsurf": int(onsurf.sum()),
+           "hitmiss": int(((gh != wh) & ~onsurf).sum()),
+           "identical": int((same & (ulps == 0) & uv_same).sum()),
+           "tie_equal_t": int((~same & (ulps == 0)).sum()),
+           "closer_by_ulps": int(((ulps < 0) & near).sum()),
+           "closer_by_ulps_same_prim": int(((ulps < 0) & near & same).sum()),
+           "farther_by_ulps": int(((ulps > 0) & near).sum()),
+           "max_ulps": int(np.abs(ulps[near]).max()) if near.any() else 0,
+           "prim_real": int((~same & ~near).sum()),
+           "t_bad": int((same & ~near).sum()),
+           "uv_differs": int((same & (ulps == 0) & ~uv_same).sum())}
+    res["differ_from_reference"] = res["tie_equal_t"] + res["closer_by_ulps"] + res["farther_by_ulps"]
     return res
 
 

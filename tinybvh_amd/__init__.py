@@ -113,6 +113,14 @@ class Context:
     def time_last_ms(self) -> float:
         return float(lib.tbvh_time_last_ms(self._h))
 
+    def time_history(self, k: int):
+        """HIP-event durations (ms) of the last k timed operations on this context, oldest first (tbvh_time_history): what a
+        caller that enqueues its launches back to back reads ONCE instead of synchronizing after every launch."""
+        buf = (C.c_float * max(int(k), 1))()
+        cnt = C.c_uint32(0)
+        check(lib.tbvh_time_history(self._h, buf, int(k), C.byref(cnt)), "tbvh_time_history")
+        return [float(buf[i]) for i in range(cnt.value)]
+
     def set_debug_flags(self, flags: int):
         check(lib.tbvh_debug_set_flags(self._h, int(flags)), "tbvh_debug_set_flags")
 

@@ -21,6 +21,20 @@ int setDevice(tbvh_context* c) {
     HIP_TRY(hipSetDevice(c->device));
     return 0;
 }
+hipError_t timedBegin(tbvh_context* c) {
+    const uint32_t slot = (uint32_t)(c->evSeq % tbvh_context::kTimeRing);
+    for (int k = 0; k < 2; k++)
+        if (!c->evRing[slot][k]) { const hipError_t e = hipEventCreate(&c->evRing[slot][k]); if (e != hipSuccess) return e; }
+    c->evDone[slot] = false;
+    c->ev0 = c->evRing[slot][0]; c->ev1 = c->evRing[slot][1];
+    c->evSeq++;
+    return hipEventRecord(c->ev0, c->stream);
+}
+hipError_t timedEnd(tbvh_context* c) {
+    const hipError_t e = hipEventRecord(c->ev1, c->stream);
+    if (e == hipSuccess && c->evSeq) { c->evDone[(c->evSeq - 1) % tbvh_context::kTimeRing] = true; c->timed = true; }
+    return e;
+}
 }  // namespace tbvh_capi
 
 extern "C" {
@@ -48,8 +62,6 @@ int tbvh_init(int device, tbvh_context** out) {
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e != hipSuccess) { delete c; return fail(TBVH_E_HIP, "context setup failed: %s", hipGetErrorString(e)); }
     c->stream = c->ownStream;
     c->numCUs = prop.multiProcessorCount;
@@ -99,8 +111,7 @@ void tbvh_shutdown(tbvh_context* c) {
     if (c->stageOcc) hipFree(c->stageOcc);
     if (c->binScratch) hipFree(c->binScratch);
     delete c->pipe;
-    if (c->ev0) hipEventDestroy(c->ev0);
-    if (c->ev1) hipEventDestroy(c->ev1);
+    for (auto& pair : c->evRing) for (hipEvent_t ev : pair) if (ev) hipEventDestroy(ev);
     if (c->ownStream) hipStreamDestroy(c->ownStream);
     delete c;
 }
@@ -125,6 +136,25 @@ float tbvh_time_last_ms(tbvh_context* c) {
     float ms = -1.0f;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) != hipSuccess) return -1.0f;
     return ms;
+}
+
+int tbvh_time_history(tbvh_context* c, float* ms, uint32_t cap, uint32_t* count) {
+    if (!c || !count || (!ms && cap)) return fail(TBVH_E_INVALID, "tbvh_time_history: null argument");
+    *count = 0;
+    if (int r = setDevice(c)) return r;
+    uint64_t n = c->evSeq < tbvh_context::kTimeRing ? c->evSeq : tbvh_context::kTimeRing;
+    if (n > cap) n = cap;
+    for (uint64_t i = 0; i < n; i++) {   // oldest first
+        const uint32_t slot = (uint32_t)((c->evSeq - n + i) % tbvh_context::kTimeRing);
+        float t = -1.0f;
+        if (c->evDone[slot]) {
+            HIP_TRY(hipEventSynchronize(c->evRing[slot][1]));
+            HIP_TRY(hipEventElapsedTime(&t, c->evRing[slot][0], c->evRing[slot][1]));
+        }
+        ms[i] = t;
+    }
+    *count = (uint32_t)n;
+    return 0;
 }
 
 int tbvh_debug_stats(tbvh_context* c, uint64_t out[8], int reset) {

@@ -44,6 +44,13 @@ struct tbvh_context {
     int device = 0;
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
+    // HIP-event timing: every timed operation (query, refit, build, ...) takes the next of kTimeRing event pairs, so a caller can enqueue many
+    // operations back to back and read all their durations afterwards (tbvh_time_history) instead of synchronizing after each one
+    // (tbvh_time_last_ms); ev0 / ev1 = the pair of the most recent operation.
+    static constexpr uint32_t kTimeRing = 256;
+    hipEvent_t evRing[kTimeRing][2] = {};
+    bool evDone[kTimeRing] = {};
+    uint64_t evSeq = 0;           // timed operations begun on this context
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int numCUs = 0;
@@ -204,6 +211,8 @@ struct HostPipe {
 
 namespace tbvh_capi {
 int setDevice(tbvh_context* c);
+hipError_t timedBegin(tbvh_context* c);   // next event pair of the ring, start event recorded on the context's stream
+hipError_t timedEnd(tbvh_context* c);     // end event recorded; the operation counts as timed
 // one query launch (probe-in-kernel + traversal kernel(s)) on the context's stream; asynchronous.  nDev: batch size in device memory (wavefront queues)
 int launchQuery(tbvh_scene* s, tbvh::RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh = false, float freshTmax = 1e30f,
                 const unsigned long long* nDev = nullptr);

@@ -132,17 +132,15 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     uint64_t want = (n + perBlock - 1) / perBlock;
     const uint32_t lo = (uint32_t)c->numCUs * 4u;
     uint32_t blocks = (uint32_t)(want < lo ? lo : (want > cap ? cap : want));
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));   // the probe below is part of the query's time
+    HIP_TRY(timedBegin(c));   // the probe below is part of the query's time
     // BVH8_CWBVH scenes beyond the L2s (the `small` class runs dense triangle phases, where the gated schedule loses 15 %) but within reach
     // of the Infinity Cache (beyond it camera rays are bound by memory too: 30 M / 60 M triangles lose 11 / 19 % under the gate), batches of 2 M
-    // rays and more (the probe costs ~10 us, 3-4 % of a 1 M-ray launch): a 16-workgroup probe of the batch's coherence (4096 neighbour pairs)
+    // rays and more: a probe of the batch's coherence (256 neighbouring ray pairs, sampled by every wave of the traversal kernel itself: kernels_cwbvh.hip)
     // lets the traversal kernel pick its schedule for the launch; a coherent batch also gets a third more waves (the surplus leaves at once
     // otherwise).  Bistro stand-in, 16.7 M rays: camera rays +4.5 %, shadow rays +6 %, bounce rays unchanged.
     uint32_t blocksBase = blocks;
     if (!s->isTlas && !small && blobBytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || s->variant == 88)) {
         uint32_t* probe = poolArea + (size_t)kPoolParts * kPoolCounterStride;
-        launch_coherence_probe(d_rays, n, nDev, probe, c->stream);
-        HIP_TRY(hipGetLastError());
         q.probe = probe; q.baseBlocks = blocks;
         c->lastProbed = true;
         if (!c->gridOverride && blocks == c->blocks) blocks = c->blocks + c->blocks / 3u;   // 24 -> 32 one-wave workgroups per CU
@@ -153,31 +151,31 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             q.spillStride = c->spillEntries;   // 32-bit stack entries
             launch_tlas4(any, 0, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(c->ev1, c->stream));
-            c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
+            HIP_TRY(timedEnd(c));
+            c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
             return 0;
         }
         if (s->tlas8 && (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2)) {   // BVH8_CWBVH BLASes (or those and BVH_GPU ones): the unified 8-wide kernel
             q.spillStride = c->spillEntries / 2;   // 8-byte stack entries
             launch_tlas8(any, 0, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7, s->blasMixCw2);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(c->ev1, c->stream));
-            c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
+            HIP_TRY(timedEnd(c));
+            c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
             return 0;
         }
         if (s->blasLayout == TBVH_LAYOUT_BVH_GPU) {   // BVH_GPU BLASes: the TLAS already has their node format (kernels_tlas2.hip)
             q.spillStride = c->spillEntries;   // 32-bit stack entries
             launch_tlas2(any, 0, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(c->ev1, c->stream));
-            c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
+            HIP_TRY(timedEnd(c));
+            c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
             return 0;
         }
         q.spillStride = c->spillEntries / 2;
         launch_tlas(any, s->blasLayout, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev1, c->stream));
-        c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
+        HIP_TRY(timedEnd(c));
+        c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
         return 0;
     }
     switch (s->layout) {
@@ -222,8 +220,8 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         return fail(TBVH_E_INVALID, "scene layout %d has no query kernel", s->layout);
     }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true; c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
+    HIP_TRY(timedEnd(c));
+    c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
     return 0;
 }
 
@@ -424,10 +422,9 @@ int tbvh_bin_rays_device(tbvh_context* c, const void* dIn, void* dOut, uint64_t 
         a.scale[k] = ext > 0 ? (float)(1u << cellBits) / ext : 0.f;
     }
     a.cellBits = cellBits; a.flags = flags;
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(timedBegin(c));
     HIP_TRY(launch_ray_bin((const RayRec*)dIn, (RayRec*)dOut, dPerm, n, nullptr, a, c->binScratch, scanTemp, (uint32_t)c->numCUs * 16u, c->stream));
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(timedEnd(c));
     return 0;
 }
 

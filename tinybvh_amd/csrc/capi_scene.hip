@@ -336,10 +336,9 @@ int tbvh_convert_bvh2_device(tbvh_context* c, const void* nodes32, uint64_t nNod
         HIP_TRY(hipMemcpyAsync(t.v, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream));
         dN2 = (const float4*)t.n2; dIdx = (const uint32_t*)t.idx; dV = (const float4*)t.v;
     }
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(timedBegin(c));
     const int r = convertDeviceImpl(c, layout, dN2, nNodes2, dIdx, nIdx, dV, nTris, out);
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(timedEnd(c));
     return r;
 }
 
@@ -364,12 +363,11 @@ int buildDeviceImpl(const char* who, tbvh_context* c, const void* verts16, uint6
     size_t sortTemp = 0, scanTemp = 0;
     const size_t scratchBytes = builder == 1 ? ploc_scratch_bytes((uint32_t)nTris, &sortTemp, &scanTemp) : lbvh_scratch_bytes((uint32_t)nTris, &sortTemp);
     HIP_TRY(hipMalloc(&t.n2, nTris * 2 * 32)); HIP_TRY(hipMalloc(&t.idx, nTris * 4)); HIP_TRY(hipMalloc(&t.scratch, scratchBytes));
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(timedBegin(c));
     if (builder == 1) HIP_TRY(launch_ploc_build(dV, (uint32_t)nTris, radius, (float4*)t.n2, (uint32_t*)t.idx, t.scratch, sortTemp, scanTemp, c->stream, nullptr));
     else HIP_TRY(launch_lbvh_build(dV, (uint32_t)nTris, maxLeafTris, (float4*)t.n2, (uint32_t*)t.idx, t.scratch, sortTemp, c->stream));
     const int r = convertDeviceImpl(c, layout, (const float4*)t.n2, nTris * 2, (const uint32_t*)t.idx, nTris, dV, nTris, out);
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(timedEnd(c));
     return r;
 }
 }  // namespace
@@ -473,10 +471,9 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
         uint32_t* counter = (uint32_t*)base;
         void* items = base + 256;
         float4* childBox = (float4*)(base + 256 + (size_t)capNodes * 16);
-        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        HIP_TRY(timedBegin(c));
         HIP_TRY(run_refit_bvh4(s->nodes, s->nNodeBlocks, dv4, nTris, items, capNodes, counter, childBox, s->b4Levels, c->status, c->stream));
-        HIP_TRY(hipEventRecord(c->ev1, c->stream));
-        c->timed = true;
+        HIP_TRY(timedEnd(c));
         return 0;
     }
     if (s->layout != TBVH_LAYOUT_CWBVH && s->layout != TBVH_LAYOUT_BVH_GPU)
@@ -495,10 +492,9 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
         HIP_TRY(hipMemcpyAsync(s->vertStage, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream));
         dv = s->vertStage;
     }
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(timedBegin(c));
     HIP_TRY(launch_refit(s->layout, s->nodes, nNodes, s->tris, nRecords, dv, nTris, s->refitScratch, c->status, c->stream));
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(timedEnd(c));
     // derived node layouts of the experiment kernels would be stale now
     if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copy current
     if (s->nodesHy) launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, nNodes, s->hybridK, c->stream);
@@ -544,13 +540,12 @@ int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice
             xf = s->xformStage;
         }
     }
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(timedBegin(c));
     HIP_TRY(launch_tlas_rebuild(s->nodes, s->tlasIdx, s->instances, xf, s->blasBounds, (uint32_t)n, (uint32_t)s->nBlas, s->buildScratch, s->sortTempBytes, c->stream));
     s->bytes = nNodes * 64 + n * 4 + n * 192;
     s->nTlasNodes = nNodes; s->nTlasIdx = n;
     if (int r = buildTlas4(s)) return r;
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
+    HIP_TRY(timedEnd(c));
     return 0;
 }
 

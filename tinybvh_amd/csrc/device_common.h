@@ -122,9 +122,10 @@ struct QueryArgs {
     Omm omm;               // opacity micromaps of the scene (map == nullptr: none)
     uint32_t fresh;        // 1: ignore the stored hit, start every ray from {freshTmax,0,0,0} and always write the record
     float freshTmax;
-    // coherence probe of this batch (kernels_raygen.hip: k_coherence_probe): probe[0] = sampled neighbour pairs whose directions agree, probe[1] = pairs
-    // sampled; nullptr = no probe ran (small batches).  baseBlocks: workgroups beyond this index only take part when the batch is coherent.
-    const uint32_t* probe;
+    // coherence probe of this batch (kernels_cwbvh.hip: coherence_sample, run by the traversal kernel itself): probe[0] = sampled neighbour pairs whose
+    // directions agree, probe[1] = pairs sampled (published by the first kernel of the query); nullptr = this launch does not probe (small batches).
+    // baseBlocks: workgroups beyond this index only take part when the batch is coherent.
+    uint32_t* probe;
     uint32_t baseBlocks;
     uint32_t flags;        // experiments: 1 = non-temporal ray loads / hit stores, 2 = triangle records padded to 64 bytes
     uint32_t hybridK;      // BVH8_CWBVH, hybrid node array (cwbvh_node.h: kNodeHybrid): nodes below this index are packed, the others one per line

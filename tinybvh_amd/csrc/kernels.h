@@ -61,8 +61,6 @@ hipError_t run_refit_bvh4(float4* blocks, uint64_t nBlocks, const float4* verts,
 size_t refit_scratch_bytes(int layout, uint32_t nNodes);
 hipError_t launch_refit(int layout, float4* nodes, uint32_t nNodes, float4* tris, uint64_t nTriRecords, const float4* verts, uint64_t nTris,
                         void* scratch, uint32_t* status, hipStream_t s);
-// samples neighbouring ray pairs of a batch and counts those whose directions agree (dot > 0.98): counters[0] agreeing, counters[1] sampled
-void launch_coherence_probe(const RayRec* rays, uint64_t n, const unsigned long long* nDev, uint32_t* counters, hipStream_t s);
 void launch_stream_copy(const float4* src, float4* dst, uint64_t n16, hipStream_t s);
 void launch_stream_read(const float4* src, float* sink, uint64_t n16, uint32_t blocks, hipStream_t s);
 void launch_valu_mix(float* out, int iters, uint32_t blocks, hipStream_t s);   // 32 VALU instructions per iteration and wave

@@ -36,6 +36,22 @@ constexpr int WG = 64;
 // STATS (experiment builds): q.stats[0] wave iterations, [1] sum of active lanes, [2] sum of lanes visiting a node,
 // [3] triangle-phase iterations, [4] sum of lanes in them, [5] node phases whose lanes all visit ONE node with ONE octant,
 // [6] sum of lanes in those, [7] node-phase iterations
+// Coherence of a batch: of kProbePairs pairs of neighbouring rays spread over the batch, how many agree in direction (camera rays and shadow
+// rays towards one light: almost all; bounce rays: almost none).  Wave-uniform result, the same in every wave of the launch.
+constexpr uint32_t kProbePairs = 256;
+__device__ __forceinline__ void coherence_sample(const RayRec* __restrict__ rays, uint64_t n, uint32_t& agree, uint32_t& pairs) {
+    const uint64_t stride = n / kProbePairs > 2 ? n / kProbePairs : 2;
+    agree = 0; pairs = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kProbePairs / 64u; j++) {
+        const uint64_t i = (uint64_t)(j * 64u + threadIdx.x) * stride;
+        const bool valid = i + 1 < n;
+        bool ok = false;
+        if (valid) { const float4 a = rays[i].D, b = rays[i + 1].D; ok = a.x * b.x + a.y * b.y + a.z * b.z > 0.98f; }
+        agree += (uint32_t)__popcll(__ballot(ok)); pairs += (uint32_t)__popcll(__ballot(valid));
+    }
+}
+
 template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, int STATS = 0, int NSTRIDE = 5, int PROBED = 0, int STEAL = 0, int MINW = 8>
 __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
@@ -59,7 +75,17 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
     // (read once by one CU: they should not displace tree lines in the L2s).
     bool coh = false;
     if (PROBED && q.probe) {
-        const uint32_t agree = q.probe[0], pairs = q.probe[1];
+        // The probe runs IN the traversal kernel (round 4; until then a 16-workgroup launch of its own ahead of the traversal kernels: one more
+        // launch latency per query on the host's critical path): every wave compares the directions of the same kProbePairs neighbouring ray
+        // pairs spread over the batch — 8 loads per lane from 32 KB that the first waves leave in the L2s — so all waves reach the same verdict
+        // without a counter to wait on.  The coherent flavor (launched first) publishes the two counts for the incoherent flavor behind it in the
+        // stream and for tbvh_debug_last_probe.
+        uint32_t agree, pairs;
+        if (PROBED == 2) { agree = q.probe[0]; pairs = q.probe[1]; }
+        else {
+            coherence_sample(q.rays, nRaysTotal, agree, pairs);
+            if (blockIdx.x == 0 && threadIdx.x == 0) { q.probe[0] = agree; q.probe[1] = pairs; }
+        }
         coh = pairs != 0 && agree * 10u >= pairs * 6u;
         if (PROBED == 2) { if (coh) return; }
         else if (PROBED == 3) { if (!coh) return; }   // the coherent flavor of a two-kernel launch: deferred + gated schedule only (SPEC = true)

@@ -124,30 +124,6 @@ __global__ void k_pack_hits(const RayRec* __restrict__ rays, uint32_t* __restric
     o[0] = w[11]; o[1] = w[12]; o[2] = w[13]; o[3] = w[14]; o[4] = w[15];
 }
 }  // namespace
-// Coherence probe: 4096 neighbour pairs (i, i + 1) spread over the batch; a pair agrees when the two directions are within ~11 degrees.
-// Camera rays and shadow rays towards one light agree almost everywhere, bounce rays almost nowhere (adjacent bounce rays start next to
-// each other but leave in unrelated directions).  The CWBVH kernel reads the two counters and picks its schedule (kernels_cwbvh.hip).
-namespace {
-__global__ __launch_bounds__(256) void k_coherence_probe(const RayRec* __restrict__ rays, uint64_t n, const unsigned long long* __restrict__ nDev, uint32_t* __restrict__ counters) {
-    if (nDev) { const unsigned long long m = *nDev; n = m < n ? m : n; }
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t pairs = 4096;
-    bool ok = false, valid = false;
-    if (n >= 2) {
-        const uint64_t stride = n / pairs > 2 ? n / pairs : 2;
-        const uint64_t i = (uint64_t)t * stride;
-        if (t < pairs && i + 1 < n) {
-            const float4 a = rays[i].D, b = rays[i + 1].D;
-            ok = a.x * b.x + a.y * b.y + a.z * b.z > 0.98f; valid = true;
-        }
-    }
-    const uint32_t nOk = (uint32_t)__popcll(__ballot(ok)), nValid = (uint32_t)__popcll(__ballot(valid));
-    if ((threadIdx.x & 63u) == 0 && nValid) { atomicAdd(counters, nOk); atomicAdd(counters + 1, nValid); }
-}
-}  // namespace
-void launch_coherence_probe(const RayRec* rays, uint64_t n, const unsigned long long* nDev, uint32_t* counters, hipStream_t s) {
-    hipLaunchKernelGGL(k_coherence_probe, dim3(16), dim3(256), 0, s, rays, n, nDev, counters);
-}
 
 // ---- the machine's own ceilings, measured where the kernels run (bench.py: roofline) ----------------------------------------------------
 // Streaming copy / read, 16 bytes per lane, ONE float4 per thread with the non-temporal hint: the shape that reaches the hardware guide's
