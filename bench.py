@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--device-build", action="store_true", help="build the layout on the device (tbvh_build_device: LBVH) instead of the host builder")
     ap.add_argument("--no-hbm-regime", action="store_true", help="skip detail.hbm_regime (the same kernels on a 30 M-triangle scene, beyond the Infinity Cache)")
     ap.add_argument("--hbm-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--blob-cache", default="", help="BVH8_CWBVH blob file (BVH8_CWBVH::Save format): read if it exists, else written after the host build (child runs of one bench share one build)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,7 +108,32 @@ def main():
     # N ranks build the same BVH at the same time on one host: give each its share of the cores (the build is deterministic
     # whatever the thread count)
     build_threads = max(1, usable_cores() // world) if world > 1 else 0
-    sc = tb.LAYOUT_CLASSES[a.layout](ctx).BuildOnDevice(verts) if a.device_build else tb.LAYOUT_CLASSES[a.layout](ctx).Build(verts, threads=build_threads)
+    replication = None
+    if use_dist and a.layout == tb.LAYOUT_CWBVH and not a.device_build:
+        # N processes on one node: ONE host build (rank 0, all cores), the blobs travel as a BVH8_CWBVH::Save-compatible file, ranks 1..N-1 load
+        # it — instead of N concurrent builds on the node's cores (tinybvh_amd/sharding.py; SURVEY par. 8(e): the BVH is replicated per GPU)
+        from tinybvh_amd.sharding import build_once_load_everywhere
+        blob_path = os.path.join("/tmp", f"tbvh_bench_{os.environ.get('MASTER_PORT', '0')}_{n_tris}.cwbvh")
+        host, rep_s = build_once_load_everywhere(verts, rank, world, dist, blob_path)
+        if rank == 0:
+            try:
+                os.remove(blob_path)
+            except OSError:
+                pass
+        sc = tb.BVH8_CWBVH(ctx).Upload(host.blob(0, np.uint32, 4), host.blob(1, np.uint32, 4))
+        sc.host = host
+        replication = {"how": "rank 0 builds and writes the blob file (tbvh_cwbvh_file_write), the other ranks read it (tbvh_cwbvh_file_read)", "rank0_seconds": rep_s}
+    elif a.blob_cache and a.layout == tb.LAYOUT_CWBVH and not a.device_build:
+        # the blob cache of SURVEY par. 8(f4): the children of one bench run (timing + rocprofv3 --pmc passes on the same scene) share ONE host build
+        if os.path.exists(a.blob_cache):
+            host = tb.HostBVH.from_cwbvh_file(a.blob_cache, n_tris)
+        else:
+            host = tb.HostBVH(verts, tb.LAYOUT_CWBVH)
+            host.save_cwbvh(a.blob_cache + ".tmp"); os.replace(a.blob_cache + ".tmp", a.blob_cache)
+        sc = tb.BVH8_CWBVH(ctx).Upload(host.blob(0, np.uint32, 4), host.blob(1, np.uint32, 4))
+        sc.host = host
+    else:
+        sc = tb.LAYOUT_CLASSES[a.layout](ctx).BuildOnDevice(verts) if a.device_build else tb.LAYOUT_CLASSES[a.layout](ctx).Build(verts, threads=build_threads)
     if a.variant:
         sc.set_variant(a.variant)
     if rank == 0:
@@ -158,13 +184,19 @@ def main():
                     ms.append(ctx.time_last_ms())
             out[kind + "_ms"] = float(np.mean(ms)); out[kind + "_mrays"] = n / (out[kind + "_ms"] * 1e-3) / 1e6
         if a.layout == 10:
-            sc.set_variant(59)   # the instrumented strict kernel: node visits and triangle tests per ray
+            # node visits S and triangle tests T per ray: the oracle's mirror of the layout (tiny_bvh.h:7046-7154 restated) on a strided 16 k
+            # sample, over the blobs as they are on the device (the tree may have been built there)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_lib import Oracle
+            orc = Oracle()
+            host = getattr(sc, "host", None)
+            nodes, tris = (host.blob(0, np.uint32, 4), host.blob(1, np.uint32, 4)) if host is not None else sc.download_blobs()
             for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
-                st = (C.c_uint64 * 8)()
-                tb.lib.tbvh_debug_stats(ctx._h, st, 1)
-                sc.intersect_device_fresh(d, n, 1e30)
-                tb.lib.tbvh_debug_stats(ctx._h, st, 1)
-                out[kind + "_S"] = int(st[2]) / n; out[kind + "_T"] = int(st[4]) / n
+                full = np.zeros(n, dtype=tb.RAY_DTYPE); ctx.from_device(full, d)
+                sample = full[:: max(n // 16384, 1)][:16384].copy(); del full
+                sample["t"] = 1e30
+                _, cnt = orc.cwbvh_intersect(nodes, tris, sample, counts=True)
+                out[kind + "_S"] = float(cnt[0]) / sample.shape[0]; out[kind + "_T"] = float(cnt[1]) / sample.shape[0]
         print(json.dumps(out), flush=True)
         ctx.close()
         return
@@ -201,6 +233,7 @@ def main():
         step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     hist = ctx.time_history(2 * min(a.steps, 128))      # (primary, diffuse) x steps, oldest first
     kern_ms["primary"], kern_ms["diffuse"] = hist[0::2], hist[1::2]
     # the records the TIMED launches left in HBM, sampled now — before anything else traces into these buffers — for the parity checks below
@@ -219,6 +252,7 @@ def main():
 
     # ---- config 4 as BASELINE.json words it: ONE 64 M-ray diffuse batch, sharded over the ranks (strong scaling) ------
     strong = None
+    km4_local, dm4_local, el4_local = [], [], 0.0
     if not a.no_strong:
         try:
             from tinybvh_amd.sharding import shard_range
@@ -249,6 +283,7 @@ def main():
                     km4.append(km[0]); dm4.append(dm[0])
             sync_all()
             el4 = time.perf_counter() - t0
+            km4_local, dm4_local, el4_local = km4, dm4, el4 / reps4
             if use_dist:
                 import torch
                 t = torch.tensor([el4], dtype=torch.float64, device="cuda")
@@ -261,6 +296,21 @@ def main():
             ctx.free(d_a); ctx.free(d_b)
         except Exception as e:
             log(f"[bench] config 4 strong-scaling batch failed: {e!r}")
+    # what every GPU did, side by side (SURVEY par. 8(e): per-GPU kernel ms and dispatch gap next to the max-over-ranks wall)
+    per_gpu = None
+    mine = [float(np.mean(kern_ms["primary"])), float(np.mean(kern_ms["diffuse"])), elapsed_local / a.steps * 1e3,
+            float(np.mean(km4_local)) if km4_local else -1.0, float(np.mean(dm4_local)) if dm4_local else -1.0, el4_local * 1e3]
+    if use_dist:
+        import torch
+        t = torch.tensor(mine, dtype=torch.float64, device="cuda")
+        rows = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(rows, t)
+        rows = [[float(x) for x in r.cpu()] for r in rows]
+    else:
+        rows = [mine]
+    per_gpu = [{"rank": i, "primary_kernel_ms": r[0], "diffuse_kernel_ms": r[1], "step_wall_ms": r[2], "step_dispatch_gap_ms": r[2] - r[0] - r[1],
+                "config4_shard_kernel_ms": r[3] if r[3] >= 0 else None, "config4_host_dispatch_ms": r[4] if r[4] >= 0 else None, "config4_shard_wall_ms": r[5]} for i, r in enumerate(rows)]
+
     # the same batch from ONE process over K devices through the C ABI (tbvh_intersect_sharded_device): K = --one-process-devices, or every
     # visible device when this is a single-process run that sees more than one
     one_proc = None
@@ -368,6 +418,7 @@ def main():
     # BASELINE configs 1 and 2 and the drop-in case, next to the headline number (outside the timed steps, rank 0 only)
     cfg12 = None
     ref_blob = None
+    ref_ocl = None
     if rank == 0 and not a.no_configs:
         try:
             cfg12 = configs_1_and_2(tb, ctx, R, scenes)
@@ -377,6 +428,12 @@ def main():
             ref_blob = reference_blob_step(tb, ctx, verts, d_prim, d_diff, n, timed_got, par_stride, ns_par)
         except Exception as e:
             log(f"[bench] reference-blob step failed: {e!r}")
+        if a.layout == tb.LAYOUT_CWBVH:
+            try:
+                ref_ocl = reference_opencl_headline(tb, ctx, sc, d_prim, d_diff, n, kern_ms)
+            except Exception as e:
+                log(f"[bench] reference OpenCL kernel on the headline batches failed: {e!r}")
+                ref_ocl = {"error": repr(e)[:300]}
 
     # ---- results (rank 0) ---------------------------------------------------------------------------
     if rank == 0:
@@ -394,12 +451,16 @@ def main():
         detail["device_side_ops"] = dev_ops
         detail["tlas_1000_instances"] = tlas_detail
         detail["config4_strong"] = strong
+        detail["per_gpu"] = per_gpu
+        if replication:
+            detail["bvh_replication"] = replication
         if one_proc:
             detail["config4_strong_one_process"] = one_proc
         if cfg12:
             detail["config1"] = cfg12.get("config1")
             detail["config2"] = cfg12.get("config2")
         detail["reference_blob"] = ref_blob
+        detail["ref_opencl_cwbvh"] = ref_ocl
         if world == 1 and not a.no_hbm_regime and a.layout == 10:
             detail["hbm_regime"] = hbm_regime(a, log)
 
@@ -458,19 +519,23 @@ def main():
         detail["parity_sample"] = parity
 
         # ---- roofline -------------------------------------------------------------------------------------------------------------------
-        # ONE headline fraction per kernel that cannot exceed 1: the larger of
-        #   fabric   bytes the kernel really moved beyond the L2s per launch (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, live child run:
-        #            Infinity-Cache hits included, so an upper bound on HBM bytes) / launch time, over the MEASURED streaming-read bandwidth of
-        #            this GPU (tbvh_measure_read_bandwidth; the data-sheet 8 TB/s is never reached: profiles/r03_copy_rate.txt);
-        #   valu     useful lane-operations per second — S x (VALU of one node visit) + T x (of one triangle test) + the per-ray part, counted
-        #            in the gfx950 ISA of the shipped kernel — over the MEASURED issue ceiling for that instruction mix (tbvh_measure_valu_issue
-        #            x 64 lanes; profiles/r03_valu_issue.txt).
-        # The contract's algorithmic-HBM line (64 + 16 + node_bytes x S + tri_bytes x T bytes per ray over the launch time against 8 TB/s) is
-        # kept as `algorithmic_hbm`: the tree lives in the L2s and the Infinity Cache, so that figure counts bytes that never reach HBM and can
-        # exceed 1 — a model of the work, not of a memory system.
+        # Everything here comes from the guide's peaks and from counters read live in child runs of this script under `rocprofv3 --pmc`
+        # (separate passes, --kernel-trace only): no hand-counted instruction constants.
+        #   roofline.{achieved, peak, frac, traffic}   the dominant kernel (incoherent flavor, diffuse batch): bytes its launch moved beyond the L2s
+        #            (FETCH_SIZE x 2 + WRITE_SIZE: the guide's gfx950 correction) over its mean HIP-event duration, against the guide's 8 TB/s
+        #            HBM3E peak.  FETCH_SIZE counts L2 misses, INCLUDING those the Infinity Cache serves: an upper bound on HBM bytes.
+        #            `frac_of_measured_read` = the same against this GPU's measured streaming-read bandwidth (tbvh_measure_read_bandwidth).
+        #   roofline.infinity_cache   what separates HBM from Infinity-Cache traffic: the TCC has no counter for it (the cache sits memory-side),
+        #            but the mean latency of an L2 miss does (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ); detail.hbm_regime brackets this scene
+        #            between a host-SAH scene that fits the Infinity Cache and one far beyond it, same kernels, same counters.
+        #   roofline.valu   SQ_INSTS_VALU per launch over the launch time against the measured issue ceiling of the node-test instruction mix
+        #            (tbvh_measure_valu_issue) = how busy the issue ports are; SQ_THREAD_CYCLES_VALU / (64 SQ_ACTIVE_INST_VALU) = how many lanes
+        #            of an issued instruction do work; their product = useful fraction of the VALU ceiling.
+        #   roofline.algorithmic_hbm   the contract's line (64 + 16 + node_bytes x S + tri_bytes x T bytes per ray, S / T from the oracle's
+        #            mirror on the parity sample, over the launch time, against 8 TB/s): counts every visit as an HBM fetch while the tree
+        #            lives in the L2s and the Infinity Cache, so it can exceed 1 — a model of the work (SURVEY par. 8(d) says so itself).
         try:
             nb, tbytes = {tb.LAYOUT_CWBVH: (80, 48), tb.LAYOUT_BVH4_GPU: (64, 48), tb.LAYOUT_BVH_GPU: (64, 52)}[a.layout]
-            valu_node, valu_tri, valu_ray = {tb.LAYOUT_CWBVH: (235, 65, 70), tb.LAYOUT_BVH4_GPU: (150, 65, 70), tb.LAYOUT_BVH_GPU: (60, 65, 70)}[a.layout]
             copy_gbps = read_gbps = valu_ginstr = None
             try:
                 copy_gbps = ctx.copy_bandwidth_gbps(1 << 30, 5)
@@ -478,16 +543,8 @@ def main():
                 valu_ginstr = ctx.valu_issue_ginstr(3)
             except Exception as e:
                 log(f"[bench] ceiling measurement failed: {e!r}")
-            traffic, traffic_src = live_pmc_traffic(a, log) if (world == 1 and not a.no_pmc) else (None, None)
-            if traffic is None:
-                pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-                if os.path.exists(pmc):
-                    try:
-                        j = json.load(open(pmc))
-                        traffic = {"diffuse": j.get("diffuse_kernel_hbm_bytes_per_launch"), "primary": j.get("primary_kernel_hbm_bytes_per_launch")}
-                        traffic_src = "profiles/pmc_traffic.json (committed rocprofv3 --pmc run of this command)"
-                    except Exception:
-                        traffic = None
+            pm = live_counters(a, log) if (world == 1 and not a.no_pmc) else None
+            traffic_src = pm.get("source") if pm else None
             lines = {}
             for kind in ("diffuse", "primary"):
                 if kind not in S_T:
@@ -496,33 +553,38 @@ def main():
                 sec = mean[kind] * 1e-3
                 bpr = 64 + 16 + nb * S + tbytes * T
                 alg = bpr * n / sec / 1e9
-                lane_ops = (S * valu_node + T * valu_tri + valu_ray) * n / sec / 1e9            # G lane-ops/s
-                valu_peak = valu_ginstr * 64 if valu_ginstr else None
-                tr = (traffic or {}).get(kind)
+                c = (pm or {}).get(kind, {})
+                tr = (c["FETCH_SIZE"] * 2048.0 + c.get("WRITE_SIZE", 0.0) * 1024.0) if "FETCH_SIZE" in c else None
                 fabric = (tr / sec / 1e9) if tr else None
-                f_fabric = (fabric / read_gbps) if (fabric and read_gbps) else None
-                f_valu = (lane_ops / valu_peak) if valu_peak else None
-                cands = [(f, nm) for f, nm in ((f_fabric, "fabric"), (f_valu, "valu")) if f is not None]
-                head = max(cands) if cands else (None, None)
-                lines[kind] = {"frac": head[0], "frac_is": head[1], "avg_launch_ms": mean[kind], "nodes_per_ray": S, "tris_per_ray": T,
-                               "fabric": {"achieved": fabric, "peak": read_gbps, "unit": "GB/s", "frac": f_fabric, "traffic_bytes_per_launch": tr},
-                               "valu_issue": {"achieved": lane_ops, "peak": valu_peak, "unit": "G lane-ops/s", "frac": f_valu},
+                valu = None
+                if "SQ_INSTS_VALU" in c:
+                    rate = c["SQ_INSTS_VALU"] / sec / 1e9                        # G wave-instructions / s, whole chip
+                    lane = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]) if c.get("SQ_ACTIVE_INST_VALU") else None
+                    issue = rate / valu_ginstr if valu_ginstr else None
+                    valu = {"insts_valu_per_launch": c["SQ_INSTS_VALU"], "insts_valu_per_ray": c["SQ_INSTS_VALU"] * 64.0 / n, "issue_rate_ginstr_per_s": rate,
+                            "issue_ceiling_ginstr_per_s": valu_ginstr, "issue_frac": issue, "lane_utilisation": lane,
+                            "useful_frac": (issue * lane) if (issue is not None and lane is not None) else None,
+                            "source": "live SQ_INSTS_VALU, SQ_THREAD_CYCLES_VALU, SQ_ACTIVE_INST_VALU (rocprofv3 --pmc child); ceiling: tbvh_measure_valu_issue (the node-test instruction mix at 8 waves per SIMD)"}
+                lat = None
+                if c.get("TCC_EA0_RDREQ_sum"):
+                    lat = {"mean_l2_miss_latency_cycles": c["TCC_EA0_RDREQ_LEVEL_sum"] / c["TCC_EA0_RDREQ_sum"], "l2_miss_requests_per_ray": c["TCC_EA0_RDREQ_sum"] / n}
+                lines[kind] = {"avg_launch_ms": mean[kind], "nodes_per_ray": S, "tris_per_ray": T,
+                               "fabric": {"achieved": fabric, "peak": 8000.0, "unit": "GB/s", "frac": fabric / 8000.0 if fabric else None,
+                                          "frac_of_measured_read": (fabric / read_gbps) if (fabric and read_gbps) else None, "traffic_bytes_per_launch": tr,
+                                          "bytes_per_ray": tr / n if tr else None},
+                               "valu": valu, "l2_miss_latency": lat,
                                "algorithmic_hbm": {"achieved": alg, "peak": 8000.0, "unit": "GB/s", "frac": alg / 8000.0, "bytes_per_ray": bpr}}
-            kname = {tb.LAYOUT_CWBVH: "k_cwbvh<false, ..., PROBED = 2> (incoherent flavor; diffuse batch)", tb.LAYOUT_BVH4_GPU: "k_bvh4_w8<false> (diffuse batch)", tb.LAYOUT_BVH_GPU: "k_bvh2<false> (diffuse batch)"}[a.layout]
+            kname = {tb.LAYOUT_CWBVH: "k_cwbvh<false, ..., NSTRIDE = kNodeHybrid, PROBED = 2> (incoherent flavor; diffuse batch)", tb.LAYOUT_BVH4_GPU: "k_bvh4_w8<false> (diffuse batch)", tb.LAYOUT_BVH_GPU: "k_bvh2<false> (diffuse batch)"}[a.layout]
             d_ = lines.get("diffuse")
             if d_:
-                use_fabric = d_["frac_is"] == "fabric"
-                top = d_["fabric"] if use_fabric else d_["valu_issue"]
-                roof = {"bound": "hbm" if use_fabric else "valu-issue", "kernel": kname, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": d_["frac"],
-                        "frac_is": ("fabric-side traffic (FETCH_SIZE x 2 + WRITE_SIZE) over the measured read bandwidth" if use_fabric else
-                                    "useful VALU lane-operations over the measured issue ceiling of the node-test mix") + "; = max(fabric.frac, valu_issue.frac), <= 1 by construction",
-                        "traffic": d_["fabric"]["traffic_bytes_per_launch"], "traffic_source": traffic_src,
+                f_ = d_["fabric"]
+                roof = {"bound": "hbm", "kernel": kname, "achieved": f_["achieved"], "peak": 8000.0, "unit": "GB/s", "frac": f_["frac"],
+                        "frac_is": "bytes the launch moved beyond the L2s (FETCH_SIZE x 2 + WRITE_SIZE, live rocprofv3 --pmc child; Infinity-Cache hits included: an upper bound on HBM bytes) / mean HIP-event launch time, over the guide's 8 TB/s HBM3E peak",
+                        "frac_of_measured_read": f_["frac_of_measured_read"], "traffic": f_["traffic_bytes_per_launch"], "traffic_source": traffic_src,
                         "measured_copy_gbps": copy_gbps, "measured_read_gbps": read_gbps, "measured_valu_ginstr_per_s": valu_ginstr,
-                        "fabric": d_["fabric"], "valu_issue": d_["valu_issue"], "algorithmic_hbm": d_["algorithmic_hbm"],
+                        "fabric": f_, "valu": d_["valu"], "l2_miss_latency": d_["l2_miss_latency"], "algorithmic_hbm": d_["algorithmic_hbm"],
                         "nodes_per_ray": d_["nodes_per_ray"], "tris_per_ray": d_["tris_per_ray"], "avg_launch_ms": d_["avg_launch_ms"],
-                        "valu_issue_model": {"lane_ops_per_node_visit": valu_node, "lane_ops_per_triangle_test": valu_tri, "lane_ops_per_ray": valu_ray,
-                                             "peak": "tbvh_measure_valu_issue (k_valu_mix: 32-instruction block in the proportions of cw_test_node, 8 waves per SIMD) x 64 lanes; profiles/r03_valu_issue.txt"},
-                        "limiter": "incoherent rays: the L2-miss path (lines from the Infinity Cache) with VALU issue close behind; camera rays: VALU issue (DESIGN.md §5)",
+                        "limiter": "incoherent rays: line fills from beyond the L2s (Infinity Cache and HBM: detail.hbm_regime), VALU issue close behind; camera rays: VALU issue (DESIGN.md par. 5)",
                         "primary": lines.get("primary")}
         except Exception as e:  # the checker is optional for the number itself
             log(f"[bench] roofline failed: {e!r}")
@@ -709,6 +771,34 @@ def reference_blob_step(tb, ctx, verts, d_prim, d_diff, n, timed_got, par_stride
     return out
 
 
+def reference_opencl_headline(tb, ctx, sc, d_prim, d_diff, n, kern_ms):
+    """The reference's OWN kernel for this path — batch_cwbvh (traverse_cwbvh.cl:554-570), compiled by ROCm OpenCL from the source text embedded
+    in oracle/_ref/libtinybvh_refocl.so — on the SAME GPU, the SAME BVH8_CWBVH blobs and the SAME 16.7 M-ray primary and diffuse batches the
+    metric is quoted on, next to the HIP kernels' timed launches; plus the agreement of the two hit sets (the .cl kernel derives rD with
+    native_recip and compares strictly: t to 1e-4)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import ReferenceOpenCL, compare_hits
+    ocl = ReferenceOpenCL()
+    h = sc.host
+    blobs = [h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4)]
+    out = {"ref_kernel": "batch_cwbvh (traverse_cwbvh.cl) through ROCm OpenCL, same blobs, same rays, same GPU", "opencl_device": ocl.device, "rays_per_batch": n}
+    tot_ref = tot_hip = 0.0
+    for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
+        sc.intersect_device_fresh(d, n, 1e30)          # (other legs have traced other trees into these buffers since the timed loop)
+        mine = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(mine, d)
+        rays = mine.copy(); rays["t"] = 1e30; rays["u"] = 0; rays["v"] = 0; rays["prim"] = 0
+        theirs, ref_ms = ocl.run(10, blobs, rays, passes=3)
+        del rays
+        cmp_ = compare_hits(mine[: theirs.shape[0]][::16], theirs[::16], rtol=1e-4)
+        hip_ms = float(np.mean(kern_ms[kind]))
+        out[kind] = {"hip_mrays": n / (hip_ms * 1e-3) / 1e6, "ref_opencl_mrays": theirs.shape[0] / (ref_ms * 1e-3) / 1e6, "ratio": ref_ms / hip_ms,
+                     "hitmiss_diff": cmp_["hitmiss"], "prim_diff": cmp_["prim_mismatch"], "rays_compared": cmp_["n"]}
+        tot_ref += ref_ms; tot_hip += hip_ms
+        del mine, theirs
+    out["primary_plus_diffuse"] = {"hip_mrays": 2 * n / (tot_hip * 1e-3) / 1e6, "ref_opencl_mrays": 2 * n / (tot_ref * 1e-3) / 1e6, "ratio": tot_ref / tot_hip}
+    return out
+
+
 def usable_cores():
     """Host threads this process can really run at once: the affinity mask, cut by the cgroup CPU quota if there is one
     (os.cpu_count() reports the whole machine even inside a container limited to a few cores)."""
@@ -726,92 +816,112 @@ def usable_cores():
 
 
 def hbm_regime(a, log):
-    """north_star asks for ">= 50 % HBM roofline on the node-fetch loop"; the bench's own scene (184 MB of tree) lives in the L2s and the Infinity
-    Cache, so that bar is measured where the kernel really fetches from HBM: the same street generator at 30 M triangles (3.3 GB of nodes and
-    triangles, built on the device), 4.19 M camera rays and bounce rays (depth 1-3) per launch, the shipped kernels.  A child of this script
-    times the launches and counts node visits S / triangle tests T per ray with the instrumented kernel; two more children under
-    `rocprofv3 --pmc` give the bytes fetched and written per launch.  Reported per ray kind: MRays/s, algorithmic bytes per ray
-    (80 S + 48 T + 64 + 16: SURVEY.md par. 8(d)), fetched bytes per ray, and both as TB/s against the 8 TB/s HBM peak."""
+    """north_star asks for ">= 50 % HBM roofline on the node-fetch loop"; the bench's own scene (2.83 M triangles: 0.2 GB of tree, 0.44 GB with
+    the incoherent-batch copies) is served by the L2s and the 256 MB Infinity Cache to a degree the TCC counters cannot state (they count L2
+    misses, whoever serves them).  So the SAME kernels, builder (the library's host SAH builder — the product's default), launches and counters run
+    on two more sizes of the same street generator that bracket it: 1.5 M triangles (0.1 GB: everything beyond the L2s comes from the Infinity
+    Cache) and 12 M triangles (0.9 GB: mostly from HBM), 4.19 M camera rays and bounce rays (depth 1-3) per launch.  Per scene a child of this
+    script times the launches and counts node visits S / triangle tests T per ray with the oracle's mirror; children under `rocprofv3 --pmc`
+    give bytes beyond the L2s and the mean latency of an L2 miss (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ).  The latency separates the two
+    regimes; `frac_of_hbm_peak` of the 12 M scene is the figure north_star asks for, on the default builder."""
     import copy
     import subprocess
-    b = copy.copy(a)
-    b.scene, b.side, b.device_build, b.layout, b.variant = "street30m", 2048, True, 10, 0
-    cmd = [sys.executable, os.path.abspath(__file__), "--hbm-child", "--device-build", "--scene", b.scene, "--side", str(b.side), "--layout", "10"]
+    import tempfile
+    res = {"scenes": {}, "peak_tb_per_s": 8.0, "builder": "library host builder (binned SAH + SAH-optimal wide collapse): the default"}
+    tmpdir = tempfile.mkdtemp(prefix="tbvh_hbm_", dir="/tmp")
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST"):
         env.pop(k, None)
     try:
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=400, check=True)
-        out = json.loads([l for l in r.stdout.decode().split("\n") if l.startswith("{")][-1])
-    except Exception as e:
-        log(f"[bench] hbm_regime child failed: {e!r}")
-        return {"error": repr(e)}
-    n = out["rays_per_launch"]
-    traffic, src = (live_pmc_traffic(b, log) if not a.no_pmc else (None, None))
-    for kind in ("primary", "diffuse"):
-        alg = 80.0 * out.get(kind + "_S", 0.0) + 48.0 * out.get(kind + "_T", 0.0) + 80.0
-        sec = out[kind + "_ms"] * 1e-3
-        row = {"mrays": out[kind + "_mrays"], "node_visits_per_ray": out.get(kind + "_S"), "triangle_tests_per_ray": out.get(kind + "_T"),
-               "algorithmic_bytes_per_ray": alg, "algorithmic_tb_per_s": alg * n / sec / 1e12}
-        if traffic:
-            row["fabric_bytes_per_ray"] = traffic[kind] / n
-            row["fabric_tb_per_s"] = traffic[kind] / sec / 1e12
-            row["frac_of_hbm_peak"] = traffic[kind] / sec / 8e12
-        out[kind] = row
-    out["traffic_source"] = src
-    out["peak_tb_per_s"] = 8.0
-    for k in [k for k in list(out) if k.endswith(("_ms", "_mrays", "_S", "_T")) and "_" in k and k.split("_")[0] in ("primary", "diffuse")]:
-        out.pop(k)
-    return out
+        for tag, scene in (("fits_infinity_cache", "street1.5m"), ("beyond_infinity_cache", "street12m")):
+            b = copy.copy(a)
+            b.scene, b.side, b.device_build, b.layout, b.variant = scene, 2048, False, 10, 0
+            b.blob_cache = os.path.join(tmpdir, scene + ".cwbvh")
+            cmd = [sys.executable, os.path.abspath(__file__), "--hbm-child", "--scene", b.scene, "--side", str(b.side), "--layout", "10", "--blob-cache", b.blob_cache]
+            try:
+                r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=400, check=True)
+                out = json.loads([l for l in r.stdout.decode().split("\n") if l.startswith("{")][-1])
+            except Exception as e:
+                log(f"[bench] hbm_regime child ({scene}) failed: {e!r}")
+                res["scenes"][tag] = {"error": repr(e)}
+                continue
+            n = out["rays_per_launch"]
+            pm = live_counters(b, log, passes=("FETCH_SIZE", "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum")) if not a.no_pmc else None
+            row = {"scene": out["scene"], "triangles": out["triangles"], "bvh_mb": out["bvh_mb"], "rays_per_launch": n, "tree": out["tree"]}
+            for kind in ("primary", "diffuse"):
+                alg = 80.0 * out.get(kind + "_S", 0.0) + 48.0 * out.get(kind + "_T", 0.0) + 80.0
+                sec = out[kind + "_ms"] * 1e-3
+                k_ = {"mrays": out[kind + "_mrays"], "node_visits_per_ray": out.get(kind + "_S"), "triangle_tests_per_ray": out.get(kind + "_T"),
+                      "algorithmic_bytes_per_ray": alg, "algorithmic_tb_per_s": alg * n / sec / 1e12}
+                c = (pm or {}).get(kind, {})
+                if "FETCH_SIZE" in c:
+                    tr = c["FETCH_SIZE"] * 2048.0
+                    k_.update(fetched_bytes_per_ray=tr / n, fetched_tb_per_s=tr / sec / 1e12, frac_of_hbm_peak=tr / sec / 8e12)
+                if c.get("TCC_EA0_RDREQ_sum"):
+                    k_["mean_l2_miss_latency_cycles"] = c["TCC_EA0_RDREQ_LEVEL_sum"] / c["TCC_EA0_RDREQ_sum"]
+                row[kind] = k_
+            res["scenes"][tag] = row
+        res["traffic_source"] = "live: rocprofv3 --pmc FETCH_SIZE (x 2, guide correction; read side only) and TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ child runs per scene"
+    finally:
+        import shutil
+        shutil.rmtree(tmpdir, ignore_errors=True)
+    return res
 
 
-def live_pmc_traffic(a, log):
-    """Fabric-side bytes per launch of the two timed kernels, measured now: this script is run again as a short child
-    (--pmc-child: same scene, same batches, three (primary, diffuse) launch pairs) under `rocprofv3 --pmc FETCH_SIZE` and,
-    separately, `--pmc WRITE_SIZE` (TCC counters do not fit one pass; --kernel-trace only).  FETCH_SIZE is in KB and
-    tallies 64 of every 128 bytes on gfx950 (MI355X_MICROARCH.md), hence x 1024 x 2; WRITE_SIZE x 1024 taken as is.
-    Infinity-Cache hits are counted, so this is an upper bound on HBM bytes.  Returns ({"primary": bytes, "diffuse": bytes}, source)
-    or (None, None)."""
+def live_counters(a, log, passes=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES", "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum")):
+    """Hardware counters of the two timed kernels, measured now: this script is run again as a short child (--pmc-child: same scene, same
+    batches, three (primary, diffuse) launch pairs) under `rocprofv3 --pmc <pass>` once per pass (TCC counters do not fit one pass; --kernel-trace
+    only, as the pool requires).  Returns {"primary": {counter: per-launch value}, "diffuse": {...}, "source": ...}, the mean of the last two
+    pairs (the first warms the caches), summed over the dispatches of one query (a probed query is two traversal dispatches).
+    FETCH_SIZE is in KB and tallies 64 of every 128 bytes on gfx950 (MI355X_MICROARCH.md): callers multiply by 2048; WRITE_SIZE x 1024.
+    A pass that fails (a counter this box does not have) is skipped with a note; None if nothing could be collected."""
     import csv
     import glob
     import shutil
     import subprocess
     import tempfile
     if not shutil.which("rocprofv3"):
-        return None, None
-    out = {"primary": 0.0, "diffuse": 0.0}
-    for counter, scale in (("FETCH_SIZE", 2048.0), ("WRITE_SIZE", 1024.0)):
+        return None
+    out = {"primary": {}, "diffuse": {}}
+    got_any = False
+    for pass_ in passes:
+        counters = pass_.split()
         d = tempfile.mkdtemp(prefix="tbvh_pmc_", dir="/tmp")
-        cmd = ["rocprofv3", "--output-format", "csv", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "pmc", "--",
+        cmd = ["rocprofv3", "--output-format", "csv", "--pmc"] + counters + ["--kernel-trace", "-d", d, "-o", "pmc", "--",
                sys.executable, os.path.abspath(__file__), "--pmc-child", "--scene", a.scene, "--side", str(a.side), "--layout", str(a.layout),
-               "--variant", str(a.variant)] + (["--device-build"] if getattr(a, "device_build", False) else [])
+               "--variant", str(a.variant)] + (["--device-build"] if getattr(a, "device_build", False) else []) + \
+              (["--blob-cache", a.blob_cache] if getattr(a, "blob_cache", "") else [])
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST"):
             env.pop(k, None)
         try:
-            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=300, check=True)
-            rows = []
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200, check=True)
+            per_disp = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     kn = r["Kernel_Name"]
-                    if r["Counter_Name"] == counter and ("k_cwbvh<false" in kn or "k_bvh4_w8<false" in kn or "k_bvh4<false" in kn or "k_bvh2<false" in kn):
-                        rows.append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
-            rows.sort()
+                    if r["Counter_Name"] in counters and ("k_cwbvh<false" in kn or "k_bvh4_w8<false" in kn or "k_bvh4<false" in kn or "k_bvh2<false" in kn):
+                        row = per_disp.setdefault(int(r["Dispatch_Id"]), {})
+                        row[r["Counter_Name"]] = row.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+            ids = sorted(per_disp)
             # the child makes 9 queries (3 preparing the batches, then (primary, diffuse) x 3); a probed query on a scene with the incoherent-batch
             # copies is TWO traversal dispatches (the flavor the probe's verdict is not for leaves at once): sum per query
-            per_query = len(rows) // 9
-            if per_query not in (1, 2) or len(rows) != 9 * per_query:
-                raise RuntimeError(f"{len(rows)} traversal dispatches in the {counter} pass, expected 9 or 18")
-            allv = [v for _, v in rows]
-            vals = [sum(allv[i * per_query:(i + 1) * per_query]) for i in range(9)][-6:]   # (primary, diffuse) x 3; the first pair warms the caches
-            out["primary"] += (vals[2] + vals[4]) / 2 * scale
-            out["diffuse"] += (vals[3] + vals[5]) / 2 * scale
+            per_query = len(ids) // 9
+            if per_query not in (1, 2) or len(ids) != 9 * per_query:
+                raise RuntimeError(f"{len(ids)} traversal dispatches in the {pass_!r} pass, expected 9 or 18")
+            for cn in counters:
+                vals = [sum(per_disp[ids[q * per_query + j]].get(cn, 0.0) for j in range(per_query)) for q in range(9)][-6:]
+                out["primary"][cn] = (vals[2] + vals[4]) / 2
+                out["diffuse"][cn] = (vals[3] + vals[5]) / 2
+            got_any = True
         except Exception as e:
-            log(f"[bench] rocprofv3 --pmc {counter} child failed: {e!r}")
-            return None, None
+            log(f"[bench] rocprofv3 --pmc {pass_!r} child failed: {e!r}")
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return out, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child runs of this command (FETCH_SIZE x 2, guide correction); includes Infinity-Cache hits"
+    if not got_any:
+        return None
+    out["source"] = "live: rocprofv3 --pmc child runs of this command, one per counter group (" + "; ".join(passes) + "); FETCH_SIZE x 2 (guide correction for gfx950), Infinity-Cache hits included"
+    return out
 
 
 def cpu_baseline(tb, ctx, verts, d_prim, d_diff, n):

@@ -26,9 +26,15 @@
  *     Intersect reads O, D, rD and hit.t (= tmax) and writes bytes 48..63 only, and only
  *     for rays that hit (a miss leaves the record untouched, like BVH::Intersect,
  *     tiny_bvh.h:3247-3304 / 8524-8529).  TLAS queries also write hit.inst at byte 44.
- *   - one tbvh_context per HIP device; contexts and the scenes created from them are
- *     not thread-safe, different contexts are independent (the reference has a single
- *     process-global OpenCL device, tiny_ocl.h:362-364).
+ *   - one tbvh_context per HIP device — or several: contexts are independent (the reference
+ *     has a single process-global OpenCL device, tiny_ocl.h:362-364).  Every entry point takes
+ *     its context's lock, so host threads may share a context and its scenes the way the
+ *     reference's callers share a const BVH (tiny_bvh_speedtest.cpp:1077-1083: Intersect from
+ *     8 threads): concurrent calls on ONE context are safe and serialise; threads whose
+ *     queries should overlap on the device use one context (and one upload of the scene)
+ *     each.  tbvh_shutdown / tbvh_free_scene must not race with calls on what they destroy.
+ *     tbvh_time_last_ms reports the calling context's most recent operation — with several
+ *     threads on one context that may be another thread's.
  */
 #ifndef TINYBVH_AMD_H_
 #define TINYBVH_AMD_H_
@@ -40,7 +46,7 @@
 extern "C" {
 #endif
 
-#define TBVH_ABI_VERSION 3   /* 3: deterministic ties, tbvh_bin_rays_device, tbvh_cwbvh_set_hybrid, device-resident multi-device calls */
+#define TBVH_ABI_VERSION 4   /* 4: tbvh_update_bvh_gpu / _bvh4_gpu / _cwbvh, tbvh_time_history, contexts are thread-safe; 3: deterministic ties, tbvh_bin_rays_device, tbvh_cwbvh_set_hybrid, device-resident multi-device calls */
 
 /* error codes */
 #define TBVH_OK            0
@@ -115,6 +121,17 @@ int tbvh_upload_tlas(tbvh_context* ctx, const void* tlas_nodes64, uint64_t n_nod
 int tbvh_update_tlas(tbvh_scene* tlas, const void* tlas_nodes64, uint64_t n_nodes,
                      const uint32_t* tlas_idx, uint64_t n_idx,
                      const void* instances192, uint64_t n_instances);
+
+/* In-place re-upload of a BLAS whose blob the caller refitted and re-converted on the host — BVH::Refit (tiny_bvh.h:3055-3093) followed by
+ * BVH_GPU / BVH4_GPU / BVH8_CWBVH::ConvertFrom again, the reference's own flow for animated geometry — without freeing the scene: the handle,
+ * the device allocations and the pointers every TLAS over this BLAS holds stay valid (tbvh_update_tlas is the same for the top level;
+ * tbvh_refit does the whole refit on the device instead).  Arguments as for the matching tbvh_upload_*; the blob may be SMALLER than the
+ * one uploaded (ConvertFrom of a refitted tree can collapse differently), a larger one is TBVH_E_INVALID: free the scene and upload.
+ * Validated like an upload (TBVH_E_FORMAT).  The library's derived copies follow: re-derived on the device when the tree kept its shape,
+ * dropped and rebuilt as after an upload when it did not.  Synchronous (the caller's arrays may be reused on return). */
+int tbvh_update_bvh_gpu(tbvh_scene* scene, const void* nodes64, uint64_t n_nodes, const uint32_t* prim_idx, uint64_t n_idx, const void* verts16, uint64_t n_tris);
+int tbvh_update_bvh4_gpu(tbvh_scene* scene, const void* blocks16, uint64_t n_blocks);
+int tbvh_update_cwbvh(tbvh_scene* scene, const void* nodes16, uint64_t n_node_blocks, const void* tris16, uint64_t n_tri_blocks);
 
 /* BVH2 -> wide layout conversion ON THE DEVICE: replaces BVH8_CWBVH::ConvertFrom (tiny_bvh.h:5884-6018, with
  * the MBVH<8> collapse of 4975-5048) for callers that have a plain BVH2.  nodes32 = BVH::bvhNode (32-byte
@@ -290,15 +307,19 @@ int tbvh_debug_stats(tbvh_context* ctx, uint64_t out[8], int reset);
  * (rounded down to a multiple of 8) packed 80 bytes apart, all later ones one per 128-byte line, plus the triangle records padded to 64
  * bytes.  The top of the tree is served by the L2s, where the packed form moves 40 % more nodes per second; deep nodes and triangles come
  * from beyond them, where a cache line is the unit and a packed node straddles 1.6 lines, a 48-byte record 1.4 (tools/ubench/
- * gather_lanes.hip).  Scenes of 48 - 384 MB get these copies at upload with packed_nodes = 8192, and batches of 2 M rays and more whose
- * coherence probe says "incoherent" are traced on them (DESIGN.md par. 5; TBVH_INCOHERENT_COPIES=0 turns that off); this call (re)builds
+ * gather_lanes.hip).  Scenes of 48 - 384 MB get these copies from their first launch of 2 M rays or more (packed_nodes =
+ * 8192; every node on a line of its own also carries ONE of its triangles in the line's spare 48 bytes, and the traversal reads that triangle
+ * from there), and batches of 2 M rays and more whose coherence probe says "incoherent" are traced on them (DESIGN.md par. 5; TBVH_INCOHERENT_COPIES=0 turns that off); this call (re)builds
  * them with another split for any BVH8_CWBVH scene — tbvh_set_variant(scene, 90) then traces every batch on them.  packed_nodes >= the
  * node count: priority order, all packed; 0: all padded; < 0: drop the node copy.  Hit records do not depend on the placement.  Kept
  * current by tbvh_refit. */
 int tbvh_cwbvh_set_hybrid(tbvh_scene* scene, int64_t packed_nodes);
 
 /* Experiment switches for the BVH8_CWBVH kernel of the next launches on this context (development aid; 0 = as shipped):
- * 1 = non-temporal ray loads / hit stores, 2 = triangle records padded to 64 bytes (a padded copy is built on first use). */
+ * 1 = non-temporal ray loads / hit stores, 2 = the 64-byte triangle records in the ordinary kernels too (only where the scene has them:
+ * after tbvh_cwbvh_set_hybrid or the first large launch; ignored otherwise), 4 = a probed launch as ONE kernel even where the copies exist,
+ * 8 = the next tbvh_cwbvh_set_hybrid / lazy build derives the node copy WITHOUT a triangle in each node's line, bits 8..15 = waves per CU of
+ * the incoherent flavor (clamped to the 32 per CU the stack spill area is sized for). */
 int tbvh_debug_set_flags(tbvh_context* ctx, uint32_t flags);
 
 /* The per-launch coherence probe of the most recent query on this context (development aid; DESIGN.md par. 3): out[0] = sampled

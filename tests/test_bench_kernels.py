@@ -31,7 +31,7 @@ def test_probed_schedules_on_the_bench_scene(ctx, oracle):
     sc = tb.BVH8_CWBVH(ctx).Build(verts)
     blob_bytes = sc.host.blob(0, np.uint32, 4).nbytes + sc.host.blob(1, np.uint32, 4).nbytes
     assert (48 << 20) < blob_bytes <= (384 << 20), blob_bytes      # the size class that gets the probe (and the incoherent-batch copies)
-    assert sc.device_bytes > blob_bytes * 2                         # ... which are there: hybrid node copy + 64-byte triangle records
+    assert sc.device_bytes < blob_bytes * 1.1                       # ... which are built lazily, by the first launch of 2 M rays or more
     side = 4096
     n = side * side
     cam = R.camera(*scenes.STREET_CAMERAS[0], side, side, 1, 1)              # bench.py's camera
@@ -44,6 +44,7 @@ def test_probed_schedules_on_the_bench_scene(ctx, oracle):
     ctx.generate_primary(cam, d_a, 0, n)
     ctx.from_device(before, d_a)
     sc.intersect_device_fresh(d_a, n, 1e30)
+    assert sc.device_bytes > blob_bytes * 2                         # now they are there: hybrid node copy + 64-byte triangle records
     agree, pairs, verdict = ctx.last_probe()
     assert verdict == 2 and pairs >= 256, (agree, pairs, verdict)
     ctx.from_device(after, d_a)

@@ -54,6 +54,23 @@ def _worker(rank, world, port, q):
             want = np.ascontiguousarray(ref).view(np.uint32).reshape(-1, 16)[:, 12:16]
             q.put(bool(np.array_equal(full, want)))
         dist.barrier()
+        # the replicated BVH of a multi-process run: rank 0 builds once and writes the blob file, the others load it (bench.py --gpus N)
+        from tinybvh_amd.sharding import build_once_load_everywhere
+        path = os.path.join("/tmp", f"tbvh_gloo_{port}.cwbvh")
+        host, _ = build_once_load_everywhere(verts, rank, world, dist, path)
+        sums = [int(host.blob(k, np.uint32, 4).astype(np.uint64).sum()) for k in (0, 1)] + [int(host.blob(0, np.uint32, 4).shape[0]), int(host.n_tris)]
+        import torch
+        t = torch.tensor(sums, dtype=torch.int64)
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        same = all(bool(torch.equal(g, got[0])) for g in got)
+        has_bvh2 = host.blob(2, np.uint32, 8).shape[0] > 0
+        if rank == 0:
+            os.remove(path)
+            q.put(bool(same and has_bvh2))
+        else:
+            assert not has_bvh2           # only the builder holds the BVH2 (the oracle runs on rank 0)
+        dist.barrier()
     finally:
         dist.destroy_process_group()
 
@@ -69,4 +86,5 @@ def test_two_ranks_over_gloo():
     for p in procs:
         p.join(timeout=240)
         assert p.exitcode == 0
-    assert q.get(timeout=5) is True
+    assert q.get(timeout=5) is True      # sharded trace == single-process trace
+    assert q.get(timeout=5) is True      # every rank holds the same blobs, built once

@@ -197,6 +197,12 @@ class HostBVH:
         self.layout = LAYOUT_CWBVH
         return self
 
+    def save_cwbvh(self, path: str) -> None:
+        """Write this BVH8_CWBVH's blobs as a file BVH8_CWBVH::Load accepts (tbvh_cwbvh_file_write; tiny_bvh.h:5786-5795)."""
+        assert self.layout == LAYOUT_CWBVH
+        nodes, tris = self.blob(0, np.uint32, 4), self.blob(1, np.uint32, 4)
+        check(lib.tbvh_cwbvh_file_write(os.fsencode(path), _ptr(nodes), nodes.shape[0], _ptr(tris), tris.shape[0], self.n_tris or tris.shape[0] // 3, None), "tbvh_cwbvh_file_write")
+
     def blob(self, which: int, dtype, width: int) -> np.ndarray:
         """Zero-copy numpy view of blob `which` (the view keeps this object alive)."""
         p = lib.tbvh_host_blob(self._h, which)
@@ -335,6 +341,13 @@ class BVH_GPU(_Scene):
                                       _ptr(verts), verts.size // 12, C.byref(self._h)), "tbvh_upload_bvh_gpu")
         return self
 
+    def Update(self, nodes64: np.ndarray, prim_idx: np.ndarray, verts: np.ndarray) -> "BVH_GPU":
+        """In-place re-upload of a blob refitted / re-converted on the host (tbvh_update_bvh_gpu): same handle, same device memory."""
+        nodes64 = np.ascontiguousarray(nodes64); prim_idx = np.ascontiguousarray(prim_idx, dtype=np.uint32)
+        verts = np.ascontiguousarray(verts, dtype=np.float32)
+        check(lib.tbvh_update_bvh_gpu(self._h, _ptr(nodes64), nodes64.nbytes // 64, _ptr(prim_idx), prim_idx.size, _ptr(verts), verts.size // 12), "tbvh_update_bvh_gpu")
+        return self
+
 
 class BVH4_GPU(_Scene):
     """Quantized 4-wide layout with inline triangles (tiny_bvh.h:1245-1289)."""
@@ -363,6 +376,12 @@ class BVH4_GPU(_Scene):
     def Upload(self, blocks16: np.ndarray) -> "BVH4_GPU":
         blocks16 = np.ascontiguousarray(blocks16)
         check(lib.tbvh_upload_bvh4_gpu(self.ctx._h, _ptr(blocks16), blocks16.nbytes // 16, C.byref(self._h)), "tbvh_upload_bvh4_gpu")
+        return self
+
+    def Update(self, blocks16: np.ndarray) -> "BVH4_GPU":
+        """In-place re-upload of a blob refitted / re-converted on the host (tbvh_update_bvh4_gpu)."""
+        blocks16 = np.ascontiguousarray(blocks16)
+        check(lib.tbvh_update_bvh4_gpu(self._h, _ptr(blocks16), blocks16.nbytes // 16), "tbvh_update_bvh4_gpu")
         return self
 
 
@@ -414,6 +433,13 @@ class BVH8_CWBVH(_Scene):
         nodes16 = np.ascontiguousarray(nodes16); tris16 = np.ascontiguousarray(tris16)
         check(lib.tbvh_upload_cwbvh(self.ctx._h, _ptr(nodes16), nodes16.nbytes // 16, _ptr(tris16), tris16.nbytes // 16,
                                     C.byref(self._h)), "tbvh_upload_cwbvh")
+        return self
+
+    def Update(self, nodes16: np.ndarray, tris16: np.ndarray) -> "BVH8_CWBVH":
+        """In-place re-upload of a blob refitted / re-converted on the host (tbvh_update_cwbvh): BVH::Refit + ConvertFrom of the
+        reference's animation flow without freeing the scene; TLASes over this BLAS keep working."""
+        nodes16 = np.ascontiguousarray(nodes16); tris16 = np.ascontiguousarray(tris16)
+        check(lib.tbvh_update_cwbvh(self._h, _ptr(nodes16), nodes16.nbytes // 16, _ptr(tris16), tris16.nbytes // 16), "tbvh_update_cwbvh")
         return self
 
 

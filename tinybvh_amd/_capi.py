@@ -55,6 +55,9 @@ SYMBOLS = {
     "tbvh_upload_cwbvh": (_i, [_vp, _vp, _u64, _vp, _u64, _pp]),
     "tbvh_upload_tlas": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _pp, _u64, _pp]),
     "tbvh_update_tlas": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u64]),
+    "tbvh_update_bvh_gpu": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u64]),
+    "tbvh_update_bvh4_gpu": (_i, [_vp, _vp, _u64]),
+    "tbvh_update_cwbvh": (_i, [_vp, _vp, _u64, _vp, _u64]),
     "tbvh_rebuild_tlas_device": (_i, [_vp, _vp, _i, _vp, _u64]),
     "tbvh_refit": (_i, [_vp, _vp, _u64, _i]),
     "tbvh_set_opacity_micromaps": (_i, [_vp, _vp, _u32, _u64, _i]),

@@ -77,6 +77,7 @@ int tbvh_init(int device, tbvh_context** out) {
     }
     if (const char* e = getenv("TBVH_SPLIT_RAYS")) { if (atoi(e) == 0) c->splitBelow = 0; }
     if (const char* e = getenv("TBVH_INCOHERENT_COPIES")) { if (atoi(e) == 0) c->incoherentCopies = false; }
+    if (const char* e = getenv("TBVH_EMBED_TRIS")) { if (atoi(e) == 0) c->embedTris = false; }
     if (const char* e = getenv("TBVH_POOL_PARTS")) {  // experiment knob
         const int b = atoi(e);
         if (b >= 0 && (1 << b) <= kPoolParts) c->poolParts = (uint32_t)b;   // log2 of the partition count
@@ -118,19 +119,22 @@ void tbvh_shutdown(tbvh_context* c) {
 
 int tbvh_synchronize(tbvh_context* c) {
     if (!c) return fail(TBVH_E_INVALID, "null context");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 
 int tbvh_set_stream(tbvh_context* c, void* s) {
     if (!c) return fail(TBVH_E_INVALID, "null context");
+    TBVH_LOCK(c);
     c->stream = s ? (hipStream_t)s : c->ownStream;
     return 0;
 }
 
 float tbvh_time_last_ms(tbvh_context* c) {
-    if (!c || !c->timed) return -1.0f;
+    if (!c) return -1.0f;
+    TBVH_LOCK(c);
+    if (!c->timed) return -1.0f;
     hipSetDevice(c->device);
     if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0f;
     float ms = -1.0f;
@@ -141,7 +145,7 @@ float tbvh_time_last_ms(tbvh_context* c) {
 int tbvh_time_history(tbvh_context* c, float* ms, uint32_t cap, uint32_t* count) {
     if (!c || !count || (!ms && cap)) return fail(TBVH_E_INVALID, "tbvh_time_history: null argument");
     *count = 0;
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     uint64_t n = c->evSeq < tbvh_context::kTimeRing ? c->evSeq : tbvh_context::kTimeRing;
     if (n > cap) n = cap;
     for (uint64_t i = 0; i < n; i++) {   // oldest first
@@ -159,7 +163,7 @@ int tbvh_time_history(tbvh_context* c, float* ms, uint32_t cap, uint32_t* count)
 
 int tbvh_debug_stats(tbvh_context* c, uint64_t out[8], int reset) {
     if (!c || !out) return fail(TBVH_E_INVALID, "tbvh_debug_stats: null argument");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(out, c->counter + 8, 64, hipMemcpyDeviceToHost));
     if (reset) HIP_TRY(hipMemset(c->counter + 8, 0, 64));
@@ -168,13 +172,14 @@ int tbvh_debug_stats(tbvh_context* c, uint64_t out[8], int reset) {
 
 int tbvh_debug_set_flags(tbvh_context* c, uint32_t flags) {
     if (!c) return fail(TBVH_E_INVALID, "tbvh_debug_set_flags: null context");
+    TBVH_LOCK(c);
     c->expFlags = flags;
     return 0;
 }
 
 int tbvh_debug_last_probe(tbvh_context* c, uint32_t out[3]) {
     if (!c || !out) return fail(TBVH_E_INVALID, "tbvh_debug_last_probe: null argument");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     out[0] = out[1] = out[2] = 0;
     if (!c->lastProbed) return 0;
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -188,28 +193,28 @@ int tbvh_debug_last_probe(tbvh_context* c, uint32_t out[3]) {
 
 int tbvh_device_malloc(tbvh_context* c, uint64_t bytes, void** out) {
     if (!c || !out) return fail(TBVH_E_INVALID, "tbvh_device_malloc: null argument");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     hipError_t e = hipMalloc(out, bytes ? bytes : 16);
     if (e != hipSuccess) return fail(TBVH_E_NOMEM, "hipMalloc(%llu): %s", (unsigned long long)bytes, hipGetErrorString(e));
     return 0;
 }
 int tbvh_device_free(tbvh_context* c, void* p) {
     if (!c) return fail(TBVH_E_INVALID, "null context");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipFree(p));
     return 0;
 }
 int tbvh_copy_to_device(tbvh_context* c, void* d, const void* src, uint64_t bytes) {
     if (!c || ((!d || !src) && bytes)) return fail(TBVH_E_INVALID, "tbvh_copy_to_device: null argument");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     HIP_TRY(hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 int tbvh_copy_from_device(tbvh_context* c, void* dst, const void* d, uint64_t bytes) {
     if (!c || ((!d || !dst) && bytes)) return fail(TBVH_E_INVALID, "tbvh_copy_from_device: null argument");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     HIP_TRY(hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
@@ -242,7 +247,7 @@ static int timeBest(tbvh_context* c, uint32_t reps, const std::function<void()>&
 
 int tbvh_measure_copy_bandwidth(tbvh_context* c, uint64_t bytes, uint32_t reps, double* gbps) {
     if (!c || !gbps || bytes < (1u << 20)) return fail(TBVH_E_INVALID, "tbvh_measure_copy_bandwidth: null argument or under 1 MB");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     void *a = nullptr, *b = nullptr;
     if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { if (a) hipFree(a); return fail(TBVH_E_NOMEM, "tbvh_measure_copy_bandwidth: cannot allocate 2 x %llu bytes", (unsigned long long)bytes); }
     int r = 0;
@@ -257,7 +262,7 @@ int tbvh_measure_copy_bandwidth(tbvh_context* c, uint64_t bytes, uint32_t reps, 
 
 int tbvh_measure_read_bandwidth(tbvh_context* c, uint64_t bytes, uint32_t reps, double* gbps) {
     if (!c || !gbps || bytes < (1u << 20)) return fail(TBVH_E_INVALID, "tbvh_measure_read_bandwidth: null argument or under 1 MB");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     void *a = nullptr, *sink = nullptr;
     if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&sink, 256) != hipSuccess) { if (a) hipFree(a); return fail(TBVH_E_NOMEM, "tbvh_measure_read_bandwidth: cannot allocate %llu bytes", (unsigned long long)bytes); }
     int r = 0;
@@ -274,7 +279,7 @@ int tbvh_measure_read_bandwidth(tbvh_context* c, uint64_t bytes, uint32_t reps, 
 // wave64 VALU instructions per second over the whole chip, in units of 1e9.
 int tbvh_measure_valu_issue(tbvh_context* c, uint32_t reps, double* ginstr_per_s) {
     if (!c || !ginstr_per_s) return fail(TBVH_E_INVALID, "tbvh_measure_valu_issue: null argument");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     const uint32_t blocks = (uint32_t)c->numCUs * 32u;
     const int iters = 20000;
     void* out = nullptr;

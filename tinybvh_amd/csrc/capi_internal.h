@@ -41,6 +41,12 @@ int fail(int code, const char* fmt, ...);   // sets tbvh_last_error() of the cal
     } while (0)
 
 struct tbvh_context {
+    // One lock per context: every entry point that touches the context (its stream position, staging buffers, ray-pool counter areas, event
+    // ring, scenes) holds it, so host threads may share a context and a scene the way the reference's callers share a BVH
+    // (tiny_bvh_speedtest.cpp:1077-1083 runs the const Intersect from 8 threads): calls on ONE context serialise — correct, not concurrent;
+    // threads that want their queries to overlap use one context each (include/tiny_hip.h: tinyhip::Scene::ForThread).  Recursive: entry
+    // points call each other (tbvh_upload_host -> tbvh_upload_cwbvh, the sharded calls -> the per-device ones).
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t ownStream = nullptr;
     hipStream_t stream = nullptr;
@@ -59,6 +65,7 @@ struct tbvh_context {
     uint32_t spillEntries = 0;    // 32-bit entries per lane
     unsigned long long* counter = nullptr;  // status word, instrumentation counters
     uint32_t poolParts = 5;   // log2: 32 partitions
+    bool embedTris = true;          // TBVH_EMBED_TRIS=0: the hybrid node copy without a triangle in each node's line (A/B: tools/ab_configs.py)
     bool incoherentCopies = true;   // TBVH_INCOHERENT_COPIES=0: no hybrid node copy / 64-byte triangle records (prepareIncoherentCopies)
     uint32_t expFlags = 0;     // tbvh_debug_set_flags: QueryArgs::flags of the next launches (experiments)
     bool lastProbed = false;   // the most recent query launch ran the coherence probe (tbvh_debug_last_probe)
@@ -94,8 +101,12 @@ struct tbvh_scene {
     uint32_t* hyPerm = nullptr; // device: position of node i in nodesHy
     float4* tris64 = nullptr;   // CWBVH (experiment flag 2): triangle records padded to 64 bytes
     uint32_t hybridK = 0;
+    bool hyTried = false;       // the incoherent-batch copies were built, or found impossible / unwanted: launchQuery does not try again
+    bool hyLevelOrder = false;  // the node array is in level order (made on the device): the hybrid copy needs no renumbering
     uint32_t nNodes = 0;
     uint64_t nNodeBlocks = 0, nTriBlocks = 0;
+    uint64_t capNodeBlocks = 0, capTriBlocks = 0;   // what the allocations hold (tbvh_update_*: a re-converted blob of at most this size goes in place)
+    uint64_t topoHash = 0;       // CWBVH: hash of every node's (imask, child base): an update with the same topology keeps the hybrid copy's numbering
     uint64_t bytes = 0;
     // TLAS (layout = BVH_GPU nodes in `nodes`)
     bool isTlas = false;
@@ -211,6 +222,9 @@ struct HostPipe {
 
 namespace tbvh_capi {
 int setDevice(tbvh_context* c);
+// first statement of an entry point once its arguments are known to be non-null: take the context's lock for the rest of the call, make its device current
+#define TBVH_LOCK(ctxptr) std::lock_guard<std::recursive_mutex> ctx_lock_((ctxptr)->mu)
+#define TBVH_ENTER(ctxptr) std::lock_guard<std::recursive_mutex> ctx_lock_((ctxptr)->mu); if (int r_ = tbvh_capi::setDevice(ctxptr)) return r_
 hipError_t timedBegin(tbvh_context* c);   // next event pair of the ring, start event recorded on the context's stream
 hipError_t timedEnd(tbvh_context* c);     // end event recorded; the operation counts as timed
 // one query launch (probe-in-kernel + traversal kernel(s)) on the context's stream; asynchronous.  nDev: batch size in device memory (wavefront queues)
@@ -218,7 +232,9 @@ int launchQuery(tbvh_scene* s, tbvh::RayRec* d_rays, uint64_t n, uint8_t* d_occ,
                 const unsigned long long* nDev = nullptr);
 int checkStatus(tbvh_context* c);   // synchronizes the stream, turns the device status word into an error code
 tbvh_scene* newScene(tbvh_context* c, int layout);
+uint64_t cwbvhTopologyHash(const tbvh::Vec4* nodes, uint32_t nNodes);
 int padCwbvhIfLarge(tbvh_scene* s);
 size_t hybridBytes(uint32_t nNodes, uint32_t K);
-int prepareIncoherentCopies(tbvh_scene* s, const tbvh::Vec4* hostNodes);
+bool wantsIncoherentCopies(const tbvh_scene* s);
+int prepareIncoherentCopies(tbvh_scene* s);   // (lazily, from launchQuery) hybrid node copy + 64-byte triangle records for incoherent batches
 }  // namespace tbvh_capi

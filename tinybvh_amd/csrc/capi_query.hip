@@ -101,7 +101,7 @@ constexpr uint64_t kPipeMinRays = 1ull << 15;
 
 int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh, float freshTmax, const unsigned long long* nDev) {
     tbvh_context* c = s->ctx;
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     if (n == 0) return 0;
     const bool any = d_occ != nullptr;
     // ray-fetch counters: two areas alternate; the kernels of this launch zero the other area for the next one.  After anything that went wrong
@@ -132,14 +132,17 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     uint64_t want = (n + perBlock - 1) / perBlock;
     const uint32_t lo = (uint32_t)c->numCUs * 4u;
     uint32_t blocks = (uint32_t)(want < lo ? lo : (want > cap ? cap : want));
-    HIP_TRY(timedBegin(c));   // the probe below is part of the query's time
+    const bool probed = !s->isTlas && !small && blobBytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || s->variant == 88);
+    if (probed && !s->hyTried) { if (int r = prepareIncoherentCopies(s)) return r; }   // first launch of this class on the scene: the derived copies for incoherent batches (not part of the query's time)
+    q.hybridK = s->hybridK;
+    HIP_TRY(timedBegin(c));
     // BVH8_CWBVH scenes beyond the L2s (the `small` class runs dense triangle phases, where the gated schedule loses 15 %) but within reach
     // of the Infinity Cache (beyond it camera rays are bound by memory too: 30 M / 60 M triangles lose 11 / 19 % under the gate), batches of 2 M
     // rays and more: a probe of the batch's coherence (256 neighbouring ray pairs, sampled by every wave of the traversal kernel itself: kernels_cwbvh.hip)
     // lets the traversal kernel pick its schedule for the launch; a coherent batch also gets a third more waves (the surplus leaves at once
     // otherwise).  Bistro stand-in, 16.7 M rays: camera rays +4.5 %, shadow rays +6 %, bounce rays unchanged.
     uint32_t blocksBase = blocks;
-    if (!s->isTlas && !small && blobBytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || s->variant == 88)) {
+    if (probed) {
         uint32_t* probe = poolArea + (size_t)kPoolParts * kPoolCounterStride;
         q.probe = probe; q.baseBlocks = blocks;
         c->lastProbed = true;
@@ -201,6 +204,11 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             const bool twoFlavors = q.probe && s->variant == 0 && !autoPad && s->nodesHy && s->tris64 && !(c->expFlags & 4u);
             if (s->variant == 90 && s->nodesHy && s->tris64)   // diagnostic: the incoherent flavor whatever the batch (tests, tools/ab_configs.py)
                 launch_cwbvh(any, 0, s->nodesHy, s->tris64, q, c->status, blocksBase, c->stream, 13, small, blocks7);
+            else if (s->variant == 91) {   // diagnostic: the coherent flavor (deferred triangles, gated triangle phase) whatever the batch and whatever its probe says
+                QueryArgs qa = q;
+                qa.probe = poolArea + (size_t)kPoolParts * kPoolCounterStride; qa.baseBlocks = 0; qa.flags |= 16u;
+                launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, blocks, c->stream, 5, small, blocks7);
+            }
             else if (twoFlavors) {
                 QueryArgs qa = q;
                 qa.baseBlocks = 0;   // every wave of the coherent flavor leaves unless the batch is coherent
@@ -209,7 +217,8 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                 QueryArgs qb = q;
                 // the incoherent flavor on 28 one-wave workgroups per CU when the batch fills the grid (24 is the persistent grid's size: 20 / 26 / 28 / 30 /
                 // 32 per CU trace bounce rays at -4.4 / +0.6 / +0.9 / +0.5 / +0.5 %, interleaved medians of 13 rounds)
-                const uint32_t wX = (c->expFlags >> 8) & 0xffu;   // experiment: another number of waves per CU
+                uint32_t wX = (c->expFlags >> 8) & 0xffu;   // experiment: another number of waves per CU
+                if (wX > 32u) wX = 32u;                     // (the spill area holds blocks + blocks / 3 = 32 workgroups per CU: LaneStack strides by gridDim)
                 const uint32_t wB = wX ? wX : (c->gridOverride ? 0u : 28u);
                 launch_cwbvh(any, 0, s->nodesHy, s->tris64, qb, c->status, (wB && blocksBase == c->blocks) ? (uint32_t)c->numCUs * wB : blocksBase, c->stream, 13, small, blocks7);
             } else
@@ -272,7 +281,7 @@ int tbvh_intersect(tbvh_scene* s, void* rays, uint64_t n, uint32_t stride) {
     if (stride < 64 || (stride & 3)) return fail(TBVH_E_INVALID, "stride must be >= 64 and a multiple of 4 (got %u)", stride);
     if (n == 0) return 0;
     tbvh_context* c = s->ctx;
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     if (int r = ensureStage(c, n)) return r;
     if (n >= kPipeMinRays) {   // pinned, chunked, multi-threaded staging (see HostPipe)
         if (int r = ensurePipe(c, n)) return r;
@@ -293,7 +302,7 @@ int tbvh_occluded(tbvh_scene* s, const void* rays, uint64_t n, uint32_t stride, 
     if (stride < 64 || (stride & 3)) return fail(TBVH_E_INVALID, "stride must be >= 64 and a multiple of 4 (got %u)", stride);
     if (n == 0) return 0;
     tbvh_context* c = s->ctx;
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     if (int r = ensureStage(c, n)) return r;
     if (int r = ensureStageOcc(c, n)) return r;
     if (n >= kPipeMinRays) {
@@ -404,7 +413,7 @@ int tbvh_bin_rays_device(tbvh_context* c, const void* dIn, void* dOut, uint64_t 
     if (dIn == dOut) return fail(TBVH_E_INVALID, "tbvh_bin_rays_device: the batch cannot be binned in place");
     if (cellBits > 6 || (flags & ~3u) || (flags & 3u) == 3u) return fail(TBVH_E_INVALID, "tbvh_bin_rays_device: cell_bits 0..6, flags 0, 1 or 2");
     if (n > 0xffffffffull) return fail(TBVH_E_INVALID, "tbvh_bin_rays_device: at most 2^32 - 1 rays per call");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     if (!n) return 0;
     size_t scanTemp = 0;
     const size_t need = ray_bin_scratch_bytes(n, cellBits, flags, &scanTemp);
@@ -433,7 +442,7 @@ int tbvh_bin_rays_device(tbvh_context* c, const void* dIn, void* dOut, uint64_t 
 int tbvh_generate_primary_device(tbvh_context* c, const tbvh_camera* cam, void* dRays, uint64_t first, uint64_t n) {
     if (!c || !cam || (!dRays && n)) return fail(TBVH_E_INVALID, "tbvh_generate_primary_device: null argument");
     if (cam->width % 4 || cam->height % 4 || !cam->spp_x || !cam->spp_y) return fail(TBVH_E_INVALID, "camera: width/height must be multiples of 4, spp > 0");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     if (!n) return 0;
     CameraArgs a;
     memcpy(a.eye, cam->eye, 12); memcpy(a.p1, cam->p1, 12); memcpy(a.p2, cam->p2, 12); memcpy(a.p3, cam->p3, 12);
@@ -445,7 +454,7 @@ int tbvh_generate_primary_device(tbvh_context* c, const tbvh_camera* cam, void* 
 
 int tbvh_generate_bounce_device(tbvh_context* c, const void* dVerts, const void* dIn, void* dOut, uint64_t n, uint32_t seed) {
     if (!c || ((!dVerts || !dIn || !dOut) && n)) return fail(TBVH_E_INVALID, "tbvh_generate_bounce_device: null argument");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     if (!n) return 0;
     TriSource src; src.mode = 0; src.verts = (const float4*)dVerts;
     launch_gen_bounce(src, (const RayRec*)dIn, (RayRec*)dOut, n, seed, c->stream);
@@ -455,7 +464,7 @@ int tbvh_generate_bounce_device(tbvh_context* c, const void* dVerts, const void*
 
 int tbvh_generate_shadow_device(tbvh_context* c, const void* dIn, void* dOut, uint64_t n, const float light[3], float eps) {
     if (!c || !light || ((!dIn || !dOut) && n)) return fail(TBVH_E_INVALID, "tbvh_generate_shadow_device: null argument");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     if (!n) return 0;
     launch_gen_shadow((const RayRec*)dIn, (RayRec*)dOut, n, light[0], light[1], light[2], eps, c->stream);
     HIP_TRY(hipGetLastError());
@@ -464,7 +473,7 @@ int tbvh_generate_shadow_device(tbvh_context* c, const void* dIn, void* dOut, ui
 
 int tbvh_reset_hits_device(tbvh_context* c, void* dRays, uint64_t n, float tmax) {
     if (!c || (!dRays && n)) return fail(TBVH_E_INVALID, "tbvh_reset_hits_device: null argument");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     if (!n) return 0;
     launch_reset_hits((RayRec*)dRays, n, tmax, c->stream);
     HIP_TRY(hipGetLastError());

@@ -23,34 +23,56 @@ size_t hybridBytes(uint32_t nNodes, uint32_t K) { return ((size_t)K * 5 + (size_
 
 // BVH8_CWBVH scenes of the class that gets the per-launch coherence probe (48 - 384 MB of blobs: beyond the L2s, within reach of the Infinity
 // Cache) keep two derived copies for INCOHERENT batches (kernels_cwbvh.hip: PROBED == 2): the nodes in surface-area priority order with the
-// first kHybridPacked packed and the others one per 128-byte line, and the triangle records padded to 64 bytes.  hostNodes: the blob as
-// uploaded (priority order computed on the host, ~0.1 s for 600 k nodes), or nullptr for trees made on the device (tbvh_convert_bvh2_device,
-// tbvh_build_device emit level order, which already is close to priority order: no renumbering).  Failure to allocate is not an error: the
-// scene then runs the one-kernel path.  TBVH_INCOHERENT_COPIES=0 turns the copies off.
+// first kHybridPacked packed and the others one per 128-byte line (each with one of its triangles in the line's spare 48 bytes), and the
+// triangle records padded to 64 bytes.  Built LAZILY by the first launch that would use them (launchQuery: a batch of 2 M rays or more) — a
+// scene that is only ever a BLAS under a TLAS, or only traced with small batches, never pays the 2.3 x memory and the host pass; that first
+// launch waits for the build (~0.1 s for 600 k nodes: the node array is read back, ordered on the host, scattered on the device).  Trees made
+// on the device (tbvh_convert_bvh2_device, tbvh_build_device) are in level order, which already is close to priority order: no renumbering.
+// A blob that is not a strict tree (cwbvh_priority_order), one with 2^27 triangle records or more, or a failed allocation is not an error:
+// the scene then runs the one-kernel path.  TBVH_INCOHERENT_COPIES=0 turns the copies off.
 constexpr uint32_t kHybridPacked = 8192;
-int prepareIncoherentCopies(tbvh_scene* s, const Vec4* hostNodes) {
-    tbvh_context* c = s->ctx;
+bool wantsIncoherentCopies(const tbvh_scene* s) {
     const uint64_t blobBytes = (s->nNodeBlocks + s->nTriBlocks) * 16;
-    if (s->layout != TBVH_LAYOUT_CWBVH || s->isTlas || !c->incoherentCopies || blobBytes < (48ull << 20) || blobBytes > (384ull << 20) || s->nNodes <= kHybridPacked || !s->nTriBlocks) return 0;
+    return s->layout == TBVH_LAYOUT_CWBVH && !s->isTlas && s->ctx->incoherentCopies && blobBytes >= (48ull << 20) && blobBytes <= (384ull << 20) && s->nNodes > kHybridPacked &&
+           s->nTriBlocks != 0 && s->nTriBlocks / 3 < (1ull << 27);
+}
+int prepareIncoherentCopies(tbvh_scene* s) {
+    tbvh_context* c = s->ctx;
+    s->hyTried = true;
+    if (!wantsIncoherentCopies(s)) return 0;
     const uint32_t K = kHybridPacked;
     const uint64_t nT = s->nTriBlocks / 3;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!s->hyLevelOrder && !s->hyPerm) {
+        std::vector<Vec4> host((size_t)s->nNodes * 5);
+        HIP_TRY(hipMemcpy(host.data(), s->nodes, host.size() * 16, hipMemcpyDeviceToHost));
+        std::vector<uint32_t> perm;
+        if (!cwbvh_priority_order(host.data(), s->nNodes, perm)) return 0;   // not a strict tree: traversed as uploaded
+        if (hipMalloc((void**)&s->hyPerm, (size_t)s->nNodes * 4) != hipSuccess) { s->hyPerm = nullptr; (void)hipGetLastError(); return 0; }
+        HIP_TRY(hipMemcpy(s->hyPerm, perm.data(), (size_t)s->nNodes * 4, hipMemcpyHostToDevice));
+    }
     if (!s->nodesHy && hipMalloc((void**)&s->nodesHy, hybridBytes(s->nNodes, K)) != hipSuccess) { s->nodesHy = nullptr; (void)hipGetLastError(); return 0; }
     if (!s->tris64 && hipMalloc((void**)&s->tris64, nT * 64) != hipSuccess) { s->tris64 = nullptr; (void)hipGetLastError(); hipFree(s->nodesHy); s->nodesHy = nullptr; return 0; }
-    if (hostNodes && !s->hyPerm) {
-        std::vector<uint32_t> perm;
-        cwbvh_priority_order(hostNodes, s->nNodes, perm);
-        if (hipMalloc((void**)&s->hyPerm, (size_t)s->nNodes * 4) == hipSuccess) HIP_TRY(hipMemcpyAsync(s->hyPerm, perm.data(), (size_t)s->nNodes * 4, hipMemcpyHostToDevice, c->stream));
-        else { s->hyPerm = nullptr; (void)hipGetLastError(); }
-        HIP_TRY(hipStreamSynchronize(c->stream));   // perm goes out of scope
-    }
     s->hybridK = K;
     HIP_TRY(hipMemsetAsync(s->nodesHy, 0, hybridBytes(s->nNodes, K), c->stream));
-    launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, s->nNodes, K, c->stream);
+    launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, s->nNodes, K, (c->embedTris && !(c->expFlags & 8u)) ? s->tris : nullptr, c->stream);
     launch_cwbvh_pad_tris(s->tris, s->tris64, nT, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     s->bytes += hybridBytes(s->nNodes, K) + nT * 64;
     return 0;
+}
+
+// order-dependent hash of what the hybrid copy's numbering depends on: which slots of every node are interior children and where they start
+uint64_t cwbvhTopologyHash(const Vec4* nodes, uint32_t nNodes) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ nNodes;
+    for (uint32_t i = 0; i < nNodes; i++) {
+        uint32_t w[2];
+        std::memcpy(&w[0], &nodes[(size_t)i * 5].w, 4); std::memcpy(&w[1], &nodes[(size_t)i * 5 + 1].x, 4);
+        const uint64_t k = ((uint64_t)(w[0] >> 24) << 32) | ((w[0] >> 24) ? w[1] : 0u);
+        h = (h ^ k) * 0x100000001B3ull; h ^= h >> 29;
+    }
+    return h;
 }
 
 tbvh_scene* newScene(tbvh_context* c, int layout) {
@@ -71,7 +93,7 @@ int tbvh_upload_bvh_gpu(tbvh_context* c, const void* nodes64, uint64_t nNodes, c
                         const void* verts16, uint64_t nTris, tbvh_scene** out) {
     if (!c || !nodes64 || !primIdx || !verts16 || !out || nNodes == 0) return fail(TBVH_E_INVALID, "tbvh_upload_bvh_gpu: null/empty argument");
     if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(TBVH_E_FORMAT, "%s", why);
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
     uint32_t* dIdx = nullptr; float4* dVerts = nullptr;
@@ -88,6 +110,7 @@ int tbvh_upload_bvh_gpu(tbvh_context* c, const void* nodes64, uint64_t nNodes, c
     if (dVerts) hipFree(dVerts);
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH_GPU upload failed: %s", hipGetErrorString(e)); }
     s->nNodeBlocks = nNodes * 4; s->nTriBlocks = nIdx * 3;
+    s->capNodeBlocks = s->nNodeBlocks; s->capTriBlocks = s->nTriBlocks;
     s->bytes = nNodes * 64 + nIdx * 48;
     *out = s;
     return 0;
@@ -96,14 +119,14 @@ int tbvh_upload_bvh_gpu(tbvh_context* c, const void* nodes64, uint64_t nNodes, c
 int tbvh_upload_bvh4_gpu(tbvh_context* c, const void* blocks16, uint64_t nBlocks, tbvh_scene** out) {
     if (!c || !blocks16 || !out || nBlocks < 4) return fail(TBVH_E_INVALID, "tbvh_upload_bvh4_gpu: null/empty argument");
     if (const char* why = validate_bvh4_gpu((const Vec4*)blocks16, nBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH4_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
     hipError_t e = hipMalloc((void**)&s->nodes, nBlocks * 16);
     if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, blocks16, nBlocks * 16, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH4_GPU upload failed: %s", hipGetErrorString(e)); }
-    s->nNodeBlocks = nBlocks; s->bytes = nBlocks * 16;
+    s->nNodeBlocks = nBlocks; s->capNodeBlocks = nBlocks; s->bytes = nBlocks * 16;
     *out = s;
     return 0;
 }
@@ -113,7 +136,7 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
     if (!c || !nodes16 || !out || nNodeBlocks < 5 || (nTriBlocks && !tris16)) return fail(TBVH_E_INVALID, "tbvh_upload_cwbvh: null/empty argument");
     if (nNodeBlocks % 5) return fail(TBVH_E_FORMAT, "CWBVH node blocks (%llu) not a multiple of 5", (unsigned long long)nNodeBlocks);
     if (const char* why = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_CWBVH);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
     hipError_t e = hipMalloc((void**)&s->nodes, nNodeBlocks * 16);
@@ -124,9 +147,10 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "CWBVH upload failed: %s", hipGetErrorString(e)); }
     s->nNodeBlocks = nNodeBlocks; s->nTriBlocks = nTriBlocks;
+    s->capNodeBlocks = nNodeBlocks; s->capTriBlocks = nTriBlocks ? nTriBlocks : 1;
+    s->topoHash = cwbvhTopologyHash((const Vec4*)nodes16, s->nNodes);
     s->bytes = (nNodeBlocks + nTriBlocks) * 16;
     if (int r = padCwbvhIfLarge(s)) { tbvh_free_scene(s); return r; }
-    if (int r = prepareIncoherentCopies(s, (const Vec4*)nodes16)) { tbvh_free_scene(s); return r; }
     *out = s;
     return 0;
 }
@@ -224,7 +248,7 @@ int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, cons
         layout = i == 0 ? b->layout : (layout == b->layout ? layout : 0);   // 0: the BLASes mix layouts (traverse_tlas.cl:50-72)
         desc[i].nodes = b->nodes; desc[i].tris = b->tris; desc[i].opmap = b->opmap; desc[i].opmapN = b->opmapN; desc[i].layout = (uint32_t)b->layout;
     }
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
     s->isTlas = true; s->blasLayout = layout; s->nBlas = nBlas;
@@ -241,8 +265,80 @@ int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, cons
 
 int tbvh_update_tlas(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* idx, uint64_t nIdx, const void* inst, uint64_t nInst) {
     if (!s || !s->isTlas || !nodes64 || !idx || !inst || !nNodes || !nIdx || !nInst) return fail(TBVH_E_INVALID, "tbvh_update_tlas: not a TLAS or null/empty argument");
-    if (int r = setDevice(s->ctx)) return r;
+    TBVH_ENTER(s->ctx);
     return tlasCopy(s, nodes64, nNodes, idx, nIdx, inst, nInst);
+}
+
+// ---- in-place re-upload of a BLAS whose blob the caller refitted / re-converted on the host ---------------------------------------------
+// (BVH::Refit tiny_bvh.h:3055-3093 + X::ConvertFrom again: the reference's flow for animated geometry.)  The device allocations, the scene
+// handle and the pointers the TLASes over this BLAS hold stay as they are; the library's derived copies follow.
+int tbvh_update_bvh_gpu(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx, const void* verts16, uint64_t nTris) {
+    if (!s || s->isTlas || s->layout != TBVH_LAYOUT_BVH_GPU || !nodes64 || !primIdx || !verts16 || !nNodes) return fail(TBVH_E_INVALID, "tbvh_update_bvh_gpu: not a BVH_GPU scene or null/empty argument");
+    if (nNodes * 4 > s->capNodeBlocks || nIdx * 3 > s->capTriBlocks) return fail(TBVH_E_INVALID, "tbvh_update_bvh_gpu: the blob (%llu nodes, %llu indices) is larger than the one uploaded: free the scene and upload", (unsigned long long)nNodes, (unsigned long long)nIdx);
+    if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(TBVH_E_FORMAT, "%s", why);
+    tbvh_context* c = s->ctx;
+    TBVH_ENTER(c);
+    uint32_t* dIdx = nullptr; float4* dVerts = nullptr;
+    hipError_t e = hipMalloc((void**)&dIdx, (nIdx ? nIdx : 1) * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dVerts, (nTris ? nTris : 1) * 48);
+    if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, nodes64, nNodes * 64, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dIdx, primIdx, nIdx * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(dVerts, verts16, nTris * 48, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && nIdx) { launch_gather_tris(dIdx, dVerts, s->tris, nIdx, nTris, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (dIdx) hipFree(dIdx);
+    if (dVerts) hipFree(dVerts);
+    if (e != hipSuccess) return fail(TBVH_E_HIP, "tbvh_update_bvh_gpu: %s", hipGetErrorString(e));
+    s->nNodeBlocks = nNodes * 4; s->nTriBlocks = nIdx * 3;
+    return 0;
+}
+
+int tbvh_update_bvh4_gpu(tbvh_scene* s, const void* blocks16, uint64_t nBlocks) {
+    if (!s || s->isTlas || s->layout != TBVH_LAYOUT_BVH4_GPU || !blocks16 || nBlocks < 4) return fail(TBVH_E_INVALID, "tbvh_update_bvh4_gpu: not a BVH4_GPU scene or null/empty argument");
+    if (nBlocks > s->capNodeBlocks) return fail(TBVH_E_INVALID, "tbvh_update_bvh4_gpu: %llu blocks, the scene holds %llu: free the scene and upload", (unsigned long long)nBlocks, (unsigned long long)s->capNodeBlocks);
+    if (const char* why = validate_bvh4_gpu((const Vec4*)blocks16, nBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
+    tbvh_context* c = s->ctx;
+    TBVH_ENTER(c);
+    HIP_TRY(hipMemcpyAsync(s->nodes, blocks16, nBlocks * 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    s->nNodeBlocks = nBlocks;
+    s->b4Levels.clear();   // (the node list of a device refit is rebuilt by the next tbvh_refit)
+    if (s->refitScratch) { hipFree(s->refitScratch); s->refitScratch = nullptr; }
+    return 0;
+}
+
+int tbvh_update_cwbvh(tbvh_scene* s, const void* nodes16, uint64_t nNodeBlocks, const void* tris16, uint64_t nTriBlocks) {
+    if (!s || s->isTlas || s->layout != TBVH_LAYOUT_CWBVH || !nodes16 || nNodeBlocks < 5 || (nTriBlocks && !tris16)) return fail(TBVH_E_INVALID, "tbvh_update_cwbvh: not a BVH8_CWBVH scene or null/empty argument");
+    if (nNodeBlocks % 5) return fail(TBVH_E_FORMAT, "CWBVH node blocks (%llu) not a multiple of 5", (unsigned long long)nNodeBlocks);
+    if (nNodeBlocks > s->capNodeBlocks || nTriBlocks > s->capTriBlocks) return fail(TBVH_E_INVALID, "tbvh_update_cwbvh: the blob (%llu + %llu blocks) is larger than the one uploaded (%llu + %llu): free the scene and upload",
+                                                                                    (unsigned long long)nNodeBlocks, (unsigned long long)nTriBlocks, (unsigned long long)s->capNodeBlocks, (unsigned long long)s->capTriBlocks);
+    if (const char* why = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
+    tbvh_context* c = s->ctx;
+    TBVH_ENTER(c);
+    HIP_TRY(hipMemcpyAsync(s->nodes, nodes16, nNodeBlocks * 16, hipMemcpyHostToDevice, c->stream));
+    if (nTriBlocks) HIP_TRY(hipMemcpyAsync(s->tris, tris16, nTriBlocks * 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // the caller may reuse its arrays
+    const uint32_t nNodes = (uint32_t)(nNodeBlocks / 5);
+    const uint64_t hash = cwbvhTopologyHash((const Vec4*)nodes16, nNodes);
+    const bool sameShape = nNodes == s->nNodes && nTriBlocks == s->nTriBlocks && hash == s->topoHash;
+    s->bytes -= (s->nNodeBlocks + s->nTriBlocks) * 16; s->bytes += (nNodeBlocks + nTriBlocks) * 16;
+    s->nNodes = nNodes; s->nNodeBlocks = nNodeBlocks; s->nTriBlocks = nTriBlocks; s->topoHash = hash;
+    if (s->refitScratch) { hipFree(s->refitScratch); s->refitScratch = nullptr; }   // (sized and filled for the old tree)
+    if (sameShape) {   // boxes and vertices moved, the tree did not: the derived copies keep their numbering and are re-derived on the device
+        if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);
+        if (s->nodesHy) launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, nNodes, s->hybridK, (c->embedTris && !(c->expFlags & 8u)) ? s->tris : nullptr, c->stream);
+        if (s->tris64) launch_cwbvh_pad_tris(s->tris, s->tris64, nTriBlocks / 3, c->stream);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+    // another tree in the same allocation: the derived copies go; they come back as at upload (padded nodes now, the incoherent-batch copies lazily)
+    if (s->nodes128) { hipFree(s->nodes128); s->nodes128 = nullptr; }
+    if (s->nodesHy) { hipFree(s->nodesHy); s->nodesHy = nullptr; }
+    if (s->tris64) { hipFree(s->tris64); s->tris64 = nullptr; }
+    if (s->hyPerm) { hipFree(s->hyPerm); s->hyPerm = nullptr; }
+    s->hybridK = 0; s->hyTried = false; s->hyLevelOrder = false;
+    s->bytes = (nNodeBlocks + nTriBlocks) * 16 + s->opmapBytes;
+    return padCwbvhIfLarge(s);
 }
 
 namespace {
@@ -273,7 +369,7 @@ int convertDeviceImpl4(tbvh_context* c, const float4* dN2, uint64_t nNodes2, con
     if (e == hipSuccess) e = hipMemcpyAsync(s->nodes, t.blocks, nBlocks * 16, hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH2 -> BVH4_GPU: %s", hipGetErrorString(e)); }
-    s->nNodeBlocks = nBlocks; s->bytes = nBlocks * 16;
+    s->nNodeBlocks = nBlocks; s->capNodeBlocks = nBlocks; s->bytes = nBlocks * 16;
     *out = s;
     return 0;
 }
@@ -309,9 +405,10 @@ int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t n
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH2 -> CWBVH: %s", hipGetErrorString(e)); }
     s->nNodes = nWide; s->nNodeBlocks = (uint64_t)nWide * 5; s->nTriBlocks = nWideTris * 3;
+    s->capNodeBlocks = s->nNodeBlocks; s->capTriBlocks = nWideTris ? s->nTriBlocks : 3;
     s->bytes = (s->nNodeBlocks + s->nTriBlocks) * 16;
     if (int r = padCwbvhIfLarge(s)) { tbvh_free_scene(s); return r; }
-    if (int r = prepareIncoherentCopies(s, nullptr)) { tbvh_free_scene(s); return r; }
+    s->hyLevelOrder = true;   // (level order is close to priority order: the incoherent-batch copies need no renumbering)
     *out = s;
     return 0;
 }
@@ -322,7 +419,7 @@ int tbvh_convert_bvh2_device(tbvh_context* c, const void* nodes32, uint64_t nNod
     if (!c || !nodes32 || !primIdx || !verts16 || !out || nNodes2 == 0 || nIdx == 0 || nTris == 0) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: null/empty argument");
     if (layout != TBVH_LAYOUT_CWBVH && layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: target layout %d not supported (BVH8_CWBVH and BVH4_GPU are)", layout);
     if (nNodes2 > 0x7fffffffull || nIdx > 0x7fffffffull) return fail(TBVH_E_INVALID, "tbvh_convert_bvh2_device: BVH2 too large for 32-bit node / triangle indices");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     struct Tmp {
         void *n2 = nullptr, *idx = nullptr, *v = nullptr;
         ~Tmp() { for (void* p : {n2, idx, v}) if (p) hipFree(p); }
@@ -349,7 +446,7 @@ int buildDeviceImpl(const char* who, tbvh_context* c, const void* verts16, uint6
     if (!c || !verts16 || !out || nTris == 0) return fail(TBVH_E_INVALID, "%s: null/empty argument", who);
     if (layout != TBVH_LAYOUT_CWBVH && layout != TBVH_LAYOUT_BVH4_GPU) return fail(TBVH_E_INVALID, "%s: target layout %d not supported (BVH8_CWBVH and BVH4_GPU are)", who, layout);
     if (nTris > 0x3fffffffull) return fail(TBVH_E_INVALID, "%s: too many triangles for 32-bit node indices", who);
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     struct Tmp {
         void *v = nullptr, *n2 = nullptr, *idx = nullptr, *scratch = nullptr;
         ~Tmp() { for (void* p : {v, n2, idx, scratch}) if (p) hipFree(p); }
@@ -404,7 +501,7 @@ int refreshBlasDescs(tbvh_scene* b) {
 int tbvh_set_opacity_micromaps(tbvh_scene* s, const uint32_t* mapData, uint32_t N, uint64_t nTris, int onDevice) {
     if (!s || s->isTlas) return fail(TBVH_E_INVALID, "tbvh_set_opacity_micromaps: not a BLAS scene (set the maps on the BLASes before uploading their TLAS)");
     tbvh_context* c = s->ctx;
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     // validate first, build the new map next, and only then swap it in: every exit leaves the scene and the TLASes over it (their BlasDesc
     // snapshots) pointing at live memory — the old maps on a failure, the new ones on success
     const bool clear = !mapData || N == 0;
@@ -435,7 +532,7 @@ int tbvh_set_opacity_micromaps(tbvh_scene* s, const uint32_t* mapData, uint32_t 
 int tbvh_scene_download(tbvh_scene* s, int which, void* dst, uint64_t capBytes, uint64_t* bytesOut) {
     if (!s || s->isTlas || (which != 0 && which != 1)) return fail(TBVH_E_INVALID, "tbvh_scene_download: not a BLAS scene or bad blob selector");
     tbvh_context* c = s->ctx;
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     const void* src = which == 0 ? (const void*)s->nodes : (const void*)s->tris;
     const uint64_t bytes = (which == 0 ? s->nNodeBlocks : s->nTriBlocks) * 16;
     if (bytesOut) *bytesOut = src ? bytes : 0;
@@ -451,7 +548,7 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
     if (!s || !verts16 || !nTris) return fail(TBVH_E_INVALID, "tbvh_refit: null/empty argument");
     if (s->isTlas) return fail(TBVH_E_INVALID, "tbvh_refit: a TLAS is rebuilt with tbvh_rebuild_tlas_device / tbvh_update_tlas");
     tbvh_context* c = s->ctx;
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     if (s->layout == TBVH_LAYOUT_BVH4_GPU) {
         // node list per level, child-box hand-over area: sized for the most nodes the stream can hold (4 blocks each)
         const uint32_t capNodes = (uint32_t)(s->nNodeBlocks / 4 + 1);
@@ -497,7 +594,7 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
     HIP_TRY(timedEnd(c));
     // derived node layouts of the experiment kernels would be stale now
     if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copy current
-    if (s->nodesHy) launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, nNodes, s->hybridK, c->stream);
+    if (s->nodesHy) launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, nNodes, s->hybridK, (c->embedTris && !(c->expFlags & 8u)) ? s->tris : nullptr, c->stream);
     if (s->tris64) launch_cwbvh_pad_tris(s->tris, s->tris64, s->nTriBlocks / 3, c->stream);
     return 0;
 }
@@ -505,7 +602,7 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
 int tbvh_rebuild_tlas_device(tbvh_scene* s, const void* transforms, int onDevice, const float* blasBounds6, uint64_t nBlas) {
     if (!s || !s->isTlas) return fail(TBVH_E_INVALID, "tbvh_rebuild_tlas_device: not a TLAS");
     tbvh_context* c = s->ctx;
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     const uint64_t n = s->nInst;
     if (n == 0 || n > 0x7fffffffull) return fail(TBVH_E_INVALID, "tbvh_rebuild_tlas_device: %llu instances", (unsigned long long)n);
     if (blasBounds6) {
@@ -553,7 +650,7 @@ int tbvh_tlas_download(tbvh_scene* s, void* nodes64, uint64_t capNodes, uint32_t
                        uint64_t* nNodesOut) {
     if (!s || !s->isTlas) return fail(TBVH_E_INVALID, "tbvh_tlas_download: not a TLAS");
     tbvh_context* c = s->ctx;
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     const uint64_t n = s->nInst, nNodes = s->nTlasNodes;
     if (nNodesOut) *nNodesOut = nNodes;
@@ -566,6 +663,7 @@ int tbvh_tlas_download(tbvh_scene* s, void* nodes64, uint64_t capNodes, uint32_t
 void tbvh_free_scene(tbvh_scene* s) {
     if (!s) return;
     tbvh_context* c = s->ctx;
+    TBVH_LOCK(c);
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (!s->isTlas && !s->usedBy.empty()) { s->zombie = true; return; }   // a TLAS still points at this BLAS's memory: freed with the last such TLAS
@@ -605,6 +703,7 @@ uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0;
 
 int tbvh_set_variant(tbvh_scene* s, int v) {
     if (!s) return fail(TBVH_E_INVALID, "null scene");
+    TBVH_LOCK(s->ctx);
     // only the BVH8_CWBVH kernel keeps diagnostic variants (kernels_cwbvh.hip: forced schedules, instrumented kernels)
     const bool ok = v == 0 || (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH && cwbvh_variant_valid(v));
     if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
@@ -615,23 +714,25 @@ int tbvh_set_variant(tbvh_scene* s, int v) {
 int tbvh_cwbvh_set_hybrid(tbvh_scene* s, int64_t packedNodes) {
     if (!s || s->isTlas || s->layout != TBVH_LAYOUT_CWBVH) return fail(TBVH_E_INVALID, "tbvh_cwbvh_set_hybrid: not a BVH8_CWBVH scene");
     tbvh_context* c = s->ctx;
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (s->nodesHy) { s->bytes -= hybridBytes(s->nNodes, s->hybridK); hipFree(s->nodesHy); s->nodesHy = nullptr; }
+    s->hyTried = true;   // the caller decides now: no lazy build behind its back
     if (packedNodes < 0) return 0;
+    if (s->nTriBlocks / 3 >= (1ull << 27)) return fail(TBVH_E_INVALID, "tbvh_cwbvh_set_hybrid: 2^27 triangle records or more");
     const uint32_t K = (uint32_t)std::min<uint64_t>((uint64_t)packedNodes, s->nNodes) & ~7u;   // the padded part starts on a 128-byte line
-    if (!s->hyPerm) {
+    if (!s->hyPerm && !s->hyLevelOrder) {
         std::vector<Vec4> host((size_t)s->nNodes * 5);
         HIP_TRY(hipMemcpy(host.data(), s->nodes, host.size() * 16, hipMemcpyDeviceToHost));
         std::vector<uint32_t> perm;
-        cwbvh_priority_order(host.data(), s->nNodes, perm);
+        if (!cwbvh_priority_order(host.data(), s->nNodes, perm)) return fail(TBVH_E_FORMAT, "tbvh_cwbvh_set_hybrid: the node array is not a strict tree (a child range shared by two parents or out of range)");
         HIP_TRY(hipMalloc((void**)&s->hyPerm, (size_t)s->nNodes * 4));
         HIP_TRY(hipMemcpy(s->hyPerm, perm.data(), (size_t)s->nNodes * 4, hipMemcpyHostToDevice));
     }
     HIP_TRY(hipMalloc((void**)&s->nodesHy, hybridBytes(s->nNodes, K)));
     HIP_TRY(hipMemsetAsync(s->nodesHy, 0, hybridBytes(s->nNodes, K), c->stream));
     s->hybridK = K;
-    launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, s->nNodes, K, c->stream);
+    launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, s->nNodes, K, (c->embedTris && !(c->expFlags & 8u)) ? s->tris : nullptr, c->stream);
     HIP_TRY(hipGetLastError());
     s->bytes += hybridBytes(s->nNodes, K);
     if (!s->tris64 && s->nTriBlocks) {

@@ -30,7 +30,7 @@ struct tbvh_wavefront {
 
 int tbvh_wavefront_create(tbvh_context* c, uint32_t width, uint32_t height, tbvh_wavefront** out) {
     if (!c || !out || !width || !height || (width & 3) || (height & 3)) return fail(TBVH_E_INVALID, "tbvh_wavefront_create: null argument or size not a multiple of 4");
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     tbvh_wavefront* w = new (std::nothrow) tbvh_wavefront;
     if (!w) return fail(TBVH_E_NOMEM, "out of host memory");
     w->ctx = c; w->width = width; w->height = height; w->n = (uint64_t)width * height;
@@ -54,6 +54,7 @@ int tbvh_wavefront_create(tbvh_context* c, uint32_t width, uint32_t height, tbvh
 
 void tbvh_wavefront_destroy(tbvh_wavefront* w) {
     if (!w) return;
+    TBVH_LOCK(w->ctx);
     hipSetDevice(w->ctx->device);
     hipStreamSynchronize(w->ctx->stream);
     for (int i = 0; i < 2; i++) { if (w->rays[i]) hipFree(w->rays[i]); if (w->aux[i]) hipFree(w->aux[i]); }
@@ -71,7 +72,7 @@ void tbvh_wavefront_destroy(tbvh_wavefront* w) {
 
 int tbvh_wavefront_set_blas_vertices(tbvh_wavefront* w, const void* const* dVertsPerBlas, uint64_t nBlas) {
     if (!w || !dVertsPerBlas || !nBlas) return fail(TBVH_E_INVALID, "tbvh_wavefront_set_blas_vertices: null/empty argument");
-    if (int r = setDevice(w->ctx)) return r;
+    TBVH_ENTER(w->ctx);
     HIP_TRY(hipStreamSynchronize(w->ctx->stream));
     if (w->blasVerts) { hipFree((void*)w->blasVerts); w->blasVerts = nullptr; w->nBlasVerts = 0; }
     HIP_TRY(hipMalloc((void**)&w->blasVerts, nBlas * sizeof(void*)));
@@ -91,7 +92,7 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
     if (cam->width != w->width || cam->height != fullH) return fail(TBVH_E_INVALID, "camera size differs from the wavefront's (a band takes the FULL image's camera)");
     const uint32_t maxDepth = p->max_depth ? (p->max_depth > 8 ? 8 : p->max_depth) : 3;
     tbvh_context* c = w->ctx;
-    if (int r = setDevice(c)) return r;
+    TBVH_ENTER(c);
     hipStream_t st = c->stream;
     HIP_TRY(hipEventRecord(w->e0, st));
     if (p->clear) HIP_TRY(hipMemsetAsync(w->accum, 0, w->n * 16, st));
@@ -143,6 +144,7 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
 
 int tbvh_wavefront_set_band(tbvh_wavefront* w, uint32_t firstRow, uint32_t fullHeight) {
     if (!w) return fail(TBVH_E_INVALID, "tbvh_wavefront_set_band: null wavefront");
+    TBVH_LOCK(w->ctx);
     if (fullHeight == 0) { w->firstRow = 0; w->fullHeight = 0; return 0; }
     if ((firstRow & 3u) || (fullHeight & 3u) || (uint64_t)firstRow + w->height > fullHeight) return fail(TBVH_E_INVALID, "tbvh_wavefront_set_band: rows %u + %u of %u (multiples of 4, inside the image)", firstRow, w->height, fullHeight);
     w->firstRow = firstRow; w->fullHeight = fullHeight;
@@ -172,7 +174,7 @@ int tbvh_wavefront_render_sharded(tbvh_wavefront* const* wfs, tbvh_scene* const*
     for (uint32_t i = 0; i < nDev; i++) {
         tbvh_wavefront* w = wfs[i];
         tbvh_context* c = w->ctx;
-        if (int r = setDevice(c)) return r;
+        TBVH_ENTER(c);
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (int r = checkStatus(c)) return r;
         if (stats) {
@@ -199,7 +201,7 @@ int tbvh_wavefront_read_sharded(tbvh_wavefront* const* wfs, uint32_t nDev, float
 int tbvh_wavefront_set_blue_noise(tbvh_wavefront* w, const uint32_t* table, uint64_t nWords) {
     if (!w) return fail(TBVH_E_INVALID, "tbvh_wavefront_set_blue_noise: null wavefront");
     if (table && nWords != 128ull * 128 * 8) return fail(TBVH_E_INVALID, "tbvh_wavefront_set_blue_noise: the table is 128 x 128 x 8 = 131072 words (got %llu)", (unsigned long long)nWords);
-    if (int r = setDevice(w->ctx)) return r;
+    TBVH_ENTER(w->ctx);
     HIP_TRY(hipStreamSynchronize(w->ctx->stream));
     if (w->blueNoise) { hipFree(w->blueNoise); w->blueNoise = nullptr; }
     if (!table) return 0;
@@ -210,7 +212,7 @@ int tbvh_wavefront_set_blue_noise(tbvh_wavefront* w, const uint32_t* table, uint
 
 int tbvh_wavefront_read(tbvh_wavefront* w, float* rgba) {
     if (!w || !rgba) return fail(TBVH_E_INVALID, "tbvh_wavefront_read: null argument");
-    if (int r = setDevice(w->ctx)) return r;
+    TBVH_ENTER(w->ctx);
     HIP_TRY(hipMemcpyAsync(rgba, w->accum, w->n * 16, hipMemcpyDeviceToHost, w->ctx->stream));
     HIP_TRY(hipStreamSynchronize(w->ctx->stream));
     return 0;
@@ -218,7 +220,7 @@ int tbvh_wavefront_read(tbvh_wavefront* w, float* rgba) {
 
 int tbvh_wavefront_finalize(tbvh_wavefront* w, float scale, uint32_t* pixels) {
     if (!w || !pixels) return fail(TBVH_E_INVALID, "tbvh_wavefront_finalize: null argument");
-    if (int r = setDevice(w->ctx)) return r;
+    TBVH_ENTER(w->ctx);
     uint32_t* d = (uint32_t*)w->shadow;   // 4 bytes per pixel in the shadow-ray buffer (64 bytes per pixel, idle between frames)
     launch_wf_finalize(w->accum, scale, d, w->n, w->ctx->stream);
     HIP_TRY(hipGetLastError());

@@ -32,6 +32,10 @@ struct CwNodeHits { uint32_t childBase, triBase, hitmask, imask; };
 // per second) packed, all later ones (fetched from beyond the L2s, where a line is the unit and a packed node straddles 1.6 of them) one
 // per line.  hybridK is a multiple of 8, so the padded part starts on a line.
 constexpr int kNodeHybrid = 13;
+// ... and in the hybrid copy the triangle word of a node is  embedded << 27 | first 64-byte triangle record  (kernels_cwbvh.hip: k_derive_hybrid):
+// the node's triangle number `embedded` (kNoEmbedded: none) is ALSO stored in float4s 5..7 of the node's own line.
+constexpr uint32_t kNoEmbedded = 31u;
+__device__ __forceinline__ uint32_t cw_hybrid_offset(uint32_t nodeIdx, uint32_t hybridK) { return nodeIdx * 8u - (nodeIdx < hybridK ? nodeIdx : hybridK) * 3u; }   // in float4s
 template <int NSTRIDE = 5>
 __device__ __forceinline__ CwNode cw_load_node(const float4* __restrict__ nodes, uint32_t nodeIdx, uint32_t hybridK = 0u) {
     const size_t off = NSTRIDE == kNodeHybrid ? (size_t)nodeIdx * 8u - (size_t)(nodeIdx < hybridK ? nodeIdx : hybridK) * 3u : (size_t)nodeIdx * (uint32_t)NSTRIDE;

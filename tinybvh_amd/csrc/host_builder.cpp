@@ -806,7 +806,9 @@ namespace tbvh {
 // childBaseIndex + popc(...) addressing still works).  The first K nodes of the result are
 // (to first order) the K nodes a random ray is most likely to visit.  Works on any valid
 // CWBVH blob, reference-built or ours.  newIdx[old] = new; unreachable nodes keep 0xffffffff.
-void cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>& newIdx) {
+// Returns false — and the caller must not renumber — when the blob is not a strict tree (a child range that leaves the array, or a node
+// reachable from two parents): the numbering would then collide or run past nNodes.
+bool cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>& newIdx) {
     auto u32 = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
     auto area = [&](uint32_t n) {
         const Vec4* p = in + (size_t)n * 5;
@@ -830,15 +832,17 @@ void cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>
         const Vec4* p = in + (size_t)n * 5;
         const uint32_t imask = u32(p[0].w) >> 24, base = u32(p[1].x);
         const uint32_t cnt = (uint32_t)__builtin_popcount(imask);
+        if ((uint64_t)next + cnt > nNodes) return false;
         for (uint32_t j = 0; j < cnt; j++) {
             const uint32_t c = base + j;
-            if (c >= nNodes || newIdx[c] != 0xffffffffu) continue;  // malformed blob: leave as is
+            if (c >= nNodes || newIdx[c] != 0xffffffffu) return false;   // child out of range / shared by two parents: not a tree
             newIdx[c] = next + j;
             pq.push({area(c), c});
         }
         next += cnt;
     }
     for (uint32_t i = 0; i < nNodes; i++) if (newIdx[i] == 0xffffffffu) newIdx[i] = next++;   // unreachable nodes go last
+    return next == nNodes;
 }
 
 }  // namespace tbvh
@@ -852,6 +856,19 @@ const char* validate_bvh_gpu(const NodeAL* n, uint64_t nNodes, uint64_t nIdx) {
         if (n[i].triCount) {
             if ((uint64_t)n[i].firstTri + n[i].triCount > nIdx) return "BVH_GPU leaf: firstTri + triCount exceeds the primIdx array";
         } else if (n[i].left >= nNodes || n[i].right >= nNodes) return "BVH_GPU interior node: child index out of range";
+    }
+    // in-range indices keep every read in bounds; only a TREE keeps the traversal finite (a cycle would hang the GPU): walk from the root,
+    // no node may be reached twice
+    std::vector<uint8_t> seen(nNodes, 0);
+    std::vector<uint32_t> stack{0};
+    seen[0] = 1;
+    while (!stack.empty()) {
+        const uint32_t i = stack.back(); stack.pop_back();
+        if (n[i].triCount) continue;
+        for (const uint32_t c : {n[i].left, n[i].right}) {
+            if (seen[c]) return "BVH_GPU: a node is reachable along two paths (the node array is not a tree)";
+            seen[c] = 1; stack.push_back(c);
+        }
     }
     return nullptr;
 }
@@ -889,6 +906,9 @@ const char* validate_cwbvh(const Vec4* nodes, uint64_t nNodes, uint64_t nTriBloc
         uint8_t meta[8]; std::memcpy(meta, &p[1].z, 8);
         uint32_t maxTri = 0;
         for (int s = 0; s < 8; s++) {
+            // the kernels take a slot for an interior child by its meta byte (0b001sssss, sssss = 24 + slot: bits 3 and 4 set) and index the
+            // children through imask: the two must agree, or a child index runs past the range validated above
+            if ((((uint32_t)meta[s] & 0x18u) == 0x18u) != (((imask >> s) & 1u) != 0u)) return "CWBVH node: a slot's meta byte and the interior mask disagree";
             if ((imask >> s) & 1) continue;
             const uint32_t m = meta[s];
             if (!m) continue;
@@ -901,6 +921,20 @@ const char* validate_cwbvh(const Vec4* nodes, uint64_t nNodes, uint64_t nTriBloc
         // switch: 64-byte Baldwin-Weber records, four float4 each) counts in fours
         if (maxTri && triBase % 3u != 0u) return "CWBVH node: triangle base is not a multiple of 3 float4 (a CWBVH_COMPRESSED_TRIS blob? that experimental format is not supported)";
         if (maxTri && (uint64_t)triBase + 3ull * maxTri > nTriBlocks) return "CWBVH node: triangle range exceeds the triangle array";
+    }
+    // ... and the node array must be a TREE under the root: a child range shared by two parents may close a cycle, and a cyclic blob is a
+    // traversal that never ends (a hung GPU, not a wrong answer).  Nodes the root does not reach are ignored, as the traversal ignores them.
+    std::vector<uint8_t> seen(nNodes, 0);
+    std::vector<uint32_t> stack{0};
+    seen[0] = 1;
+    while (!stack.empty()) {
+        const Vec4* p = nodes + (size_t)stack.back() * 5; stack.pop_back();
+        const uint32_t imask = u32(p[0].w) >> 24, base = u32(p[1].x);
+        const uint32_t cnt = (uint32_t)__builtin_popcount(imask);
+        for (uint32_t j = 0; j < cnt; j++) {
+            if (seen[base + j]) return "CWBVH: a node is reachable along two paths (the node array is not a strict tree)";
+            seen[base + j] = 1; stack.push_back(base + j);
+        }
     }
     return nullptr;
 }

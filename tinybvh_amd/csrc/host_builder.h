@@ -62,7 +62,7 @@ void encode_cwbvh(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std:
                   std::vector<Vec4>& triBlocks);
 
 // CWBVH nodes (5 x Vec4 each) in surface-area priority order: newIdx[old] = new; see host_builder.cpp.
-void cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>& newIdx);
+bool cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>& newIdx);   // false: not a strict tree, no numbering
 
 // Structural validation of caller-supplied blobs (returns nullptr when fine, else a message).
 const char* validate_bvh_gpu(const NodeAL* nodes, uint64_t nNodes, uint64_t nIdx);

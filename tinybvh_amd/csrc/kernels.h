@@ -15,7 +15,7 @@ void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& 
 // Cache); 13 (cwbvh_node.h: kNodeHybrid) = the priority-ordered copy whose first q.hybridK nodes are packed and the others one per line
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                   uint32_t blocks, hipStream_t s, int nodeStride = 5, bool shallow = false, uint32_t blocks7 = 0xFFFFFFFFu);   // blocks7: grid of the kernels built for 7 waves per SIMD
-void launch_cwbvh_derive_hybrid(const float4* src, const uint32_t* perm, float4* dst, uint32_t nNodes, uint32_t hybridK, hipStream_t s);
+void launch_cwbvh_derive_hybrid(const float4* src, const uint32_t* perm, float4* dst, uint32_t nNodes, uint32_t hybridK, const float4* tris, hipStream_t s);   // tris: the packed 48-byte records (one per node is embedded in its line), or nullptr
 bool cwbvh_variant_valid(int variant);     // diagnostic variants of the BVH8_CWBVH kernel (tbvh_set_variant); the other layouts have none
 void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream_t s);
 void launch_cwbvh_pad_tris(const float4* src, float4* dst, uint64_t nTris, hipStream_t s);

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
             coherence_sample(q.rays, nRaysTotal, agree, pairs);
             if (blockIdx.x == 0 && threadIdx.x == 0) { q.probe[0] = agree; q.probe[1] = pairs; }
         }
-        coh = pairs != 0 && agree * 10u >= pairs * 6u;
+        coh = (pairs != 0 && agree * 10u >= pairs * 6u) || (q.flags & 16u) != 0;   // (flag 16: tbvh_set_variant 91 forces the coherent verdict — tests)
         if (PROBED == 2) { if (coh) return; }
         else if (PROBED == 3) { if (!coh) return; }   // the coherent flavor of a two-kernel launch: deferred + gated schedule only (SPEC = true)
         else if (!coh && blockIdx.x >= q.baseBlocks) return;
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
     bool found = false;
     uint32_t oct = 0, octinv4 = 0;
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u), tg2 = make_uint2(0u, 0u);
+    uint32_t tgn = 0;   // hybrid node copy: where tg's node lives (its line may hold one of its triangles: k_derive_hybrid)
     // STEAL > 0 (idle lanes needed): once the ray pool is dry, idle lanes take pending subtrees off the lanes that still traverse (ray_split.h)
     __shared__ SplitLds<STEAL ? WG : 1> split;
     int grp = -1;
@@ -185,8 +186,12 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
             if (STATS == 1) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sTriIter++; sTri += __popcll(m); } }
             const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
             tg.y &= ~(1u << ti);
-            const uint32_t ta = tri64 ? (__umulhi(tg.x, 0xAAAAAAABu) >> 1) * 4u + ti * 4u : tg.x + ti * 3u;   // (experiment) records padded to 64 bytes: tg.x counts float4s of the packed array
-            const float4 e2 = tris[ta], e1 = tris[ta + 1], v0 = tris[ta + 2];
+            const float4* tp;
+            if (NSTRIDE == kNodeHybrid)   // the hybrid copy's triangle word: embedded << 27 | first 64-byte record; the embedded triangle sits in the node's own line
+                tp = ti == (tg.x >> 27) ? nodes + ((size_t)tgn + 5u) : tris + ((size_t)(tg.x & 0x07FFFFFFu) + ti) * 4u;
+            else
+                tp = tris + (tri64 ? (size_t)((__umulhi(tg.x, 0xAAAAAAABu) >> 1) + ti) * 4u : (size_t)tg.x + ti * 3u);   // (experiment) records padded to 64 bytes: tg.x counts float4s of the packed array
+            const float4 e2 = tp[0], e1 = tp[1], v0 = tp[2];
             TriHit h;
             if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w)) &&
                 (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), found, hit))) {   // (a split ray's group arbitrates: split_publish)
@@ -215,7 +220,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
                 const CwNodeHits r = cw_test_node(cw_load_node<NSTRIDE>(nodes, ci, hybridK), O, rD, cull_bound(hit.x), octinv4);
                 ng = make_uint2(r.childBase, (r.hitmask & 0xFF000000u) | r.imask);
                 const uint2 nt = make_uint2(r.triBase, r.hitmask & 0x00FFFFFFu);
-                if (tg.y == 0) tg = nt;
+                if (tg.y == 0) { tg = nt; if (NSTRIDE == kNodeHybrid) tgn = cw_hybrid_offset(ci, hybridK); }
                 else tg2 = nt;
             }
         }
@@ -273,22 +278,52 @@ __global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__
 }
 
 // the hybrid node array (cwbvh_node.h: kNodeHybrid) from the packed one: node i goes to position perm[i], its childBaseIndex follows its
-// first child (children stay consecutive in slot order under the priority order)
-__global__ void k_derive_hybrid(const float4* __restrict__ src, const uint32_t* __restrict__ perm, float4* __restrict__ dst, uint32_t nNodes, uint32_t hybridK) {
+// first child (children stay consecutive in slot order under the priority order).  Round 4: a node on a line of its own has 48 spare bytes —
+// exactly one triangle record.  The first triangle of its leaf child with the LARGEST box (the child a ray that visits the node is most likely
+// to hit) is copied there, and the node's triangle word becomes  embedded << 27 | first 64-byte record  (embedded = the triangle's index
+// relative to the node, kNoEmbedded = none): the traversal reads that triangle from the node's own line — fetched a moment ago — instead of a
+// line of the triangle array.  tools/line_model.py (the oracle's mirror on a bounce batch): 32 % of all triangle tests, 2.1 of 36.5 line
+// fetches per ray; nearly all of them lines from beyond the L2s.
+__global__ void k_derive_hybrid(const float4* __restrict__ src, const uint32_t* __restrict__ perm, float4* __restrict__ dst, uint32_t nNodes, uint32_t hybridK,
+                                const float4* __restrict__ tris) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nNodes) return;
     const uint32_t ni = perm ? perm[i] : i;   // (no permutation: trees made on the device are in level order already)
+    if (ni >= nNodes) return;                 // (a blob whose child ranges are not a tree: capi_scene.hip refuses the copies; belt and braces)
     float4* o = dst + ((size_t)ni * 8u - (size_t)(ni < hybridK ? ni : hybridK) * 3u);
     const float4* p = src + (size_t)i * 5u;
+    const float4 n0 = p[0], n2 = p[2], n3 = p[3], n4 = p[4];
     float4 n1 = p[1];
-    if (as_u32(p[0].w) >> 24) { const uint32_t cb = as_u32(n1.x); n1.x = as_f32(cb < nNodes ? (perm ? perm[cb] : cb) : 0u); }
-    o[0] = p[0]; o[1] = n1; o[2] = p[2]; o[3] = p[3]; o[4] = p[4];
+    if (as_u32(n0.w) >> 24) { const uint32_t cb = as_u32(n1.x); n1.x = as_f32(cb < nNodes ? (perm ? perm[cb] : cb) : 0u); }
+    uint32_t emb = kNoEmbedded;
+    if (ni >= hybridK && tris) {
+        const uint32_t ew = as_u32(n0.w);
+        const float sx = ldexpf(1.f, (int)(int8_t)ew), sy = ldexpf(1.f, (int)(int8_t)(ew >> 8)), sz = ldexpf(1.f, (int)(int8_t)(ew >> 16));
+        float best = -1.f;
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t sh = 8u * (j & 3u), hi = j >> 2;
+            const uint32_t meta = ((hi ? as_u32(n1.w) : as_u32(n1.z)) >> sh) & 255u;
+            if (meta == 0u || (meta & 0x18u) == 0x18u) continue;    // empty slot / interior child (0b001sssss, sssss = 24 + slot)
+            const float dx = (float)((int)(((hi ? as_u32(n3.w) : as_u32(n3.z)) >> sh) & 255u) - (int)(((hi ? as_u32(n2.y) : as_u32(n2.x)) >> sh) & 255u)) * sx;
+            const float dy = (float)((int)(((hi ? as_u32(n4.y) : as_u32(n4.x)) >> sh) & 255u) - (int)(((hi ? as_u32(n2.w) : as_u32(n2.z)) >> sh) & 255u)) * sy;
+            const float dz = (float)((int)(((hi ? as_u32(n4.w) : as_u32(n4.z)) >> sh) & 255u) - (int)(((hi ? as_u32(n3.y) : as_u32(n3.x)) >> sh) & 255u)) * sz;
+            const float area = dx * dy + dy * dz + dz * dx;
+            if (area > best) { best = area; emb = meta & 31u; }
+        }
+    }
+    const uint32_t triBase = as_u32(n1.y);
+    if (emb != kNoEmbedded) {
+        const float4* t = tris + (size_t)triBase + (size_t)emb * 3u;
+        o[5] = t[0]; o[6] = t[1]; o[7] = t[2];
+    }
+    n1.y = as_f32((emb << 27) | (triBase / 3u));
+    o[0] = n0; o[1] = n1; o[2] = n2; o[3] = n3; o[4] = n4;
 }
 
 }  // namespace
 
-void launch_cwbvh_derive_hybrid(const float4* src, const uint32_t* perm, float4* dst, uint32_t nNodes, uint32_t hybridK, hipStream_t s) {
-    hipLaunchKernelGGL(k_derive_hybrid, dim3((nNodes + 255u) / 256u), dim3(256), 0, s, src, perm, dst, nNodes, hybridK);
+void launch_cwbvh_derive_hybrid(const float4* src, const uint32_t* perm, float4* dst, uint32_t nNodes, uint32_t hybridK, const float4* tris, hipStream_t s) {
+    hipLaunchKernelGGL(k_derive_hybrid, dim3((nNodes + 255u) / 256u), dim3(256), 0, s, src, perm, dst, nNodes, hybridK, tris);
 }
 
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
@@ -298,13 +333,16 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
         if (anyhit) launch_k<true, __VA_ARGS__>(nodes, tris, q, status, blocks, s);     \
         else launch_k<false, __VA_ARGS__>(nodes, tris, q, status, blocks, s);           \
     } while (0)
-    // diagnostic variants (tbvh_set_variant; tools/ab_probe.py, tests/test_cwbvh_schedules.py): a schedule forced whatever the probe says, and the
-    // instrumented kernels behind the counters of DESIGN.md §5 (profiles/r02_schedule_variants.txt, r02_counters_*.txt)
+    // forced schedules (tbvh_set_variant; tests/test_cwbvh_schedules.py, tools/ab_probe.py): kernels the library ships anyway, picked whatever the
+    // batch size or the probe says
     switch (variant) {
-    case 52: TBVH_K(8, 16, 8, true); return;      // the coherent schedule: deferred triangles, triangle phase once 8 lanes wait
     case 72: TBVH_K(8, 16, 1, false); return;     // the strict schedule
     case 75: TBVH_K(8, 16, 1, false, 0, 5, 0, 16); return;   // strict + split rays whatever the batch size
     case 88: if (blocks > blocks7) blocks = blocks7; if (q.probe) TBVH_K(6, 16, 8, true, 0, 5, 1, 16, 7); else TBVH_K(6, 16, 1, false, 0, 5, 0, 16, 7); return;   // the probed schedule + split rays whatever the batch size
+#ifdef TBVH_EXPERIMENTS
+    // diagnostic kernels, only in the experiment build (make EXPERIMENTS=1 -> libtinybvh_amd_exp.so; TBVH_LIB_OVERRIDE points the tools at it): a schedule
+    // that is not shipped under this template signature, and the instrumented kernels behind the counters of DESIGN.md §5
+    case 52: TBVH_K(8, 16, 8, true); return;      // the coherent schedule without the probe: deferred triangles, triangle phase once 8 lanes wait
     case 89: if (q.probe) TBVH_K(6, 16, 8, true, 0, 5, 1, 16, 8); else break; return;   // round 2's shipped form of the probed schedule + split rays: 64 VGPRs, 20 bytes of scratch per lane
     case 59: if (anyhit) break; launch_k<false, 8, 16, 1, false, 1>(nodes, tris, q, status, blocks, s); return;    // lane statistics of the strict schedule (q.stats)
     case 61: if (anyhit) break; launch_k<false, 8, 16, 8, true, 1>(nodes, tris, q, status, blocks, s); return;     // ... of the coherent schedule
@@ -312,6 +350,7 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     case 78: if (anyhit) break; launch_k<false, 8, 16, 1, false, 2, 5, 0, 16>(nodes, tris, q, status, blocks, s); return;   // ... with split rays
     case 82: if (anyhit) break; launch_k<false, 8, 16, 1, false, 5>(nodes, tris, q, status, blocks, s); return;    // tail statistics, strict schedule
     case 83: if (anyhit) break; launch_k<false, 8, 16, 1, false, 5, 5, 0, 16>(nodes, tris, q, status, blocks, s); return;   // ... with split rays
+#endif
     default: break;
     }
     // with a coherence probe of the batch (capi.hip: launchQuery) the schedule is chosen per launch; without one, the strict schedule.
@@ -327,7 +366,7 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
         if (tail) TBVH_K(8, 16, 1, false, 0, 8, 0, 16);
         else TBVH_K(8, 16, 1, false, 0, 8);
     } else if (nodeStride == kNodeHybrid) {   // the incoherent flavor of a probed launch: `nodes` = the hybrid copy, `tris` = the 64-byte records (cwbvh_node.h, capi.hip)
-        if (tail) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 16);
+        if (tail) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 16, 6);   // (built for 6 waves per SIMD: 80 VGPRs; left alone the compiler takes 83, one wave per SIMD fewer)
         else TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2);
     } else if (q.probe && q.baseBlocks == 0) {   // the coherent flavor of a two-kernel probed launch (capi.hip): no strict path compiled in (camera rays +1.5 %)
         if (tail) { if (blocks > blocks7) blocks = blocks7; TBVH_K(6, 16, 8, true, 0, 5, 3, 16, 7); }
@@ -360,6 +399,11 @@ void launch_cwbvh_pad(const float4* src, float4* dst, uint32_t nNodes, hipStream
     hipLaunchKernelGGL(k_pad_nodes, dim3((nNodes * 8u + 255u) / 256u), dim3(256), 0, s, src, dst, nNodes);
 }
 
-bool cwbvh_variant_valid(int v) { return v == 0 || v == 90 || v == 52 || v == 72 || v == 75 || v == 88 || v == 89 || v == 59 || v == 61 || v == 73 || v == 78 || v == 82 || v == 83; }
+bool cwbvh_variant_valid(int v) {
+#ifdef TBVH_EXPERIMENTS
+    if (v == 52 || v == 89 || v == 59 || v == 61 || v == 73 || v == 78 || v == 82 || v == 83) return true;
+#endif
+    return v == 0 || v == 90 || v == 91 || v == 72 || v == 75 || v == 88;
+}
 
 }  // namespace tbvh

@@ -22,6 +22,30 @@ def shard_range(n_rays: int, rank: int, world: int, align: int = WAVE):
     return min(b * align, n_rays), min(e * align, n_rays)
 
 
+def build_once_load_everywhere(verts, rank: int, world: int, dist, path: str, **build_kw):
+    """The replicated BVH8_CWBVH of an N-process run without N concurrent host builds on one node's cores: rank 0 builds (all cores) and
+    writes the blobs as a BVH8_CWBVH::Save-compatible file (tbvh_cwbvh_file_write), everyone meets at a barrier, ranks 1..N-1 read the file
+    (tbvh_cwbvh_file_read).  Returns a HostBVH on every rank — rank 0's with the BVH2 it was encoded from (what the oracle needs), the others'
+    with the two blobs only — and the seconds this rank spent.  `path` must be visible to all ranks (one node: /tmp)."""
+    import os
+    import time
+    import tinybvh_amd as tb
+    t0 = time.time()
+    host = None
+    if rank == 0:
+        host = tb.HostBVH(verts, tb.LAYOUT_CWBVH, **build_kw)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        host.save_cwbvh(tmp)
+        os.replace(tmp, path)             # the file appears complete or not at all
+    if dist is not None and world > 1:
+        dist.barrier()
+    if rank != 0:
+        host = tb.HostBVH.from_cwbvh_file(path, verts.shape[0] // 3)
+    if dist is not None and world > 1:
+        dist.barrier()                    # everyone has read it: rank 0 may delete it
+    return host, time.time() - t0
+
+
 def max_over_ranks(seconds: float, dist=None, device=None) -> float:
     """MAX of a per-rank elapsed time (the bench contract's timing rule)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

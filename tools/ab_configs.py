@@ -1,7 +1,7 @@
 """Interleaved A/B of run-time configurations of the BVH8_CWBVH kernel on the contract bench's own batches: every round runs every configuration
 once (so clock drift and box-to-box differences hit all of them alike), the report is the MEDIAN over the rounds.
 A configuration is  name=hybridK:flags:variant  with hybridK = keep (the copies made at upload) | -1 (drop the node copy) | all | <n>, flags = tbvh_debug_set_flags bits, variant =
-tbvh_set_variant.
+tbvh_set_variant.  Flag 8 = derive the hybrid copy without embedded triangles (round 4 A/B).
     python tools/ab_configs.py --side 4096 --rounds 7 base=-1:0:0 hy8k=8192:0:0 hy8k_nt=8192:1:0"""
 import argparse
 import os
@@ -45,9 +45,9 @@ def main():
     cur_k = None
     for r in range(a.rounds + 1):
         for name, k, fl, v in cfgs:
-            if k is not None and k != cur_k:
-                sc.set_hybrid(k); cur_k = k
             ctx.set_debug_flags(fl)
+            if k is not None and (k, fl & 8) != cur_k:      # (flag 8: the hybrid copy is derived WITHOUT a triangle in each node's line)
+                sc.set_hybrid(k); cur_k = (k, fl & 8)
             sc.set_variant(v)
             for kind, fn in (("primary", lambda: sc.intersect_device_fresh(d_prim, n, 1e30)), ("diffuse", lambda: sc.intersect_device_fresh(d_diff, n, 1e30)),
                              ("shadow", lambda: sc.occluded_device(d_shad, n, d_occ))):

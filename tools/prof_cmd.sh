@@ -16,7 +16,9 @@ for pass in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
             "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE" \
             "FETCH_SIZE GRBM_GUI_ACTIVE" \
             "WRITE_SIZE GRBM_GUI_ACTIVE" \
-            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" ; do
+            "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_PENDING_STALL_CYCLES_sum" \
+            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" \
+            "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum GRBM_GUI_ACTIVE" ; do
   n=$(echo $pass | tr ' ' '_' | cut -c1-40)
   timeout 240 rocprofv3 --output-format csv --pmc $pass --kernel-trace -d $OUT/pmc_$n -o pmc -- $CMD > $OUT/pmc_$n.log 2>&1
 done
