@@ -430,7 +430,7 @@ def main():
             log(f"[bench] reference-blob step failed: {e!r}")
         if a.layout == tb.LAYOUT_CWBVH:
             try:
-                ref_ocl = reference_opencl_headline(tb, ctx, sc, d_prim, d_diff, n, kern_ms)
+                ref_ocl = reference_opencl_headline(tb, ctx, sc, d_prim, d_diff, n, kern_ms, timed_got, par_stride, ns_par)
             except Exception as e:
                 log(f"[bench] reference OpenCL kernel on the headline batches failed: {e!r}")
                 ref_ocl = {"error": repr(e)[:300]}
@@ -771,7 +771,7 @@ def reference_blob_step(tb, ctx, verts, d_prim, d_diff, n, timed_got, par_stride
     return out
 
 
-def reference_opencl_headline(tb, ctx, sc, d_prim, d_diff, n, kern_ms):
+def reference_opencl_headline(tb, ctx, sc, d_prim, d_diff, n, kern_ms, timed_got, par_stride, ns_par):
     """The reference's OWN kernel for this path — batch_cwbvh (traverse_cwbvh.cl:554-570), compiled by ROCm OpenCL from the source text embedded
     in oracle/_ref/libtinybvh_refocl.so — on the SAME GPU, the SAME BVH8_CWBVH blobs and the SAME 16.7 M-ray primary and diffuse batches the
     metric is quoted on, next to the HIP kernels' timed launches; plus the agreement of the two hit sets (the .cl kernel derives rD with
@@ -784,17 +784,18 @@ def reference_opencl_headline(tb, ctx, sc, d_prim, d_diff, n, kern_ms):
     out = {"ref_kernel": "batch_cwbvh (traverse_cwbvh.cl) through ROCm OpenCL, same blobs, same rays, same GPU", "opencl_device": ocl.device, "rays_per_batch": n}
     tot_ref = tot_hip = 0.0
     for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
-        sc.intersect_device_fresh(d, n, 1e30)          # (other legs have traced other trees into these buffers since the timed loop)
-        mine = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(mine, d)
-        rays = mine.copy(); rays["t"] = 1e30; rays["u"] = 0; rays["v"] = 0; rays["prim"] = 0
+        # the HIP side of the comparison = the strided sample of the records the TIMED launches left (this scene has been refitted to moved
+        # vertices by the device_side_ops leg since; the blobs on the host, which the OpenCL kernel gets, and the rays have not changed)
+        rays = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(rays, d)
+        rays["t"] = 1e30; rays["u"] = 0; rays["v"] = 0; rays["prim"] = 0
         theirs, ref_ms = ocl.run(10, blobs, rays, passes=3)
         del rays
-        cmp_ = compare_hits(mine[: theirs.shape[0]][::16], theirs[::16], rtol=1e-4)
+        cmp_ = compare_hits(timed_got[kind], theirs[::par_stride][:ns_par], rtol=1e-4)
         hip_ms = float(np.mean(kern_ms[kind]))
         out[kind] = {"hip_mrays": n / (hip_ms * 1e-3) / 1e6, "ref_opencl_mrays": theirs.shape[0] / (ref_ms * 1e-3) / 1e6, "ratio": ref_ms / hip_ms,
                      "hitmiss_diff": cmp_["hitmiss"], "prim_diff": cmp_["prim_mismatch"], "rays_compared": cmp_["n"]}
         tot_ref += ref_ms; tot_hip += hip_ms
-        del mine, theirs
+        del theirs
     out["primary_plus_diffuse"] = {"hip_mrays": 2 * n / (tot_hip * 1e-3) / 1e6, "ref_opencl_mrays": 2 * n / (tot_ref * 1e-3) / 1e6, "ratio": tot_ref / tot_hip}
     return out
 
@@ -819,7 +820,7 @@ def hbm_regime(a, log):
     """north_star asks for ">= 50 % HBM roofline on the node-fetch loop"; the bench's own scene (2.83 M triangles: 0.2 GB of tree, 0.44 GB with
     the incoherent-batch copies) is served by the L2s and the 256 MB Infinity Cache to a degree the TCC counters cannot state (they count L2
     misses, whoever serves them).  So the SAME kernels, builder (the library's host SAH builder — the product's default), launches and counters run
-    on two more sizes of the same street generator that bracket it: 1.5 M triangles (0.1 GB: everything beyond the L2s comes from the Infinity
+    on two more sizes of the same street generator that bracket it: 1 M triangles (0.07 GB, 0.16 GB with the copies: everything beyond the L2s comes from the Infinity
     Cache) and 12 M triangles (0.9 GB: mostly from HBM), 4.19 M camera rays and bounce rays (depth 1-3) per launch.  Per scene a child of this
     script times the launches and counts node visits S / triangle tests T per ray with the oracle's mirror; children under `rocprofv3 --pmc`
     give bytes beyond the L2s and the mean latency of an L2 miss (TCC_EA0_RDREQ_LEVEL / TCC_EA0_RDREQ).  The latency separates the two
@@ -833,7 +834,7 @@ def hbm_regime(a, log):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST"):
         env.pop(k, None)
     try:
-        for tag, scene in (("fits_infinity_cache", "street1.5m"), ("beyond_infinity_cache", "street12m")):
+        for tag, scene in (("fits_infinity_cache", "street1m"), ("beyond_infinity_cache", "street12m")):
             b = copy.copy(a)
             b.scene, b.side, b.device_build, b.layout, b.variant = scene, 2048, False, 10, 0
             b.blob_cache = os.path.join(tmpdir, scene + ".cwbvh")
@@ -896,21 +897,27 @@ def live_counters(a, log, passes=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_
             env.pop(k, None)
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200, check=True)
-            per_disp = {}
+            per_disp, names = {}, {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     kn = r["Kernel_Name"]
                     if r["Counter_Name"] in counters and ("k_cwbvh<false" in kn or "k_bvh4_w8<false" in kn or "k_bvh4<false" in kn or "k_bvh2<false" in kn):
                         row = per_disp.setdefault(int(r["Dispatch_Id"]), {})
                         row[r["Counter_Name"]] = row.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                        names[int(r["Dispatch_Id"])] = kn
             ids = sorted(per_disp)
-            # the child makes 9 queries (3 preparing the batches, then (primary, diffuse) x 3); a probed query on a scene with the incoherent-batch
-            # copies is TWO traversal dispatches (the flavor the probe's verdict is not for leaves at once): sum per query
-            per_query = len(ids) // 9
-            if per_query not in (1, 2) or len(ids) != 9 * per_query:
-                raise RuntimeError(f"{len(ids)} traversal dispatches in the {pass_!r} pass, expected 9 or 18")
+            # the child makes 9 queries (3 preparing the batches — smaller ones among them —, then (primary, diffuse) x 3); a probed query on a scene
+            # with the incoherent-batch copies is TWO traversal dispatches back to back — the coherent flavor (PROBED = 3), then the incoherent one
+            # (NSTRIDE = kNodeHybrid = 13, PROBED = 2); the one the probe's verdict is not for leaves at once —: group them into queries
+            queries, i = [], 0
+            while i < len(ids):
+                pair = i + 1 < len(ids) and ", 5, 3, " in names[ids[i]] and ", 13, 2, " in names[ids[i + 1]]
+                queries.append(ids[i:i + 2] if pair else ids[i:i + 1])
+                i += 2 if pair else 1
+            if len(queries) != 9:
+                raise RuntimeError(f"{len(ids)} traversal dispatches in {len(queries)} queries in the {pass_!r} pass, expected 9 queries")
             for cn in counters:
-                vals = [sum(per_disp[ids[q * per_query + j]].get(cn, 0.0) for j in range(per_query)) for q in range(9)][-6:]
+                vals = [sum(per_disp[j].get(cn, 0.0) for j in q) for q in queries][-6:]
                 out["primary"][cn] = (vals[2] + vals[4]) / 2
                 out["diffuse"][cn] = (vals[3] + vals[5]) / 2
             got_any = True

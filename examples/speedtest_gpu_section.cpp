@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <fstream>
+#include <thread>
 #include <vector>
 
 #include "tiny_hip.h"   // the binding a tinybvh maintainer adds (include/tiny_hip.h over the C ABI of tinybvh_amd.h)
@@ -114,6 +115,29 @@ int main(int argc, char** argv) {
         for (unsigned i = 0; i < N; i++) occBad += (occ[i] != 0) != refbvh.IsOccluded(rays[i]);
         printf("  %-12s IsOccluded mismatches %u\n", "BVH8_CWBVH", occBad);
         bad += occBad > 2;
+    }
+    {   // the reference's own flow for animated geometry — move the vertices, BVH::Refit on the host (tiny_bvh.h:3055-3093), BVH_GPU::ConvertFrom
+        // again — handed to the engine IN PLACE (tinyhip::Scene::Update -> tbvh_update_bvh_gpu), and the speedtest's thread loop
+        // (tiny_bvh_speedtest.cpp:1077-1083: 8 threads on one BVH) kept as it is: 4 host threads share the one Scene
+        std::vector<bvhvec4> anim(tris);
+        BVH_GPU g; g.Build(anim.data(), triCount);
+        tinyhip::Scene gpu(g, anim.data());
+        for (auto& v : anim) v.y += 0.04f * ext * sinf(v.x * (5.0f / ext));
+        g.bvh.Refit();
+        g.ConvertFrom(g.bvh, false);
+        gpu.Update(g, anim.data());
+        BVH movedBvh; movedBvh.Build(anim.data(), triCount);
+        Ray* ref2 = (Ray*)malloc64(N * sizeof(Ray));
+        memcpy((void*)ref2, (void*)rays, N * sizeof(Ray));
+        for (unsigned i = 0; i < N; i++) movedBvh.Intersect(ref2[i]);
+        const int T = 4;
+        std::vector<Ray*> mine(T);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) { mine[t] = (Ray*)malloc64(N * sizeof(Ray)); memcpy((void*)mine[t], (void*)rays, N * sizeof(Ray)); }
+        for (int t = 0; t < T; t++) th.emplace_back([&, t] { gpu.Intersect(mine[t], N); });
+        for (auto& x : th) x.join();
+        for (int t = 0; t < T; t++) { bad += validate(t ? "  (thread)" : "host Refit + Update, 4 threads", mine[t], ref2, N); free64(mine[t]); }
+        free64(ref2);
     }
     // ---- beyond the speedtest: the per-frame / build-time host work of a tinybvh user, moved to the GPU -------------
     {   // BVH8_CWBVH::ConvertFrom on the device: tinybvh builds the BVH2 (Build + Compact + SplitLeafs(3), what

@@ -11,6 +11,7 @@
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "tinybvh_amd.h"
@@ -21,25 +22,44 @@ inline void Check(int rc, const char* what) {
     if (rc) { fprintf(stderr, "tinyhip: %s -> %d: %s\n", what, rc, tbvh_last_error()); exit(1); }
 }
 
-// one tbvh_context per HIP device, created on first use (tinyocl::Kernel::InitCL creates its single context the same way, tiny_ocl.h:945-1139)
+// one shared tbvh_context per HIP device, created on first use (tinyocl::Kernel::InitCL creates its single context the same way, tiny_ocl.h:945-1139).
+// Threads: every call of the C ABI takes its context's lock, so host threads may share this context and the Scenes on it the way the
+// reference's callers share a const BVH (tiny_bvh_speedtest.cpp:1077-1083: Intersect from 8 threads) — their calls serialise.  A thread whose
+// queries should OVERLAP with other threads' on the device takes a context of its own: NewContext() + the Scene constructors' last argument.
 inline tbvh_context* Context(int device = 0) {
     static tbvh_context* ctx[64] = {};
+    static std::mutex m;
     if (device < 0 || device >= 64) { fprintf(stderr, "tinyhip: device %d out of range\n", device); exit(1); }
+    std::lock_guard<std::mutex> lk(m);
     if (!ctx[device]) Check(tbvh_init(device, &ctx[device]), "tbvh_init");
     return ctx[device];
+}
+// a context of the caller's own on `device` (its own stream, staging buffers and lock); release with tbvh_shutdown after its Scenes are gone
+inline tbvh_context* NewContext(int device = 0) {
+    tbvh_context* c = nullptr;
+    Check(tbvh_init(device, &c), "tbvh_init");
+    return c;
 }
 inline int DeviceCount() { const int n = tbvh_device_count(); return n < 0 ? 0 : n; }
 
 // One uploaded layout: replaces the Buffer triple + Kernel of a speedtest GPU block.  The blobs are consumed verbatim.
 class Scene {
 public:
-    Scene(const tinybvh::BVH_GPU& b, const tinybvh::bvhvec4* verts, int device = 0) : dev(device) {
-        Check(tbvh_upload_bvh_gpu(Context(dev), b.bvhNode, b.usedNodes, b.bvh.primIdx, b.bvh.idxCount, verts, b.triCount, &s), "tbvh_upload_bvh_gpu");
+    // own: a context from NewContext() for a thread of its own; nullptr = the shared context of the device
+    Scene(const tinybvh::BVH_GPU& b, const tinybvh::bvhvec4* verts, int device = 0, tbvh_context* own = nullptr) : dev(device), ctx(own ? own : Context(device)) {
+        Check(tbvh_upload_bvh_gpu(ctx, b.bvhNode, b.usedNodes, b.bvh.primIdx, b.bvh.idxCount, verts, b.triCount, &s), "tbvh_upload_bvh_gpu");
     }
-    explicit Scene(const tinybvh::BVH4_GPU& b, int device = 0) : dev(device) { Check(tbvh_upload_bvh4_gpu(Context(dev), b.bvh4Data, b.usedBlocks, &s), "tbvh_upload_bvh4_gpu"); }
-    explicit Scene(const tinybvh::BVH8_CWBVH& b, int device = 0) : dev(device) {
-        Check(tbvh_upload_cwbvh(Context(dev), b.bvh8Data, b.usedBlocks, b.bvh8Tris, (uint64_t)b.bvh8.idxCount * 3, &s), "tbvh_upload_cwbvh");
+    explicit Scene(const tinybvh::BVH4_GPU& b, int device = 0, tbvh_context* own = nullptr) : dev(device), ctx(own ? own : Context(device)) {
+        Check(tbvh_upload_bvh4_gpu(ctx, b.bvh4Data, b.usedBlocks, &s), "tbvh_upload_bvh4_gpu");
     }
+    explicit Scene(const tinybvh::BVH8_CWBVH& b, int device = 0, tbvh_context* own = nullptr) : dev(device), ctx(own ? own : Context(device)) {
+        Check(tbvh_upload_cwbvh(ctx, b.bvh8Data, b.usedBlocks, b.bvh8Tris, (uint64_t)b.bvh8.idxCount * 3, &s), "tbvh_upload_cwbvh");
+    }
+    // the reference's flow for animated geometry — bvh.Refit() on the host, X.ConvertFrom( bvh ) again (tiny_bvh.h:3055-3093) — without a new
+    // Scene: the refitted blob goes into the same device memory, TLASes over this BLAS keep working (tbvh_update_*)
+    void Update(const tinybvh::BVH_GPU& b, const tinybvh::bvhvec4* verts) { Check(tbvh_update_bvh_gpu(s, b.bvhNode, b.usedNodes, b.bvh.primIdx, b.bvh.idxCount, verts, b.triCount), "tbvh_update_bvh_gpu"); }
+    void Update(const tinybvh::BVH4_GPU& b) { Check(tbvh_update_bvh4_gpu(s, b.bvh4Data, b.usedBlocks), "tbvh_update_bvh4_gpu"); }
+    void Update(const tinybvh::BVH8_CWBVH& b) { Check(tbvh_update_cwbvh(s, b.bvh8Data, b.usedBlocks, b.bvh8Tris, (uint64_t)b.bvh8.idxCount * 3), "tbvh_update_cwbvh"); }
     Scene(const Scene&) = delete;
     Scene& operator=(const Scene&) = delete;
     ~Scene() { tbvh_free_scene(s); }
@@ -48,14 +68,16 @@ public:
     void Intersect(tinybvh::Ray* rays, size_t n) { Check(tbvh_intersect(s, rays, n, sizeof(tinybvh::Ray)), "tbvh_intersect"); }
     void IsOccluded(const tinybvh::Ray* rays, size_t n, uint8_t* out) { Check(tbvh_occluded(s, rays, n, sizeof(tinybvh::Ray), out), "tbvh_occluded"); }
     // device time of the last launch in ms: the CL_PROFILING_COMMAND_START / END read of tiny_bvh_speedtest.cpp:1126-1131
-    float LastKernelMs() const { return tbvh_time_last_ms(Context(dev)); }
+    float LastKernelMs() const { return tbvh_time_last_ms(ctx); }
     // animated geometry: BVH::Refit + ConvertFrom + upload of the reference flow, on the device
     void Refit(const tinybvh::bvhvec4* verts, size_t triCount) { Check(tbvh_refit(s, verts, triCount, 0), "tbvh_refit"); }
     tbvh_scene* Handle() const { return s; }
     int Device() const { return dev; }
+    tbvh_context* Ctx() const { return ctx; }
 private:
     tbvh_scene* s = nullptr;
     int dev = 0;
+    tbvh_context* ctx = nullptr;
 };
 
 // One host Ray[] over several devices (each holds a Scene of the same BVH): contiguous shards, results in place.
@@ -76,7 +98,7 @@ public:
         uint32_t row = 0;
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t next = (uint32_t)((uint64_t)(H / 4) * (i + 1) / n) * 4;   // bands of whole 4-row tiles
-            tbvh_context* c = Context(scenes[i]->Device());
+            tbvh_context* c = scenes[i]->Ctx();
             tbvh_wavefront* w = nullptr;
             Check(tbvh_wavefront_create(c, W, next - row, &w), "tbvh_wavefront_create");
             Check(tbvh_wavefront_set_band(w, row, H), "tbvh_wavefront_set_band");

@@ -295,7 +295,7 @@ int tbvh_update_bvh_gpu(tbvh_scene* s, const void* nodes64, uint64_t nNodes, con
 
 int tbvh_update_bvh4_gpu(tbvh_scene* s, const void* blocks16, uint64_t nBlocks) {
     if (!s || s->isTlas || s->layout != TBVH_LAYOUT_BVH4_GPU || !blocks16 || nBlocks < 4) return fail(TBVH_E_INVALID, "tbvh_update_bvh4_gpu: not a BVH4_GPU scene or null/empty argument");
-    if (nBlocks > s->capNodeBlocks) return fail(TBVH_E_INVALID, "tbvh_update_bvh4_gpu: %llu blocks, the scene holds %llu: free the scene and upload", (unsigned long long)nBlocks, (unsigned long long)s->capNodeBlocks);
+    if (nBlocks > s->capNodeBlocks) return fail(TBVH_E_INVALID, "tbvh_update_bvh4_gpu: the blob (%llu blocks) is larger than the one uploaded (%llu): free the scene and upload", (unsigned long long)nBlocks, (unsigned long long)s->capNodeBlocks);
     if (const char* why = validate_bvh4_gpu((const Vec4*)blocks16, nBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
