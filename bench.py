@@ -212,7 +212,11 @@ def main():
 
     # the any-hit pass (config "16 M IsOccluded shadow rays") is reported in `detail`; it is not
     # part of the metric's step (primary + diffuse), so it is timed by HIP events only
-    for i in range(a.warmup + a.steps):
+    for i in range(max(a.warmup, 6)):       # (also lets the scene's coherent-schedule tuner settle for any-hit launches: it alternates schedules while it measures)
+        sc.occluded_device(d_shad, n, d_occ)
+        if i % 2:
+            ctx.synchronize()
+    for i in range(a.steps):
         sc.occluded_device(d_shad, n, d_occ)
     ctx.synchronize()
     kern_ms["shadow"] = ctx.time_history(min(a.steps, 128))
@@ -225,8 +229,15 @@ def main():
         shadow_sample = full[::par_stride][:ns_par].copy(); del full
         occ_all = np.zeros(n, np.uint8); ctx.from_device(occ_all, d_occ)
         shadow_occ = occ_all[::par_stride][:ns_par].copy(); del occ_all
-    for _ in range(a.warmup):
+    for i in range(max(a.warmup, 1)):
         step()
+        if i % 2:
+            ctx.synchronize()               # (finished launches are what the coherent-schedule tuner learns from; a renderer's frames end likewise)
+    if a.layout == tb.LAYOUT_CWBVH:
+        for _ in range(6):                  # untimed: make sure the tuner has decided before the timed region, whatever --warmup was
+            if sc.coherent_schedule(False)[0]:
+                break
+            sc.intersect_device_fresh(d_prim, n, 1e30); ctx.synchronize()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -447,6 +458,11 @@ def main():
         # what a step costs beyond its two queries' own HIP-event time (launch latency the stream could not hide, the barrier): the
         # round-3 driver run had 0.42 ms here, from a synchronisation after every launch and a three-launch probed query
         detail["dispatch_gap_ms"] = ms_per_step - (mean["primary"] + mean["diffuse"])
+        if a.layout == tb.LAYOUT_CWBVH:
+            names = {0: "still measuring", 1: "deferred triangles + gated triangle phase on 32 waves per CU", 2: "strict"}
+            detail["coherent_schedule"] = {kind: {"decision": names[t_[0]], "samples": [t_[1], t_[2]], "strict_over_deferred_time_per_ray": t_[3] / 1000.0}
+                                           for kind, t_ in (("closest_hit", sc.coherent_schedule(False)), ("any_hit", sc.coherent_schedule(True)))}
+            detail["coherent_schedule"]["how"] = "measured per scene by the library during the first launches (CohTuner, tinybvh_amd/csrc/capi_internal.h); TBVH_COHERENT_TUNER pins it"
         detail["wavefront_frame_3_bounces"] = wf_detail
         detail["device_side_ops"] = dev_ops
         detail["tlas_1000_instances"] = tlas_detail
@@ -543,6 +559,8 @@ def main():
                 valu_ginstr = ctx.valu_issue_ginstr(3)
             except Exception as e:
                 log(f"[bench] ceiling measurement failed: {e!r}")
+            # (the children run the schedule this process's tuner settled on for coherent batches, pinned: a child is too short to decide for itself)
+            a.coh_pin = {1: "0", 2: "2"}.get(sc.coherent_schedule(False)[0] if a.layout == tb.LAYOUT_CWBVH else 0)
             pm = live_counters(a, log) if (world == 1 and not a.no_pmc) else None
             traffic_src = pm.get("source") if pm else None
             lines = {}
@@ -838,6 +856,8 @@ def hbm_regime(a, log):
             b = copy.copy(a)
             b.scene, b.side, b.device_build, b.layout, b.variant = scene, 2048, False, 10, 0
             b.blob_cache = os.path.join(tmpdir, scene + ".cwbvh")
+            b.coh_pin = "0"          # (timing child and counter children alike: the deferred + gated schedule for coherent batches, the street scenes' choice)
+            env["TBVH_COHERENT_TUNER"] = "0"
             cmd = [sys.executable, os.path.abspath(__file__), "--hbm-child", "--scene", b.scene, "--side", str(b.side), "--layout", "10", "--blob-cache", b.blob_cache]
             try:
                 r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=400, check=True)
@@ -895,6 +915,8 @@ def live_counters(a, log, passes=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_
         env = dict(os.environ, TMPDIR="/tmp")
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST"):
             env.pop(k, None)
+        if getattr(a, "coh_pin", None) is not None:
+            env["TBVH_COHERENT_TUNER"] = a.coh_pin
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200, check=True)
             per_disp, names = {}, {}
@@ -908,10 +930,11 @@ def live_counters(a, log, passes=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_
             ids = sorted(per_disp)
             # the child makes 9 queries (3 preparing the batches — smaller ones among them —, then (primary, diffuse) x 3); a probed query on a scene
             # with the incoherent-batch copies is TWO traversal dispatches back to back — the coherent flavor (PROBED = 3), then the incoherent one
-            # (NSTRIDE = kNodeHybrid = 13, PROBED = 2); the one the probe's verdict is not for leaves at once —: group them into queries
+            # (NSTRIDE = kNodeHybrid = 13, PROBED = 2); the one the probe's verdict is not for leaves at once —: group them into queries (PROBED = 4: the
+            # strict form of the first kernel, while the scene's coherent-schedule tuner is measuring)
             queries, i = [], 0
             while i < len(ids):
-                pair = i + 1 < len(ids) and ", 5, 3, " in names[ids[i]] and ", 13, 2, " in names[ids[i + 1]]
+                pair = i + 1 < len(ids) and (", 5, 3, " in names[ids[i]] or ", 5, 4, " in names[ids[i]]) and ", 13, 2, " in names[ids[i + 1]]
                 queries.append(ids[i:i + 2] if pair else ids[i:i + 1])
                 i += 2 if pair else 1
             if len(queries) != 9:

@@ -318,9 +318,17 @@ int tbvh_cwbvh_set_hybrid(tbvh_scene* scene, int64_t packed_nodes);
 /* Experiment switches for the BVH8_CWBVH kernel of the next launches on this context (development aid; 0 = as shipped):
  * 1 = non-temporal ray loads / hit stores, 2 = the 64-byte triangle records in the ordinary kernels too (only where the scene has them:
  * after tbvh_cwbvh_set_hybrid or the first large launch; ignored otherwise), 4 = a probed launch as ONE kernel even where the copies exist,
- * 8 = the next tbvh_cwbvh_set_hybrid / lazy build derives the node copy WITHOUT a triangle in each node's line, bits 8..15 = waves per CU of
- * the incoherent flavor (clamped to the 32 per CU the stack spill area is sized for). */
+ * 8 = the next tbvh_cwbvh_set_hybrid / lazy build derives the node copy WITHOUT a triangle in each node's line, 64 = no coherence probe (every
+ * launch takes the unprobed path), bits 8..15 = waves per CU of the incoherent flavor (clamped to the 32 per CU the stack spill area is sized for). */
 int tbvh_debug_set_flags(tbvh_context* ctx, uint32_t flags);
+
+/* Which schedule the library has settled on for COHERENT batches of 2 M rays and more on this BVH8_CWBVH scene (closest-hit: anyhit = 0,
+ * any-hit: 1) — the deferred-triangles + gated schedule on a third more waves, or the strict one.  No static property of a blob tells which
+ * is faster (profiles/r04_sensitivity.txt: +1 ... +8 % for the first on most scenes, +10 % for the second on large-occluder scenes), so the
+ * first few such launches alternate and are timed on the device (no synchronisation), then the faster stays (TBVH_COHERENT_TUNER=0 / 2 in
+ * the environment pins the first / the second).  out[0] = 0 still measuring, 1 deferred + gated, 2 strict; out[1], out[2] = coherent samples
+ * taken of each; out[3] = 1000 x best time per ray of the strict schedule / of the deferred one (0 until both have samples). */
+int tbvh_debug_coherent_schedule(tbvh_scene* scene, int anyhit, uint32_t out[4]);
 
 /* The per-launch coherence probe of the most recent query on this context (development aid; DESIGN.md par. 3): out[0] = sampled
  * neighbouring ray pairs whose directions agree, out[1] = pairs sampled, out[2] = 0 no probe ran (small batches, small or very

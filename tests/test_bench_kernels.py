@@ -145,3 +145,63 @@ def test_probed_launches_random_batches(ctx, oracle, tris_m):
     assert any(v == 2 for _, _, v in verdicts) and any(v == 1 for _, _, v in verdicts), verdicts   # both flavors were exercised
     for p in (d_verts, d_a, d_b, d_occ):
         ctx.free(p)
+
+
+def test_both_coherent_schedules_and_the_tuner(oracle):
+    """Coherent batches of a two-flavor launch run the deferred + gated schedule (PROBED == 3) or the strict one (PROBED == 4); which, the library
+    measures per scene (CohTuner).  Both pinned through TBVH_COHERENT_TUNER, with and without split rays, camera and shadow rays: oracle-exact
+    and byte-identical to each other; left alone, the tuner reaches a decision within a handful of launches and keeps it."""
+    import os
+    verts, _ = scenes.get("bistro")
+    side, m_side = 4096, 2048
+    n, m = side * side, m_side * m_side
+    results = {}
+    for pin in ("0", "2", None):
+        if pin is None:
+            os.environ.pop("TBVH_COHERENT_TUNER", None)
+        else:
+            os.environ["TBVH_COHERENT_TUNER"] = pin
+        c = tb.Context(0)
+        os.environ.pop("TBVH_COHERENT_TUNER", None)
+        try:
+            sc = tb.BVH8_CWBVH(c).Build(verts)
+            d_a, d_s, d_occ = c.malloc(n * 64), c.malloc(n * 64), c.malloc(n)
+            before = np.zeros(n, tb.RAY_DTYPE); after = np.zeros(n, tb.RAY_DTYPE)
+            c.generate_primary(R.camera(*scenes.STREET_CAMERAS[0], side, side, 1, 1), d_a, 0, n)
+            c.from_device(before, d_a)
+            sc.intersect_device_fresh(d_a, n, 1e30)
+            assert c.last_probe()[2] == 2
+            c.from_device(after, d_a)
+            sample_check(oracle, sc, verts, before, after, n, f"16.7 M camera rays, tuner pin {pin}")
+            if pin is None:
+                for _ in range(7):
+                    sc.intersect_device_fresh(d_a, n, 1e30)
+                c.synchronize()
+                sc.intersect_device_fresh(d_a, n, 1e30)
+                dec = sc.coherent_schedule(False)
+                assert dec[0] in (1, 2) and dec[1] >= 2 and dec[2] >= 2, dec
+                again = np.zeros(n, tb.RAY_DTYPE); c.from_device(again, d_a)
+                assert np.array_equal(again.view(np.uint8), after.view(np.uint8))
+            else:
+                assert sc.coherent_schedule(False)[0] == (1 if pin == "0" else 2)
+            results[(pin, "camera")] = after[:: n // 65536].copy()
+            ext = float((verts[:, :3].max(0) - verts[:, :3].min(0)).max())
+            c.generate_shadow(d_a, d_s, n, (0.0, 0.9 * float(verts[:, 1].max()), 0.0), ext * 5e-7)
+            sc.occluded_device(d_s, n, d_occ)
+            occ = np.zeros(n, np.uint8); c.from_device(occ, d_occ)
+            results[(pin, "shadow")] = occ[:: n // 65536].copy()
+            # 4.2 M camera rays: the same flavors with split rays
+            c.generate_primary(R.camera(*scenes.STREET_CAMERAS[0], m_side, m_side, 1, 1), d_s, 0, m)
+            c.from_device(before[:m], d_s)
+            sc.intersect_device_fresh(d_s, m, 1e30)
+            c.from_device(after[:m], d_s)
+            sample_check(oracle, sc, verts, before[:m], after[:m], m, f"4.2 M camera rays + split rays, tuner pin {pin}")
+            results[(pin, "camera4m")] = after[:m][:: m // 65536].copy()
+            for p in (d_a, d_s, d_occ):
+                c.free(p)
+            sc.free()
+        finally:
+            c.close()
+    for kind in ("camera", "shadow", "camera4m"):
+        assert np.array_equal(results[("0", kind)].view(np.uint8), results[("2", kind)].view(np.uint8)), kind
+        assert np.array_equal(results[("0", kind)].view(np.uint8), results[(None, kind)].view(np.uint8)), kind

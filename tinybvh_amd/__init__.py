@@ -292,6 +292,12 @@ class _Scene:
             out.append(a)
         return tuple(out)
 
+    def coherent_schedule(self, anyhit: bool = False):
+        """(decision, samples of the deferred schedule, samples of the strict one, 1000 x strict / deferred time per ray): tbvh_debug_coherent_schedule."""
+        out = (C.c_uint32 * 4)()
+        check(lib.tbvh_debug_coherent_schedule(self._h, 1 if anyhit else 0, out), "tbvh_debug_coherent_schedule")
+        return tuple(int(x) for x in out)
+
     def set_variant(self, v: int):
         check(lib.tbvh_set_variant(self._h, v), "tbvh_set_variant")
 

@@ -84,6 +84,7 @@ SYMBOLS = {
     "tbvh_intersect_device_fresh": (_i, [_vp, _vp, _u64, C.c_float]),
     "tbvh_reset_hits_device": (_i, [_vp, _vp, _u64, C.c_float]),
     "tbvh_time_last_ms": (C.c_float, [_vp]),
+    "tbvh_debug_coherent_schedule": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_uint32)]),
     "tbvh_time_history": (C.c_int, [_vp, C.POINTER(C.c_float), C.c_uint32, C.POINTER(C.c_uint32)]),
     "tbvh_measure_copy_bandwidth": (_i, [_vp, _u64, _u32, C.POINTER(C.c_double)]),
     "tbvh_measure_read_bandwidth": (_i, [_vp, _u64, _u32, C.POINTER(C.c_double)]),

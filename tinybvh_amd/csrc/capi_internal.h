@@ -56,6 +56,8 @@ struct tbvh_context {
     static constexpr uint32_t kTimeRing = 256;
     hipEvent_t evRing[kTimeRing][2] = {};
     bool evDone[kTimeRing] = {};
+    hipEvent_t evMid[kTimeRing] = {};   // two-flavor launches while a scene's coherent-schedule tuner is measuring: between the two kernels
+    int cohTunerMode = 0;         // TBVH_COHERENT_TUNER: 0 = measure per scene (default), 1 = always the deferred + gated schedule, 2 = always the strict one
     uint64_t evSeq = 0;           // timed operations begun on this context
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -90,6 +92,20 @@ struct tbvh_context {
     std::vector<tbvh_scene*> scenes;
 };
 
+// Which schedule runs COHERENT batches of a two-flavor launch on this scene: the deferred-triangles + gated schedule on a third more waves
+// (kernels_cwbvh.hip: PROBED == 3; +1 ... +8 % on camera and shadow rays of the street, foliage, soup stand-ins) or the strict one (PROBED == 4; +10 %
+// on camera rays of the atrium generator at 1 M triangles, whose big occluders make every node visited ahead of a pending triangle test wasted work:
+// profiles/r04_sensitivity.txt).  No static property of a blob told the two apart, so the library measures: while undecided the launches alternate
+// between the two, an event between the two kernels times the first one, and after two coherent samples of each the faster (by 3 %) stays.
+struct CohTuner {
+    int decided = 0;                    // 0 measuring, 1 deferred + gated, 2 strict
+    uint32_t launches = 0;
+    uint32_t n[2] = {0, 0};             // coherent-verdict samples per schedule
+    float best[2] = {1e30f, 1e30f};     // ns per ray of the first kernel: best sample per schedule
+    struct Pending { uint64_t seq; int mode; uint64_t rays; };
+    std::vector<Pending> pending;
+};
+
 struct tbvh_scene {
     tbvh_context* ctx = nullptr;
     int layout = 0;
@@ -101,6 +117,7 @@ struct tbvh_scene {
     uint32_t* hyPerm = nullptr; // device: position of node i in nodesHy
     float4* tris64 = nullptr;   // CWBVH (experiment flag 2): triangle records padded to 64 bytes
     uint32_t hybridK = 0;
+    CohTuner cohTuner[2];       // [any-hit]
     bool hyTried = false;       // the incoherent-batch copies were built, or found impossible / unwanted: launchQuery does not try again
     bool hyLevelOrder = false;  // the node array is in level order (made on the device): the hybrid copy needs no renumbering
     uint32_t nNodes = 0;

@@ -132,7 +132,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     uint64_t want = (n + perBlock - 1) / perBlock;
     const uint32_t lo = (uint32_t)c->numCUs * 4u;
     uint32_t blocks = (uint32_t)(want < lo ? lo : (want > cap ? cap : want));
-    const bool probed = !s->isTlas && !small && blobBytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || s->variant == 88);
+    const bool probed = !s->isTlas && !small && blobBytes <= (384ull << 20) && s->layout == TBVH_LAYOUT_CWBVH && n >= (1ull << 21) && (s->variant == 0 || s->variant == 88) && !(c->expFlags & 64u);
     if (probed && !s->hyTried) { if (int r = prepareIncoherentCopies(s)) return r; }   // first launch of this class on the scene: the derived copies for incoherent batches (not part of the query's time)
     q.hybridK = s->hybridK;
     HIP_TRY(timedBegin(c));
@@ -212,8 +212,37 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             else if (twoFlavors) {
                 QueryArgs qa = q;
                 qa.baseBlocks = 0;   // every wave of the coherent flavor leaves unless the batch is coherent
-                launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, blocks, c->stream, 5, small, blocks7);
+                // which schedule serves a coherent batch on this scene is measured, not assumed (CohTuner, capi_internal.h)
+                CohTuner& tu = s->cohTuner[any ? 1 : 0];
+                const uint32_t slot = (uint32_t)((c->evSeq - 1) % tbvh_context::kTimeRing);   // this query's event pair (timedBegin above)
+                if (!tu.decided && !c->cohTunerMode) {
+                    for (size_t k = 0; k < tu.pending.size();) {   // harvest the launches that have finished since
+                        const CohTuner::Pending pe = tu.pending[k];
+                        const uint32_t ps = (uint32_t)((pe.seq - 1) % tbvh_context::kTimeRing);
+                        bool drop = c->evSeq - pe.seq >= tbvh_context::kTimeRing || !c->evDone[ps];
+                        if (!drop && hipEventQuery(c->evRing[ps][1]) == hipSuccess) {
+                            float t1 = 0.f;
+                            if (hipEventElapsedTime(&t1, c->evRing[ps][0], c->evMid[ps]) == hipSuccess && t1 > 0.05f) {   // (an incoherent batch: the first kernel left after a few us)
+                                const float perRay = t1 * 1e6f / (float)pe.rays;
+                                tu.n[pe.mode - 1]++;
+                                if (perRay < tu.best[pe.mode - 1]) tu.best[pe.mode - 1] = perRay;
+                            }
+                            drop = true;
+                        } else (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+                        if (drop) tu.pending.erase(tu.pending.begin() + k); else k++;
+                    }
+                    if (tu.n[0] >= 2 && tu.n[1] >= 2) { tu.decided = tu.best[1] < 0.97f * tu.best[0] ? 2 : 1; tu.pending.clear(); }
+                }
+                const int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : (nDev ? 1 : 1 + (int)(tu.launches & 1u));
+                tu.launches++;
+                if (mode == 2) qa.flags |= 32u;
+                launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, mode == 2 ? blocksBase : blocks, c->stream, 5, small, blocks7);
                 HIP_TRY(hipGetLastError());
+                if (!tu.decided && !c->cohTunerMode && !nDev && tu.pending.size() < 16) {
+                    if (!c->evMid[slot]) HIP_TRY(hipEventCreate(&c->evMid[slot]));
+                    HIP_TRY(hipEventRecord(c->evMid[slot], c->stream));
+                    tu.pending.push_back(CohTuner::Pending{c->evSeq, mode, n});
+                }
                 QueryArgs qb = q;
                 // the incoherent flavor on 28 one-wave workgroups per CU when the batch fills the grid (24 is the persistent grid's size: 20 / 26 / 28 / 30 /
                 // 32 per CU trace bounce rays at -4.4 / +0.6 / +0.9 / +0.5 / +0.5 %, interleaved medians of 13 rounds)

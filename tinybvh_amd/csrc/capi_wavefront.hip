@@ -166,18 +166,25 @@ int tbvh_wavefront_render_sharded(tbvh_wavefront* const* wfs, tbvh_scene* const*
         for (uint32_t k = 0; k < i; k++) if (wfs[k]->ctx == wfs[i]->ctx) return fail(TBVH_E_INVALID, "tbvh_wavefront_render_sharded: bands %u and %u share a context", k, i);
     }
     if (row != cam->height) return fail(TBVH_E_INVALID, "tbvh_wavefront_render_sharded: the bands cover %u of %u rows", row, cam->height);
-    for (uint32_t i = 0; i < nDev; i++) {
+    // enqueue every band; after a failure stop enqueueing, but still wait for everything that WAS enqueued (the caller — tinyhip::PathTracer,
+    // Python — may free or reuse accumulators and vertex buffers as soon as this returns) and report the first error
+    int rc = 0;
+    std::string firstErr;
+    uint32_t launched = 0;
+    for (; launched < nDev && !rc; launched++) {
+        const uint32_t i = launched;
         const auto t0 = std::chrono::steady_clock::now();
-        if (int r = tbvh_wavefront_render(wfs[i], scenes[i], dVerts ? dVerts[i] : nullptr, cam, p, nullptr)) return r;
+        rc = tbvh_wavefront_render(wfs[i], scenes[i], dVerts ? dVerts[i] : nullptr, cam, p, nullptr);
+        if (rc) firstErr = tbvh_last_error();
         if (dispatchMs) dispatchMs[i] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
-    for (uint32_t i = 0; i < nDev; i++) {
+    auto finish = [&](uint32_t i) -> int {
         tbvh_wavefront* w = wfs[i];
         tbvh_context* c = w->ctx;
         TBVH_ENTER(c);
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (int r = checkStatus(c)) return r;
-        if (stats) {
+        if (stats && !rc) {
             const uint32_t maxDepth = p->max_depth ? (p->max_depth > 8 ? 8 : p->max_depth) : 3;
             std::vector<unsigned long long> h(kWfCounterWords);
             HIP_TRY(hipMemcpy(h.data(), w->counters, (size_t)kWfCounterWords * 8, hipMemcpyDeviceToHost));
@@ -185,7 +192,13 @@ int tbvh_wavefront_render_sharded(tbvh_wavefront* const* wfs, tbvh_scene* const*
             for (uint32_t d = 0; d < maxDepth; d++) { stats[i].extend_rays[d] = h[32u * d]; stats[i].shadow_rays[d] = h[32u * (9u + d)]; }
             HIP_TRY(hipEventElapsedTime(&stats[i].frame_ms, w->e0, w->e1));
         }
+        return 0;
+    };
+    for (uint32_t i = 0; i < launched; i++) {
+        const int r = finish(i);
+        if (r && !rc) { rc = r; firstErr = tbvh_last_error(); }
     }
+    if (rc) return fail(rc, "tbvh_wavefront_render_sharded: %s", firstErr.c_str());
     return 0;
 }
 

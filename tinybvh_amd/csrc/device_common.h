@@ -127,7 +127,7 @@ struct QueryArgs {
     // baseBlocks: workgroups beyond this index only take part when the batch is coherent.
     uint32_t* probe;
     uint32_t baseBlocks;
-    uint32_t flags;        // 1 = non-temporal ray loads / hit stores, 2 = triangle records padded to 64 bytes (experiments); 16 = take the batch for coherent whatever the probe finds (variant 91)
+    uint32_t flags;        // 1 = non-temporal ray loads / hit stores, 2 = triangle records padded to 64 bytes (experiments); 16 = take the batch for coherent whatever the probe finds (variant 91); 32 = the first kernel of a two-flavor launch runs the strict schedule (PROBED == 4)
     uint32_t hybridK;      // BVH8_CWBVH, hybrid node array (cwbvh_node.h: kNodeHybrid): nodes below this index are packed, the others one per line
 };
 

@@ -88,7 +88,8 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
         }
         coh = (pairs != 0 && agree * 10u >= pairs * 6u) || (q.flags & 16u) != 0;   // (flag 16: tbvh_set_variant 91 forces the coherent verdict — tests)
         if (PROBED == 2) { if (coh) return; }
-        else if (PROBED == 3) { if (!coh) return; }   // the coherent flavor of a two-kernel launch: deferred + gated schedule only (SPEC = true)
+        else if (PROBED == 3 || PROBED == 4) { if (!coh) return; }   // the coherent flavor of a two-kernel launch: 3 = deferred + gated schedule only (SPEC = true); 4 = the strict
+                                                                     // schedule for coherent batches too (scenes where deferral loses: the per-scene tuner of capi_query.hip picks)
         else if (!coh && blockIdx.x >= q.baseBlocks) return;
     }
     const uint32_t hybridK = q.hybridK;
@@ -368,6 +369,9 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
     } else if (nodeStride == kNodeHybrid) {   // the incoherent flavor of a probed launch: `nodes` = the hybrid copy, `tris` = the 64-byte records (cwbvh_node.h, capi.hip)
         if (tail) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 16, 6);   // (built for 6 waves per SIMD: 80 VGPRs; left alone the compiler takes 83, one wave per SIMD fewer)
         else TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2);
+    } else if (q.probe && q.baseBlocks == 0 && (q.flags & 32u)) {   // ... and the same slot of a two-kernel launch with the STRICT schedule (PROBED == 4): coherent batches of
+        if (tail) TBVH_K(8, 16, 1, false, 0, 5, 4, 16);              // scenes on which the deferred schedule measured slower (the online tuner of capi_query.hip)
+        else TBVH_K(8, 16, 1, false, 0, 5, 4);
     } else if (q.probe && q.baseBlocks == 0) {   // the coherent flavor of a two-kernel probed launch (capi.hip): no strict path compiled in (camera rays +1.5 %)
         if (tail) { if (blocks > blocks7) blocks = blocks7; TBVH_K(6, 16, 8, true, 0, 5, 3, 16, 7); }
         else TBVH_K(8, 16, 8, true, 0, 5, 3);

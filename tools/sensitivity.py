@@ -13,7 +13,9 @@ heuristic is OFF (positive = the default loses there).
                 atrium1m     the Sponza stand-in generator at 1 M triangles (the `small` / probed boundary class by size: ~70 MB)
                 street12m    the street generator at 12 M triangles (0.9 GB: beyond the probed size class, padded nodes)
     heuristics  copies       the incoherent-batch copies + two-flavor launch (TBVH_INCOHERENT_COPIES=0 turns them off)
-                probe        the per-launch coherence probe / coherent schedule on 32 waves per CU (off: tbvh_set_variant 72, the strict kernel)
+                probe        the per-launch coherence probe and what hangs on it: two flavors, the coherent schedule (off: debug flag 64, every launch unprobed)
+                coh. schedule  which schedule serves coherent batches: the library measures per scene (CohTuner) — shown: pinned to the deferred + gated one
+                             (TBVH_COHERENT_TUNER=0) and to the strict one (=2), and what the tuner decided
                 split        split rays at the end of a launch below 12 M rays (TBVH_SPLIT_RAYS=0)
                 waves28      28 instead of 24 waves per CU for the incoherent flavor (off: 24)
                 hybridK      first 8192 nodes packed (alternatives: 0 = all padded, all = all packed)
@@ -79,7 +81,8 @@ def main():
     ap.add_argument("--sizes", default="1024,2048,4096")
     a = ap.parse_args()
     sizes = [int(x) for x in a.sizes.split(",")]
-    envs = {"base": {}, "copies_off": {"TBVH_INCOHERENT_COPIES": "0"}, "split_off": {"TBVH_SPLIT_RAYS": "0"}}
+    envs = {"base": {}, "copies_off": {"TBVH_INCOHERENT_COPIES": "0"}, "split_off": {"TBVH_SPLIT_RAYS": "0"}, "coh_deferred": {"TBVH_COHERENT_TUNER": "0"}, "coh_strict": {"TBVH_COHERENT_TUNER": "2"}}
+    knobs = ("TBVH_INCOHERENT_COPIES", "TBVH_SPLIT_RAYS", "TBVH_COHERENT_TUNER")
     for sname in a.scenes.split(","):
         t0 = time.time()
         verts, (eye, view) = make_scene(sname)
@@ -89,12 +92,12 @@ def main():
         print(f"== {sname}: {verts.shape[0] // 3} triangles, {mb:.0f} MB of CWBVH blobs (generated + built in {time.time() - t0:.1f}s)", flush=True)
         ctxs, scs = {}, {}
         for en, ev in envs.items():
-            for k in ("TBVH_INCOHERENT_COPIES", "TBVH_SPLIT_RAYS"):
+            for k in knobs:
                 os.environ.pop(k, None)
             os.environ.update(ev)
             ctxs[en] = tb.Context(0)
             scs[en] = tb.BVH8_CWBVH(ctxs[en]).Upload(nodes, tris)
-        for k in ("TBVH_INCOHERENT_COPIES", "TBVH_SPLIT_RAYS"):
+        for k in knobs:
             os.environ.pop(k, None)
         c0 = ctxs["base"]
         in_size_class = 48e6 <= mb <= 384e6 / 1.0 if False else (48 <= mb <= 384)
@@ -122,12 +125,22 @@ def main():
             chk = np.zeros(min(n, 1 << 18), tb.RAY_DTYPE); c0.from_device(chk, d_p)
             hit_frac = float((chk["t"] < 1e30).mean())
             # configurations: (name, context key, scene object, variant, flags)
-            cfgs = [("default", "base", scs["base"], 0, 0), ("copies off", "copies_off", scs["copies_off"], 0, 0), ("probe off", "base", scs["base"], 72, 0),
+            if n >= (1 << 21) and in_size_class and scs["base"].coherent_schedule(False)[0] == 0:
+                for _ in range(6):          # let the tuner of the default scene settle before anything is timed (it alternates schedules while it measures)
+                    scs["base"].intersect_device_fresh(d_p, n, 1e30); scs["base"].occluded_device(d_s, n, d_occ)
+                c0.synchronize()
+                for _ in range(2):
+                    scs["base"].intersect_device_fresh(d_p, n, 1e30); scs["base"].occluded_device(d_s, n, d_occ)
+                c0.synchronize()
+                print(f"        [coherent-schedule tuner on this scene: closest-hit {scs['base'].coherent_schedule(False)}, any-hit {scs['base'].coherent_schedule(True)}  (decision 1 = deferred + gated, 2 = strict; samples; 1000 x strict / deferred)]", flush=True)
+            cfgs = [("default", "base", scs["base"], 0, 0), ("copies off", "copies_off", scs["copies_off"], 0, 0), ("probe off", "base", scs["base"], 0, 64),
                     ("split off", "split_off", scs["split_off"], 0, 0), ("24 waves", "base", scs["base"], 0, 24 << 8)]
+            if in_size_class:
+                cfgs += [("coh deferred", "coh_deferred", scs["coh_deferred"], 0, 0), ("coh strict", "coh_strict", scs["coh_strict"], 0, 0)]
             cfgs += [(nm.replace("_", " "), "base", s_, 0, 0) for nm, s_ in alt.items()]
             ms = {c[0]: {"camera": [], "bounce": [], "shadow": []} for c in cfgs}
             for r in range(a.rounds + 1):
-                for nm, ck, sc, var, fl in cfgs:
+                for nm, ck, sc, var, fl in cfgs[r % len(cfgs):] + cfgs[:r % len(cfgs)]:      # (the order rotates: whoever runs first in a round sees another clock)
                     cx = ctxs[ck]
                     cx.set_debug_flags(fl); sc.set_variant(var)
                     for kind, fn in (("camera", lambda: sc.intersect_device_fresh(d_p, n, 1e30)), ("bounce", lambda: sc.intersect_device_fresh(d_b, n, 1e30)),
