@@ -128,3 +128,20 @@ def test_update_cwbvh_keeps_the_incoherent_copies_current(ctx, oracle):
     assert sc.device_bytes < (nodes.nbytes + tris.nbytes) * 1.1       # another tree: the copies went
     _check(sc, oracle, h3, h3.verts, rays, "updated, another tree")
     sc.free()
+
+
+def test_time_history_reads_every_launch_once(ctx):
+    """tbvh_time_history: launches enqueued back to back, their HIP-event durations read once afterwards (what bench.py's timed loop does)."""
+    verts = scenes.soup(20_000, seed=2)
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    rays = R.random_rays(200_000, (0, 0, 0), (10, 10, 10), seed=1)
+    d = ctx.malloc(rays.nbytes); ctx.to_device(d, rays)
+    sizes = [200_000, 50_000, 200_000, 10_000, 120_000]
+    for m in sizes:
+        sc.intersect_device_fresh(d, m, 1e30)
+    h = ctx.time_history(len(sizes))
+    assert len(h) == len(sizes) and all(t > 0 for t in h), h
+    assert abs(h[-1] - ctx.time_last_ms()) < 1e-6
+    assert h[3] < h[0]                                   # 10 k rays take less than 200 k
+    assert len(ctx.time_history(1000)) <= 256            # the ring remembers 256 operations
+    ctx.free(d); sc.free()
