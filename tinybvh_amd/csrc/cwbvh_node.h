@@ -20,8 +20,9 @@ __device__ __forceinline__ float cw_fmin3(float a, float b, float c) { return __
 __device__ __forceinline__ float cw_fmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
 __device__ __forceinline__ uint32_t cw_sext_s8x4(uint32_t i) {
-    // every byte with its top bit set becomes 0xff, others 0x00
-    return ((i >> 7) & 0x01010101u) * 0xffu;
+    // every byte with its top bit set becomes 0xff, others 0x00  (x * 255 as (x << 8) - x: v_mul_lo_u32 is a quarter-rate instruction)
+    const uint32_t b = (i >> 7) & 0x01010101u;
+    return (b << 8) - b;
 }
 
 struct CwNode { float4 n0, n1, n2, n3, n4; };   // one node as fetched
