@@ -121,3 +121,55 @@ def test_random_tlas_configuration(ctx, oracle, seed):
     check(tlas.Intersect(rays.copy()), want)
     occ = tlas.IsOccluded(rays.copy())
     assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+
+
+@pytest.mark.parametrize("seed", range(max(N_SEEDS // 2, 1)))
+def test_random_hybrid_copy_configuration(ctx, oracle, seed):
+    """The placement incoherent batches of large scenes are traced on — priority-ordered node copy with a random split between packed and one-per-line
+    nodes, one triangle embedded in every padded node's line, 64-byte triangle records — forced onto SMALL random scenes (tbvh_cwbvh_set_hybrid +
+    variant 90), where the oracle is cheap: trees of the library's builder in both collapse flavours, of the device builders (level order: no
+    renumbering), and leaves of up to three triangles (the embedded triangle is then the first of a multi-triangle leaf); ragged batch sizes,
+    infinite and finite ranges, closest-hit and any-hit; a refit to moved vertices and an in-place tbvh_update_cwbvh keep the copies current."""
+    rng = np.random.default_rng(9000 + seed)
+    verts = make_scene(rng)
+    opts = {}
+    if rng.random() < 0.4:
+        opts["greedy_collapse"] = True
+    if rng.random() < 0.4:
+        opts["max_leaf_tris"] = int(rng.choice([2, 3]))
+    on_device = rng.random() < 0.25
+    if on_device:
+        sc = tb.BVH8_CWBVH(ctx).BuildOnDevice(verts, max_leaf_tris=int(rng.choice([0, 3])))
+        host = tb.HostBVH(verts, tb.LAYOUT_CWBVH)
+    else:
+        sc = tb.BVH8_CWBVH(ctx).Build(verts, **opts)
+        host = sc.host
+    n_nodes = sc.download_blobs()[0].shape[0] // 5
+    sc.set_hybrid(int(rng.choice([0, 8, 64, max(n_nodes // 2, 8), 10**9])))
+    sc.set_variant(90)
+    lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+    pad = 0.1 * (hi - lo) + 0.01
+    n = int(rng.choice([1, 63, 65, 129, 4097, 20000, 33333]))
+    tmax = np.float32(rng.choice([1e30, float(np.linalg.norm(hi - lo)) * 0.3]))
+    rays = R.random_rays(n, lo - pad, hi + pad, seed=int(rng.integers(1, 1 << 20)), tmax=tmax)
+
+    def check_against(h, v, what):
+        want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), v, rays)
+        c = compare_hits(sc.Intersect(rays.copy()), want, rtol=1e-5)
+        assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] == 0, (seed, what, opts, on_device, n, float(tmax), c)
+        assert c["bit_identical"] == c["same_prim"], (seed, what, c)
+        hit = (want["prim"] != rays["prim"]) | (want["t"] != rays["t"])
+        occ = sc.IsOccluded(rays.copy())
+        assert int((occ.astype(bool) != hit).sum()) <= max(2, n // 2000), (seed, what, n, float(tmax))
+
+    check_against(host, verts, "as placed")
+    moved = verts.copy(); moved[:, 2] += np.float32(0.03 * float((hi - lo).max())) * np.sin(verts[:, 0] * 3).astype(np.float32)
+    h2 = tb.HostBVH(moved, tb.LAYOUT_BVH2_WALD)
+    sc.Refit(moved)
+    check_against(h2, moved, "refitted")
+    if rng.random() < 0.5:       # hand the refitted blob back through the in-place update (same shape: the copies are re-derived on the device)
+        nodes, tris = sc.download_blobs()
+        sc.Refit(verts)
+        sc.Update(nodes, tris)
+        check_against(h2, moved, "updated in place")
+    sc.free()
