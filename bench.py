@@ -889,6 +889,19 @@ def hbm_regime(a, log):
     return res
 
 
+def group_dispatches_into_queries(ids, names):
+    """Traversal dispatches (ids in launch order, names[id] = kernel name) -> queries.  A probed query on a scene with the incoherent-batch copies is
+    TWO dispatches back to back: the first kernel — the coherent flavor, `k_cwbvh<..., NSTRIDE 5, PROBED 3, ...>`, or its strict form `PROBED 4` while
+    the scene's coherent-schedule tuner is still measuring — then the incoherent flavor (`NSTRIDE 13 = kNodeHybrid, PROBED 2`); every other query
+    is one dispatch."""
+    queries, i = [], 0
+    while i < len(ids):
+        pair = i + 1 < len(ids) and (", 5, 3, " in names[ids[i]] or ", 5, 4, " in names[ids[i]]) and ", 13, 2, " in names[ids[i + 1]]
+        queries.append(ids[i:i + 2] if pair else ids[i:i + 1])
+        i += 2 if pair else 1
+    return queries
+
+
 def live_counters(a, log, passes=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES", "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum")):
     """Hardware counters of the two timed kernels, measured now: this script is run again as a short child (--pmc-child: same scene, same
     batches, three (primary, diffuse) launch pairs) under `rocprofv3 --pmc <pass>` once per pass (TCC counters do not fit one pass; --kernel-trace
@@ -932,11 +945,7 @@ def live_counters(a, log, passes=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_
             # with the incoherent-batch copies is TWO traversal dispatches back to back — the coherent flavor (PROBED = 3), then the incoherent one
             # (NSTRIDE = kNodeHybrid = 13, PROBED = 2); the one the probe's verdict is not for leaves at once —: group them into queries (PROBED = 4: the
             # strict form of the first kernel, while the scene's coherent-schedule tuner is measuring)
-            queries, i = [], 0
-            while i < len(ids):
-                pair = i + 1 < len(ids) and (", 5, 3, " in names[ids[i]] or ", 5, 4, " in names[ids[i]]) and ", 13, 2, " in names[ids[i + 1]]
-                queries.append(ids[i:i + 2] if pair else ids[i:i + 1])
-                i += 2 if pair else 1
+            queries = group_dispatches_into_queries(ids, names)
             if len(queries) != 9:
                 raise RuntimeError(f"{len(ids)} traversal dispatches in {len(queries)} queries in the {pass_!r} pass, expected 9 queries")
             for cn in counters:
