@@ -36,10 +36,13 @@ constexpr int kNodeHybrid = 13;
 // ... and in the hybrid copy the triangle word of a node is  embedded << 27 | first 64-byte triangle record  (kernels_cwbvh.hip: k_derive_hybrid):
 // the node's triangle number `embedded` (kNoEmbedded: none) is ALSO stored in float4s 5..7 of the node's own line.
 constexpr uint32_t kNoEmbedded = 31u;
-__device__ __forceinline__ uint32_t cw_hybrid_offset(uint32_t nodeIdx, uint32_t hybridK) { return nodeIdx * 8u - (nodeIdx < hybridK ? nodeIdx : hybridK) * 3u; }   // in float4s
+__device__ __forceinline__ uint32_t cw_hybrid_offset(uint32_t nodeIdx, uint32_t hybridK) {   // in float4s: 8 i - 3 min(i, K), as shifts and adds (v_mul_lo_u32 is quarter rate)
+    const uint32_t m = nodeIdx < hybridK ? nodeIdx : hybridK;
+    return (nodeIdx << 3) - ((m << 1) + m);
+}
 template <int NSTRIDE = 5>
 __device__ __forceinline__ CwNode cw_load_node(const float4* __restrict__ nodes, uint32_t nodeIdx, uint32_t hybridK = 0u) {
-    const size_t off = NSTRIDE == kNodeHybrid ? (size_t)nodeIdx * 8u - (size_t)(nodeIdx < hybridK ? nodeIdx : hybridK) * 3u : (size_t)nodeIdx * (uint32_t)NSTRIDE;
+    const size_t off = NSTRIDE == kNodeHybrid ? (size_t)cw_hybrid_offset(nodeIdx, hybridK) : (size_t)nodeIdx * (uint32_t)NSTRIDE;   // (the hybrid copy is only built below 2^32 float4s: capi_scene.hip)
     const float4* np = nodes + off;
     return CwNode{np[0], np[1], np[2], np[3], np[4]};
 }
