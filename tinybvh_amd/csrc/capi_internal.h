@@ -100,6 +100,7 @@ struct tbvh_context {
 struct CohTuner {
     int decided = 0;                    // 0 measuring, 1 deferred + gated, 2 strict
     uint32_t launches = 0;
+    uint64_t refRays = 0;               // size of the first coherent batch sampled: only batches within 3/4 ... 4/3 of it are compared
     uint32_t n[2] = {0, 0};             // coherent-verdict samples per schedule
     float best[2] = {1e30f, 1e30f};     // ns per ray of the first kernel: best sample per schedule
     struct Pending { uint64_t seq; int mode; uint64_t rays; };

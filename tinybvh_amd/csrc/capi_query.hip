@@ -223,15 +223,20 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                         if (!drop && hipEventQuery(c->evRing[ps][1]) == hipSuccess) {
                             float t1 = 0.f;
                             if (hipEventElapsedTime(&t1, c->evRing[ps][0], c->evMid[ps]) == hipSuccess && t1 > 0.05f) {   // (an incoherent batch: the first kernel left after a few us)
-                                const float perRay = t1 * 1e6f / (float)pe.rays;
-                                tu.n[pe.mode - 1]++;
-                                if (perRay < tu.best[pe.mode - 1]) tu.best[pe.mode - 1] = perRay;
+                                // time per ray depends on the batch size (the tail of a launch): only batches of about one size are compared
+                                if (!tu.refRays) tu.refRays = pe.rays;
+                                if (pe.rays * 4 >= tu.refRays * 3 && pe.rays * 3 <= tu.refRays * 4) {
+                                    const float perRay = t1 * 1e6f / (float)pe.rays;
+                                    tu.n[pe.mode - 1]++;
+                                    if (perRay < tu.best[pe.mode - 1]) tu.best[pe.mode - 1] = perRay;
+                                }
                             }
                             drop = true;
                         } else (void)hipGetLastError();   // (hipErrorNotReady is not an error)
                         if (drop) tu.pending.erase(tu.pending.begin() + k); else k++;
                     }
                     if (tu.n[0] >= 2 && tu.n[1] >= 2) { tu.decided = tu.best[1] < 0.97f * tu.best[0] ? 2 : 1; tu.pending.clear(); }
+                    else if (tu.launches >= 64) { tu.decided = 1; tu.pending.clear(); }   // batches too varied to compare: the schedule that wins on most scenes
                 }
                 const int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : (nDev ? 1 : 1 + (int)(tu.launches & 1u));
                 tu.launches++;
