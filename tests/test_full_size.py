@@ -154,3 +154,37 @@ def test_config5_tlas_against_the_real_reference(ctx, reference):
     _real_reference_clean(c2, "config 5 random rays")
     print("config 5 differences from the real IntersectTLAS:", {k: (v["tie_equal_t"], v["closer_by_ulps"], v["max_ulps"]) for k, v in (("camera", c), ("random", c2))})
     ctx.free(d); tlas.free(); blas.free()
+
+
+@pytest.mark.parametrize("layout", [tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU])
+def test_other_layouts_16m_against_the_real_reference(ctx, reference, layout):
+    """The same pin for the two other layouts at BASELINE scale: blobs the REAL tiny_bvh.h encoded (BVH_GPU / BVH4_GPU ::Build of the 2.83 M-triangle
+    scene), 16.7 M camera and 16.7 M bounce rays on the GPU, a strided 65 k sample of each against the real BVH::Intersect under its own tie rule."""
+    verts, _ = scenes.get("bistro")
+    side = 4096
+    n = side * side
+    rs = reference.build(verts, hq=False, threaded=True)
+    if layout == tb.LAYOUT_BVH_GPU:
+        sc = tb.BVH_GPU(ctx).Upload(rs.blob(5, 0, np.uint32, 16), rs.blob(5, 1, np.uint32, 1), verts)
+    else:
+        sc = tb.BVH4_GPU(ctx).Upload(rs.blob(8, 0, np.uint32, 4))
+    d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
+    d_p, d_b = ctx.malloc(n * 64), ctx.malloc(n * 64)
+    ctx.generate_primary(R.camera(*scenes.STREET_CAMERAS[2], side, side, 1, 1), d_p, 0, n)
+    sc.intersect_device(d_p, n)
+    ctx.generate_bounce(d_verts, d_p, d_b, n, 1717)
+    idx = np.arange(0, n, n // 65536)[:65536]
+    full = np.zeros(n, tb.RAY_DTYPE)
+    for kind, d in (("camera", d_p), ("bounce", d_b)):
+        ctx.from_device(full, d)
+        sample = full[idx].copy()
+        sample["t"] = 1e30; sample["u"] = 0; sample["v"] = 0; sample["prim"] = 0
+        want = rs.intersect(1, sample)
+        sc.intersect_device_fresh(d, n, 1e30)
+        ctx.from_device(full, d)
+        c = compare_with_real_reference(full[idx], want)
+        assert c["hits"] > 65536 // 4, (kind, c)
+        _real_reference_clean(c, f"{kind} rays, layout {layout}, reference-built blob")
+    for p in (d_verts, d_p, d_b):
+        ctx.free(p)
+    sc.free()
