@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--scene", default="bistro")
     ap.add_argument("--side", type=int, default=4096)
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--check", action="store_true", help="after the timing: the bounce batch's records and the shadow flags of every configuration byte-compared with the first one's")
     a = ap.parse_args()
     verts, label = scenes.get(a.scene)
     ctx = tb.Context(0)
@@ -63,6 +64,21 @@ def main():
             base = rate
         print(f"{name:16s} hybrid {str(k):>7s} flags {fl} variant {v:3d}: primary {rate['primary']:7.1f} ({rate['primary'] / base['primary'] - 1:+.1%})  diffuse {rate['diffuse']:7.1f} ({rate['diffuse'] / base['diffuse'] - 1:+.1%})  "
               f"shadow {rate['shadow']:7.1f} ({rate['shadow'] / base['shadow'] - 1:+.1%})   primary+diffuse {2 * n / ((med['primary'] + med['diffuse']) * 1e-3) / 1e6:7.1f}", flush=True)
+    if a.check:
+        want = None
+        for name, k, fl, v in cfgs:
+            ctx.set_debug_flags(fl)
+            if k is not None and (k, fl & 8) != cur_k:
+                sc.set_hybrid(k); cur_k = (k, fl & 8)
+            sc.set_variant(v)
+            sc.intersect_device_fresh(d_diff, n, 1e30); sc.occluded_device(d_shad, n, d_occ)
+            got = np.zeros((n, 16), np.uint32); occ = np.zeros(n, np.uint8)
+            ctx.from_device(got, d_diff); ctx.from_device(occ, d_occ)
+            if want is None:
+                want = (got[:, 12:].copy(), occ)
+                print(f"check: {name} is the yardstick ({int((got[:, 12].view(np.float32) < 1e30).sum())} bounce hits, {int(occ.sum())} occluded)")
+            else:
+                print(f"check: {name}: {int((got[:, 12:] != want[0]).any(1).sum())} bounce records differ, {int((occ != want[1]).sum())} shadow flags differ", flush=True)
     ctx.close()
 
 

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--passes", type=int, default=4)
     ap.add_argument("--out", default="")
     ap.add_argument("--device-build", action="store_true")
+    ap.add_argument("--flags", type=int, default=0, help="tbvh_debug_set_flags for the measured launches")
     a = ap.parse_args()
     verts, label = scenes.get(a.scene)
     ctx = tb.Context(0)
@@ -63,6 +64,7 @@ def main():
     cam = R.camera(*cams[0], a.side, a.side, 1, 1)
     d_prim, d_diff, d_shad = make_batches(ctx, sc, verts, cam, n)
     d_occ = ctx.malloc(n)
+    ctx.set_debug_flags(a.flags)
     res = {}
     ref_hits = {}
     for v in [int(x) for x in a.variants.split(",") if x]:
