@@ -421,7 +421,8 @@ typedef struct tbvh_wf_stats {
 int  tbvh_wavefront_create(tbvh_context* ctx, uint32_t width, uint32_t height, tbvh_wavefront** out);
 void tbvh_wavefront_destroy(tbvh_wavefront* wf);
 /* d_verts16: device copy of the scene's original vertex array.  stats may be NULL (fully
- * asynchronous); when given, the call synchronizes and fills it. */
+ * asynchronous); when given, the call synchronizes and fills it.  The frame is bracketed by ONE event pair
+ * (frame_ms; tbvh_time_last_ms() after the call = the frame): its queries do not enter tbvh_time_history. */
 int  tbvh_wavefront_render(tbvh_wavefront* wf, tbvh_scene* scene, const void* d_verts16, const tbvh_camera* cam,
                            const tbvh_wf_params* params, tbvh_wf_stats* stats);
 /* Several devices, one image (BASELINE config 4: "wavefront path tracer, 3 bounces, ray batch sharded across 8 x MI355X"; the frame loop

@@ -70,6 +70,7 @@ struct tbvh_context {
     bool embedTris = true;          // TBVH_EMBED_TRIS=0: the hybrid node copy without a triangle in each node's line (A/B: tools/ab_configs.py)
     bool incoherentCopies = true;   // TBVH_INCOHERENT_COPIES=0: no hybrid node copy / 64-byte triangle records (prepareIncoherentCopies)
     uint32_t expFlags = 0;     // tbvh_debug_set_flags: QueryArgs::flags of the next launches (experiments)
+    bool skipTiming = false;   // launches enqueued by a stage loop of the library itself (the wavefront frame): no event pair per query
     bool lastProbed = false;   // the most recent query launch ran the coherence probe (tbvh_debug_last_probe)
     bool gridOverride = false;     // TBVH_BLOCKS_PER_CU / TBVH_RAYS_PER_BLOCK given: no per-scene adjustment
     uint64_t splitBelow = 12ull << 20;   // batches of fewer rays split their last rays over idle lanes; TBVH_SPLIT_RAYS=0 turns that off (tie order then reproducible run to run)
