@@ -41,6 +41,8 @@ inline tbvh_context* NewContext(int device = 0) {
     return c;
 }
 inline int DeviceCount() { const int n = tbvh_device_count(); return n < 0 ? 0 : n; }
+// the CL_PROFILING_COMMAND_* equivalent costs two event records per query: a renderer that never calls LastKernelMs() switches it off
+inline void SetTiming(bool enabled, tbvh_context* ctx = nullptr, int device = 0) { Check(tbvh_set_timing(ctx ? ctx : Context(device), enabled ? 1 : 0), "tbvh_set_timing"); }
 
 // One uploaded layout: replaces the Buffer triple + Kernel of a speedtest GPU block.  The blobs are consumed verbatim.
 class Scene {

@@ -79,6 +79,12 @@ int         tbvh_synchronize(tbvh_context* ctx);
 /* Make subsequent launches of this context go to an external hipStream_t (e.g. the
  * current torch stream); NULL restores the context's own stream. */
 int         tbvh_set_stream(tbvh_context* ctx, void* hip_stream);
+/* Per-operation device timing on (default) or off.  On: every query / refit / rebuild is bracketed by a HIP event pair — what
+ * tbvh_time_last_ms and tbvh_time_history read, the CL_PROFILING_COMMAND_START / END of tiny_bvh_speedtest.cpp:1126-1131.  Off: nothing but the
+ * kernels is enqueued (two event records fewer per query: a few microseconds each, which a renderer issuing many small queries per frame
+ * notices); the time calls then keep reporting the last operation that was timed, and a scene whose coherent-batch schedule is still being
+ * measured (tbvh_debug_coherent_schedule) runs the default schedule until timing is back on. */
+int         tbvh_set_timing(tbvh_context* ctx, int enabled);
 
 /* ------------------------------------------------------------------------------------
  * uploads — replace tinyocl::Buffer(bytes, hostPtr) + CopyToDevice()

@@ -145,3 +145,28 @@ def test_time_history_reads_every_launch_once(ctx):
     assert h[3] < h[0]                                   # 10 k rays take less than 200 k
     assert len(ctx.time_history(1000)) <= 256            # the ring remembers 256 operations
     ctx.free(d); sc.free()
+
+
+def test_timing_can_be_switched_off(ctx):
+    """tbvh_set_timing(0): queries enqueue their kernels only — the records are the same, the time calls keep the last TIMED operation; back on, they follow again."""
+    verts = scenes.soup(20_000, seed=3)
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    rays = R.random_rays(100_000, (0, 0, 0), (10, 10, 10), seed=2)
+    d = ctx.malloc(rays.nbytes); ctx.to_device(d, rays)
+    sc.intersect_device_fresh(d, 100_000, 1e30)
+    want = np.zeros_like(rays); ctx.from_device(want, d)
+    t_timed = ctx.time_last_ms()
+    n_hist = len(ctx.time_history(1000))
+    try:
+        ctx.set_timing(False)
+        for m in (5_000, 100_000):
+            sc.intersect_device_fresh(d, m, 1e30)
+        got = np.zeros_like(rays); ctx.from_device(got, d)
+        assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+        assert abs(ctx.time_last_ms() - t_timed) < 1e-6          # still the operation that was timed
+        assert len(ctx.time_history(1000)) == n_hist
+    finally:
+        ctx.set_timing(True)
+    sc.intersect_device_fresh(d, 5_000, 1e30)
+    assert len(ctx.time_history(1000)) == min(n_hist + 1, 256) and 0 < ctx.time_last_ms() < t_timed
+    ctx.free(d); sc.free()

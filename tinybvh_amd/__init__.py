@@ -92,6 +92,10 @@ class Context:
     def set_stream(self, hip_stream: Optional[int]):
         check(lib.tbvh_set_stream(self._h, C.c_void_p(hip_stream or 0)), "tbvh_set_stream")
 
+    def set_timing(self, enabled: bool):
+        """Per-operation HIP-event timing on / off (tbvh_set_timing): off saves two event records per query."""
+        check(lib.tbvh_set_timing(self._h, 1 if enabled else 0), "tbvh_set_timing")
+
     def copy_bandwidth_gbps(self, nbytes: int = 1 << 30, reps: int = 3) -> float:
         """Measured streaming-copy bandwidth of this device (tbvh_measure_copy_bandwidth), GB/s read + written."""
         g = C.c_double(0)

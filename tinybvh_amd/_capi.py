@@ -50,6 +50,7 @@ SYMBOLS = {
     "tbvh_shutdown": (None, [_vp]),
     "tbvh_synchronize": (_i, [_vp]),
     "tbvh_set_stream": (_i, [_vp, _vp]),
+    "tbvh_set_timing": (_i, [_vp, _i]),
     "tbvh_upload_bvh_gpu": (_i, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _pp]),
     "tbvh_upload_bvh4_gpu": (_i, [_vp, _vp, _u64, _pp]),
     "tbvh_upload_cwbvh": (_i, [_vp, _vp, _u64, _vp, _u64, _pp]),

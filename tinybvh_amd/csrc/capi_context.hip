@@ -174,6 +174,13 @@ int tbvh_debug_stats(tbvh_context* c, uint64_t out[8], int reset) {
     return 0;
 }
 
+int tbvh_set_timing(tbvh_context* c, int enabled) {
+    if (!c) return fail(TBVH_E_INVALID, "tbvh_set_timing: null context");
+    TBVH_LOCK(c);
+    c->skipTiming = enabled == 0;
+    return 0;
+}
+
 int tbvh_debug_set_flags(tbvh_context* c, uint32_t flags) {
     if (!c) return fail(TBVH_E_INVALID, "tbvh_debug_set_flags: null context");
     TBVH_LOCK(c);

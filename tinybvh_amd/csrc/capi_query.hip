@@ -238,12 +238,13 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                     if (tu.n[0] >= 2 && tu.n[1] >= 2) { tu.decided = tu.best[1] < 0.97f * tu.best[0] ? 2 : 1; tu.pending.clear(); }
                     else if (tu.launches >= 64) { tu.decided = 1; tu.pending.clear(); }   // batches too varied to compare: the schedule that wins on most scenes
                 }
-                const int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : (nDev ? 1 : 1 + (int)(tu.launches & 1u));
-                tu.launches++;
+                const bool untimed = c->skipTiming;   // (tbvh_set_timing(0), or a query of the wavefront frame: no event pair to measure with)
+                const int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : ((nDev || untimed) ? 1 : 1 + (int)(tu.launches & 1u));
+                if (!untimed) tu.launches++;
                 if (mode == 2) qa.flags |= 32u;
                 launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, mode == 2 ? blocksBase : blocks, c->stream, 5, small, blocks7);
                 HIP_TRY(hipGetLastError());
-                if (!tu.decided && !c->cohTunerMode && !nDev && tu.pending.size() < 16) {
+                if (!tu.decided && !c->cohTunerMode && !nDev && !untimed && tu.pending.size() < 16) {
                     if (!c->evMid[slot]) HIP_TRY(hipEventCreate(&c->evMid[slot]));
                     HIP_TRY(hipEventRecord(c->evMid[slot], c->stream));
                     tu.pending.push_back(CohTuner::Pending{c->evSeq, mode, n});
