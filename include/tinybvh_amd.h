@@ -339,7 +339,7 @@ int tbvh_debug_set_flags(tbvh_context* ctx, uint32_t flags);
 int tbvh_debug_coherent_schedule(tbvh_scene* scene, int anyhit, uint32_t out[4]);
 
 /* The per-launch coherence probe of the most recent query on this context (development aid; DESIGN.md par. 3): out[0] = sampled
- * neighbouring ray pairs whose directions agree, out[1] = pairs sampled, out[2] = 0 no probe ran (small batches, small or very
+ * neighbouring ray pairs whose directions agree (and, for rays of finite reach, whose origins lie within 5 % of that reach), out[1] = pairs sampled, out[2] = 0 no probe ran (small batches, small or very
  * large scenes, other layouts), 1 the batch was classified incoherent (strict schedule), 2 coherent (deferred triangles, gated
  * triangle phase, a third more waves).  Synchronizes the stream. */
 int tbvh_debug_last_probe(tbvh_context* ctx, uint32_t out[3]);
