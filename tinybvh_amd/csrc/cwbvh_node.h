@@ -83,7 +83,14 @@ __device__ __forceinline__ CwNodeHits cw_test_node(const CwNode& nr, float3 O, f
             const float tnz = __builtin_fmaf((float)((loz >> sh) & 255), az, oz), tfz = __builtin_fmaf((float)((hiz >> sh) & 255), az, oz);
             const float cmin = __builtin_fmaxf(cw_fmax3(tnx, tny, tnz), 0.0f);
             const float cmax = __builtin_fminf(cw_fmin3(tfx, tfy, tfz), tmax);
-            if (cmin <= cmax) hitmask |= ((bits4 >> sh) & 255u) << ((bitidx4 >> sh) & 255u);
+            // (child bits) << (bit index), both bytes picked by SDWA selects in ONE instruction (the compiler spends a v_bfe_u32 and, for the odd
+            // bytes, a shift of the index word as well)
+            uint32_t placed;
+            if (i == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:BYTE_0" : "=v"(placed) : "v"(bitidx4), "v"(bits4));
+            else if (i == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:BYTE_1" : "=v"(placed) : "v"(bitidx4), "v"(bits4));
+            else if (i == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:BYTE_2" : "=v"(placed) : "v"(bitidx4), "v"(bits4));
+            else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:BYTE_3" : "=v"(placed) : "v"(bitidx4), "v"(bits4));
+            if (cmin <= cmax) hitmask |= placed;
         }
     }
     CwNodeHits r;
