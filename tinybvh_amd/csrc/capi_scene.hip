@@ -10,6 +10,7 @@ namespace tbvh_capi {
 // 60 % larger array costs (tools/size_sweep.py, 60 M triangles: bounce rays +6 %; below that size the smaller footprint wins).
 int padCwbvhIfLarge(tbvh_scene* s) {
     if (s->layout != TBVH_LAYOUT_CWBVH || s->isTlas || s->nodes128 || (uint64_t)s->nNodes * 80 < (512ull << 20)) return 0;
+    if ((uint64_t)s->nNodes * 8 >> 32) return 0;   // (cw_load_node addresses float4s with 32 bits: beyond 2^29 nodes — 64 GB padded — the packed array serves)
     tbvh_context* c = s->ctx;
     if (hipMalloc((void**)&s->nodes128, (size_t)s->nNodes * 128) != hipSuccess) { s->nodes128 = nullptr; (void)hipGetLastError(); return 0; }   // no memory to spare: the packed array serves
     launch_cwbvh_pad(s->nodes, s->nodes128, s->nNodes, c->stream);
@@ -135,6 +136,7 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
                       tbvh_scene** out) {
     if (!c || !nodes16 || !out || nNodeBlocks < 5 || (nTriBlocks && !tris16)) return fail(TBVH_E_INVALID, "tbvh_upload_cwbvh: null/empty argument");
     if (nNodeBlocks % 5) return fail(TBVH_E_FORMAT, "CWBVH node blocks (%llu) not a multiple of 5", (unsigned long long)nNodeBlocks);
+    if (nNodeBlocks >> 32) return fail(TBVH_E_FORMAT, "CWBVH node blocks (%llu) beyond the layout's 32-bit block index", (unsigned long long)nNodeBlocks);   // (cw_load_node: 32-bit float4 offsets)
     if (const char* why = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
     TBVH_ENTER(c);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_CWBVH);

@@ -42,7 +42,13 @@ __device__ __forceinline__ uint32_t cw_hybrid_offset(uint32_t nodeIdx, uint32_t 
 }
 template <int NSTRIDE = 5>
 __device__ __forceinline__ CwNode cw_load_node(const float4* __restrict__ nodes, uint32_t nodeIdx, uint32_t hybridK = 0u) {
-    const size_t off = NSTRIDE == kNodeHybrid ? (size_t)cw_hybrid_offset(nodeIdx, hybridK) : (size_t)nodeIdx * (uint32_t)NSTRIDE;   // (the hybrid copy is only built below 2^32 float4s: capi_scene.hip)
+    // the offset in float4s fits 32 bits (a CWBVH blob is addressed in 32-bit float4 blocks: tbvh_upload_cwbvh; the padded copy is only made below
+    // 2^29 nodes, the hybrid one below 2^32 float4s: capi_scene.hip), so the address is a shift-add and one v_lshl_add_u64 — (size_t)nodeIdx * 5
+    // is a v_mad_u64_u32, a quarter-rate instruction.  (Pinned in assembly: written in C the compiler turns i * 4 + i back into the multiply.)
+    uint32_t off;
+    if (NSTRIDE == kNodeHybrid) off = cw_hybrid_offset(nodeIdx, hybridK);
+    else if (NSTRIDE == 5) asm("v_lshl_add_u32 %0, %1, 2, %1" : "=v"(off) : "v"(nodeIdx));
+    else off = nodeIdx * (uint32_t)NSTRIDE;
     const float4* np = nodes + off;
     return CwNode{np[0], np[1], np[2], np[3], np[4]};
 }
@@ -64,8 +70,11 @@ __device__ __forceinline__ CwNodeHits cw_test_node(const CwNode& nr, float3 O, f
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         const uint32_t meta4 = half ? as_u32(n1.w) : as_u32(n1.z);
-        const uint32_t inner4 = (meta4 & (meta4 << 1)) & 0x10101010u;
-        const uint32_t imask4 = cw_sext_s8x4(inner4 << 3);
+        // interior children (meta = 0b001sssss with sssss = 24 + slot: bits 3 and 4 set) get their bit index through the ray's octant: index ^= octinv.
+        // octinv4's bytes are 0..7, so the mask only needs 0x07 per interior byte: y = bit 3 of (meta & meta >> 1), 0x07 = y - (y >> 3) — two full-rate
+        // instructions where the 0xff-per-byte sign extension took a v_mul_lo_u32 (quarter rate) on top of its shifts
+        const uint32_t inner8 = (meta4 & (meta4 >> 1)) & 0x08080808u;
+        const uint32_t imask4 = inner8 - (inner8 >> 3);
         const uint32_t bitidx4 = (meta4 ^ (octinv4 & imask4)) & 0x1F1F1F1Fu;
         const uint32_t bits4 = (meta4 >> 5) & 0x07070707u;
         const uint32_t qlx = half ? as_u32(n2.y) : as_u32(n2.x), qhx = half ? as_u32(n3.w) : as_u32(n3.z);
