@@ -77,7 +77,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
     pool.init(q.poolParts, q.counterNext);
     LockstepGovernor gov;
     gov.init();
-    if (PROBED == 2) gov.lockstep = false;   // the probe has said the batch is incoherent: no lockstep generation to find that out again (4 M bounce rays +1 %)
+    if (PROBED == 2) gov.lockstep = 0u;   // the probe has said the batch is incoherent: no lockstep generation to find that out again (4 M bounce rays +1 %)
     // PROBED: the batch's coherence probe (QueryArgs::probe) picks the schedule for the whole launch: coherent batches (camera rays, shadow rays
     // towards one light) are VALU-bound and run deferred triangles + a gated triangle phase on a third more waves; incoherent ones are bound by
     // the cache-miss path and keep the strict schedule.  PROBED == 1: this kernel holds both schedules (waves beyond q.baseBlocks leave at once
@@ -125,7 +125,8 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
 
     for (;;) {
         // ---- ray replacement -------------------------------------------------------------
-        const uint32_t nIdle = (uint32_t)__popcll(__ballot(!active));
+        uint32_t nIdle;   // a 32-bit SCALAR by construction: left to the compiler the count stays a 64-bit value, and 64-bit ordered compares only exist as vector instructions
+        { const unsigned long long idleMask = __ballot(!active); asm("s_bcnt1_i32_b64 %0, %1" : "=s"(nIdle) : "s"(idleMask) : "scc"); }
         if (gov.want_refill(nIdle, (uint32_t)REFILL_MIN) || nIdle == (uint32_t)WG) {
             if (!pool.dry()) {
                 uint64_t nri = 0;

@@ -37,9 +37,11 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask) {
 // Sponza stand-in 0.75-0.95, bounce rays < 0.6 everywhere, Bistro stand-in camera rays spread over 0.3-1.
 constexpr uint32_t kLockstepKeep = 184, kLockstepBail = 179;   // x / 256: 0.72, 0.70
 template <uint32_t KEEP = kLockstepKeep, uint32_t BAIL = kLockstepBail> struct LockstepGovernorT {
-    bool lockstep;
+    // (every member is wave-uniform; callers pass nIdle as a 32-bit scalar — kernels_cwbvh.hip takes it from s_bcnt1_i32_b64 directly: as the 64-bit
+    // value __popcll returns it is compared with VECTOR instructions, 64-bit ordered compares do not exist on the scalar unit)
+    uint32_t lockstep;
     uint32_t genIters, genActive, ema;
-    __device__ __forceinline__ void init() { lockstep = true; genIters = 0; genActive = 0; ema = 0; }
+    __device__ __forceinline__ void init() { lockstep = 1u; genIters = 0; genActive = 0; ema = 0; }
     // Call once per traversal iteration with the number of idle lanes; returns whether the wave should
     // take new rays now.
     __device__ __forceinline__ bool want_refill(uint32_t nIdle, uint32_t refillMin) {
@@ -49,10 +51,10 @@ template <uint32_t KEEP = kLockstepKeep, uint32_t BAIL = kLockstepBail> struct L
                 if (genIters > 1u) {
                     const uint32_t e = genActive * 4u / genIters;   // x / 256
                     ema = ema ? (ema + e) >> 1 : e;
-                    if (ema < KEEP) lockstep = false;
+                    if (ema < KEEP) lockstep = 0u;
                 }
                 genIters = 0; genActive = 0;
-            } else if (genIters >= 16u && genActive * 4u < BAIL * genIters) lockstep = false;
+            } else if (genIters >= 16u && genActive * 4u < BAIL * genIters) lockstep = 0u;
         }
         return lockstep ? nIdle == 64u : nIdle >= refillMin;
     }
