@@ -115,7 +115,10 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     q.spill = c->spill; q.counter = poolArea; q.counterNext = (uint32_t*)c->pool + (size_t)(c->poolCur ^ 1) * poolWords; q.poolParts = c->poolParts;
     q.stats = c->counter + 8;
     q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.omm = Omm{s->opmap, s->opmapN};
-    q.probe = nullptr; q.baseBlocks = 0; q.hybridK = s->hybridK; q.flags = c->expFlags & 1u;
+    q.probe = nullptr; q.baseBlocks = 0; q.hybridK = s->hybridK; q.flags = 0u;
+#ifdef TBVH_EXPERIMENTS
+    q.flags = c->expFlags & 1u;
+#endif
     c->lastProbed = false;
     q.splitBelow = c->splitBelow;
     // persistent grid: 24 one-wave workgroups per CU for large batches; small batches get fewer
@@ -196,7 +199,9 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             const bool autoPad = s->variant == 0 && s->nodes128 != nullptr;   // nodes beyond the Infinity Cache: the padded copy (padCwbvhIfLarge)
             const uint32_t blocks7 = c->gridOverride ? 0xFFFFFFFFu : (uint32_t)c->numCUs * 28u;
             const float4* tris = s->tris;
+#ifdef TBVH_EXPERIMENTS
             if ((c->expFlags & 2u) && s->tris64) { tris = s->tris64; q.flags |= 2u; }   // experiment: 64-byte triangle records in the ordinary kernels too
+#endif
             // A probed launch on a scene with the incoherent-batch copies (prepareIncoherentCopies) is TWO kernels back to back, each for one
             // verdict of the probe; the one the verdict is not for leaves at once (~10 us).  The coherent flavor keeps the packed arrays as
             // uploaded (its working set lives in the L2s); the incoherent one walks the hybrid node copy and the 64-byte triangle records.

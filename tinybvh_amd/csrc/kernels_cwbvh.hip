@@ -33,6 +33,17 @@ namespace {
 
 constexpr int WG = 64;
 
+// Ballots of a bool straight from the compare that made it (HIP's __ballot takes an int: bool -> 0 / 1 -> compare again, two vector instructions
+// per ballot), and lane counts as 32-bit SCALARS (the 64-bit value __popcll returns is compared with vector instructions: the scalar unit has no
+// 64-bit ordered compare).
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ uint32_t wave_count(bool p) {
+    const unsigned long long m = wave_ballot(p);
+    uint32_t n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
+    return n;
+}
+
 // STATS (experiment builds): q.stats[0] wave iterations, [1] sum of active lanes, [2] sum of lanes visiting a node,
 // [3] triangle-phase iterations, [4] sum of lanes in them, [5] node phases whose lanes all visit ONE node with ONE octant,
 // [6] sum of lanes in those, [7] node-phase iterations
@@ -106,7 +117,11 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
         else if (!coh && blockIdx.x >= q.baseBlocks) return;
     }
     const uint32_t hybridK = q.hybridK;
-    const bool ntRays = PROBED == 2 || (q.flags & 1u) != 0, tri64 = PROBED == 2 || (q.flags & 2u) != 0;
+#ifdef TBVH_EXPERIMENTS
+    const bool ntRays = PROBED == 2 || (q.flags & 1u) != 0, tri64 = PROBED == 2 || (q.flags & 2u) != 0;   // (round 3's A/B switches: debug flags 1 and 2)
+#else
+    constexpr bool ntRays = PROBED == 2, tri64 = PROBED == 2;
+#endif
 
     bool active = false;
     uint64_t ri = 0;
@@ -125,8 +140,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
 
     for (;;) {
         // ---- ray replacement -------------------------------------------------------------
-        uint32_t nIdle;   // a 32-bit SCALAR by construction: left to the compiler the count stays a 64-bit value, and 64-bit ordered compares only exist as vector instructions
-        { const unsigned long long idleMask = __ballot(!active); asm("s_bcnt1_i32_b64 %0, %1" : "=s"(nIdle) : "s"(idleMask) : "scc"); }
+        const uint32_t nIdle = wave_count(!active);
         if (gov.want_refill(nIdle, (uint32_t)REFILL_MIN) || nIdle == (uint32_t)WG) {
             if (!pool.dry()) {
                 uint64_t nri = 0;
@@ -149,7 +163,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
                 }
             }
             if (STATS >= 2 && !tDry && pool.dry()) tDry = wall_clock64();
-            if (__ballot(active) == 0) break;
+            if (wave_ballot(active) == 0) break;
         }
         const bool tail = STEAL && pool.dry();   // wave-uniform: nothing of the split-ray code costs a vector instruction before the pool is dry
         if (tail && nIdle >= (uint32_t)STEAL) {
@@ -193,9 +207,9 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
         const bool spec = PROBED == 1 ? coh : SPEC;   // (PROBED == 3 is launched with SPEC = true)
         bool triPhase = true;
         if (TRI_MIN > 1 && (PROBED == 1 ? coh : true)) {
-            const uint32_t nPend = (uint32_t)__popcll(__ballot(tg.y != 0));
+            const uint32_t nPend = wave_count(tg.y != 0);
             const bool canNode = spec ? (tg2.y == 0 && (cw_has_child(ng) || !st.empty())) : tg.y == 0;
-            triPhase = nPend >= (uint32_t)TRI_MIN || __ballot(canNode) == 0;
+            triPhase = nPend >= (uint32_t)TRI_MIN || wave_ballot(canNode) == 0;
         }
         if (triPhase && tg.y != 0 && !(STEAL && ANYHIT && done)) {
             if (STATS == 1) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sTriIter++; sTri += __popcll(m); } }
