@@ -113,7 +113,7 @@ __device__ __forceinline__ CwNodeHits cw_test_node(const CwNode& nr, float3 O, f
 // cw_next_child takes the front-most pending child off ng and returns its node index.
 __device__ __forceinline__ uint32_t cw_next_child(uint2& ng, uint32_t oct) {
     const uint32_t imask = ng.y;
-    const uint32_t bit = 31u - (uint32_t)__clz(ng.y);
+    const uint32_t bit = 31u - (uint32_t)__builtin_clz(ng.y);   // (callers have checked cw_has_child: ng.y != 0 — __clz would guard the zero case with a v_min_u32)
     ng.y &= ~(1u << bit);
     const uint32_t slot = (bit - 24u) ^ oct;
     return ng.x + __popc(imask & ~(0xFFFFFFFFu << slot));
