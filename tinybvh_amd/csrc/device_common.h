@@ -83,6 +83,17 @@ __device__ __forceinline__ bool tri_test(float3 O, float3 D, float3 v0, float3 e
     return true;
 }
 
+// Ballots of a bool straight from the compare that made it (HIP's __ballot takes an int: bool -> 0 / 1 -> compare again, two vector instructions
+// per ballot), and lane counts as 32-bit SCALARS (the 64-bit value __popcll returns is compared with vector instructions: the scalar unit has no
+// 64-bit ordered compare).
+__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ uint32_t wave_count(bool p) {
+    const unsigned long long m = wave_ballot(p);
+    uint32_t n;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
+    return n;
+}
+
 __device__ __forceinline__ float3 xyz(float4 v) { return make_float3(v.x, v.y, v.z); }
 
 // The library's tie rule.  tri_test has established t <= best.x; the candidate replaces the closest hit so far iff it is the

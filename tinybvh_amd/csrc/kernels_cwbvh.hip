@@ -33,17 +33,6 @@ namespace {
 
 constexpr int WG = 64;
 
-// Ballots of a bool straight from the compare that made it (HIP's __ballot takes an int: bool -> 0 / 1 -> compare again, two vector instructions
-// per ballot), and lane counts as 32-bit SCALARS (the 64-bit value __popcll returns is compared with vector instructions: the scalar unit has no
-// 64-bit ordered compare).
-__device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-__device__ __forceinline__ uint32_t wave_count(bool p) {
-    const unsigned long long m = wave_ballot(p);
-    uint32_t n;
-    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n) : "s"(m) : "scc");
-    return n;
-}
-
 // STATS (experiment builds): q.stats[0] wave iterations, [1] sum of active lanes, [2] sum of lanes visiting a node,
 // [3] triangle-phase iterations, [4] sum of lanes in them, [5] node phases whose lanes all visit ONE node with ONE octant,
 // [6] sum of lanes in those, [7] node-phase iterations
