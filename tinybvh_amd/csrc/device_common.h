@@ -83,6 +83,10 @@ __device__ __forceinline__ bool tri_test(float3 O, float3 D, float3 v0, float3 e
     return true;
 }
 
+// Put right after the three loads of a triangle record: all three go out together.  Left alone the compiler sinks the third (v0, first needed behind
+// the determinant test) into that branch — one load fewer for an edge-on triangle, a second memory round trip for every other one.
+__device__ __forceinline__ void tri_loads_together(const float4& v0) { asm volatile("" :: "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w)); }
+
 // Ballots of a bool straight from the compare that made it (HIP's __ballot takes an int: bool -> 0 / 1 -> compare again, two vector instructions
 // per ballot), and lane counts as 32-bit SCALARS (the 64-bit value __popcll returns is compared with vector instructions: the scalar unit has no
 // 64-bit ordered compare).

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(WG) void k_bvh2(const float4* __restrict__ nodes, c
             const float4 v0 = tris[triPtr], e1 = tris[triPtr + 1], e2 = tris[triPtr + 2];
             triPtr += 3; triLeft--;
             TriHit h;
+            tri_loads_together(v0);   // (BVH_GPU, A/B of two builds: Bistro stand-in camera / bounce / shadow rays +1.4 / +2.2 / +1 %, Sponza stand-in bounce rays +3 %; k_bvh4 and the two-level kernels measured neutral or slower with it)
             if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w)) &&
                 (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), found, hit))) {   // (a split ray's group arbitrates: split_publish)
                 found = true;
