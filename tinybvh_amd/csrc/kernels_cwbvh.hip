@@ -213,7 +213,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
             // Incoherent batches: all three loads of the record issue together.  Left alone the compiler sinks v0's load into the branch behind the
             // determinant test — one load fewer for a lane whose triangle is edge-on, a second memory round trip for every other one: bounce rays +7 %
             // with the loads together, camera and shadow rays -2 % (their triangle phase is gated and full of L2 hits: the extra registers cost more).
-            if (PROBED == 2) asm volatile("" :: "v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w));
+            if (PROBED == 2) tri_loads_together(v0);
             TriHit h;
             if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w)) &&
                 (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), found, hit))) {   // (a split ray's group arbitrates: split_publish)
