@@ -336,7 +336,9 @@ int tbvh_debug_set_flags(tbvh_context* ctx, uint32_t flags);
  * is faster (profiles/r04_sensitivity.txt: +1 ... +8 % for the first on most scenes, +10 % for the second on large-occluder scenes), so the
  * first few such launches alternate and are timed on the device (no synchronisation), then the faster stays (TBVH_COHERENT_TUNER=0 / 2 in
  * the environment pins the first / the second).  out[0] = 0 still measuring, 1 deferred + gated, 2 strict; out[1], out[2] = coherent samples
- * taken of each; out[3] = 1000 x best time per ray of the strict schedule / of the deferred one (0 until both have samples). */
+ * taken of each; out[3] = 1000 x best time per ray of the strict schedule / of the deferred one (0 until both have samples).  The choice is kept
+ * per batch-size class (below 6 M rays, below 12 M, more: the end of a launch weighs differently — the atrium generator's camera rays are 15 % faster
+ * strict at 16.7 M rays and even at 4.2 M); the call reports the class of the most recent launch. */
 int tbvh_debug_coherent_schedule(tbvh_scene* scene, int anyhit, uint32_t out[4]);
 
 /* The per-launch coherence probe of the most recent query on this context (development aid; DESIGN.md par. 3): out[0] = sampled

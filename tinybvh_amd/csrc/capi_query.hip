@@ -218,7 +218,9 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                 QueryArgs qa = q;
                 qa.baseBlocks = 0;   // every wave of the coherent flavor leaves unless the batch is coherent
                 // which schedule serves a coherent batch on this scene is measured, not assumed (CohTuner, capi_internal.h)
-                CohTuner& tu = s->cohTuner[any ? 1 : 0];
+                const int sizeClass = n < (6ull << 20) ? 0 : n < (12ull << 20) ? 1 : 2;
+                s->cohLastClass[any ? 1 : 0] = (uint8_t)sizeClass;
+                CohTuner& tu = s->cohTuner[any ? 1 : 0][sizeClass];
                 const uint32_t slot = (uint32_t)((c->evSeq - 1) % tbvh_context::kTimeRing);   // this query's event pair (timedBegin above)
                 if (!tu.decided && !c->cohTunerMode) {
                     for (size_t k = 0; k < tu.pending.size();) {   // harvest the launches that have finished since

@@ -706,7 +706,7 @@ uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0;
 int tbvh_debug_coherent_schedule(tbvh_scene* s, int anyhit, uint32_t out[4]) {
     if (!s || !out) return fail(TBVH_E_INVALID, "tbvh_debug_coherent_schedule: null argument");
     TBVH_LOCK(s->ctx);
-    const CohTuner& t = s->cohTuner[anyhit ? 1 : 0];
+    const CohTuner& t = s->cohTuner[anyhit ? 1 : 0][s->cohLastClass[anyhit ? 1 : 0]];   // (kept per batch-size class; this is the class of the most recent such launch)
     out[0] = s->ctx->cohTunerMode ? (uint32_t)s->ctx->cohTunerMode : (uint32_t)t.decided;
     out[1] = t.n[0]; out[2] = t.n[1];
     out[3] = (t.n[0] && t.n[1]) ? (uint32_t)(1000.f * t.best[1] / t.best[0]) : 0u;
