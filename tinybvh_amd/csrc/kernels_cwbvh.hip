@@ -210,10 +210,12 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
             else
                 tp = tris + (tri64 ? (size_t)((__umulhi(tg.x, 0xAAAAAAABu) >> 1) + ti) * 4u : (size_t)tg.x + ti * 3u);   // (experiment) records padded to 64 bytes: tg.x counts float4s of the packed array
             const float4 e2 = tp[0], e1 = tp[1], v0 = tp[2];
-            // Incoherent batches: all three loads of the record issue together.  Left alone the compiler sinks v0's load into the branch behind the
-            // determinant test — one load fewer for a lane whose triangle is edge-on, a second memory round trip for every other one: bounce rays +7 %
-            // with the loads together, camera and shadow rays -2 % (their triangle phase is gated and full of L2 hits: the extra registers cost more).
-            if (PROBED == 2) tri_loads_together(v0);
+            // The strict schedule: all three loads of the record issue together.  Left alone the compiler sinks v0's load into the branch behind the
+            // determinant test — one load fewer for a lane whose triangle is edge-on, a second memory round trip for every other one.  Bounce rays
+            // +7 % on the Bistro and Sponza stand-ins, +7-10 % on 12 M triangles, camera and shadow rays +-1 % (profiles/r04_ab_triangle_loads_together.txt).
+            // The deferred + gated schedule keeps the lazy load: -2 % with the loads together (its triangle phases are full of L2 hits, the saved
+            // registers are worth more).
+            if (!SPEC && PROBED != 1) tri_loads_together(v0);
             TriHit h;
             if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w)) &&
                 (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), found, hit))) {   // (a split ray's group arbitrates: split_publish)
