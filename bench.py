@@ -602,7 +602,7 @@ def main():
                         "measured_copy_gbps": copy_gbps, "measured_read_gbps": read_gbps, "measured_valu_ginstr_per_s": valu_ginstr,
                         "fabric": f_, "valu": d_["valu"], "l2_miss_latency": d_["l2_miss_latency"], "algorithmic_hbm": d_["algorithmic_hbm"],
                         "nodes_per_ray": d_["nodes_per_ray"], "tris_per_ray": d_["tris_per_ray"], "avg_launch_ms": d_["avg_launch_ms"],
-                        "limiter": "incoherent rays: no single wall - VALU issue (valu.issue_frac), the L1 lookup rate and the latency of ~9 L2 misses per ray sit within a quarter of each other; taking 10 % of the bytes or 7 % of the L1 lookups away moved the launch by < 1 % (DESIGN.md par. 5 Round 4, par. 9); camera rays: VALU issue",
+                        "limiter": "incoherent rays: no single wall - VALU issue (valu.issue_frac), the L1 lookup rate and the latency of ~9 L2 misses per ray sit within a quarter of each other; taking 10 % of the bytes, 7 % of the L1 lookups or 6 % of the instructions away moved the launch by < 1 % each, removing one DEPENDENT load (the triangle record's third, sunk behind a branch by the compiler) by 7 % (DESIGN.md par. 5 Round 4, par. 9); camera rays: VALU issue at 0.97 of its ceiling",
                         "primary": lines.get("primary")}
         except Exception as e:  # the checker is optional for the number itself
             log(f"[bench] roofline failed: {e!r}")
