@@ -61,7 +61,9 @@ __device__ __forceinline__ CwNode cw_load_node(const GlobalF4 nodes, uint32_t no
 __device__ __forceinline__ uint32_t cw_oct(float3 D) { return 7u - ((D.x < 0 ? 4u : 0u) | (D.y < 0 ? 2u : 0u) | (D.z < 0 ? 1u : 0u)); }
 
 // Slab-test the 8 children against [0, tmax] (inclusive at both ends, like the oracle's box rule).
-__device__ __forceinline__ CwNodeHits cw_test_node(const CwNode& nr, float3 O, float3 rD, float tmax, uint32_t octinv4) {
+// negX / negY / negZ: rD.x < 0 etc. — callers that keep them per ray (kernels_cwbvh.hip: set when a lane takes a ray) save the three compares of
+// every node test: as loop-carried bools they live in scalar lane masks that the twelve near / far selects read directly.
+__device__ __forceinline__ CwNodeHits cw_test_node(const CwNode& nr, float3 O, float3 rD, float tmax, uint32_t octinv4, bool negX, bool negY, bool negZ) {
     const float4 n0 = nr.n0, n1 = nr.n1, n2 = nr.n2, n3 = nr.n3, n4 = nr.n4;
     const uint32_t ew = as_u32(n0.w);
     const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
@@ -81,9 +83,9 @@ __device__ __forceinline__ CwNodeHits cw_test_node(const CwNode& nr, float3 O, f
         const uint32_t qly = half ? as_u32(n2.w) : as_u32(n2.z), qhy = half ? as_u32(n4.y) : as_u32(n4.x);
         const uint32_t qlz = half ? as_u32(n3.y) : as_u32(n3.x), qhz = half ? as_u32(n4.w) : as_u32(n4.z);
         // near / far plane words picked once per axis by the sign of the ray direction
-        const uint32_t lox = rD.x < 0 ? qhx : qlx, hix = rD.x < 0 ? qlx : qhx;
-        const uint32_t loy = rD.y < 0 ? qhy : qly, hiy = rD.y < 0 ? qly : qhy;
-        const uint32_t loz = rD.z < 0 ? qhz : qlz, hiz = rD.z < 0 ? qlz : qhz;
+        const uint32_t lox = negX ? qhx : qlx, hix = negX ? qlx : qhx;
+        const uint32_t loy = negY ? qhy : qly, hiy = negY ? qly : qhy;
+        const uint32_t loz = negZ ? qhz : qlz, hiz = negZ ? qlz : qhz;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int sh = 8 * i;
@@ -105,6 +107,10 @@ __device__ __forceinline__ CwNodeHits cw_test_node(const CwNode& nr, float3 O, f
     CwNodeHits r;
     r.childBase = as_u32(n1.x); r.triBase = as_u32(n1.y); r.hitmask = hitmask; r.imask = ew >> 24;
     return r;
+}
+
+__device__ __forceinline__ CwNodeHits cw_test_node(const CwNode& nr, float3 O, float3 rD, float tmax, uint32_t octinv4) {
+    return cw_test_node(nr, O, rD, tmax, octinv4, rD.x < 0, rD.y < 0, rD.z < 0);
 }
 
 // Traversal state of one ray in a CWBVH (Ylitie's node group / triangle group):

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
     float3 O = make_float3(0, 0, 0), D = O, rD = O;
     float4 hit = make_float4(0, 0, 0, 0);
     bool found = false;
+    bool negX = false, negY = false, negZ = false;   // rD.x < 0 ...: per ray, kept in scalar lane masks (cw_test_node)
     uint32_t oct = 0, octinv4 = 0;
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u), tg2 = make_uint2(0u, 0u);
     uint32_t tgn = 0;   // hybrid node copy: where tg's node lives (its line may hold one of its triangles: k_derive_hybrid)
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
                     found = false;
                     oct = cw_oct(D);
                     octinv4 = oct * 0x01010101u;
+                    negX = rD.x < 0; negY = rD.y < 0; negZ = rD.z < 0;
                     ng = make_uint2(0u, 0x80000000u); tg = make_uint2(0u, 0u); tg2 = make_uint2(0u, 0u);
                     st.reset();
                     active = true;
@@ -179,6 +181,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
                 if (m.takes) {
                     found = false;
                     oct = cw_oct(D); octinv4 = oct * 0x01010101u;
+                    negX = rD.x < 0; negY = rD.y < 0; negZ = rD.z < 0;
                     ng = part; tg = make_uint2(0u, 0u); tg2 = make_uint2(0u, 0u);
                     st.reset();
                     active = true;
@@ -241,7 +244,7 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
                     if (lane_rank(m) == 0) { sNodeIter++; sNode += __popcll(m); if (uni) { sRefill++; sRefilled += __popcll(m); } }   // [5], [6]: uniform node phases, lanes in them
                 }
                 if (cw_has_child(ng)) st.push(ng);
-                const CwNodeHits r = cw_test_node(cw_load_node<NSTRIDE>(nodes, ci, hybridK), O, rD, cull_bound(hit.x), octinv4);
+                const CwNodeHits r = cw_test_node(cw_load_node<NSTRIDE>(nodes, ci, hybridK), O, rD, cull_bound(hit.x), octinv4, negX, negY, negZ);
                 ng = make_uint2(r.childBase, (r.hitmask & 0xFF000000u) | r.imask);
                 const uint2 nt = make_uint2(r.triBase, r.hitmask & 0x00FFFFFFu);
                 if (tg.y == 0) { tg = nt; if (NSTRIDE == kNodeHybrid) tgn = cw_hybrid_offset(ci, hybridK); }
