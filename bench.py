@@ -141,7 +141,7 @@ def main():
 
     # ---- ray batches on the device (untimed) -----------------------------------------------------
     n = a.side * a.side
-    cams = scenes.STREET_CAMERAS if (a.scene == "bistro" or a.scene.startswith("street")) else scenes.SPONZA_CAMERAS
+    cams = scenes.cameras(a.scene)
     eye, view = cams[0]   # the same camera on every rank: equal work per GPU, so the N-GPU aggregate measures scaling, not workload differences
     cam = R.camera(eye, view, a.side, a.side, 1, 1)
     d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)

@@ -482,7 +482,7 @@ typedef struct tbvh_build_params {
     uint32_t bins;          /* SAH bins per axis; 0 = default (8, BVHBINS)               */
     uint32_t max_leaf_tris; /* 0 = layout default (CWBVH 1 with the optimal collapse, 3 with the greedy one; others 4) */
     uint32_t threads;       /* 0 = hardware concurrency                                  */
-    uint32_t flags;         /* TBVH_BUILD_* | (triangle cost in 1/100 of a node visit) << 8, 0 = defaults */
+    uint32_t flags;         /* TBVH_BUILD_* | (triangle cost in 1/100 of a node visit, 16 bits) << 8 | (split budget in percent) << 24, 0 = defaults */
 } tbvh_build_params;
 #define TBVH_BUILD_OPTIMAL_COLLAPSE 2u /* wide layouts: SAH-optimal collapse (Ylitie et al. 2017 dynamic program: merges
                                           <= 3-triangle subtrees into leaves, fills nodes) instead of the surface-area-greedy
@@ -490,6 +490,11 @@ typedef struct tbvh_build_params {
                                           BVH8_CWBVH and BVH4_GPU, with a triangle test priced like a node visit
                                           (flags >> 8 = 100). */
 #define TBVH_BUILD_GREEDY_COLLAPSE 4u  /* force the greedy collapse (the reference's strategy) */
+#define TBVH_BUILD_SPLIT_TRIANGLES 8u  /* what BVH::BuildHQ's spatial splits are for (tiny_bvh.h:2623-3040): triangles whose boxes are
+                                          mostly empty (large, off the coordinate axes) are cut into pieces BEFORE the binned-SAH build,
+                                          up to (flags >> 24) per cent extra references (0 = 30), shared out by wasted box area x tree
+                                          level (Karras & Aila 2013 section 4.3).  A triangle may then sit in several leaves, as in a
+                                          BuildHQ tree (bvh8Tris / primIdx grow by the budget at most). */
 
 int tbvh_host_build(const void* verts16, uint64_t n_tris, int layout,
                     const tbvh_build_params* params, tbvh_hostbvh** out);

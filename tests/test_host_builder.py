@@ -190,3 +190,76 @@ def test_wide_encoder_output_does_not_depend_on_the_thread_count(layout, kw):
         h = tb.HostBVH(verts, layout, threads=th, **kw)
         assert np.array_equal(h.blob(0, np.uint32, 4), ref.blob(0, np.uint32, 4)), th
         assert np.array_equal(h.blob(1, np.uint32, 4), ref.blob(1, np.uint32, 4)), th
+
+
+# ---- triangle splitting ahead of the build (TBVH_BUILD_SPLIT_TRIANGLES; what BVH::BuildHQ's spatial splits are for, tiny_bvh.h:2623-3040) ----
+
+def _rotated(verts):
+    return scenes.rotate(scenes.rotate(verts, 0, 0.6180339887), 1, 0.7548776662)
+
+
+@pytest.mark.parametrize("budget", [0.1, 0.3, 1.0])
+@pytest.mark.parametrize("layout", [tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU, tb.LAYOUT_CWBVH])
+def test_split_triangles_same_hits_tighter_tree(oracle, small_scene, layout, budget):
+    """A tree over split references reports exactly the records of the tree over whole triangles (a triangle named by several leaves is
+    the same triangle), names every triangle, no triangle twice in one leaf, and stays within the budget."""
+    verts = _rotated(small_scene)                       # walls off the axes: the geometry splitting exists for
+    n_tris = verts.shape[0] // 3
+    plain = tb.HostBVH(verts, tb.LAYOUT_BVH2_WALD, max_leaf_tris=4)
+    h = tb.HostBVH(verts, layout, split_budget=budget)
+    nodes, idx = h.bvh2_nodes(), h.bvh2_prim_idx()
+    assert n_tris <= idx.shape[0] <= int(n_tris * (1 + budget)) + 1
+    assert idx.max() < n_tris and np.unique(idx).shape[0] == n_tris
+    leaves = nodes[nodes[:, 7] > 0]
+    assert int(leaves[:, 7].sum()) == idx.shape[0]      # primIdx has no holes
+    for lf, tc in zip(leaves[:, 3], leaves[:, 7]):
+        assert np.unique(idx[lf:lf + tc]).shape[0] == tc
+    if budget >= 0.3:
+        assert idx.shape[0] > n_tris                    # large rotated wall triangles do get split
+    eye, view = scenes.SPONZA_CAMERAS[0]
+    cam_rays = R.primary(R.camera(tuple(_rotated(np.asarray([list(eye) + [0]], np.float32))[0, :3]), tuple(_rotated(np.asarray([list(view) + [0]], np.float32))[0, :3]), 96, 64, 1, 1))
+    for rays in (cam_rays, R.random_rays(8000, verts[:, :3].min(0), verts[:, :3].max(0), seed=2)):
+        want = oracle.bvh2_intersect(plain.bvh2_nodes(), plain.bvh2_prim_idx(), verts, rays)
+        got2 = oracle.bvh2_intersect(nodes, idx, verts, rays)
+        if layout == tb.LAYOUT_BVH_GPU:
+            got = oracle.bvhgpu_intersect(h.blob(0, np.uint32, 16), h.blob(1, np.uint32, 1), verts, rays)
+        elif layout == tb.LAYOUT_BVH4_GPU:
+            got = oracle.bvh4_intersect(h.blob(0, np.uint32, 4), rays)
+        else:
+            got = oracle.cwbvh_intersect(h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4), rays)
+        for g in (got2, got):
+            c = compare_hits(g, want)
+            assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] == 0, c
+            assert c["bit_identical"] == c["same_prim"], c
+        assert (want["t"] < 1e30).sum() > 1000
+
+
+def test_split_triangles_reduce_box_area_of_long_diagonal_triangles():
+    """The point of it: a few long diagonal triangles among many small ones (the classic case for spatial splits) — the summed leaf box
+    area, what a random ray's triangle tests are proportional to, drops several-fold; the small triangles are left alone."""
+    def leaf_area(h):
+        n = h.bvh2_nodes(); f = n.view(np.float32)
+        lv = n[:, 7] > 0
+        e = f[lv, 4:7] - f[lv, 0:3]
+        return float(((e[:, 0] * e[:, 1] + e[:, 1] * e[:, 2] + e[:, 2] * e[:, 0]) * n[lv, 7]).sum())
+    rng = np.random.default_rng(4)
+    small = scenes.soup(20_000, seed=7, extent=10.0, size=0.05).reshape(-1, 3, 4)
+    a = rng.random((40, 3), dtype=np.float32) * 10
+    d = (rng.random((40, 3), dtype=np.float32) - 0.5) * 16
+    w = (rng.random((40, 3), dtype=np.float32) - 0.5) * 0.4
+    big = np.zeros((40, 3, 4), np.float32); big[:, 0, :3] = a; big[:, 1, :3] = a + d; big[:, 2, :3] = a + d * 0.5 + w
+    verts = np.concatenate([small, big]).reshape(-1, 4)
+    h0, h1 = tb.HostBVH(verts, tb.LAYOUT_BVH2_WALD, max_leaf_tris=1), tb.HostBVH(verts, tb.LAYOUT_BVH2_WALD, max_leaf_tris=1, split_budget=0.3)
+    assert leaf_area(h1) < 0.4 * leaf_area(h0), (leaf_area(h0), leaf_area(h1))
+    idx = h1.bvh2_prim_idx()
+    counts = np.bincount(idx, minlength=verts.shape[0] // 3)
+    assert counts[20_000:].min() > 8 and (counts[:20_000] > 1).mean() < 0.25   # the budget goes to the long triangles
+
+
+def test_split_triangles_degenerate_inputs():
+    one = np.array([[0, 0, 0, 0], [4, 3, 2, 0], [1, 5, 7, 0]], np.float32)
+    h = tb.HostBVH(one, tb.LAYOUT_CWBVH, split_budget=2.0)
+    assert np.unique(h.bvh2_prim_idx()).tolist() == [0]
+    flat = np.zeros((30, 4), np.float32)                 # ten zero-area triangles at the origin: nothing to split, nothing to crash on
+    h = tb.HostBVH(flat, tb.LAYOUT_CWBVH, split_budget=0.5)
+    assert sorted(np.unique(h.bvh2_prim_idx()).tolist()) == list(range(10))

@@ -176,13 +176,15 @@ class HostBVH:
     """Blobs built on the host by the library's own builder (tbvh_host_build)."""
 
     def __init__(self, verts: np.ndarray, layout: int, bins: int = 0, max_leaf_tris: int = 0, threads: int = 0,
-                 optimal_collapse: bool = False, c_prim: float = 0.0, greedy_collapse: bool = False):
+                 optimal_collapse: bool = False, c_prim: float = 0.0, greedy_collapse: bool = False, split_budget: float = 0.0):
         verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 4)
         assert verts.shape[0] % 3 == 0
         self.verts = verts
         self.n_tris = verts.shape[0] // 3
         self.layout = layout
         flags = (2 if optimal_collapse else 0) | (4 if greedy_collapse else 0) | (int(round(c_prim * 100)) << 8)
+        if split_budget > 0:   # TBVH_BUILD_SPLIT_TRIANGLES, budget in per cent of the triangle count
+            flags |= 8 | (min(max(int(round(split_budget * 100)), 1), 255) << 24)
         bp = BuildParams(bins, max_leaf_tris, threads, flags)
         h = C.c_void_p()
         check(lib.tbvh_host_build(_ptr(verts), self.n_tris, layout, C.byref(bp), C.byref(h)), "tbvh_host_build")

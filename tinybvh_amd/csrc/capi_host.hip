@@ -30,7 +30,8 @@ int tbvh_host_build(const void* verts16, uint64_t nTris, int layout, const tbvh_
         bp.bins = p->bins ? p->bins : 8; bp.threads = p->threads; bp.maxLeafTris = p->max_leaf_tris;
         if (p->flags & TBVH_BUILD_OPTIMAL_COLLAPSE) bp.greedyCollapse = false;
         if (p->flags & TBVH_BUILD_GREEDY_COLLAPSE) bp.greedyCollapse = true;
-        if (p->flags >> 8) bp.cPrim = (float)((p->flags >> 8) & 0xffff) * 0.01f;
+        if ((p->flags >> 8) & 0xffff) bp.cPrim = (float)((p->flags >> 8) & 0xffff) * 0.01f;
+        if (p->flags & TBVH_BUILD_SPLIT_TRIANGLES) bp.splitBudget = (p->flags >> 24) ? (float)(p->flags >> 24) * 0.01f : 0.3f;
     }
     if (!bp.maxLeafTris) bp.maxLeafTris = layout == TBVH_LAYOUT_CWBVH ? (bp.greedyCollapse ? 3 : 1) : 4;
     if (layout == TBVH_LAYOUT_CWBVH && bp.maxLeafTris > 3) bp.maxLeafTris = 3;

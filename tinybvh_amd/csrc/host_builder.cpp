@@ -415,7 +415,186 @@ uint32_t usable_host_threads() {
     return std::max(1u, n);
 }
 
+// ---- triangle splitting ahead of the build (BuildParams::splitBudget) --------------------------------------------------
+// What BVH::BuildHQ's spatial splits are for (tiny_bvh.h:2623-3040, 8614-8795: Stich et al. 2009, a reference-duplicating
+// split evaluated per node and only where the children overlap by more than 1e-4 of the root's area): triangles whose boxes
+// are mostly empty — large ones off the coordinate axes — make every box above them loose.  Here the duplication happens BEFORE
+// the build and the builder stays the in-place binned-SAH sweep over boxes: every triangle gets a share of a global budget of
+// extra references by how much box it wastes and how high up in the tree the waste sits (after Karras & Aila 2013, §4.3:
+// priority = cbrt(2^-level * (A_box - A_ideal)), level = the most important spatial-median plane of the scene box that cuts
+// the triangle's box), and is cut along such median planes into that many pieces, each reference carrying the box of its
+// clipped piece.  primIdx then names a triangle once per leaf it ended up in (the format allows that; BuildHQ emits the same).
+namespace {
+
+struct SplitGrid {   // the scene box and its binary subdivision: plane j * 2^-level along each axis
+    float mn[3], ext[3];
+    static constexpr int kBits = 22;
+    uint32_t cell(int a, float x) const {
+        const float r = ext[a] > 0 ? (x - mn[a]) / ext[a] : 0.f;
+        const float c = std::min(std::max(r, 0.f), 1.f) * (float)(1u << kBits);
+        return std::min((uint32_t)c, (1u << kBits) - 1u);
+    }
+    // the most important plane cutting [lo, hi] on axis a: level (1 = the scene's middle, kBits + 1 = none) and position
+    int plane(int a, float lo, float hi, float& pos) const {
+        const uint32_t cl = cell(a, lo), ch = cell(a, hi);
+        if (cl == ch) return kBits + 1;
+        const int msb = 31 - __builtin_clz(cl ^ ch);
+        const uint32_t k = (ch >> msb) << msb;            // first cell right of the plane
+        pos = mn[a] + ext[a] * ((float)k / (float)(1u << kBits));
+        if (!(pos > lo && pos < hi)) return kBits + 1;    // rounding put the plane on or outside the box: nothing to cut
+        return kBits - msb;
+    }
+};
+
+struct Poly { float v[10][3]; int n; };
+
+// Sutherland-Hodgman against the plane x[a] = pos: `in` -> the part on the low side and the part on the high side
+void clip_poly(const Poly& in, int a, float pos, Poly& lo, Poly& hi) {
+    lo.n = hi.n = 0;
+    for (int i = 0; i < in.n; i++) {
+        const float* p = in.v[i]; const float* q = in.v[(i + 1) % in.n];
+        const bool pl = p[a] <= pos, ph = p[a] >= pos;
+        if (pl && lo.n < 10) std::memcpy(lo.v[lo.n++], p, 12);
+        if (ph && hi.n < 10) std::memcpy(hi.v[hi.n++], p, 12);
+        if ((p[a] < pos && q[a] > pos) || (p[a] > pos && q[a] < pos)) {
+            const float t = (pos - p[a]) / (q[a] - p[a]);
+            float x[3];
+            for (int k = 0; k < 3; k++) x[k] = p[k] + t * (q[k] - p[k]);
+            x[a] = pos;
+            if (lo.n < 10) std::memcpy(lo.v[lo.n++], x, 12);
+            if (hi.n < 10) std::memcpy(hi.v[hi.n++], x, 12);
+        }
+    }
+}
+
+// box of a clipped piece: its vertices, widened by a few ulps of the coordinates involved off the cut axis (the cut points are rounded
+// results; a box must never be smaller than the exact piece), and never beyond the box of the piece it was cut from
+Box piece_box(const Poly& p, const Box& parent, const float* pad) {
+    Box b; b.reset();
+    for (int i = 0; i < p.n; i++) b.grow(p.v[i]);
+    for (int a = 0; a < 3; a++) {
+        b.mn[a] = std::max(b.mn[a] - pad[a], parent.mn[a]);
+        b.mx[a] = std::min(b.mx[a] + pad[a], parent.mx[a]);
+    }
+    return b;
+}
+
+void split_piece(const SplitGrid& g, const Poly& poly, const Box& box, uint32_t splits, uint32_t tri, const float* pad,
+                 std::vector<Prim>& prims, std::vector<uint32_t>& refTri) {
+    if (splits > 0 && poly.n >= 3) {
+        int bestA = -1, bestLevel = SplitGrid::kBits + 1; float bestPos = 0, bestExt = -1;
+        for (int a = 0; a < 3; a++) {
+            float pos; const int lv = g.plane(a, box.mn[a], box.mx[a], pos);
+            const float e = box.mx[a] - box.mn[a];
+            if (lv < bestLevel || (lv == bestLevel && lv <= SplitGrid::kBits && e > bestExt)) bestLevel = lv, bestA = a, bestPos = pos, bestExt = e;
+        }
+        if (bestA >= 0 && bestLevel <= SplitGrid::kBits) {
+            Poly lo, hi;
+            clip_poly(poly, bestA, bestPos, lo, hi);
+            if (lo.n >= 3 && hi.n >= 3) {
+                Box pl = box, ph = box; pl.mx[bestA] = bestPos; ph.mn[bestA] = bestPos;
+                const Box bl = piece_box(lo, pl, pad), bh = piece_box(hi, ph, pad);
+                auto longest = [](const Box& b) { return std::max(std::max(b.mx[0] - b.mn[0], b.mx[1] - b.mn[1]), b.mx[2] - b.mn[2]); };
+                const float wl = longest(bl), wh = longest(bh);
+                const uint32_t rest = splits - 1;
+                uint32_t sl = wl + wh > 0 ? (uint32_t)((float)rest * wl / (wl + wh) + 0.5f) : rest / 2;
+                if (sl > rest) sl = rest;
+                split_piece(g, lo, bl, sl, tri, pad, prims, refTri);
+                split_piece(g, hi, bh, rest - sl, tri, pad, prims, refTri);
+                return;
+            }
+        }
+    }
+    Prim pr; pr.box = box;
+    for (int a = 0; a < 3; a++) pr.c[a] = 0.5f * (box.mn[a] + box.mx[a]);
+    prims.push_back(pr); refTri.push_back(tri);
+}
+
+// prims / refTri: one entry per reference (>= one per triangle), in triangle order
+void presplit(const Vec4* verts, uint32_t triCount, float budgetFrac, std::vector<Prim>& prims, std::vector<uint32_t>& refTri) {
+    Box scene; scene.reset();
+    for (size_t i = 0; i < (size_t)triCount * 3; i++) scene.grow(&verts[i].x);
+    SplitGrid g;
+    float pad[3];
+    for (int a = 0; a < 3; a++) {
+        g.mn[a] = scene.mn[a]; g.ext[a] = scene.mx[a] - scene.mn[a];
+        pad[a] = 4e-7f * std::max(std::max(std::fabs(scene.mn[a]), std::fabs(scene.mx[a])), g.ext[a]);
+    }
+    std::vector<float> prio(triCount);
+    std::vector<Box> boxes(triCount);
+    for (uint32_t i = 0; i < triCount; i++) {
+        const Vec4* v = verts + 3 * (size_t)i;
+        Box b; b.reset();
+        for (int k = 0; k < 3; k++) b.grow(&v[k].x);
+        boxes[i] = b;
+        int level = SplitGrid::kBits + 1;
+        for (int a = 0; a < 3; a++) { float pos; level = std::min(level, g.plane(a, b.mn[a], b.mx[a], pos)); }
+        float p = 0.f;
+        if (level <= SplitGrid::kBits) {
+            const float e1[3] = {v[1].x - v[0].x, v[1].y - v[0].y, v[1].z - v[0].z}, e2[3] = {v[2].x - v[0].x, v[2].y - v[0].y, v[2].z - v[0].z};
+            const float cx = e1[1] * e2[2] - e1[2] * e2[1], cy = e1[2] * e2[0] - e1[0] * e2[2], cz = e1[0] * e2[1] - e1[1] * e2[0];
+            const float ideal = std::fabs(cx) + std::fabs(cy) + std::fabs(cz);    // twice the triangle's three axis projections: the box area a flat triangle needs
+            const float waste = 2.f * b.halfArea() - ideal;
+            // (exponents 1/2, 2/3 and 1, with and without the level term, measured on the rotated street: node visits + triangle tests per ray within
+            // 1 % of each other, profiles/r05_rotated.txt — the published rule stays)
+            if (waste > 0 && std::isfinite(waste)) p = std::cbrt(std::ldexp(waste, -level));
+        }
+        prio[i] = p;
+    }
+    // the scale D with sum floor(D * prio) <= budget, by bisection
+    const double budget = std::max(0.0, (double)budgetFrac) * (double)triCount;
+    double sum = 0; for (uint32_t i = 0; i < triCount; i++) sum += prio[i];
+    auto total = [&](double D) { double t = 0; for (uint32_t i = 0; i < triCount; i++) t += std::floor(D * (double)prio[i]); return t; };
+    double lo = 0, hi = sum > 0 ? 2.0 * budget / sum + 1.0 : 0;
+    while (hi > 0 && total(hi) <= budget && hi < 1e30) hi *= 2;
+    for (int it = 0; it < 40 && hi > 0; it++) { const double mid = 0.5 * (lo + hi); if (total(mid) <= budget) lo = mid; else hi = mid; }
+    prims.clear(); refTri.clear();
+    prims.reserve((size_t)triCount + (size_t)budget + 16); refTri.reserve(prims.capacity());
+    for (uint32_t i = 0; i < triCount; i++) {
+        const uint32_t s = (uint32_t)std::min(std::floor(lo * (double)prio[i]), 4096.0);
+        if (s == 0) {
+            Prim pr; pr.box = boxes[i];
+            for (int a = 0; a < 3; a++) pr.c[a] = 0.5f * (pr.box.mn[a] + pr.box.mx[a]);
+            prims.push_back(pr); refTri.push_back(i);
+            continue;
+        }
+        Poly poly; poly.n = 3;
+        for (int k = 0; k < 3; k++) { poly.v[k][0] = verts[3 * (size_t)i + k].x; poly.v[k][1] = verts[3 * (size_t)i + k].y; poly.v[k][2] = verts[3 * (size_t)i + k].z; }
+        split_piece(g, poly, boxes[i], s, i, pad, prims, refTri);
+    }
+}
+
+// after a build over references: primIdx names triangles again, a leaf names each of its triangles once, no holes in primIdx
+void refs_to_triangles(BVH2& bvh, const std::vector<uint32_t>& refTri) {
+    std::vector<uint32_t> leaves;
+    for (uint32_t n = 0; n < (uint32_t)bvh.nodes.size(); n++) if (bvh.nodes[n].leaf()) leaves.push_back(n);
+    std::sort(leaves.begin(), leaves.end(), [&](uint32_t a, uint32_t b) { return bvh.nodes[a].leftFirst < bvh.nodes[b].leftFirst; });
+    std::vector<uint32_t> out; out.reserve(bvh.primIdx.size());
+    for (const uint32_t n : leaves) {
+        Node2& nd = bvh.nodes[n];
+        const uint32_t first = (uint32_t)out.size();
+        for (uint32_t j = 0; j < nd.triCount; j++) {
+            const uint32_t t = refTri[bvh.primIdx[nd.leftFirst + j]];
+            bool dup = false;
+            for (uint32_t k = first; k < (uint32_t)out.size(); k++) if (out[k] == t) { dup = true; break; }
+            if (!dup) out.push_back(t);
+        }
+        nd.leftFirst = first; nd.triCount = (uint32_t)out.size() - first;
+    }
+    bvh.primIdx.swap(out);
+}
+
+}  // namespace
+
 void build_bvh2(const Vec4* verts, uint32_t triCount, const BuildParams& p, BVH2& out) {
+    if (p.splitBudget > 0 && triCount > 0) {
+        std::vector<Prim> prims; std::vector<uint32_t> refTri;
+        presplit(verts, triCount, p.splitBudget, prims, refTri);
+        buildFromPrims(prims, p, out);
+        refs_to_triangles(out, refTri);
+        out.triCount = triCount;
+        return;
+    }
     std::vector<Prim> prims(triCount);
     for (uint32_t i = 0; i < triCount; i++) {
         Prim& pr = prims[i];

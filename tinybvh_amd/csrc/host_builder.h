@@ -41,11 +41,12 @@ struct BuildParams {
     uint32_t threads = 0;
     bool greedyCollapse = true;   // wide layouts: surface-area-greedy collapse (default; measured faster on the GPU) or the SAH-optimal one
     float cPrim = 0.3f;           // cost of one triangle test relative to one wide-node visit (optimal collapse)
+    float splitBudget = 0.f;      // > 0: triangle splitting ahead of the build, up to splitBudget * triCount extra references (host_builder.cpp: presplit)
 };
 
 struct BVH2 {
     std::vector<Node2> nodes;       // root = 0, siblings adjacent
-    std::vector<uint32_t> primIdx;  // permutation of [0, triCount)
+    std::vector<uint32_t> primIdx;  // permutation of [0, triCount); with BuildParams::splitBudget a triangle may be named by several leaves
     uint32_t triCount = 0;
 };
 

@@ -39,8 +39,8 @@ constexpr int WG = 64;
 // Coherence of a batch: of kProbePairs pairs of neighbouring rays spread over the batch, how many agree in direction (camera rays and shadow
 // rays towards one light: almost all; bounce rays: almost none) AND start close to each other measured by how far they reach (shadow rays of a
 // path tracer's later depths all point at the light but start all over the scene: they walk different subtrees — the incoherent flavor traces
-// them 6-9 % faster; a ray that may reach infinitely far has no such measure and counts by its direction alone).  Wave-uniform result, the same
-// in every wave of the launch.
+// them 6-9 % faster; a ray that may reach infinitely far has no such measure and counts by its direction alone).  Wave-uniform result; the same
+// in every wave of a launch whose rays' t does not change under it (fresh and any-hit launches; see the note at the call).
 constexpr uint32_t kProbePairs = 256;
 __device__ __forceinline__ void coherence_sample(const RayRec* __restrict__ rays, uint64_t n, bool fresh, float freshTmax, uint32_t& agree, uint32_t& pairs) {
     const uint64_t stride = n / kProbePairs > 2 ? n / kProbePairs : 2;
@@ -65,8 +65,8 @@ __device__ __forceinline__ void coherence_sample(const RayRec* __restrict__ rays
     }
 }
 
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, int STATS = 0, int NSTRIDE = 5, int PROBED = 0, int STEAL = 0, int MINW = 8>
-__global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, int STATS = 0, int NSTRIDE = 5, int PROBED = 0, int STEAL = 0, int MINW = 8, int TRI2 = 0>
+__global__ __launch_bounds__(WG, (STEAL || TRI2) ? MINW : 1) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
     const uint32_t glane = blockIdx.x * WG + threadIdx.x;
@@ -82,28 +82,33 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
     // towards one light) are VALU-bound and run deferred triangles + a gated triangle phase on a third more waves; incoherent ones are bound by
     // the cache-miss path and keep the strict schedule.  PROBED == 1: this kernel holds both schedules (waves beyond q.baseBlocks leave at once
     // when the batch is incoherent; with baseBlocks == 0 the kernel serves coherent batches only).  PROBED == 2: the INCOHERENT flavor of a probed
-    // launch (capi.hip launches the two back to back, the one the verdict is not for costs ~10 us): strict schedule, leaves at once when the batch
-    // is coherent, and reads what an incoherent batch is bound by in its cheapest form — the priority-ordered node copy whose deep nodes have a
+    // launch (capi.hip launches the two back to back, the one the verdict is not for costs ~10 us): strict schedule, finds the ray pool dry when the
+    // coherent flavor ahead of it took the batch, and reads what an incoherent batch is bound by in its cheapest form — the priority-ordered node copy whose deep nodes have a
     // line each (NSTRIDE = kNodeHybrid), triangle records padded to 64 bytes (none straddles a line), ray records with the non-temporal hint
     // (read once by one CU: they should not displace tree lines in the L2s).
     bool coh = false;
     if (PROBED && q.probe) {
         // The probe runs IN the traversal kernel (round 4; until then a 16-workgroup launch of its own ahead of the traversal kernels: one more
         // launch latency per query on the host's critical path): every wave compares the directions of the same kProbePairs neighbouring ray
-        // pairs spread over the batch — 8 loads per lane from 32 KB that the first waves leave in the L2s — so all waves reach the same verdict
-        // without a counter to wait on.  The coherent flavor (launched first) publishes the two counts for the incoherent flavor behind it in the
-        // stream and for tbvh_debug_last_probe.
-        uint32_t agree, pairs;
-        if (PROBED == 2) { agree = q.probe[0]; pairs = q.probe[1]; }
-        else {
+        // pairs spread over the batch — 8 loads per lane from 32 KB that the first waves leave in the L2s — without a counter to wait on.  The
+        // coherent flavor (launched first) publishes block 0's two counts for tbvh_debug_last_probe.
+        // NOT launch-uniform in one case, and nothing may depend on it being so: a closest-hit launch that is not `fresh` reads the rays' own
+        // hit.x as their reach while earlier waves of the same launch are already writing hit distances there — a pair that counted by its
+        // direction alone (reach 1e30) can fail the origin test once one of its rays has been hit, so a late wave may vote "incoherent" where an
+        // early one voted "coherent" (parallel rays from scattered origins: an orthographic camera, sun shadow rays traced with Intersect).
+        // The verdict therefore only ever picks a SCHEDULE; which rays get traced is the ray pool's business alone: a wave of the coherent
+        // flavor that votes "incoherent" leaves its stripe's remaining chunks in the pool, and the incoherent flavor behind it in the stream
+        // (PROBED == 2) never looks at the verdict — it draws from the same counters and finds them dry (one atomic per wave) exactly when the
+        // coherent flavor traced everything.
+        uint32_t agree = 0, pairs = 0;
+        if (PROBED != 2) {
             coherence_sample(q.rays, nRaysTotal, q.fresh != 0u, q.freshTmax, agree, pairs);
             if (blockIdx.x == 0 && threadIdx.x == 0) { q.probe[0] = agree; q.probe[1] = pairs; }
         }
         coh = (pairs != 0 && agree * 10u >= pairs * 6u) || (q.flags & 16u) != 0;   // (flag 16: tbvh_set_variant 91 forces the coherent verdict — tests)
-        if (PROBED == 2) { if (coh) return; }
-        else if (PROBED == 3 || PROBED == 4) { if (!coh) return; }   // the coherent flavor of a two-kernel launch: 3 = deferred + gated schedule only (SPEC = true); 4 = the strict
-                                                                     // schedule for coherent batches too (scenes where deferral loses: the per-scene tuner of capi_query.hip picks)
-        else if (!coh && blockIdx.x >= q.baseBlocks) return;
+        if (PROBED == 3 || PROBED == 4) { if (!coh) return; }   // the coherent flavor of a two-kernel launch: 3 = deferred + gated schedule only (SPEC = true); 4 = the strict
+                                                                // schedule for coherent batches too (scenes where deferral loses: the per-scene tuner of capi_query.hip picks)
+        else if (PROBED == 1 && !coh && blockIdx.x >= q.baseBlocks) return;   // (the surplus waves of a one-kernel launch: the base grid covers every stripe)
     }
     const uint32_t hybridK = q.hybridK;
 #ifdef TBVH_EXPERIMENTS
@@ -207,18 +212,31 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
             if (STATS == 1) { const unsigned long long m = __ballot(true); if (lane_rank(m) == 0) { sTriIter++; sTri += __popcll(m); } }
             const uint32_t ti = 31u - (uint32_t)__clz(tg.y);
             tg.y &= ~(1u << ti);
-            const float4* tp;
-            if (NSTRIDE == kNodeHybrid)   // the hybrid copy's triangle word: embedded << 27 | first 64-byte record; the embedded triangle sits in the node's own line
-                tp = ti == (tg.x >> 27) ? nodes + ((size_t)tgn + 5u) : tris + ((size_t)(tg.x & 0x07FFFFFFu) + ti) * 4u;
-            else
-                tp = tris + (tri64 ? (size_t)((__umulhi(tg.x, 0xAAAAAAABu) >> 1) + ti) * 4u : (size_t)tg.x + ti * 3u);   // (experiment) records padded to 64 bytes: tg.x counts float4s of the packed array
+            auto record = [&](uint32_t k) -> const float4* {
+                if (NSTRIDE == kNodeHybrid)   // the hybrid copy's triangle word: embedded << 27 | first 64-byte record; the embedded triangle sits in the node's own line
+                    return k == (tg.x >> 27) ? nodes + ((size_t)tgn + 5u) : tris + ((size_t)(tg.x & 0x07FFFFFFu) + k) * 4u;
+                return tris + (tri64 ? (size_t)((__umulhi(tg.x, 0xAAAAAAABu) >> 1) + k) * 4u : (size_t)tg.x + k * 3u);   // (experiment) records padded to 64 bytes: tg.x counts float4s of the packed array
+            };
+            const float4* tp = record(ti);
             const float4 e2 = tp[0], e1 = tp[1], v0 = tp[2];
+            // TRI2 (experiment, round 5): a lane whose group holds a second triangle tests it in the SAME pass — all six loads out together, two tests
+            // one after the other —, so a 2- or 3-triangle group costs the lane one pass less in which it sits out the node phase
+            // (traverse_cwbvh.cl:289-327 tests a group's triangles in one loop).  Front-most bit first, as the mirror does; the tie rule makes the
+            // order immaterial for the record.
+            const bool two = TRI2 && tg.y != 0;
+            float4 f2 = make_float4(0, 0, 0, 0), f1 = f2, w0 = f2;
+            if (two) {
+                const uint32_t tj = 31u - (uint32_t)__clz(tg.y);
+                tg.y &= ~(1u << tj);
+                const float4* tq = record(tj);
+                f2 = tq[0]; f1 = tq[1]; w0 = tq[2];
+            }
             // The strict schedule: all three loads of the record issue together.  Left alone the compiler sinks v0's load into the branch behind the
             // determinant test — one load fewer for a lane whose triangle is edge-on, a second memory round trip for every other one.  Bounce rays
             // +7 % on the Bistro and Sponza stand-ins, +7-10 % on 12 M triangles, camera and shadow rays +-1 % (profiles/r04_ab_triangle_loads_together.txt).
             // The deferred + gated schedule keeps the lazy load: -2 % with the loads together (its triangle phases are full of L2 hits, the saved
             // registers are worth more).
-            if (!SPEC && PROBED != 1) tri_loads_together(v0);
+            if (!SPEC && PROBED != 1) { tri_loads_together(v0); if (TRI2) tri_loads_together(w0); }
             TriHit h;
             if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w)) &&
                 (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), found, hit))) {   // (a split ray's group arbitrates: split_publish)
@@ -226,6 +244,15 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
                 if (ANYHIT) done = true;
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
                 if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
+            }
+            if (TRI2 && two && !(ANYHIT && done)) {
+                if (tri_test(O, D, xyz(w0), xyz(f1), xyz(f2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(w0.w)) &&
+                    (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(w0.w), found, hit))) {
+                    found = true;
+                    if (ANYHIT) done = true;
+                    else hit = make_float4(h.t, h.u, h.v, w0.w);
+                    if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
+                }
             }
             if ((SPEC || PROBED == 1) && tg.y == 0) { tg = tg2; tg2 = make_uint2(0u, 0u); }
         }
@@ -290,11 +317,11 @@ __global__ __launch_bounds__(WG, STEAL ? MINW : 1) void k_cwbvh(const float4* __
     }
 }
 
-template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, int STATS = 0, int NSTRIDE = 5, int PROBED = 0, int STEAL = 0, int MINW = 8>
+template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, int STATS = 0, int NSTRIDE = 5, int PROBED = 0, int STEAL = 0, int MINW = 8, int TRI2 = 0>
 void launch_k(const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
     // without opacity micromaps on the scene the check is compiled out (+1-2 %)
-    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE, PROBED, STEAL, MINW>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
-    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE, PROBED, STEAL, MINW>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    if (q.omm.map) hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, true, STATS, NSTRIDE, PROBED, STEAL, MINW, TRI2>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
+    else hipLaunchKernelGGL((k_cwbvh<ANYHIT, LDS_N, REFILL_MIN, TRI_MIN, SPEC, false, STATS, NSTRIDE, PROBED, STEAL, MINW, TRI2>), dim3(blocks), dim3(WG), 0, s, nodes, tris, q, status);
 }
 
 __global__ void k_pad_nodes(const float4* __restrict__ src, float4* __restrict__ dst, uint32_t nNodes) {
@@ -393,6 +420,14 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
         if (tail) TBVH_K(8, 16, 1, false, 0, 8, 0, 16);
         else TBVH_K(8, 16, 1, false, 0, 8);
     } else if (nodeStride == kNodeHybrid) {   // the incoherent flavor of a probed launch: `nodes` = the hybrid copy, `tris` = the 64-byte records (cwbvh_node.h, capi.hip)
+#ifdef TBVH_EXPERIMENTS
+        if (q.flags & 0x10000u) {   // round 5: up to two triangle tests per pass (debug flag 0x10000, + 0x20000: built for 7 waves per SIMD instead of 6)
+            if (tail) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 16, 6, 1);
+            else if (q.flags & 0x20000u) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 0, 7, 1);
+            else TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 0, 6, 1);
+            return;
+        }
+#endif
         if (tail) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 16, 6);   // (built for 6 waves per SIMD: 80 VGPRs; left alone the compiler takes 83, one wave per SIMD fewer)
         else TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2);
     } else if (q.probe && q.baseBlocks == 0 && (q.flags & 32u)) {   // ... and the same slot of a two-kernel launch with the STRICT schedule (PROBED == 4): coherent batches of

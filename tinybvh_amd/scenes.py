@@ -215,6 +215,35 @@ def street(target_tris: int = 2_832_120, seed: int = 2) -> np.ndarray:
     return v
 
 
+def rotate(verts: np.ndarray, axis: int, angle: float) -> np.ndarray:
+    """`verts` (n, >= 3) rotated about coordinate axis `axis` by `angle` radians (float32 arithmetic, w columns kept)."""
+    c, s = np.float32(np.cos(angle)), np.float32(np.sin(angle))
+    v = verts.copy(); i, j = [(1, 2), (2, 0), (0, 1)][axis]
+    v[:, i], v[:, j] = c * verts[:, i] - s * verts[:, j], s * verts[:, i] + c * verts[:, j]
+    return v
+
+
+STREET_ROT_ANGLES = ((0, 0.6180339887), (1, 0.7548776662))   # (axis, radians): irrational turns about x, then y
+
+
+def street_rot(target_tris: int = 2_832_120, seed: int = 2) -> np.ndarray:
+    """The street with every wall off the coordinate axes: the other end of the range real scenes lie in (large facade and ground triangles
+    get loose boxes; a binned-SAH builder without spatial splits pays for that, tiny_bvh.h:2623-3040 exists for this geometry)."""
+    v = street(target_tris, seed)
+    for ax, ang in STREET_ROT_ANGLES:
+        v = rotate(v, ax, ang)
+    return v
+
+
+def street_rot_camera(k: int = 0):
+    """STREET_CAMERAS[k] carried along with street_rot()'s rotation."""
+    eye, view = STREET_CAMERAS[k]
+    e = np.asarray([list(eye) + [0.0]], np.float32); d = np.asarray([list(view) + [0.0]], np.float32)
+    for ax, ang in STREET_ROT_ANGLES:
+        e, d = rotate(e, ax, ang), rotate(d, ax, ang)
+    return tuple(float(x) for x in e[0, :3]), tuple(float(x) for x in d[0, :3])
+
+
 def blob(target_tris: int = 100_000, seed: int = 3) -> np.ndarray:
     """Dragon stand-in for instancing: a closed, bumpy, finely tessellated surface in
     roughly the unit cube around the origin."""
@@ -255,6 +284,8 @@ def get(name: str):
             v[:, :3] = (v[:, :3] - (lo + hi) * np.float32(0.5)) * np.float32(1.6 / float((hi - lo).max()))
             return v, "bunny.bin (69 630 tris: the stated stand-in for the stripped dragon.bin), recentred, 1.6-unit footprint"
         return blob(), "procedural blob (Dragon stand-in, 100k tris, seed 3)"
+    if name == "street_rot":
+        return street_rot(), "procedural street rotated by irrational angles about two axes (2.83M tris, no axis-aligned wall left)"
     if name.startswith("street") and name.endswith("m"):   # the street generator at another size, e.g. street30m (scene-size sweeps)
         m = float(name[6:-1])
         return street(int(m * 1e6), seed=2), f"procedural street at {m:g} M triangles (seed 2)"
@@ -274,3 +305,13 @@ def view_pyramid(eye, view, aspect_up: float = 0.8):
 
 SPONZA_CAMERAS = [((-15.24, 21.5, 2.54), (0.826, -0.438, -0.356)), ((-34, 5, 11.26), (0.9427, 0.0292, -0.3324)), ((-1.3, 4.96, 12.28), (-0.9886, 0.0507, -0.1419))]
 STREET_CAMERAS = [((-70.0, 1.7, 0.5), (0.995, 0.02, -0.03)), ((10.0, 14.0, -5.0), (0.8, -0.45, 0.4)), ((40.0, 2.0, 2.0), (-0.97, 0.12, 0.05))]
+
+
+def cameras(scene: str):
+    """(eye, view) pairs for a scene name of get(): the speedtest's Sponza cameras for the atrium, street-level cameras for the street
+    generator (rotated along with it for street_rot)."""
+    if scene == "street_rot":
+        return [street_rot_camera(k) for k in range(len(STREET_CAMERAS))]
+    if scene == "bistro" or scene.startswith("street"):
+        return STREET_CAMERAS
+    return SPONZA_CAMERAS

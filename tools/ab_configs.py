@@ -31,7 +31,7 @@ def main():
     ctx = tb.Context(0)
     sc = tb.BVH8_CWBVH(ctx).Build(verts)
     n = a.side * a.side
-    cams = scenes.STREET_CAMERAS if a.scene == "bistro" else scenes.SPONZA_CAMERAS
+    cams = scenes.cameras(a.scene)
     cam = R.camera(*cams[0], a.side, a.side, 1, 1)
     d_prim, d_diff, d_shad = make_batches(ctx, sc, verts, cam, n)
     d_occ = ctx.malloc(n)

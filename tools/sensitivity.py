@@ -43,10 +43,7 @@ def rotv(p, ax, ang):
 def make_scene(name):
     rng = np.random.default_rng(11)
     if name == "street_rot":
-        a1, a2 = 0.6180339887, 0.7548776662
-        v = rot(rot(scenes.street(), 0, a1), 1, a2)
-        eye, view = scenes.STREET_CAMERAS[0]
-        return v, (tuple(rotv(rotv(eye, 0, a1), 1, a2)), tuple(rotv(rotv(view, 0, a1), 1, a2)))
+        return scenes.street_rot(), scenes.street_rot_camera(0)
     if name == "foliage":
         k = 500
         centers = np.stack([rng.uniform(-40, 40, k), rng.uniform(0, 25, k), rng.uniform(-40, 40, k)], -1).astype(np.float32)

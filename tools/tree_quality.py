@@ -3,7 +3,7 @@
 host-builder parameters, counted by the oracle's CWBVH mirror (oracle/tbvh_oracle.c: orc_cwbvh_trace) on ONE fixed set of camera and
 bounce rays of the bench scene.  The bounce kernel's L1 lookups per ray are 5 S + 3 T + 4 (DESIGN.md §5 "Round 4").
 
-usage: tools/tree_quality.py [--scene bistro] [--side 160] name=bins:max_leaf:collapse(0 default, 1 optimal, 2 greedy):c_prim | name=ref | name=refhq ...
+usage: tools/tree_quality.py [--scene bistro] [--side 160] name=bins:max_leaf:collapse(0 default, 1 optimal, 2 greedy):c_prim[:split_budget] | name=ref | name=refhq ...
 """
 import argparse, ctypes as C, os, sys, time
 import numpy as np
@@ -41,7 +41,7 @@ def main():
     h = tb.HostBVH(verts, tb.LAYOUT_CWBVH)
     nodes, tris = h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4)
     orc = Oracle(1)
-    cams = scenes.STREET_CAMERAS if a.scene.startswith(("bistro", "street")) else scenes.SPONZA_CAMERAS
+    cams = scenes.cameras(a.scene)
     prim = R.primary(R.camera(*cams[0], a.side, a.side, 1, 1))
     rng = np.random.default_rng(5)
     h1 = orc.cwbvh_intersect(nodes, tris, prim)
@@ -65,8 +65,9 @@ def main():
             continue
         f = spec.split(":")
         bins, leaf, opt, cp = int(f[0]), int(f[1]), int(f[2]), float(f[3])
+        sb_ = float(f[4]) if len(f) > 4 else 0.0   # triangle split budget (fraction of the triangle count)
         t0 = time.time()
-        hb = tb.HostBVH(verts, tb.LAYOUT_CWBVH, bins=bins, max_leaf_tris=leaf, optimal_collapse=opt == 1, greedy_collapse=opt == 2, c_prim=cp)
+        hb = tb.HostBVH(verts, tb.LAYOUT_CWBVH, bins=bins, max_leaf_tris=leaf, optimal_collapse=opt == 1, greedy_collapse=opt == 2, c_prim=cp, split_budget=sb_)
         dt = time.time() - t0
         n, t = hb.blob(0, np.uint32, 4), hb.blob(1, np.uint32, 4)
         sp, tp = count(orc, n, t, prim)
