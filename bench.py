@@ -65,6 +65,11 @@ def main():
     ap.add_argument("--device-build", action="store_true", help="build the layout on the device (tbvh_build_device: LBVH) instead of the host builder")
     ap.add_argument("--no-hbm-regime", action="store_true", help="skip detail.hbm_regime (the same kernels on a 30 M-triangle scene, beyond the Infinity Cache)")
     ap.add_argument("--hbm-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--ref-ocl", action="store_true", help=argparse.SUPPRESS)   # (scene child: also time the reference's own OpenCL kernel of the layout on the same blobs and rays)
+    ap.add_argument("--tlas-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-rotated", action="store_true", help="skip detail.rotated_scene (the same triangles off the coordinate axes)")
+    ap.add_argument("--no-other-layouts", action="store_true", help="skip detail.other_layouts (BVH_GPU and BVH4_GPU on the headline batches, with the reference's OpenCL kernels and counters)")
+    ap.add_argument("--no-host-rays", action="store_true", help="skip detail.host_rays (tbvh_intersect on a host Ray[])")
     ap.add_argument("--blob-cache", default="", help="BVH8_CWBVH blob file (BVH8_CWBVH::Save format): read if it exists, else written after the host build (child runs of one bench share one build)")
     a = ap.parse_args()
 
@@ -73,6 +78,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     use_dist = world > 1 or bool(os.environ.get("TBVH_BENCH_FORCE_DIST"))  # the env knob exercises the RCCL path on one GPU
+    # `python bench.py --gpus N` WITHOUT torchrun (the driver's plain command line): this one process drives N devices itself — one context,
+    # one BVH replica and one set of batches per device, one host thread enqueueing every device's launches (resolve_devices below)
+    inproc_devices = None
+    if not use_dist and "WORLD_SIZE" not in os.environ and a.gpus > 1 and not (a.pmc_child or a.hbm_child or a.tlas_child):
+        import tinybvh_amd as tb_
+        try:
+            inproc_devices = resolve_devices(a.gpus, tb_.device_count(), os.environ.get("TBVH_BENCH_DEVICE_MAP"))
+        except ValueError as e:
+            print(json.dumps({"metric": "MRays/s (primary + diffuse) on Bistro CWBVH", "value": None, "unit": "MRays/s", "n_gpus": a.gpus, "error": str(e),
+                              "visible_devices": tb_.device_count()}), flush=True)
+            log(f"[bench] {e}")
+            sys.exit(2)
     if use_dist:
         import torch
         import torch.distributed as dist
@@ -81,6 +98,10 @@ def main():
     import tinybvh_amd as tb
     from tinybvh_amd import rays as R
     from tinybvh_amd import scenes
+
+    if a.tlas_child:
+        tlas_child(a, tb, R, scenes)
+        return
 
     def flush_c_stdio():
         # RCCL prints a banner ("Hostname", "Librccl path") through C stdio when the communicator comes up; a pipe holds
@@ -92,6 +113,8 @@ def main():
         except Exception:
             pass
 
+    others_ref = []   # (filled once the other devices of a one-process run exist)
+
     def sync_all():
         if use_dist:
             import torch
@@ -99,6 +122,8 @@ def main():
             torch.cuda.synchronize()
             flush_c_stdio()
         ctx.synchronize()
+        for o_ in others_ref:
+            o_[0].synchronize()
 
     # ---- scene + layout (host build, untimed) ------------------------------------------------
     t0 = time.time()
@@ -144,26 +169,43 @@ def main():
     cams = scenes.cameras(a.scene)
     eye, view = cams[0]   # the same camera on every rank: equal work per GPU, so the N-GPU aggregate measures scaling, not workload differences
     cam = R.camera(eye, view, a.side, a.side, 1, 1)
-    d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
-    d_prim, d_diff, d_shad, d_tmp = (ctx.malloc(n * 64) for _ in range(4))
-    d_occ = ctx.malloc(n)
     ext = float((verts[:, :3].max(0) - verts[:, :3].min(0)).max())
     light = (0.0, 0.9 * float(verts[:, 1].max()), 0.0)
-    third = n // 3
-    ctx.generate_primary(cam, d_prim, 0, n)
-    sc.intersect_device(d_prim, n)
-    ctx.generate_shadow(d_prim, d_shad, n, light, ext * 5e-7)
-    # diffuse batch: thirds of depth 1 / 2 / 3 (wavefront.cl's 3-bounce loop, wavefront.cl:225)
+
+    def make_batches(ctx_, sc_, seed_):
+        """camera rays, bounce rays (thirds of depth 1 / 2 / 3: wavefront.cl's 3-bounce loop, wavefront.cl:225) and shadow rays of one device"""
+        d_verts_ = ctx_.malloc(verts.nbytes); ctx_.to_device(d_verts_, verts)
+        d_prim_, d_diff_, d_shad_, d_tmp_ = (ctx_.malloc(n * 64) for _ in range(4))
+        third = n // 3
+        ctx_.generate_primary(cam, d_prim_, 0, n)
+        sc_.intersect_device(d_prim_, n)
+        ctx_.generate_shadow(d_prim_, d_shad_, n, light, ext * 5e-7)
+        ctx_.generate_bounce(d_verts_, d_prim_, d_tmp_, n, seed_ + 1)          # depth 1 for all
+        # the first third stays at depth 1; the rest is traced and bounced again, in place
+        sc_.intersect_device(d_tmp_ + third * 64, n - third)
+        ctx_.generate_bounce(d_verts_, d_tmp_ + third * 64, d_tmp_ + third * 64, n - third, seed_ + 2)   # depth 2
+        sc_.intersect_device(d_tmp_ + 2 * third * 64, n - 2 * third)
+        ctx_.generate_bounce(d_verts_, d_tmp_ + 2 * third * 64, d_tmp_ + 2 * third * 64, n - 2 * third, seed_ + 3)  # depth 3
+        d_diff_, d_tmp_ = d_tmp_, d_diff_
+        ctx_.reset_hits(d_prim_, n)
+        ctx_.synchronize()
+        return d_verts_, d_prim_, d_diff_, d_shad_, d_tmp_
+
     seed = 1000 * (rank + 1)
-    ctx.generate_bounce(d_verts, d_prim, d_tmp, n, seed + 1)          # depth 1 for all
-    # the first third stays at depth 1; the rest is traced and bounced again, in place
-    sc.intersect_device(d_tmp + third * 64, n - third)
-    ctx.generate_bounce(d_verts, d_tmp + third * 64, d_tmp + third * 64, n - third, seed + 2)   # depth 2
-    sc.intersect_device(d_tmp + 2 * third * 64, n - 2 * third)
-    ctx.generate_bounce(d_verts, d_tmp + 2 * third * 64, d_tmp + 2 * third * 64, n - 2 * third, seed + 3)  # depth 3
-    d_diff, d_tmp = d_tmp, d_diff
-    ctx.reset_hits(d_prim, n)
-    ctx.synchronize()
+    d_verts, d_prim, d_diff, d_shad, d_tmp = make_batches(ctx, sc, seed)
+    d_occ = ctx.malloc(n)
+    # the other devices of a one-process N-GPU run: (context, replica, camera batch, bounce batch) each; the blobs are uploaded from the ONE host build
+    others = []
+    if inproc_devices:
+        for k_, dev in enumerate(inproc_devices[1:], start=1):
+            c_ = tb.Context(dev)
+            r_ = tb.BVH8_CWBVH(c_).Upload(sc.host.blob(0, np.uint32, 4), sc.host.blob(1, np.uint32, 4)) if a.layout == tb.LAYOUT_CWBVH else tb.LAYOUT_CLASSES[a.layout](c_).Build(verts)
+            dv_, dp_, dd_, ds_, dt_ = make_batches(c_, r_, 1000 * (k_ + 1))
+            for x_ in (dv_, ds_, dt_):
+                c_.free(x_)
+            others.append((c_, r_, dp_, dd_))
+        others_ref.extend(others)
+        log(f"[bench] one process, {len(inproc_devices)} contexts on devices {inproc_devices}")
 
     if a.pmc_child:   # under rocprofv3 --pmc: 3 preparation launches above, then (primary, diffuse) x 3; nothing else
         for _ in range(3):
@@ -183,25 +225,57 @@ def main():
                 if p_:
                     ms.append(ctx.time_last_ms())
             out[kind + "_ms"] = float(np.mean(ms)); out[kind + "_mrays"] = n / (out[kind + "_ms"] * 1e-3) / 1e6
+        # node visits S and triangle tests T per ray: the oracle's mirror of the layout (tiny_bvh.h:7046-7154 / 5252-5343 / 4657-4712 restated) on a
+        # strided 16 k sample, over the blobs as they are on the device (the tree may have been built there)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_lib import Oracle
+        orc = Oracle()
+        host = getattr(sc, "host", None)
         if a.layout == 10:
-            # node visits S and triangle tests T per ray: the oracle's mirror of the layout (tiny_bvh.h:7046-7154 restated) on a strided 16 k
-            # sample, over the blobs as they are on the device (the tree may have been built there)
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            from oracle_lib import Oracle
-            orc = Oracle()
-            host = getattr(sc, "host", None)
-            nodes, tris = (host.blob(0, np.uint32, 4), host.blob(1, np.uint32, 4)) if host is not None else sc.download_blobs()
-            for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
-                full = np.zeros(n, dtype=tb.RAY_DTYPE); ctx.from_device(full, d)
-                sample = full[:: max(n // 16384, 1)][:16384].copy(); del full
-                sample["t"] = 1e30
-                _, cnt = orc.cwbvh_intersect(nodes, tris, sample, counts=True)
-                out[kind + "_S"] = float(cnt[0]) / sample.shape[0]; out[kind + "_T"] = float(cnt[1]) / sample.shape[0]
+            blobs = [host.blob(0, np.uint32, 4), host.blob(1, np.uint32, 4)] if host is not None else list(sc.download_blobs())
+        elif a.layout == 8:
+            blobs = [host.blob(0, np.uint32, 4)]
+        else:
+            blobs = [host.blob(0, np.uint32, 16), host.blob(1, np.uint32, 1), verts]
+        for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
+            full = np.zeros(n, dtype=tb.RAY_DTYPE); ctx.from_device(full, d)
+            sample = full[:: max(n // 16384, 1)][:16384].copy()
+            sample["t"] = 1e30
+            if a.layout == 10:
+                _, cnt = orc.cwbvh_intersect(blobs[0], blobs[1], sample, counts=True)
+            elif a.layout == 8:
+                _, cnt = orc.bvh4_intersect(blobs[0], sample, counts=True)
+            else:
+                _, cnt = orc.bvhgpu_intersect(blobs[0], blobs[1], verts, sample, counts=True)
+            out[kind + "_S"] = float(cnt[0]) / sample.shape[0]; out[kind + "_T"] = float(cnt[1]) / sample.shape[0]
+            if a.ref_ocl:
+                # the reference's own kernel of this layout (batch_ailalaine traverse_bvh2.cl:209-219 / batch_gpu4way traverse_bvh4.cl:277-286 /
+                # batch_cwbvh traverse_cwbvh.cl:554-570) through ROCm OpenCL: same GPU, same blobs, same batch
+                try:
+                    from oracle_lib import ReferenceOpenCL, compare_hits
+                    ocl = ReferenceOpenCL()
+                    mine = full[:: max(n // 65536, 1)][:65536].copy()
+                    full["t"] = 1e30; full["u"] = 0; full["v"] = 0; full["prim"] = 0
+                    theirs, ref_ms = ocl.run(a.layout, blobs, full, passes=3)
+                    cmp_ = compare_hits(mine, theirs[:: max(n // 65536, 1)][:65536], rtol=1e-4)   # (the .cl kernels use native_recip and strict comparisons: t to 1e-4)
+                    out[kind + "_ref_opencl_mrays"] = theirs.shape[0] / (ref_ms * 1e-3) / 1e6
+                    out[kind + "_ratio"] = ref_ms / out[kind + "_ms"]
+                    out[kind + "_hitmiss_diff"] = int(cmp_["hitmiss"]); out[kind + "_prim_diff"] = int(cmp_["prim_mismatch"])
+                    out["opencl_device"] = ocl.device
+                    del theirs
+                except Exception as e:
+                    out["ref_opencl_error"] = repr(e)[:300]
+            del full
         print(json.dumps(out), flush=True)
         ctx.close()
         return
 
     kern_ms = {"primary": [], "diffuse": [], "shadow": []}
+
+    def sync_all_local():
+        ctx.synchronize()
+        for o_ in others:
+            o_[0].synchronize()
 
     def step():
         # "fresh" = re-arm (hit = {1e30,0,0,0}) fused into the traversal kernel: every step traces
@@ -209,6 +283,9 @@ def main():
         # per-launch HIP-event durations are read ONCE after the loop (tbvh_time_history), as a renderer would enqueue them.
         sc.intersect_device_fresh(d_prim, n, 1e30)
         sc.intersect_device_fresh(d_diff, n, 1e30)
+        for c_, r_, dp_, dd_ in others:     # (asynchronous launches on each context's own stream: one host thread keeps N devices busy)
+            r_.intersect_device_fresh(dp_, n, 1e30)
+            r_.intersect_device_fresh(dd_, n, 1e30)
 
     # the any-hit pass (config "16 M IsOccluded shadow rays") is reported in `detail`; it is not
     # part of the metric's step (primary + diffuse), so it is timed by HIP events only
@@ -232,12 +309,17 @@ def main():
     for i in range(max(a.warmup, 1)):
         step()
         if i % 2:
-            ctx.synchronize()               # (finished launches are what the coherent-schedule tuner learns from; a renderer's frames end likewise)
+            sync_all_local()                # (finished launches are what the coherent-schedule tuner learns from; a renderer's frames end likewise)
     if a.layout == tb.LAYOUT_CWBVH:
         for _ in range(6):                  # untimed: make sure the tuner has decided before the timed region, whatever --warmup was
             if sc.coherent_schedule(False)[0]:
                 break
             sc.intersect_device_fresh(d_prim, n, 1e30); ctx.synchronize()
+        for c_, r_, dp_, dd_ in others:
+            for _ in range(6):
+                if r_.coherent_schedule(False)[0]:
+                    break
+                r_.intersect_device_fresh(dp_, n, 1e30); c_.synchronize()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -264,7 +346,8 @@ def main():
     # ---- config 4 as BASELINE.json words it: ONE 64 M-ray diffuse batch, sharded over the ranks (strong scaling) ------
     strong = None
     km4_local, dm4_local, el4_local = [], [], 0.0
-    if not a.no_strong:
+    n_gpus = len(inproc_devices) if inproc_devices else world
+    if not a.no_strong and not inproc_devices:   # (a one-process N-GPU run shards the batch over its contexts instead: strong_one_process below)
         try:
             from tinybvh_amd.sharding import shard_range
             side4 = 8192 if a.side >= 4096 else 2 * a.side
@@ -319,16 +402,19 @@ def main():
         rows = [[float(x) for x in r.cpu()] for r in rows]
     else:
         rows = [mine]
-    per_gpu = [{"rank": i, "primary_kernel_ms": r[0], "diffuse_kernel_ms": r[1], "step_wall_ms": r[2], "step_dispatch_gap_ms": r[2] - r[0] - r[1],
+        for c_, r_, dp_, dd_ in others:     # the other devices of a one-process run: their own event times of the same timed steps
+            h_ = c_.time_history(2 * min(a.steps, 128))
+            rows.append([float(np.mean(h_[0::2])), float(np.mean(h_[1::2])), elapsed_local / a.steps * 1e3, -1.0, -1.0, 0.0])
+    per_gpu = [{"rank": i, "device": (inproc_devices[i] if inproc_devices else None), "primary_kernel_ms": r[0], "diffuse_kernel_ms": r[1], "step_wall_ms": r[2], "step_dispatch_gap_ms": r[2] - r[0] - r[1],
                 "config4_shard_kernel_ms": r[3] if r[3] >= 0 else None, "config4_host_dispatch_ms": r[4] if r[4] >= 0 else None, "config4_shard_wall_ms": r[5]} for i, r in enumerate(rows)]
 
     # the same batch from ONE process over K devices through the C ABI (tbvh_intersect_sharded_device): K = --one-process-devices, or every
     # visible device when this is a single-process run that sees more than one
     one_proc = None
-    kdev = a.one_process_devices if a.one_process_devices else (tb.device_count() if (world == 1 and tb.device_count() > 1 and a.gpus > 1) else 0)
+    kdev = a.one_process_devices if a.one_process_devices else (len(inproc_devices) if inproc_devices else 0)
     if rank == 0 and world == 1 and kdev >= 2 and not a.no_strong:
         try:
-            one_proc = strong_one_process(tb, R, sc, verts, eye, view, 8192 if a.side >= 4096 else 2 * a.side, kdev, log)
+            one_proc = strong_one_process(tb, R, sc, verts, eye, view, 8192 if a.side >= 4096 else 2 * a.side, kdev, log, devices=inproc_devices)
         except Exception as e:
             log(f"[bench] one-process multi-device batch failed: {e!r}")
 
@@ -449,7 +535,7 @@ def main():
     # ---- results (rank 0) ---------------------------------------------------------------------------
     if rank == 0:
         ms_per_step = elapsed / a.steps * 1e3
-        rays_per_step = 2 * n * world  # primary + diffuse (the metric); shadow reported in detail
+        rays_per_step = 2 * n * n_gpus  # primary + diffuse (the metric); shadow reported in detail
         value = rays_per_step / (elapsed / a.steps) / 1e6
         mean = {k: float(np.mean(v)) for k, v in kern_ms.items()}
         detail = {k + "_mrays": n / (mean[k] * 1e-3) / 1e6 for k in mean}
@@ -466,7 +552,10 @@ def main():
         detail["wavefront_frame_3_bounces"] = wf_detail
         detail["device_side_ops"] = dev_ops
         detail["tlas_1000_instances"] = tlas_detail
-        detail["config4_strong"] = strong
+        detail["config4_strong"] = strong if strong is not None else one_proc
+        if inproc_devices:
+            detail["launch"] = {"how": "one process, one context per device, one host thread enqueues every device's launches (no torchrun, no collective)", "devices": inproc_devices,
+                                "visible_devices": tb.device_count(), "device_map_env": os.environ.get("TBVH_BENCH_DEVICE_MAP")}
         detail["per_gpu"] = per_gpu
         if replication:
             detail["bvh_replication"] = replication
@@ -479,6 +568,30 @@ def main():
         detail["ref_opencl_cwbvh"] = ref_ocl
         if world == 1 and not a.no_hbm_regime and a.layout == 10:
             detail["hbm_regime"] = hbm_regime(a, log)
+        valu_ceiling = None
+        try:
+            valu_ceiling = ctx.valu_issue_ginstr(3)
+        except Exception as e:
+            log(f"[bench] VALU ceiling measurement failed: {e!r}")
+        if world == 1 and not a.no_rotated and a.layout == 10 and a.scene == "bistro":
+            # the other end of the range real scenes lie in: the SAME triangles with every wall off the coordinate axes (review of round 4, item 1)
+            detail["rotated_scene"] = scene_leg(a, log, "street_rot", a.side, 10, False, valu_ceiling,
+                                                note="the bench scene rotated by irrational angles about two axes, same camera carried along; node visits S / triangle tests T per ray from the oracle's mirror: "
+                                                     "the gap to the headline is S and T (boxes of off-axis geometry are mostly empty), for every builder incl. the reference's BuildHQ: profiles/r05_rotated.txt")
+        if world == 1 and not a.no_other_layouts and a.scene == "bistro":
+            detail["other_layouts"] = {name: scene_leg(a, log, a.scene, a.side, lay, True, valu_ceiling, note=f"{kern} on the headline batches next to the reference's {refk} (ROCm OpenCL, same GPU, blobs and rays)")
+                                       for name, lay, kern, refk in (("BVH_GPU", 5, "k_bvh2", "batch_ailalaine (traverse_bvh2.cl:209-219)"), ("BVH4_GPU", 8, "k_bvh4", "batch_gpu4way (traverse_bvh4.cl:277-286)"))}
+        if world == 1 and tlas_detail is not None and not a.no_other_layouts:
+            try:
+                tlas_detail.update(tlas_leg(a, log, valu_ceiling))
+            except Exception as e:
+                log(f"[bench] TLAS leg failed: {e!r}")
+        if rank == 0 and world == 1 and not a.no_host_rays:
+            try:
+                detail["host_rays"] = host_rays_leg(tb, ctx, sc, d_prim, n)
+            except Exception as e:
+                log(f"[bench] host-rays leg failed: {e!r}")
+                detail["host_rays"] = {"error": repr(e)[:300]}
 
         # ---- parity of the timed kernels, in this run (outside the timed region; the oracle is the checker, never the thing measured) -------
         # a strided 65 k sample of the primary and the diffuse batch: the GPU records the timed launches left in HBM against BVH::Intersect
@@ -616,11 +729,11 @@ def main():
 
         out = {
             "metric": "MRays/s (primary + diffuse) on Bistro CWBVH", "value": value, "unit": "MRays/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+            "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}; BVH8_CWBVH; per GPU per step {n} primary + {n} diffuse (depth 1-3) Intersect; + {n} shadow IsOccluded timed separately",
                        "scene_tris": n_tris, "layout": {5: "BVH_GPU", 8: "BVH4_GPU", 10: "BVH8_CWBVH"}[a.layout],
-                       "rays_per_gpu_per_step": 2 * n, "shadow_rays_per_gpu": n, "sharding": f"value: weak — every rank its own {2 * n}-ray step, BVH replicated, no collective; detail.config4_strong: one 64 M-ray batch in {world} contiguous shard(s)"},
+                       "rays_per_gpu_per_step": 2 * n, "shadow_rays_per_gpu": n, "sharding": f"value: weak — every GPU its own {2 * n}-ray step, BVH replicated, no collective; detail.config4_strong: one 64 M-ray batch in {n_gpus} contiguous shard(s)"},
             "parity_checked": bool(parity.get("n")) and "error" not in parity, "parity_ok": bool(parity.get("ok", False)),
             "detail": detail, "roofline": roof, "cpu_baseline": cpu,
         }
@@ -629,6 +742,8 @@ def main():
     sync_all()
     if use_dist:
         dist.destroy_process_group()
+    for c_, r_, dp_, dd_ in others:
+        c_.close()
     ctx.close()
     if rank == 0 and not a.no_parity:
         if "error" in parity:      # the timed kernels were never checked: not a result either
@@ -639,7 +754,7 @@ def main():
             sys.exit(3)
 
 
-def strong_one_process(tb, R, sc0, verts, eye, view, side4, k, log):
+def strong_one_process(tb, R, sc0, verts, eye, view, side4, k, log, devices=None):
     """Config 4's batch (side4 x side4 camera rays, bounced to depths 1-3 in thirds) from ONE process over k contexts — context i on device
     i mod (visible devices) — through tbvh_intersect_sharded_device: the BVH uploaded once per context, every shard generated, traced and kept
     on its device, one host thread enqueueing all launches.  Reports the batch rate, per-device kernel ms and the host dispatch gap."""
@@ -647,7 +762,7 @@ def strong_one_process(tb, R, sc0, verts, eye, view, side4, k, log):
     n_dev = tb.device_count()
     n4 = side4 * side4
     cam4 = R.camera(eye, view, side4, side4, 1, 1)
-    ctxs = [tb.Context(i % n_dev) for i in range(k)]
+    ctxs = [tb.Context(devices[i] if devices else i % n_dev) for i in range(k)]
     try:
         h = sc0.host
         reps = [tb.BVH8_CWBVH(c).Upload(h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4)) for c in ctxs]
@@ -818,6 +933,28 @@ def reference_opencl_headline(tb, ctx, sc, d_prim, d_diff, n, kern_ms, timed_got
     return out
 
 
+def resolve_devices(gpus, visible, device_map=None):
+    """The HIP devices a ONE-PROCESS `--gpus N` run drives (no torchrun): devices 0 .. N-1, or — TBVH_BENCH_DEVICE_MAP="0,0,1,..." — the N listed
+    ones (several contexts may share a device: how a 1-GPU box exercises the N-context path).  Raises ValueError when fewer than N devices are
+    visible and no map covers for it: a 1-GPU number must never be reported under an N-GPU flag."""
+    if gpus < 1:
+        raise ValueError(f"--gpus {gpus}: at least one GPU")
+    if device_map:
+        try:
+            devs = [int(x) for x in device_map.split(",") if x.strip() != ""]
+        except ValueError:
+            raise ValueError(f"TBVH_BENCH_DEVICE_MAP={device_map!r}: a comma-separated list of device indices")
+        if len(devs) != gpus:
+            raise ValueError(f"TBVH_BENCH_DEVICE_MAP lists {len(devs)} devices for --gpus {gpus}")
+        bad = [d for d in devs if d < 0 or d >= visible]
+        if bad:
+            raise ValueError(f"TBVH_BENCH_DEVICE_MAP names device(s) {bad}, {visible} visible")
+        return devs
+    if visible < gpus:
+        raise ValueError(f"--gpus {gpus} but {visible} HIP device(s) visible (launch through torch.distributed.run, or map contexts onto devices with TBVH_BENCH_DEVICE_MAP)")
+    return list(range(gpus))
+
+
 def usable_cores():
     """Host threads this process can really run at once: the affinity mask, cut by the cgroup CPU quota if there is one
     (os.cpu_count() reports the whole machine even inside a container limited to a few cores)."""
@@ -887,6 +1024,230 @@ def hbm_regime(a, log):
         import shutil
         shutil.rmtree(tmpdir, ignore_errors=True)
     return res
+
+
+LAYOUT_BYTES = {10: (80, 48), 8: (64, 48), 5: (64, 52)}   # node bytes, bytes per triangle test (SURVEY par. 8(d))
+
+
+def scene_leg(a, log, scene, side, layout, ref_ocl, valu_ceiling, note=""):
+    """One more (scene, layout) measured like the headline: a child of this script times `side`^2 camera and bounce rays (HIP events) and counts
+    S / T with the oracle's mirror (and, ref_ocl, times the reference's own OpenCL kernel of the layout on the same blobs and rays); two more
+    children under `rocprofv3 --pmc` give the bytes beyond the L2s and the VALU counters of the same launches."""
+    import copy
+    import subprocess
+    import tempfile
+    env = dict(os.environ, TBVH_COHERENT_TUNER="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    tmpdir = tempfile.mkdtemp(prefix="tbvh_leg_", dir="/tmp")
+    b = copy.copy(a)
+    b.scene, b.side, b.device_build, b.layout, b.variant, b.coh_pin = scene, side, False, layout, 0, "0"
+    b.blob_cache = os.path.join(tmpdir, scene + ".cwbvh") if layout == 10 else ""
+    cmd = [sys.executable, os.path.abspath(__file__), "--hbm-child", "--scene", scene, "--side", str(side), "--layout", str(layout)] + \
+          (["--blob-cache", b.blob_cache] if b.blob_cache else []) + (["--ref-ocl"] if ref_ocl else [])
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
+        out = json.loads([l for l in r.stdout.decode().split("\n") if l.startswith("{")][-1])
+        n = out["rays_per_launch"]
+        pm = live_counters(b, log, passes=("FETCH_SIZE", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES")) if not a.no_pmc else None
+        nb, tbytes = LAYOUT_BYTES[layout]
+        row = {"scene": out["scene"], "triangles": out["triangles"], "layout": {5: "BVH_GPU", 8: "BVH4_GPU", 10: "BVH8_CWBVH"}[layout], "bvh_mb": out["bvh_mb"], "rays_per_launch": n,
+               "coherent_schedule": "deferred + gated, pinned (a child is too short for the tuner)" if layout == 10 else None, "note": note}
+        if "opencl_device" in out:
+            row["opencl_device"] = out["opencl_device"]
+        if "ref_opencl_error" in out:
+            row["ref_opencl_error"] = out["ref_opencl_error"]
+        for kind in ("primary", "diffuse"):
+            S, T = out.get(kind + "_S", 0.0), out.get(kind + "_T", 0.0)
+            alg = 80.0 + nb * S + tbytes * T
+            sec = out[kind + "_ms"] * 1e-3
+            k_ = {"mrays": out[kind + "_mrays"], "launch_ms": out[kind + "_ms"], "node_visits_per_ray": S, "triangle_tests_per_ray": T,
+                  "algorithmic_bytes_per_ray": alg, "algorithmic_tb_per_s": alg * n / sec / 1e12}
+            if kind + "_ref_opencl_mrays" in out:
+                k_.update(ref_opencl_mrays=out[kind + "_ref_opencl_mrays"], ratio=out[kind + "_ratio"], hitmiss_diff=out[kind + "_hitmiss_diff"], prim_diff=out[kind + "_prim_diff"])
+            c = (pm or {}).get(kind, {})
+            if "FETCH_SIZE" in c:
+                tr = c["FETCH_SIZE"] * 2048.0
+                k_["fabric"] = {"fetched_bytes_per_ray": tr / n, "achieved_gbps": tr / sec / 1e9, "peak_gbps": 8000.0, "frac": tr / sec / 8e12}
+            if c.get("SQ_INSTS_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
+                rate = c["SQ_INSTS_VALU"] / sec / 1e9
+                lane = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"])
+                k_["valu"] = {"insts_valu_per_ray": c["SQ_INSTS_VALU"] * 64.0 / n, "issue_frac": rate / valu_ceiling if valu_ceiling else None, "lane_utilisation": lane}
+            row[kind] = k_
+        if pm:
+            row["counters_source"] = pm.get("source")
+        return row
+    except Exception as e:
+        log(f"[bench] scene leg ({scene}, layout {layout}) failed: {e!r}")
+        return {"error": repr(e)[:300]}
+    finally:
+        import shutil
+        shutil.rmtree(tmpdir, ignore_errors=True)
+
+
+def config5_setup(tb, R, scenes, ctx, blas_layout):
+    """BASELINE config 5's scene: 1000 instances of the Dragon stand-in (10 x 10 x 10 grid, scale 0.7, seeded rotation), 3840 x 2160 camera rays."""
+    dv, dlabel = scenes.get("dragon")
+    blas = tb.LAYOUT_CLASSES[blas_layout](ctx).Build(dv)
+    side, scale = 10, 0.7
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    ang = (np.arange(g.shape[0]) * 0.37).astype(np.float32)
+    c_, s_ = np.cos(ang), np.sin(ang)
+    T = np.zeros((g.shape[0], 4, 4), np.float32)
+    T[:, 0, 0] = c_ * scale; T[:, 0, 2] = s_ * scale; T[:, 1, 1] = scale; T[:, 2, 0] = -s_ * scale; T[:, 2, 2] = c_ * scale; T[:, 3, 3] = 1
+    T[:, :3, 3] = g * 2.0
+    inst = tb.make_instances(T, np.zeros(g.shape[0], np.uint32))
+    W_, H_ = 3840, 2160
+    ext = 2.0 * side
+    cam = R.camera((-0.6 * ext, 0.8 * ext, -0.9 * ext), (0.62, -0.38, 0.68), W_, H_, 1, 1)
+    tlas = tb.TLAS(ctx).Build(inst, [blas])
+    return dlabel, blas, tlas, cam, W_ * H_
+
+
+def tlas_child(a, tb, R, scenes):
+    """Config 5 in a process of its own: camera rays through the TLAS over BVH4_GPU BLASes (k_tlas4) — under rocprofv3 --pmc (--pmc-child) only
+    the launches; otherwise also the TLAS over BVH8_CWBVH BLASes (k_tlas8) next to the reference's traverse_tlas (traverse_tlas.cl:13-107, through
+    wavefront2.cl's Extend as tiny_bvh_gpu2.cpp:191 launches it) on the same TLAS nodes, instance records, BLAS blobs and rays."""
+    ctx = tb.Context(0)
+    dlabel, blas, tlas, cam, nt = config5_setup(tb, R, scenes, ctx, 8)
+    d = ctx.malloc(nt * 64)
+    ctx.generate_primary(cam, d, 0, nt)
+    ms = []
+    for f in range(4):
+        tlas.intersect_device_fresh(d, nt, 1e30); ctx.synchronize()
+        if f:
+            ms.append(ctx.time_last_ms())
+    if a.pmc_child:
+        ctx.close()
+        return
+    out = {"blas": dlabel, "camera_rays": nt, "k_tlas4_ms": float(np.mean(ms)), "k_tlas4_mrays": nt / float(np.mean(ms)) / 1e3}
+    tlas.free(); blas.free()
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_lib import ReferenceOpenCL
+        ocl = ReferenceOpenCL()
+        _, blas8, tlas8, _, _ = config5_setup(tb, R, scenes, ctx, 10)
+        ms8 = []
+        for f in range(4):
+            tlas8.intersect_device_fresh(d, nt, 1e30); ctx.synchronize()
+            if f:
+                ms8.append(ctx.time_last_ms())
+        mine = np.zeros(nt, tb.RAY_DTYPE); ctx.from_device(mine, d)
+        rays = mine.copy(); rays["t"] = 1e30; rays["u"] = 0; rays["v"] = 0; rays["prim"] = 0
+        nodes, idx, irec = tlas8.Download()
+        h = blas8.host
+        ref, ref_ms = ocl.tlas_extend(nodes, idx, irec, h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4), rays, passes=3)
+        mh, rh = mine["t"][: ref.shape[0]] < 1e30, ref[:, 0] < 1e30
+        out.update({"k_tlas8_ms": float(np.mean(ms8)), "k_tlas8_mrays": nt / float(np.mean(ms8)) / 1e3, "ref_opencl_traverse_tlas_ms": ref_ms,
+                    "ref_opencl_traverse_tlas_mrays": ref.shape[0] / ref_ms / 1e3, "ratio_k_tlas8_cwbvh_blas": ref_ms / float(np.mean(ms8)),
+                    "ratio_k_tlas4_bvh4_blas": ref_ms / float(np.mean(ms)), "hitmiss_diff": int((mh != rh).sum()), "opencl_device": ocl.device,
+                    "ref_kernel": "traverse_tlas (traverse_tlas.cl:13-107) via wavefront2.cl Extend, BVH8_CWBVH BLAS (the configuration of tiny_bvh_gpu2.cpp), same TLAS / instances / rays"})
+    except Exception as e:
+        out["ref_opencl_error"] = repr(e)[:300]
+    print(json.dumps(out), flush=True)
+    ctx.close()
+
+
+def pmc_dispatches(child_args, counters, match, env_extra=None, timeout=300):
+    """Runs `python bench.py <child_args>` under `rocprofv3 --pmc <counters> --kernel-trace` (counters in their own run, as the pool requires) and
+    returns, in launch order, {counter: value summed over the dispatch's rows} for every dispatch whose kernel name satisfies `match`."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    d = tempfile.mkdtemp(prefix="tbvh_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", **(env_extra or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    try:
+        cmd = ["rocprofv3", "--output-format", "csv", "--pmc"] + counters + ["--kernel-trace", "-d", d, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__)] + child_args
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, check=True)
+        per = {}
+        for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] in counters and match(r["Kernel_Name"]):
+                    row = per.setdefault(int(r["Dispatch_Id"]), {})
+                    row[r["Counter_Name"]] = row.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+        return [per[k] for k in sorted(per)]
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def tlas_leg(a, log, valu_ceiling):
+    """detail.tlas_1000_instances: the reference's traverse_tlas beside k_tlas8 / k_tlas4, and k_tlas4's counters (FETCH_SIZE; the SQ VALU group)."""
+    import shutil
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--tlas-child"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
+    out = json.loads([l for l in r.stdout.decode().split("\n") if l.startswith("{")][-1])
+    res = {"vs_reference_opencl": out}
+    if not a.no_pmc and shutil.which("rocprofv3"):
+        cnt = {}
+        for pass_ in ("FETCH_SIZE", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES"):
+            try:
+                rows = pmc_dispatches(["--tlas-child", "--pmc-child"], pass_.split(), lambda kn: "k_tlas4" in kn)
+                for cn in pass_.split():
+                    vals = [r_.get(cn, 0.0) for r_ in rows][-3:]
+                    cnt[cn] = float(np.mean(vals))
+            except Exception as e:
+                log(f"[bench] rocprofv3 --pmc {pass_!r} TLAS child failed: {e!r}")
+        nt, sec = out["camera_rays"], out["k_tlas4_ms"] * 1e-3
+        k_ = {"kernel": "k_tlas4 (BVH4_GPU BLASes), 3840 x 2160 camera rays", "launch_ms": out["k_tlas4_ms"]}
+        if "FETCH_SIZE" in cnt:
+            tr = cnt["FETCH_SIZE"] * 2048.0
+            k_["fabric"] = {"fetched_bytes_per_ray": tr / nt, "achieved_gbps": tr / sec / 1e9, "peak_gbps": 8000.0, "frac": tr / sec / 8e12}
+        if cnt.get("SQ_INSTS_VALU") and cnt.get("SQ_ACTIVE_INST_VALU"):
+            rate = cnt["SQ_INSTS_VALU"] / sec / 1e9
+            k_["valu"] = {"insts_valu_per_ray": cnt["SQ_INSTS_VALU"] * 64.0 / nt, "issue_frac": rate / valu_ceiling if valu_ceiling else None,
+                          "lane_utilisation": cnt["SQ_THREAD_CYCLES_VALU"] / (64.0 * cnt["SQ_ACTIVE_INST_VALU"])}
+        res["counters"] = k_
+    return res
+
+
+def host_rays_leg(tb, ctx, sc, d_prim, n):
+    """The speedtest's literal call (tiny_bvh_speedtest.cpp:1110-1137): a HOST tinybvh::Ray[] (128-byte records) traced in place through
+    tbvh_intersect, and the packed 64-byte form; as staged by the library (pageable memory: worker threads + pinned bounce buffers) and, pinned
+    by the caller (tbvh_pin_host: the tinyocl::Buffer of this boundary), in place over the link.  84 bytes cross the link per ray (64 up, 20
+    down); `frac_of_link` = that traffic over the call's wall time against the link's measured pinned hipMemcpyAsync rates."""
+    up, down = ctx.link_bandwidth_gbps(1 << 28, 3)
+    rays64 = np.zeros(n, dtype=tb.RAY_DTYPE); ctx.from_device(rays64, d_prim)
+    rays64["t"] = 1e30; rays64["u"] = 0; rays64["v"] = 0; rays64["prim"] = 0
+    rays128 = np.zeros((n, 32), np.uint32)
+    rays128[:, :16] = rays64.view(np.uint32).reshape(n, 16)
+    ideal_s = n * 64 / (up * 1e9) + n * 20 / (down * 1e9)
+    out = {"rays": n, "link_h2d_gbps": up, "link_d2h_gbps": down, "bytes_per_ray_on_the_link": 84, "mrays_at_link_rate": n / ideal_s / 1e6,
+           "call": "tbvh_intersect(scene, host Ray[], n, stride): replaces the memcpy loop + CopyToDevice + Kernel::Run + CopyFromDevice of tiny_bvh_speedtest.cpp:1110-1137"}
+    first_hits = None
+    for tag, arr, pin in (("stride_128", rays128, False), ("stride_64", rays64.view(np.uint32).reshape(n, 16), False), ("stride_128_pinned", rays128, True), ("stride_64_pinned", rays64.view(np.uint32).reshape(n, 16), True)):
+        try:
+            t_pin = 0.0
+            if pin:
+                t0 = time.perf_counter(); ctx.pin_host(arr); t_pin = time.perf_counter() - t0
+            wall, kern = [], []
+            for p_ in range(4):
+                arr[:, 12] = np.float32(1e30).view(np.uint32); arr[:, 13:16] = 0
+                t0 = time.perf_counter()
+                sc.Intersect(arr)
+                dt = time.perf_counter() - t0
+                if p_:
+                    wall.append(dt); kern.append(ctx.time_last_ms())
+            if pin:
+                ctx.unpin_host(arr)
+            w = float(np.median(wall))
+            hits = int((arr[:, 12].view(np.float32) < 1e30).sum())
+            if first_hits is None:
+                first_hits = arr[:, 11:16].copy()
+                same = True
+            else:
+                same = bool(np.array_equal(arr[:, 11:16], first_hits))
+            out[tag] = {"mrays": n / w / 1e6, "ms_per_call": w * 1e3, "kernel_ms": float(np.median(kern)), "frac_of_link": ideal_s / w, "hits": hits, "records_equal_first_variant": same,
+                        **({"pin_ms_once": t_pin * 1e3} if pin else {})}
+        except Exception as e:
+            out[tag] = {"error": repr(e)[:300]}
+    return out
 
 
 def group_dispatches_into_queries(ids, names):

@@ -233,6 +233,13 @@ int tbvh_intersect(tbvh_scene* scene, void* rays, uint64_t n_rays, uint32_t stri
  * (BVH::IsOccluded, tiny_bvh.h:3382-3453; isoccluded_* in the .cl files). */
 int tbvh_occluded(tbvh_scene* scene, const void* rays, uint64_t n_rays,
                   uint32_t stride_bytes, uint8_t* occluded);
+/* The tinyocl::Buffer( bytes, hostPtr ) of this boundary (tiny_ocl.h; tiny_bvh_speedtest.cpp:1101-1108 wraps its Ray array in one before
+ * every GPU block): page-locks [ptr, ptr + bytes) and maps it into the device's address space.  tbvh_intersect / tbvh_occluded on this
+ * context whose records lie inside a pinned range then read the 64-byte prefixes and write bytes 44..63 IN PLACE over the link
+ * (no staging copy on the host).  Pinning costs about as much as one pass over the array: pin once, trace many times
+ * (the speedtest traces the same array 9 times).  The caller unpins before it frees the memory. */
+int tbvh_pin_host(tbvh_context* ctx, void* ptr, uint64_t bytes);
+int tbvh_unpin_host(tbvh_context* ctx, void* ptr);
 
 /* Device-resident packed rays (64-byte stride, 16-byte aligned).  Asynchronous on the
  * context's stream; no host copies.  This is the timed path.
@@ -304,6 +311,8 @@ int tbvh_time_history(tbvh_context* ctx, float* ms, uint32_t cap, uint32_t* coun
 int tbvh_measure_copy_bandwidth(tbvh_context* ctx, uint64_t bytes, uint32_t reps, double* gbps);
 int tbvh_measure_read_bandwidth(tbvh_context* ctx, uint64_t bytes, uint32_t reps, double* gbps);
 int tbvh_measure_valu_issue(tbvh_context* ctx, uint32_t reps, double* ginstr_per_s);
+/* the host link: GB/s of a pinned hipMemcpyAsync of `bytes` up and down, best of `reps` (bench.py: detail.host_rays) */
+int tbvh_measure_link_bandwidth(tbvh_context* ctx, uint64_t bytes, uint32_t reps, double* h2d_gbps, double* d2h_gbps);
 
 /* Lane-utilisation counters of the instrumented kernel variants (development aid):
  * out[0] wave iterations, [1] sum of active lanes, [2] sum of lanes in the node step,

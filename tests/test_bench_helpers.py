@@ -7,13 +7,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-COH = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 8, true, false, 0, 5, 3, 0, 8>(...)"
-COH_STRICT = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false, 0, 5, 4, 0, 8>(...)"
-COH_SPLIT = "void tbvh::(anonymous namespace)::k_cwbvh<false, 6, 16, 8, true, false, 0, 5, 3, 16, 7>(...)"
-INC = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false, 0, 13, 2, 0, 8>(...)"
-INC_SPLIT = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false, 0, 13, 2, 16, 6>(...)"
-PLAIN = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false, 0, 5, 0, 16, 8>(...)"
-PLAIN_BIG = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false, 0, 8, 0, 0, 8>(...)"
+COH = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 8, true, false, 0, 5, 3, 0, 8, 0>(...)"
+COH_STRICT = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false, 0, 5, 4, 0, 8, 0>(...)"
+COH_SPLIT = "void tbvh::(anonymous namespace)::k_cwbvh<false, 6, 16, 8, true, false, 0, 5, 3, 16, 7, 0>(...)"
+INC = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false, 0, 13, 2, 0, 8, 0>(...)"
+INC_SPLIT = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false, 0, 13, 2, 16, 6, 0>(...)"
+PLAIN = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false, 0, 5, 0, 16, 8, 0>(...)"
+PLAIN_BIG = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false, 0, 8, 0, 0, 8, 0>(...)"
 
 
 def group(seq):
@@ -40,3 +40,48 @@ def test_small_preparation_batches_are_single_dispatches():
 
 def test_unprobed_scene_is_one_dispatch_per_query():
     assert group([PLAIN_BIG] * 9) == [[k] for k in range(9)]
+
+
+# ---- `python bench.py --gpus N` without torchrun: which devices one process drives (the reference has no multi-device at all, tiny_ocl.h:362-364) ----
+import json  # noqa: E402
+import subprocess  # noqa: E402
+
+import pytest  # noqa: E402
+
+
+def test_resolve_devices_plain():
+    assert bench.resolve_devices(1, 1) == [0]
+    assert bench.resolve_devices(8, 8) == list(range(8))
+    assert bench.resolve_devices(2, 8) == [0, 1]
+
+
+def test_resolve_devices_refuses_a_1_gpu_number_under_an_n_gpu_flag():
+    with pytest.raises(ValueError, match="--gpus 8 but 1 HIP device"):
+        bench.resolve_devices(8, 1)
+    with pytest.raises(ValueError):
+        bench.resolve_devices(2, 0)
+    with pytest.raises(ValueError):
+        bench.resolve_devices(0, 4)
+
+
+def test_resolve_devices_map():
+    assert bench.resolve_devices(2, 1, "0,0") == [0, 0]          # two contexts on one device: how a 1-GPU box exercises the N-context path
+    assert bench.resolve_devices(3, 2, "1, 0,1") == [1, 0, 1]
+    with pytest.raises(ValueError, match="lists 2 devices for --gpus 3"):
+        bench.resolve_devices(3, 4, "0,1")
+    with pytest.raises(ValueError, match="names device"):
+        bench.resolve_devices(2, 1, "0,1")
+    with pytest.raises(ValueError, match="comma-separated"):
+        bench.resolve_devices(2, 2, "a,b")
+
+
+def test_plain_gpus_n_without_devices_says_so_and_exits_nonzero():
+    """No GPU here: `python bench.py --gpus 2` (no torchrun) must not fall back to anything — one JSON line naming the problem, exit code 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TBVH_BENCH_DEVICE_MAP", "TBVH_BENCH_FORCE_DIST")}
+    import tinybvh_amd as tb
+    if tb.device_count() >= 2:
+        pytest.skip("two devices visible: the run would start")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+    line = json.loads([l for l in r.stdout.split("\n") if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] is None and "HIP device" in line["error"]

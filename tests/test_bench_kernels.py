@@ -205,3 +205,44 @@ def test_both_coherent_schedules_and_the_tuner(oracle):
     for kind in ("camera", "shadow", "camera4m"):
         assert np.array_equal(results[("0", kind)].view(np.uint8), results[("2", kind)].view(np.uint8)), kind
         assert np.array_equal(results[("0", kind)].view(np.uint8), results[(None, kind)].view(np.uint8)), kind
+
+
+@pytest.mark.parametrize("split", [0.0, 0.3])
+def test_rotated_scene_at_bench_size(ctx, oracle, split):
+    """bench.py's detail.rotated_scene, parity-pinned at bench size: the 2.83 M triangles rotated off the axes (scenes.street_rot), 16.7 M camera,
+    bounce and shadow rays through the probed launches, a strided 65 k sample of each against BVH::Intersect / IsOccluded restated.  split = 0.3:
+    the tree of TBVH_BUILD_SPLIT_TRIANGLES (a triangle in several leaves) — records must not change."""
+    verts, _ = scenes.get("street_rot")
+    sc = tb.BVH8_CWBVH(ctx).Build(verts, split_budget=split)
+    if split:
+        assert sc.host.blob(1, np.uint32, 4).shape[0] // 3 > verts.shape[0] // 3     # the budget was spent: some triangles sit in several leaves
+    side = 4096
+    n = side * side
+    cam = R.camera(*scenes.street_rot_camera(0), side, side, 1, 1)
+    d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
+    d_a, d_b, d_occ = ctx.malloc(n * 64), ctx.malloc(n * 64), ctx.malloc(n)
+    before = np.zeros(n, tb.RAY_DTYPE); after = np.zeros(n, tb.RAY_DTYPE)
+    ctx.generate_primary(cam, d_a, 0, n)
+    ctx.from_device(before, d_a)
+    sc.intersect_device_fresh(d_a, n, 1e30)
+    assert ctx.last_probe()[2] == 2
+    ctx.from_device(after, d_a)
+    sample_check(oracle, sc, verts, before, after, n, f"street_rot camera rays, split {split}")
+    ext = float((verts[:, :3].max(0) - verts[:, :3].min(0)).max())
+    ctx.generate_shadow(d_a, d_b, n, (0.0, 0.9 * float(verts[:, 1].max()), 0.0), ext * 5e-7)
+    sc.occluded_device(d_b, n, d_occ)
+    occ = np.zeros(n, np.uint8); ctx.from_device(occ, d_occ)
+    ctx.from_device(before, d_b)
+    idx = np.arange(0, n, n // 65536)[:65536]
+    h = sc.host
+    want_occ = oracle.bvh2_occluded(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, before[idx])
+    assert np.array_equal(occ[idx], want_occ), int((occ[idx] != want_occ).sum())
+    ctx.generate_bounce(d_verts, d_a, d_b, n, 4711)
+    ctx.from_device(before, d_b)
+    sc.intersect_device_fresh(d_b, n, 1e30)
+    assert ctx.last_probe()[2] == 1
+    ctx.from_device(after, d_b)
+    sample_check(oracle, sc, verts, before, after, n, f"street_rot bounce rays, split {split}")
+    for p in (d_verts, d_a, d_b, d_occ):
+        ctx.free(p)
+    sc.free()

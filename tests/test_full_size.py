@@ -71,10 +71,13 @@ def test_bistro_16m_properties(ctx, oracle):
 
 
 def _real_reference_clean(c, what):
-    """No real error against the real reference; its tie rule and the cull slack may differ on a few rays, which are COUNTED (DESIGN.md par. 4)."""
+    """No real error against the real reference.  Its tie rule differs from the library's on rays that hit two triangles at the bit-identical t
+    (DESIGN.md par. 4): those are COUNTED, and budgeted at 4 per 65 536-ray sample (0-1 observed on every batch of rounds 4 and 5; a change
+    that multiplied ties would fail here).  A record CLOSER by ulps (the cull_bound class) has never been observed at this scale: none allowed."""
     assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_differs"] == 0 and c["farther_by_ulps"] == 0, (what, c)
     assert c["onsurf"] <= 16, (what, c)
-    assert c["differ_from_reference"] <= max(c["hits"] // 2000, 8), (what, c)     # ties + closer-by-ulps: well under 0.1 % of the hits
+    assert c["closer_by_ulps"] == 0, (what, c)
+    assert c["differ_from_reference"] <= 4 * max(1, -(-c["n"] // 65536)), (what, c)
 
 
 def test_bistro_16m_against_the_real_reference(ctx, reference):
@@ -110,6 +113,21 @@ def test_bistro_16m_against_the_real_reference(ctx, reference):
             _real_reference_clean(c, f"{kind} rays, {tree}")
             totals[(kind, tree)] = (c["tie_equal_t"], c["closer_by_ulps"], c["max_ulps"])
     print("differences from the real reference (ties at equal t, closer by ulps, max ulps):", totals)
+    # ... and the 16.7 M shadow rays (camera hit points towards the light) against the REAL BVH::IsOccluded (tiny_bvh.h:3382-3453), both trees
+    ext = float((verts[:, :3].max(0) - verts[:, :3].min(0)).max())
+    mine.intersect_device_fresh(d_p, n, 1e30)
+    ctx.generate_shadow(d_p, d_b, n, (0.0, 0.9 * float(verts[:, 1].max()), 0.0), ext * 5e-7)
+    ctx.from_device(full, d_b)
+    sample = full[idx].copy()
+    want_occ = rs.occluded(1, sample)
+    assert 1000 < int(want_occ.sum()) < idx.size - 1000
+    d_occ = ctx.malloc(n)
+    occ = np.zeros(n, np.uint8)
+    for tree, sc in (("library tree", mine), ("reference BuildHQ blob", theirs)):
+        sc.occluded_device(d_b, n, d_occ)
+        ctx.from_device(occ, d_occ)
+        assert int((occ[idx] != want_occ).sum()) == 0, (tree, int((occ[idx] != want_occ).sum()))
+    ctx.free(d_occ)
     for p in (d_verts, d_p, d_b):
         ctx.free(p)
     mine.free(); theirs.free()

@@ -114,6 +114,19 @@ class Context:
         check(lib.tbvh_measure_valu_issue(self._h, reps, C.byref(g)), "tbvh_measure_valu_issue")
         return float(g.value)
 
+    def link_bandwidth_gbps(self, nbytes: int = 1 << 28, reps: int = 3):
+        """Measured host link rates (tbvh_measure_link_bandwidth): (host-to-device, device-to-host) GB/s of a pinned hipMemcpyAsync."""
+        up, down = C.c_double(0), C.c_double(0)
+        check(lib.tbvh_measure_link_bandwidth(self._h, nbytes, reps, C.byref(up), C.byref(down)), "tbvh_measure_link_bandwidth")
+        return float(up.value), float(down.value)
+
+    def pin_host(self, a: np.ndarray):
+        """tbvh_pin_host on a numpy array's memory: host-array queries on it then run in place over the link.  Unpin before the array goes away."""
+        check(lib.tbvh_pin_host(self._h, _ptr(a), a.nbytes), "tbvh_pin_host")
+
+    def unpin_host(self, a: np.ndarray):
+        check(lib.tbvh_unpin_host(self._h, _ptr(a)), "tbvh_unpin_host")
+
     def time_last_ms(self) -> float:
         return float(lib.tbvh_time_last_ms(self._h))
 

@@ -111,6 +111,8 @@ void tbvh_shutdown(tbvh_context* c) {
     if (c->spill) hipFree(c->spill);
     if (c->counter) hipFree(c->counter);
     if (c->pool) hipFree(c->pool);
+    for (const tbvh_context::PinnedRange& r : c->pinned) hipHostUnregister(r.host);   // (ranges the caller never unpinned: the registration must not outlive the context)
+    c->pinned.clear();
     if (c->stageRays) hipFree(c->stageRays);
     if (c->stageOcc) hipFree(c->stageOcc);
     if (c->binScratch) hipFree(c->binScratch);
@@ -283,6 +285,24 @@ int tbvh_measure_read_bandwidth(tbvh_context* c, uint64_t bytes, uint32_t reps, 
     hipFree(a); hipFree(sink);
     if (r) return r;
     *gbps = (double)bytes / (ms * 1e-3) / 1e9;
+    return 0;
+}
+
+// Host link as this box delivers it: one pinned buffer, hipMemcpyAsync up and down, best of `reps` each.  The denominator of bench.py's
+// detail.host_rays (a host tinybvh::Ray[] costs 64 bytes up and 20 bytes down per ray).
+int tbvh_measure_link_bandwidth(tbvh_context* c, uint64_t bytes, uint32_t reps, double* h2d_gbps, double* d2h_gbps) {
+    if (!c || !h2d_gbps || !d2h_gbps || bytes < (1u << 20)) return fail(TBVH_E_INVALID, "tbvh_measure_link_bandwidth: null argument or under 1 MB");
+    TBVH_ENTER(c);
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess) return fail(TBVH_E_NOMEM, "tbvh_measure_link_bandwidth: cannot pin %llu bytes", (unsigned long long)bytes);
+    if (hipMalloc(&d, bytes) != hipSuccess) { hipHostFree(h); return fail(TBVH_E_NOMEM, "tbvh_measure_link_bandwidth: cannot allocate %llu device bytes", (unsigned long long)bytes); }
+    memset(h, 1, bytes);
+    double up = 0, down = 0;
+    int r = timeBest(c, reps ? reps : 3, [&] { (void)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream); }, &up);
+    if (!r) r = timeBest(c, reps ? reps : 3, [&] { (void)hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream); }, &down);
+    hipFree(d); hipHostFree(h);
+    if (r) return r;
+    *h2d_gbps = (double)bytes / (up * 1e-3) / 1e9; *d2h_gbps = (double)bytes / (down * 1e-3) / 1e9;
     return 0;
 }
 

@@ -88,6 +88,10 @@ struct tbvh_context {
     // hipMemcpy2D moves ~9 GB/s because one CPU thread does the staging copy), and the 20 result bytes per ray come back
     // packed (k_pack_hits) and are scattered by the same workers
     struct HostPipe* pipe = nullptr;
+    // host ranges the caller pinned for this context (tbvh_pin_host): a host-array query whose records lie inside one reads and writes them in
+    // place over the link (kernels_raygen.hip: k_gather_host_rays / k_scatter_host_hits) instead of staging them through the library's buffers
+    struct PinnedRange { char* host; uint64_t bytes; char* dev; };
+    std::vector<PinnedRange> pinned;
     void* binScratch = nullptr;   // tbvh_bin_rays_device
     size_t binScratchBytes = 0;
     std::vector<tbvh_scene*> scenes;

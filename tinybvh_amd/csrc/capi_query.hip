@@ -99,6 +99,13 @@ int pipeDownloadHits(tbvh_context* c, char* rays, uint64_t n, uint32_t stride, c
 
 constexpr uint64_t kPipeMinRays = 1ull << 15;
 
+// the device-side address of [p, p + bytes) if the caller pinned a range that holds it (tbvh_pin_host), else nullptr
+static char* pinnedDevicePtr(tbvh_context* c, const void* p, uint64_t bytes) {
+    for (const tbvh_context::PinnedRange& r : c->pinned)
+        if ((const char*)p >= r.host && (const char*)p + bytes <= r.host + r.bytes) return r.dev + ((const char*)p - r.host);
+    return nullptr;
+}
+
 int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh, float freshTmax, const unsigned long long* nDev) {
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
@@ -325,6 +332,14 @@ int tbvh_intersect(tbvh_scene* s, void* rays, uint64_t n, uint32_t stride) {
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
     if (int r = ensureStage(c, n)) return r;
+    if (char* dp = pinnedDevicePtr(c, rays, (n - 1) * (uint64_t)stride + 64)) {   // the caller pinned the array: in place over the link, no host copy at all
+        launch_gather_host_rays(dp, stride, c->stageRays, n, c->stream);
+        HIP_TRY(hipGetLastError());
+        if (int r = launchQuery(s, c->stageRays, n, nullptr)) return r;
+        launch_scatter_host_hits(c->stageRays, dp, stride, n, c->stream);
+        HIP_TRY(hipGetLastError());
+        return checkStatus(c);
+    }
     if (n >= kPipeMinRays) {   // pinned, chunked, multi-threaded staging (see HostPipe)
         if (int r = ensurePipe(c, n)) return r;
         if (int r = pipeUpload(c, (const char*)rays, n, stride, c->stageRays)) return r;
@@ -347,13 +362,45 @@ int tbvh_occluded(tbvh_scene* s, const void* rays, uint64_t n, uint32_t stride, 
     TBVH_ENTER(c);
     if (int r = ensureStage(c, n)) return r;
     if (int r = ensureStageOcc(c, n)) return r;
-    if (n >= kPipeMinRays) {
+    if (char* dp = pinnedDevicePtr(c, rays, (n - 1) * (uint64_t)stride + 64)) {
+        launch_gather_host_rays(dp, stride, c->stageRays, n, c->stream);
+        HIP_TRY(hipGetLastError());
+    } else if (n >= kPipeMinRays) {
         if (int r = ensurePipe(c, n)) return r;
         if (int r = pipeUpload(c, (const char*)rays, n, stride, c->stageRays)) return r;
     } else HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
     if (int r = launchQuery(s, c->stageRays, n, c->stageOcc)) return r;
     HIP_TRY(hipMemcpyAsync(occ, c->stageOcc, n, hipMemcpyDeviceToHost, c->stream));
     return checkStatus(c);
+}
+
+// ---- host arrays the caller pins: the tinyocl::Buffer( bytes, hostPtr ) of this boundary (tiny_ocl.h; tiny_bvh_speedtest.cpp:1101-1108 wraps its
+// ---- Ray array in one before every GPU block) ------------------------------------------------------------------------------------------------
+int tbvh_pin_host(tbvh_context* c, void* ptr, uint64_t bytes) {
+    if (!c || !ptr || !bytes) return fail(TBVH_E_INVALID, "tbvh_pin_host: null/empty argument");
+    TBVH_ENTER(c);
+    for (const tbvh_context::PinnedRange& r : c->pinned)
+        if ((char*)ptr < r.host + r.bytes && r.host < (char*)ptr + bytes) return fail(TBVH_E_INVALID, "tbvh_pin_host: the range overlaps one that is pinned already");
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
+    void* dp = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(&dp, ptr, 0);
+    if (e != hipSuccess || !dp) { hipHostUnregister(ptr); return fail(TBVH_E_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e)); }
+    try { c->pinned.push_back(tbvh_context::PinnedRange{(char*)ptr, bytes, (char*)dp}); }
+    catch (const std::bad_alloc&) { hipHostUnregister(ptr); return fail(TBVH_E_NOMEM, "out of host memory"); }
+    return 0;
+}
+
+int tbvh_unpin_host(tbvh_context* c, void* ptr) {
+    if (!c || !ptr) return fail(TBVH_E_INVALID, "tbvh_unpin_host: null argument");
+    TBVH_ENTER(c);
+    for (size_t i = 0; i < c->pinned.size(); i++)
+        if (c->pinned[i].host == (char*)ptr) {
+            HIP_TRY(hipStreamSynchronize(c->stream));   // nothing of this context may still be reading or writing the range
+            c->pinned.erase(c->pinned.begin() + i);
+            HIP_TRY(hipHostUnregister(ptr));
+            return 0;
+        }
+    return fail(TBVH_E_INVALID, "tbvh_unpin_host: %p was not pinned through this context", ptr);
 }
 
 // ---- one ray array over several devices -----------------------------------------------------------
