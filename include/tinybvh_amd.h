@@ -82,8 +82,8 @@ int         tbvh_set_stream(tbvh_context* ctx, void* hip_stream);
 /* Per-operation device timing on (default) or off.  On: every query / refit / rebuild is bracketed by a HIP event pair — what
  * tbvh_time_last_ms and tbvh_time_history read, the CL_PROFILING_COMMAND_START / END of tiny_bvh_speedtest.cpp:1126-1131.  Off: nothing but the
  * kernels is enqueued (two event records fewer per query: a few microseconds each, which a renderer issuing many small queries per frame
- * notices); the time calls then keep reporting the last operation that was timed, and a scene whose coherent-batch schedule is still being
- * measured (tbvh_debug_coherent_schedule) runs the default schedule until timing is back on. */
+ * notices); the time calls then keep reporting the last operation that was timed.  (A scene whose coherent-batch schedule is still being
+ * measured keeps measuring: the tuner brackets those few launches with events of its own, tbvh_scene_get_schedule_hint.) */
 int         tbvh_set_timing(tbvh_context* ctx, int enabled);
 
 /* ------------------------------------------------------------------------------------
@@ -350,6 +350,18 @@ int tbvh_debug_set_flags(tbvh_context* ctx, uint32_t flags);
  * strict at 16.7 M rays and even at 4.2 M); the call reports the class of the most recent launch. */
 int tbvh_debug_coherent_schedule(tbvh_scene* scene, int anyhit, uint32_t out[4]);
 
+/* The same decision as something a caller can READ, KEEP and GIVE BACK (a renderer that wants its first frame at full speed and the same
+ * schedule from run to run): one entry per batch-size class (fewer than 6 M rays, fewer than 12 M, more) and query kind; 0 = not decided yet
+ * (the library is still alternating and timing — with its own events, so tbvh_set_timing(0) does not stop it; batches whose size only the
+ * device knows are never sampled and run the deferred schedule), 1 = deferred + gated, 2 = strict.  tbvh_scene_set_schedule_hint pins the
+ * non-zero entries (no measuring launches at all for those classes; kept across tbvh_update_cwbvh) and sends the zero ones back to
+ * measuring.  The struct is 8 plain bytes: store it next to the scene's blob cache (tbvh_cwbvh_file_write) if it should outlive the process.
+ * Measured decisions are taken from the best of 3 device-timed launches per schedule, 3 % apart at least; other work on the GPU during those
+ * launches can tip a close call, which is what pinning is for. */
+typedef struct tbvh_schedule_hint { uint8_t closest_hit[3]; uint8_t any_hit[3]; uint8_t reserved[2]; } tbvh_schedule_hint;
+int tbvh_scene_get_schedule_hint(tbvh_scene* scene, tbvh_schedule_hint* out);
+int tbvh_scene_set_schedule_hint(tbvh_scene* scene, const tbvh_schedule_hint* hint);
+
 /* The per-launch coherence probe of the most recent query on this context (development aid; DESIGN.md par. 3): out[0] = sampled
  * neighbouring ray pairs whose directions agree (and, for rays of finite reach, whose origins lie within 5 % of that reach), out[1] = pairs sampled, out[2] = 0 no probe ran (small batches, small or very
  * large scenes, other layouts), 1 the batch was classified incoherent (strict schedule), 2 coherent (deferred triangles, gated
@@ -503,7 +515,9 @@ typedef struct tbvh_build_params {
                                           mostly empty (large, off the coordinate axes) are cut into pieces BEFORE the binned-SAH build,
                                           up to (flags >> 24) per cent extra references (0 = 30), shared out by wasted box area x tree
                                           level (Karras & Aila 2013 section 4.3).  A triangle may then sit in several leaves, as in a
-                                          BuildHQ tree (bvh8Tris / primIdx grow by the budget at most). */
+                                          BuildHQ tree (bvh8Tris / primIdx grow by the budget at most).  DEFAULT for BVH8_CWBVH at 30 %
+                                          (measured +1 ... +8 % MRays/s, profiles/r05_rotated.txt); off for the other layouts. */
+#define TBVH_BUILD_WHOLE_TRIANGLES 16u /* never split: every triangle in exactly one leaf, primIdx a permutation (as BVH::Build) */
 
 int tbvh_host_build(const void* verts16, uint64_t n_tris, int layout,
                     const tbvh_build_params* params, tbvh_hostbvh** out);

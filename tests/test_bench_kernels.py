@@ -246,3 +246,44 @@ def test_rotated_scene_at_bench_size(ctx, oracle, split):
     for p in (d_verts, d_a, d_b, d_occ):
         ctx.free(p)
     sc.free()
+
+
+def test_schedule_hint_pins_reads_back_and_survives_timing_off(oracle):
+    """tbvh_scene_get / set_schedule_hint (round-4 review: the tuner's decision must be readable, pinnable and persistable): a pinned class runs its
+    schedule from the FIRST launch and takes no samples; the hint reads back; zero entries send a class back to measuring; the tuner measures
+    with tbvh_set_timing(0) too (its own events); a device-side ray count never samples; records are the same bytes whatever the hint."""
+    verts, _ = scenes.get("bistro")
+    side = 4096
+    n = side * side
+    c = tb.Context(0)
+    try:
+        sc = tb.BVH8_CWBVH(c).Build(verts)
+        d_a = c.malloc(n * 64)
+        c.generate_primary(R.camera(*scenes.STREET_CAMERAS[0], side, side, 1, 1), d_a, 0, n)
+        assert sc.schedule_hint() == {"closest_hit": [0, 0, 0], "any_hit": [0, 0, 0]}
+        recs = {}
+        for v in (2, 1):
+            sc.set_schedule_hint({"closest_hit": [0, 0, v], "any_hit": [0, 0, 0]})
+            assert sc.schedule_hint()["closest_hit"] == [0, 0, v]
+            sc.intersect_device_fresh(d_a, n, 1e30)
+            dec = sc.coherent_schedule(False)
+            assert dec[0] == v and dec[1] == 0 and dec[2] == 0, dec            # decided before the first launch, nothing sampled
+            got = np.zeros(n, tb.RAY_DTYPE); c.from_device(got, d_a)
+            recs[v] = got[:: n // 65536].copy()
+        assert np.array_equal(recs[1].view(np.uint8), recs[2].view(np.uint8))
+        # back to measuring, with per-operation timing OFF: the tuner still reaches a decision
+        sc.set_schedule_hint({"closest_hit": [0, 0, 0], "any_hit": [0, 0, 0]})
+        c.set_timing(False)
+        for _ in range(8):
+            sc.intersect_device_fresh(d_a, n, 1e30)
+        c.synchronize()
+        sc.intersect_device_fresh(d_a, n, 1e30)
+        c.set_timing(True)
+        dec = sc.coherent_schedule(False)
+        assert dec[0] in (1, 2) and dec[1] >= 3 and dec[2] >= 3, dec
+        assert sc.schedule_hint()["closest_hit"][2] == dec[0]
+        with pytest.raises(tb.TbvhError):
+            sc.set_schedule_hint({"closest_hit": [3, 0, 0], "any_hit": [0, 0, 0]})
+        c.free(d_a); sc.free()
+    finally:
+        c.close()

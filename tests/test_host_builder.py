@@ -66,12 +66,15 @@ def test_bvh2_is_a_valid_tree(small_scene):
     assert seen.all()
 
 
-def test_cwbvh_blob_invariants(small_scene):
+@pytest.mark.parametrize("split", [0.0, None])
+def test_cwbvh_blob_invariants(small_scene, split):
     """<=3 tris per leaf slot, <=24 per node, meta/imask consistent, interior
     children contiguous from childBaseIndex in slot order, decoded child boxes contain the
-    triangles below them."""
+    triangles below them.  split = 0: whole triangles (TBVH_BUILD_WHOLE_TRIANGLES), every triangle in exactly one leaf;
+    None: the layout's default (30 % extra references: a leaf box holds the PIECE of the triangle it was built for, a triangle may sit in
+    several leaves — hit parity of such trees: test_split_triangles_same_hits_tighter_tree)."""
     verts = small_scene
-    h = tb.HostBVH(verts, tb.LAYOUT_CWBVH)
+    h = tb.HostBVH(verts, tb.LAYOUT_CWBVH, split_budget=split)
     nodes = h.blob(0, np.uint32, 4).reshape(-1, 5, 4)
     tris = h.blob(1, np.uint32, 4).view(np.float32).reshape(-1, 3, 4)
     n_nodes = nodes.shape[0]
@@ -103,7 +106,7 @@ def test_cwbvh_blob_invariants(small_scene):
                     t = tris[tri_base // 3 + n_tri + j]
                     prim = int(t[2, 3].view(np.uint32)); used_prims[prim] += 1
                     v0 = t[2, :3]; pts = np.stack([v0, v0 + t[1, :3], v0 + t[0, :3]])
-                    for a in range(3):
+                    for a in range(3 if split == 0.0 else 0):
                         sc = np.float32(2.0) ** np.float32(e[a])
                         assert lo[a] + sc * q[a, s] <= pts[:, a].min() + 1e-4 * abs(sc)
                         assert lo[a] + sc * q[3 + a, s] >= pts[:, a].max() - 1e-4 * abs(sc)
@@ -111,7 +114,10 @@ def test_cwbvh_blob_invariants(small_scene):
         assert n_tri <= 24
         assert tri_base % 3 == 0
     assert children_seen[0] == 0 and (children_seen[1:] == 1).all()  # a tree: every non-root node has one parent
-    assert (used_prims == 1).all()                                  # every triangle in exactly one leaf
+    if split == 0.0:
+        assert (used_prims == 1).all()                              # every triangle in exactly one leaf
+    else:
+        assert (used_prims >= 1).all() and used_prims.sum() <= int(1.3 * used_prims.shape[0]) + 1
 
 
 def test_bvh4_blob_invariants(small_scene):
@@ -165,8 +171,8 @@ def test_optimal_collapse_gives_same_hits_with_fewer_nodes(oracle, small_scene, 
     """TBVH_BUILD_OPTIMAL_COLLAPSE (SAH dynamic program): still a valid blob of the format, same
     hits as BVH::Intersect, fewer nodes than the greedy collapse."""
     verts = small_scene
-    g = tb.HostBVH(verts, layout, greedy_collapse=True)
-    o = tb.HostBVH(verts, layout, optimal_collapse=True, c_prim=0.3, max_leaf_tris=3)
+    g = tb.HostBVH(verts, layout, greedy_collapse=True, split_budget=0.0)       # (whole triangles on both sides: the collapse is what is compared)
+    o = tb.HostBVH(verts, layout, optimal_collapse=True, c_prim=0.3, max_leaf_tris=3, split_budget=0.0)
     assert o.blob(0, np.uint32, 4).shape[0] < g.blob(0, np.uint32, 4).shape[0]
     for rays in ray_sets(verts):
         want = oracle.bvh2_intersect(o.bvh2_nodes(), o.bvh2_prim_idx(), verts, rays)

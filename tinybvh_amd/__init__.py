@@ -189,15 +189,18 @@ class HostBVH:
     """Blobs built on the host by the library's own builder (tbvh_host_build)."""
 
     def __init__(self, verts: np.ndarray, layout: int, bins: int = 0, max_leaf_tris: int = 0, threads: int = 0,
-                 optimal_collapse: bool = False, c_prim: float = 0.0, greedy_collapse: bool = False, split_budget: float = 0.0):
+                 optimal_collapse: bool = False, c_prim: float = 0.0, greedy_collapse: bool = False, split_budget: Optional[float] = None):
         verts = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 4)
         assert verts.shape[0] % 3 == 0
         self.verts = verts
         self.n_tris = verts.shape[0] // 3
         self.layout = layout
         flags = (2 if optimal_collapse else 0) | (4 if greedy_collapse else 0) | (int(round(c_prim * 100)) << 8)
-        if split_budget > 0:   # TBVH_BUILD_SPLIT_TRIANGLES, budget in per cent of the triangle count
-            flags |= 8 | (min(max(int(round(split_budget * 100)), 1), 255) << 24)
+        if split_budget is not None:   # None: the layout's default (BVH8_CWBVH: 30 % extra references; the others: whole triangles)
+            if split_budget > 0:       # TBVH_BUILD_SPLIT_TRIANGLES, budget in per cent of the triangle count
+                flags |= 8 | (min(max(int(round(split_budget * 100)), 1), 255) << 24)
+            else:
+                flags |= 16            # TBVH_BUILD_WHOLE_TRIANGLES
         bp = BuildParams(bins, max_leaf_tris, threads, flags)
         h = C.c_void_p()
         check(lib.tbvh_host_build(_ptr(verts), self.n_tris, layout, C.byref(bp), C.byref(h)), "tbvh_host_build")
@@ -316,6 +319,17 @@ class _Scene:
         out = (C.c_uint32 * 4)()
         check(lib.tbvh_debug_coherent_schedule(self._h, 1 if anyhit else 0, out), "tbvh_debug_coherent_schedule")
         return tuple(int(x) for x in out)
+
+    def schedule_hint(self):
+        """tbvh_scene_get_schedule_hint: {"closest_hit": [c0, c1, c2], "any_hit": [...]} per batch-size class (< 6 M, < 12 M, more rays); 0 undecided, 1 deferred + gated, 2 strict."""
+        b = (C.c_uint8 * 8)()
+        check(lib.tbvh_scene_get_schedule_hint(self._h, C.cast(b, C.c_void_p)), "tbvh_scene_get_schedule_hint")
+        return {"closest_hit": [int(b[0]), int(b[1]), int(b[2])], "any_hit": [int(b[3]), int(b[4]), int(b[5])]}
+
+    def set_schedule_hint(self, hint) -> None:
+        """tbvh_scene_set_schedule_hint: pins the non-zero entries of a dict as schedule_hint() returns it; zero entries go back to measuring."""
+        b = (C.c_uint8 * 8)(*(list(hint["closest_hit"]) + list(hint["any_hit"]) + [0, 0]))
+        check(lib.tbvh_scene_set_schedule_hint(self._h, C.cast(b, C.c_void_p)), "tbvh_scene_set_schedule_hint")
 
     def set_variant(self, v: int):
         check(lib.tbvh_set_variant(self._h, v), "tbvh_set_variant")

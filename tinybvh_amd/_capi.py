@@ -91,6 +91,8 @@ SYMBOLS = {
     "tbvh_measure_read_bandwidth": (_i, [_vp, _u64, _u32, C.POINTER(C.c_double)]),
     "tbvh_measure_valu_issue": (_i, [_vp, _u32, C.POINTER(C.c_double)]),
     "tbvh_measure_link_bandwidth": (_i, [_vp, _u64, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "tbvh_scene_get_schedule_hint": (_i, [_vp, _vp]),
+    "tbvh_scene_set_schedule_hint": (_i, [_vp, _vp]),
     "tbvh_pin_host": (_i, [_vp, _vp, _u64]),
     "tbvh_unpin_host": (_i, [_vp, _vp]),
     "tbvh_set_variant": (_i, [_vp, _i]),

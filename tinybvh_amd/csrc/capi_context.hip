@@ -80,6 +80,7 @@ int tbvh_init(int device, tbvh_context** out) {
     if (const char* e = getenv("TBVH_SPLIT_RAYS")) { if (atoi(e) == 0) c->splitBelow = 0; }
     if (const char* e = getenv("TBVH_INCOHERENT_COPIES")) { if (atoi(e) == 0) c->incoherentCopies = false; }
     if (const char* e = getenv("TBVH_EMBED_TRIS")) { if (atoi(e) == 0) c->embedTris = false; }
+    if (const char* e = getenv("TBVH_DEBUG_FLAGS")) c->expFlags = (uint32_t)strtoul(e, nullptr, 0);   // tbvh_debug_set_flags from the environment (counter runs of tools/)
     if (const char* e = getenv("TBVH_COHERENT_TUNER")) { const int v = atoi(e); c->cohTunerMode = v == 0 ? 1 : (v == 2 ? 2 : 0); }   // 0: off (always deferred + gated), 2: always strict
     if (const char* e = getenv("TBVH_POOL_PARTS")) {  // experiment knob
         const int b = atoi(e);
@@ -118,7 +119,6 @@ void tbvh_shutdown(tbvh_context* c) {
     if (c->binScratch) hipFree(c->binScratch);
     delete c->pipe;
     for (auto& pair : c->evRing) for (hipEvent_t ev : pair) if (ev) hipEventDestroy(ev);
-    for (hipEvent_t ev : c->evMid) if (ev) hipEventDestroy(ev);
     if (c->ownStream) hipStreamDestroy(c->ownStream);
     delete c;
 }

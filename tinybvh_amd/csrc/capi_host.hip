@@ -22,7 +22,9 @@ int tbvh_host_build(const void* verts16, uint64_t nTris, int layout, const tbvh_
     // forms the leaves).  On the MI355X kernel a triangle test costs about as much as a node visit (the triangle phase runs
     // at ~20 % lane utilisation); against the greedy collapse with 3-triangle leaves: Bistro stand-in camera rays equal,
     // bounce rays +3 % (depth 1) / +6 % (depth 2), 6 % less memory.
-    if (layout == TBVH_LAYOUT_CWBVH) { bp.greedyCollapse = false; bp.cPrim = 1.0f; }
+    // ... and triangles split ahead of the build, 30 % extra references (host_builder.cpp: presplit): the 2.83 M-triangle street, 16.7 M rays:
+    // camera / bounce / shadow rays +2.6 / +1.7 / +1.2 %; the same street off the axes +8.2 / +1.5 / +5.6 % (profiles/r05_rotated.txt)
+    if (layout == TBVH_LAYOUT_CWBVH) { bp.greedyCollapse = false; bp.cPrim = 1.0f; bp.splitBudget = 0.3f; }
     // BVH4_GPU: the same collapse (leaves of <= 4 triangles as the BVH2 builder made them): 1-3 % fewer node visits + triangle
     // tests per ray on both stand-in scenes, measured +1-3 % on the GPU
     if (layout == TBVH_LAYOUT_BVH4_GPU) { bp.greedyCollapse = false; bp.cPrim = 1.0f; }
@@ -32,6 +34,7 @@ int tbvh_host_build(const void* verts16, uint64_t nTris, int layout, const tbvh_
         if (p->flags & TBVH_BUILD_GREEDY_COLLAPSE) bp.greedyCollapse = true;
         if ((p->flags >> 8) & 0xffff) bp.cPrim = (float)((p->flags >> 8) & 0xffff) * 0.01f;
         if (p->flags & TBVH_BUILD_SPLIT_TRIANGLES) bp.splitBudget = (p->flags >> 24) ? (float)(p->flags >> 24) * 0.01f : 0.3f;
+        if (p->flags & TBVH_BUILD_WHOLE_TRIANGLES) bp.splitBudget = 0.f;
     }
     if (!bp.maxLeafTris) bp.maxLeafTris = layout == TBVH_LAYOUT_CWBVH ? (bp.greedyCollapse ? 3 : 1) : 4;
     if (layout == TBVH_LAYOUT_CWBVH && bp.maxLeafTris > 3) bp.maxLeafTris = 3;
@@ -87,7 +90,7 @@ int tbvh_cwbvh_file_write(const char* path, const void* nodes16, uint64_t nNodeB
     if (!path || !nodes16 || !tris16) return fail(TBVH_E_INVALID, "tbvh_cwbvh_file_write: null argument");
     if (nNodeBlocks == 0 || nNodeBlocks % 5 || nTriBlocks % 3 || nNodeBlocks > 0xffffffffull || nTriBlocks / 3 > 0xffffffffull || nTris > 0xffffffffull)
         return fail(TBVH_E_INVALID, "tbvh_cwbvh_file_write: node blocks must be a multiple of 5, triangle blocks of 3, counts 32-bit");
-    if (const char* e = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_write: %s", e);
+    if (const char* e = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(e == kValidateNoMemory ? TBVH_E_NOMEM : TBVH_E_FORMAT, "tbvh_cwbvh_file_write: %s", e);
     const uint32_t idxCount = (uint32_t)(nTriBlocks / 3), usedBlocks = (uint32_t)nNodeBlocks, triCount = (uint32_t)nTris;
     unsigned char obj[kCwObjBytes];
     std::memset(obj, 0, sizeof obj);                 // pointers, context, the embedded MBVH<8>: all rebuilt by Load
@@ -151,7 +154,7 @@ int tbvh_cwbvh_file_read(const char* path, uint64_t expectedTris, tbvh_hostbvh**
     if (fread(h->blocksA.data(), 16, usedBlocks, fc.f) != usedBlocks || fread(h->blocksB.data(), 16, (size_t)idxCount * 3, fc.f) != (size_t)idxCount * 3) {
         delete h; return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_read: short read from %s", path);
     }
-    if (const char* e = validate_cwbvh(h->blocksA.data(), usedBlocks / 5, (uint64_t)idxCount * 3)) { delete h; return fail(TBVH_E_FORMAT, "tbvh_cwbvh_file_read: %s", e); }
+    if (const char* e = validate_cwbvh(h->blocksA.data(), usedBlocks / 5, (uint64_t)idxCount * 3)) { delete h; return fail(e == kValidateNoMemory ? TBVH_E_NOMEM : TBVH_E_FORMAT, "tbvh_cwbvh_file_read: %s", e); }
     if (nTrisOut) *nTrisOut = head[1];
     *out = h;
     return 0;

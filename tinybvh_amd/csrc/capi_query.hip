@@ -124,7 +124,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.omm = Omm{s->opmap, s->opmapN};
     q.probe = nullptr; q.baseBlocks = 0; q.hybridK = s->hybridK; q.flags = 0u;
 #ifdef TBVH_EXPERIMENTS
-    q.flags = c->expFlags & 0x30001u;
+    q.flags = c->expFlags & 0xF30001u;
 #endif
     c->lastProbed = false;
     q.splitBelow = c->splitBelow;
@@ -228,40 +228,42 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                 const int sizeClass = n < (6ull << 20) ? 0 : n < (12ull << 20) ? 1 : 2;
                 s->cohLastClass[any ? 1 : 0] = (uint8_t)sizeClass;
                 CohTuner& tu = s->cohTuner[any ? 1 : 0][sizeClass];
-                const uint32_t slot = (uint32_t)((c->evSeq - 1) % tbvh_context::kTimeRing);   // this query's event pair (timedBegin above)
                 if (!tu.decided && !c->cohTunerMode) {
                     for (size_t k = 0; k < tu.pending.size();) {   // harvest the launches that have finished since
-                        const CohTuner::Pending pe = tu.pending[k];
-                        const uint32_t ps = (uint32_t)((pe.seq - 1) % tbvh_context::kTimeRing);
-                        bool drop = c->evSeq - pe.seq >= tbvh_context::kTimeRing || !c->evDone[ps];
-                        if (!drop && hipEventQuery(c->evRing[ps][1]) == hipSuccess) {
-                            float t1 = 0.f;
-                            if (hipEventElapsedTime(&t1, c->evRing[ps][0], c->evMid[ps]) == hipSuccess && t1 > 0.05f) {   // (an incoherent batch: the first kernel left after a few us)
-                                // time per ray depends on the batch size (the tail of a launch): only batches of about one size are compared
-                                if (!tu.refRays) tu.refRays = pe.rays;
-                                if (pe.rays * 4 >= tu.refRays * 3 && pe.rays * 3 <= tu.refRays * 4) {
-                                    const float perRay = t1 * 1e6f / (float)pe.rays;
-                                    tu.n[pe.mode - 1]++;
-                                    if (perRay < tu.best[pe.mode - 1]) tu.best[pe.mode - 1] = perRay;
-                                }
+                        CohTuner::Pending pe = tu.pending[k];
+                        const hipError_t qe = hipEventQuery(pe.e1);
+                        if (qe == hipErrorNotReady) { (void)hipGetLastError(); k++; continue; }
+                        float t1 = 0.f;
+                        if (qe == hipSuccess && hipEventElapsedTime(&t1, pe.e0, pe.e1) == hipSuccess && t1 > 0.05f) {   // (an incoherent batch: the first kernel left after a few us)
+                            // time per ray depends on the batch size (the tail of a launch): only batches of about one size are compared
+                            if (!tu.refRays) tu.refRays = pe.rays;
+                            if (pe.rays * 4 >= tu.refRays * 3 && pe.rays * 3 <= tu.refRays * 4) {
+                                const float perRay = t1 * 1e6f / (float)pe.rays;
+                                tu.n[pe.mode - 1]++;
+                                if (perRay < tu.best[pe.mode - 1]) tu.best[pe.mode - 1] = perRay;
                             }
-                            drop = true;
-                        } else (void)hipGetLastError();   // (hipErrorNotReady is not an error)
-                        if (drop) tu.pending.erase(tu.pending.begin() + k); else k++;
+                        } else (void)hipGetLastError();
+                        hipEventDestroy(pe.e0); hipEventDestroy(pe.e1);
+                        tu.pending.erase(tu.pending.begin() + k);
                     }
-                    if (tu.n[0] >= 2 && tu.n[1] >= 2) { tu.decided = tu.best[1] < 0.97f * tu.best[0] ? 2 : 1; tu.pending.clear(); }
-                    else if (tu.launches >= 64) { tu.decided = 1; tu.pending.clear(); }   // batches too varied to compare: the schedule that wins on most scenes
+                    if (tu.n[0] >= CohTuner::kSamples && tu.n[1] >= CohTuner::kSamples) { tu.decided = tu.best[1] < 0.97f * tu.best[0] ? 2 : 1; tu.drop_pending(); }
+                    else if (tu.launches >= 64) { tu.decided = 1; tu.drop_pending(); }   // batches too varied to compare: the schedule that wins on most scenes
                 }
-                const bool untimed = c->skipTiming;   // (tbvh_set_timing(0), or a query of the wavefront frame: no event pair to measure with)
-                const int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : ((nDev || untimed) ? 1 : 1 + (int)(tu.launches & 1u));
-                if (!untimed) tu.launches++;
+                // a batch whose size only the device knows (the wavefront stages) cannot be priced per ray: the default schedule, no sample
+                const bool measure = !tu.decided && !c->cohTunerMode && !nDev && tu.pending.size() < 16;
+                const int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : (nDev ? 1 : 1 + (int)(tu.launches & 1u));
+                if (!nDev) tu.launches++;
                 if (mode == 2) qa.flags |= 32u;
+                CohTuner::Pending pe{nullptr, nullptr, mode, n};
+                if (measure) {
+                    if (hipEventCreate(&pe.e0) != hipSuccess || hipEventCreate(&pe.e1) != hipSuccess) { if (pe.e0) hipEventDestroy(pe.e0); pe.e0 = pe.e1 = nullptr; (void)hipGetLastError(); }
+                    else HIP_TRY(hipEventRecord(pe.e0, c->stream));
+                }
                 launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, mode == 2 ? blocksBase : blocks, c->stream, 5, small, blocks7);
                 HIP_TRY(hipGetLastError());
-                if (!tu.decided && !c->cohTunerMode && !nDev && !untimed && tu.pending.size() < 16) {
-                    if (!c->evMid[slot]) HIP_TRY(hipEventCreate(&c->evMid[slot]));
-                    HIP_TRY(hipEventRecord(c->evMid[slot], c->stream));
-                    tu.pending.push_back(CohTuner::Pending{c->evSeq, mode, n});
+                if (pe.e0) {
+                    HIP_TRY(hipEventRecord(pe.e1, c->stream));
+                    tu.pending.push_back(pe);
                 }
                 QueryArgs qb = q;
                 // the incoherent flavor on 28 one-wave workgroups per CU when the batch fills the grid (24 is the persistent grid's size: 20 / 26 / 28 / 30 /

@@ -93,7 +93,7 @@ extern "C" {
 int tbvh_upload_bvh_gpu(tbvh_context* c, const void* nodes64, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx,
                         const void* verts16, uint64_t nTris, tbvh_scene** out) {
     if (!c || !nodes64 || !primIdx || !verts16 || !out || nNodes == 0) return fail(TBVH_E_INVALID, "tbvh_upload_bvh_gpu: null/empty argument");
-    if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(TBVH_E_FORMAT, "%s", why);
+    if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(why == kValidateNoMemory ? TBVH_E_NOMEM : TBVH_E_FORMAT, "%s", why);
     TBVH_ENTER(c);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
@@ -119,7 +119,7 @@ int tbvh_upload_bvh_gpu(tbvh_context* c, const void* nodes64, uint64_t nNodes, c
 
 int tbvh_upload_bvh4_gpu(tbvh_context* c, const void* blocks16, uint64_t nBlocks, tbvh_scene** out) {
     if (!c || !blocks16 || !out || nBlocks < 4) return fail(TBVH_E_INVALID, "tbvh_upload_bvh4_gpu: null/empty argument");
-    if (const char* why = validate_bvh4_gpu((const Vec4*)blocks16, nBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
+    if (const char* why = validate_bvh4_gpu((const Vec4*)blocks16, nBlocks)) return fail(why == kValidateNoMemory ? TBVH_E_NOMEM : TBVH_E_FORMAT, "%s", why);
     TBVH_ENTER(c);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH4_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
@@ -137,7 +137,7 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
     if (!c || !nodes16 || !out || nNodeBlocks < 5 || (nTriBlocks && !tris16)) return fail(TBVH_E_INVALID, "tbvh_upload_cwbvh: null/empty argument");
     if (nNodeBlocks % 5) return fail(TBVH_E_FORMAT, "CWBVH node blocks (%llu) not a multiple of 5", (unsigned long long)nNodeBlocks);
     if (nNodeBlocks >> 32) return fail(TBVH_E_FORMAT, "CWBVH node blocks (%llu) beyond the layout's 32-bit block index", (unsigned long long)nNodeBlocks);   // (cw_load_node: 32-bit float4 offsets)
-    if (const char* why = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
+    if (const char* why = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(why == kValidateNoMemory ? TBVH_E_NOMEM : TBVH_E_FORMAT, "%s", why);
     TBVH_ENTER(c);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_CWBVH);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
@@ -220,7 +220,7 @@ int buildTlas4(tbvh_scene* s) {
 int tlasCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* idx, uint64_t nIdx, const void* inst, uint64_t nInst) {
     tbvh_context* c = s->ctx;
     // same hardening as the BLAS uploads: the TLAS kernels index instances[idx[]] and blas[blasIdx] unguarded
-    if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(TBVH_E_FORMAT, "TLAS: %s", why);
+    if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(why == kValidateNoMemory ? TBVH_E_NOMEM : TBVH_E_FORMAT, "TLAS: %s", why);
     for (uint64_t i = 0; i < nIdx; i++) if (idx[i] >= nInst) return fail(TBVH_E_FORMAT, "TLAS: primIdx[%llu] = %u is not an instance (%llu instances)", (unsigned long long)i, idx[i], (unsigned long long)nInst);
     const BLASInstanceCheck* ic = (const BLASInstanceCheck*)inst;
     for (uint64_t i = 0; i < nInst; i++) if (ic[i].blasIdx >= s->nBlas) return fail(TBVH_E_FORMAT, "instance %llu: blasIdx %u out of range (%llu BLASes)", (unsigned long long)i, ic[i].blasIdx, (unsigned long long)s->nBlas);
@@ -277,7 +277,7 @@ int tbvh_update_tlas(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const 
 int tbvh_update_bvh_gpu(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx, const void* verts16, uint64_t nTris) {
     if (!s || s->isTlas || s->layout != TBVH_LAYOUT_BVH_GPU || !nodes64 || !primIdx || !verts16 || !nNodes) return fail(TBVH_E_INVALID, "tbvh_update_bvh_gpu: not a BVH_GPU scene or null/empty argument");
     if (nNodes * 4 > s->capNodeBlocks || nIdx * 3 > s->capTriBlocks) return fail(TBVH_E_INVALID, "tbvh_update_bvh_gpu: the blob (%llu nodes, %llu indices) is larger than the one uploaded: free the scene and upload", (unsigned long long)nNodes, (unsigned long long)nIdx);
-    if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(TBVH_E_FORMAT, "%s", why);
+    if (const char* why = validate_bvh_gpu((const NodeAL*)nodes64, nNodes, nIdx)) return fail(why == kValidateNoMemory ? TBVH_E_NOMEM : TBVH_E_FORMAT, "%s", why);
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
     uint32_t* dIdx = nullptr; float4* dVerts = nullptr;
@@ -298,7 +298,7 @@ int tbvh_update_bvh_gpu(tbvh_scene* s, const void* nodes64, uint64_t nNodes, con
 int tbvh_update_bvh4_gpu(tbvh_scene* s, const void* blocks16, uint64_t nBlocks) {
     if (!s || s->isTlas || s->layout != TBVH_LAYOUT_BVH4_GPU || !blocks16 || nBlocks < 4) return fail(TBVH_E_INVALID, "tbvh_update_bvh4_gpu: not a BVH4_GPU scene or null/empty argument");
     if (nBlocks > s->capNodeBlocks) return fail(TBVH_E_INVALID, "tbvh_update_bvh4_gpu: the blob (%llu blocks) is larger than the one uploaded (%llu): free the scene and upload", (unsigned long long)nBlocks, (unsigned long long)s->capNodeBlocks);
-    if (const char* why = validate_bvh4_gpu((const Vec4*)blocks16, nBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
+    if (const char* why = validate_bvh4_gpu((const Vec4*)blocks16, nBlocks)) return fail(why == kValidateNoMemory ? TBVH_E_NOMEM : TBVH_E_FORMAT, "%s", why);
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
     HIP_TRY(hipMemcpyAsync(s->nodes, blocks16, nBlocks * 16, hipMemcpyHostToDevice, c->stream));
@@ -314,7 +314,7 @@ int tbvh_update_cwbvh(tbvh_scene* s, const void* nodes16, uint64_t nNodeBlocks, 
     if (nNodeBlocks % 5) return fail(TBVH_E_FORMAT, "CWBVH node blocks (%llu) not a multiple of 5", (unsigned long long)nNodeBlocks);
     if (nNodeBlocks > s->capNodeBlocks || nTriBlocks > s->capTriBlocks) return fail(TBVH_E_INVALID, "tbvh_update_cwbvh: the blob (%llu + %llu blocks) is larger than the one uploaded (%llu + %llu): free the scene and upload",
                                                                                     (unsigned long long)nNodeBlocks, (unsigned long long)nTriBlocks, (unsigned long long)s->capNodeBlocks, (unsigned long long)s->capTriBlocks);
-    if (const char* why = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(TBVH_E_FORMAT, "%s", why);
+    if (const char* why = validate_cwbvh((const Vec4*)nodes16, nNodeBlocks / 5, nTriBlocks)) return fail(why == kValidateNoMemory ? TBVH_E_NOMEM : TBVH_E_FORMAT, "%s", why);
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
     HIP_TRY(hipMemcpyAsync(s->nodes, nodes16, nNodeBlocks * 16, hipMemcpyHostToDevice, c->stream));
@@ -326,6 +326,7 @@ int tbvh_update_cwbvh(tbvh_scene* s, const void* nodes16, uint64_t nNodeBlocks, 
     s->bytes -= (s->nNodeBlocks + s->nTriBlocks) * 16; s->bytes += (nNodeBlocks + nTriBlocks) * 16;
     s->nNodes = nNodes; s->nNodeBlocks = nNodeBlocks; s->nTriBlocks = nTriBlocks; s->topoHash = hash;
     if (s->refitScratch) { hipFree(s->refitScratch); s->refitScratch = nullptr; }   // (sized and filled for the old tree)
+    if (!sameShape) for (auto& kind : s->cohTuner) for (CohTuner& tu : kind) if (!tu.pinned) { tu.drop_pending(); tu = CohTuner(); }   // (its timings were taken on the old tree)
     if (sameShape) {   // boxes and vertices moved, the tree did not: the derived copies keep their numbering and are re-derived on the device
         if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);
         if (s->nodesHy) launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, nNodes, s->hybridK, (c->embedTris && !(c->expFlags & 8u)) ? s->tris : nullptr, c->stream);
@@ -397,6 +398,7 @@ int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t n
         return fail(TBVH_E_FORMAT, (st & 8u) ? "BVH2 -> CWBVH: a BVH2 leaf holds more than 3 triangles (SplitLeafs(3) first, like BVH8_CWBVH::ConvertFrom)"
                                              : "BVH2 -> CWBVH: malformed BVH2 (child, primitive or triangle index out of range)");
     }
+    if (((uint64_t)nWide * 5) >> 32) return fail(TBVH_E_FORMAT, "BVH2 -> CWBVH: %u nodes are beyond the layout's 32-bit block index", nWide);   // (as tbvh_upload_cwbvh refuses them)
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_CWBVH);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
     // keep exactly what was produced
@@ -696,6 +698,7 @@ void tbvh_free_scene(tbvh_scene* s) {
     if (s->refitScratch) hipFree(s->refitScratch);
     if (s->opmap) hipFree(s->opmap);
     if (s->vertStage) hipFree(s->vertStage);
+    for (auto& kind : s->cohTuner) for (CohTuner& tu : kind) tu.drop_pending();
     for (size_t i = 0; i < c->scenes.size(); i++)
         if (c->scenes[i] == s) { c->scenes.erase(c->scenes.begin() + i); break; }
     delete s;
@@ -710,6 +713,32 @@ int tbvh_debug_coherent_schedule(tbvh_scene* s, int anyhit, uint32_t out[4]) {
     out[0] = s->ctx->cohTunerMode ? (uint32_t)s->ctx->cohTunerMode : (uint32_t)t.decided;
     out[1] = t.n[0]; out[2] = t.n[1];
     out[3] = (t.n[0] && t.n[1]) ? (uint32_t)(1000.f * t.best[1] / t.best[0]) : 0u;
+    return 0;
+}
+
+// ---- the coherent-batch schedule as something a caller can read, keep and give back -------------------------------------------------------
+int tbvh_scene_get_schedule_hint(tbvh_scene* s, tbvh_schedule_hint* out) {
+    if (!s || !out) return fail(TBVH_E_INVALID, "tbvh_scene_get_schedule_hint: null argument");
+    TBVH_LOCK(s->ctx);
+    std::memset(out, 0, sizeof *out);
+    for (int k = 0; k < 3; k++) {
+        out->closest_hit[k] = (uint8_t)(s->ctx->cohTunerMode ? s->ctx->cohTunerMode : s->cohTuner[0][k].decided);
+        out->any_hit[k] = (uint8_t)(s->ctx->cohTunerMode ? s->ctx->cohTunerMode : s->cohTuner[1][k].decided);
+    }
+    return 0;
+}
+
+int tbvh_scene_set_schedule_hint(tbvh_scene* s, const tbvh_schedule_hint* hint) {
+    if (!s || !hint) return fail(TBVH_E_INVALID, "tbvh_scene_set_schedule_hint: null argument");
+    for (int k = 0; k < 3; k++) if (hint->closest_hit[k] > 2 || hint->any_hit[k] > 2) return fail(TBVH_E_INVALID, "tbvh_scene_set_schedule_hint: entries are 0 (measure), 1 (deferred + gated) or 2 (strict)");
+    TBVH_LOCK(s->ctx);
+    for (int a = 0; a < 2; a++) for (int k = 0; k < 3; k++) {
+        const uint8_t v = a ? hint->any_hit[k] : hint->closest_hit[k];
+        CohTuner& tu = s->cohTuner[a][k];
+        tu.drop_pending();
+        tu = CohTuner();          // (0: back to measuring, from scratch)
+        if (v) { tu.decided = v; tu.pinned = true; }
+    }
     return 0;
 }
 
@@ -732,6 +761,7 @@ int tbvh_cwbvh_set_hybrid(tbvh_scene* s, int64_t packedNodes) {
     s->hyTried = true;   // the caller decides now: no lazy build behind its back
     if (packedNodes < 0) return 0;
     if (s->nTriBlocks / 3 >= (1ull << 27)) return fail(TBVH_E_INVALID, "tbvh_cwbvh_set_hybrid: 2^27 triangle records or more");
+    if ((uint64_t)s->nNodes * 8 >> 32) return fail(TBVH_E_INVALID, "tbvh_cwbvh_set_hybrid: 2^29 nodes or more (the copy is addressed in 32-bit float4 offsets: cwbvh_node.h)");
     const uint32_t K = (uint32_t)std::min<uint64_t>((uint64_t)packedNodes, s->nNodes) & ~7u;   // the padded part starts on a 128-byte line
     if (!s->hyPerm && !s->hyLevelOrder) {
         std::vector<Vec4> host((size_t)s->nNodes * 5);

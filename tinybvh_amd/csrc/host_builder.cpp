@@ -1030,7 +1030,8 @@ bool cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>
 // ---- not a wild read on the device ----------------------------------------------------------
 namespace tbvh {
 
-const char* validate_bvh_gpu(const NodeAL* n, uint64_t nNodes, uint64_t nIdx) {
+static const char* validate_bvh_gpu_impl(const NodeAL* n, uint64_t nNodes, uint64_t nIdx) {
+    if (nNodes == 0) return "BVH_GPU: empty node array";
     for (uint64_t i = 0; i < nNodes; i++) {
         if (n[i].triCount) {
             if ((uint64_t)n[i].firstTri + n[i].triCount > nIdx) return "BVH_GPU leaf: firstTri + triCount exceeds the primIdx array";
@@ -1052,7 +1053,7 @@ const char* validate_bvh_gpu(const NodeAL* n, uint64_t nNodes, uint64_t nIdx) {
     return nullptr;
 }
 
-const char* validate_bvh4_gpu(const Vec4* b, uint64_t nBlocks) {
+static const char* validate_bvh4_gpu_impl(const Vec4* b, uint64_t nBlocks) {
     // walk the stream from the root; every reachable node and triangle run must lie inside it
     std::vector<uint32_t> stack{0};
     uint64_t visited = 0;
@@ -1072,11 +1073,12 @@ const char* validate_bvh4_gpu(const Vec4* b, uint64_t nBlocks) {
     return nullptr;
 }
 
-const char* validate_cwbvh(const Vec4* nodes, uint64_t nNodes, uint64_t nTriBlocks) {
+static const char* validate_cwbvh_impl(const Vec4* nodes, uint64_t nNodes, uint64_t nTriBlocks) {
     auto u32 = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    if (nNodes == 0) return "CWBVH: empty node array";
     const uint32_t rootImask = u32(nodes[0].w) >> 24;
     uint32_t rootMeta[2]; std::memcpy(rootMeta, &nodes[1].z, 8);
-    if (nNodes == 0 || (rootImask == 0 && rootMeta[0] == 0 && rootMeta[1] == 0)) return "CWBVH root node is empty";
+    if (rootImask == 0 && rootMeta[0] == 0 && rootMeta[1] == 0) return "CWBVH root node is empty";
     for (uint64_t k = 0; k < nNodes; k++) {
         const Vec4* p = nodes + k * 5;
         const uint32_t imask = u32(p[0].w) >> 24, base = u32(p[1].x), triBase = u32(p[1].y);
@@ -1116,6 +1118,19 @@ const char* validate_cwbvh(const Vec4* nodes, uint64_t nNodes, uint64_t nTriBloc
         }
     }
     return nullptr;
+}
+
+// The walks above allocate (a visited flag per node, a stack): running out of host memory on a very large blob must come back through the C ABI
+// as TBVH_E_NOMEM, not unwind through extern "C" (kValidateNoMemory is compared by address in capi_internal.h: validate_failed).
+const char* const kValidateNoMemory = "out of host memory while validating the blob";
+const char* validate_bvh_gpu(const NodeAL* n, uint64_t nNodes, uint64_t nIdx) {
+    try { return validate_bvh_gpu_impl(n, nNodes, nIdx); } catch (const std::bad_alloc&) { return kValidateNoMemory; }
+}
+const char* validate_bvh4_gpu(const Vec4* b, uint64_t nBlocks) {
+    try { return validate_bvh4_gpu_impl(b, nBlocks); } catch (const std::bad_alloc&) { return kValidateNoMemory; }
+}
+const char* validate_cwbvh(const Vec4* nodes, uint64_t nNodes, uint64_t nTriBlocks) {
+    try { return validate_cwbvh_impl(nodes, nNodes, nTriBlocks); } catch (const std::bad_alloc&) { return kValidateNoMemory; }
 }
 
 }  // namespace tbvh

@@ -69,6 +69,7 @@ bool cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>
 const char* validate_bvh_gpu(const NodeAL* nodes, uint64_t nNodes, uint64_t nIdx);
 const char* validate_bvh4_gpu(const Vec4* blocks, uint64_t nBlocks);
 const char* validate_cwbvh(const Vec4* nodes, uint64_t nNodes, uint64_t nTriBlocks);
+extern const char* const kValidateNoMemory;   // what the three return (by address) when the walk itself ran out of host memory
 
 // BLASInstance record, 192 bytes (tiny_bvh.h:1443-1457).
 struct Instance192 {

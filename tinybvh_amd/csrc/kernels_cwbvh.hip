@@ -223,7 +223,9 @@ __global__ __launch_bounds__(WG, (STEAL || TRI2) ? MINW : 1) void k_cwbvh(const 
             // one after the other —, so a 2- or 3-triangle group costs the lane one pass less in which it sits out the node phase
             // (traverse_cwbvh.cl:289-327 tests a group's triangles in one loop).  Front-most bit first, as the mirror does; the tie rule makes the
             // order immaterial for the record.
-            const bool two = TRI2 && tg.y != 0;
+            // (gate, flags bits 20..23: only when at least that many lanes of the wave hold a second triangle — the second test is issued for the
+            // whole wave whenever ONE lane wants it)
+            const bool two = TRI2 && tg.y != 0 && (((q.flags >> 20) & 15u) == 0u || wave_count(tg.y != 0) >= ((q.flags >> 20) & 15u));
             float4 f2 = make_float4(0, 0, 0, 0), f1 = f2, w0 = f2;
             if (two) {
                 const uint32_t tj = 31u - (uint32_t)__clz(tg.y);
