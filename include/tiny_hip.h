@@ -82,6 +82,19 @@ private:
     tbvh_context* ctx = nullptr;
 };
 
+// tinyocl::Buffer( bytes, hostPtr ) for a host array that is traced many times (tiny_bvh_speedtest.cpp:1101-1108 wraps its ray array in one per GPU
+// block): page-locks the memory for the object's lifetime (tbvh_pin_host); a PACKED 64-byte ray array then goes up by DMA straight from here.
+class PinnedHost {
+public:
+    PinnedHost(void* ptr, size_t bytes, tbvh_context* own = nullptr, int device = 0) : p(ptr), ctx(own ? own : Context(device)) { Check(tbvh_pin_host(ctx, p, bytes), "tbvh_pin_host"); }
+    PinnedHost(const PinnedHost&) = delete;
+    PinnedHost& operator=(const PinnedHost&) = delete;
+    ~PinnedHost() { tbvh_unpin_host(ctx, p); }
+private:
+    void* p;
+    tbvh_context* ctx;
+};
+
 // One host Ray[] over several devices (each holds a Scene of the same BVH): contiguous shards, results in place.
 inline void IntersectSharded(const std::vector<Scene*>& replicas, tinybvh::Ray* rays, size_t n) {
     std::vector<tbvh_scene*> h;

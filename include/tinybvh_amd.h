@@ -233,11 +233,16 @@ int tbvh_intersect(tbvh_scene* scene, void* rays, uint64_t n_rays, uint32_t stri
  * (BVH::IsOccluded, tiny_bvh.h:3382-3453; isoccluded_* in the .cl files). */
 int tbvh_occluded(tbvh_scene* scene, const void* rays, uint64_t n_rays,
                   uint32_t stride_bytes, uint8_t* occluded);
-/* The tinyocl::Buffer( bytes, hostPtr ) of this boundary (tiny_ocl.h; tiny_bvh_speedtest.cpp:1101-1108 wraps its Ray array in one before
- * every GPU block): page-locks [ptr, ptr + bytes) and maps it into the device's address space.  tbvh_intersect / tbvh_occluded on this
- * context whose records lie inside a pinned range then read the 64-byte prefixes and write bytes 44..63 IN PLACE over the link
- * (no staging copy on the host).  Pinning costs about as much as one pass over the array: pin once, trace many times
- * (the speedtest traces the same array 9 times).  The caller unpins before it frees the memory. */
+/* Host arrays of 32 k rays and more are pipelined in groups of ~4 M rays: host threads pack group g + 1 into pinned buffers while the link
+ * carries it up, the device traces group g, a second stream carries its 20 result bytes per ray down (full duplex) and the host scatters
+ * group g - 1's results into the caller's records; 16.7 M tinybvh::Ray records: bench.py detail.host_rays.  TBVH_HOST_THREADS = host threads
+ * used (default: every core the process may use, up to 16).  tbvh_time_last_ms then reports the sum of the groups' kernel times.
+ *
+ * The tinyocl::Buffer( bytes, hostPtr ) of this boundary (tiny_ocl.h; tiny_bvh_speedtest.cpp:1101-1108 wraps its Ray array in one before
+ * every GPU block): tbvh_pin_host page-locks [ptr, ptr + bytes).  A PACKED (64-byte stride) ray array inside a pinned range then goes up by DMA
+ * straight from the caller's memory, without the packing pass (a 128-byte-stride array is packed by the host threads either way: letting
+ * the device read it in place costs a 128-byte read per 64 useful bytes, profiles/r05_link_rate.txt).  Pinning costs about as much as several
+ * passes over the array: pin once, trace many times.  The caller unpins before it frees the memory. */
 int tbvh_pin_host(tbvh_context* ctx, void* ptr, uint64_t bytes);
 int tbvh_unpin_host(tbvh_context* ctx, void* ptr);
 
@@ -314,11 +319,6 @@ int tbvh_measure_valu_issue(tbvh_context* ctx, uint32_t reps, double* ginstr_per
 /* the host link: GB/s of a pinned hipMemcpyAsync of `bytes` up and down, best of `reps` (bench.py: detail.host_rays) */
 int tbvh_measure_link_bandwidth(tbvh_context* ctx, uint64_t bytes, uint32_t reps, double* h2d_gbps, double* d2h_gbps);
 
-/* Lane-utilisation counters of the instrumented kernel variants (development aid):
- * out[0] wave iterations, [1] sum of active lanes, [2] sum of lanes in the node step,
- * [3] triangle-loop iterations, [4] sum of lanes in them, [5] refill events, [6] rays handed out. */
-int tbvh_debug_stats(tbvh_context* ctx, uint64_t out[8], int reset);
-
 /* BVH8_CWBVH placement for INCOHERENT batches (the blob the caller uploaded is unchanged; "the library may keep a re-laid-out copy"):
  * a copy of the nodes in surface-area priority order — the nodes a ray is most likely to visit first —, the first packed_nodes of them
  * (rounded down to a multiple of 8) packed 80 bytes apart, all later ones one per 128-byte line, plus the triangle records padded to 64
@@ -332,25 +332,10 @@ int tbvh_debug_stats(tbvh_context* ctx, uint64_t out[8], int reset);
  * current by tbvh_refit. */
 int tbvh_cwbvh_set_hybrid(tbvh_scene* scene, int64_t packed_nodes);
 
-/* Experiment switches for the BVH8_CWBVH kernel of the next launches on this context (development aid; 0 = as shipped):
- * 1 = non-temporal ray loads / hit stores, 2 = the 64-byte triangle records in the ordinary kernels too (only where the scene has them:
- * after tbvh_cwbvh_set_hybrid or the first large launch; ignored otherwise) — both only in the experiment build (make EXPERIMENTS=1: the
- * shipped kernels do not carry the two code paths), 4 = a probed launch as ONE kernel even where the copies exist,
- * 8 = the next tbvh_cwbvh_set_hybrid / lazy build derives the node copy WITHOUT a triangle in each node's line, 64 = no coherence probe (every
- * launch takes the unprobed path), bits 8..15 = waves per CU of the incoherent flavor (clamped to the 32 per CU the stack spill area is sized for). */
-int tbvh_debug_set_flags(tbvh_context* ctx, uint32_t flags);
-
-/* Which schedule the library has settled on for COHERENT batches of 2 M rays and more on this BVH8_CWBVH scene (closest-hit: anyhit = 0,
- * any-hit: 1) — the deferred-triangles + gated schedule on a third more waves, or the strict one.  No static property of a blob tells which
- * is faster (profiles/r04_sensitivity.txt: +1 ... +8 % for the first on most scenes, +10 % for the second on large-occluder scenes), so the
- * first few such launches alternate and are timed on the device (no synchronisation), then the faster stays (TBVH_COHERENT_TUNER=0 / 2 in
- * the environment pins the first / the second).  out[0] = 0 still measuring, 1 deferred + gated, 2 strict; out[1], out[2] = coherent samples
- * taken of each; out[3] = 1000 x best time per ray of the strict schedule / of the deferred one (0 until both have samples).  The choice is kept
- * per batch-size class (below 6 M rays, below 12 M, more: the end of a launch weighs differently — the atrium generator's camera rays are 15 % faster
- * strict at 16.7 M rays and even at 4.2 M); the call reports the class of the most recent launch. */
-int tbvh_debug_coherent_schedule(tbvh_scene* scene, int anyhit, uint32_t out[4]);
-
-/* The same decision as something a caller can READ, KEEP and GIVE BACK (a renderer that wants its first frame at full speed and the same
+/* Which schedule serves COHERENT batches of 2 M rays and more on a BVH8_CWBVH scene — deferred triangles + a gated triangle phase on a third more
+ * waves, or the strict one — is measured by the library during the scene's first such launches (no static property of a blob tells which is faster:
+ * +1 ... +8 % for the first on most scenes, +10 % for the second on large-occluder scenes, profiles/r04_sensitivity.txt).  The decision as something
+ * a caller can READ, KEEP and GIVE BACK (a renderer that wants its first frame at full speed and the same
  * schedule from run to run): one entry per batch-size class (fewer than 6 M rays, fewer than 12 M, more) and query kind; 0 = not decided yet
  * (the library is still alternating and timing — with its own events, so tbvh_set_timing(0) does not stop it; batches whose size only the
  * device knows are never sampled and run the deferred schedule), 1 = deferred + gated, 2 = strict.  tbvh_scene_set_schedule_hint pins the
@@ -361,17 +346,6 @@ int tbvh_debug_coherent_schedule(tbvh_scene* scene, int anyhit, uint32_t out[4])
 typedef struct tbvh_schedule_hint { uint8_t closest_hit[3]; uint8_t any_hit[3]; uint8_t reserved[2]; } tbvh_schedule_hint;
 int tbvh_scene_get_schedule_hint(tbvh_scene* scene, tbvh_schedule_hint* out);
 int tbvh_scene_set_schedule_hint(tbvh_scene* scene, const tbvh_schedule_hint* hint);
-
-/* The per-launch coherence probe of the most recent query on this context (development aid; DESIGN.md par. 3): out[0] = sampled
- * neighbouring ray pairs whose directions agree (and, for rays of finite reach, whose origins lie within 5 % of that reach), out[1] = pairs sampled, out[2] = 0 no probe ran (small batches, small or very
- * large scenes, other layouts), 1 the batch was classified incoherent (strict schedule), 2 coherent (deferred triangles, gated
- * triangle phase, a third more waves).  Synchronizes the stream. */
-int tbvh_debug_last_probe(tbvh_context* ctx, uint32_t out[3]);
-
-/* Diagnostic kernel variants of BVH8_CWBVH scenes (0 = default): 72 / 52 force the strict / the coherent schedule whatever
- * the probe says, 90 the incoherent flavor on the copies of tbvh_cwbvh_set_hybrid, 75 / 88 split the last rays whatever the batch size, 59 / 61 / 73 / 78 / 82 / 83 are the instrumented
- * kernels behind tbvh_debug_stats.  Returns TBVH_E_INVALID for anything else. */
-int tbvh_set_variant(tbvh_scene* scene, int variant);
 
 /* ------------------------------------------------------------------------------------
  * wavefront path-tracing helpers (device) — the ray generators of

@@ -1,0 +1,48 @@
+/* tinybvh_amd_debug.h — development aids of the MI355X engine: instrumentation counters, experiment switches, forced kernel schedules, the
+ * coherence probe's last verdict.  NOT part of the boundary a tinybvh maintainer binds (include/tinybvh_amd.h is); used by tests/ and tools/.
+ * Same library, same ABI version. */
+#ifndef TINYBVH_AMD_DEBUG_H_
+#define TINYBVH_AMD_DEBUG_H_
+#include "tinybvh_amd.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Lane-utilisation counters of the instrumented kernel variants (development aid):
+ * out[0] wave iterations, [1] sum of active lanes, [2] sum of lanes in the node step,
+ * [3] triangle-loop iterations, [4] sum of lanes in them, [5] refill events, [6] rays handed out. */
+int tbvh_debug_stats(tbvh_context* ctx, uint64_t out[8], int reset);
+
+/* Experiment switches for the BVH8_CWBVH kernel of the next launches on this context (development aid; 0 = as shipped):
+ * 1 = non-temporal ray loads / hit stores, 2 = the 64-byte triangle records in the ordinary kernels too (only where the scene has them:
+ * after tbvh_cwbvh_set_hybrid or the first large launch; ignored otherwise) — both only in the experiment build (make EXPERIMENTS=1: the
+ * shipped kernels do not carry the two code paths), 4 = a probed launch as ONE kernel even where the copies exist,
+ * 8 = the next tbvh_cwbvh_set_hybrid / lazy build derives the node copy WITHOUT a triangle in each node's line, 64 = no coherence probe (every
+ * launch takes the unprobed path), bits 8..15 = waves per CU of the incoherent flavor (clamped to the 32 per CU the stack spill area is sized for). */
+int tbvh_debug_set_flags(tbvh_context* ctx, uint32_t flags);
+
+/* Which schedule the library has settled on for COHERENT batches of 2 M rays and more on this BVH8_CWBVH scene (closest-hit: anyhit = 0,
+ * any-hit: 1) — the deferred-triangles + gated schedule on a third more waves, or the strict one.  No static property of a blob tells which
+ * is faster (profiles/r04_sensitivity.txt: +1 ... +8 % for the first on most scenes, +10 % for the second on large-occluder scenes), so the
+ * first few such launches alternate and are timed on the device (no synchronisation), then the faster stays (TBVH_COHERENT_TUNER=0 / 2 in
+ * the environment pins the first / the second).  out[0] = 0 still measuring, 1 deferred + gated, 2 strict; out[1], out[2] = coherent samples
+ * taken of each; out[3] = 1000 x best time per ray of the strict schedule / of the deferred one (0 until both have samples).  The choice is kept
+ * per batch-size class (below 6 M rays, below 12 M, more: the end of a launch weighs differently — the atrium generator's camera rays are 15 % faster
+ * strict at 16.7 M rays and even at 4.2 M); the call reports the class of the most recent launch. */
+int tbvh_debug_coherent_schedule(tbvh_scene* scene, int anyhit, uint32_t out[4]);
+
+/* The per-launch coherence probe of the most recent query on this context (development aid; DESIGN.md par. 3): out[0] = sampled
+ * neighbouring ray pairs whose directions agree (and, for rays of finite reach, whose origins lie within 5 % of that reach), out[1] = pairs sampled, out[2] = 0 no probe ran (small batches, small or very
+ * large scenes, other layouts), 1 the batch was classified incoherent (strict schedule), 2 coherent (deferred triangles, gated
+ * triangle phase, a third more waves).  Synchronizes the stream. */
+int tbvh_debug_last_probe(tbvh_context* ctx, uint32_t out[3]);
+
+/* Diagnostic kernel variants of BVH8_CWBVH scenes (0 = default): 72 / 52 force the strict / the coherent schedule whatever
+ * the probe says, 90 the incoherent flavor on the copies of tbvh_cwbvh_set_hybrid, 75 / 88 split the last rays whatever the batch size, 59 / 61 / 73 / 78 / 82 / 83 are the instrumented
+ * kernels behind tbvh_debug_stats.  Returns TBVH_E_INVALID for anything else. */
+int tbvh_set_variant(tbvh_scene* scene, int variant);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYBVH_AMD_DEBUG_H_ */

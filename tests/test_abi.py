@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def header_symbols():
-    src = open(os.path.join(ROOT, "include", "tinybvh_amd.h")).read()
+    src = open(os.path.join(ROOT, "include", "tinybvh_amd.h")).read() + open(os.path.join(ROOT, "include", "tinybvh_amd_debug.h")).read()   # (the boundary + the development aids)
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(tbvh_[a-z0-9_]+)\s*\(", src)))
 

@@ -63,13 +63,34 @@ def test_refit_parity(ctx, oracle, layout):
 def test_refit_to_same_vertices_reproduces_the_encoder(ctx):
     """CWBVH: the device re-quantisation is the host encoder's arithmetic: same vertices -> same node bytes."""
     verts = scenes.soup(3000, seed=5)
-    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    sc = tb.BVH8_CWBVH(ctx).Build(verts, split_budget=0.0)      # whole triangles: a leaf box is its triangles' box, which is what a refit computes
     before_n = sc.host.blob(0, np.uint32, 4).copy(); before_t = sc.host.blob(1, np.uint32, 4).copy()
     sc.Refit(verts)
     n, t = sc.download_blobs()
     assert np.array_equal(t, before_t)
     same = np.all(n.reshape(-1, 20) == before_n.reshape(-1, 20), axis=1)
     assert same.mean() > 0.999, f"{(~same).sum()} of {same.size} nodes differ"
+
+
+@pytest.mark.gpu
+def test_refit_of_a_split_tree_keeps_every_record(ctx, oracle):
+    """The default BVH8_CWBVH tree holds PIECES of large triangles (TBVH_BUILD_SPLIT_TRIANGLES): a refit fits every leaf to its whole triangles again
+    (looser boxes, same topology, the triangle records untouched) — the hit records must not change, before or after moving the vertices."""
+    verts = scenes.rotate(scenes.rotate(scenes.atrium(30_000, seed=1), 0, 0.618), 1, 0.755)
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    assert sc.host.blob(1, np.uint32, 4).shape[0] // 3 > verts.shape[0] // 3                    # the tree does hold split triangles
+    lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+    rays = R.random_rays(40_000, lo, hi, seed=11)
+    want = oracle_hits(oracle, verts, rays)
+    check(sc.Intersect(rays.copy()), want)
+    before_t = sc.host.blob(1, np.uint32, 4).copy()
+    sc.Refit(verts)
+    n, t = sc.download_blobs()
+    assert np.array_equal(t, before_t)
+    check(sc.Intersect(rays.copy()), want)
+    v2 = deform(verts, 0.1, seed=4)
+    sc.Refit(v2)
+    check(sc.Intersect(rays.copy()), oracle_hits(oracle, v2, rays))
 
 
 @pytest.mark.gpu

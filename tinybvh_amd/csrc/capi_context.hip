@@ -141,6 +141,7 @@ float tbvh_time_last_ms(tbvh_context* c) {
     if (!c) return -1.0f;
     TBVH_LOCK(c);
     if (!c->timed) return -1.0f;
+    if (c->hostQuerySeq == c->evSeq && c->hostQueryMs >= 0.f) return c->hostQueryMs;   // a host-array query runs as several launches: their sum
     hipSetDevice(c->device);
     if (hipEventSynchronize(c->ev1) != hipSuccess) return -1.0f;
     float ms = -1.0f;

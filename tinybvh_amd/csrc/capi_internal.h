@@ -3,6 +3,7 @@
 // Not installed; nothing outside tinybvh_amd/csrc includes it.
 #pragma once
 #include "../../include/tinybvh_amd.h"
+#include "../../include/tinybvh_amd_debug.h"
 
 #include <hip/hip_runtime.h>
 
@@ -87,9 +88,11 @@ struct tbvh_context {
     // hipMemcpy2D moves ~9 GB/s because one CPU thread does the staging copy), and the 20 result bytes per ray come back
     // packed (k_pack_hits) and are scattered by the same workers
     struct HostPipe* pipe = nullptr;
-    // host ranges the caller pinned for this context (tbvh_pin_host): a host-array query whose records lie inside one reads and writes them in
-    // place over the link (kernels_raygen.hip: k_gather_host_rays / k_scatter_host_hits) instead of staging them through the library's buffers
-    struct PinnedRange { char* host; uint64_t bytes; char* dev; };
+    // host ranges the caller pinned for this context (tbvh_pin_host): a packed (64-byte) ray array inside one goes up by DMA straight from the
+    // caller's memory, without the packing pass through the library's pinned ring (capi_query.hip: hostQuery)
+    struct PinnedRange { char* host; uint64_t bytes; };
+    float hostQueryMs = -1.f;     // device time of the most recent host-array query (the sum over its groups' launches) ...
+    uint64_t hostQuerySeq = ~0ull; // ... valid while no later operation was timed (evSeq still equals this)
     std::vector<PinnedRange> pinned;
     void* binScratch = nullptr;   // tbvh_bin_rays_device
     size_t binScratchBytes = 0;
@@ -191,9 +194,12 @@ struct tbvh_hostbvh {
 struct HostPipe {
     static constexpr uint64_t kChunk = 1ull << 18;   // rays per chunk: 16 MB up, 5 MB down
     void* pinUp[2] = {nullptr, nullptr};
-    void* pinDown[2] = {nullptr, nullptr};
-    hipEvent_t evUp[2] = {nullptr, nullptr}, evDown[2] = {nullptr, nullptr};
+    hipEvent_t evUp[2] = {nullptr, nullptr};
+    hipStream_t down = nullptr;   // the results' way back: pack kernel + device-to-host copies, beside the uploads and kernels on the context's stream
+    hipEvent_t evKernel = nullptr;
+    std::vector<hipEvent_t> evGroup;   // group g's results have landed in pinDown
     uint32_t* packed = nullptr;   // device: 5 dwords per ray (bytes 44..63 of the record)
+    void* pinDown = nullptr;      // pinned host: the same, for the whole batch
     uint64_t packedCap = 0;
     // a small persistent worker pool: parallel_for(n, fn) runs fn(part, parts) on every worker and the caller
     std::vector<std::thread> workers;
@@ -239,10 +245,12 @@ struct HostPipe {
         for (auto& w : workers) w.join();
         for (int i = 0; i < 2; i++) {
             if (pinUp[i]) hipHostFree(pinUp[i]);
-            if (pinDown[i]) hipHostFree(pinDown[i]);
             if (evUp[i]) hipEventDestroy(evUp[i]);
-            if (evDown[i]) hipEventDestroy(evDown[i]);
         }
+        for (hipEvent_t e : evGroup) hipEventDestroy(e);
+        if (evKernel) hipEventDestroy(evKernel);
+        if (down) hipStreamDestroy(down);
+        if (pinDown) hipHostFree(pinDown);
         if (packed) hipFree(packed);
     }
 };

@@ -24,87 +24,124 @@ int ensureStageOcc(tbvh_context* c, uint64_t n) {
 }  // namespace tbvh_capi
 namespace tbvh_capi {
 
-int ensurePipe(tbvh_context* c, uint64_t n) {
+int ensurePipe(tbvh_context* c, uint64_t nHits) {
     if (!c->pipe) {
         HostPipe* p = new (std::nothrow) HostPipe;
         if (!p) return fail(TBVH_E_NOMEM, "out of host memory");
         c->pipe = p;
         for (int i = 0; i < 2; i++) {
             HIP_TRY(hipHostMalloc(&p->pinUp[i], HostPipe::kChunk * 64, hipHostMallocDefault));
-            HIP_TRY(hipHostMalloc(&p->pinDown[i], HostPipe::kChunk * 20, hipHostMallocDefault));
             HIP_TRY(hipEventCreateWithFlags(&p->evUp[i], hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&p->evDown[i], hipEventDisableTiming));
         }
-        uint32_t hw = usable_host_threads();
-        uint32_t t = hw >= 32 ? 7 : hw >= 8 ? 3 : hw >= 4 ? 1 : 0;   // + the calling thread
+        HIP_TRY(hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&p->evKernel, hipEventDisableTiming));
+        // The packing and scattering of the caller's records is host memcpy work: 16.7 M records of a tinybvh::Ray[] pack in 78 / 22 / 17 / 13 ms on
+        // 1 / 4 / 8 / 16 threads of the round-5 box (tools/ubench/link_rate.hip) against 19 ms the link needs for them — every core the process
+        // may use takes part (up to 16), the calling thread being one of them
+        const uint32_t hw = usable_host_threads();
+        uint32_t t = hw > 16 ? 15 : hw > 1 ? hw - 1 : 0;
         if (const char* e = getenv("TBVH_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) t = (uint32_t)v - 1; }
         p->start(t);
     }
     HostPipe* p = c->pipe;
-    if (p->packedCap < n) {
+    if (p->packedCap < nHits) {
+        HIP_TRY(hipStreamSynchronize(p->down));
         if (p->packed) hipFree(p->packed);
-        p->packed = nullptr; p->packedCap = 0;
-        HIP_TRY(hipMalloc((void**)&p->packed, n * 20));
-        p->packedCap = n;
+        if (p->pinDown) hipHostFree(p->pinDown);
+        p->packed = nullptr; p->pinDown = nullptr; p->packedCap = 0;
+        HIP_TRY(hipMalloc((void**)&p->packed, nHits * 20));
+        HIP_TRY(hipHostMalloc(&p->pinDown, nHits * 20, hipHostMallocDefault));
+        p->packedCap = nHits;
     }
     return 0;
 }
 
-// caller records (stride bytes apart) -> device array of 64-byte records
-int pipeUpload(tbvh_context* c, const char* rays, uint64_t n, uint32_t stride, RayRec* dst) {
+static bool isPinned(tbvh_context* c, const void* p, uint64_t bytes) {
+    for (const tbvh_context::PinnedRange& r : c->pinned)
+        if ((const char*)p >= r.host && (const char*)p + bytes <= r.host + r.bytes) return true;
+    return false;
+}
+
+// ---- a host ray array through the device, pipelined -----------------------------------------------------------------------------------------
+// tiny_bvh_speedtest.cpp:1110-1137 does, one after the other: a memcpy loop (64 of every 128 bytes into a tinyocl::Buffer), CopyToDevice, Kernel::Run,
+// CopyFromDevice, and the caller's loop over the results.  Here the batch is cut into groups of ~4 M rays and the stages of consecutive groups
+// overlap: while the host threads pack group g + 1 into the pinned upload ring (chunks of 256 k rays, two buffers) and the link carries them up,
+// the device traces group g and a second stream packs its 20 result bytes per ray and carries them DOWN (the link is full duplex:
+// 48 GB/s each way at once against 57 one way, tools/ubench/link_rate.hip); the host scatters group g - 1's results into the caller's records.
+// What was measured and NOT taken (profiles/r05_link_rate.txt): hipMemcpy2D for the strided side (19 GB/s up, 3-4 GB/s down), and the device
+// reading / writing the caller's pinned array itself (a 128-byte record costs a 128-byte read for its 64 useful bytes: 27 GB/s; 20-byte writes
+// cost a 64-byte line each: 20 GB/s of results).  A packed (64-byte) array the caller pinned (tbvh_pin_host) needs no packing: it goes up by DMA
+// straight from the caller's memory.
+constexpr uint64_t kGroupRays = 4ull << 20;
+
+int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint32_t stride, uint8_t* occ) {
+    tbvh_context* c = s->ctx;
+    if (int r = ensureStage(c, n)) return r;
+    if (occ) if (int r = ensureStageOcc(c, n)) return r;
+    if (int r = ensurePipe(c, occ ? 0 : n)) return r;
     HostPipe* p = c->pipe;
-    for (uint64_t first = 0, k = 0; first < n; first += HostPipe::kChunk, k++) {
-        const uint64_t cnt = n - first < HostPipe::kChunk ? n - first : HostPipe::kChunk;
-        const int b = (int)(k & 1);
-        if (k >= 2) HIP_TRY(hipEventSynchronize(p->evUp[b]));   // the DMA that last read this buffer is done
-        char* pin = (char*)p->pinUp[b];
-        const char* src = rays + first * stride;
+    const bool direct = stride == 64 && isPinned(c, raysIn, n * 64);
+    const uint64_t G = n <= kGroupRays + kGroupRays / 2 ? 1 : (n + kGroupRays - 1) / kGroupRays;
+    const uint64_t per = (((n + G - 1) / G) + HostPipe::kChunk - 1) / HostPipe::kChunk * HostPipe::kChunk;
+    while (p->evGroup.size() < G) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->evGroup.push_back(e); }
+    const uint64_t seq0 = c->evSeq;
+    uint64_t chunkNo = 0;
+    auto drain = [&](uint64_t g) -> int {   // group g's results into the caller's records
+        const uint64_t b = g * per, e = b + per < n ? b + per : n;
+        HIP_TRY(hipEventSynchronize(p->evGroup[g]));
+        const char* pin = (const char*)p->pinDown;
         p->parallel_for([=](uint32_t part, uint32_t parts) {
-            const uint64_t lo = cnt * part / parts, hi = cnt * (part + 1) / parts;
-            if (stride == 64) std::memcpy(pin + lo * 64, src + lo * 64, (hi - lo) * 64);
-            else for (uint64_t i = lo; i < hi; i++) std::memcpy(pin + i * 64, src + i * stride, 64);
+            const uint64_t lo = b + (e - b) * part / parts, hi = b + (e - b) * (part + 1) / parts;
+            for (uint64_t i = lo; i < hi; i++) std::memcpy(raysOut + i * stride + 44, pin + i * 20, 20);
         });
-        HIP_TRY(hipMemcpyAsync(dst + first, pin, cnt * 64, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipEventRecord(p->evUp[b], c->stream));
-    }
-    return 0;
-}
-
-// device records -> bytes 44..63 of the caller's records
-int pipeDownloadHits(tbvh_context* c, char* rays, uint64_t n, uint32_t stride, const RayRec* src) {
-    HostPipe* p = c->pipe;
-    launch_pack_hits(src, p->packed, n, c->stream);
-    HIP_TRY(hipGetLastError());
-    const uint64_t chunks = (n + HostPipe::kChunk - 1) / HostPipe::kChunk;
-    auto issue = [&](uint64_t k) -> int {
-        const uint64_t first = k * HostPipe::kChunk, cnt = n - first < HostPipe::kChunk ? n - first : HostPipe::kChunk;
-        HIP_TRY(hipMemcpyAsync(p->pinDown[k & 1], (const char*)p->packed + first * 20, cnt * 20, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipEventRecord(p->evDown[k & 1], c->stream));
         return 0;
     };
-    if (int r = issue(0)) return r;
-    for (uint64_t k = 0; k < chunks; k++) {
-        if (k + 1 < chunks) if (int r = issue(k + 1)) return r;   // next chunk in flight while this one is scattered
-        HIP_TRY(hipEventSynchronize(p->evDown[k & 1]));
-        const uint64_t first = k * HostPipe::kChunk, cnt = n - first < HostPipe::kChunk ? n - first : HostPipe::kChunk;
-        const char* pin = (const char*)p->pinDown[k & 1];
-        char* dstRays = rays + first * stride;
-        p->parallel_for([=](uint32_t part, uint32_t parts) {
-            const uint64_t lo = cnt * part / parts, hi = cnt * (part + 1) / parts;
-            for (uint64_t i = lo; i < hi; i++) std::memcpy(dstRays + i * stride + 44, pin + i * 20, 20);
-        });
+    for (uint64_t g = 0; g < G; g++) {
+        const uint64_t b = g * per, e = b + per < n ? b + per : n;
+        for (uint64_t first = b; first < e; first += HostPipe::kChunk, chunkNo++) {
+            const uint64_t cnt = e - first < HostPipe::kChunk ? e - first : HostPipe::kChunk;
+            if (direct) { HIP_TRY(hipMemcpyAsync(c->stageRays + first, raysIn + first * 64, cnt * 64, hipMemcpyHostToDevice, c->stream)); continue; }
+            const int k = (int)(chunkNo & 1);
+            if (chunkNo >= 2) HIP_TRY(hipEventSynchronize(p->evUp[k]));   // the DMA that last read this buffer is done
+            char* pin = (char*)p->pinUp[k];
+            const char* src = raysIn + first * stride;
+            p->parallel_for([=](uint32_t part, uint32_t parts) {
+                const uint64_t lo = cnt * part / parts, hi = cnt * (part + 1) / parts;
+                if (stride == 64) std::memcpy(pin + lo * 64, src + lo * 64, (hi - lo) * 64);
+                else for (uint64_t i = lo; i < hi; i++) std::memcpy(pin + i * 64, src + i * stride, 64);
+            });
+            HIP_TRY(hipMemcpyAsync(c->stageRays + first, pin, cnt * 64, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipEventRecord(p->evUp[k], c->stream));
+        }
+        if (int r = launchQuery(s, c->stageRays + b, e - b, occ ? c->stageOcc + b : nullptr)) return r;
+        if (!occ) {
+            HIP_TRY(hipEventRecord(p->evKernel, c->stream));
+            HIP_TRY(hipStreamWaitEvent(p->down, p->evKernel, 0));
+            launch_pack_hits(c->stageRays + b, p->packed + b * 5, e - b, p->down);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync((char*)p->pinDown + b * 20, p->packed + b * 5, (e - b) * 20, hipMemcpyDeviceToHost, p->down));
+            HIP_TRY(hipEventRecord(p->evGroup[g], p->down));
+            if (g) if (int r = drain(g - 1)) return r;
+        }
+    }
+    if (occ) HIP_TRY(hipMemcpyAsync(occ, c->stageOcc, n, hipMemcpyDeviceToHost, c->stream));
+    else if (int r = drain(G - 1)) return r;
+    if (int r = checkStatus(c)) return r;
+    // the query's device time = the sum over its groups' launches (what tbvh_time_last_ms reports for a host-array query)
+    if (!c->skipTiming && c->evSeq - seq0 == G && G <= tbvh_context::kTimeRing) {
+        float sum = 0.f; bool ok = true;
+        for (uint64_t q = seq0; q < c->evSeq && ok; q++) {
+            const uint32_t slot = (uint32_t)(q % tbvh_context::kTimeRing);
+            float t = 0.f;
+            ok = c->evDone[slot] && hipEventElapsedTime(&t, c->evRing[slot][0], c->evRing[slot][1]) == hipSuccess;
+            sum += t;
+        }
+        if (ok) { c->hostQueryMs = sum; c->hostQuerySeq = c->evSeq; } else (void)hipGetLastError();
     }
     return 0;
 }
 
 constexpr uint64_t kPipeMinRays = 1ull << 15;
-
-// the device-side address of [p, p + bytes) if the caller pinned a range that holds it (tbvh_pin_host), else nullptr
-static char* pinnedDevicePtr(tbvh_context* c, const void* p, uint64_t bytes) {
-    for (const tbvh_context::PinnedRange& r : c->pinned)
-        if ((const char*)p >= r.host && (const char*)p + bytes <= r.host + r.bytes) return r.dev + ((const char*)p - r.host);
-    return nullptr;
-}
 
 int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh, float freshTmax, const unsigned long long* nDev) {
     tbvh_context* c = s->ctx;
@@ -333,22 +370,8 @@ int tbvh_intersect(tbvh_scene* s, void* rays, uint64_t n, uint32_t stride) {
     if (n == 0) return 0;
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
+    if (n >= kPipeMinRays) return hostQuery(s, (const char*)rays, (char*)rays, n, stride, nullptr);   // pinned, chunked, multi-threaded, pipelined staging
     if (int r = ensureStage(c, n)) return r;
-    if (char* dp = pinnedDevicePtr(c, rays, (n - 1) * (uint64_t)stride + 64)) {   // the caller pinned the array: in place over the link, no host copy at all
-        launch_gather_host_rays(dp, stride, c->stageRays, n, c->stream);
-        HIP_TRY(hipGetLastError());
-        if (int r = launchQuery(s, c->stageRays, n, nullptr)) return r;
-        launch_scatter_host_hits(c->stageRays, dp, stride, n, c->stream);
-        HIP_TRY(hipGetLastError());
-        return checkStatus(c);
-    }
-    if (n >= kPipeMinRays) {   // pinned, chunked, multi-threaded staging (see HostPipe)
-        if (int r = ensurePipe(c, n)) return r;
-        if (int r = pipeUpload(c, (const char*)rays, n, stride, c->stageRays)) return r;
-        if (int r = launchQuery(s, c->stageRays, n, nullptr)) return r;
-        if (int r = pipeDownloadHits(c, (char*)rays, n, stride, c->stageRays)) return r;
-        return checkStatus(c);
-    }
     HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
     if (int r = launchQuery(s, c->stageRays, n, nullptr)) return r;
     // copy back bytes 44..63 of every record (hit.inst + hit)
@@ -362,15 +385,10 @@ int tbvh_occluded(tbvh_scene* s, const void* rays, uint64_t n, uint32_t stride, 
     if (n == 0) return 0;
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
+    if (n >= kPipeMinRays) return hostQuery(s, (const char*)rays, nullptr, n, stride, occ);
     if (int r = ensureStage(c, n)) return r;
     if (int r = ensureStageOcc(c, n)) return r;
-    if (char* dp = pinnedDevicePtr(c, rays, (n - 1) * (uint64_t)stride + 64)) {
-        launch_gather_host_rays(dp, stride, c->stageRays, n, c->stream);
-        HIP_TRY(hipGetLastError());
-    } else if (n >= kPipeMinRays) {
-        if (int r = ensurePipe(c, n)) return r;
-        if (int r = pipeUpload(c, (const char*)rays, n, stride, c->stageRays)) return r;
-    } else HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
     if (int r = launchQuery(s, c->stageRays, n, c->stageOcc)) return r;
     HIP_TRY(hipMemcpyAsync(occ, c->stageOcc, n, hipMemcpyDeviceToHost, c->stream));
     return checkStatus(c);
@@ -383,11 +401,8 @@ int tbvh_pin_host(tbvh_context* c, void* ptr, uint64_t bytes) {
     TBVH_ENTER(c);
     for (const tbvh_context::PinnedRange& r : c->pinned)
         if ((char*)ptr < r.host + r.bytes && r.host < (char*)ptr + bytes) return fail(TBVH_E_INVALID, "tbvh_pin_host: the range overlaps one that is pinned already");
-    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterMapped | hipHostRegisterPortable));
-    void* dp = nullptr;
-    const hipError_t e = hipHostGetDevicePointer(&dp, ptr, 0);
-    if (e != hipSuccess || !dp) { hipHostUnregister(ptr); return fail(TBVH_E_HIP, "hipHostGetDevicePointer failed: %s", hipGetErrorString(e)); }
-    try { c->pinned.push_back(tbvh_context::PinnedRange{(char*)ptr, bytes, (char*)dp}); }
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
+    try { c->pinned.push_back(tbvh_context::PinnedRange{(char*)ptr, bytes}); }
     catch (const std::bad_alloc&) { hipHostUnregister(ptr); return fail(TBVH_E_NOMEM, "out of host memory"); }
     return 0;
 }
@@ -397,7 +412,7 @@ int tbvh_unpin_host(tbvh_context* c, void* ptr) {
     TBVH_ENTER(c);
     for (size_t i = 0; i < c->pinned.size(); i++)
         if (c->pinned[i].host == (char*)ptr) {
-            HIP_TRY(hipStreamSynchronize(c->stream));   // nothing of this context may still be reading or writing the range
+            HIP_TRY(hipStreamSynchronize(c->stream));   // nothing of this context may still be reading the range
             c->pinned.erase(c->pinned.begin() + i);
             HIP_TRY(hipHostUnregister(ptr));
             return 0;

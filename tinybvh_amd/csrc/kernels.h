@@ -64,8 +64,6 @@ hipError_t launch_refit(int layout, float4* nodes, uint32_t nNodes, float4* tris
 void launch_stream_copy(const float4* src, float4* dst, uint64_t n16, hipStream_t s);
 void launch_stream_read(const float4* src, float* sink, uint64_t n16, uint32_t blocks, hipStream_t s);
 void launch_valu_mix(float* out, int iters, uint32_t blocks, hipStream_t s);   // 32 VALU instructions per iteration and wave
-void launch_gather_host_rays(const void* src, uint32_t stride, RayRec* dst, uint64_t n, hipStream_t s);    // pinned host records -> packed device array
-void launch_scatter_host_hits(const RayRec* rays, void* dst, uint32_t stride, uint64_t n, hipStream_t s);   // bytes 44..63 back into pinned host records
 void launch_pack_hits(const RayRec* rays, uint32_t* out, uint64_t n, hipStream_t s);
 void launch_gather_tris(const uint32_t* primIdx, const float4* verts, float4* out, uint64_t nIdx, uint64_t nTris,
                         hipStream_t s);

@@ -382,24 +382,81 @@ void launch_cwbvh_derive_hybrid(const float4* src, const uint32_t* perm, float4*
     hipLaunchKernelGGL(k_derive_hybrid, dim3((nNodes + 255u) / 256u), dim3(256), 0, s, src, perm, dst, nNodes, hybridK, tris);
 }
 
+// ---- which instantiation serves a launch: a table, first match wins ----------------------------------------------------------------------
+// template arguments of launch_k after ANYHIT:  LDS_N, REFILL_MIN, TRI_MIN, SPEC, STATS, NSTRIDE, PROBED, STEAL, MINW, TRI2
+namespace {
+struct LaunchSel {
+    int nodeStride;        // 5 packed as uploaded, 8 one node per line (padCwbvhIfLarge), kNodeHybrid = the incoherent-batch copies
+    bool tail;             // split the last rays over idle lanes (batches below 12 M rays, device-side ray counts)
+    bool probed;           // the launch carries a coherence probe
+    bool firstOfTwo;       // ... and is the coherent flavor of a two-kernel launch (baseBlocks == 0)
+    bool strictFirst;      // ... which the scene's tuner wants on the strict schedule (flag 32)
+    bool shallow;          // scene under 48 MB
+    uint32_t expFlags;     // experiment builds: QueryArgs::flags
+};
+typedef void (*LaunchFn)(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
+template <auto... A> void launch_both(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s) {
+    if (anyhit) launch_k<true, A...>(nodes, tris, q, status, blocks, s);
+    else launch_k<false, A...>(nodes, tris, q, status, blocks, s);
+}
+struct LaunchRow {
+    bool (*when)(const LaunchSel&);
+    LaunchFn fn;
+    bool cap28;            // built for 7 waves per SIMD (72 VGPRs): at most 28 one-wave workgroups per CU
+};
+// Stack entries in LDS next to the split groups: 6 let more than 24 waves per CU fit (what scenes under 48 MB and coherent probed batches are
+// launched with; Bistro-size trees measure the same with 6 or 8), deep trees want 8 (30 M triangles: 6 costs 7 % on camera rays, 13 % on bounce rays).
+// Those 6-entry kernels with split rays are built for 7 waves per SIMD (72 VGPRs) and launched 28 per CU: under the budget of 8 (64 VGPRs) they
+// spill 12-24 bytes per lane inside the loop (round 2 shipped that: 4 M bounce rays 2420 -> 2810 MRays/s without the spill).
+// Split rays (ray_split.h): Bistro stand-in 0.26 / 1 / 4 / 8 M rays: camera +7 / +20 / +6 / +4 %, bounce +26 / +23 / +8 / +4 %, shadow +20 / +18 / +6 / +4 %;
+// at 16.7 M rays the tail is 5 % of the launch and the kernel's register cap costs as much as it gains.
+const LaunchRow kLaunchTable[] = {
+    // one node per cache line (scenes whose node array is beyond the Infinity Cache; DESIGN.md par. 5: -17 % bytes, +6 % at 60 M triangles)
+    {[](const LaunchSel& x) { return x.nodeStride == 8 && x.tail; },  &launch_both<8, 16, 1, false, 0, 8, 0, 16>, false},
+    {[](const LaunchSel& x) { return x.nodeStride == 8; },            &launch_both<8, 16, 1, false, 0, 8>, false},
+#ifdef TBVH_EXPERIMENTS
+    // round 5: up to two triangle tests per pass (debug flag 0x10000): -13 % on bounce rays (profiles/r05_ab_tri2.txt), not shipped
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x10000u) && x.tail; }, &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 16, 6, 1>, false},
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x10000u) != 0; },      &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 0, 6, 1>, false},
+#endif
+    // the incoherent flavor of a probed launch: `nodes` = the hybrid copy, `tris` = the 64-byte records (cwbvh_node.h, capi_query.hip);
+    // with split rays built for 6 waves per SIMD (80 VGPRs; left alone the compiler takes 83, one wave per SIMD fewer)
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && x.tail; }, &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 16, 6>, false},
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid; },           &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2>, false},
+    // the coherent flavor of a two-kernel probed launch on the STRICT schedule (PROBED == 4): scenes on which the deferred schedule measured
+    // slower (the online tuner of capi_query.hip)
+    {[](const LaunchSel& x) { return x.firstOfTwo && x.strictFirst && x.tail; }, &launch_both<8, 16, 1, false, 0, 5, 4, 16>, false},
+    {[](const LaunchSel& x) { return x.firstOfTwo && x.strictFirst; },           &launch_both<8, 16, 1, false, 0, 5, 4>, false},
+    // ... on the deferred + gated schedule (PROBED == 3): no strict path compiled in (camera rays +1.5 %)
+    {[](const LaunchSel& x) { return x.firstOfTwo && x.tail; }, &launch_both<6, 16, 8, true, 0, 5, 3, 16, 7>, true},
+    {[](const LaunchSel& x) { return x.firstOfTwo; },           &launch_both<8, 16, 8, true, 0, 5, 3>, false},
+    // one kernel for both verdicts (scenes without the incoherent-batch copies)
+    {[](const LaunchSel& x) { return x.probed && x.tail; }, &launch_both<6, 16, 8, true, 0, 5, 1, 16, 7>, true},
+    {[](const LaunchSel& x) { return x.probed; },           &launch_both<8, 16, 8, true, 0, 5, 1>, false},
+    // no probe (small batches, small or very large scenes): the strict schedule
+    {[](const LaunchSel& x) { return x.tail && x.shallow; }, &launch_both<6, 16, 1, false, 0, 5, 0, 16, 7>, true},
+    {[](const LaunchSel& x) { return x.tail; },              &launch_both<8, 16, 1, false, 0, 5, 0, 16>, false},
+    {[](const LaunchSel&) { return true; },                  &launch_both<8, 16, 1, false>, false},
+};
+}  // namespace
+
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                   uint32_t blocks, hipStream_t s, int nodeStride, bool shallow, uint32_t blocks7) {
-#define TBVH_K(...)                                                                     \
-    do {                                                                                \
-        if (anyhit) launch_k<true, __VA_ARGS__>(nodes, tris, q, status, blocks, s);     \
-        else launch_k<false, __VA_ARGS__>(nodes, tris, q, status, blocks, s);           \
-    } while (0)
+    const uint32_t capped = blocks > blocks7 ? blocks7 : blocks;
     // forced schedules (tbvh_set_variant; tests/test_cwbvh_schedules.py, tools/ab_probe.py): kernels the library ships anyway, picked whatever the
     // batch size or the probe says
     switch (variant) {
-    case 72: TBVH_K(8, 16, 1, false); return;     // the strict schedule
-    case 75: TBVH_K(8, 16, 1, false, 0, 5, 0, 16); return;   // strict + split rays whatever the batch size
-    case 88: if (blocks > blocks7) blocks = blocks7; if (q.probe) TBVH_K(6, 16, 8, true, 0, 5, 1, 16, 7); else TBVH_K(6, 16, 1, false, 0, 5, 0, 16, 7); return;   // the probed schedule + split rays whatever the batch size
+    case 72: launch_both<8, 16, 1, false>(anyhit, nodes, tris, q, status, blocks, s); return;                  // the strict schedule
+    case 75: launch_both<8, 16, 1, false, 0, 5, 0, 16>(anyhit, nodes, tris, q, status, blocks, s); return;     // strict + split rays whatever the batch size
+    case 88:                                                                                                   // the probed schedule + split rays whatever the batch size
+        if (q.probe) launch_both<6, 16, 8, true, 0, 5, 1, 16, 7>(anyhit, nodes, tris, q, status, capped, s);
+        else launch_both<6, 16, 1, false, 0, 5, 0, 16, 7>(anyhit, nodes, tris, q, status, capped, s);
+        return;
 #ifdef TBVH_EXPERIMENTS
     // diagnostic kernels, only in the experiment build (make EXPERIMENTS=1 -> libtinybvh_amd_exp.so; TBVH_LIB_OVERRIDE points the tools at it): a schedule
-    // that is not shipped under this template signature, and the instrumented kernels behind the counters of DESIGN.md §5
-    case 52: TBVH_K(8, 16, 8, true); return;      // the coherent schedule without the probe: deferred triangles, triangle phase once 8 lanes wait
-    case 89: if (q.probe) TBVH_K(6, 16, 8, true, 0, 5, 1, 16, 8); else break; return;   // round 2's shipped form of the probed schedule + split rays: 64 VGPRs, 20 bytes of scratch per lane
+    // that is not shipped under this template signature, and the instrumented kernels behind the counters of DESIGN.md par. 5
+    case 52: launch_both<8, 16, 8, true>(anyhit, nodes, tris, q, status, blocks, s); return;      // the coherent schedule without the probe: deferred triangles, triangle phase once 8 lanes wait
+    case 89: if (q.probe) { launch_both<6, 16, 8, true, 0, 5, 1, 16, 8>(anyhit, nodes, tris, q, status, capped, s); return; } break;   // round 2's shipped form of the probed schedule + split rays: 64 VGPRs, 20 bytes of scratch per lane
     case 59: if (anyhit) break; launch_k<false, 8, 16, 1, false, 1>(nodes, tris, q, status, blocks, s); return;    // lane statistics of the strict schedule (q.stats)
     case 61: if (anyhit) break; launch_k<false, 8, 16, 8, true, 1>(nodes, tris, q, status, blocks, s); return;     // ... of the coherent schedule
     case 73: if (anyhit) break; launch_k<false, 8, 16, 1, false, 2>(nodes, tris, q, status, blocks, s); return;    // wave timeline of the strict schedule
@@ -409,43 +466,13 @@ void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* t
 #endif
     default: break;
     }
-    // with a coherence probe of the batch (capi.hip: launchQuery) the schedule is chosen per launch; without one, the strict schedule.
-    // Batches below 12 M rays (and the wavefront stages, whose ray count only the device knows) also split their last rays over idle
-    // lanes (ray_split.h): Bistro stand-in 0.26 / 1 / 4 / 8 M rays: camera +7 / +20 / +6 / +4 %, bounce +26 / +23 / +8 / +4 %, shadow
-    // +20 / +18 / +6 / +4 %; at 16.7 M rays the tail is 5 % of the launch and the kernel's register cap costs as much as it gains
-    const bool tail = split_rays_wanted(q);
-    // Stack entries in LDS next to the split groups: 6 let more than 24 waves per CU fit (what scenes under 48 MB and coherent probed batches are
-    // launched with; Bistro-size trees measure the same with 6 or 8), deep trees want 8 (30 M triangles: 6 costs 7 % on camera rays, 13 % on bounce rays).
-    // Those 6-entry kernels with split rays are built for 7 waves per SIMD (72 VGPRs) and launched 28 per CU: under the budget of 8 (64 VGPRs) they
-    // spill 12-24 bytes per lane inside the loop (round 2 shipped that: 4 M bounce rays 2420 -> 2810 MRays/s without the spill)
-    if (nodeStride == 8) {   // one node per cache line (capi.hip: scenes whose node array is beyond the Infinity Cache; DESIGN.md §5: -17 % bytes, +6 % at 60 M triangles)
-        if (tail) TBVH_K(8, 16, 1, false, 0, 8, 0, 16);
-        else TBVH_K(8, 16, 1, false, 0, 8);
-    } else if (nodeStride == kNodeHybrid) {   // the incoherent flavor of a probed launch: `nodes` = the hybrid copy, `tris` = the 64-byte records (cwbvh_node.h, capi.hip)
-#ifdef TBVH_EXPERIMENTS
-        if (q.flags & 0x10000u) {   // round 5: up to two triangle tests per pass (debug flag 0x10000, + 0x20000: built for 7 waves per SIMD instead of 6)
-            if (tail) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 16, 6, 1);
-            else if (q.flags & 0x20000u) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 0, 7, 1);
-            else TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 0, 6, 1);
-            return;
-        }
-#endif
-        if (tail) TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2, 16, 6);   // (built for 6 waves per SIMD: 80 VGPRs; left alone the compiler takes 83, one wave per SIMD fewer)
-        else TBVH_K(8, 16, 1, false, 0, kNodeHybrid, 2);
-    } else if (q.probe && q.baseBlocks == 0 && (q.flags & 32u)) {   // ... and the same slot of a two-kernel launch with the STRICT schedule (PROBED == 4): coherent batches of
-        if (tail) TBVH_K(8, 16, 1, false, 0, 5, 4, 16);              // scenes on which the deferred schedule measured slower (the online tuner of capi_query.hip)
-        else TBVH_K(8, 16, 1, false, 0, 5, 4);
-    } else if (q.probe && q.baseBlocks == 0) {   // the coherent flavor of a two-kernel probed launch (capi.hip): no strict path compiled in (camera rays +1.5 %)
-        if (tail) { if (blocks > blocks7) blocks = blocks7; TBVH_K(6, 16, 8, true, 0, 5, 3, 16, 7); }
-        else TBVH_K(8, 16, 8, true, 0, 5, 3);
-    } else if (q.probe) {                        // one kernel for both verdicts (scenes without the incoherent-batch copies)
-        if (tail) { if (blocks > blocks7) blocks = blocks7; TBVH_K(6, 16, 8, true, 0, 5, 1, 16, 7); }
-        else TBVH_K(8, 16, 8, true, 0, 5, 1);
-    } else if (tail) {
-        if (shallow) { if (blocks > blocks7) blocks = blocks7; TBVH_K(6, 16, 1, false, 0, 5, 0, 16, 7); }
-        else TBVH_K(8, 16, 1, false, 0, 5, 0, 16);
-    } else TBVH_K(8, 16, 1, false);
-#undef TBVH_K
+    // with a coherence probe of the batch (capi_query.hip: launchQuery) the schedule is chosen per launch; without one, the strict schedule.
+    // Batches below 12 M rays (and the wavefront stages, whose ray count only the device knows) also split their last rays over idle lanes.
+    LaunchSel sel;
+    sel.nodeStride = nodeStride; sel.tail = split_rays_wanted(q); sel.probed = q.probe != nullptr;
+    sel.firstOfTwo = q.probe && q.baseBlocks == 0; sel.strictFirst = (q.flags & 32u) != 0; sel.shallow = shallow; sel.expFlags = q.flags;
+    for (const LaunchRow& row : kLaunchTable)
+        if (row.when(sel)) { row.fn(anyhit, nodes, tris, q, status, row.cap28 ? capped : blocks, s); return; }
 }
 
 namespace {

@@ -180,36 +180,6 @@ void launch_valu_mix(float* out, int iters, uint32_t blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_valu_mix, dim3(blocks), dim3(64), 0, s, out, iters, 1.0001f, 0.5f);
 }
 
-// ---- host ray arrays the caller pinned (tbvh_pin_host): read and written in place over the link, no staging copy on the host ----------------
-// gather: the 64-byte prefix of every `stride`-byte record, four lanes per ray (one 16-byte load each: a ray is ONE 64-byte read request on
-// the link, as wide as a read of mapped host memory gets), written as the packed device array the traversal kernels take.
-// scatter: bytes 44..63 of every record (hit.inst, t, u, v, prim — what CopyFromDevice + the caller's loop take from a tinybvh::Ray), one 4-byte
-// and one 16-byte posted write per ray; the rest of the caller's record is not touched.
-namespace {
-__global__ __launch_bounds__(256) void k_gather_host_rays(const char* __restrict__ src, uint32_t stride, float4* __restrict__ dst, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per float4
-    if (i >= n * 4u) return;
-    const uint64_t r = i >> 2; const uint32_t k = (uint32_t)i & 3u;
-    const tbvh_f4 v = __builtin_nontemporal_load((const tbvh_f4*)(src + r * stride) + k);
-    dst[i] = make_float4(v.x, v.y, v.z, v.w);
-}
-__global__ __launch_bounds__(256) void k_scatter_host_hits(const RayRec* __restrict__ rays, char* __restrict__ dst, uint32_t stride, uint64_t n) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t inst = ((const uint32_t*)(rays + i))[11];
-    const float4 hit = rays[i].hit;
-    char* o = dst + i * stride;
-    *(uint32_t*)(o + 44) = inst;
-    *(float4*)(o + 48) = hit;
-}
-}  // namespace
-void launch_gather_host_rays(const void* src, uint32_t stride, RayRec* dst, uint64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_gather_host_rays, dim3((uint32_t)((n * 4u + 255) / 256)), dim3(256), 0, s, (const char*)src, stride, (float4*)dst, n);
-}
-void launch_scatter_host_hits(const RayRec* rays, void* dst, uint32_t stride, uint64_t n, hipStream_t s) {
-    hipLaunchKernelGGL(k_scatter_host_hits, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, rays, (char*)dst, stride, n);
-}
-
 void launch_pack_hits(const RayRec* rays, uint32_t* out, uint64_t n, hipStream_t s) {
     hipLaunchKernelGGL(k_pack_hits, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, s, rays, out, n);
 }

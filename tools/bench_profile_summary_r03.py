@@ -1,5 +1,5 @@
 """Summary of `rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --no-pmc --no-configs --no-cpu-baseline --no-strong`
-(tools/r03_run6.sh) next to the JSON line the same process printed: per traversal kernel the launches that did work (a probed query is TWO
+(tools/runs/r03_run6.sh) next to the JSON line the same process printed: per traversal kernel the launches that did work (a probed query is TWO
 launches, one per verdict of the coherence probe; the flavor the verdict is not for leaves after ~4 us and is listed apart), whose average must
 agree with the HIP-event averages inside bench.py (detail.kernel_ms).
     python tools/bench_profile_summary_r03.py gpurun_out/r03_6/kt gpurun_out/r03_6/kt_bench.json"""

@@ -1,5 +1,5 @@
 #!/bin/bash
-# builds the library of the last commit into tools/_ab/libbase.so (for tools/r04_ab_lib.sh: A/B of two builds)
+# builds the library of the last commit into tools/_ab/libbase.so (for tools/runs/r04_ab_lib.sh: A/B of two builds)
 set -e
 rm -rf /tmp/basebuild && mkdir -p /tmp/basebuild
 git -C /root/repo archive HEAD tinybvh_amd/csrc include | tar -x -C /tmp/basebuild

@@ -2,8 +2,9 @@
 """The non-axis-aligned gap (round 5, review item 1): the SAME 2.83 M triangles straight and rotated by irrational angles about two axes, the
 same camera carried along, 16.7 M camera / bounce (depth 1-3) / shadow rays each, traced on
 
-    library      the library's own host builder (binned SAH + SAH-optimal collapse): the default
-    library+30%  ... with TBVH_BUILD_SPLIT_TRIANGLES, 30 % extra references (host_builder.cpp: presplit)
+    lib whole    the library's own host builder (binned SAH + SAH-optimal collapse) over whole triangles (TBVH_BUILD_WHOLE_TRIANGLES: round 4's default)
+    lib +30%     ... with triangles split ahead of the build, 30 % extra references (host_builder.cpp: presplit): the default since round 5
+    lib +100%    ... 100 % extra references
     ref Build    the real tinybvh BVH8_CWBVH::Build blob (oracle/_ref), uploaded verbatim
     ref BuildHQ  the real tinybvh BVH8_CWBVH::BuildHQ blob (spatial splits, tiny_bvh.h:2623-3040), uploaded verbatim
 
@@ -46,7 +47,7 @@ def main():
             del full
         print(f"\n{label}; {n} rays per batch, median of {a.passes} launches; S / T on {a.sample} strided rays of each batch")
         print(f"{'tree':14s} {'nodes':>8s} {'tri rec':>8s} {'build s':>7s} | {'camera S':>8s} {'T':>6s} {'lookups':>7s} {'MRays/s':>8s} | {'bounce S':>8s} {'T':>6s} {'lookups':>7s} {'MRays/s':>8s} | {'shadow MRays/s':>14s}")
-        trees = [("library", None), ("library+30%", 0.3)]
+        trees = [("lib whole", 0.0), ("lib +30%", 0.3), ("lib +100%", 1.0)]
         if have_reference():
             trees += [("ref Build", "ref"), ("ref BuildHQ", "refhq")]
         first = {}
@@ -57,11 +58,11 @@ def main():
                 nodes, tris = rs.blob(10, 0, np.uint32, 4), rs.blob(10, 1, np.uint32, 4)
                 used = int(np.flatnonzero(tris.any(1)).max() + 1) // 3 if tris.shape[0] else 0   # (BuildHQ sizes bvh8Tris for 1.5 x the triangles; the tail is slack)
             else:
-                host = tb.HostBVH(verts, tb.LAYOUT_CWBVH, split_budget=spec or 0.0)
+                host = tb.HostBVH(verts, tb.LAYOUT_CWBVH, split_budget=spec)
                 nodes, tris = host.blob(0, np.uint32, 4), host.blob(1, np.uint32, 4)
                 used = tris.shape[0] // 3
             dt = time.time() - t0
-            sc = base if tname == "library" else tb.BVH8_CWBVH(ctx).Upload(nodes, tris)
+            sc = tb.BVH8_CWBVH(ctx).Upload(nodes, tris)
             row = {}
             for kind, d, fn in (("camera", d_prim, None), ("bounce", d_diff, None), ("shadow", d_shad, None)):
                 ms = []
@@ -82,8 +83,7 @@ def main():
                 first = dict(row)
             cells = " | ".join(f"{st[k][0]:8.2f} {st[k][1]:6.2f} {5 * st[k][0] + 3 * st[k][1] + 4:7.1f} {row[k]:8.0f}" for k in ("camera", "bounce"))
             print(f"{tname:14s} {nodes.shape[0] // 5:8d} {used:8d} {dt:7.1f} | {cells} | {row['shadow']:14.0f}", flush=True)
-            if sc is not base:
-                sc.free()
+            sc.free()
         for p_ in (d_prim, d_diff, d_shad, d_occ):
             ctx.free(p_)
         base.free(); ctx.close()
