@@ -23,12 +23,24 @@ timed with the same barrier / max-over-ranks rule: strong scaling.
 the measured device copy bandwidth as a second denominator, the fabric-side traffic measured LIVE by a rocprofv3 --pmc
 child run of this same script (FETCH_SIZE and WRITE_SIZE in separate passes, MI355X_MICROARCH.md corrections), and the
 VALU-issue roofline of both kernels (what actually bounds them: DESIGN.md §5).  `detail.hbm_regime` prices the same kernels against HBM where
-they really fetch from it: the street generator at 30 M triangles (3.3 GB of tree), S / T per ray from the instrumented kernel, bytes from two
-more rocprofv3 --pmc children (hbm_regime below).
+they really fetch from it: the street generator at 1 M and at 12 M triangles (0.9 GB of tree), S / T per ray from the oracle's mirror, bytes
+from two more rocprofv3 --pmc children per scene (hbm_regime below).
 
-One process per GPU; launched by the driver as
+Beside the headline (all outside the timed region, rank 0, one-GPU runs):
+    detail.rotated_scene    the SAME triangles rotated off the coordinate axes (scenes.street_rot), same camera carried along: MRays/s, S / T per ray,
+                            live counters — the other end of the range real scenes lie in (review of round 4, item 1)
+    detail.other_layouts    k_bvh2 / k_bvh4 on the headline batches with the reference's batch_ailalaine / batch_gpu4way (ROCm OpenCL) beside them and
+                            one FETCH_SIZE + one SQ VALU-group counter child each
+    detail.tlas_1000_instances   config 5; k_tlas8 / k_tlas4 beside the reference's traverse_tlas, counters of k_tlas4
+    detail.host_rays        the speedtest's literal call: tbvh_intersect on a HOST tinybvh::Ray[] (stride 128) and packed (stride 64), against the
+                            box's measured link rate
+
+N GPUs, two ways: one process per GPU, launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-torch is used for the barrier / max-reduce over ranks only.
+(torch is used for the barrier / max-reduce over ranks only), or — plain `python bench.py --gpus N`, no torchrun — ONE process that drives N
+devices itself: one context, BVH replica and set of batches per device, one host thread enqueueing every device's launches; `n_gpus` = N and
+detail.per_gpu has N rows either way.  Fewer than N devices visible: an error line and exit code 2, never a 1-GPU number under an N-GPU flag
+(TBVH_BENCH_DEVICE_MAP="0,0" maps N contexts onto listed devices: how a 1-GPU box exercises the path).
 """
 import argparse
 import json
