@@ -229,7 +229,8 @@ struct HostPipe {
                 }
             });
     }
-    void parallel_for(const std::function<void(uint32_t, uint32_t)>& f) {
+    void parallel_for(uint64_t items, const std::function<void(uint32_t, uint32_t)>& f) {
+        if (items < 16384 || workers.empty()) { f(0, 1); return; }   // (a few thousand records: waking the workers costs more than the copy)
         {
             std::lock_guard<std::mutex> lk(m);
             job = f; pending = (uint32_t)workers.size(); generation++;

@@ -78,7 +78,7 @@ int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint
     tbvh_context* c = s->ctx;
     if (int r = ensureStage(c, n)) return r;
     if (occ) if (int r = ensureStageOcc(c, n)) return r;
-    if (int r = ensurePipe(c, occ ? 0 : n)) return r;
+    if (int r = ensurePipe(c, occ ? (n + 19) / 20 : n)) return r;   // (the pinned result buffer: 20 bytes per closest-hit record, 1 per any-hit flag)
     HostPipe* p = c->pipe;
     const bool direct = stride == 64 && isPinned(c, raysIn, n * 64);
     const uint64_t G = n <= kGroupRays + kGroupRays / 2 ? 1 : (n + kGroupRays - 1) / kGroupRays;
@@ -90,7 +90,7 @@ int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint
         const uint64_t b = g * per, e = b + per < n ? b + per : n;
         HIP_TRY(hipEventSynchronize(p->evGroup[g]));
         const char* pin = (const char*)p->pinDown;
-        p->parallel_for([=](uint32_t part, uint32_t parts) {
+        p->parallel_for(e - b, [=](uint32_t part, uint32_t parts) {
             const uint64_t lo = b + (e - b) * part / parts, hi = b + (e - b) * (part + 1) / parts;
             for (uint64_t i = lo; i < hi; i++) std::memcpy(raysOut + i * stride + 44, pin + i * 20, 20);
         });
@@ -105,7 +105,7 @@ int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint
             if (chunkNo >= 2) HIP_TRY(hipEventSynchronize(p->evUp[k]));   // the DMA that last read this buffer is done
             char* pin = (char*)p->pinUp[k];
             const char* src = raysIn + first * stride;
-            p->parallel_for([=](uint32_t part, uint32_t parts) {
+            p->parallel_for(cnt, [=](uint32_t part, uint32_t parts) {
                 const uint64_t lo = cnt * part / parts, hi = cnt * (part + 1) / parts;
                 if (stride == 64) std::memcpy(pin + lo * 64, src + lo * 64, (hi - lo) * 64);
                 else for (uint64_t i = lo; i < hi; i++) std::memcpy(pin + i * 64, src + i * stride, 64);
@@ -124,9 +124,10 @@ int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint
             if (g) if (int r = drain(g - 1)) return r;
         }
     }
-    if (occ) HIP_TRY(hipMemcpyAsync(occ, c->stageOcc, n, hipMemcpyDeviceToHost, c->stream));
+    if (occ) HIP_TRY(hipMemcpyAsync(p->pinDown, c->stageOcc, n, hipMemcpyDeviceToHost, c->stream));
     else if (int r = drain(G - 1)) return r;
     if (int r = checkStatus(c)) return r;
+    if (occ) std::memcpy(occ, p->pinDown, n);
     // the query's device time = the sum over its groups' launches (what tbvh_time_last_ms reports for a host-array query)
     if (!c->skipTiming && c->evSeq - seq0 == G && G <= tbvh_context::kTimeRing) {
         float sum = 0.f; bool ok = true;
@@ -141,7 +142,6 @@ int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint
     return 0;
 }
 
-constexpr uint64_t kPipeMinRays = 1ull << 15;
 
 int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh, float freshTmax, const unsigned long long* nDev) {
     tbvh_context* c = s->ctx;
@@ -370,13 +370,7 @@ int tbvh_intersect(tbvh_scene* s, void* rays, uint64_t n, uint32_t stride) {
     if (n == 0) return 0;
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
-    if (n >= kPipeMinRays) return hostQuery(s, (const char*)rays, (char*)rays, n, stride, nullptr);   // pinned, chunked, multi-threaded, pipelined staging
-    if (int r = ensureStage(c, n)) return r;
-    HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
-    if (int r = launchQuery(s, c->stageRays, n, nullptr)) return r;
-    // copy back bytes 44..63 of every record (hit.inst + hit)
-    HIP_TRY(hipMemcpy2DAsync((char*)rays + 44, stride, (char*)c->stageRays + 44, 64, 20, n, hipMemcpyDeviceToHost, c->stream));
-    return checkStatus(c);
+    return hostQuery(s, (const char*)rays, (char*)rays, n, stride, nullptr);   // pinned, chunked, multi-threaded, pipelined staging (capi_query.hip: hostQuery)
 }
 
 int tbvh_occluded(tbvh_scene* s, const void* rays, uint64_t n, uint32_t stride, uint8_t* occ) {
@@ -385,13 +379,7 @@ int tbvh_occluded(tbvh_scene* s, const void* rays, uint64_t n, uint32_t stride, 
     if (n == 0) return 0;
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
-    if (n >= kPipeMinRays) return hostQuery(s, (const char*)rays, nullptr, n, stride, occ);
-    if (int r = ensureStage(c, n)) return r;
-    if (int r = ensureStageOcc(c, n)) return r;
-    HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, rays, stride, 64, n, hipMemcpyHostToDevice, c->stream));
-    if (int r = launchQuery(s, c->stageRays, n, c->stageOcc)) return r;
-    HIP_TRY(hipMemcpyAsync(occ, c->stageOcc, n, hipMemcpyDeviceToHost, c->stream));
-    return checkStatus(c);
+    return hostQuery(s, (const char*)rays, nullptr, n, stride, occ);
 }
 
 // ---- host arrays the caller pins: the tinyocl::Buffer( bytes, hostPtr ) of this boundary (tiny_ocl.h; tiny_bvh_speedtest.cpp:1101-1108 wraps its
