@@ -1221,8 +1221,8 @@ def tlas_leg(a, log, valu_ceiling):
 
 def host_rays_leg(tb, ctx, sc, d_prim, n):
     """The speedtest's literal call (tiny_bvh_speedtest.cpp:1110-1137): a HOST tinybvh::Ray[] (128-byte records) traced in place through
-    tbvh_intersect, and the packed 64-byte form; as staged by the library (pageable memory: worker threads + pinned bounce buffers) and, pinned
-    by the caller (tbvh_pin_host: the tinyocl::Buffer of this boundary), in place over the link.  84 bytes cross the link per ray (64 up, 20
+    tbvh_intersect, and the packed 64-byte form; from pageable memory (host threads pack into the library's pinned ring) and, packed, from
+    page-locked memory of the library's (tbvh_pinned_malloc: the tinyocl::Buffer of this boundary; DMA straight from it).  84 bytes cross the link per ray (64 up, 20
     down); `frac_of_link` = that traffic over the call's wall time against the link's measured pinned hipMemcpyAsync rates."""
     up, down = ctx.link_bandwidth_gbps(1 << 28, 3)
     rays64 = np.zeros(n, dtype=tb.RAY_DTYPE); ctx.from_device(rays64, d_prim)
@@ -1233,11 +1233,10 @@ def host_rays_leg(tb, ctx, sc, d_prim, n):
     out = {"rays": n, "link_h2d_gbps": up, "link_d2h_gbps": down, "bytes_per_ray_on_the_link": 84, "mrays_at_link_rate": n / ideal_s / 1e6,
            "call": "tbvh_intersect(scene, host Ray[], n, stride): replaces the memcpy loop + CopyToDevice + Kernel::Run + CopyFromDevice of tiny_bvh_speedtest.cpp:1110-1137"}
     first_hits = None
-    for tag, arr, pin in (("stride_128", rays128, False), ("stride_64", rays64.view(np.uint32).reshape(n, 16), False), ("stride_128_pinned", rays128, True), ("stride_64_pinned", rays64.view(np.uint32).reshape(n, 16), True)):
+    pinned64 = ctx.pinned_array((n, 16), np.uint32)       # the packed array in page-locked memory of the library's (tbvh_pinned_malloc)
+    pinned64[:] = rays64.view(np.uint32).reshape(n, 16)
+    for tag, arr in (("stride_128", rays128), ("stride_64", rays64.view(np.uint32).reshape(n, 16)), ("stride_64_pinned", pinned64)):
         try:
-            t_pin = 0.0
-            if pin:
-                t0 = time.perf_counter(); ctx.pin_host(arr); t_pin = time.perf_counter() - t0
             wall, kern = [], []
             for p_ in range(4):
                 arr[:, 12] = np.float32(1e30).view(np.uint32); arr[:, 13:16] = 0
@@ -1246,8 +1245,6 @@ def host_rays_leg(tb, ctx, sc, d_prim, n):
                 dt = time.perf_counter() - t0
                 if p_:
                     wall.append(dt); kern.append(ctx.time_last_ms())
-            if pin:
-                ctx.unpin_host(arr)
             w = float(np.median(wall))
             hits = int((arr[:, 12].view(np.float32) < 1e30).sum())
             if first_hits is None:
@@ -1255,10 +1252,10 @@ def host_rays_leg(tb, ctx, sc, d_prim, n):
                 same = True
             else:
                 same = bool(np.array_equal(arr[:, 11:16], first_hits))
-            out[tag] = {"mrays": n / w / 1e6, "ms_per_call": w * 1e3, "kernel_ms": float(np.median(kern)), "frac_of_link": ideal_s / w, "hits": hits, "records_equal_first_variant": same,
-                        **({"pin_ms_once": t_pin * 1e3} if pin else {})}
+            out[tag] = {"mrays": n / w / 1e6, "ms_per_call": w * 1e3, "kernel_ms": float(np.median(kern)), "frac_of_link": ideal_s / w, "hits": hits, "records_equal_first_variant": same}
         except Exception as e:
             out[tag] = {"error": repr(e)[:300]}
+    ctx.pinned_free(pinned64)
     return out
 
 

@@ -82,16 +82,17 @@ private:
     tbvh_context* ctx = nullptr;
 };
 
-// tinyocl::Buffer( bytes, hostPtr ) for a host array that is traced many times (tiny_bvh_speedtest.cpp:1101-1108 wraps its ray array in one per GPU
-// block): page-locks the memory for the object's lifetime (tbvh_pin_host); a PACKED 64-byte ray array then goes up by DMA straight from here.
-class PinnedHost {
+// tinyocl::Buffer( bytes ) for a ray array that is traced many times (tiny_bvh_speedtest.cpp:1101-1108 wraps its ray array in one per GPU block): page-locked
+// host memory of the library's for the object's lifetime (tbvh_pinned_malloc); a PACKED 64-byte ray array in it goes up by DMA straight from there.
+class PinnedBuffer {
 public:
-    PinnedHost(void* ptr, size_t bytes, tbvh_context* own = nullptr, int device = 0) : p(ptr), ctx(own ? own : Context(device)) { Check(tbvh_pin_host(ctx, p, bytes), "tbvh_pin_host"); }
-    PinnedHost(const PinnedHost&) = delete;
-    PinnedHost& operator=(const PinnedHost&) = delete;
-    ~PinnedHost() { tbvh_unpin_host(ctx, p); }
+    explicit PinnedBuffer(size_t bytes, tbvh_context* own = nullptr, int device = 0) : ctx(own ? own : Context(device)) { Check(tbvh_pinned_malloc(ctx, bytes, &p), "tbvh_pinned_malloc"); }
+    PinnedBuffer(const PinnedBuffer&) = delete;
+    PinnedBuffer& operator=(const PinnedBuffer&) = delete;
+    ~PinnedBuffer() { tbvh_pinned_free(ctx, p); }
+    void* GetHostPtr() const { return p; }      // (tinyocl::Buffer::GetHostPtr)
 private:
-    void* p;
+    void* p = nullptr;
     tbvh_context* ctx;
 };
 

@@ -238,13 +238,14 @@ int tbvh_occluded(tbvh_scene* scene, const void* rays, uint64_t n_rays,
  * group g - 1's results into the caller's records; 16.7 M tinybvh::Ray records: bench.py detail.host_rays.  TBVH_HOST_THREADS = host threads
  * used (default: every core the process may use, up to 16).  tbvh_time_last_ms then reports the sum of the groups' kernel times.
  *
- * The tinyocl::Buffer( bytes, hostPtr ) of this boundary (tiny_ocl.h; tiny_bvh_speedtest.cpp:1101-1108 wraps its Ray array in one before
- * every GPU block): tbvh_pin_host page-locks [ptr, ptr + bytes).  A PACKED (64-byte stride) ray array inside a pinned range then goes up by DMA
- * straight from the caller's memory, without the packing pass (a 128-byte-stride array is packed by the host threads either way: letting
- * the device read it in place costs a 128-byte read per 64 useful bytes, profiles/r05_link_rate.txt).  Pinning costs about as much as several
- * passes over the array: pin once, trace many times.  The caller unpins before it frees the memory. */
-int tbvh_pin_host(tbvh_context* ctx, void* ptr, uint64_t bytes);
-int tbvh_unpin_host(tbvh_context* ctx, void* ptr);
+ * The tinyocl::Buffer( bytes ) of this boundary (a Buffer made without a host pointer owns its host side, tiny_ocl.h; tiny_bvh_speedtest.cpp:1101-1108
+ * wraps its ray array in one before every GPU block): tbvh_pinned_malloc hands out page-locked host memory.  A PACKED (64-byte stride) ray array that lives
+ * there goes up by DMA straight from it, without the packing pass (a 128-byte-stride array is packed by the host threads wherever it lives: letting the
+ * device read it in place costs a 128-byte read per 64 useful bytes, profiles/r05_link_rate.txt).  The library never page-locks memory it did not allocate:
+ * registering caller memory (hipHostRegister) made later, unrelated pageable copies fault the GPU on this stack (DESIGN.md par. 0, "found on the way").
+ * Memory not given back by tbvh_pinned_free goes with the context. */
+int tbvh_pinned_malloc(tbvh_context* ctx, uint64_t bytes, void** out);
+int tbvh_pinned_free(tbvh_context* ctx, void* ptr);
 
 /* Device-resident packed rays (64-byte stride, 16-byte aligned).  Asynchronous on the
  * context's stream; no host copies.  This is the timed path.

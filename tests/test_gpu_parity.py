@@ -357,48 +357,39 @@ def test_bvh4_leaves_beyond_255_triangles(ctx, oracle, counts):
 
 @pytest.mark.parametrize("n", [777, 200_000])
 @pytest.mark.parametrize("layout", LAYOUTS)
-def test_pinned_host_rays_are_traced_in_place(ctx, oracle, soup, layout, n):
-    """tbvh_pin_host (the tinyocl::Buffer( bytes, hostPtr ) of this boundary, tiny_bvh_speedtest.cpp:1101-1108): a pinned host Ray[] is read and
-    written IN PLACE over the link — same records as the staged path byte for byte, the caller's half of every 128-byte record untouched, misses
-    untouched, sub-ranges of the pinned range work, IsOccluded likewise; pinning twice / unpinning a stranger is an error code, not a crash."""
+def test_rays_in_pinned_memory_of_the_library(ctx, oracle, soup, layout, n):
+    """tbvh_pinned_malloc (the tinyocl::Buffer( bytes ) of this boundary, tiny_bvh_speedtest.cpp:1101-1108): a packed ray array in page-locked memory of the
+    library's goes up by DMA straight from there — same records as from pageable memory byte for byte; a 128-byte-stride array in such memory, sub-ranges
+    and IsOccluded work the same; freeing a stranger is an error code, not a crash."""
     sc = upload(ctx, layout, soup)
     rays = R.random_rays(n, (0, 0, 0), (10, 10, 10), seed=31)
     rays["u"] = 3.0; rays["prim"] = 4242
-    want = sc.Intersect(rays.copy())                                   # the staged path (pageable memory)
+    want = sc.Intersect(rays.copy())                                   # from pageable memory
     assert_parity(want, oracle_hits(oracle, sc, soup, rays))
-    wide = np.zeros((n, 2), dtype=tb.RAY_DTYPE)
-    wide[:, 0] = rays
-    wide[:, 1]["t"] = 99.0; wide[:, 1]["prim"] = 7
-    flat = wide.reshape(-1)
     from tinybvh_amd import _capi
     import ctypes as C
-    ctx.pin_host(flat)
+    packed = ctx.pinned_array((n,), tb.RAY_DTYPE)
+    wide = ctx.pinned_array((n, 2), tb.RAY_DTYPE)
     try:
-        assert _capi.lib.tbvh_pin_host(ctx._h, C.c_void_p(flat.ctypes.data + 64), 1024) != 0       # overlaps a pinned range
-        _capi.check(_capi.lib.tbvh_intersect(sc._h, C.c_void_p(flat.ctypes.data), n, 128), "tbvh_intersect")
-        got = np.ascontiguousarray(wide[:, 0])
-        assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
-        assert np.all(wide[:, 1]["t"] == 99.0) and np.all(wide[:, 1]["prim"] == 7)
-        # a sub-range of the pinned array (the speedtest traces slices of its Ray array), re-armed
-        k0, k1 = n // 3, n // 3 + n // 2
-        wide[:, 0] = rays
-        _capi.check(_capi.lib.tbvh_intersect(sc._h, C.c_void_p(flat.ctypes.data + k0 * 128), k1 - k0, 128), "tbvh_intersect")
-        assert np.array_equal(np.ascontiguousarray(wide[k0:k1, 0]).view(np.uint8), want[k0:k1].view(np.uint8))
-        assert np.array_equal(np.ascontiguousarray(wide[:k0, 0]).view(np.uint8), rays[:k0].view(np.uint8))      # outside the slice: not touched
-        # any-hit from the pinned array
-        wide[:, 0] = rays; wide[:, 0]["t"] = np.float32(2.5)
-        sh = np.ascontiguousarray(wide[:, 0])
-        occ = np.zeros(n, np.uint8)
-        _capi.check(_capi.lib.tbvh_occluded(sc._h, C.c_void_p(flat.ctypes.data), n, 128, C.c_void_p(occ.ctypes.data)), "tbvh_occluded")
-        assert np.array_equal(occ, sc.IsOccluded(sh))
-    finally:
-        ctx.unpin_host(flat)
-    assert _capi.lib.tbvh_unpin_host(ctx._h, C.c_void_p(flat.ctypes.data)) != 0                     # not pinned any more
-    # packed 64-byte records, pinned
-    packed = rays.copy()
-    ctx.pin_host(packed)
-    try:
+        packed[:] = rays
         got = sc.Intersect(packed)
         assert np.array_equal(got.view(np.uint8), want.view(np.uint8))
+        # a sub-range (the speedtest traces slices of its ray array), re-armed
+        k0, k1 = n // 3, n // 3 + n // 2
+        packed[:] = rays
+        _capi.check(_capi.lib.tbvh_intersect(sc._h, C.c_void_p(packed.ctypes.data + k0 * 64), k1 - k0, 64), "tbvh_intersect")
+        assert np.array_equal(packed[k0:k1].view(np.uint8), want[k0:k1].view(np.uint8))
+        assert np.array_equal(packed[:k0].view(np.uint8), rays[:k0].view(np.uint8))      # outside the slice: not touched
+        # any-hit from the same memory
+        packed[:] = rays; packed["t"] = np.float32(2.5)
+        occ = sc.IsOccluded(packed)
+        assert np.array_equal(occ, sc.IsOccluded(packed.copy()))
+        # a tinybvh::Ray[] (128-byte records) in such memory: the caller's half stays untouched
+        wide[:, 0] = rays
+        wide[:, 1]["t"] = 99.0; wide[:, 1]["prim"] = 7
+        _capi.check(_capi.lib.tbvh_intersect(sc._h, C.c_void_p(wide.ctypes.data), n, 128), "tbvh_intersect")
+        assert np.array_equal(np.ascontiguousarray(wide[:, 0]).view(np.uint8), want.view(np.uint8))
+        assert np.all(wide[:, 1]["t"] == 99.0) and np.all(wide[:, 1]["prim"] == 7)
     finally:
-        ctx.unpin_host(packed)
+        ctx.pinned_free(packed); ctx.pinned_free(wide)
+    assert _capi.lib.tbvh_pinned_free(ctx._h, C.c_void_p(rays.ctypes.data)) != 0       # not memory of tbvh_pinned_malloc

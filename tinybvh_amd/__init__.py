@@ -120,12 +120,22 @@ class Context:
         check(lib.tbvh_measure_link_bandwidth(self._h, nbytes, reps, C.byref(up), C.byref(down)), "tbvh_measure_link_bandwidth")
         return float(up.value), float(down.value)
 
-    def pin_host(self, a: np.ndarray):
-        """tbvh_pin_host on a numpy array's memory: host-array queries on it then run in place over the link.  Unpin before the array goes away."""
-        check(lib.tbvh_pin_host(self._h, _ptr(a), a.nbytes), "tbvh_pin_host")
+    def pinned_array(self, shape, dtype) -> np.ndarray:
+        """A numpy array in page-locked host memory of the library's (tbvh_pinned_malloc): a packed RAY_DTYPE array that lives there goes up by DMA
+        without the packing pass.  Give it back with pinned_free(array) (or it goes with the context)."""
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = C.c_void_p()
+        check(lib.tbvh_pinned_malloc(self._h, max(n, 1), C.byref(p)), "tbvh_pinned_malloc")
+        buf = (C.c_char * max(n, 1)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
 
-    def unpin_host(self, a: np.ndarray):
-        check(lib.tbvh_unpin_host(self._h, _ptr(a)), "tbvh_unpin_host")
+    def pinned_free(self, a: np.ndarray):
+        p = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        check(lib.tbvh_pinned_free(self._h, C.c_void_p(p if p is not None else a.ctypes.data)), "tbvh_pinned_free")
 
     def time_last_ms(self) -> float:
         return float(lib.tbvh_time_last_ms(self._h))

@@ -93,8 +93,8 @@ SYMBOLS = {
     "tbvh_measure_link_bandwidth": (_i, [_vp, _u64, _u32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "tbvh_scene_get_schedule_hint": (_i, [_vp, _vp]),
     "tbvh_scene_set_schedule_hint": (_i, [_vp, _vp]),
-    "tbvh_pin_host": (_i, [_vp, _vp, _u64]),
-    "tbvh_unpin_host": (_i, [_vp, _vp]),
+    "tbvh_pinned_malloc": (_i, [_vp, _u64, _pp]),
+    "tbvh_pinned_free": (_i, [_vp, _vp]),
     "tbvh_set_variant": (_i, [_vp, _i]),
     "tbvh_debug_stats": (_i, [_vp, _vp, _i]),
     "tbvh_debug_last_probe": (_i, [_vp, _vp]),

@@ -112,7 +112,7 @@ void tbvh_shutdown(tbvh_context* c) {
     if (c->spill) hipFree(c->spill);
     if (c->counter) hipFree(c->counter);
     if (c->pool) hipFree(c->pool);
-    for (const tbvh_context::PinnedRange& r : c->pinned) hipHostUnregister(r.host);   // (ranges the caller never unpinned: the registration must not outlive the context)
+    for (const tbvh_context::PinnedRange& r : c->pinned) hipHostFree(r.host);   // (memory of tbvh_pinned_malloc the caller never gave back goes with the context)
     c->pinned.clear();
     if (c->stageRays) hipFree(c->stageRays);
     if (c->stageOcc) hipFree(c->stageOcc);

@@ -88,8 +88,8 @@ struct tbvh_context {
     // hipMemcpy2D moves ~9 GB/s because one CPU thread does the staging copy), and the 20 result bytes per ray come back
     // packed (k_pack_hits) and are scattered by the same workers
     struct HostPipe* pipe = nullptr;
-    // host ranges the caller pinned for this context (tbvh_pin_host): a packed (64-byte) ray array inside one goes up by DMA straight from the
-    // caller's memory, without the packing pass through the library's pinned ring (capi_query.hip: hostQuery)
+    // page-locked host memory handed out by tbvh_pinned_malloc: a packed (64-byte) ray array inside such a range goes up by DMA straight from there,
+    // without the packing pass through the library's pinned ring (capi_query.hip: hostQuery)
     struct PinnedRange { char* host; uint64_t bytes; };
     float hostQueryMs = -1.f;     // device time of the most recent host-array query (the sum over its groups' launches) ...
     uint64_t hostQuerySeq = ~0ull; // ... valid while no later operation was timed (evSeq still equals this)

@@ -70,8 +70,8 @@ static bool isPinned(tbvh_context* c, const void* p, uint64_t bytes) {
 // 48 GB/s each way at once against 57 one way, tools/ubench/link_rate.hip); the host scatters group g - 1's results into the caller's records.
 // What was measured and NOT taken (profiles/r05_link_rate.txt): hipMemcpy2D for the strided side (19 GB/s up, 3-4 GB/s down), and the device
 // reading / writing the caller's pinned array itself (a 128-byte record costs a 128-byte read for its 64 useful bytes: 27 GB/s; 20-byte writes
-// cost a 64-byte line each: 20 GB/s of results).  A packed (64-byte) array the caller pinned (tbvh_pin_host) needs no packing: it goes up by DMA
-// straight from the caller's memory.
+// cost a 64-byte line each: 20 GB/s of results).  A packed (64-byte) array in page-locked memory of the library's (tbvh_pinned_malloc) needs no packing: it goes up
+// by DMA straight from there.
 constexpr uint64_t kGroupRays = 4ull << 20;
 
 int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint32_t stride, uint8_t* occ) {
@@ -382,30 +382,33 @@ int tbvh_occluded(tbvh_scene* s, const void* rays, uint64_t n, uint32_t stride, 
     return hostQuery(s, (const char*)rays, nullptr, n, stride, occ);
 }
 
-// ---- host arrays the caller pins: the tinyocl::Buffer( bytes, hostPtr ) of this boundary (tiny_ocl.h; tiny_bvh_speedtest.cpp:1101-1108 wraps its
-// ---- Ray array in one before every GPU block) ------------------------------------------------------------------------------------------------
-int tbvh_pin_host(tbvh_context* c, void* ptr, uint64_t bytes) {
-    if (!c || !ptr || !bytes) return fail(TBVH_E_INVALID, "tbvh_pin_host: null/empty argument");
+// ---- page-locked host memory FROM the library: the tinyocl::Buffer( bytes ) of this boundary (tiny_ocl.h: a Buffer made without a host pointer owns
+// ---- its host side; tiny_bvh_speedtest.cpp:1101-1108 wraps its ray array in one before every GPU block) -----------------------------------------
+// Round 5 first page-locked the CALLER's memory (hipHostRegister): with that in the process, later plain hipMemcpy calls from pageable memory that
+// had been registered, unregistered, freed and handed out again by the allocator faulted the GPU ("Memory access fault ... Reason: Unknown", 3 runs of the
+// GPU suite in 9; 0 in 6 without the registering tests).  The library therefore never registers foreign memory: it hands out memory of its own.
+int tbvh_pinned_malloc(tbvh_context* c, uint64_t bytes, void** out) {
+    if (!c || !out || !bytes) return fail(TBVH_E_INVALID, "tbvh_pinned_malloc: null/empty argument");
     TBVH_ENTER(c);
-    for (const tbvh_context::PinnedRange& r : c->pinned)
-        if ((char*)ptr < r.host + r.bytes && r.host < (char*)ptr + bytes) return fail(TBVH_E_INVALID, "tbvh_pin_host: the range overlaps one that is pinned already");
-    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
-    try { c->pinned.push_back(tbvh_context::PinnedRange{(char*)ptr, bytes}); }
-    catch (const std::bad_alloc&) { hipHostUnregister(ptr); return fail(TBVH_E_NOMEM, "out of host memory"); }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess || !p) { (void)hipGetLastError(); return fail(TBVH_E_NOMEM, "tbvh_pinned_malloc: cannot page-lock %llu bytes", (unsigned long long)bytes); }
+    try { c->pinned.push_back(tbvh_context::PinnedRange{(char*)p, bytes}); }
+    catch (const std::bad_alloc&) { hipHostFree(p); return fail(TBVH_E_NOMEM, "out of host memory"); }
+    *out = p;
     return 0;
 }
 
-int tbvh_unpin_host(tbvh_context* c, void* ptr) {
-    if (!c || !ptr) return fail(TBVH_E_INVALID, "tbvh_unpin_host: null argument");
+int tbvh_pinned_free(tbvh_context* c, void* ptr) {
+    if (!c || !ptr) return fail(TBVH_E_INVALID, "tbvh_pinned_free: null argument");
     TBVH_ENTER(c);
     for (size_t i = 0; i < c->pinned.size(); i++)
         if (c->pinned[i].host == (char*)ptr) {
             HIP_TRY(hipStreamSynchronize(c->stream));   // nothing of this context may still be reading the range
             c->pinned.erase(c->pinned.begin() + i);
-            HIP_TRY(hipHostUnregister(ptr));
+            HIP_TRY(hipHostFree(ptr));
             return 0;
         }
-    return fail(TBVH_E_INVALID, "tbvh_unpin_host: %p was not pinned through this context", ptr);
+    return fail(TBVH_E_INVALID, "tbvh_pinned_free: %p did not come from tbvh_pinned_malloc of this context", ptr);
 }
 
 // ---- one ray array over several devices -----------------------------------------------------------

@@ -106,7 +106,7 @@ int main(int argc, char** argv) {
         t = timeit(s, 3, [&] { hipLaunchKernelGGL(scatter32, dim3((uint32_t)((n * 2 + 255) / 256)), dim3(256), 0, s, d, dst, stride, n); });  printf("kernel scatter 32 B/ray, stride %3u       %7.2f ms  %6.1f GB/s (of 20 B/ray)\n", stride, t, down / t);
         t = timeit(s, 3, [&] { hipLaunchKernelGGL(scatter64, dim3((uint32_t)((n * 4 + 255) / 256)), dim3(256), 0, s, d, dst, stride, n); });  printf("kernel scatter 64 B/ray, stride %3u       %7.2f ms  %6.1f GB/s (of 20 B/ray)\n", stride, t, down / t);
     }
-    // registered (not hipHostMalloc'ed) memory: what tbvh_pin_host gives the kernels
+    // registered (not hipHostMalloc'ed) memory: what page-locking CALLER memory would give (not done: DESIGN.md par. 0)
     {
         char* p = (char*)aligned_alloc(4096, n * 64); memset(p, 1, n * 64);
         const auto t0 = std::chrono::steady_clock::now();
