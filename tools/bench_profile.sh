@@ -7,7 +7,7 @@ TAG=$1
 OUT=$PWD/gpurun_out/bench_prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CMD="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-strong"
+CMD="python $PWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pmc --no-strong --no-rotated --no-other-layouts --no-host-rays --no-hbm-regime --no-configs"
 [ -x tools/ubench/gather_rate ] || make -C tools/ubench gather_rate > /dev/null
 cd /tmp
 timeout 400 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/kt -o kt -- $CMD > $OUT/kt.log 2>&1
