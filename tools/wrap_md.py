@@ -14,7 +14,7 @@ def split_cells(line):
 def wrap(text, first, rest):
     return textwrap.fill(text, width=W, initial_indent=first, subsequent_indent=rest, break_long_words=False, break_on_hyphens=False)
 src=open(sys.argv[1]).read().split('\n')
-out=[]; i=0
+out=[]; i=0; fence=False
 while i<len(src):
     l=src[i]
     if l.startswith('|'):
@@ -35,13 +35,12 @@ while i<len(src):
         else:
             out.extend(tbl)
         i=j; continue
-    if len(l)>W and not l.startswith('```') and not l.startswith('    '):
+    if l.lstrip().startswith('```'):
+        fence = not fence
+    if len(l)>W and not fence and not l.lstrip().startswith('```'):
+        lead=' '*(len(l)-len(l.lstrip()))
         m=re.match(r'^(\s*(?:[*-]|\d+\.)\s+)',l)
-        if m:
-            ind=' '*len(m.group(1)); out.append(wrap(l.strip(), ' '*(len(l)-len(l.lstrip())), ' '*(len(l)-len(l.lstrip()))+ind[len(l)-len(l.lstrip()):] if False else ' '*len(m.group(1))))
-        else:
-            lead=' '*(len(l)-len(l.lstrip()))
-            out.append(wrap(l.strip(), lead, lead))
+        out.append(wrap(l.strip(), lead, ' '*len(m.group(1)) if m else lead))
     else:
         out.append(l)
     i+=1
