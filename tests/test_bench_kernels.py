@@ -287,3 +287,37 @@ def test_schedule_hint_pins_reads_back_and_survives_timing_off(oracle):
         c.free(d_a); sc.free()
     finally:
         c.close()
+
+
+def test_parallel_rays_from_scattered_origins_are_all_traced(ctx, oracle):
+    """The coherence probe of a closest-hit launch that is NOT `fresh` reads the rays' own hit.x as their reach while earlier waves of the launch write hit
+    distances there: parallel rays with tmax = 1e30 and origins all over the scene (an orthographic camera, sun shadow rays traced with Intersect) count as
+    coherent by direction at first and fail the origin test once one of a pair has been hit — waves may vote differently (round-4 advisor).  Which rays get
+    traced must not depend on that: every ray of the batch is traced exactly once, whatever each wave voted."""
+    verts, _ = scenes.get("bistro")
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    side = 2048
+    n = side * side
+    lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+    gx, gz = np.meshgrid(np.linspace(lo[0], hi[0], side, dtype=np.float32), np.linspace(lo[2], hi[2], side, dtype=np.float32), indexing="ij")
+    O = np.stack([gx.ravel(), np.full(n, hi[1] + 5.0, np.float32), gz.ravel()], 1)
+    d = np.array([0.13, -0.97, 0.21], np.float32); d /= np.linalg.norm(d)
+    rays = tb.make_rays(O, np.tile(d, (n, 1)))                      # an orthographic "sun" view: one direction, origins 160 m x 60 m apart
+    d_r = ctx.malloc(n * 64)
+    h = sc.host
+    idx = np.arange(0, n, n // 65536)[:65536]
+    want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays[idx])
+    assert (want["t"] < 1e30).sum() > 30000
+    for rep in range(3):                                            # (the vote depends on timing: a few launches)
+        ctx.to_device(d_r, rays)
+        sc.intersect_device(d_r, n)                                 # NOT fresh: the probe reads the records the launch is writing
+        got = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(got, d_r)
+        c = compare_hits(got[idx], want)
+        assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["tie"] == 0, (rep, c)
+        assert c["bit_identical"] == c["same_prim"], (rep, c)
+    # and the same batch through the fresh entry point gives the same bytes
+    sc.intersect_device_fresh(d_r, n, 1e30)
+    fresh = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(fresh, d_r)
+    hit = got["t"] < 1e30
+    assert np.array_equal(fresh[hit].view(np.uint8), got[hit].view(np.uint8)) and int((fresh["t"] < 1e30).sum()) == int(hit.sum())
+    ctx.free(d_r); sc.free()
