@@ -323,12 +323,12 @@ def main():
         if i % 2:
             sync_all_local()                # (finished launches are what the coherent-schedule tuner learns from; a renderer's frames end likewise)
     if a.layout == tb.LAYOUT_CWBVH:
-        for _ in range(6):                  # untimed: make sure the tuner has decided before the timed region, whatever --warmup was
+        for _ in range(12):                 # untimed: make sure the tuner has decided before the timed region, whatever --warmup was
             if sc.coherent_schedule(False)[0]:
                 break
             sc.intersect_device_fresh(d_prim, n, 1e30); ctx.synchronize()
         for c_, r_, dp_, dd_ in others:
-            for _ in range(6):
+            for _ in range(12):
                 if r_.coherent_schedule(False)[0]:
                     break
                 r_.intersect_device_fresh(dp_, n, 1e30); c_.synchronize()
@@ -557,7 +557,7 @@ def main():
         # round-3 driver run had 0.42 ms here, from a synchronisation after every launch and a three-launch probed query
         detail["dispatch_gap_ms"] = ms_per_step - (mean["primary"] + mean["diffuse"])
         if a.layout == tb.LAYOUT_CWBVH:
-            names = {0: "still measuring", 1: "deferred triangles + gated triangle phase on 32 waves per CU", 2: "strict"}
+            names = {0: "still measuring", 1: "deferred triangles + gated triangle phase on 32 waves per CU", 2: "strict", 3: "one traversal per wave of 64 consecutive rays (kernels_cwbvh_packet.hip)"}
             detail["coherent_schedule"] = {kind: {"decision": names[t_[0]], "samples": [t_[1], t_[2]], "strict_over_deferred_time_per_ray": t_[3] / 1000.0}
                                            for kind, t_ in (("closest_hit", sc.coherent_schedule(False)), ("any_hit", sc.coherent_schedule(True)))}
             detail["coherent_schedule"]["how"] = "measured per scene by the library during the first launches (CohTuner, tinybvh_amd/csrc/capi_internal.h); TBVH_COHERENT_TUNER pins it"
@@ -685,7 +685,7 @@ def main():
             except Exception as e:
                 log(f"[bench] ceiling measurement failed: {e!r}")
             # (the children run the schedule this process's tuner settled on for coherent batches, pinned: a child is too short to decide for itself)
-            a.coh_pin = {1: "0", 2: "2"}.get(sc.coherent_schedule(False)[0] if a.layout == tb.LAYOUT_CWBVH else 0)
+            a.coh_pin = {1: "0", 2: "2", 3: "3"}.get(sc.coherent_schedule(False)[0] if a.layout == tb.LAYOUT_CWBVH else 0)
             pm = live_counters(a, log) if (world == 1 and not a.no_pmc) else None
             traffic_src = pm.get("source") if pm else None
             lines = {}

@@ -81,7 +81,7 @@ int tbvh_init(int device, tbvh_context** out) {
     if (const char* e = getenv("TBVH_INCOHERENT_COPIES")) { if (atoi(e) == 0) c->incoherentCopies = false; }
     if (const char* e = getenv("TBVH_EMBED_TRIS")) { if (atoi(e) == 0) c->embedTris = false; }
     if (const char* e = getenv("TBVH_DEBUG_FLAGS")) c->expFlags = (uint32_t)strtoul(e, nullptr, 0);   // tbvh_debug_set_flags from the environment (counter runs of tools/)
-    if (const char* e = getenv("TBVH_COHERENT_TUNER")) { const int v = atoi(e); c->cohTunerMode = v == 0 ? 1 : (v == 2 ? 2 : 0); }   // 0: off (always deferred + gated), 2: always strict
+    if (const char* e = getenv("TBVH_COHERENT_TUNER")) { const int v = atoi(e); c->cohTunerMode = v == 0 ? 1 : (v == 2 ? 2 : (v == 3 ? 3 : 0)); }   // 0: off (always deferred + gated), 2: always strict, 3: always one traversal per wave
     if (const char* e = getenv("TBVH_POOL_PARTS")) {  // experiment knob
         const int b = atoi(e);
         if (b >= 0 && (1 << b) <= kPoolParts) c->poolParts = (uint32_t)b;   // log2 of the partition count

@@ -57,7 +57,7 @@ struct tbvh_context {
     static constexpr uint32_t kTimeRing = 256;
     hipEvent_t evRing[kTimeRing][2] = {};
     bool evDone[kTimeRing] = {};
-    int cohTunerMode = 0;         // TBVH_COHERENT_TUNER: 0 = measure per scene (default), 1 = always the deferred + gated schedule, 2 = always the strict one
+    int cohTunerMode = 0;         // TBVH_COHERENT_TUNER: 0 = measure per scene (default), 1 = always the deferred + gated schedule, 2 = always the strict one, 3 = always one traversal per wave
     uint64_t evSeq = 0;           // timed operations begun on this context
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
@@ -105,12 +105,13 @@ struct tbvh_context {
 // profiles/r04_sensitivity.txt).  No static property of a blob told the two apart, so the library measures: while undecided the launches alternate
 // between the two, an event between the two kernels times the first one, and after two coherent samples of each the faster (by 3 %) stays.
 struct CohTuner {
-    int decided = 0;                    // 0 measuring, 1 deferred + gated, 2 strict
+    int decided = 0;                    // 0 measuring, 1 deferred + gated, 2 strict, 3 one traversal per wave (kernels_cwbvh_packet.hip)
     bool pinned = false;                // `decided` came from the caller (tbvh_scene_set_schedule_hint): not measured, not reset by a topology change
     uint32_t launches = 0;
     uint64_t refRays = 0;               // size of the first coherent batch sampled: only batches within 3/4 ... 4/3 of it are compared
-    uint32_t n[2] = {0, 0};             // coherent-verdict samples per schedule
-    float best[2] = {1e30f, 1e30f};     // ns per ray of the first kernel: best sample per schedule (other work on the GPU only ever ADDS time: the minimum is the robust statistic)
+    static constexpr int kModes = 3;
+    uint32_t n[kModes] = {0, 0, 0};             // coherent-verdict samples per schedule
+    float best[kModes] = {1e30f, 1e30f, 1e30f};     // ns per ray of the first kernel: best sample per schedule (other work on the GPU only ever ADDS time: the minimum is the robust statistic)
     // a launch being measured: the tuner's OWN event pair around the first kernel (so it measures with tbvh_set_timing(0) as well)
     struct Pending { hipEvent_t e0, e1; int mode; uint64_t rays; };
     std::vector<Pending> pending;

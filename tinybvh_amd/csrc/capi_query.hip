@@ -283,12 +283,15 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                         hipEventDestroy(pe.e0); hipEventDestroy(pe.e1);
                         tu.pending.erase(tu.pending.begin() + k);
                     }
-                    if (tu.n[0] >= CohTuner::kSamples && tu.n[1] >= CohTuner::kSamples) { tu.decided = tu.best[1] < 0.97f * tu.best[0] ? 2 : 1; tu.drop_pending(); }
-                    else if (tu.launches >= 64) { tu.decided = 1; tu.drop_pending(); }   // batches too varied to compare: the schedule that wins on most scenes
+                    if (tu.n[0] >= CohTuner::kSamples && tu.n[1] >= CohTuner::kSamples && tu.n[2] >= CohTuner::kSamples) {
+                        int win = 0;   // the deferred + gated schedule unless another one beats it by 3 %
+                        for (int m = 1; m < CohTuner::kModes; m++) if (tu.best[m] < 0.97f * tu.best[0] && tu.best[m] < tu.best[win]) win = m;
+                        tu.decided = win + 1; tu.drop_pending();
+                    } else if (tu.launches >= 96) { tu.decided = 1; tu.drop_pending(); }   // batches too varied to compare: the schedule that wins on most scenes
                 }
                 // a batch whose size only the device knows (the wavefront stages) cannot be priced per ray: the default schedule, no sample
                 const bool measure = !tu.decided && !c->cohTunerMode && !nDev && tu.pending.size() < 16;
-                const int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : (nDev ? 1 : 1 + (int)(tu.launches & 1u));
+                const int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : (nDev ? 1 : 1 + (int)(tu.launches % (uint32_t)CohTuner::kModes));
                 if (!nDev) tu.launches++;
                 if (mode == 2) qa.flags |= 32u;
                 CohTuner::Pending pe{nullptr, nullptr, mode, n};
@@ -296,7 +299,8 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                     if (hipEventCreate(&pe.e0) != hipSuccess || hipEventCreate(&pe.e1) != hipSuccess) { if (pe.e0) hipEventDestroy(pe.e0); pe.e0 = pe.e1 = nullptr; (void)hipGetLastError(); }
                     else HIP_TRY(hipEventRecord(pe.e0, c->stream));
                 }
-                launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, mode == 2 ? blocksBase : blocks, c->stream, 5, small, blocks7);
+                if (mode == 3) launch_cwbvh_packet(any, s->nodes, s->tris, qa, c->status, blocks, c->stream);   // one traversal per wave of 64 consecutive rays
+                else launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, mode == 2 ? blocksBase : blocks, c->stream, 5, small, blocks7);
                 HIP_TRY(hipGetLastError());
                 if (pe.e0) {
                     HIP_TRY(hipEventRecord(pe.e1, c->stream));

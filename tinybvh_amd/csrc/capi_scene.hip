@@ -730,7 +730,7 @@ int tbvh_scene_get_schedule_hint(tbvh_scene* s, tbvh_schedule_hint* out) {
 
 int tbvh_scene_set_schedule_hint(tbvh_scene* s, const tbvh_schedule_hint* hint) {
     if (!s || !hint) return fail(TBVH_E_INVALID, "tbvh_scene_set_schedule_hint: null argument");
-    for (int k = 0; k < 3; k++) if (hint->closest_hit[k] > 2 || hint->any_hit[k] > 2) return fail(TBVH_E_INVALID, "tbvh_scene_set_schedule_hint: entries are 0 (measure), 1 (deferred + gated) or 2 (strict)");
+    for (int k = 0; k < 3; k++) if (hint->closest_hit[k] > 3 || hint->any_hit[k] > 3) return fail(TBVH_E_INVALID, "tbvh_scene_set_schedule_hint: entries are 0 (measure), 1 (deferred + gated), 2 (strict) or 3 (one traversal per wave)");
     TBVH_LOCK(s->ctx);
     for (int a = 0; a < 2; a++) for (int k = 0; k < 3; k++) {
         const uint8_t v = a ? hint->any_hit[k] : hint->closest_hit[k];

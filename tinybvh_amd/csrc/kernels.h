@@ -13,6 +13,8 @@ void launch_bvh2(bool anyhit, int variant, const float4* nodes, const float4* tr
 void launch_bvh4(bool anyhit, int variant, const float4* data, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
 // nodeStride: 5 = `nodes` is the packed array; 8 = the copy with one node per 128-byte line (scenes whose nodes outgrow the Infinity
 // Cache); 13 (cwbvh_node.h: kNodeHybrid) = the priority-ordered copy whose first q.hybridK nodes are packed and the others one per line
+// the coherent flavor of a probed launch as ONE traversal per wave of 64 consecutive rays (kernels_cwbvh_packet.hip)
+void launch_cwbvh_packet(bool anyhit, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status, uint32_t blocks, hipStream_t s);
 void launch_cwbvh(bool anyhit, int variant, const float4* nodes, const float4* tris, const QueryArgs& q, uint32_t* status,
                   uint32_t blocks, hipStream_t s, int nodeStride = 5, bool shallow = false, uint32_t blocks7 = 0xFFFFFFFFu);   // blocks7: grid of the kernels built for 7 waves per SIMD
 void launch_cwbvh_derive_hybrid(const float4* src, const uint32_t* perm, float4* dst, uint32_t nNodes, uint32_t hybridK, const float4* tris, hipStream_t s);   // tris: the packed 48-byte records (one per node is embedded in its line), or nullptr
