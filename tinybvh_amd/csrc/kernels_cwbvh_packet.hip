@@ -31,6 +31,41 @@ constexpr int kPkLds = 24;   // stack entries in LDS; deeper entries live in the
 
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
+// The children of the wave's current node against THIS lane's ray; the planes come from LDS (decoded once for the wave, near / far in the order of the
+// wave's octant).  Returns the WAVE's ordered hit mask (a child counts when any lane's ray enters its box).  Empty slots (meta byte 0: half the slots of
+// the library's trees, whose nodes hold 1 interior child and 3 leaves on average) cost no vector instruction — a wave-uniform branch —, and the planes of
+// slot c + 1 are read from LDS while slot c is tested.  MIXED: some lane's octant differs from the wave's — near and far are sorted per lane through min / max.
+template <bool MIXED>
+__device__ __forceinline__ uint32_t pk_test_children(const float (*planes)[8], float ax, float ay, float az, float ox, float oy, float oz, float tcull, bool lives,
+                                                     uint32_t m0, uint32_t m1, uint32_t oct0) {
+    uint32_t hitmask = 0;
+    float4 pa = *(const float4*)&planes[0][0];
+    float2 pb = *(const float2*)&planes[0][4];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const uint32_t meta = ((c < 4 ? m0 : m1) >> (8 * (c & 3))) & 255u;
+        const float4 qa = pa; const float2 qb = pb;
+        if (c < 7) { pa = *(const float4*)&planes[c + 1][0]; pb = *(const float2*)&planes[c + 1][4]; }
+        if (meta == 0u) continue;
+        float tnx = __builtin_fmaf(qa.x, ax, ox), tny = __builtin_fmaf(qa.y, ay, oy), tnz = __builtin_fmaf(qa.z, az, oz);
+        float tfx = __builtin_fmaf(qa.w, ax, ox), tfy = __builtin_fmaf(qb.x, ay, oy), tfz = __builtin_fmaf(qb.y, az, oz);
+        if (MIXED) {
+            const float a0 = __builtin_fminf(tnx, tfx), a1 = __builtin_fmaxf(tnx, tfx), b0 = __builtin_fminf(tny, tfy), b1 = __builtin_fmaxf(tny, tfy);
+            const float c0 = __builtin_fminf(tnz, tfz), c1 = __builtin_fmaxf(tnz, tfz);
+            tnx = a0; tfx = a1; tny = b0; tfy = b1; tnz = c0; tfz = c1;
+        }
+        const float cmin = __builtin_fmaxf(cw_fmax3(tnx, tny, tnz), 0.0f);
+        const float cmax = __builtin_fminf(cw_fmin3(tfx, tfy, tfz), tcull);
+        if (wave_ballot(lives && cmin <= cmax) != 0ull) {
+            // interior child (meta = 0b001sssss, sssss = 24 + slot): bit 24 + (slot ^ octinv); leaf: its unary triangle bits at its offset
+            const bool inner = (meta & 0x18u) == 0x18u;
+            const uint32_t bitidx = (inner ? (meta ^ oct0) : meta) & 31u;
+            hitmask |= (meta >> 5) << bitidx;
+        }
+    }
+    return hitmask;
+}
+
 template <bool ANYHIT, bool HAS_OMM>
 __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict__ nodes, const float4* __restrict__ tris, QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ float planes[8][8];      // the current node's child boxes as floats: [child][near x, near y, near z, far x, far y, far z, -, -] in units of 2^e from the node's origin
@@ -71,7 +106,6 @@ __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict
         const uint32_t first = (uint32_t)__builtin_ctzll(haveMask);
         const uint32_t oct0 = (uint32_t)__builtin_amdgcn_readlane((int)oct, (int)first);
         const bool mixed = wave_ballot(have && oct != oct0) != 0;
-        const uint32_t octinv4 = oct0 * 0x01010101u;
         const bool negX0 = ((7u - oct0) & 4u) != 0, negY0 = ((7u - oct0) & 2u) != 0, negZ0 = ((7u - oct0) & 1u) != 0;
         // where lane L's plane goes in planes[child][.]: byte L of the node's 48 is plane p = L >> 3 (qlo_x, qlo_y, qlo_z, qhi_x, qhi_y, qhi_z) of child L & 7;
         // near = lo unless the wave's rays travel in -axis
@@ -82,14 +116,15 @@ __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict
 
         uint32_t sp = 0;
         uint32_t ngx = 0, ngy = 0x80000000u;
-        for (;;) {
-            // ---- next node of the wave ------------------------------------------------------------------------------------
+        // the wave's next node: taken off the current node group, or off the stack; false when the traversal is over.  Only the wave-uniform state decides
+        // (never a ray's hit distance), so the NEXT node can be picked — and its loads issued — before the current node's triangles are tested.
+        auto pick = [&](uint32_t& ci) -> bool {
             if (!(ngy > 0x00FFFFFFu)) {
-                if (sp == 0) break;
+                if (sp == 0) return false;
                 sp--;
                 uint2 e;
                 if (sp < (uint32_t)kPkLds) e = stk[sp];
-                else { const uint32_t j = sp - kPkLds; e = spill[(j & 63u) + (size_t)(j >> 6) * spillRow]; }
+                else { const uint32_t j_ = sp - kPkLds; e = spill[(j_ & 63u) + (size_t)(j_ >> 6) * spillRow]; }
                 ngx = sgpr(e.x); ngy = sgpr(e.y);
             }
             const uint32_t imaskWord = ngy;
@@ -98,19 +133,29 @@ __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict
             if (ngy > 0x00FFFFFFu) {   // children of this group still pending: keep it
                 if (sp < (uint32_t)kPkLds) { if (lane == 0) stk[sp] = make_uint2(ngx, ngy); }
                 else {
-                    const uint32_t j = sp - kPkLds;
-                    if (j < spillCap) { if (lane == 0) spill[(j & 63u) + (size_t)(j >> 6) * spillRow] = make_uint2(ngx, ngy); }
+                    const uint32_t j_ = sp - kPkLds;
+                    if (j_ < spillCap) { if (lane == 0) spill[(j_ & 63u) + (size_t)(j_ >> 6) * spillRow] = make_uint2(ngx, ngy); }
                     else overflow = true;
                 }
                 sp++;
             }
             const uint32_t slot = (bit - 24u) ^ oct0;
-            const uint32_t ci = sgpr(ngx + (uint32_t)__popc(imaskWord & ~(0xFFFFFFFFu << slot)));
-            // ---- the node: fetched and decoded once for the wave ----------------------------------------------------------
-            const float4* np = nodes + (size_t)ci * 5u;
-            const float4 n0 = np[0], n1 = np[1];
-            uint32_t qb = 0;
+            ci = sgpr(ngx + (uint32_t)__popc(imaskWord & ~(0xFFFFFFFFu << slot)));
+            return true;
+        };
+        uint32_t ci = 0;
+        bool more = pick(ci);
+        // a node in flight: n0, n1 (one request for the wave: every lane asks for the same 32 bytes) and lane L's plane byte
+        float4 n0 = make_float4(0, 0, 0, 0), n1 = n0;
+        uint32_t qb = 0;
+        auto fetch = [&](uint32_t c_) {
+            const float4* np = nodes + (size_t)c_ * 5u;
+            n0 = np[0]; n1 = np[1];
             if (lane < 48u) qb = ((const uint8_t*)(np + 2))[lane];
+        };
+        if (more) fetch(ci);
+        while (more) {
+            // ---- the node: decoded once for the wave ---------------------------------------------------------------------
             __builtin_amdgcn_wave_barrier();               // (every lane has read the previous node's planes before they are overwritten)
             if (lane < 48u) *myPlane = (float)qb;
             __builtin_amdgcn_wave_barrier();
@@ -119,35 +164,18 @@ __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict
             const float ox = (n0.x - O.x) * rD.x, oy = (n0.y - O.y) * rD.y, oz = (n0.z - O.z) * rD.z;
             const float tcull = cull_bound(hit.x);
             const bool lives = ANYHIT ? (on && !found) : on;
-            uint32_t hitmask = 0;
             const uint32_t m0 = sgpr(as_u32(n1.z)), m1 = sgpr(as_u32(n1.w));
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const uint32_t meta = ((c < 4 ? m0 : m1) >> (8 * (c & 3))) & 255u;
-                if (meta == 0u) continue;                  // (wave-uniform: an empty slot costs no vector instruction)
-                const float4 pa = *(const float4*)&planes[c][0];
-                const float2 pb = *(const float2*)&planes[c][4];
-                float tnx = __builtin_fmaf(pa.x, ax, ox), tny = __builtin_fmaf(pa.y, ay, oy), tnz = __builtin_fmaf(pa.z, az, oz);
-                float tfx = __builtin_fmaf(pa.w, ax, ox), tfy = __builtin_fmaf(pb.x, ay, oy), tfz = __builtin_fmaf(pb.y, az, oz);
-                if (mixed) {   // a lane of another octant has near and far the other way round on some axis
-                    const float a0 = __builtin_fminf(tnx, tfx), a1 = __builtin_fmaxf(tnx, tfx), b0 = __builtin_fminf(tny, tfy), b1 = __builtin_fmaxf(tny, tfy);
-                    const float c0 = __builtin_fminf(tnz, tfz), c1 = __builtin_fmaxf(tnz, tfz);
-                    tnx = a0; tfx = a1; tny = b0; tfy = b1; tnz = c0; tfz = c1;
-                }
-                const float cmin = __builtin_fmaxf(cw_fmax3(tnx, tny, tnz), 0.0f);
-                const float cmax = __builtin_fminf(cw_fmin3(tfx, tfy, tfz), tcull);
-                if (wave_ballot(lives && cmin <= cmax) != 0ull) {
-                    // interior child (meta = 0b001sssss, sssss = 24 + slot): bit 24 + (slot ^ octinv); leaf: its unary triangle bits at its offset
-                    const bool inner = (meta & 0x18u) == 0x18u;
-                    const uint32_t bitidx = (inner ? (meta ^ (octinv4 & 7u)) : meta) & 31u;
-                    hitmask |= (meta >> 5) << bitidx;
-                }
-            }
+            const uint32_t hitmask = mixed ? pk_test_children<true>(planes, ax, ay, az, ox, oy, oz, tcull, lives, m0, m1, oct0)
+                                           : pk_test_children<false>(planes, ax, ay, az, ox, oy, oz, tcull, lives, m0, m1, oct0);
             ngx = sgpr(as_u32(n1.x));
             ngy = (hitmask & 0xFF000000u) | (ew >> 24);
-            // ---- the triangles of the leaves any ray entered: every lane tests them -----------------------------------------
             uint32_t tgy = hitmask & 0x00FFFFFFu;
             const uint32_t tgx = sgpr(as_u32(n1.y));
+            // ---- the next node's loads go out now: they fly while this node's triangles are tested ------------------------------
+            // (issuing the first triangle's loads ahead of them as well measured 5-9 % slower)
+            more = pick(ci);
+            if (more) fetch(ci);
+            // ---- the triangles of the leaves any ray entered: every lane tests them -----------------------------------------
             while (tgy != 0u) {
                 const uint32_t ti = 31u - (uint32_t)__builtin_clz(tgy);
                 tgy &= ~(1u << ti);
