@@ -333,17 +333,18 @@ int tbvh_measure_link_bandwidth(tbvh_context* ctx, uint64_t bytes, uint32_t reps
  * current by tbvh_refit. */
 int tbvh_cwbvh_set_hybrid(tbvh_scene* scene, int64_t packed_nodes);
 
-/* Which schedule serves COHERENT batches of 2 M rays and more on a BVH8_CWBVH scene — deferred triangles + a gated triangle phase on a third more
- * waves, or the strict one — is measured by the library during the scene's first such launches (no static property of a blob tells which is faster:
- * +1 ... +8 % for the first on most scenes, +10 % for the second on large-occluder scenes, profiles/r04_sensitivity.txt).  The decision as something
- * a caller can READ, KEEP and GIVE BACK (a renderer that wants its first frame at full speed and the same
- * schedule from run to run): one entry per batch-size class (fewer than 6 M rays, fewer than 12 M, more) and query kind; 0 = not decided yet
- * (the library is still alternating and timing — with its own events, so tbvh_set_timing(0) does not stop it; batches whose size only the
- * device knows are never sampled and run the deferred schedule), 1 = deferred + gated, 2 = strict.  tbvh_scene_set_schedule_hint pins the
- * non-zero entries (no measuring launches at all for those classes; kept across tbvh_update_cwbvh) and sends the zero ones back to
- * measuring.  The struct is 8 plain bytes: store it next to the scene's blob cache (tbvh_cwbvh_file_write) if it should outlive the process.
- * Measured decisions are taken from the best of 3 device-timed launches per schedule, 3 % apart at least; other work on the GPU during those
- * launches can tip a close call, which is what pinning is for. */
+/* Which schedule serves COHERENT batches of 2 M rays and more on a BVH8_CWBVH scene — (1) deferred triangles + a gated triangle phase on a third more
+ * waves, (2) the strict per-lane schedule, or (3) ONE traversal per wave of 64 consecutive rays (kernels_cwbvh_packet.hip: +24 % on camera rays of the 2.83 M-
+ * triangle street at 16.7 M rays, +46 % on the same street off the axes, slower on shadow rays and on batches of a few M rays) — is measured by the library
+ * during the scene's first such launches: no static property of a blob tells which is faster (profiles/r04_sensitivity.txt, profiles/r05_packet.txt).
+ * The decision as something a caller can READ, KEEP and GIVE BACK (a renderer that wants its first frame at full speed and the same schedule from run to
+ * run): one entry per batch-size class (fewer than 6 M rays, fewer than 12 M, more) and query kind; 0 = not decided yet (the library is still alternating
+ * and timing — with its own events, so tbvh_set_timing(0) does not stop it; batches whose size only the device knows are never sampled and run schedule 1),
+ * 1, 2, 3 as above.  tbvh_scene_set_schedule_hint pins the non-zero entries (no measuring launches at all for those classes; kept across
+ * tbvh_update_cwbvh) and sends the zero ones back to measuring.  The struct is 8 plain bytes: store it next to the scene's blob cache
+ * (tbvh_cwbvh_file_write) if it should outlive the process.  Measured decisions are taken from the best of 3 device-timed launches per schedule, 3 %
+ * apart at least; other work on the GPU during those launches can tip a close call, which is what pinning is for.  Hit records do not depend on the
+ * schedule: the same bytes. */
 typedef struct tbvh_schedule_hint { uint8_t closest_hit[3]; uint8_t any_hit[3]; uint8_t reserved[2]; } tbvh_schedule_hint;
 int tbvh_scene_get_schedule_hint(tbvh_scene* scene, tbvh_schedule_hint* out);
 int tbvh_scene_set_schedule_hint(tbvh_scene* scene, const tbvh_schedule_hint* hint);

@@ -25,7 +25,7 @@ int tbvh_debug_set_flags(tbvh_context* ctx, uint32_t flags);
  * any-hit: 1) — the deferred-triangles + gated schedule on a third more waves, or the strict one.  No static property of a blob tells which
  * is faster (profiles/r04_sensitivity.txt: +1 ... +8 % for the first on most scenes, +10 % for the second on large-occluder scenes), so the
  * first few such launches alternate and are timed on the device (no synchronisation), then the faster stays (TBVH_COHERENT_TUNER=0 / 2 in
- * the environment pins the first / the second).  out[0] = 0 still measuring, 1 deferred + gated, 2 strict; out[1], out[2] = coherent samples
+ * the environment pins the first / the second, 3 one traversal per wave).  out[0] = 0 still measuring, 1 deferred + gated, 2 strict, 3 one traversal per wave (kernels_cwbvh_packet.hip); out[1], out[2] = coherent samples
  * taken of each; out[3] = 1000 x best time per ray of the strict schedule / of the deferred one (0 until both have samples).  The choice is kept
  * per batch-size class (below 6 M rays, below 12 M, more: the end of a launch weighs differently — the atrium generator's camera rays are 15 % faster
  * strict at 16.7 M rays and even at 4.2 M); the call reports the class of the most recent launch. */
