@@ -230,6 +230,12 @@ def main():
     if a.hbm_child:   # detail.hbm_regime: the timed kernels on a scene beyond the Infinity Cache; one JSON line, nothing else
         import ctypes as C
         out = {"scene": label, "triangles": n_tris, "bvh_mb": sc.device_bytes / 1e6, "rays_per_launch": n, "tree": "device LBVH" if a.device_build else "host SAH"}
+        if a.layout == 10 and not os.environ.get("TBVH_COHERENT_TUNER"):
+            for _ in range(14):                # let the scene's tuner try its three schedules for coherent batches and settle (untimed)
+                if sc.coherent_schedule(False)[0]:
+                    break
+                sc.intersect_device_fresh(d_prim, n, 1e30); ctx.synchronize()
+            out["coherent_schedule"] = int(sc.coherent_schedule(False)[0])
         for kind, d in (("primary", d_prim), ("diffuse", d_diff)):
             ms = []
             for p_ in range(4):
@@ -305,6 +311,11 @@ def main():
         sc.occluded_device(d_shad, n, d_occ)
         if i % 2:
             ctx.synchronize()
+    if a.layout == tb.LAYOUT_CWBVH:
+        for _ in range(12):                 # untimed: the tuner tries three schedules three times each before it decides
+            if sc.coherent_schedule(True)[0]:
+                break
+            sc.occluded_device(d_shad, n, d_occ); ctx.synchronize()
     for i in range(a.steps):
         sc.occluded_device(d_shad, n, d_occ)
     ctx.synchronize()
@@ -727,7 +738,7 @@ def main():
                         "measured_copy_gbps": copy_gbps, "measured_read_gbps": read_gbps, "measured_valu_ginstr_per_s": valu_ginstr,
                         "fabric": f_, "valu": d_["valu"], "l2_miss_latency": d_["l2_miss_latency"], "algorithmic_hbm": d_["algorithmic_hbm"],
                         "nodes_per_ray": d_["nodes_per_ray"], "tris_per_ray": d_["tris_per_ray"], "avg_launch_ms": d_["avg_launch_ms"],
-                        "limiter": "incoherent rays: no single wall - VALU issue (valu.issue_frac), the L1 lookup rate and the latency of ~9 L2 misses per ray sit within a quarter of each other; taking 10 % of the bytes, 7 % of the L1 lookups or 6 % of the instructions away moved the launch by < 1 % each, removing one DEPENDENT load (the triangle record's third, sunk behind a branch by the compiler) by 7 % (DESIGN.md par. 5 Round 4, par. 9); camera rays: VALU issue at 0.97 of its ceiling",
+                        "limiter": "incoherent rays: no single wall - VALU issue (valu.issue_frac), the L1 lookup rate and the latency of ~9 L2 misses per ray sit within a quarter of each other; taking 10 % of the bytes, 7 % of the L1 lookups or 6 % of the instructions away moved the launch by < 1 % each, removing one DEPENDENT load (the triangle record's third, sunk behind a branch by the compiler) by 7 % (DESIGN.md par. 5 Round 4, par. 9); camera rays: roofline.primary, on the schedule the scene's tuner settled on (detail.coherent_schedule)",
                         "primary": lines.get("primary")}
         except Exception as e:  # the checker is optional for the number itself
             log(f"[bench] roofline failed: {e!r}")
@@ -1005,8 +1016,8 @@ def hbm_regime(a, log):
             b = copy.copy(a)
             b.scene, b.side, b.device_build, b.layout, b.variant = scene, 2048, False, 10, 0
             b.blob_cache = os.path.join(tmpdir, scene + ".cwbvh")
-            b.coh_pin = "0"          # (timing child and counter children alike: the deferred + gated schedule for coherent batches, the street scenes' choice)
-            env["TBVH_COHERENT_TUNER"] = "0"
+            b.coh_pin = None         # (the timing child lets the scene's tuner settle; the counter children are pinned to what it chose)
+            env.pop("TBVH_COHERENT_TUNER", None)
             cmd = [sys.executable, os.path.abspath(__file__), "--hbm-child", "--scene", b.scene, "--side", str(b.side), "--layout", "10", "--blob-cache", b.blob_cache]
             try:
                 r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=400, check=True)
@@ -1016,8 +1027,10 @@ def hbm_regime(a, log):
                 res["scenes"][tag] = {"error": repr(e)}
                 continue
             n = out["rays_per_launch"]
+            b.coh_pin = {1: "0", 2: "2", 3: "3"}.get(out.get("coherent_schedule"), "0")
             pm = live_counters(b, log, passes=("FETCH_SIZE", "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum")) if not a.no_pmc else None
-            row = {"scene": out["scene"], "triangles": out["triangles"], "bvh_mb": out["bvh_mb"], "rays_per_launch": n, "tree": out["tree"]}
+            row = {"scene": out["scene"], "triangles": out["triangles"], "bvh_mb": out["bvh_mb"], "rays_per_launch": n, "tree": out["tree"],
+                   "coherent_schedule": {1: "deferred + gated", 2: "strict", 3: "one traversal per wave"}.get(out.get("coherent_schedule"), "undecided")}
             for kind in ("primary", "diffuse"):
                 alg = 80.0 * out.get(kind + "_S", 0.0) + 48.0 * out.get(kind + "_T", 0.0) + 80.0
                 sec = out[kind + "_ms"] * 1e-3
@@ -1048,12 +1061,12 @@ def scene_leg(a, log, scene, side, layout, ref_ocl, valu_ceiling, note=""):
     import copy
     import subprocess
     import tempfile
-    env = dict(os.environ, TBVH_COHERENT_TUNER="0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST"):
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST", "TBVH_COHERENT_TUNER"):
         env.pop(k, None)
     tmpdir = tempfile.mkdtemp(prefix="tbvh_leg_", dir="/tmp")
     b = copy.copy(a)
-    b.scene, b.side, b.device_build, b.layout, b.variant, b.coh_pin = scene, side, False, layout, 0, "0"
+    b.scene, b.side, b.device_build, b.layout, b.variant, b.coh_pin = scene, side, False, layout, 0, None
     b.blob_cache = os.path.join(tmpdir, scene + ".cwbvh") if layout == 10 else ""
     cmd = [sys.executable, os.path.abspath(__file__), "--hbm-child", "--scene", scene, "--side", str(side), "--layout", str(layout)] + \
           (["--blob-cache", b.blob_cache] if b.blob_cache else []) + (["--ref-ocl"] if ref_ocl else [])
@@ -1061,10 +1074,11 @@ def scene_leg(a, log, scene, side, layout, ref_ocl, valu_ceiling, note=""):
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
         out = json.loads([l for l in r.stdout.decode().split("\n") if l.startswith("{")][-1])
         n = out["rays_per_launch"]
+        b.coh_pin = {1: "0", 2: "2", 3: "3"}.get(out.get("coherent_schedule"), "0")      # the counter children run the schedule the timing child's tuner chose
         pm = live_counters(b, log, passes=("FETCH_SIZE", "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_BUSY_CYCLES")) if not a.no_pmc else None
         nb, tbytes = LAYOUT_BYTES[layout]
         row = {"scene": out["scene"], "triangles": out["triangles"], "layout": {5: "BVH_GPU", 8: "BVH4_GPU", 10: "BVH8_CWBVH"}[layout], "bvh_mb": out["bvh_mb"], "rays_per_launch": n,
-               "coherent_schedule": "deferred + gated, pinned (a child is too short for the tuner)" if layout == 10 else None, "note": note}
+               "coherent_schedule": {1: "deferred + gated", 2: "strict", 3: "one traversal per wave"}.get(out.get("coherent_schedule"), "undecided") if layout == 10 else None, "note": note}
         if "opencl_device" in out:
             row["opencl_device"] = out["opencl_device"]
         if "ref_opencl_error" in out:
@@ -1266,7 +1280,7 @@ def group_dispatches_into_queries(ids, names):
     is one dispatch."""
     queries, i = [], 0
     while i < len(ids):
-        pair = i + 1 < len(ids) and (", 5, 3, " in names[ids[i]] or ", 5, 4, " in names[ids[i]]) and ", 13, 2, " in names[ids[i + 1]]
+        pair = i + 1 < len(ids) and (", 5, 3, " in names[ids[i]] or ", 5, 4, " in names[ids[i]] or "k_cwbvh_packet<" in names[ids[i]]) and ", 13, 2, " in names[ids[i + 1]]
         queries.append(ids[i:i + 2] if pair else ids[i:i + 1])
         i += 2 if pair else 1
     return queries
@@ -1306,7 +1320,7 @@ def live_counters(a, log, passes=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     kn = r["Kernel_Name"]
-                    if r["Counter_Name"] in counters and ("k_cwbvh<false" in kn or "k_bvh4_w8<false" in kn or "k_bvh4<false" in kn or "k_bvh2<false" in kn):
+                    if r["Counter_Name"] in counters and ("k_cwbvh<false" in kn or "k_cwbvh_packet<false" in kn or "k_bvh4_w8<false" in kn or "k_bvh4<false" in kn or "k_bvh2<false" in kn):
                         row = per_disp.setdefault(int(r["Dispatch_Id"]), {})
                         row[r["Counter_Name"]] = row.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
                         names[int(r["Dispatch_Id"])] = kn

@@ -16,6 +16,9 @@ PLAIN = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false
 PLAIN_BIG = "void tbvh::(anonymous namespace)::k_cwbvh<false, 8, 16, 1, false, false, 0, 8, 0, 0, 8, 0>(...)"
 
 
+PACKET = "void tbvh::(anonymous namespace)::k_cwbvh_packet<false, false>(...)"
+
+
 def group(seq):
     ids = list(range(10, 10 + len(seq)))
     return [[i - 10 for i in q] for q in bench.group_dispatches_into_queries(ids, dict(zip(ids, seq)))]
@@ -29,6 +32,11 @@ def test_probed_scene_every_query_is_a_pair():
 def test_pairs_while_the_tuner_alternates_the_first_kernel():
     seq = [COH, INC, COH_STRICT, INC, COH, INC]
     assert group(seq) == [[0, 1], [2, 3], [4, 5]]
+
+
+def test_pairs_when_the_first_kernel_is_the_packet_traversal():
+    seq = [PACKET, INC, COH, INC, COH_STRICT, INC, PACKET, INC]
+    assert group(seq) == [[0, 1], [2, 3], [4, 5], [6, 7]]
 
 
 def test_small_preparation_batches_are_single_dispatches():
