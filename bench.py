@@ -1030,7 +1030,7 @@ def hbm_regime(a, log):
             b.coh_pin = {1: "0", 2: "2", 3: "3"}.get(out.get("coherent_schedule"), "0")
             pm = live_counters(b, log, passes=("FETCH_SIZE", "TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum")) if not a.no_pmc else None
             row = {"scene": out["scene"], "triangles": out["triangles"], "bvh_mb": out["bvh_mb"], "rays_per_launch": n, "tree": out["tree"],
-                   "coherent_schedule": {1: "deferred + gated", 2: "strict", 3: "one traversal per wave"}.get(out.get("coherent_schedule"), "undecided")}
+                   "coherent_schedule": {1: "deferred + gated", 2: "strict", 3: "one traversal per wave"}.get(out.get("coherent_schedule"), "n/a (no per-launch probe on a scene of this size: the strict schedule)")}
             for kind in ("primary", "diffuse"):
                 alg = 80.0 * out.get(kind + "_S", 0.0) + 48.0 * out.get(kind + "_T", 0.0) + 80.0
                 sec = out[kind + "_ms"] * 1e-3
