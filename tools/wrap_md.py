@@ -1,5 +1,5 @@
 import sys, textwrap, re
-W=154
+W=150
 def split_cells(line):
     line=line.strip()
     assert line.startswith('|')
