@@ -35,18 +35,26 @@ __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builti
 // wave's octant).  Returns the WAVE's ordered hit mask (a child counts when any lane's ray enters its box).  Empty slots (meta byte 0: half the slots of
 // the library's trees, whose nodes hold 1 interior child and 3 leaves on average) cost no vector instruction — a wave-uniform branch —, and the planes of
 // slot c + 1 are read from LDS while slot c is tested.  MIXED: some lane's octant differs from the wave's — near and far are sorted per lane through min / max.
+// The scalar unit is shared by the CU's four SIMDs and this kernel leans on it as hard as on the vector units (67 scalar + 20 branch against 81 vector
+// instructions per ray before this form), so what a slot's bits look like in the hit mask (`placed`: its unary triangle bits at its offset, or bit
+// 24 + (slot ^ octant) for an interior child) is worked out by LANES 0..7 in a handful of vector instructions and read back per slot, instead of eight
+// times a dozen scalar ones; a lane whose ray is out of the game carries tcull = -1 and needs no mask of its own.
 template <bool MIXED>
-__device__ __forceinline__ uint32_t pk_test_children(const float (*planes)[8], float ax, float ay, float az, float ox, float oy, float oz, float tcull, bool lives,
+__device__ __forceinline__ uint32_t pk_test_children(const float (*planes)[8], float ax, float ay, float az, float ox, float oy, float oz, float tcull,
                                                      uint32_t m0, uint32_t m1, uint32_t oct0) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t metaL = ((lane & 4u) ? m1 : m0) >> (8u * (lane & 3u)) & 255u;          // lane c (< 8): slot c's meta byte
+    const bool innerL = (metaL & 0x18u) == 0x18u;
+    const uint32_t placedL = (metaL >> 5) << ((innerL ? (metaL ^ oct0) : metaL) & 31u);
+    const uint32_t nonEmpty = (uint32_t)wave_ballot(lane < 8u && metaL != 0u);
     uint32_t hitmask = 0;
     float4 pa = *(const float4*)&planes[0][0];
     float2 pb = *(const float2*)&planes[0][4];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        const uint32_t meta = ((c < 4 ? m0 : m1) >> (8 * (c & 3))) & 255u;
         const float4 qa = pa; const float2 qb = pb;
         if (c < 7) { pa = *(const float4*)&planes[c + 1][0]; pb = *(const float2*)&planes[c + 1][4]; }
-        if (meta == 0u) continue;
+        if (!((nonEmpty >> c) & 1u)) continue;
         float tnx = __builtin_fmaf(qa.x, ax, ox), tny = __builtin_fmaf(qa.y, ay, oy), tnz = __builtin_fmaf(qa.z, az, oz);
         float tfx = __builtin_fmaf(qa.w, ax, ox), tfy = __builtin_fmaf(qb.x, ay, oy), tfz = __builtin_fmaf(qb.y, az, oz);
         if (MIXED) {
@@ -56,12 +64,8 @@ __device__ __forceinline__ uint32_t pk_test_children(const float (*planes)[8], f
         }
         const float cmin = __builtin_fmaxf(cw_fmax3(tnx, tny, tnz), 0.0f);
         const float cmax = __builtin_fminf(cw_fmin3(tfx, tfy, tfz), tcull);
-        if (wave_ballot(lives && cmin <= cmax) != 0ull) {
-            // interior child (meta = 0b001sssss, sssss = 24 + slot): bit 24 + (slot ^ octinv); leaf: its unary triangle bits at its offset
-            const bool inner = (meta & 0x18u) == 0x18u;
-            const uint32_t bitidx = (inner ? (meta ^ oct0) : meta) & 31u;
-            hitmask |= (meta >> 5) << bitidx;
-        }
+        const uint32_t placed = (uint32_t)__builtin_amdgcn_readlane((int)placedL, c);
+        hitmask |= wave_ballot(cmin <= cmax) != 0ull ? placed : 0u;
     }
     return hitmask;
 }
@@ -162,11 +166,11 @@ __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict
             const uint32_t ew = sgpr(as_u32(n0.w));
             const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
             const float ox = (n0.x - O.x) * rD.x, oy = (n0.y - O.y) * rD.y, oz = (n0.z - O.z) * rD.z;
-            const float tcull = cull_bound(hit.x);
             const bool lives = ANYHIT ? (on && !found) : on;
+            const float tcull = lives ? cull_bound(hit.x) : -1.0f;   // (a lane without a live ray enters no box: entry distances are clamped to >= 0)
             const uint32_t m0 = sgpr(as_u32(n1.z)), m1 = sgpr(as_u32(n1.w));
-            const uint32_t hitmask = mixed ? pk_test_children<true>(planes, ax, ay, az, ox, oy, oz, tcull, lives, m0, m1, oct0)
-                                           : pk_test_children<false>(planes, ax, ay, az, ox, oy, oz, tcull, lives, m0, m1, oct0);
+            const uint32_t hitmask = mixed ? pk_test_children<true>(planes, ax, ay, az, ox, oy, oz, tcull, m0, m1, oct0)
+                                           : pk_test_children<false>(planes, ax, ay, az, ox, oy, oz, tcull, m0, m1, oct0);
             ngx = sgpr(as_u32(n1.x));
             ngy = (hitmask & 0xFF000000u) | (ew >> 24);
             uint32_t tgy = hitmask & 0x00FFFFFFu;
