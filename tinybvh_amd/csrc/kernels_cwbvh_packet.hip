@@ -4,7 +4,7 @@
 // the same 48 quantised planes (48 v_cvt_f32_ubyte of the node test's ~210 VALU instructions) and, one triangle test or node visit out of step
 // with its neighbours after a few passes, fetches them on its own (only 5 % of the node phases of a 16.7 M-ray camera batch find every lane on one
 // node: DESIGN.md par. 5 "Round 2").  Here a wave of 64 CONSECUTIVE rays walks the tree ONCE:
-//   * one wave-uniform traversal state (node group, triangle group, stack in LDS with the wave's share of the global spill area behind it);
+//   * one wave-uniform traversal state (node group, triangle group; the stack in the lanes of two vector registers, the global spill area behind it);
 //   * a node is fetched once per wave (n0, n1 through the scalar cache; its 48 plane bytes one per lane), decoded once per wave — lane L converts
 //     byte L — and handed to all lanes through LDS in near / far order of the wave's octant; each lane then spends 6 FMAs + 4 min / max + 1 compare per
 //     child on ITS ray, and the wave descends into a child when ANY lane's ray enters its box (culled per lane against that lane's own closest hit,
@@ -27,7 +27,6 @@ namespace tbvh {
 namespace {
 
 constexpr int WG = 64;
-constexpr int kPkLds = 24;   // stack entries in LDS; deeper entries live in the wave's 64 lane-slots of the global spill area
 
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
@@ -73,7 +72,6 @@ __device__ __forceinline__ uint32_t pk_test_children(const float (*planes)[8], f
 template <bool ANYHIT, bool HAS_OMM>
 __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict__ nodes, const float4* __restrict__ tris, QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ float planes[8][8];      // the current node's child boxes as floats: [child][near x, near y, near z, far x, far y, far z, -, -] in units of 2^e from the node's origin
-    __shared__ uint2 stk[kPkLds];
     const uint64_t nRaysTotal = q.nRaysDev ? *q.nRaysDev : q.nRays;
     RayPool<64> pool;
     pool.init(q.poolParts, q.counterNext);
@@ -116,28 +114,30 @@ __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict
         const uint32_t p = lane >> 3, axis = p % 3u, isHi = p / 3u;
         const bool negA = axis == 0 ? negX0 : axis == 1 ? negY0 : negZ0;
         const uint32_t dstPlane = axis + 3u * (isHi ^ (negA ? 1u : 0u));
-        float* const myPlane = &planes[lane & 7u][dstPlane & 7u];
+        float* const myPlane = &planes[lane & 7u][lane < 48u ? dstPlane : 6u + ((lane >> 3) & 1u)];   // (columns 6, 7 of a row are spare)
 
         uint32_t sp = 0;
         uint32_t ngx = 0, ngy = 0x80000000u;
+        uint32_t stkx = 0, stky = 0;
         // the wave's next node: taken off the current node group, or off the stack; false when the traversal is over.  Only the wave-uniform state decides
         // (never a ray's hit distance), so the NEXT node can be picked — and its loads issued — before the current node's triangles are tested.
+        // The wave's stack lives in the LANES of two vector registers: entry k = lane k of (stkx, stky), written with v_writelane and read with v_readlane
+        // at a wave-uniform index — no LDS round trip, no exec juggling for "lane 0 only".  Entries beyond 64 (no tree seen needs them) go to the wave's
+        // slots of the global spill area.
         auto pick = [&](uint32_t& ci) -> bool {
             if (!(ngy > 0x00FFFFFFu)) {
                 if (sp == 0) return false;
                 sp--;
-                uint2 e;
-                if (sp < (uint32_t)kPkLds) e = stk[sp];
-                else { const uint32_t j_ = sp - kPkLds; e = spill[(j_ & 63u) + (size_t)(j_ >> 6) * spillRow]; }
-                ngx = sgpr(e.x); ngy = sgpr(e.y);
+                if (sp < 64u) { ngx = (uint32_t)__builtin_amdgcn_readlane((int)stkx, (int)sp); ngy = (uint32_t)__builtin_amdgcn_readlane((int)stky, (int)sp); }
+                else { const uint32_t j_ = sp - 64u; const uint2 e = spill[(j_ & 63u) + (size_t)(j_ >> 6) * spillRow]; ngx = sgpr(e.x); ngy = sgpr(e.y); }
             }
             const uint32_t imaskWord = ngy;
             const uint32_t bit = 31u - (uint32_t)__builtin_clz(ngy);
             ngy &= ~(1u << bit);
             if (ngy > 0x00FFFFFFu) {   // children of this group still pending: keep it
-                if (sp < (uint32_t)kPkLds) { if (lane == 0) stk[sp] = make_uint2(ngx, ngy); }
+                if (sp < 64u) { asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(stkx), "+v"(stky) : "s"(ngx), "s"(sp), "s"(ngy) : "m0"); }   // (one SGPR operand per VOP3: the lane select goes through m0)
                 else {
-                    const uint32_t j_ = sp - kPkLds;
+                    const uint32_t j_ = sp - 64u;
                     if (j_ < spillCap) { if (lane == 0) spill[(j_ & 63u) + (size_t)(j_ >> 6) * spillRow] = make_uint2(ngx, ngy); }
                     else overflow = true;
                 }
@@ -155,13 +155,13 @@ __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict
         auto fetch = [&](uint32_t c_) {
             const float4* np = nodes + (size_t)c_ * 5u;
             n0 = np[0]; n1 = np[1];
-            if (lane < 48u) qb = ((const uint8_t*)(np + 2))[lane];
+            qb = ((const uint8_t*)(np + 2))[lane < 48u ? lane : 47u];   // (lanes 48..63 re-read byte 47 and park it in an unused column: no exec mask to set up)
         };
         if (more) fetch(ci);
         while (more) {
             // ---- the node: decoded once for the wave ---------------------------------------------------------------------
             __builtin_amdgcn_wave_barrier();               // (every lane has read the previous node's planes before they are overwritten)
-            if (lane < 48u) *myPlane = (float)qb;
+            *myPlane = (float)qb;
             __builtin_amdgcn_wave_barrier();
             const uint32_t ew = sgpr(as_u32(n0.w));
             const float ax = ldexpf(rD.x, (int)(int8_t)(ew)), ay = ldexpf(rD.y, (int)(int8_t)(ew >> 8)), az = ldexpf(rD.z, (int)(int8_t)(ew >> 16));
