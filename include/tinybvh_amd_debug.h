@@ -17,7 +17,8 @@ int tbvh_debug_stats(tbvh_context* ctx, uint64_t out[8], int reset);
  * 1 = non-temporal ray loads / hit stores, 2 = the 64-byte triangle records in the ordinary kernels too (only where the scene has them:
  * after tbvh_cwbvh_set_hybrid or the first large launch; ignored otherwise) — both only in the experiment build (make EXPERIMENTS=1: the
  * shipped kernels do not carry the two code paths), 4 = a probed launch as ONE kernel even where the copies exist,
- * 8 = the next tbvh_cwbvh_set_hybrid / lazy build derives the node copy WITHOUT a triangle in each node's line, 64 = no coherence probe (every
+ * 8 = the next tbvh_cwbvh_set_hybrid / lazy build derives the node copy WITHOUT a triangle in each node's line, 16 = the coherent flavor of a two-flavor
+ * launch takes the batch whatever its probe finds (tests put incoherent rays through the coherent schedules), 64 = no coherence probe (every
  * launch takes the unprobed path), bits 8..15 = waves per CU of the incoherent flavor (clamped to the 32 per CU the stack spill area is sized for). */
 int tbvh_debug_set_flags(tbvh_context* ctx, uint32_t flags);
 

@@ -322,3 +322,57 @@ def test_parallel_rays_from_scattered_origins_are_all_traced(ctx, oracle):
     hit = got["t"] < 1e30
     assert np.array_equal(fresh[hit].view(np.uint8), got[hit].view(np.uint8)) and int((fresh["t"] < 1e30).sum()) == int(hit.sum())
     ctx.free(d_r); sc.free()
+
+
+def test_packet_traversal_on_hostile_batches(oracle):
+    """kernels_cwbvh_packet.hip (one traversal per wave of 64 consecutive rays; the tuner's third schedule) where it is NOT at home, pinned through the
+    schedule hint with the coherent verdict forced (debug flag 16): random rays (every wave of mixed octants: the min / max slab path, large unions), a ray
+    count that is no multiple of 64, rays along the axes and with zero direction components (rD = 1e30), finite tmax on a launch that is not `fresh`,
+    any-hit, and opacity micromaps — records byte-identical with the per-lane strict schedule's and oracle-exact on a sample."""
+    from test_oracle_vs_reference import random_opmap
+    verts, _ = scenes.get("bistro")
+    c = tb.Context(0)
+    try:
+        sc = tb.BVH8_CWBVH(c).Build(verts)
+        h = sc.host
+        n = 2_200_000 + 37                                             # above the probe's 2 M threshold, not a multiple of 64
+        lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+        rays = R.random_rays(n, lo, hi, seed=77, tmax=np.float32(60.0))
+        k = np.arange(0, 4096)                                          # a block of axis-parallel rays and rays with zero components
+        D = np.zeros((k.size, 3), np.float32); D[np.arange(k.size), k % 3] = np.where(k % 2, 1.0, -1.0)
+        D[k % 7 == 0, (k[k % 7 == 0] + 1) % 3] = 0.5
+        rays[1000:1000 + k.size] = tb.make_rays(rays["O"][1000:1000 + k.size], D, tmax=np.float32(1e30))
+        d = c.malloc(n * 64); d_occ = c.malloc(n)
+
+        def run(hint, flags, anyhit=False):
+            sc.set_schedule_hint({"closest_hit": [hint] * 3, "any_hit": [hint] * 3})
+            c.set_debug_flags(flags)
+            c.to_device(d, rays)
+            if anyhit:
+                sc.occluded_device(d, n, d_occ)
+                out = np.zeros(n, np.uint8); c.from_device(out, d_occ)
+            else:
+                sc.intersect_device(d, n)                               # not fresh: the records' own tmax
+                out = np.zeros(n, tb.RAY_DTYPE); c.from_device(out, d)
+            c.set_debug_flags(0)
+            return out
+        strict = run(2, 16)
+        packet = run(3, 16)
+        assert sc.coherent_schedule(False)[0] == 3
+        assert np.array_equal(packet.view(np.uint8), strict.view(np.uint8))
+        idx = np.arange(0, n, n // 32768)[:32768]
+        want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays[idx])
+        cmp_ = compare_hits(packet[idx], want)
+        assert cmp_["hits"] > 8000 and cmp_["hitmiss"] == 0 and cmp_["prim_real"] == 0 and cmp_["t_bad"] == 0 and cmp_["tie"] == 0, cmp_
+        assert cmp_["bit_identical"] == cmp_["same_prim"], cmp_
+        assert np.array_equal(run(3, 16, anyhit=True), run(2, 16, anyhit=True))
+        # opacity micromaps: the HAS_OMM instantiations
+        N = 4
+        om = random_opmap(verts.shape[0] // 3, N, seed=5)
+        sc.SetOpacityMicroMaps(om, N)
+        a, b = run(2, 16), run(3, 16)
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)) and int((a["prim"] != strict["prim"]).sum()) > 10000
+        assert np.array_equal(run(3, 16, anyhit=True), run(2, 16, anyhit=True))
+        c.free(d); c.free(d_occ); sc.free()
+    finally:
+        c.close()

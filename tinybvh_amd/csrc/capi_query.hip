@@ -261,6 +261,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             else if (twoFlavors) {
                 QueryArgs qa = q;
                 qa.baseBlocks = 0;   // every wave of the coherent flavor leaves unless the batch is coherent
+                if (c->expFlags & 16u) qa.flags |= 16u;   // (debug flag 16: the coherent flavor takes the batch whatever the probe finds: tests put incoherent rays through it)
                 // which schedule serves a coherent batch on this scene is measured, not assumed (CohTuner, capi_internal.h)
                 const int sizeClass = n < (6ull << 20) ? 0 : n < (12ull << 20) ? 1 : 2;
                 s->cohLastClass[any ? 1 : 0] = (uint8_t)sizeClass;

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict
         uint32_t stkx = 0, stky = 0;
         // the wave's next node: taken off the current node group, or off the stack; false when the traversal is over.  Only the wave-uniform state decides
         // (never a ray's hit distance), so the NEXT node can be picked — and its loads issued — before the current node's triangles are tested.
-        // The wave's stack lives in the LANES of two vector registers: entry k = lane k of (stkx, stky), written with v_writelane and read with v_readlane
+        // The wave's stack lives in the LANES of two vector registers: entry k = lane k of (stkx, stky), written by a select on lane == k and read with v_readlane
         // at a wave-uniform index — no LDS round trip, no exec juggling for "lane 0 only".  Entries beyond 64 (no tree seen needs them) go to the wave's
         // slots of the global spill area.
         auto pick = [&](uint32_t& ci) -> bool {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict
             const uint32_t bit = 31u - (uint32_t)__builtin_clz(ngy);
             ngy &= ~(1u << bit);
             if (ngy > 0x00FFFFFFu) {   // children of this group still pending: keep it
-                if (sp < 64u) { asm volatile("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0" : "+v"(stkx), "+v"(stky) : "s"(ngx), "s"(sp), "s"(ngy) : "m0"); }   // (one SGPR operand per VOP3: the lane select goes through m0)
+                if (sp < 64u) { const bool mine = lane == sp; stkx = mine ? ngx : stkx; stky = mine ? ngy : stky; }   // (lane sp of the pair takes the entry: a compare and two selects)
                 else {
                     const uint32_t j_ = sp - 64u;
                     if (j_ < spillCap) { if (lane == 0) spill[(j_ & 63u) + (size_t)(j_ >> 6) * spillRow] = make_uint2(ngx, ngy); }
