@@ -46,7 +46,7 @@
 extern "C" {
 #endif
 
-#define TBVH_ABI_VERSION 4   /* 4: tbvh_update_bvh_gpu / _bvh4_gpu / _cwbvh, tbvh_time_history, contexts are thread-safe; 3: deterministic ties, tbvh_bin_rays_device, tbvh_cwbvh_set_hybrid, device-resident multi-device calls */
+#define TBVH_ABI_VERSION 5   /* 5: tbvh_pinned_malloc / _free, tbvh_scene_get / _set_schedule_hint, tbvh_measure_link_bandwidth, TBVH_BUILD_SPLIT_TRIANGLES / _WHOLE_TRIANGLES, development aids moved to tinybvh_amd_debug.h (nothing removed from the library); 4: tbvh_update_bvh_gpu / _bvh4_gpu / _cwbvh, tbvh_time_history, contexts are thread-safe; 3: deterministic ties, tbvh_bin_rays_device, tbvh_cwbvh_set_hybrid, device-resident multi-device calls */
 
 /* error codes */
 #define TBVH_OK            0

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 
 
 def test_abi_version_and_layout_constants():
-    assert _capi.lib.tbvh_abi_version() == 4
+    assert _capi.lib.tbvh_abi_version() == 5
     assert tb.RAY_DTYPE.itemsize == 64
     assert tb.RAY_DTYPE.fields["t"][1] == 48 and tb.RAY_DTYPE.fields["prim"][1] == 60
     assert tb.RAY_DTYPE.fields["inst"][1] == 44 and tb.RAY_DTYPE.fields["rD"][1] == 32
