@@ -87,6 +87,10 @@ int tbvh_init(int device, tbvh_context** out) {
         if (b >= 0 && (1 << b) <= kPoolParts) c->poolParts = (uint32_t)b;   // log2 of the partition count
     }
     c->spillEntries = 232;  // 32-bit entries per lane beyond the LDS part of the stack
+    if (const char* e2 = getenv("TBVH_SPILL_ENTRIES")) {   // a SMALLER spill area: how the tests reach the "traversal stack overflow" path with a tree of a few hundred levels
+        const int v = atoi(e2);
+        if (v >= 2 && v <= 232) c->spillEntries = (uint32_t)v & ~1u;
+    }
     const size_t spillBytes = (size_t)(c->blocks + c->blocks / 3u) * 64 * c->spillEntries * 4;   // the largest grid any launch uses
     e = hipMalloc((void**)&c->spill, spillBytes);
     if (e == hipSuccess) e = hipMalloc((void**)&c->counter, 256);

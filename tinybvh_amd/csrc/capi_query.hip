@@ -26,9 +26,10 @@ namespace tbvh_capi {
 
 int ensurePipe(tbvh_context* c, uint64_t nHits) {
     if (!c->pipe) {
-        HostPipe* p = new (std::nothrow) HostPipe;
+        // built aside and published only when complete: a failure half way (pinned memory is a scarce resource) must leave the context without a
+        // pipe, so that the next host query tries again instead of running on null buffers (HIP_TRY returns; ~HostPipe releases what was made)
+        std::unique_ptr<HostPipe> p(new (std::nothrow) HostPipe);
         if (!p) return fail(TBVH_E_NOMEM, "out of host memory");
-        c->pipe = p;
         for (int i = 0; i < 2; i++) {
             HIP_TRY(hipHostMalloc(&p->pinUp[i], HostPipe::kChunk * 64, hipHostMallocDefault));
             HIP_TRY(hipEventCreateWithFlags(&p->evUp[i], hipEventDisableTiming));
@@ -41,7 +42,9 @@ int ensurePipe(tbvh_context* c, uint64_t nHits) {
         const uint32_t hw = usable_host_threads();
         uint32_t t = hw > 16 ? 15 : hw > 1 ? hw - 1 : 0;
         if (const char* e = getenv("TBVH_HOST_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 64) t = (uint32_t)v - 1; }
-        p->start(t);
+        try { p->start(t); }
+        catch (const std::exception&) { return fail(TBVH_E_NOMEM, "cannot start the host staging threads"); }   // (~HostPipe joins the ones that did start)
+        c->pipe = p.release();
     }
     HostPipe* p = c->pipe;
     if (p->packedCap < nHits) {
@@ -258,6 +261,8 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                 qa.probe = poolArea + (size_t)kPoolParts * kPoolCounterStride; qa.baseBlocks = 0; qa.flags |= 16u;
                 launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, blocks, c->stream, 5, small, blocks7);
             }
+            else if (s->variant == 92)   // diagnostic: one traversal per wave of 64 consecutive rays (kernels_cwbvh_packet.hip) whatever the batch, the scene's size and the tuner
+                launch_cwbvh_packet(any, s->nodes, s->tris, q, c->status, blocks, c->stream);
             else if (twoFlavors) {
                 QueryArgs qa = q;
                 qa.baseBlocks = 0;   // every wave of the coherent flavor leaves unless the batch is coherent
@@ -292,7 +297,16 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                 }
                 // a batch whose size only the device knows (the wavefront stages) cannot be priced per ray: the default schedule, no sample
                 const bool measure = !tu.decided && !c->cohTunerMode && !nDev && tu.pending.size() < 16;
-                const int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : (nDev ? 1 : 1 + (int)(tu.launches % (uint32_t)CohTuner::kModes));
+                // while undecided: the schedule with the fewest samples taken or in flight (round-robin by launch count aliased with callers whose coherent
+                // launches come every third time: one schedule got every sample, the others none, and the tuner idled into its fallback)
+                int least = 0;
+                if (!tu.decided && !c->cohTunerMode && !nDev) {
+                    uint32_t cnt[CohTuner::kModes];
+                    for (int m = 0; m < CohTuner::kModes; m++) cnt[m] = tu.n[m];
+                    for (const CohTuner::Pending& pe : tu.pending) cnt[pe.mode - 1]++;
+                    for (int m = 1; m < CohTuner::kModes; m++) if (cnt[m] < cnt[least]) least = m;
+                }
+                const int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : (nDev ? 1 : 1 + least);
                 if (!nDev) tu.launches++;
                 if (mode == 2) qa.flags |= 32u;
                 CohTuner::Pending pe{nullptr, nullptr, mode, n};

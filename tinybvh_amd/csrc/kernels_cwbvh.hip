@@ -469,7 +469,7 @@ bool cwbvh_variant_valid(int v) {
 #ifdef TBVH_EXPERIMENTS
     if (v == 52 || v == 89 || v == 59 || v == 61 || v == 73 || v == 78 || v == 82 || v == 83) return true;
 #endif
-    return v == 0 || v == 90 || v == 91 || v == 72 || v == 75 || v == 88;
+    return v == 0 || v == 90 || v == 91 || v == 92 || v == 72 || v == 75 || v == 88;
 }
 
 }  // namespace tbvh

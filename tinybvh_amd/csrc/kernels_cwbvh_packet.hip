@@ -139,7 +139,7 @@ __global__ __launch_bounds__(WG, 8) void k_cwbvh_packet(const float4* __restrict
                 else {
                     const uint32_t j_ = sp - 64u;
                     if (j_ < spillCap) { if (lane == 0) spill[(j_ & 63u) + (size_t)(j_ >> 6) * spillRow] = make_uint2(ngx, ngy); }
-                    else overflow = true;
+                    else { overflow = true; sp--; }   // dropped (status bit 1 -> TBVH_E_FORMAT): the stack pointer must not run past the wave's rows of the spill area
                 }
                 sp++;
             }
