@@ -1,0 +1,105 @@
+"""A BVH_GPU scene keeps an 8-wide copy of its tree (tinybvh_amd/csrc/capi_scene.hip: makeWideCopy) and its queries trace that copy: the hit records
+must be the ones the uploaded 2-wide nodes give — byte for byte under the library's tie rule (device_common.h: hit_wins), variant 1 = k_bvh2 on the
+nodes as uploaded — and the reference's own (golden vectors from the real tiny_bvh.h: BVH::Intersect, tiny_bvh.h:3222-3304).  Blobs: the reference's
+BVH_GPU::Build and BuildHQ (SBVH: clipped leaf boxes, primIdx with repeats and slack) from tests/golden, and the library's own builder; the copy
+follows tbvh_update_bvh_gpu, tbvh_refit and tbvh_set_opacity_micromaps; small blobs do not get one."""
+import os
+
+import numpy as np
+import pytest
+
+import tinybvh_amd as tb
+from tinybvh_amd import rays as R
+from tinybvh_amd import scenes
+from oracle_lib import compare_hits
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture
+def wide_from_one_entry():
+    old = os.environ.get("TBVH_WIDE_COPY_MIN")
+    os.environ["TBVH_WIDE_COPY_MIN"] = "1"
+    yield
+    if old is None:
+        os.environ.pop("TBVH_WIDE_COPY_MIN", None)
+    else:
+        os.environ["TBVH_WIDE_COPY_MIN"] = old
+
+
+@pytest.mark.parametrize("name", ["soup_2k", "atrium_6k", "suzanne_decimated"])
+def test_reference_blobs_through_the_wide_copy(ctx, wide_from_one_entry, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    verts, rays = g["verts"], g["rays"]
+    want = rays.copy()
+    want.view(np.uint32).reshape(-1, 16)[:, 12:16] = g["hits"]
+    for k in (0, 1):                                      # BVH_GPU::Build and BuildHQ
+        nodes, idx = g[f"bvhgpu_nodes_{k}"], g[f"bvhgpu_idx_{k}"].reshape(-1)
+        sc = tb.BVH_GPU(ctx).Upload(nodes, idx, verts)
+        plain_bytes = nodes.shape[0] * 64 + idx.shape[0] * 48
+        assert sc.device_bytes > plain_bytes                # the copy exists
+        wide = sc.Intersect(rays.copy())
+        sc.set_variant(1)
+        native = sc.Intersect(rays.copy())
+        sc.set_variant(0)
+        assert np.array_equal(wide.view(np.uint8), native.view(np.uint8)), (name, k)
+        c = compare_hits(wide, want)
+        assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] <= 2, (name, k, c)
+        occ = sc.IsOccluded(g["shadow_rays"].copy())
+        assert int((occ != g["occluded"]).sum()) == 0
+        sc.free()
+
+
+def test_library_built_scene_update_refit_micromaps(ctx, oracle):
+    verts = scenes.atrium(60_000, seed=3)
+    sc = tb.BVH_GPU(ctx).Build(verts)
+    h = sc.host
+    assert sc.device_bytes > h.blob(0, np.uint32, 16).shape[0] * 64 + h.blob(1, np.uint32, 1).shape[0] * 48
+    rays = np.concatenate([R.random_rays(60_000, (-20, 0, -10), (20, 15, 10), seed=8), R.primary(R.camera(*scenes.SPONZA_CAMERAS[0], 256, 128, 1, 1))])
+    want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
+
+    def both():
+        a = sc.Intersect(rays.copy())
+        sc.set_variant(1)
+        b = sc.Intersect(rays.copy())
+        sc.set_variant(0)
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+        return a
+    c = compare_hits(both(), want)
+    assert c["hits"] > 10_000 and c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["tie"] == 0 and c["bit_identical"] == c["same_prim"], c
+    # refit to moved vertices: both the uploaded nodes and the copy follow; the oracle's answer on a tree refitted the same way = the tree's own answer
+    moved = verts.copy()
+    moved[:, 1] += np.float32(0.05) * np.sin(verts[:, 0]).astype(np.float32)
+    sc.Refit(moved)
+    a = both()
+    h2 = tb.HostBVH(moved, tb.LAYOUT_BVH2_WALD)
+    want2 = oracle.bvh2_intersect(h2.bvh2_nodes(), h2.bvh2_prim_idx(), moved, rays)
+    c = compare_hits(a, want2)
+    assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0, c
+    # update with another tree of the same size class (rebuilt over the moved vertices with the same builder)
+    hb = tb.HostBVH(moved, tb.LAYOUT_BVH_GPU)
+    nodes, idx = hb.blob(0, np.uint32, 16), hb.blob(1, np.uint32, 1).reshape(-1)
+    if nodes.shape[0] * 4 <= h.blob(0, np.uint32, 16).shape[0] * 4 and idx.shape[0] <= h.blob(1, np.uint32, 1).shape[0]:
+        sc.Update(nodes, idx, moved)
+        c = compare_hits(both(), want2)
+        assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0, c
+    # opacity micromaps: every second triangle fully transparent — the copy must honour the same maps
+    n_tris = verts.shape[0] // 3
+    N = 2
+    words = np.zeros((n_tris, 1), np.uint32)
+    words[0::2] = 0xffffffff
+    sc.SetOpacityMicroMaps(words, N)
+    a = both()
+    hit = a["t"] < 1e30
+    assert hit.sum() > 1000 and np.all(a["prim"][hit] % 2 == 0)
+    sc.SetOpacityMicroMaps(None, 0)
+    sc.free()
+
+
+def test_small_blobs_keep_the_two_wide_kernel(ctx):
+    verts = scenes.soup(2_000, seed=2)
+    sc = tb.BVH_GPU(ctx).Build(verts)
+    h = sc.host
+    assert sc.device_bytes == h.blob(0, np.uint32, 16).shape[0] * 64 + h.blob(1, np.uint32, 1).shape[0] * 48
+    sc.free()

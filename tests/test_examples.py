@@ -42,3 +42,32 @@ def test_wavefront_demos_with_real_tinybvh():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "wavefront demos ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_reference_minimal_gpu_main_unmodified():
+    """/root/reference/tiny_bvh_minimal_gpu.cpp compiled with ZERO edits against include/shim/tiny_ocl.h (tinyocl::Buffer / Kernel("traverse.cl",
+    "batch_ailalaine") / SetArguments / Run over the C ABI; __graft_entry__.build()) prints, for its 1024 rays, exactly what the real
+    tinybvh::BVH::Intersect finds on the CPU for the same rand() sequence (examples/ref_minimal_check.cpp): its own output, line for line."""
+    exe, chk = os.path.join(BUILD, "ref_minimal_gpu"), os.path.join(BUILD, "ref_minimal_check")
+    if not (os.path.exists(exe) and os.path.exists(chk)):
+        pytest.skip("needs the reference checkout at build time")
+    got = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert got.returncode == 0, got.stdout[-500:] + got.stderr[-500:]
+    want = subprocess.run([chk], capture_output=True, text=True, timeout=120)
+    assert want.returncode == 0
+    g = [l for l in got.stdout.split("\n") if l.startswith("ray ")]
+    w = [l for l in want.stdout.split("\n") if l.startswith("ray ")]
+    assert len(g) == 1024 and g == w, [(a, b) for a, b in zip(g, w) if a != b][:5]
+
+
+@pytest.mark.gpu
+def test_speedtest_blocks_in_tinyocl_names():
+    """The three GPU blocks of tiny_bvh_speedtest.cpp:1092-1241 in tinyocl's own names and statement order (Buffer, CopyToDevice, Kernel, SetArguments,
+    Run with a cl_event, clGetEventProfilingInfo, CopyFromDevice) on include/shim/tiny_ocl.h, layouts from the real BuildHQ; t bit-equal to BVH::Intersect."""
+    exe = os.path.join(BUILD, "shim_speedtest_blocks")
+    if not os.path.exists(exe):
+        pytest.skip("needs the reference header at build time")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "shim speedtest blocks ok" in out.stdout

@@ -206,3 +206,67 @@ def test_other_layouts_16m_against_the_real_reference(ctx, reference, layout):
     for p in (d_verts, d_p, d_b):
         ctx.free(p)
     sc.free()
+
+
+def test_config4_64m_diffuse_rays_at_stated_size(ctx, reference):
+    """BASELINE configs[3] at its STATED size: 67 108 864 incoherent diffuse rays (bounce depths 1-3 in thirds) = 4.29 GB of ray records in ONE
+    buffer — the size tinyocl::Buffer cannot express (`unsigned int size`, tiny_ocl.h:136,152: 64 M x 64 B wraps to 0).  Traced through
+    tbvh_intersect_device_fresh; a strided 65 k sample against the REAL BVH::Intersect (tiny_bvh.h:3222-3304) under its own tie rule; then the same
+    batch cut into two contiguous wave-aligned shards over two contexts on device 0 through tbvh_intersect_sharded_device (the replicated-BVH
+    split of SURVEY par. 8(e)): byte-identical to the single launch.  Records at byte offsets beyond 2^31 (tinyocl's `int` offsets) up to 2^32 are covered by the sample and
+    by the whole-array comparison of the sharded call."""
+    from tinybvh_amd.sharding import shard_range
+    verts, label = scenes.get("bistro")
+    side = 8192
+    n = side * side
+    assert n * 64 >= 2 ** 32                                # 64 M x 64 B = 2^32 exactly: an `unsigned int` size reads 0, an `int` offset overflows from 2^31 on
+    cam = R.camera(*scenes.STREET_CAMERAS[0], side, side, 1, 1)
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    rs = reference.build(verts, hq=True, threaded=True)
+    d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
+    d_a, d_b = ctx.malloc(n * 64), ctx.malloc(n * 64)
+    ctx.generate_primary(cam, d_a, 0, n)
+    sc.intersect_device(d_a, n)
+    t3 = n // 3
+    ctx.generate_bounce(d_verts, d_a, d_b, n, 4001)
+    sc.intersect_device(d_b + t3 * 64, n - t3)
+    ctx.generate_bounce(d_verts, d_b + t3 * 64, d_b + t3 * 64, n - t3, 4002)
+    sc.intersect_device(d_b + 2 * t3 * 64, n - 2 * t3)
+    ctx.generate_bounce(d_verts, d_b + 2 * t3 * 64, d_b + 2 * t3 * 64, n - 2 * t3, 4003)
+    ctx.synchronize()
+    ctx.free(d_a)
+    sc.intersect_device_fresh(d_b, n, 1e30)
+    ctx.synchronize()
+    ms = ctx.time_last_ms()
+    single = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(single, d_b)
+    idx = np.arange(0, n, n // 65536)[:65536]
+    assert int(idx[-1]) * 64 > 2 ** 31 + 2 ** 30           # the sample reaches far beyond what tinyocl's `int offset` (tiny_ocl.h:141,144) can address
+    sample = single[idx].copy()
+    sample["t"] = 1e30; sample["u"] = 0; sample["v"] = 0; sample["prim"] = 0
+    want = rs.intersect(1, sample)                         # the real BVH::Intersect
+    c = compare_with_real_reference(single[idx], want)
+    assert c["hits"] > 65536 // 4, c
+    _real_reference_clean(c, "64 M diffuse rays, library tree")
+    print(f"config 4 at its stated size: {n} rays in {ms:.2f} ms = {n / ms / 1e3:.0f} MRays/s; vs the real reference: {c}")
+    # the same batch in two contiguous shards over two contexts of device 0, device-resident, one call
+    c2 = tb.Context(0)
+    try:
+        h = sc.host
+        rep = tb.BVH8_CWBVH(c2).Upload(h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4))
+        (b0, e0), (b1, e1) = shard_range(n, 0, 2), shard_range(n, 1, 2)
+        assert b0 == 0 and e0 == b1 and e1 == n and b1 % 64 == 0
+        # rays back to their untraced state through the fresh launch itself: shard 0 in place, shard 1 in a buffer of context 2
+        d_s1 = c2.malloc((e1 - b1) * 64)
+        c2.to_device(d_s1, single[b1:e1])
+        km, dm = tb.intersect_sharded_device([sc, rep], [d_b, d_s1], [e0 - b0, e1 - b1], fresh=True, tmax=1e30)
+        assert len(km) == 2 and all(k > 0 for k in km)
+        part = np.zeros(e0 - b0, tb.RAY_DTYPE); ctx.from_device(part, d_b)
+        assert np.array_equal(part.view(np.uint8), single[b0:e0].view(np.uint8))
+        part = np.zeros(e1 - b1, tb.RAY_DTYPE); c2.from_device(part, d_s1)
+        assert np.array_equal(part.view(np.uint8), single[b1:e1].view(np.uint8))
+        c2.free(d_s1); rep.free()
+    finally:
+        c2.close()
+    for p in (d_verts, d_b):
+        ctx.free(p)
+    sc.free()

@@ -84,6 +84,40 @@ tbvh_scene* newScene(tbvh_context* c, int layout) {
     return s;
 }
 
+void freeWideCopy(tbvh_scene* s) {
+    if (!s || !s->wide) return;
+    tbvh_scene* w = s->wide;
+    s->wide = nullptr;
+    s->bytes -= w->bytes < s->bytes ? w->bytes : 0;
+    w->opmap = nullptr; w->opmapBytes = 0;   // (shared with the owner, never owned)
+    tbvh_free_scene(w);
+}
+
+// The 8-wide copy of an uploaded BVH_GPU blob (tbvh_scene::wide): host side, the Aila-Laine nodes become a Wald-layout BVH2 with leaves of at most
+// 3 entries (host_builder.cpp: bvh_gpu_to_bvh2); device side, the converter every BVH8_CWBVH conversion uses collapses and encodes it
+// (kernels_convert.hip, the greedy collapse of MBVH<8>::ConvertFrom, tiny_bvh.h:4975-5048).  Blobs below TBVH_WIDE_COPY_MIN primIdx entries
+// (default 32768; 0 = never) keep the 2-wide kernel: the conversion costs more than a few small batches gain.  A failure here is not an error of
+// the upload: the scene then simply traces its own nodes.
+static int makeWideCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx, const void* verts16, uint64_t nTris) {
+    tbvh_context* c = s->ctx;
+    freeWideCopy(s);
+    uint64_t minIdx = 32768;
+    if (const char* e = getenv("TBVH_WIDE_COPY_MIN")) { const long long v = atoll(e); minIdx = v <= 0 ? ~0ull : (uint64_t)v; }
+    if (nIdx < minIdx || nIdx > 0x7fffffffull || nNodes > 0x3fffffffull) return 0;
+    std::vector<Node2> n2;
+    try {
+        if (!bvh_gpu_to_bvh2((const NodeAL*)nodes64, nNodes, primIdx, nIdx, (const Vec4*)verts16, nTris, 3u, n2)) return 0;
+    } catch (const std::bad_alloc&) { return 0; }
+    tbvh_scene* w = nullptr;
+    if (tbvh_convert_bvh2_device(c, n2.data(), n2.size(), primIdx, nIdx, verts16, nTris, 0, TBVH_LAYOUT_CWBVH, &w) != 0 || !w) return 0;
+    for (size_t i = 0; i < c->scenes.size(); i++)
+        if (c->scenes[i] == w) { c->scenes.erase(c->scenes.begin() + i); break; }   // owned by `s`, freed with it
+    w->opmap = s->opmap; w->opmapN = s->opmapN;
+    s->wide = w;
+    s->bytes += w->bytes;
+    return 0;
+}
+
 }  // namespace tbvh_capi
 
 extern "C" {
@@ -113,6 +147,7 @@ int tbvh_upload_bvh_gpu(tbvh_context* c, const void* nodes64, uint64_t nNodes, c
     s->nNodeBlocks = nNodes * 4; s->nTriBlocks = nIdx * 3;
     s->capNodeBlocks = s->nNodeBlocks; s->capTriBlocks = s->nTriBlocks;
     s->bytes = nNodes * 64 + nIdx * 48;
+    makeWideCopy(s, nodes64, nNodes, primIdx, nIdx, verts16, nTris);
     *out = s;
     return 0;
 }
@@ -292,6 +327,7 @@ int tbvh_update_bvh_gpu(tbvh_scene* s, const void* nodes64, uint64_t nNodes, con
     if (dVerts) hipFree(dVerts);
     if (e != hipSuccess) return fail(TBVH_E_HIP, "tbvh_update_bvh_gpu: %s", hipGetErrorString(e));
     s->nNodeBlocks = nNodes * 4; s->nTriBlocks = nIdx * 3;
+    makeWideCopy(s, nodes64, nNodes, primIdx, nIdx, verts16, nTris);   // (the tree may have changed: collapsed again)
     return 0;
 }
 
@@ -528,6 +564,7 @@ int tbvh_set_opacity_micromaps(tbvh_scene* s, const uint32_t* mapData, uint32_t 
     const uint64_t oldBytes = s->opmapBytes;
     s->opmap = fresh; s->opmapN = clear ? 0u : N; s->opmapBytes = freshBytes;
     s->bytes += freshBytes; s->bytes -= oldBytes;
+    if (s->wide) { s->wide->opmap = s->opmap; s->wide->opmapN = s->opmapN; }   // (shared, owned here)
     const int r = refreshBlasDescs(s);   // the descriptors are rewritten before the old maps go
     if (old && r == 0) hipFree(old);   // (a failed refresh may have left a descriptor on the old maps: leak them rather than dangle)
     return r;
@@ -600,6 +637,7 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
     if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copy current
     if (s->nodesHy) launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, nNodes, s->hybridK, (c->embedTris && !(c->expFlags & 8u)) ? s->tris : nullptr, c->stream);
     if (s->tris64) launch_cwbvh_pad_tris(s->tris, s->tris64, s->nTriBlocks / 3, c->stream);
+    if (s->wide) return tbvh_refit(s->wide, dv, nTris, 1);   // the 8-wide copy follows (same vertices, already on the device)
     return 0;
 }
 
@@ -671,6 +709,7 @@ void tbvh_free_scene(tbvh_scene* s) {
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (!s->isTlas && !s->usedBy.empty()) { s->zombie = true; return; }   // a TLAS still points at this BLAS's memory: freed with the last such TLAS
+    freeWideCopy(s);
     if (s->isTlas) {
         std::vector<tbvh_scene*> mine;
         mine.swap(s->blasList);
@@ -746,7 +785,8 @@ int tbvh_set_variant(tbvh_scene* s, int v) {
     if (!s) return fail(TBVH_E_INVALID, "null scene");
     TBVH_LOCK(s->ctx);
     // only the BVH8_CWBVH kernel keeps diagnostic variants (kernels_cwbvh.hip: forced schedules, instrumented kernels)
-    const bool ok = v == 0 || (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH && cwbvh_variant_valid(v));
+    // ... and a BVH_GPU scene one: 1 = trace the uploaded 2-wide nodes with k_bvh2 even when the scene has an 8-wide copy (tests, A/B)
+    const bool ok = v == 0 || (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH && cwbvh_variant_valid(v)) || (!s->isTlas && s->layout == TBVH_LAYOUT_BVH_GPU && v == 1);
     if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
     s->variant = v;
     return 0;

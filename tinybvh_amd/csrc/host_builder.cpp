@@ -1030,6 +1030,70 @@ bool cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>
 // ---- not a wild read on the device ----------------------------------------------------------
 namespace tbvh {
 
+bool bvh_gpu_to_bvh2(const NodeAL* al, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx, const Vec4* verts, uint64_t nTris, uint32_t maxLeafTris,
+                     std::vector<Node2>& out) {
+    out.clear();
+    if (!nNodes || al[0].triCount) return false;
+    out.reserve(nNodes + nNodes / 4 + 2);
+    out.resize(2);                                  // root = 0; slot 1 stays unused so that siblings sit at (even, odd) like the reference's array (tiny_bvh.h:2277)
+    std::memset(out.data(), 0, 2 * sizeof(Node2));
+    for (int k = 0; k < 3; k++) {
+        out[0].mn[k] = std::min(al[0].lmin[k], al[0].rmin[k]);
+        out[0].mx[k] = std::max(al[0].lmax[k], al[0].rmax[k]);
+    }
+    struct Item { uint32_t src, dst; bool leafRange; uint32_t first, count; };
+    std::vector<Item> stack;
+    stack.push_back(Item{0u, 0u, false, 0u, 0u});
+    auto range_box = [&](uint32_t first, uint32_t count, const Node2& clip, Node2& n) {
+        float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+        for (uint32_t i = first; i < first + count; i++) {
+            const uint32_t p = i < nIdx ? primIdx[i] : 0xffffffffu;
+            if (p >= nTris) continue;               // slack entries of an SBVH primIdx array
+            for (int v = 0; v < 3; v++) {
+                const Vec4& q = verts[(uint64_t)p * 3 + v];
+                const float c[3] = {q.x, q.y, q.z};
+                for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], c[k]); mx[k] = std::max(mx[k], c[k]); }
+            }
+        }
+        for (int k = 0; k < 3; k++) {
+            n.mn[k] = std::max(mn[k], clip.mn[k]); n.mx[k] = std::min(mx[k], clip.mx[k]);
+            if (!(n.mn[k] <= n.mx[k])) { n.mn[k] = clip.mn[k]; n.mx[k] = clip.mx[k]; }   // (nothing valid inside: keep the leaf's box, conservative)
+        }
+    };
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        uint32_t first = it.first, count = it.count;
+        if (!it.leafRange) {
+            const NodeAL& a = al[it.src];
+            if (!a.triCount) {
+                const uint32_t c = (uint32_t)out.size();
+                out.resize(out.size() + 2);
+                out[it.dst].leftFirst = c; out[it.dst].triCount = 0;
+                for (int k = 0; k < 3; k++) {
+                    out[c].mn[k] = a.lmin[k]; out[c].mx[k] = a.lmax[k];
+                    out[c + 1].mn[k] = a.rmin[k]; out[c + 1].mx[k] = a.rmax[k];
+                }
+                out[c].leftFirst = out[c].triCount = out[c + 1].leftFirst = out[c + 1].triCount = 0;
+                stack.push_back(Item{a.right, c + 1, false, 0u, 0u});
+                stack.push_back(Item{a.left, c, false, 0u, 0u});
+                continue;
+            }
+            first = a.firstTri; count = a.triCount;
+        }
+        if (count <= maxLeafTris) { out[it.dst].leftFirst = first; out[it.dst].triCount = count; continue; }
+        const uint32_t c = (uint32_t)out.size(), half = count / 2;
+        out.resize(out.size() + 2);
+        const Node2 clip = out[it.dst];
+        out[it.dst].leftFirst = c; out[it.dst].triCount = 0;
+        out[c].leftFirst = out[c].triCount = out[c + 1].leftFirst = out[c + 1].triCount = 0;
+        range_box(first, half, clip, out[c]);
+        range_box(first + half, count - half, clip, out[c + 1]);
+        stack.push_back(Item{0u, c + 1, true, first + half, count - half});
+        stack.push_back(Item{0u, c, true, first, half});
+    }
+    return true;
+}
+
 static const char* validate_bvh_gpu_impl(const NodeAL* n, uint64_t nNodes, uint64_t nIdx) {
     if (nNodes == 0) return "BVH_GPU: empty node array";
     for (uint64_t i = 0; i < nNodes; i++) {

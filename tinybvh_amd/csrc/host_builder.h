@@ -62,6 +62,14 @@ void encode_bvh4_gpu(const BVH2& bvh, const Vec4* verts, const BuildParams& p, s
 void encode_cwbvh(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std::vector<Vec4>& nodeBlocks,
                   std::vector<Vec4>& triBlocks);
 
+// An uploaded BVH_GPU blob (Aila-Laine nodes: every node carries its CHILDREN's boxes, tiny_bvh.h:1095-1105) as a BVH2 in the Wald layout the wide
+// converters take (kernels_convert.hip), leaves cut down to maxLeafTris entries (the SplitLeafs( 3 ) step of BVH8_CWBVH::Build, tiny_bvh.h:5831,
+// here by halving a leaf's primIdx range: the order of the entries is kept, primIdx is shared with the blob).  A half's box = the bounds of its
+// triangles CLIPPED to the leaf's box, so the leaves of an SBVH (BuildHQ: spatial splits, boxes smaller than their triangles) stay as tight as
+// they were.  false: the root is a leaf (nothing to collapse).
+bool bvh_gpu_to_bvh2(const NodeAL* al, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx, const Vec4* verts, uint64_t nTris, uint32_t maxLeafTris,
+                     std::vector<Node2>& out);
+
 // CWBVH nodes (5 x Vec4 each) in surface-area priority order: newIdx[old] = new; see host_builder.cpp.
 bool cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>& newIdx);   // false: not a strict tree, no numbering
 
