@@ -233,10 +233,14 @@ int tbvh_intersect(tbvh_scene* scene, void* rays, uint64_t n_rays, uint32_t stri
  * (BVH::IsOccluded, tiny_bvh.h:3382-3453; isoccluded_* in the .cl files). */
 int tbvh_occluded(tbvh_scene* scene, const void* rays, uint64_t n_rays,
                   uint32_t stride_bytes, uint8_t* occluded);
-/* Host arrays of 32 k rays and more are pipelined in groups of ~4 M rays: host threads pack group g + 1 into pinned buffers while the link
+/* Host arrays of more than 16 k rays are pipelined in groups of ~1 M rays: host threads pack group g + 1 into pinned buffers while the link
  * carries it up, the device traces group g, a second stream carries its 20 result bytes per ray down (full duplex) and the host scatters
- * group g - 1's results into the caller's records; 16.7 M tinybvh::Ray records: bench.py detail.host_rays.  TBVH_HOST_THREADS = host threads
- * used (default: every core the process may use, up to 16).  tbvh_time_last_ms then reports the sum of the groups' kernel times.
+ * group g - 1's results into the caller's records (smaller batches: two strided copies around one launch, no threads).  TBVH_HOST_THREADS =
+ * host threads used (default: every core the process may use, up to 16).  tbvh_time_last_ms then reports the sum of the groups' kernel times.
+ * WHAT TO EXPECT: a host array is bound by the HOST, not by the GPU — 16.7 M pageable tinybvh::Ray records cost ~6 GB of host memory traffic
+ * per call (pack + scatter) next to 1.4 GB on the link, and run at 0.3-0.75 of the link rate depending on the box's cores and memory
+ * (220-500 MRays/s measured on 16-core MI355X hosts) against 5-7 GRays/s for device-resident rays.  A caller that traces a batch more than once, or
+ * can generate its rays where it likes, should use tbvh_pinned_malloc below (packed rays: 0.85 of the link rate) or the device entry points.
  *
  * The tinyocl::Buffer( bytes ) of this boundary (a Buffer made without a host pointer owns its host side, tiny_ocl.h; tiny_bvh_speedtest.cpp:1101-1108
  * wraps its ray array in one before every GPU block): tbvh_pinned_malloc hands out page-locked host memory.  A PACKED (64-byte stride) ray array that lives

@@ -36,6 +36,7 @@ class WfStats(C.Structure):
 
 
 SYMBOLS = {
+    "tbvh_debug_wide_copy_bvh2": (_i, [_i, _vp, _u64, _vp, _u64, _vp, _u64, _u32, _vp, _u64, C.POINTER(_u64), _vp, _u64, C.POINTER(_u64)]),
     "tbvh_wavefront_create": (_i, [_vp, _u32, _u32, _pp]),
     "tbvh_wavefront_destroy": (None, [_vp]),
     "tbvh_wavefront_render": (_i, [_vp, _vp, _vp, C.POINTER(Camera), C.POINTER(WfParams), C.POINTER(WfStats)]),

@@ -197,4 +197,27 @@ int tbvh_upload_host(tbvh_context* c, const tbvh_hostbvh* h, const void* verts16
     return fail(TBVH_E_INVALID, "layout %d cannot be uploaded", h->layout);
 }
 
+int tbvh_debug_wide_copy_bvh2(int layout, const void* blob, uint64_t nBlob, const uint32_t* primIdx, uint64_t nIdx, const void* verts16, uint64_t nTris,
+                              uint32_t maxLeaf, void* nodesOut, uint64_t capNodes, uint64_t* nNodesOut, void* recsOut, uint64_t capRecs, uint64_t* nRecsOut) {
+    if (!blob || !nBlob || !maxLeaf) return fail(TBVH_E_INVALID, "tbvh_debug_wide_copy_bvh2: null/empty argument");
+    std::vector<Node2> n2;
+    std::vector<Vec4> recs;
+    try {
+        if (layout == TBVH_LAYOUT_BVH_GPU) {
+            if (!primIdx || !verts16) return fail(TBVH_E_INVALID, "tbvh_debug_wide_copy_bvh2: BVH_GPU needs prim_idx and verts16");
+            if (const char* why = validate_bvh_gpu((const NodeAL*)blob, nBlob, nIdx)) return fail(TBVH_E_FORMAT, "%s", why);
+            if (!bvh_gpu_to_bvh2((const NodeAL*)blob, nBlob, primIdx, nIdx, (const Vec4*)verts16, nTris, maxLeaf, n2)) return fail(TBVH_E_FORMAT, "the root is a leaf");
+        } else if (layout == TBVH_LAYOUT_BVH4_GPU) {
+            if (const char* why = validate_bvh4_gpu((const Vec4*)blob, nBlob)) return fail(TBVH_E_FORMAT, "%s", why);
+            if (!bvh4_gpu_to_bvh2((const Vec4*)blob, nBlob, maxLeaf, n2, recs)) return fail(TBVH_E_FORMAT, "the root is a leaf or the stream is malformed");
+        } else return fail(TBVH_E_INVALID, "tbvh_debug_wide_copy_bvh2: layout %d (BVH_GPU 5 and BVH4_GPU 8 have wide copies)", layout);
+    } catch (const std::bad_alloc&) { return fail(TBVH_E_NOMEM, "out of host memory"); }
+    if (nNodesOut) *nNodesOut = n2.size();
+    if (nRecsOut) *nRecsOut = recs.size() / 3;
+    if ((nodesOut && capNodes < n2.size()) || (recsOut && capRecs < recs.size() / 3)) return fail(TBVH_E_INVALID, "tbvh_debug_wide_copy_bvh2: output capacity too small");
+    if (nodesOut) std::memcpy(nodesOut, n2.data(), n2.size() * sizeof(Node2));
+    if (recsOut && !recs.empty()) std::memcpy(recsOut, recs.data(), recs.size() * sizeof(Vec4));
+    return 0;
+}
+
 }  // extern "C"

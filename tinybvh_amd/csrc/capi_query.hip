@@ -47,7 +47,7 @@ int ensurePipe(tbvh_context* c, uint64_t nHits) {
         c->pipe = p.release();
     }
     HostPipe* p = c->pipe;
-    if (p->packedCap < nHits) {
+    if (p->packedCap < nHits) {   // nHits: 20-byte result records the two buffers must hold (two groups of a closest-hit batch, or an any-hit batch's flags)
         HIP_TRY(hipStreamSynchronize(p->down));
         if (p->packed) hipFree(p->packed);
         if (p->pinDown) hipHostFree(p->pinDown);
@@ -75,27 +75,45 @@ static bool isPinned(tbvh_context* c, const void* p, uint64_t bytes) {
 // reading / writing the caller's pinned array itself (a 128-byte record costs a 128-byte read for its 64 useful bytes: 27 GB/s; 20-byte writes
 // cost a 64-byte line each: 20 GB/s of results).  A packed (64-byte) array in page-locked memory of the library's (tbvh_pinned_malloc) needs no packing: it goes up
 // by DMA straight from there.
-constexpr uint64_t kGroupRays = 4ull << 20;
+// Groups of ~1 M rays (round 6; 4 M before): the first group's packing and the last group's scatter overlap with nothing, so the smaller the group
+// the shorter the pipeline's fill and drain (~3 ms each of a 34 ms call at 4 M); a 1 M-ray launch still runs at > 3 GRays/s, far above the link.
+// The result buffers (device: packed hits, host: pinned) hold TWO groups and are used alternately — group g's results land in one while the host
+// scatters group g - 1 out of the other (16.7 M rays: 2 x 21 MB page-locked where the whole batch took 335 MB).
+constexpr uint64_t kGroupRays = 1ull << 20;
+constexpr uint64_t kDirectRays = 16384;   // batches up to this size skip the pipeline (no worker threads, no pinned ring): two strided copies around the launch
 
-int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint32_t stride, uint8_t* occ) {
+// a small host batch: strided copy up, launch, strided copy of bytes 44..63 back; synchronous
+static int hostQuerySmall(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint32_t stride, uint8_t* occ) {
     tbvh_context* c = s->ctx;
     if (int r = ensureStage(c, n)) return r;
     if (occ) if (int r = ensureStageOcc(c, n)) return r;
-    if (int r = ensurePipe(c, occ ? (n + 19) / 20 : n)) return r;   // (the pinned result buffer: 20 bytes per closest-hit record, 1 per any-hit flag)
-    HostPipe* p = c->pipe;
-    const bool direct = stride == 64 && isPinned(c, raysIn, n * 64);
+    HIP_TRY(hipMemcpy2DAsync(c->stageRays, 64, raysIn, stride, 64, n, hipMemcpyHostToDevice, c->stream));
+    if (int r = launchQuery(s, c->stageRays, n, occ ? c->stageOcc : nullptr)) return r;
+    if (occ) HIP_TRY(hipMemcpyAsync(occ, c->stageOcc, n, hipMemcpyDeviceToHost, c->stream));
+    else HIP_TRY(hipMemcpy2DAsync(raysOut + 44, stride, (const char*)c->stageRays + 44, 64, 20, n, hipMemcpyDeviceToHost, c->stream));
+    return checkStatus(c);   // (synchronizes the stream)
+}
+
+int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint32_t stride, uint8_t* occ) {
+    tbvh_context* c = s->ctx;
+    if (n <= kDirectRays) return hostQuerySmall(s, raysIn, raysOut, n, stride, occ);
+    if (int r = ensureStage(c, n)) return r;
+    if (occ) if (int r = ensureStageOcc(c, n)) return r;
     const uint64_t G = n <= kGroupRays + kGroupRays / 2 ? 1 : (n + kGroupRays - 1) / kGroupRays;
     const uint64_t per = (((n + G - 1) / G) + HostPipe::kChunk - 1) / HostPipe::kChunk * HostPipe::kChunk;
+    if (int r = ensurePipe(c, occ ? (n + 19) / 20 : 2 * per)) return r;   // (two groups of 20-byte closest-hit records, or one byte per any-hit flag)
+    HostPipe* p = c->pipe;
+    const bool direct = stride == 64 && isPinned(c, raysIn, n * 64);
     while (p->evGroup.size() < G) { hipEvent_t e = nullptr; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); p->evGroup.push_back(e); }
     const uint64_t seq0 = c->evSeq;
     uint64_t chunkNo = 0;
     auto drain = [&](uint64_t g) -> int {   // group g's results into the caller's records
         const uint64_t b = g * per, e = b + per < n ? b + per : n;
         HIP_TRY(hipEventSynchronize(p->evGroup[g]));
-        const char* pin = (const char*)p->pinDown;
+        const char* pin = (const char*)p->pinDown + (g & 1) * per * 20;
         p->parallel_for(e - b, [=](uint32_t part, uint32_t parts) {
-            const uint64_t lo = b + (e - b) * part / parts, hi = b + (e - b) * (part + 1) / parts;
-            for (uint64_t i = lo; i < hi; i++) std::memcpy(raysOut + i * stride + 44, pin + i * 20, 20);
+            const uint64_t lo = (e - b) * part / parts, hi = (e - b) * (part + 1) / parts;
+            for (uint64_t i = lo; i < hi; i++) std::memcpy(raysOut + (b + i) * stride + 44, pin + i * 20, 20);
         });
         return 0;
     };
@@ -118,11 +136,13 @@ int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint
         }
         if (int r = launchQuery(s, c->stageRays + b, e - b, occ ? c->stageOcc + b : nullptr)) return r;
         if (!occ) {
+            // (the half of the result buffers this group uses was last read by drain(g - 2), which returned before this point was reached)
+            uint32_t* packed = p->packed + (g & 1) * per * 5;
             HIP_TRY(hipEventRecord(p->evKernel, c->stream));
             HIP_TRY(hipStreamWaitEvent(p->down, p->evKernel, 0));
-            launch_pack_hits(c->stageRays + b, p->packed + b * 5, e - b, p->down);
+            launch_pack_hits(c->stageRays + b, packed, e - b, p->down);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipMemcpyAsync((char*)p->pinDown + b * 20, p->packed + b * 5, (e - b) * 20, hipMemcpyDeviceToHost, p->down));
+            HIP_TRY(hipMemcpyAsync((char*)p->pinDown + (g & 1) * per * 20, packed, (e - b) * 20, hipMemcpyDeviceToHost, p->down));
             HIP_TRY(hipEventRecord(p->evGroup[g], p->down));
             if (g) if (int r = drain(g - 1)) return r;
         }
@@ -165,7 +185,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.omm = Omm{s->opmap, s->opmapN};
     q.probe = nullptr; q.baseBlocks = 0; q.hybridK = s->hybridK; q.flags = 0u;
 #ifdef TBVH_EXPERIMENTS
-    q.flags = c->expFlags & 0xF30001u;
+    q.flags = c->expFlags & 0xF70001u;
 #endif
     c->lastProbed = false;
     q.splitBelow = c->splitBelow;

@@ -118,6 +118,36 @@ static int makeWideCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, con
     return 0;
 }
 
+// ... and of an uploaded BVH4_GPU stream: decoded on the host into a BVH2 over the dequantised child boxes and the inline triangle records as they are
+// (host_builder.cpp: bvh4_gpu_to_bvh2), converted in the converter's record mode.  Same threshold (counted in triangles), same "never an error".
+static int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris, tbvh_scene** out);
+static int makeWideCopy4(tbvh_scene* s, const void* blocks16, uint64_t nBlocks) {
+    tbvh_context* c = s->ctx;
+    freeWideCopy(s);
+    uint64_t minIdx = 32768;
+    if (const char* e = getenv("TBVH_WIDE_COPY_MIN")) { const long long v = atoll(e); minIdx = v <= 0 ? ~0ull : (uint64_t)v; }
+    if (nBlocks / 4 < minIdx || nBlocks > 0x7fffffffull) return 0;   // (a stream of n triangles has at least 3 n blocks: a cheap first cut)
+    std::vector<Node2> n2;
+    std::vector<Vec4> recs;
+    try {
+        if (!bvh4_gpu_to_bvh2((const Vec4*)blocks16, nBlocks, 3u, n2, recs)) return 0;
+    } catch (const std::bad_alloc&) { return 0; }
+    const uint64_t nRecs = recs.size() / 3;
+    if (nRecs < minIdx || nRecs > 0x7fffffffull || n2.size() > 0x7fffffffull) return 0;
+    struct Tmp { void *n2 = nullptr, *r = nullptr; ~Tmp() { if (n2) hipFree(n2); if (r) hipFree(r); } } t;
+    if (hipMalloc(&t.n2, n2.size() * 32) != hipSuccess || hipMalloc(&t.r, recs.size() * 16) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (hipMemcpyAsync(t.n2, n2.data(), n2.size() * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(t.r, recs.data(), recs.size() * 16, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    tbvh_scene* w = nullptr;
+    if (convertDeviceImpl(c, TBVH_LAYOUT_CWBVH, (const float4*)t.n2, n2.size(), nullptr, nRecs, (const float4*)t.r, nRecs, &w) != 0 || !w) return 0;
+    for (size_t i = 0; i < c->scenes.size(); i++)
+        if (c->scenes[i] == w) { c->scenes.erase(c->scenes.begin() + i); break; }
+    w->opmap = s->opmap; w->opmapN = s->opmapN;
+    s->wide = w;
+    s->bytes += w->bytes;
+    return 0;
+}
+
 }  // namespace tbvh_capi
 
 extern "C" {
@@ -163,6 +193,7 @@ int tbvh_upload_bvh4_gpu(tbvh_context* c, const void* blocks16, uint64_t nBlocks
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH4_GPU upload failed: %s", hipGetErrorString(e)); }
     s->nNodeBlocks = nBlocks; s->capNodeBlocks = nBlocks; s->bytes = nBlocks * 16;
+    makeWideCopy4(s, blocks16, nBlocks);
     *out = s;
     return 0;
 }
@@ -342,6 +373,7 @@ int tbvh_update_bvh4_gpu(tbvh_scene* s, const void* blocks16, uint64_t nBlocks) 
     s->nNodeBlocks = nBlocks;
     s->b4Levels.clear();   // (the node list of a device refit is rebuilt by the next tbvh_refit)
     if (s->refitScratch) { hipFree(s->refitScratch); s->refitScratch = nullptr; }
+    makeWideCopy4(s, blocks16, nBlocks);   // (the tree may have changed: decoded and collapsed again)
     return 0;
 }
 
@@ -413,7 +445,9 @@ int convertDeviceImpl4(tbvh_context* c, const float4* dN2, uint64_t nNodes2, con
     return 0;
 }
 
-int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris,
+}  // namespace
+namespace tbvh_capi {
+static int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris,
                       tbvh_scene** out) {
     if (layout == TBVH_LAYOUT_BVH4_GPU) return convertDeviceImpl4(c, dN2, nNodes2, dIdx, nIdx, dV, nTris, out);
     struct Tmp {
@@ -612,6 +646,7 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
         HIP_TRY(timedBegin(c));
         HIP_TRY(run_refit_bvh4(s->nodes, s->nNodeBlocks, dv4, nTris, items, capNodes, counter, childBox, s->b4Levels, c->status, c->stream));
         HIP_TRY(timedEnd(c));
+        if (s->wide) return tbvh_refit(s->wide, dv4, nTris, 1);   // the 8-wide copy follows
         return 0;
     }
     if (s->layout != TBVH_LAYOUT_CWBVH && s->layout != TBVH_LAYOUT_BVH_GPU)
@@ -785,8 +820,8 @@ int tbvh_set_variant(tbvh_scene* s, int v) {
     if (!s) return fail(TBVH_E_INVALID, "null scene");
     TBVH_LOCK(s->ctx);
     // only the BVH8_CWBVH kernel keeps diagnostic variants (kernels_cwbvh.hip: forced schedules, instrumented kernels)
-    // ... and a BVH_GPU scene one: 1 = trace the uploaded 2-wide nodes with k_bvh2 even when the scene has an 8-wide copy (tests, A/B)
-    const bool ok = v == 0 || (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH && cwbvh_variant_valid(v)) || (!s->isTlas && s->layout == TBVH_LAYOUT_BVH_GPU && v == 1);
+    // ... and BVH_GPU / BVH4_GPU scenes one: 1 = trace the nodes as uploaded (k_bvh2 / k_bvh4) even when the scene has an 8-wide copy (tests, A/B)
+    const bool ok = v == 0 || (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH && cwbvh_variant_valid(v)) || (!s->isTlas && (s->layout == TBVH_LAYOUT_BVH_GPU || s->layout == TBVH_LAYOUT_BVH4_GPU) && v == 1);
     if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
     s->variant = v;
     return 0;

@@ -1094,6 +1094,137 @@ bool bvh_gpu_to_bvh2(const NodeAL* al, uint64_t nNodes, const uint32_t* primIdx,
     return true;
 }
 
+bool bvh4_gpu_to_bvh2(const Vec4* b, uint64_t nBlocks, uint32_t maxLeafTris, std::vector<Node2>& out, std::vector<Vec4>& recs) {
+    out.clear(); recs.clear();
+    if (nBlocks < 4) return false;
+    auto u32 = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    auto down = [](float x) { return std::nextafter(std::nextafter(x, -INFINITY), -INFINITY); };
+    auto up = [](float x) { return std::nextafter(std::nextafter(x, INFINITY), INFINITY); };
+    struct Child { float mn[3], mx[3]; uint32_t info; };
+    // the children of the 4-wide node at block offset o, with their boxes as the kernels evaluate them: bmin + q * (ext / 255)
+    auto children = [&](uint32_t o, Child* c) -> int {
+        const Vec4 d0 = b[o], d1 = b[o + 1], d2 = b[o + 2], d3 = b[o + 3];
+        const uint32_t q[6] = {u32(d0.w), u32(d2.x), u32(d2.z), u32(d1.w), u32(d2.y), u32(d2.w)};   // xmin, ymin, zmin, xmax, ymax, zmax: four bytes each
+        const float bmin[3] = {d0.x, d0.y, d0.z}, sc[3] = {d1.x, d1.y, d1.z};
+        const uint32_t info[4] = {u32(d3.x), u32(d3.y), u32(d3.z), u32(d3.w)};
+        int n = 0;
+        for (int i = 0; i < 4; i++) {
+            if (!info[i] || ((info[i] & 0x80000000u) && ((info[i] >> 16) & 0x7fffu) == 0u)) continue;   // empty slot / empty leaf
+            Child& k = c[n++];
+            k.info = info[i];
+            for (int a = 0; a < 3; a++) {
+                // the plane bmin + q * scale in float: its rounding error is an ulp of the LARGER operand (the sum may cancel to nearly zero), so the pad is two
+                // ulps of that magnitude, not of the result
+                const float pl = (float)((q[a] >> (8 * i)) & 255u) * sc[a], ph = (float)((q[3 + a] >> (8 * i)) & 255u) * sc[a];
+                const float lo = bmin[a] + pl, hi = bmin[a] + ph;
+                const float ml = std::max(std::fabs(bmin[a]), std::max(std::fabs(pl), std::fabs(lo))), mh = std::max(std::fabs(bmin[a]), std::max(std::fabs(ph), std::fabs(hi)));
+                k.mn[a] = down(lo - ml * 2.4e-7f);
+                k.mx[a] = up(hi + mh * 2.4e-7f);
+            }
+        }
+        return n;
+    };
+    out.resize(2);
+    std::memset(out.data(), 0, 2 * sizeof(Node2));
+    struct Item { uint32_t dst; int kind; uint32_t a, b_; };   // kind 0: 4-wide node at block a; 1: leaf run of b_ triangles at block a; 2: record range [a, a + b_)
+    std::vector<Item> stack;
+    auto set_box = [&](uint32_t i, const float* mn, const float* mx) { for (int k = 0; k < 3; k++) { out[i].mn[k] = mn[k]; out[i].mx[k] = mx[k]; } };
+    auto pair = [&]() { const uint32_t c = (uint32_t)out.size(); out.resize(out.size() + 2); std::memset(&out[c], 0, 2 * sizeof(Node2)); return c; };
+    auto push_child = [&](uint32_t dst, const Child& k, uint32_t nodeOff) {
+        set_box(dst, k.mn, k.mx);
+        if (k.info & 0x80000000u) stack.push_back(Item{dst, 1, nodeOff + (k.info & 0xffffu), (k.info >> 16) & 0x7fffu});
+        else stack.push_back(Item{dst, 0, k.info, 0u});
+    };
+    auto unite = [&](const Child& x, const Child& y, Child& r) { for (int k = 0; k < 3; k++) { r.mn[k] = std::min(x.mn[k], y.mn[k]); r.mx[k] = std::max(x.mx[k], y.mx[k]); } r.info = 0; };
+    {   // the root's own box: the union of its children
+        Child c[4];
+        if ((uint64_t)0 + 4 > nBlocks) return false;
+        const int n = children(0, c);
+        if (n == 0) return false;
+        Child all = c[0];
+        for (int i = 1; i < n; i++) unite(all, c[i], all);
+        set_box(0, all.mn, all.mx);
+        if (n == 1 && (c[0].info & 0x80000000u)) return false;   // a single leaf: nothing to collapse
+    }
+    stack.push_back(Item{0u, 0, 0u, 0u});
+    uint64_t guard = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back(); stack.pop_back();
+        if (++guard > nBlocks * 4 + 16) return false;           // (validated streams are trees; belt and braces)
+        if (it.kind == 0) {
+            if ((uint64_t)it.a + 4 > nBlocks) return false;
+            Child c[4];
+            const int n = children(it.a, c);
+            if (n == 0) { out[it.dst].leftFirst = 0; out[it.dst].triCount = 0; return false; }
+            if (n == 1) {   // one child: this binary node IS that child (its box stays the tighter of the two: the child's)
+                Child k = c[0];
+                for (int a = 0; a < 3; a++) { k.mn[a] = std::max(k.mn[a], out[it.dst].mn[a]); k.mx[a] = std::min(k.mx[a], out[it.dst].mx[a]); if (!(k.mn[a] <= k.mx[a])) { k.mn[a] = c[0].mn[a]; k.mx[a] = c[0].mx[a]; } }
+                push_child(it.dst, k, it.a);
+                continue;
+            }
+            const uint32_t p = pair();
+            out[it.dst].leftFirst = p; out[it.dst].triCount = 0;
+            if (n == 2) { push_child(p, c[0], it.a); push_child(p + 1, c[1], it.a); }
+            else {
+                // ((0, 1), 2) or ((0, 1), (2, 3)): slot order is the encoder's distance order along an axis, so neighbours in it are neighbours in space
+                Child l; unite(c[0], c[1], l);
+                set_box(p, l.mn, l.mx);
+                const uint32_t pl = pair();
+                out[p].leftFirst = pl; out[p].triCount = 0;
+                push_child(pl, c[0], it.a); push_child(pl + 1, c[1], it.a);
+                if (n == 3) push_child(p + 1, c[2], it.a);
+                else {
+                    Child r; unite(c[2], c[3], r);
+                    set_box(p + 1, r.mn, r.mx);
+                    const uint32_t pr = pair();
+                    out[p + 1].leftFirst = pr; out[p + 1].triCount = 0;
+                    push_child(pr, c[2], it.a); push_child(pr + 1, c[3], it.a);
+                }
+            }
+            continue;
+        }
+        uint32_t first = it.a, count = it.b_;
+        if (it.kind == 1) {   // gather the run's records; from here on the leaf is a range of `recs`
+            if ((uint64_t)it.a + 3ull * count > nBlocks) return false;
+            first = (uint32_t)(recs.size() / 3);
+            recs.insert(recs.end(), b + it.a, b + it.a + 3ull * count);
+        }
+        if (count <= maxLeafTris) { out[it.dst].leftFirst = first; out[it.dst].triCount = count; continue; }
+        const uint32_t p = pair(), half = count / 2;
+        const Node2 clip = out[it.dst];
+        out[it.dst].leftFirst = p; out[it.dst].triCount = 0;
+        for (int h = 0; h < 2; h++) {
+            const uint32_t f = h ? first + half : first, n = h ? count - half : half;
+            float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+            for (uint32_t i = f; i < f + n; i++) {
+                const Vec4 &v0 = recs[3 * (size_t)i], &e1 = recs[3 * (size_t)i + 1], &e2 = recs[3 * (size_t)i + 2];
+                const float A[3] = {v0.x, v0.y, v0.z}, E1[3] = {e1.x, e1.y, e1.z}, E2[3] = {e2.x, e2.y, e2.z};
+                for (int k = 0; k < 3; k++) {   // the corners v0, v0 + e1, v0 + e2, each padded by two ulps of the larger operand (as above)
+                    const float m = std::max(std::fabs(A[k]), std::max(std::fabs(E1[k]), std::fabs(E2[k]))) * 2.4e-7f;
+                    const float c0 = A[k], c1 = A[k] + E1[k], c2 = A[k] + E2[k];
+                    mn[k] = std::min(mn[k], down(std::min(c0, std::min(c1, c2)) - m));
+                    mx[k] = std::max(mx[k], up(std::max(c0, std::max(c1, c2)) + m));
+                }
+            }
+            Node2& c = out[p + h];
+            for (int k = 0; k < 3; k++) {
+                c.mn[k] = std::max(mn[k], clip.mn[k]); c.mx[k] = std::min(mx[k], clip.mx[k]);
+                if (!(c.mn[k] <= c.mx[k])) { c.mn[k] = clip.mn[k]; c.mx[k] = clip.mx[k]; }
+            }
+            stack.push_back(Item{p + (uint32_t)h, 2, f, n});
+        }
+    }
+    // every level of the source rounded its children on a grid of its own, so a child may reach an ulp beyond the box its parent stored for it: make the
+    // boxes nest (children are allocated after their parent, so one sweep from the back sees every child before its parent)
+    for (size_t k = out.size(); k-- > 0;) {
+        Node2& n = out[k];
+        if (n.triCount || k == 1) continue;
+        const Node2 &l = out[n.leftFirst], &r = out[n.leftFirst + 1];
+        for (int a = 0; a < 3; a++) { n.mn[a] = std::min(n.mn[a], std::min(l.mn[a], r.mn[a])); n.mx[a] = std::max(n.mx[a], std::max(l.mx[a], r.mx[a])); }
+    }
+    return true;
+}
+
 static const char* validate_bvh_gpu_impl(const NodeAL* n, uint64_t nNodes, uint64_t nIdx) {
     if (nNodes == 0) return "BVH_GPU: empty node array";
     for (uint64_t i = 0; i < nNodes; i++) {

@@ -70,6 +70,11 @@ void encode_cwbvh(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std:
 bool bvh_gpu_to_bvh2(const NodeAL* al, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx, const Vec4* verts, uint64_t nTris, uint32_t maxLeafTris,
                      std::vector<Node2>& out);
 
+// The same for an uploaded BVH4_GPU stream (tiny_bvh.h:1248-1266, 5115-5244): every 4-wide node becomes one to three binary nodes over its children's
+// DEQUANTISED boxes (padded outward by two ulps: they only cull), leaves of at most maxLeafTris entries index `recs`, the blob's inline triangle
+// records {v0|prim, e1, e2} gathered in depth-first order (the converter copies them as they are: kernels_convert.hip, record mode).
+bool bvh4_gpu_to_bvh2(const Vec4* blocks, uint64_t nBlocks, uint32_t maxLeafTris, std::vector<Node2>& out, std::vector<Vec4>& recs);
+
 // CWBVH nodes (5 x Vec4 each) in surface-area priority order: newIdx[old] = new; see host_builder.cpp.
 bool cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>& newIdx);   // false: not a strict tree, no numbering
 

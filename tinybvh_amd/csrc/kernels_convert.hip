@@ -107,6 +107,13 @@ __global__ void k_convert_level(const float4* __restrict__ nodes2, uint32_t nNod
             meta[s] = (uint8_t)((unary << 5) | tris);
             for (uint32_t j = 0; j < c.triCount; j++) {
                 const uint64_t pi = (uint64_t)c.leftFirst + j;
+                if (!primIdx) {   // RECORD MODE (the 8-wide copy of a BVH4_GPU blob, capi_scene.hip): `verts` holds finished records {v0|prim, e1, e2}, one per leaf entry — the
+                                  // bytes the blob's own inline triangles carry; recomputing e1 = v1 - v0 from v1 = v0 + e1 would not give them back
+                    if (pi >= nTris) { atomicOr(status, 4u); continue; }
+                    float4* o = cwTris + 3 * (uint64_t)(triFirst + tris + j);
+                    o[0] = verts[3 * pi + 2]; o[1] = verts[3 * pi + 1]; o[2] = verts[3 * pi];
+                    continue;
+                }
                 const uint32_t prim = pi < nIdx ? primIdx[pi] : 0xffffffffu;
                 if (prim >= nTris) { atomicOr(status, 4u); continue; }
                 const float4 v0 = verts[3 * (uint64_t)prim], v1 = verts[3 * (uint64_t)prim + 1], v2 = verts[3 * (uint64_t)prim + 2];
@@ -120,7 +127,12 @@ __global__ void k_convert_level(const float4* __restrict__ nodes2, uint32_t nNod
     }
     const uint32_t m0 = meta[0] | (meta[1] << 8) | (meta[2] << 16) | ((uint32_t)meta[3] << 24);
     const uint32_t m1 = meta[4] | (meta[5] << 8) | (meta[6] << 16) | ((uint32_t)meta[7] << 24);
-    cw_quantize_write(cwNodes + (size_t)item.y * 5, self.mn, self.mx, cmn, cmx, used, imask, childBase, triFirst * 3u, m0, m1);
+    // the node's frame = its own box united with its children's: the same box for a well-formed BVH2; for one derived from quantised boxes (the 8-wide
+    // copy of a BVH4_GPU stream: every level of the source was rounded on its own grid) a child may reach an ulp beyond its parent's stored box, and the
+    // quantiser would clip what lies below the frame's origin — a box a grazing ray then misses
+    float3 fmn = self.mn, fmx = self.mx;
+    for (int s = 0; s < 8; s++) if (used[s]) { fmn = min3(fmn, cmn[s]); fmx = max3(fmx, cmx[s]); }
+    cw_quantize_write(cwNodes + (size_t)item.y * 5, fmn, fmx, cmn, cmx, used, imask, childBase, triFirst * 3u, m0, m1);
 }
 
 

@@ -390,6 +390,9 @@ const LaunchRow kLaunchTable[] = {
     // round 5: up to two triangle tests per pass (debug flag 0x10000): -13 % on bounce rays (profiles/r05_ab_tri2.txt), not shipped
     {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x10000u) && x.tail; }, &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 16, 6, 1>, false},
     {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x10000u) != 0; },      &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 0, 6, 1>, false},
+    // round 6: the ray-replacement threshold of the incoherent flavor (debug flags 0x20000: 8 idle lanes, 0x40000: 32; shipped: 16) — profiles/r06_diffuse.txt
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x20000u) && !x.tail; }, &launch_both<8, 8, 1, false, 0, kNodeHybrid, 2>, false},
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x40000u) && !x.tail; }, &launch_both<8, 32, 1, false, 0, kNodeHybrid, 2>, false},
 #endif
     // the incoherent flavor of a probed launch: `nodes` = the hybrid copy, `tris` = the 64-byte records (cwbvh_node.h, capi_query.hip);
     // with split rays built for 6 waves per SIMD (80 VGPRs; left alone the compiler takes 83, one wave per SIMD fewer)
