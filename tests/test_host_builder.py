@@ -262,6 +262,41 @@ def test_split_triangles_reduce_box_area_of_long_diagonal_triangles():
     assert counts[20_000:].min() > 8 and (counts[:20_000] > 1).mean() < 0.25   # the budget goes to the long triangles
 
 
+@pytest.mark.parametrize("layout", [tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU])
+def test_deeply_split_slivers_keep_their_hits_in_float_box_layouts(oracle, layout):
+    """The float-box layouts (no outward quantisation to hide behind) with the largest split budget on long thin diagonal triangles: every triangle is cut
+    dozens of levels deep, each level clipping a polygon of already-rounded points; the boxes of the pieces (padded by depth, host_builder.cpp:
+    piece_box) must still hold the exact pieces — rays aimed AT the slivers, along and across them, find what the whole-triangle tree finds."""
+    rng = np.random.default_rng(11)
+    n = 60
+    a = rng.random((n, 3), dtype=np.float32) * 10
+    d = (rng.random((n, 3), dtype=np.float32) - 0.5) * 18
+    w = (rng.random((n, 3), dtype=np.float32) - 0.5) * 0.05
+    big = np.zeros((n, 3, 4), np.float32); big[:, 0, :3] = a; big[:, 1, :3] = a + d; big[:, 2, :3] = a + d * 0.5 + w
+    small = scenes.soup(3000, seed=5, extent=10.0, size=0.05).reshape(-1, 3, 4)
+    verts = _rotated(np.concatenate([small, big]).reshape(-1, 4))
+    plain = tb.HostBVH(verts, tb.LAYOUT_BVH2_WALD, max_leaf_tris=4)
+    h = tb.HostBVH(verts, layout, split_budget=2.55)
+    counts = np.bincount(h.bvh2_prim_idx(), minlength=verts.shape[0] // 3)
+    assert counts[3000:].max() > 60                     # slivers in > 60 pieces: recursion > 6 deep even if perfectly balanced
+    # rays towards points ON the slivers (barycentric samples), from random origins: they graze piece boundaries all the time
+    tv = verts.reshape(-1, 3, 4)[3000:, :, :3]
+    k = 6000
+    t = rng.integers(0, n, k)
+    u = rng.random(k, dtype=np.float32); v = rng.random(k, dtype=np.float32) * (1 - u)
+    P = tv[t, 0] + u[:, None] * (tv[t, 1] - tv[t, 0]) + v[:, None] * (tv[t, 2] - tv[t, 0])
+    O = (rng.random((k, 3), dtype=np.float32) * 14 - 2).astype(np.float32)
+    rays = tb.make_rays(O, P - O)
+    want = oracle.bvh2_intersect(plain.bvh2_nodes(), plain.bvh2_prim_idx(), verts, rays.copy())
+    got2 = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays.copy())
+    got = oracle.bvhgpu_intersect(h.blob(0, np.uint32, 16), h.blob(1, np.uint32, 1), verts, rays.copy()) if layout == tb.LAYOUT_BVH_GPU else oracle.bvh4_intersect(h.blob(0, np.uint32, 4), rays.copy())
+    assert (want["prim"][want["t"] < 1e30] >= 3000).sum() > 2000    # the slivers are what is hit
+    for g in (got2, got):
+        c = compare_hits(g, want)
+        assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] == 0, c
+        assert c["bit_identical"] == c["same_prim"], c
+
+
 def test_split_triangles_degenerate_inputs():
     one = np.array([[0, 0, 0, 0], [4, 3, 2, 0], [1, 5, 7, 0]], np.float32)
     h = tb.HostBVH(one, tb.LAYOUT_CWBVH, split_budget=2.0)

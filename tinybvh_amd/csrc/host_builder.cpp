@@ -468,19 +468,23 @@ void clip_poly(const Poly& in, int a, float pos, Poly& lo, Poly& hi) {
 }
 
 // box of a clipped piece: its vertices, widened by a few ulps of the coordinates involved off the cut axis (the cut points are rounded
-// results; a box must never be smaller than the exact piece), and never beyond the box of the piece it was cut from
-Box piece_box(const Poly& p, const Box& parent, const float* pad) {
+// results; a box must never be smaller than the exact piece), and never beyond the box of the piece it was cut from.  The polygon a piece is
+// clipped from was itself clipped `depth` times before — every level interpolates between rounded points, so the error of the off-axis
+// coordinates grows with the depth — and the pad grows with it (round 6; a fixed pad was only safe under BVH8_CWBVH's outward quantisation,
+// and the float-box layouts BVH_GPU / BVH4_GPU take split references too).
+Box piece_box(const Poly& p, const Box& parent, const float* pad, uint32_t depth) {
     Box b; b.reset();
     for (int i = 0; i < p.n; i++) b.grow(p.v[i]);
+    const float k = (float)(depth + 1u);
     for (int a = 0; a < 3; a++) {
-        b.mn[a] = std::max(b.mn[a] - pad[a], parent.mn[a]);
-        b.mx[a] = std::min(b.mx[a] + pad[a], parent.mx[a]);
+        b.mn[a] = std::max(b.mn[a] - k * pad[a], parent.mn[a]);
+        b.mx[a] = std::min(b.mx[a] + k * pad[a], parent.mx[a]);
     }
     return b;
 }
 
 void split_piece(const SplitGrid& g, const Poly& poly, const Box& box, uint32_t splits, uint32_t tri, const float* pad,
-                 std::vector<Prim>& prims, std::vector<uint32_t>& refTri) {
+                 std::vector<Prim>& prims, std::vector<uint32_t>& refTri, uint32_t depth = 0) {
     if (splits > 0 && poly.n >= 3) {
         int bestA = -1, bestLevel = SplitGrid::kBits + 1; float bestPos = 0, bestExt = -1;
         for (int a = 0; a < 3; a++) {
@@ -493,14 +497,14 @@ void split_piece(const SplitGrid& g, const Poly& poly, const Box& box, uint32_t 
             clip_poly(poly, bestA, bestPos, lo, hi);
             if (lo.n >= 3 && hi.n >= 3) {
                 Box pl = box, ph = box; pl.mx[bestA] = bestPos; ph.mn[bestA] = bestPos;
-                const Box bl = piece_box(lo, pl, pad), bh = piece_box(hi, ph, pad);
+                const Box bl = piece_box(lo, pl, pad, depth + 1u), bh = piece_box(hi, ph, pad, depth + 1u);
                 auto longest = [](const Box& b) { return std::max(std::max(b.mx[0] - b.mn[0], b.mx[1] - b.mn[1]), b.mx[2] - b.mn[2]); };
                 const float wl = longest(bl), wh = longest(bh);
                 const uint32_t rest = splits - 1;
                 uint32_t sl = wl + wh > 0 ? (uint32_t)((float)rest * wl / (wl + wh) + 0.5f) : rest / 2;
                 if (sl > rest) sl = rest;
-                split_piece(g, lo, bl, sl, tri, pad, prims, refTri);
-                split_piece(g, hi, bh, rest - sl, tri, pad, prims, refTri);
+                split_piece(g, lo, bl, sl, tri, pad, prims, refTri, depth + 1u);
+                split_piece(g, hi, bh, rest - sl, tri, pad, prims, refTri, depth + 1u);
                 return;
             }
         }

@@ -11,8 +11,10 @@ import sys
 from collections import defaultdict
 
 d, jpath = sys.argv[1], sys.argv[2]
-line = [l for l in open(jpath).read().strip().split("\n") if l.startswith("{")][-1]
-j = json.loads(line)
+try:
+    j = json.load(open(jpath))                       # round 6: the run's full record (bench.py --detail-out), indented JSON
+except ValueError:
+    j = json.loads([l for l in open(jpath).read().strip().split("\n") if l.startswith("{")][-1])   # rounds 3-5: the one-line record
 print("bench line under rocprofv3: value %.1f MRays/s, ms_per_step %.3f, HIP-event kernel ms %s" % (j["value"], j["ms_per_step"], {k: round(v, 3) for k, v in j["detail"]["kernel_ms"].items()}))
 tr = []
 for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
