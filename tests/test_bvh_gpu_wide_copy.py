@@ -1,4 +1,4 @@
-"""A BVH_GPU scene keeps an 8-wide copy of its tree (tinybvh_amd/csrc/capi_scene.hip: makeWideCopy) and its queries trace that copy: the hit records
+"""A BVH_GPU / BVH4_GPU scene makes an 8-wide copy of its tree at its first query (tinybvh_amd/csrc/capi_scene.hip: makeWideCopy) and its queries trace that copy: the hit records
 must be the ones the uploaded 2-wide nodes give — byte for byte under the library's tie rule (device_common.h: hit_wins), variant 1 = k_bvh2 on the
 nodes as uploaded — and the reference's own (golden vectors from the real tiny_bvh.h: BVH::Intersect, tiny_bvh.h:3222-3304).  Blobs: the reference's
 BVH_GPU::Build and BuildHQ (SBVH: clipped leaf boxes, primIdx with repeats and slack) from tests/golden, and the library's own builder; the copy
@@ -38,8 +38,9 @@ def test_reference_blobs_through_the_wide_copy(ctx, wide_from_one_entry, name):
         nodes, idx = g[f"bvhgpu_nodes_{k}"], g[f"bvhgpu_idx_{k}"].reshape(-1)
         sc = tb.BVH_GPU(ctx).Upload(nodes, idx, verts)
         plain_bytes = nodes.shape[0] * 64 + idx.shape[0] * 48
-        assert sc.device_bytes > plain_bytes                # the copy exists
+        assert sc.device_bytes == plain_bytes               # nothing until the scene is queried (a BLAS under a TLAS never is)
         wide = sc.Intersect(rays.copy())
+        assert sc.device_bytes > plain_bytes                # the copy exists
         sc.set_variant(1)
         native = sc.Intersect(rays.copy())
         sc.set_variant(0)
@@ -55,12 +56,12 @@ def test_library_built_scene_update_refit_micromaps(ctx, oracle):
     verts = scenes.atrium(60_000, seed=3)
     sc = tb.BVH_GPU(ctx).Build(verts)
     h = sc.host
-    assert sc.device_bytes > h.blob(0, np.uint32, 16).shape[0] * 64 + h.blob(1, np.uint32, 1).shape[0] * 48
     rays = np.concatenate([R.random_rays(60_000, (-20, 0, -10), (20, 15, 10), seed=8), R.primary(R.camera(*scenes.SPONZA_CAMERAS[0], 256, 128, 1, 1))])
     want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
 
     def both():
         a = sc.Intersect(rays.copy())
+        assert sc.device_bytes > h.blob(0, np.uint32, 16).shape[0] * 64 + h.blob(1, np.uint32, 1).shape[0] * 48      # (made by the first query)
         sc.set_variant(1)
         b = sc.Intersect(rays.copy())
         sc.set_variant(0)
@@ -100,6 +101,7 @@ def test_library_built_scene_update_refit_micromaps(ctx, oracle):
 def test_small_blobs_keep_the_two_wide_kernel(ctx):
     verts = scenes.soup(2_000, seed=2)
     sc = tb.BVH_GPU(ctx).Build(verts)
+    sc.Intersect(R.random_rays(4096, (0, 0, 0), (10, 10, 10), seed=1))
     h = sc.host
     assert sc.device_bytes == h.blob(0, np.uint32, 16).shape[0] * 64 + h.blob(1, np.uint32, 1).shape[0] * 48
     sc.free()
@@ -124,8 +126,8 @@ def test_reference_bvh4_streams_through_the_wide_copy(ctx, wide_from_one_entry, 
     for k in (0, 1):                                      # BVH4_GPU::Build and BuildHQ
         blocks = g[f"bvh4_{k}"]
         sc = tb.BVH4_GPU(ctx).Upload(blocks)
-        assert sc.device_bytes > blocks.shape[0] * 16       # the copy exists
         wide = sc.Intersect(rays.copy())
+        assert sc.device_bytes > blocks.shape[0] * 16       # the copy exists (made by the first query)
         sc.set_variant(1)
         native = sc.Intersect(rays.copy())
         sc.set_variant(0)
@@ -141,7 +143,6 @@ def test_library_built_bvh4_scene_refit_and_micromaps(ctx, oracle):
     verts = scenes.atrium(60_000, seed=3)
     sc = tb.BVH4_GPU(ctx).Build(verts)
     h = sc.host
-    assert sc.device_bytes > h.blob(0, np.uint32, 4).shape[0] * 16
     rays = np.concatenate([R.random_rays(60_000, (-20, 0, -10), (20, 15, 10), seed=8), R.primary(R.camera(*scenes.SPONZA_CAMERAS[0], 256, 128, 1, 1))])
     want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
 
@@ -150,6 +151,7 @@ def test_library_built_bvh4_scene_refit_and_micromaps(ctx, oracle):
         sc.set_variant(1)
         b = sc.Intersect(rays.copy())
         sc.set_variant(0)
+        assert sc.device_bytes > h.blob(0, np.uint32, 4).shape[0] * 16
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8))      # (the library's own encoder quantises conservatively: nothing for the copy to find in addition)
         return a
     c = compare_hits(both(), want)
@@ -170,3 +172,19 @@ def test_library_built_bvh4_scene_refit_and_micromaps(ctx, oracle):
     assert hit.sum() > 1000 and np.all(a["prim"][hit] % 2 == 0)
     sc.SetOpacityMicroMaps(None, 0)
     sc.free()
+
+
+def test_a_blas_traced_only_through_a_tlas_never_pays_for_a_copy(ctx):
+    from test_tlas import grid_instances
+    verts = scenes.atrium(60_000, seed=3)
+    blas = tb.BVH4_GPU(ctx).Build(verts)
+    before = blas.device_bytes
+    tlas = tb.TLAS(ctx).Build(grid_instances(2, 0.05, 1), [blas])
+    got = tlas.Intersect(R.random_rays(20_000, (-1, -1, -1), (3, 3, 3), seed=2))
+    assert (got["t"] < 1e30).sum() > 100
+    assert blas.device_bytes == before                    # still only the uploaded stream
+    blas.Refit(verts)                                     # ... and a refit has no copy to follow
+    assert blas.device_bytes == before
+    blas.Intersect(R.random_rays(4096, (-20, 0, -10), (20, 15, 10), seed=3))
+    assert blas.device_bytes > before                     # the first DIRECT query makes it
+    tlas.free(); blas.free()

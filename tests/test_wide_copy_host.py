@@ -17,13 +17,13 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 NAMES = ["soup_2k", "atrium_6k", "suzanne_decimated"]
 
 
-def decode(layout, blob, idx=None, verts=None, max_leaf=3):
+def decode(layout, blob, idx=None, verts=None, max_leaf=3, n_idx=None):
     lib = _capi.lib
     blob = np.ascontiguousarray(blob)
     n_blob = blob.shape[0]
     nn, nr = C.c_uint64(), C.c_uint64()
     args = [layout, C.c_void_p(blob.ctypes.data), n_blob,
-            C.c_void_p(idx.ctypes.data) if idx is not None else None, 0 if idx is None else idx.shape[0],
+            C.c_void_p(idx.ctypes.data) if idx is not None else None, (n_idx or 0) if idx is None else idx.shape[0],
             C.c_void_p(verts.ctypes.data) if verts is not None else None, 0 if verts is None else verts.shape[0] // 3, max_leaf]
     tb.check(lib.tbvh_debug_wide_copy_bvh2(*args, None, 0, C.byref(nn), None, 0, C.byref(nr)), "tbvh_debug_wide_copy_bvh2")
     nodes = np.zeros((nn.value, 8), np.float32)
@@ -54,13 +54,21 @@ def test_bvh_gpu_blob_to_bvh2(oracle_ref, name):
     want.view(np.uint32).reshape(-1, 16)[:, 12:16] = g["hits"]
     for k in (0, 1):
         blob, idx = g[f"bvhgpu_nodes_{k}"], np.ascontiguousarray(g[f"bvhgpu_idx_{k}"].reshape(-1))
-        nodes, _ = decode(tb.LAYOUT_BVH_GPU, blob, idx, verts)
-        sizes = leaf_sizes(nodes)
-        assert max(sizes) <= 3 and sum(sizes) >= verts.shape[0] // 3
-        got = oracle_ref.bvh2_intersect(nodes, idx, verts, rays.copy())
-        c = compare_hits(got, want)
-        assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] <= 2, (name, k, c)
-        assert c["bit_identical"] == c["same_prim"], (name, k, c)
+        # (a) from primIdx + vertices, (b) RECORD MODE — what the library runs: the triangles as the gathered records it keeps on the device
+        #     {v0|prim, e1, e2} per primIdx entry (slack entries of an SBVH array: zeros)
+        p = np.minimum(idx, verts.shape[0] // 3 - 1)
+        tv = verts.reshape(-1, 3, 4)
+        recs = np.zeros((idx.shape[0], 3, 4), np.float32)
+        recs[:, 0, :3] = tv[p, 0, :3]; recs[:, 0, 3] = p.astype(np.uint32).view(np.float32)
+        recs[:, 1, :3] = tv[p, 1, :3] - tv[p, 0, :3]; recs[:, 2, :3] = tv[p, 2, :3] - tv[p, 0, :3]
+        recs[idx >= verts.shape[0] // 3] = 0
+        for nodes in (decode(tb.LAYOUT_BVH_GPU, blob, idx, verts)[0], decode(tb.LAYOUT_BVH_GPU, blob, None, np.ascontiguousarray(recs.reshape(-1, 4)), n_idx=idx.shape[0])[0]):
+            sizes = leaf_sizes(nodes)
+            assert max(sizes) <= 3 and sum(sizes) >= verts.shape[0] // 3
+            got = oracle_ref.bvh2_intersect(nodes, idx, verts, rays.copy())
+            c = compare_hits(got, want)
+            assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] <= 2, (name, k, c)
+            assert c["bit_identical"] == c["same_prim"], (name, k, c)
 
 
 def stream_records(blocks):

@@ -204,9 +204,11 @@ int tbvh_debug_wide_copy_bvh2(int layout, const void* blob, uint64_t nBlob, cons
     std::vector<Vec4> recs;
     try {
         if (layout == TBVH_LAYOUT_BVH_GPU) {
-            if (!primIdx || !verts16) return fail(TBVH_E_INVALID, "tbvh_debug_wide_copy_bvh2: BVH_GPU needs prim_idx and verts16");
+            if (!verts16) return fail(TBVH_E_INVALID, "tbvh_debug_wide_copy_bvh2: BVH_GPU needs prim_idx and verts16, or (prim_idx NULL) the gathered records in verts16");
             if (const char* why = validate_bvh_gpu((const NodeAL*)blob, nBlob, nIdx)) return fail(TBVH_E_FORMAT, "%s", why);
-            if (!bvh_gpu_to_bvh2((const NodeAL*)blob, nBlob, primIdx, nIdx, (const Vec4*)verts16, nTris, maxLeaf, n2)) return fail(TBVH_E_FORMAT, "the root is a leaf");
+            // prim_idx == NULL: RECORD MODE, what the library itself runs (capi_scene.hip: makeWideCopy) — verts16 = n_idx records {v0|prim, e1, e2}
+            if (!bvh_gpu_to_bvh2((const NodeAL*)blob, nBlob, primIdx, nIdx, primIdx ? (const Vec4*)verts16 : nullptr, nTris, maxLeaf, n2, primIdx ? nullptr : (const Vec4*)verts16))
+                return fail(TBVH_E_FORMAT, "the root is a leaf");
         } else if (layout == TBVH_LAYOUT_BVH4_GPU) {
             if (const char* why = validate_bvh4_gpu((const Vec4*)blob, nBlob)) return fail(TBVH_E_FORMAT, "%s", why);
             if (!bvh4_gpu_to_bvh2((const Vec4*)blob, nBlob, maxLeaf, n2, recs)) return fail(TBVH_E_FORMAT, "the root is a leaf or the stream is malformed");

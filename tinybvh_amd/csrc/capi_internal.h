@@ -181,11 +181,12 @@ struct tbvh_scene {
     uint32_t opmapN = 0;
     uint64_t opmapBytes = 0;
     uint64_t vertStageTris = 0;
-    // BVH_GPU: the same tree collapsed 8-wide into the BVH8_CWBVH format (capi_scene.cpp: makeWideCopy), kept current by update / refit / micromap
+    // BVH_GPU / BVH4_GPU: the same tree collapsed 8-wide into the BVH8_CWBVH format (capi_scene.hip: makeWideCopy; made by the first query), kept current by update / refit / micromap
     // calls and traced INSTEAD of `nodes` by the queries on this scene: hit records do not depend on the layout (device_common.h: hit_wins), and the
     // compressed wide kernels trace the same rays 1.6-2.9 x faster than the 2-wide one (profiles/r06_bvh2.txt).  Owned by this scene, not listed in
     // the context's scene table; TLASes over this BLAS keep using `nodes`.
     tbvh_scene* wide = nullptr;
+    bool wideTried = false;      // the copy was made, or found unwanted / impossible: launchQuery does not try again
 };
 
 struct BLASInstanceCheck { float m[32]; float mn[3]; uint32_t blasIdx; float mx[3]; uint32_t mask; uint32_t pad[8]; };
@@ -280,5 +281,6 @@ int padCwbvhIfLarge(tbvh_scene* s);
 size_t hybridBytes(uint32_t nNodes, uint32_t K);
 bool wantsIncoherentCopies(const tbvh_scene* s);
 int prepareIncoherentCopies(tbvh_scene* s);
-void freeWideCopy(tbvh_scene* s);   // (lazily, from launchQuery) hybrid node copy + 64-byte triangle records for incoherent batches
+void freeWideCopy(tbvh_scene* s);
+int makeWideCopy(tbvh_scene* s);   // (lazily, from launchQuery) the 8-wide copy of a BVH_GPU / BVH4_GPU scene   // (lazily, from launchQuery) hybrid node copy + 64-byte triangle records for incoherent batches
 }  // namespace tbvh_capi

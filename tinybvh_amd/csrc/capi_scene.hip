@@ -93,55 +93,55 @@ void freeWideCopy(tbvh_scene* s) {
     tbvh_free_scene(w);
 }
 
-// The 8-wide copy of an uploaded BVH_GPU blob (tbvh_scene::wide): host side, the Aila-Laine nodes become a Wald-layout BVH2 with leaves of at most
-// 3 entries (host_builder.cpp: bvh_gpu_to_bvh2); device side, the converter every BVH8_CWBVH conversion uses collapses and encodes it
-// (kernels_convert.hip, the greedy collapse of MBVH<8>::ConvertFrom, tiny_bvh.h:4975-5048).  Blobs below TBVH_WIDE_COPY_MIN primIdx entries
-// (default 32768; 0 = never) keep the 2-wide kernel: the conversion costs more than a few small batches gain.  A failure here is not an error of
-// the upload: the scene then simply traces its own nodes.
-static int makeWideCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx, const void* verts16, uint64_t nTris) {
+// The 8-wide copy of a BVH_GPU / BVH4_GPU scene (tbvh_scene::wide), made LAZILY by the scene's first query of 1024 rays or more (launchQuery) — a BLAS
+// that is only ever traced through a TLAS never pays for it — from what the scene keeps on the device: the blob is read back, the host turns it into a
+// Wald-layout BVH2 with leaves of at most 3 entries (host_builder.cpp: bvh_gpu_to_bvh2 in record mode / bvh4_gpu_to_bvh2), the device converter every
+// BVH8_CWBVH conversion uses collapses and encodes it in ITS record mode (kernels_convert.hip; the greedy collapse of MBVH<8>::ConvertFrom,
+// tiny_bvh.h:4975-5048): triangle records are carried over bit for bit.  Blobs below TBVH_WIDE_COPY_MIN entries / triangles (default 32768; 0 = never)
+// keep their own kernel.  A failure here is never an error of the query: the scene then simply traces its own nodes.
+static int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris, tbvh_scene** out);
+int makeWideCopy(tbvh_scene* s) {
     tbvh_context* c = s->ctx;
     freeWideCopy(s);
+    s->wideTried = true;
+    if (s->isTlas || (s->layout != TBVH_LAYOUT_BVH_GPU && s->layout != TBVH_LAYOUT_BVH4_GPU)) return 0;
     uint64_t minIdx = 32768;
     if (const char* e = getenv("TBVH_WIDE_COPY_MIN")) { const long long v = atoll(e); minIdx = v <= 0 ? ~0ull : (uint64_t)v; }
-    if (nIdx < minIdx || nIdx > 0x7fffffffull || nNodes > 0x3fffffffull) return 0;
     std::vector<Node2> n2;
+    std::vector<Vec4> blob, recs;
+    const float4* dRecs = nullptr;
+    uint64_t nRecs = 0;
+    struct Tmp { void *n2 = nullptr, *r = nullptr; ~Tmp() { if (n2) hipFree(n2); if (r) hipFree(r); } } t;
     try {
-        if (!bvh_gpu_to_bvh2((const NodeAL*)nodes64, nNodes, primIdx, nIdx, (const Vec4*)verts16, nTris, 3u, n2)) return 0;
+        if (s->layout == TBVH_LAYOUT_BVH_GPU) {
+            const uint64_t nNodes = s->nNodeBlocks / 4, nIdx = s->nTriBlocks / 3;
+            if (nIdx < minIdx || nIdx > 0x7fffffffull || nNodes > 0x3fffffffull) return 0;
+            blob.resize(s->nNodeBlocks); recs.resize(s->nTriBlocks);
+            if (hipMemcpyAsync(blob.data(), s->nodes, s->nNodeBlocks * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipMemcpyAsync(recs.data(), s->tris, s->nTriBlocks * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
+            if (!bvh_gpu_to_bvh2((const NodeAL*)blob.data(), nNodes, nullptr, nIdx, nullptr, 0, 3u, n2, recs.data())) return 0;
+            dRecs = s->tris; nRecs = nIdx;       // (the gathered records are on the device already, in leaf order)
+        } else {
+            if (s->nNodeBlocks / 4 < minIdx || s->nNodeBlocks > 0x7fffffffull) return 0;   // (a stream of n triangles has at least 3 n blocks: a cheap first cut)
+            blob.resize(s->nNodeBlocks);
+            if (hipMemcpyAsync(blob.data(), s->nodes, s->nNodeBlocks * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
+            if (!bvh4_gpu_to_bvh2(blob.data(), s->nNodeBlocks, 3u, n2, recs)) return 0;
+            nRecs = recs.size() / 3;
+            if (nRecs < minIdx || nRecs > 0x7fffffffull) return 0;
+            if (hipMalloc(&t.r, recs.size() * 16) != hipSuccess ||
+                hipMemcpyAsync(t.r, recs.data(), recs.size() * 16, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
+            dRecs = (const float4*)t.r;
+        }
     } catch (const std::bad_alloc&) { return 0; }
+    if (n2.size() > 0x7fffffffull) return 0;
+    if (hipMalloc(&t.n2, n2.size() * 32) != hipSuccess ||
+        hipMemcpyAsync(t.n2, n2.data(), n2.size() * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
     tbvh_scene* w = nullptr;
-    if (tbvh_convert_bvh2_device(c, n2.data(), n2.size(), primIdx, nIdx, verts16, nTris, 0, TBVH_LAYOUT_CWBVH, &w) != 0 || !w) return 0;
+    if (convertDeviceImpl(c, TBVH_LAYOUT_CWBVH, (const float4*)t.n2, n2.size(), nullptr, nRecs, dRecs, nRecs, &w) != 0 || !w) { (void)hipGetLastError(); return 0; }
     for (size_t i = 0; i < c->scenes.size(); i++)
         if (c->scenes[i] == w) { c->scenes.erase(c->scenes.begin() + i); break; }   // owned by `s`, freed with it
-    w->opmap = s->opmap; w->opmapN = s->opmapN;
-    s->wide = w;
-    s->bytes += w->bytes;
-    return 0;
-}
-
-// ... and of an uploaded BVH4_GPU stream: decoded on the host into a BVH2 over the dequantised child boxes and the inline triangle records as they are
-// (host_builder.cpp: bvh4_gpu_to_bvh2), converted in the converter's record mode.  Same threshold (counted in triangles), same "never an error".
-static int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris, tbvh_scene** out);
-static int makeWideCopy4(tbvh_scene* s, const void* blocks16, uint64_t nBlocks) {
-    tbvh_context* c = s->ctx;
-    freeWideCopy(s);
-    uint64_t minIdx = 32768;
-    if (const char* e = getenv("TBVH_WIDE_COPY_MIN")) { const long long v = atoll(e); minIdx = v <= 0 ? ~0ull : (uint64_t)v; }
-    if (nBlocks / 4 < minIdx || nBlocks > 0x7fffffffull) return 0;   // (a stream of n triangles has at least 3 n blocks: a cheap first cut)
-    std::vector<Node2> n2;
-    std::vector<Vec4> recs;
-    try {
-        if (!bvh4_gpu_to_bvh2((const Vec4*)blocks16, nBlocks, 3u, n2, recs)) return 0;
-    } catch (const std::bad_alloc&) { return 0; }
-    const uint64_t nRecs = recs.size() / 3;
-    if (nRecs < minIdx || nRecs > 0x7fffffffull || n2.size() > 0x7fffffffull) return 0;
-    struct Tmp { void *n2 = nullptr, *r = nullptr; ~Tmp() { if (n2) hipFree(n2); if (r) hipFree(r); } } t;
-    if (hipMalloc(&t.n2, n2.size() * 32) != hipSuccess || hipMalloc(&t.r, recs.size() * 16) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    if (hipMemcpyAsync(t.n2, n2.data(), n2.size() * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-        hipMemcpyAsync(t.r, recs.data(), recs.size() * 16, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    tbvh_scene* w = nullptr;
-    if (convertDeviceImpl(c, TBVH_LAYOUT_CWBVH, (const float4*)t.n2, n2.size(), nullptr, nRecs, (const float4*)t.r, nRecs, &w) != 0 || !w) return 0;
-    for (size_t i = 0; i < c->scenes.size(); i++)
-        if (c->scenes[i] == w) { c->scenes.erase(c->scenes.begin() + i); break; }
     w->opmap = s->opmap; w->opmapN = s->opmapN;
     s->wide = w;
     s->bytes += w->bytes;
@@ -177,7 +177,6 @@ int tbvh_upload_bvh_gpu(tbvh_context* c, const void* nodes64, uint64_t nNodes, c
     s->nNodeBlocks = nNodes * 4; s->nTriBlocks = nIdx * 3;
     s->capNodeBlocks = s->nNodeBlocks; s->capTriBlocks = s->nTriBlocks;
     s->bytes = nNodes * 64 + nIdx * 48;
-    makeWideCopy(s, nodes64, nNodes, primIdx, nIdx, verts16, nTris);
     *out = s;
     return 0;
 }
@@ -193,7 +192,6 @@ int tbvh_upload_bvh4_gpu(tbvh_context* c, const void* blocks16, uint64_t nBlocks
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "BVH4_GPU upload failed: %s", hipGetErrorString(e)); }
     s->nNodeBlocks = nBlocks; s->capNodeBlocks = nBlocks; s->bytes = nBlocks * 16;
-    makeWideCopy4(s, blocks16, nBlocks);
     *out = s;
     return 0;
 }
@@ -358,7 +356,7 @@ int tbvh_update_bvh_gpu(tbvh_scene* s, const void* nodes64, uint64_t nNodes, con
     if (dVerts) hipFree(dVerts);
     if (e != hipSuccess) return fail(TBVH_E_HIP, "tbvh_update_bvh_gpu: %s", hipGetErrorString(e));
     s->nNodeBlocks = nNodes * 4; s->nTriBlocks = nIdx * 3;
-    makeWideCopy(s, nodes64, nNodes, primIdx, nIdx, verts16, nTris);   // (the tree may have changed: collapsed again)
+    if (s->wide) makeWideCopy(s);   // (the tree may have changed: collapsed again)
     return 0;
 }
 
@@ -373,7 +371,7 @@ int tbvh_update_bvh4_gpu(tbvh_scene* s, const void* blocks16, uint64_t nBlocks) 
     s->nNodeBlocks = nBlocks;
     s->b4Levels.clear();   // (the node list of a device refit is rebuilt by the next tbvh_refit)
     if (s->refitScratch) { hipFree(s->refitScratch); s->refitScratch = nullptr; }
-    makeWideCopy4(s, blocks16, nBlocks);   // (the tree may have changed: decoded and collapsed again)
+    if (s->wide) makeWideCopy(s);   // (the tree may have changed: decoded and collapsed again)
     return 0;
 }
 

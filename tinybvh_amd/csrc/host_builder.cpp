@@ -1035,7 +1035,7 @@ bool cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>
 namespace tbvh {
 
 bool bvh_gpu_to_bvh2(const NodeAL* al, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx, const Vec4* verts, uint64_t nTris, uint32_t maxLeafTris,
-                     std::vector<Node2>& out) {
+                     std::vector<Node2>& out, const Vec4* recs) {
     out.clear();
     if (!nNodes || al[0].triCount) return false;
     out.reserve(nNodes + nNodes / 4 + 2);
@@ -1051,6 +1051,18 @@ bool bvh_gpu_to_bvh2(const NodeAL* al, uint64_t nNodes, const uint32_t* primIdx,
     auto range_box = [&](uint32_t first, uint32_t count, const Node2& clip, Node2& n) {
         float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
         for (uint32_t i = first; i < first + count; i++) {
+            if (recs) {                             // record mode: corners v0, v0 + e1, v0 + e2, each padded by two ulps of the larger operand
+                if (i >= nIdx) continue;
+                const Vec4 &v0 = recs[3 * (size_t)i], &e1 = recs[3 * (size_t)i + 1], &e2 = recs[3 * (size_t)i + 2];
+                const float A[3] = {v0.x, v0.y, v0.z}, E1[3] = {e1.x, e1.y, e1.z}, E2[3] = {e2.x, e2.y, e2.z};
+                for (int k = 0; k < 3; k++) {
+                    const float m = std::max(std::fabs(A[k]), std::max(std::fabs(E1[k]), std::fabs(E2[k]))) * 2.4e-7f;
+                    const float c0 = A[k], c1 = A[k] + E1[k], c2 = A[k] + E2[k];
+                    mn[k] = std::min(mn[k], std::min(c0, std::min(c1, c2)) - m);
+                    mx[k] = std::max(mx[k], std::max(c0, std::max(c1, c2)) + m);
+                }
+                continue;
+            }
             const uint32_t p = i < nIdx ? primIdx[i] : 0xffffffffu;
             if (p >= nTris) continue;               // slack entries of an SBVH primIdx array
             for (int v = 0; v < 3; v++) {

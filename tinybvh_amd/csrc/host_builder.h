@@ -67,8 +67,10 @@ void encode_cwbvh(const BVH2& bvh, const Vec4* verts, const BuildParams& p, std:
 // here by halving a leaf's primIdx range: the order of the entries is kept, primIdx is shared with the blob).  A half's box = the bounds of its
 // triangles CLIPPED to the leaf's box, so the leaves of an SBVH (BuildHQ: spatial splits, boxes smaller than their triangles) stay as tight as
 // they were.  false: the root is a leaf (nothing to collapse).
+// recs != nullptr: the leaves' triangles as gathered records {v0|prim, e1, e2}, one per primIdx entry (what the library keeps of a BVH_GPU blob on the
+// device: kernels_query.hip: k_gather_tris) instead of primIdx + verts — the halves' boxes then come from the records' corners, padded by ulps.
 bool bvh_gpu_to_bvh2(const NodeAL* al, uint64_t nNodes, const uint32_t* primIdx, uint64_t nIdx, const Vec4* verts, uint64_t nTris, uint32_t maxLeafTris,
-                     std::vector<Node2>& out);
+                     std::vector<Node2>& out, const Vec4* recs = nullptr);
 
 // The same for an uploaded BVH4_GPU stream (tiny_bvh.h:1248-1266, 5115-5244): every 4-wide node becomes one to three binary nodes over its children's
 // DEQUANTISED boxes (padded outward by two ulps: they only cull), leaves of at most maxLeafTris entries index `recs`, the blob's inline triangle
