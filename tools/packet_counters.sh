@@ -6,7 +6,7 @@ for pass in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_
   TBVH_COHERENT_TUNER=3 timeout 200 rocprofv3 --output-format csv --pmc $pass --kernel-trace -d $HERE/gpurun_out/pkc_$n -o pmc -- python $HERE/tools/coherent_modes.py --child bistro 4096 > /dev/null 2>&1
 done
 cd $HERE
-python - <<'PY'
+python - > gpurun_out/r06_packet_counters.txt <<'PY'
 import csv, glob, collections
 tot=collections.defaultdict(list)
 for f in glob.glob("gpurun_out/pkc_*/**/*counter_collection.csv", recursive=True):
