@@ -34,6 +34,7 @@ __device__ __forceinline__ uint32_t pk_test_children(const float (*planes)[8], f
         const float4 qa = pa; const float2 qb = pb;
         if (c < 7) { pa = *(const float4*)&planes[c + 1][0]; pb = *(const float2*)&planes[c + 1][4]; }
         if (!((nonEmpty >> c) & 1u)) continue;
+        // (the six FMAs as three v_pk_fma_f32 — the planes do arrive in register pairs — measured 6 % SLOWER on camera rays, same records: profiles/r06_packet_counters.txt)
         float tnx = __builtin_fmaf(qa.x, ax, ox), tny = __builtin_fmaf(qa.y, ay, oy), tnz = __builtin_fmaf(qa.z, az, oz);
         float tfx = __builtin_fmaf(qa.w, ax, ox), tfy = __builtin_fmaf(qb.x, ay, oy), tfz = __builtin_fmaf(qb.y, az, oz);
         if (MIXED) {
