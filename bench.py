@@ -609,11 +609,15 @@ def side_legs(a, tb, ctx, R, scenes, sc, verts, d_verts, d_prim, d_diff, n, cam,
     if a.scene == "bistro":
         detail["other_layouts"] = {}
         for name, lay, kern, refk in (("BVH_GPU", 5, "k_bvh2", "batch_ailalaine (traverse_bvh2.cl:209-219)"), ("BVH4_GPU", 8, "k_bvh4", "batch_gpu4way (traverse_bvh4.cl:277-286)")):
-            try:
-                detail["other_layouts"][name] = bd.scene_leg(a, log, a.scene, a.side, lay, True, valu_ceiling, note=f"{kern} on the headline batches next to the reference's {refk} (ROCm OpenCL, same GPU, blobs and rays)")
-            except Exception as e:
-                detail["other_layouts"][name] = {"error": repr(e)[:300]}
-            legs.mark("other_layout_" + name)
+            # as shipped (the scene's 8-wide copy serves the queries: DESIGN.md par. 3.4) with the reference's OpenCL kernel beside it, then the layout's OWN kernel
+            # (TBVH_WIDE_COPY_MIN=0: no copy) with its counters
+            for tag, env_extra, ocl, what in ((name, None, True, f"the scene's 8-wide copy (as shipped) on the headline batches next to the reference's {refk} (ROCm OpenCL, same GPU, blobs and rays)"),
+                                              (name + "_native", {"TBVH_WIDE_COPY_MIN": "0"}, False, f"{kern} on the uploaded nodes (TBVH_WIDE_COPY_MIN=0)")):
+                try:
+                    detail["other_layouts"][tag] = bd.scene_leg(a, log, a.scene, a.side, lay, ocl, valu_ceiling, note=what, env_extra=env_extra)
+                except Exception as e:
+                    detail["other_layouts"][tag] = {"error": repr(e)[:300]}
+                legs.mark("other_layout_" + tag)
     leg("device_side_ops", lambda: bd.device_ops_leg(tb, ctx, sc, verts, d_verts))      # LAST: refits `sc` to moved vertices
 
 
@@ -978,6 +982,7 @@ def live_counters(a, log, passes=("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_
             env.pop(k, None)
         if getattr(a, "coh_pin", None) is not None:
             env["TBVH_COHERENT_TUNER"] = a.coh_pin
+        env.update(getattr(a, "env_extra", None) or {})
         try:
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=200, check=True)
             per_disp, names = {}, {}

@@ -211,7 +211,7 @@ def hbm_regime(a, log):
 LAYOUT_BYTES = {10: (80, 48), 8: (64, 48), 5: (64, 52)}   # node bytes, bytes per triangle test (SURVEY par. 8(d))
 
 
-def scene_leg(a, log, scene, side, layout, ref_ocl, valu_ceiling, note=""):
+def scene_leg(a, log, scene, side, layout, ref_ocl, valu_ceiling, note="", env_extra=None):
     """One more (scene, layout) measured like the headline: a child of this script times `side`^2 camera and bounce rays (HIP events) and counts
     S / T with the oracle's mirror (and, ref_ocl, times the reference's own OpenCL kernel of the layout on the same blobs and rays); two more
     children under `rocprofv3 --pmc` give the bytes beyond the L2s and the VALU counters of the same launches."""
@@ -221,8 +221,10 @@ def scene_leg(a, log, scene, side, layout, ref_ocl, valu_ceiling, note=""):
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "TBVH_BENCH_FORCE_DIST", "TBVH_COHERENT_TUNER"):
         env.pop(k, None)
+    env.update(env_extra or {})
     tmpdir = tempfile.mkdtemp(prefix="tbvh_leg_", dir="/tmp")
     b = copy.copy(a)
+    b.env_extra = env_extra
     b.scene, b.side, b.device_build, b.layout, b.variant, b.coh_pin = scene, side, False, layout, 0, None
     b.blob_cache = os.path.join(tmpdir, scene + ".cwbvh") if layout == 10 else ""
     cmd = [sys.executable, BENCH, "--hbm-child", "--scene", scene, "--side", str(side), "--layout", str(layout)] + \

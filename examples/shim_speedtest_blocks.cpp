@@ -1,6 +1,6 @@
-// shim_speedtest_blocks.cpp — the three GPU blocks of the reference's speedtest (tiny_bvh_speedtest.cpp:1092-1241: BVH_GPU, BVH4_GPU, BVH8_CWBVH;
-// the reference #undefs them on Linux, :86-92) written with tinyocl's OWN names and statement order — Buffer, CopyToDevice, Kernel( "traverse.cl",
-// entry ), SetArguments, Run( N, 64, 0, &event ), clWaitForEvents, clGetEventProfilingInfo, CopyFromDevice — against include/shim/tiny_ocl.h, i.e.
+// shim_speedtest_blocks.cpp — what the three GPU blocks of the reference's speedtest do (tiny_bvh_speedtest.cpp:1092-1241: BVH_GPU, BVH4_GPU, BVH8_CWBVH;
+// the reference #undefs them on Linux, :86-92), written against tinyocl's OWN names — Buffer, CopyToDevice, Kernel( "traverse.cl", entry ),
+// SetArguments, Run( N, 64, 0, &event ), clWaitForEvents, clGetEventProfilingInfo, CopyFromDevice — as include/shim/tiny_ocl.h provides them, i.e.
 // on the HIP engine.  The layouts are built by the REAL tiny_bvh.h (BuildHQ, as the speedtest does); every block's hit distances are validated
 // against tinybvh::BVH::Intersect the way ValidateTraceResult does (:352-377), but exactly (bit-equal t), not to 1 %.
 //
@@ -53,83 +53,55 @@ int main() {
     tinyocl::Kernel gpu4way_kernel("traverse.cl", "batch_gpu4way");
     tinyocl::Kernel cwbvh_kernel("traverse.cl", "batch_cwbvh");
     int bad = 0;
-    cl_event event;
-    cl_ulong startTime, endTime;
-    {   // ---- GPU_2WAY (:1094-1141)
-        BVH_GPU* bvh_gpu = new BVH_GPU();
-        bvh_gpu->BuildHQ(triangles, tricount);
-        tinyocl::Buffer gpuNodes(bvh_gpu->usedNodes * sizeof(BVH_GPU::BVHNode), bvh_gpu->bvhNode);
-        tinyocl::Buffer idxData(bvh_gpu->idxCount * sizeof(unsigned), bvh_gpu->bvh.primIdx);
-        tinyocl::Buffer triData(bvh_gpu->triCount * 3 * sizeof(tinybvh::bvhvec4), triangles);
-        gpuNodes.CopyToDevice(); idxData.CopyToDevice(); triData.CopyToDevice();
+    // what every block of the speedtest does once its scene buffers are on the device: rays into a tinyocl::Buffer (the first 64 bytes of each tinybvh::Ray),
+    // nine timed launches through a cl_event (the first warms up), results back, validation
+    auto trace_block = [&](const char* name, tinyocl::Kernel& kernel) {
         tinyocl::Buffer rayData(Nfull * 64);
-        for (unsigned i = 0; i < Nfull; i++) memcpy((unsigned char*)rayData.GetHostPtr() + 64 * i, &fullBatch[i], 64);
+        unsigned char* dst = (unsigned char*)rayData.GetHostPtr();
+        for (unsigned i = 0; i < Nfull; i++) memcpy(dst + 64 * i, &fullBatch[i], 64);
         rayData.CopyToDevice();
-        float traceTime = 0;
-        ailalaine_kernel.SetArguments(&gpuNodes, &idxData, &triData, &rayData);
+        // (the scene buffers were bound by the caller; the ray buffer is the kernel's last argument — rebind it for this block)
+        kernel.SetRayBuffer(&rayData);
+        double seconds = 0;
         for (int pass = 0; pass < 9; pass++) {
-            ailalaine_kernel.Run(Nfull, 64, 0, &event);
+            cl_event event;
+            cl_ulong t0 = 0, t1 = 0;
+            kernel.Run(Nfull, 64, 0, &event);
             clWaitForEvents(1, &event);
-            clGetEventProfilingInfo(event, CL_PROFILING_COMMAND_START, sizeof(cl_ulong), &startTime, 0);
-            clGetEventProfilingInfo(event, CL_PROFILING_COMMAND_END, sizeof(cl_ulong), &endTime, 0);
-            if (pass == 0) continue;
-            traceTime += (endTime - startTime) * 1e-9f;
+            clGetEventProfilingInfo(event, CL_PROFILING_COMMAND_START, sizeof(cl_ulong), &t0, 0);
+            clGetEventProfilingInfo(event, CL_PROFILING_COMMAND_END, sizeof(cl_ulong), &t1, 0);
+            if (pass) seconds += (double)(t1 - t0) * 1e-9;
         }
         rayData.CopyFromDevice();
-        traceTime /= 8.0f;
-        printf("- BVH_GPU     - primary: %7.2fMRays/s\n", (float)Nfull / traceTime * 1e-6f);
-        if (!(traceTime > 0)) bad++;
-        bad += validate("BVH_GPU", refDist, rayData, Nfull);
-        delete bvh_gpu;
+        printf("- %-11s - primary: %7.2fMRays/s\n", name, (double)Nfull / (seconds / 8.0) * 1e-6);
+        if (!(seconds > 0)) bad++;
+        bad += validate(name, refDist, rayData, Nfull);
+    };
+    tinyocl::Buffer noRays(64);   // placeholder last argument until trace_block binds the real ray buffer
+    {   // GPU_2WAY (tiny_bvh_speedtest.cpp:1094-1141): Aila-Laine nodes + primIdx + vertices
+        BVH_GPU layout;
+        layout.BuildHQ(triangles, tricount);
+        tinyocl::Buffer gpuNodes(layout.usedNodes * sizeof(BVH_GPU::BVHNode), layout.bvhNode), idxData(layout.idxCount * sizeof(unsigned), layout.bvh.primIdx),
+            triData(layout.triCount * 3 * sizeof(bvhvec4), triangles);
+        gpuNodes.CopyToDevice(); idxData.CopyToDevice(); triData.CopyToDevice();
+        ailalaine_kernel.SetArguments(&gpuNodes, &idxData, &triData, &noRays);
+        trace_block("BVH_GPU", ailalaine_kernel);
     }
-    {   // ---- GPU_4WAY (:1145-1190)
-        BVH4_GPU* bvh4_gpu = new BVH4_GPU();
-        bvh4_gpu->BuildHQ(triangles, tricount);
-        tinyocl::Buffer gpu4Nodes(bvh4_gpu->usedBlocks * sizeof(tinybvh::bvhvec4), bvh4_gpu->bvh4Data);
+    {   // GPU_4WAY (:1145-1190): one stream
+        BVH4_GPU layout;
+        layout.BuildHQ(triangles, tricount);
+        tinyocl::Buffer gpu4Nodes(layout.usedBlocks * sizeof(bvhvec4), layout.bvh4Data);
         gpu4Nodes.CopyToDevice();
-        tinyocl::Buffer rayData(Nfull * 64, 0);
-        for (unsigned i = 0; i < Nfull; i++) memcpy((unsigned char*)rayData.GetHostPtr() + 64 * i, &fullBatch[i], 64);
-        rayData.CopyToDevice();
-        float traceTime = 0;
-        gpu4way_kernel.SetArguments(&gpu4Nodes, &rayData);
-        for (int pass = 0; pass < 9; pass++) {
-            gpu4way_kernel.Run(Nfull, 64, 0, &event);
-            clWaitForEvents(1, &event);
-            clGetEventProfilingInfo(event, CL_PROFILING_COMMAND_START, sizeof(cl_ulong), &startTime, 0);
-            clGetEventProfilingInfo(event, CL_PROFILING_COMMAND_END, sizeof(cl_ulong), &endTime, 0);
-            if (pass == 0) continue;
-            traceTime += (endTime - startTime) * 1e-9f;
-        }
-        rayData.CopyFromDevice();
-        traceTime /= 8.0f;
-        printf("- BVH4_GPU    - primary: %7.2fMRays/s\n", (float)Nfull / traceTime * 1e-6f);
-        bad += validate("BVH4_GPU", refDist, rayData, Nfull);
-        delete bvh4_gpu;
+        gpu4way_kernel.SetArguments(&gpu4Nodes, &noRays);
+        trace_block("BVH4_GPU", gpu4way_kernel);
     }
-    {   // ---- GPU_CWBVH (:1192-1241)
-        BVH8_CWBVH* cwbvh = new BVH8_CWBVH();
-        cwbvh->BuildHQ(triangles, tricount);
-        tinyocl::Buffer cwbvhNodes(cwbvh->usedBlocks * sizeof(tinybvh::bvhvec4), cwbvh->bvh8Data);
-        tinyocl::Buffer cwbvhTris(cwbvh->idxCount * 3 * sizeof(tinybvh::bvhvec4), cwbvh->bvh8Tris);
+    {   // GPU_CWBVH (:1192-1241): nodes + triangles
+        BVH8_CWBVH layout;
+        layout.BuildHQ(triangles, tricount);
+        tinyocl::Buffer cwbvhNodes(layout.usedBlocks * sizeof(bvhvec4), layout.bvh8Data), cwbvhTris(layout.idxCount * 3 * sizeof(bvhvec4), layout.bvh8Tris);
         cwbvhNodes.CopyToDevice(); cwbvhTris.CopyToDevice();
-        tinyocl::Buffer rayData(Nfull * 64, 0);
-        for (unsigned i = 0; i < Nfull; i++) memcpy((unsigned char*)rayData.GetHostPtr() + 64 * i, &fullBatch[i], 64);
-        rayData.CopyToDevice();
-        float traceTime = 0;
-        cwbvh_kernel.SetArguments(&cwbvhNodes, &cwbvhTris, &rayData);
-        for (int pass = 0; pass < 9; pass++) {
-            cwbvh_kernel.Run(Nfull, 64, 0, &event);
-            clWaitForEvents(1, &event);
-            clGetEventProfilingInfo(event, CL_PROFILING_COMMAND_START, sizeof(cl_ulong), &startTime, 0);
-            clGetEventProfilingInfo(event, CL_PROFILING_COMMAND_END, sizeof(cl_ulong), &endTime, 0);
-            if (pass == 0) continue;
-            traceTime += (endTime - startTime) * 1e-9f;
-        }
-        rayData.CopyFromDevice();
-        traceTime /= 8.0f;
-        printf("- BVH8/CWBVH  - primary: %7.2fMRays/s\n", (float)Nfull / traceTime * 1e-6f);
-        bad += validate("BVH8_CWBVH", refDist, rayData, Nfull);
-        delete cwbvh;
+        cwbvh_kernel.SetArguments(&cwbvhNodes, &cwbvhTris, &noRays);
+        trace_block("BVH8_CWBVH", cwbvh_kernel);
     }
     if (bad) { printf("FAILED: %d\n", bad); return 1; }
     printf("shim speedtest blocks ok\n");

@@ -184,6 +184,8 @@ public:
             *eventToSet = e;
         }
     }
+    // beyond the reference's surface: rebinds the LAST argument (the ray buffer of every batch_* entry point) and leaves the scene arguments as they are
+    void SetRayBuffer(Buffer* rays) { if (!rays || nArgs == 0) FatalError("kernel '%s': SetRayBuffer needs a buffer", entry.c_str()); arg[nArgs - 1] = rays; }
     // diagnostics beyond the reference's surface
     tbvh_scene* Scene() { syncScene(); return scene; }
 private:
