@@ -544,6 +544,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{label}; {LAYOUT_NAMES[a.layout]}; per GPU per step {n} primary + {n} diffuse (depth 1-3) Intersect",
                        "scene_tris": n_tris, "layout": LAYOUT_NAMES[a.layout], "rays_per_gpu_per_step": 2 * n, "shadow_rays_per_gpu": n,
+                       # the real bistro_ext_part{1,2}.bin are stripped from the reference checkout: a labelled procedural stand-in of the same triangle count unless
+                       # TBVH_SCENE_DIR holds the real files; its node visits / triangle tests per ray (roofline.nodes_per_ray, tris_per_ray) are NOT real Bistro's
+                       "scene_is_stand_in": "stand-in" in label,
                        "sharding": f"value: weak — every GPU its own {2 * n}-ray step, BVH replicated, no collective; config4_strong: one 64 M-ray batch in {n_gpus} contiguous shard(s)"},
             "parity_checked": bool(parity.get("n")) and "error" not in parity, "parity_ok": bool(parity.get("ok", False)),
             "detail": detail, "roofline": roof, "cpu_baseline": cpu, "legs_s": legs.rows,
@@ -829,7 +832,8 @@ def compact_line(full, detail_file=None):
     d = full.get("detail") or {}
     line = {k: _r(full.get(k)) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     cfg = full.get("config") or {}
-    line["config"] = {"workload": str(cfg.get("workload", ""))[:220], "scene_tris": cfg.get("scene_tris"), "layout": cfg.get("layout"), "rays_per_gpu_per_step": cfg.get("rays_per_gpu_per_step")}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:220], "scene_tris": cfg.get("scene_tris"), "layout": cfg.get("layout"), "rays_per_gpu_per_step": cfg.get("rays_per_gpu_per_step"),
+                      "scene_is_stand_in": cfg.get("scene_is_stand_in")}
     roof = full.get("roofline")
     if roof:
         short = ("avg_launch_ms", "nodes_per_ray", "tris_per_ray", "algorithmic_bytes_per_ray", "achieved", "frac", "traffic", "traffic_frac", "valu_issue_frac", "lane_utilisation")
