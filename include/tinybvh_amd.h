@@ -348,7 +348,11 @@ int tbvh_cwbvh_set_hybrid(tbvh_scene* scene, int64_t packed_nodes);
  * tbvh_update_cwbvh) and sends the zero ones back to measuring.  The struct is 8 plain bytes: store it next to the scene's blob cache
  * (tbvh_cwbvh_file_write) if it should outlive the process.  Measured decisions are taken from the best of 3 device-timed launches per schedule, 3 %
  * apart at least; other work on the GPU during those launches can tip a close call, which is what pinning is for.  Hit records do not depend on the
- * schedule: the same bytes. */
+ * schedule: the same bytes.
+ * Round 6: scenes under 48 MB are measured too, from 768 k rays on, between the per-lane kernel (entry 2: afterwards ONE unprobed kernel, as before) and the
+ * packet kernel (entry 3: a probed two-kernel launch; the Sponza stand-in's camera rays x 1.2 - 1.6, a finely tessellated mesh seen from afar x 0.15 - that is
+ * why it is measured); `reserved[0]` / `reserved[1]` carry their extra class of 768 k .. 1.5 M-ray batches (closest-hit / any-hit).  On a BVH_GPU / BVH4_GPU scene
+ * both calls address the scene's 8-wide copy, which is what its queries run on. */
 typedef struct tbvh_schedule_hint { uint8_t closest_hit[3]; uint8_t any_hit[3]; uint8_t reserved[2]; } tbvh_schedule_hint;
 int tbvh_scene_get_schedule_hint(tbvh_scene* scene, tbvh_schedule_hint* out);
 int tbvh_scene_set_schedule_hint(tbvh_scene* scene, const tbvh_schedule_hint* hint);

@@ -261,7 +261,7 @@ def test_schedule_hint_pins_reads_back_and_survives_timing_off(oracle):
         sc = tb.BVH8_CWBVH(c).Build(verts)
         d_a = c.malloc(n * 64)
         c.generate_primary(R.camera(*scenes.STREET_CAMERAS[0], side, side, 1, 1), d_a, 0, n)
-        assert sc.schedule_hint() == {"closest_hit": [0, 0, 0], "any_hit": [0, 0, 0]}
+        assert sc.schedule_hint() == {"closest_hit": [0, 0, 0], "any_hit": [0, 0, 0], "small_batches": [0, 0]}
         recs = {}
         for v in (2, 3, 1):
             sc.set_schedule_hint({"closest_hit": [0, 0, v], "any_hit": [0, 0, 0]})

@@ -104,3 +104,48 @@ def test_upload_refuses_a_node_array_that_is_not_a_tree(ctx):
     n2[inner2[3], 7] = 0
     with pytest.raises(tb.TbvhError, match="not a tree"):
         tb.BVH_GPU(ctx).Upload(n2, h2.blob(1, np.uint32, 1), h2.verts)
+
+
+@pytest.mark.gpu
+def test_small_scene_batches_are_probed_for_the_packet_kernel(ctx, oracle_ties):
+    """Scenes under 48 MB (round 6): a batch of 768 k rays or more is probed; a coherent one is traced by the coherent flavor the scene's tuner is trying or has
+    settled on (strict per-lane or one traversal per wave), an incoherent one by the unprobed kernel behind it.  Whatever the tuner does over a dozen
+    launches, every launch leaves the bytes of the forced strict schedule (variant 72) — and the oracle's records on a sample."""
+    verts = scenes.atrium(60_000, seed=3)
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    h = sc.host
+    cam = R.primary(R.camera(*scenes.SPONZA_CAMERAS[0], 1024, 1024, 1, 1))
+    rnd = R.random_rays(1 << 20, (-20, 0, -10), (20, 15, 10), seed=8)
+    n = cam.shape[0]
+    d = ctx.malloc(n * 64)
+    d_occ = ctx.malloc(n)
+    for name, rays, verdict in (("camera", cam, 2), ("random", rnd, 1)):
+        sc.set_variant(72)
+        ctx.to_device(d, rays); sc.intersect_device_fresh(d, n, 1e30)
+        want = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(want, d)
+        sc.occluded_device(d, n, d_occ)
+        want_occ = np.zeros(n, np.uint8); ctx.from_device(want_occ, d_occ)
+        sc.set_variant(0)
+        seen = set()
+        for k in range(12):
+            ctx.to_device(d, rays); sc.intersect_device_fresh(d, n, 1e30)
+            got = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(got, d)
+            assert ctx.last_probe()[2] in (verdict, 0), (name, k, ctx.last_probe())     # (0: the tuner has settled on the per-lane kernel for this class: one unprobed kernel again)
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (name, k)
+            sc.occluded_device(d, n, d_occ)
+            occ = np.zeros(n, np.uint8); ctx.from_device(occ, d_occ)
+            assert np.array_equal(occ, want_occ), (name, k)
+            seen.add(sc.coherent_schedule(False)[0])
+        if name == "camera":
+            assert sc.coherent_schedule(False)[0] in (2, 3) and sc.coherent_schedule(True)[0] in (2, 3), (sc.coherent_schedule(False), sc.coherent_schedule(True))     # decided: per-lane or packet, never the deferred schedule
+        idx = np.arange(0, n, 16)
+        ref = oracle_ties.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays[idx])
+        c = compare_hits(want[idx], ref)
+        assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0 and c["tie"] == 0 and c["bit_identical"] == c["same_prim"], (name, c)
+    # a batch below the threshold is not probed
+    ctx.to_device(d, cam[: 1 << 19]); sc.intersect_device_fresh(d, 1 << 19, 1e30)
+    assert ctx.last_probe()[2] == 0
+    # the decision can be read, and given back, through the schedule hint (its `reserved` bytes carry the class of 768 k .. 1.5 M-ray batches)
+    hint = sc.schedule_hint()
+    sc.set_schedule_hint(hint)
+    ctx.free(d); ctx.free(d_occ); sc.free()

@@ -334,11 +334,11 @@ class _Scene:
         """tbvh_scene_get_schedule_hint: {"closest_hit": [c0, c1, c2], "any_hit": [...]} per batch-size class (< 6 M, < 12 M, more rays); 0 undecided, 1 deferred + gated, 2 strict."""
         b = (C.c_uint8 * 8)()
         check(lib.tbvh_scene_get_schedule_hint(self._h, C.cast(b, C.c_void_p)), "tbvh_scene_get_schedule_hint")
-        return {"closest_hit": [int(b[0]), int(b[1]), int(b[2])], "any_hit": [int(b[3]), int(b[4]), int(b[5])]}
+        return {"closest_hit": [int(b[0]), int(b[1]), int(b[2])], "any_hit": [int(b[3]), int(b[4]), int(b[5])], "small_batches": [int(b[6]), int(b[7])]}   # small_batches: 768 k .. 1.5 M rays on a scene under 48 MB (closest-hit, any-hit)
 
     def set_schedule_hint(self, hint) -> None:
         """tbvh_scene_set_schedule_hint: pins the non-zero entries of a dict as schedule_hint() returns it; zero entries go back to measuring."""
-        b = (C.c_uint8 * 8)(*(list(hint["closest_hit"]) + list(hint["any_hit"]) + [0, 0]))
+        b = (C.c_uint8 * 8)(*(list(hint["closest_hit"]) + list(hint["any_hit"]) + list(hint.get("small_batches", [0, 0]))))
         check(lib.tbvh_scene_set_schedule_hint(self._h, C.cast(b, C.c_void_p)), "tbvh_scene_set_schedule_hint")
 
     def set_variant(self, v: int):

@@ -131,7 +131,7 @@ struct tbvh_scene {
     uint32_t* hyPerm = nullptr; // device: position of node i in nodesHy
     float4* tris64 = nullptr;   // CWBVH (experiment flag 2): triangle records padded to 64 bytes
     uint32_t hybridK = 0;
-    CohTuner cohTuner[2][3];    // [any-hit][batch-size class: < 6 M, < 12 M, more rays]: which schedule wins can depend on the batch size (the tail of a launch weighs differently)
+    CohTuner cohTuner[2][4];    // [any-hit][batch-size class: < 6 M, < 12 M, more rays; 3 = 768 k .. 1.5 M rays on a scene under 48 MB]: which schedule wins can depend on the batch size (the tail of a launch weighs differently)
     uint8_t cohLastClass[2] = {2, 2};   // the class of the most recent two-flavor launch (tbvh_debug_coherent_schedule reports that one)
     bool hyTried = false;       // the incoherent-batch copies were built, or found impossible / unwanted: launchQuery does not try again
     bool hyLevelOrder = false;  // the node array is in level order (made on the device): the hybrid copy needs no renumbering

@@ -214,6 +214,24 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     // lets the traversal kernel pick its schedule for the launch; a coherent batch also gets a third more waves (the surplus leaves at once
     // otherwise).  Bistro stand-in, 16.7 M rays: camera rays +4.5 %, shadow rays +6 %, bounce rays unchanged.
     uint32_t blocksBase = blocks;
+    // Scenes under 48 MB (round 6): batches of 768 k rays and more whose size the host knows are probed too — not for the deferred schedule (it loses
+    // there) but for the PACKET kernel: one traversal per wave traces the Sponza stand-in's camera rays 1.23 / 1.64 / 1.56 x as fast at 1 / 4.2 / 16.7 M
+    // rays, its shadow rays 0.97 / 1.51 / 1.74 x (profiles/r06_small_scene_packet.txt).  Two kernels back to back as on the larger scenes: the coherent
+    // flavor the scene's tuner has settled on (strict per-lane, or packet) leaves at once unless the batch is coherent, the unprobed kernel behind it
+    // takes what the pool still holds.
+    // The two-kernel launch costs a small launch 10-20 us (the probe, the second kernel's start and exit): where the scene's tuner has measured the per-lane
+    // kernel faster — the Dragon stand-in: a 16 x 4-pixel chunk of camera rays covers hundreds of its triangles, the packet walk is 5-8 x slower — or only
+    // a few us slower, the batch runs as before round 6: ONE unprobed kernel.  Only the measuring launches (6-9 per class of batch size) pay.
+    const int sizeClass = (small && n < (3ull << 19)) ? 3 : n < (6ull << 20) ? 0 : n < (12ull << 20) ? 1 : 2;
+    bool probedSmall = !s->isTlas && small && s->layout == TBVH_LAYOUT_CWBVH && s->variant == 0 && !nDev && n >= (3ull << 18) && !(c->expFlags & 64u) && !c->gridOverride;
+    if (probedSmall) {
+        const int m = c->cohTunerMode ? c->cohTunerMode : s->cohTuner[any ? 1 : 0][sizeClass].decided;
+        if (m == 1 || m == 2) { probedSmall = false; s->cohLastClass[any ? 1 : 0] = (uint8_t)sizeClass; }
+    }
+    if (probedSmall) {
+        q.probe = poolArea + (size_t)kPoolParts * kPoolCounterStride; q.baseBlocks = blocks;
+        c->lastProbed = true;
+    }
     if (probed) {
         uint32_t* probe = poolArea + (size_t)kPoolParts * kPoolCounterStride;
         q.probe = probe; q.baseBlocks = blocks;
@@ -275,7 +293,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             // verdict of the probe; the one the verdict is not for leaves at once (~10 us).  The coherent flavor keeps the packed arrays as
             // uploaded (its working set lives in the L2s); the incoherent one walks the hybrid node copy and the 64-byte triangle records.
             // Bistro stand-in, 16.7 M rays, interleaved medians (profiles/r03_ab_16m.txt): bounce rays +10 %, camera and shadow rays unchanged.
-            const bool twoFlavors = q.probe && s->variant == 0 && !autoPad && s->nodesHy && s->tris64 && !(c->expFlags & 4u);
+            const bool twoFlavors = q.probe && s->variant == 0 && !autoPad && ((s->nodesHy && s->tris64) || probedSmall) && !(c->expFlags & 4u);
             if (s->variant == 90 && s->nodesHy && s->tris64)   // diagnostic: the incoherent flavor whatever the batch (tests, tools/ab_configs.py)
                 launch_cwbvh(any, 0, s->nodesHy, s->tris64, q, c->status, blocksBase, c->stream, 13, small, blocks7);
             else if (s->variant == 91) {   // diagnostic: the coherent flavor (deferred triangles, gated triangle phase) whatever the batch and whatever its probe says
@@ -290,16 +308,16 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                 qa.baseBlocks = 0;   // every wave of the coherent flavor leaves unless the batch is coherent
                 if (c->expFlags & 16u) qa.flags |= 16u;   // (debug flag 16: the coherent flavor takes the batch whatever the probe finds: tests put incoherent rays through it)
                 // which schedule serves a coherent batch on this scene is measured, not assumed (CohTuner, capi_internal.h)
-                const int sizeClass = n < (6ull << 20) ? 0 : n < (12ull << 20) ? 1 : 2;
                 s->cohLastClass[any ? 1 : 0] = (uint8_t)sizeClass;
                 CohTuner& tu = s->cohTuner[any ? 1 : 0][sizeClass];
+                if (probedSmall && !tu.decided && tu.n[0] == 0) { tu.n[0] = CohTuner::kSamples; tu.best[0] = 1e30f; }   // (no deferred schedule on a small scene: strict or packet)
                 if (!tu.decided && !c->cohTunerMode) {
                     for (size_t k = 0; k < tu.pending.size();) {   // harvest the launches that have finished since
                         CohTuner::Pending pe = tu.pending[k];
                         const hipError_t qe = hipEventQuery(pe.e1);
                         if (qe == hipErrorNotReady) { (void)hipGetLastError(); k++; continue; }
                         float t1 = 0.f;
-                        if (qe == hipSuccess && hipEventElapsedTime(&t1, pe.e0, pe.e1) == hipSuccess && t1 > 0.05f) {   // (an incoherent batch: the first kernel left after a few us)
+                        if (qe == hipSuccess && hipEventElapsedTime(&t1, pe.e0, pe.e1) == hipSuccess && t1 > (probedSmall ? 0.015f : 0.05f)) {   // (an incoherent batch: the first kernel left after a few us)
                             // time per ray depends on the batch size (the tail of a launch): only batches of about one size are compared
                             if (!tu.refRays) tu.refRays = pe.rays;
                             if (pe.rays * 4 >= tu.refRays * 3 && pe.rays * 3 <= tu.refRays * 4) {
@@ -314,6 +332,10 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                     if (tu.n[0] >= CohTuner::kSamples && tu.n[1] >= CohTuner::kSamples && tu.n[2] >= CohTuner::kSamples) {
                         int win = 0;   // the deferred + gated schedule unless another one beats it by 3 %
                         for (int m = 1; m < CohTuner::kModes; m++) if (tu.best[m] < 0.97f * tu.best[0] && tu.best[m] < tu.best[win]) win = m;
+                        if (probedSmall) {   // strict (= from now on the unprobed single kernel) unless the packet kernel wins by 3 % AND by more than the second launch costs
+                            const float gainMs = (tu.best[1] - tu.best[2]) * (float)tu.refRays * 1e-6f;
+                            win = (tu.best[2] < 0.97f * tu.best[1] && gainMs >= 0.015f) ? 2 : 1;
+                        }
                         tu.decided = win + 1; tu.drop_pending();
                     } else if (tu.launches >= 96) { tu.decided = 1; tu.drop_pending(); }   // batches too varied to compare: the schedule that wins on most scenes
                 }
@@ -328,7 +350,8 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                     for (const CohTuner::Pending& pe : tu.pending) cnt[pe.mode - 1]++;
                     for (int m = 1; m < CohTuner::kModes; m++) if (cnt[m] < cnt[least]) least = m;
                 }
-                const int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : (nDev ? 1 : 1 + least);
+                int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : (nDev ? 1 : 1 + least);
+                if (probedSmall && mode == 1) mode = 2;
                 if (!nDev) tu.launches++;
                 if (mode == 2) qa.flags |= 32u;
                 CohTuner::Pending pe{nullptr, nullptr, mode, n};
@@ -342,6 +365,12 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                 if (pe.e0) {
                     HIP_TRY(hipEventRecord(pe.e1, c->stream));
                     tu.pending.push_back(pe);
+                }
+                if (probedSmall) {   // behind it: the scene's unprobed kernel, as launched without a probe
+                    QueryArgs qp = q;
+                    qp.probe = nullptr; qp.baseBlocks = 0;
+                    launch_cwbvh(any, 0, s->nodes, tris, qp, c->status, blocks, c->stream, 5, small, blocks7);
+                    break;
                 }
                 QueryArgs qb = q;
                 // the incoherent flavor on 28 one-wave workgroups per CU when the batch fills the grid (24 is the persistent grid's size: 20 / 26 / 28 / 30 /

@@ -781,6 +781,7 @@ uint64_t tbvh_scene_device_bytes(const tbvh_scene* s) { return s ? s->bytes : 0;
 int tbvh_debug_coherent_schedule(tbvh_scene* s, int anyhit, uint32_t out[4]) {
     if (!s || !out) return fail(TBVH_E_INVALID, "tbvh_debug_coherent_schedule: null argument");
     TBVH_LOCK(s->ctx);
+    if (s->wide) s = s->wide;
     const CohTuner& t = s->cohTuner[anyhit ? 1 : 0][s->cohLastClass[anyhit ? 1 : 0]];   // (kept per batch-size class; this is the class of the most recent such launch)
     out[0] = s->ctx->cohTunerMode ? (uint32_t)s->ctx->cohTunerMode : (uint32_t)t.decided;
     out[1] = t.n[0]; out[2] = t.n[1];
@@ -793,19 +794,25 @@ int tbvh_scene_get_schedule_hint(tbvh_scene* s, tbvh_schedule_hint* out) {
     if (!s || !out) return fail(TBVH_E_INVALID, "tbvh_scene_get_schedule_hint: null argument");
     TBVH_LOCK(s->ctx);
     std::memset(out, 0, sizeof *out);
+    if (s->wide) s = s->wide;   // (a BVH_GPU / BVH4_GPU scene: its queries run on the 8-wide copy, whose tuner decides)
     for (int k = 0; k < 3; k++) {
         out->closest_hit[k] = (uint8_t)(s->ctx->cohTunerMode ? s->ctx->cohTunerMode : s->cohTuner[0][k].decided);
         out->any_hit[k] = (uint8_t)(s->ctx->cohTunerMode ? s->ctx->cohTunerMode : s->cohTuner[1][k].decided);
     }
+    // reserved[0 / 1]: the class of 768 k .. 1.5 M-ray batches on a scene under 48 MB (closest-hit / any-hit)
+    out->reserved[0] = (uint8_t)(s->ctx->cohTunerMode ? s->ctx->cohTunerMode : s->cohTuner[0][3].decided);
+    out->reserved[1] = (uint8_t)(s->ctx->cohTunerMode ? s->ctx->cohTunerMode : s->cohTuner[1][3].decided);
     return 0;
 }
 
 int tbvh_scene_set_schedule_hint(tbvh_scene* s, const tbvh_schedule_hint* hint) {
     if (!s || !hint) return fail(TBVH_E_INVALID, "tbvh_scene_set_schedule_hint: null argument");
     for (int k = 0; k < 3; k++) if (hint->closest_hit[k] > 3 || hint->any_hit[k] > 3) return fail(TBVH_E_INVALID, "tbvh_scene_set_schedule_hint: entries are 0 (measure), 1 (deferred + gated), 2 (strict) or 3 (one traversal per wave)");
+    if (hint->reserved[0] > 3 || hint->reserved[1] > 3) return fail(TBVH_E_INVALID, "tbvh_scene_set_schedule_hint: entries are 0 (measure), 1 (deferred + gated), 2 (strict) or 3 (one traversal per wave)");
     TBVH_LOCK(s->ctx);
-    for (int a = 0; a < 2; a++) for (int k = 0; k < 3; k++) {
-        const uint8_t v = a ? hint->any_hit[k] : hint->closest_hit[k];
+    if (s->wide) s = s->wide;
+    for (int a = 0; a < 2; a++) for (int k = 0; k < 4; k++) {
+        const uint8_t v = k == 3 ? hint->reserved[a] : a ? hint->any_hit[k] : hint->closest_hit[k];
         CohTuner& tu = s->cohTuner[a][k];
         tu.drop_pending();
         tu = CohTuner();          // (0: back to measuring, from scratch)

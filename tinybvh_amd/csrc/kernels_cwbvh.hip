@@ -400,6 +400,9 @@ const LaunchRow kLaunchTable[] = {
     {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid; },           &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2>, false},
     // the coherent flavor of a two-kernel probed launch on the STRICT schedule (PROBED == 4): scenes on which the deferred schedule measured
     // slower (the online tuner of capi_query.hip)
+    // ... the same for scenes under 48 MB (round 6: they are probed from 768 k rays on, their coherent flavor is this or the packet kernel): the shapes
+    // of their unprobed kernels below (6 stack entries in LDS next to the split groups, 7 waves per SIMD)
+    {[](const LaunchSel& x) { return x.firstOfTwo && x.strictFirst && x.tail && x.shallow; }, &launch_both<6, 16, 1, false, 0, 5, 4, 16, 7>, true},
     {[](const LaunchSel& x) { return x.firstOfTwo && x.strictFirst && x.tail; }, &launch_both<8, 16, 1, false, 0, 5, 4, 16>, false},
     {[](const LaunchSel& x) { return x.firstOfTwo && x.strictFirst; },           &launch_both<8, 16, 1, false, 0, 5, 4>, false},
     // ... on the deferred + gated schedule (PROBED == 3): no strict path compiled in (camera rays +1.5 %)
