@@ -279,3 +279,36 @@ def test_config4_64m_diffuse_rays_at_stated_size(ctx, reference):
     for p in (d_verts, d_b):
         ctx.free(p)
     sc.free()
+
+
+def test_scene_beyond_384mb_is_measured_for_the_packet_kernel(ctx):
+    """A scene beyond 384 MB (the street generator at 12 M triangles: 1 GB of tree; never probed before round 6): from 6 M rays on its launches are measured
+    between the per-lane kernel and one traversal per wave.  Whatever the tuner tries or settles on, every launch of 16.7 M camera rays and of 16.7 M
+    bounce rays leaves the bytes of the forced strict schedule (variant 72)."""
+    verts, label = scenes.get("street12m")
+    side = 4096
+    n = side * side
+    sc = tb.BVH8_CWBVH(ctx).Build(verts)
+    assert sc.device_bytes > (384 << 20)
+    d_verts = ctx.malloc(verts.nbytes); ctx.to_device(d_verts, verts)
+    d_p, d_b = ctx.malloc(n * 64), ctx.malloc(n * 64)
+    ctx.generate_primary(R.camera(*scenes.STREET_CAMERAS[0], side, side, 1, 1), d_p, 0, n)
+    sc.intersect_device(d_p, n)
+    ctx.generate_bounce(d_verts, d_p, d_b, n, 7)
+    got = np.zeros(n, tb.RAY_DTYPE)
+    for name, d, verdict in (("camera", d_p, 2), ("bounce", d_b, 1)):
+        sc.set_variant(72)
+        sc.intersect_device_fresh(d, n, 1e30)
+        want = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(want, d)
+        sc.set_variant(0)
+        for k in range(9):
+            sc.intersect_device_fresh(d, n, 1e30)
+            ctx.from_device(got, d)
+            assert ctx.last_probe()[2] in (verdict, 0), (name, k, ctx.last_probe())
+            assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (name, k)
+        if name == "camera":
+            assert sc.coherent_schedule(False)[0] in (2, 3), sc.coherent_schedule(False)
+            print("16.7 M camera rays on", label, "-> schedule", sc.coherent_schedule(False)[0], f"{n / ctx.time_last_ms() / 1e3:.0f} MRays/s")
+    for p in (d_verts, d_p, d_b):
+        ctx.free(p)
+    sc.free()

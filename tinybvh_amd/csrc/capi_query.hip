@@ -214,7 +214,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     // lets the traversal kernel pick its schedule for the launch; a coherent batch also gets a third more waves (the surplus leaves at once
     // otherwise).  Bistro stand-in, 16.7 M rays: camera rays +4.5 %, shadow rays +6 %, bounce rays unchanged.
     uint32_t blocksBase = blocks;
-    // Scenes under 48 MB (round 6): batches of 768 k rays and more whose size the host knows are probed too — not for the deferred schedule (it loses
+    // Scenes under 48 MB (round 6; `probedSmall` also covers the scenes beyond 384 MB, below): batches of 768 k rays and more whose size the host knows are probed too — not for the deferred schedule (it loses
     // there) but for the PACKET kernel: one traversal per wave traces the Sponza stand-in's camera rays 1.23 / 1.64 / 1.56 x as fast at 1 / 4.2 / 16.7 M
     // rays, its shadow rays 0.97 / 1.51 / 1.74 x (profiles/r06_small_scene_packet.txt).  Two kernels back to back as on the larger scenes: the coherent
     // flavor the scene's tuner has settled on (strict per-lane, or packet) leaves at once unless the batch is coherent, the unprobed kernel behind it
@@ -222,8 +222,11 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     // The two-kernel launch costs a small launch 10-20 us (the probe, the second kernel's start and exit): where the scene's tuner has measured the per-lane
     // kernel faster — the Dragon stand-in: a 16 x 4-pixel chunk of camera rays covers hundreds of its triangles, the packet walk is 5-8 x slower — or only
     // a few us slower, the batch runs as before round 6: ONE unprobed kernel.  Only the measuring launches (6-9 per class of batch size) pay.
+    // ... and scenes beyond 384 MB (never probed either: the deferred schedule loses there), from 6 M rays on: the street at 12 M triangles traces 16.7 M camera
+    // rays at 7094 instead of 4718 MRays/s with the packet kernel — and 4.2 M at 3383 instead of 3733, shadow rays slower throughout: measured per class likewise.
+    const bool huge = !small && blobBytes > (384ull << 20);
     const int sizeClass = (small && n < (3ull << 19)) ? 3 : n < (6ull << 20) ? 0 : n < (12ull << 20) ? 1 : 2;
-    bool probedSmall = !s->isTlas && small && s->layout == TBVH_LAYOUT_CWBVH && s->variant == 0 && !nDev && n >= (3ull << 18) && !(c->expFlags & 64u) && !c->gridOverride;
+    bool probedSmall = !s->isTlas && (small || huge) && s->layout == TBVH_LAYOUT_CWBVH && s->variant == 0 && !nDev && n >= (small ? (3ull << 18) : (6ull << 20)) && !(c->expFlags & 64u) && !c->gridOverride;
     if (probedSmall) {
         const int m = c->cohTunerMode ? c->cohTunerMode : s->cohTuner[any ? 1 : 0][sizeClass].decided;
         if (m == 1 || m == 2) { probedSmall = false; s->cohLastClass[any ? 1 : 0] = (uint8_t)sizeClass; }
@@ -293,7 +296,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
             // verdict of the probe; the one the verdict is not for leaves at once (~10 us).  The coherent flavor keeps the packed arrays as
             // uploaded (its working set lives in the L2s); the incoherent one walks the hybrid node copy and the 64-byte triangle records.
             // Bistro stand-in, 16.7 M rays, interleaved medians (profiles/r03_ab_16m.txt): bounce rays +10 %, camera and shadow rays unchanged.
-            const bool twoFlavors = q.probe && s->variant == 0 && !autoPad && ((s->nodesHy && s->tris64) || probedSmall) && !(c->expFlags & 4u);
+            const bool twoFlavors = q.probe && s->variant == 0 && ((!autoPad && s->nodesHy && s->tris64) || probedSmall) && !(c->expFlags & 4u);
             if (s->variant == 90 && s->nodesHy && s->tris64)   // diagnostic: the incoherent flavor whatever the batch (tests, tools/ab_configs.py)
                 launch_cwbvh(any, 0, s->nodesHy, s->tris64, q, c->status, blocksBase, c->stream, 13, small, blocks7);
             else if (s->variant == 91) {   // diagnostic: the coherent flavor (deferred triangles, gated triangle phase) whatever the batch and whatever its probe says
@@ -334,7 +337,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                         for (int m = 1; m < CohTuner::kModes; m++) if (tu.best[m] < 0.97f * tu.best[0] && tu.best[m] < tu.best[win]) win = m;
                         if (probedSmall) {   // strict (= from now on the unprobed single kernel) unless the packet kernel wins by 3 % AND by more than the second launch costs
                             const float gainMs = (tu.best[1] - tu.best[2]) * (float)tu.refRays * 1e-6f;
-                            win = (tu.best[2] < 0.97f * tu.best[1] && gainMs >= 0.015f) ? 2 : 1;
+                            win = (tu.best[2] < (small ? 0.97f : 0.92f) * tu.best[1] && gainMs >= 0.015f) ? 2 : 1;   // (beyond 384 MB the per-lane flavor measured here walks the packed nodes; a scene with the padded node copy runs a few % faster unprobed)
                         }
                         tu.decided = win + 1; tu.drop_pending();
                     } else if (tu.launches >= 96) { tu.decided = 1; tu.drop_pending(); }   // batches too varied to compare: the schedule that wins on most scenes
@@ -369,7 +372,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
                 if (probedSmall) {   // behind it: the scene's unprobed kernel, as launched without a probe
                     QueryArgs qp = q;
                     qp.probe = nullptr; qp.baseBlocks = 0;
-                    launch_cwbvh(any, 0, s->nodes, tris, qp, c->status, blocks, c->stream, 5, small, blocks7);
+                    launch_cwbvh(any, s->variant, autoPad ? s->nodes128 : s->nodes, tris, qp, c->status, blocks, c->stream, autoPad ? 8 : 5, small, blocks7);
                     break;
                 }
                 QueryArgs qb = q;
