@@ -118,6 +118,13 @@ struct CohTuner {
     std::vector<Pending> pending;
     static constexpr uint32_t kSamples = 3;   // per schedule, before the faster (by 3 %) stays
     void drop_pending() { for (Pending& p : pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); } pending.clear(); }
+    // (capi_query.hip) the measured launches that have finished since: their times go into n / best; first kernels that left within `minMs` (the probe found
+    // the batch incoherent) and batches of another size than the first one sampled are not samples
+    void harvest(float minMs);
+    // once every schedule has its samples: `decided` is set.  packetOrStrict: the scene's per-lane kernel runs strict whatever (scenes under 48 MB and beyond
+    // 384 MB) — the packet kernel must win by `margin` AND by 15 us per launch, which is what the second kernel of a probed launch costs
+    void settle(bool packetOrStrict, float margin);
+    int least_sampled() const;   // the schedule with the fewest samples taken or in flight
 };
 
 struct tbvh_scene {

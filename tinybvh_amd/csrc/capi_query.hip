@@ -22,6 +22,48 @@ int ensureStageOcc(tbvh_context* c, uint64_t n) {
     return 0;
 }
 }  // namespace tbvh_capi
+
+void CohTuner::harvest(float minMs) {
+    for (size_t k = 0; k < pending.size();) {
+        const Pending pe = pending[k];
+        const hipError_t qe = hipEventQuery(pe.e1);
+        if (qe == hipErrorNotReady) { (void)hipGetLastError(); k++; continue; }
+        float t1 = 0.f;
+        if (qe == hipSuccess && hipEventElapsedTime(&t1, pe.e0, pe.e1) == hipSuccess && t1 > minMs) {
+            // time per ray depends on the batch size (the tail of a launch): only batches of about one size are compared
+            if (!refRays) refRays = pe.rays;
+            if (pe.rays * 4 >= refRays * 3 && pe.rays * 3 <= refRays * 4) {
+                const float perRay = t1 * 1e6f / (float)pe.rays;
+                n[pe.mode - 1]++;
+                if (perRay < best[pe.mode - 1]) best[pe.mode - 1] = perRay;
+            }
+        } else (void)hipGetLastError();
+        hipEventDestroy(pe.e0); hipEventDestroy(pe.e1);
+        pending.erase(pending.begin() + k);
+    }
+}
+
+void CohTuner::settle(bool packetOrStrict, float margin) {
+    if (n[0] >= kSamples && n[1] >= kSamples && n[2] >= kSamples) {
+        int win = 0;   // the deferred + gated schedule unless another one beats it by 3 %
+        for (int m = 1; m < kModes; m++) if (best[m] < 0.97f * best[0] && best[m] < best[win]) win = m;
+        if (packetOrStrict) {   // strict (= from now on the unprobed single kernel) unless the packet kernel wins by the margin AND by more than the second launch costs
+            const float gainMs = (best[1] - best[2]) * (float)refRays * 1e-6f;
+            win = (best[2] < margin * best[1] && gainMs >= 0.015f) ? 2 : 1;
+        }
+        decided = win + 1; drop_pending();
+    } else if (launches >= 96) { decided = 1; drop_pending(); }   // batches too varied to compare: the schedule that wins on most scenes
+}
+
+int CohTuner::least_sampled() const {
+    uint32_t cnt[kModes];
+    for (int m = 0; m < kModes; m++) cnt[m] = n[m];
+    for (const Pending& pe : pending) cnt[pe.mode - 1]++;
+    int least = 0;
+    for (int m = 1; m < kModes; m++) if (cnt[m] < cnt[least]) least = m;
+    return least;
+}
+
 namespace tbvh_capi {
 
 int ensurePipe(tbvh_context* c, uint64_t nHits) {
@@ -166,6 +208,118 @@ int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint
 }
 
 
+// The two-level kernels: one per BLAS layout (and one for BVH8_CWBVH and BVH_GPU BLASes mixed), each walking the TLAS form made for it at upload.
+static void launchTlasKernels(tbvh_scene* s, QueryArgs& q, bool any, uint32_t blocks) {
+    tbvh_context* c = s->ctx;
+    const uint32_t blocks7 = (!c->gridOverride && blocks == c->blocks) ? (uint32_t)c->numCUs * 28u : blocks;   // the full grid of the kernels built for 7 waves per SIMD
+    if (s->tlas4 && s->blasLayout == TBVH_LAYOUT_BVH4_GPU) {   // BVH4_GPU BLASes: the unified 4-wide kernel
+        q.spillStride = c->spillEntries;   // 32-bit stack entries
+        launch_tlas4(any, 0, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
+    } else if (s->tlas8 && (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2)) {   // BVH8_CWBVH BLASes (or those and BVH_GPU ones): the unified 8-wide kernel
+        q.spillStride = c->spillEntries / 2;   // 8-byte stack entries
+        launch_tlas8(any, 0, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7, s->blasMixCw2);
+    } else if (s->blasLayout == TBVH_LAYOUT_BVH_GPU) {   // BVH_GPU BLASes: the TLAS already has their node format (kernels_tlas2.hip)
+        q.spillStride = c->spillEntries;
+        launch_tlas2(any, 0, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
+    } else {
+        q.spillStride = c->spillEntries / 2;
+        launch_tlas(any, s->blasLayout, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+    }
+}
+
+// What launchQuery has worked out about a launch on a BVH8_CWBVH scene before the kernels are chosen.
+struct CwbvhLaunch {
+    bool any;              // IsOccluded
+    bool small;            // the scene lives in the L2s (< 48 MB)
+    bool probedSmall;      // a scene under 48 MB or beyond 384 MB whose batch is probed for the packet kernel
+    int sizeClass;         // which of the scene's tuners the batch belongs to
+    uint32_t blocks;       // grid of a coherent batch (a third more waves when probed)
+    uint32_t blocksBase;   // grid of an incoherent one
+    uint32_t* probeWords;  // the coherence probe's counters in this launch's pool area
+};
+
+// One coherent-flavor kernel of a two-flavor launch, in the schedule the scene's tuner asks for; timed by the tuner's own events while it still measures.
+static int launchCoherentFlavor(tbvh_scene* s, const QueryArgs& q, const CwbvhLaunch& L, const float4* tris, uint32_t blocks7) {
+    tbvh_context* c = s->ctx;
+    QueryArgs qa = q;
+    qa.baseBlocks = 0;   // every wave of the coherent flavor leaves unless the batch is coherent
+    if (c->expFlags & 16u) qa.flags |= 16u;   // (debug flag 16: the coherent flavor takes the batch whatever the probe finds: tests put incoherent rays through it)
+    // which schedule serves a coherent batch on this scene is measured, not assumed (CohTuner, capi_internal.h)
+    s->cohLastClass[L.any ? 1 : 0] = (uint8_t)L.sizeClass;
+    CohTuner& tu = s->cohTuner[L.any ? 1 : 0][L.sizeClass];
+    const bool sizeKnown = q.nRaysDev == nullptr;   // a batch whose size only the device knows (the wavefront stages) cannot be priced per ray: the default schedule, no sample
+    if (L.probedSmall && !tu.decided && tu.n[0] == 0) { tu.n[0] = CohTuner::kSamples; tu.best[0] = 1e30f; }   // (no deferred schedule on such a scene: strict or packet)
+    if (!tu.decided && !c->cohTunerMode) {
+        tu.harvest(L.probedSmall ? 0.015f : 0.05f);
+        tu.settle(L.probedSmall, L.small ? 0.97f : 0.92f);   // (beyond 384 MB the per-lane flavor measured here walks the packed nodes; a scene with the padded node copy runs a few % faster unprobed)
+    }
+    const bool measuring = !tu.decided && !c->cohTunerMode && sizeKnown;
+    // while undecided: the schedule with the fewest samples taken or in flight (round-robin by launch count aliased with callers whose coherent
+    // launches come every third time: one schedule got every sample, the others none, and the tuner idled into its fallback)
+    int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : measuring ? 1 + tu.least_sampled() : 1;
+    if (L.probedSmall && mode == 1) mode = 2;
+    if (sizeKnown) tu.launches++;
+    if (mode == 2) qa.flags |= 32u;
+    CohTuner::Pending pe{nullptr, nullptr, mode, q.nRays};
+    if (measuring && tu.pending.size() < 16) {
+        if (hipEventCreate(&pe.e0) != hipSuccess || hipEventCreate(&pe.e1) != hipSuccess || hipEventRecord(pe.e0, c->stream) != hipSuccess) {   // no sample then
+            if (pe.e0) hipEventDestroy(pe.e0);
+            if (pe.e1) hipEventDestroy(pe.e1);
+            pe.e0 = pe.e1 = nullptr; (void)hipGetLastError();
+        }
+    }
+    if (mode == 3) launch_cwbvh_packet(L.any, s->nodes, s->tris, qa, c->status, L.blocks, c->stream);   // one traversal per wave of 64 consecutive rays
+    else launch_cwbvh(L.any, 0, s->nodes, tris, qa, c->status, mode == 2 ? L.blocksBase : L.blocks, c->stream, 5, L.small, blocks7);
+    const hipError_t le = hipGetLastError();
+    if (pe.e0) {
+        if (le == hipSuccess && hipEventRecord(pe.e1, c->stream) == hipSuccess) tu.pending.push_back(pe);
+        else { hipEventDestroy(pe.e0); hipEventDestroy(pe.e1); }
+    }
+    HIP_TRY(le);
+    return 0;
+}
+
+// The kernels of one launch on a BVH8_CWBVH scene.  A probed launch on a scene with the incoherent-batch copies (prepareIncoherentCopies) is TWO kernels
+// back to back, each for one verdict of the probe; the one the verdict is not for leaves at once (~10 us).  The coherent flavor keeps the packed arrays as
+// uploaded (its working set lives in the L2s); the incoherent one walks the hybrid node copy and the 64-byte triangle records.
+// Bistro stand-in, 16.7 M rays, interleaved medians (profiles/r03_ab_16m.txt): bounce rays +10 %, camera and shadow rays unchanged.
+static int launchCwbvhKernels(tbvh_scene* s, QueryArgs& q, const CwbvhLaunch& L) {
+    tbvh_context* c = s->ctx;
+    const bool autoPad = s->variant == 0 && s->nodes128 != nullptr;   // nodes beyond the Infinity Cache: the padded copy (padCwbvhIfLarge)
+    const uint32_t blocks7 = c->gridOverride ? 0xFFFFFFFFu : (uint32_t)c->numCUs * 28u;
+    const float4* tris = s->tris;
+#ifdef TBVH_EXPERIMENTS
+    if ((c->expFlags & 2u) && s->tris64) { tris = s->tris64; q.flags |= 2u; }   // experiment: 64-byte triangle records in the ordinary kernels too
+#endif
+    const bool twoFlavors = q.probe && s->variant == 0 && ((!autoPad && s->nodesHy && s->tris64) || L.probedSmall) && !(c->expFlags & 4u);
+    if (s->variant == 90 && s->nodesHy && s->tris64) {   // diagnostic: the incoherent flavor whatever the batch (tests, tools/ab_configs.py)
+        launch_cwbvh(L.any, 0, s->nodesHy, s->tris64, q, c->status, L.blocksBase, c->stream, 13, L.small, blocks7);
+    } else if (s->variant == 91) {   // diagnostic: the coherent flavor (deferred triangles, gated triangle phase) whatever the batch and whatever its probe says
+        QueryArgs qa = q;
+        qa.probe = L.probeWords; qa.baseBlocks = 0; qa.flags |= 16u;
+        launch_cwbvh(L.any, 0, s->nodes, tris, qa, c->status, L.blocks, c->stream, 5, L.small, blocks7);
+    } else if (s->variant == 92) {   // diagnostic: one traversal per wave of 64 consecutive rays (kernels_cwbvh_packet.hip) whatever the batch, the scene's size and the tuner
+        launch_cwbvh_packet(L.any, s->nodes, s->tris, q, c->status, L.blocks, c->stream);
+    } else if (twoFlavors) {
+        if (int r = launchCoherentFlavor(s, q, L, tris, blocks7)) return r;
+        if (L.probedSmall) {   // behind it: the scene's unprobed kernel, as launched without a probe
+            QueryArgs qp = q;
+            qp.probe = nullptr; qp.baseBlocks = 0;
+            launch_cwbvh(L.any, s->variant, autoPad ? s->nodes128 : s->nodes, tris, qp, c->status, L.blocks, c->stream, autoPad ? 8 : 5, L.small, blocks7);
+        } else {
+            // the incoherent flavor on 28 one-wave workgroups per CU when the batch fills the grid (24 is the persistent grid's size: 20 / 26 / 28 / 30 /
+            // 32 per CU trace bounce rays at -4.4 / +0.6 / +0.9 / +0.5 / +0.5 %, interleaved medians of 13 rounds)
+            uint32_t wX = (c->expFlags >> 8) & 0xffu;   // experiment: another number of waves per CU
+            if (wX > 32u) wX = 32u;                     // (the spill area holds blocks + blocks / 3 = 32 workgroups per CU: LaneStack strides by gridDim)
+            const uint32_t wB = wX ? wX : (c->gridOverride ? 0u : 28u);
+            launch_cwbvh(L.any, 0, s->nodesHy, s->tris64, q, c->status, (wB && L.blocksBase == c->blocks) ? (uint32_t)c->numCUs * wB : L.blocksBase, c->stream, 13, L.small, blocks7);
+        }
+    } else {
+        launch_cwbvh(L.any, s->variant, autoPad ? s->nodes128 : s->nodes, tris, q, c->status, L.blocks, c->stream, autoPad ? 8 : 5, L.small, blocks7);
+    }
+    return 0;
+}
+
 int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool fresh, float freshTmax, const unsigned long long* nDev) {
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
@@ -242,33 +396,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         if (!c->gridOverride && blocks == c->blocks) blocks = c->blocks + c->blocks / 3u;   // 24 -> 32 one-wave workgroups per CU
     }
     if (s->isTlas) {
-        const uint32_t blocks7 = (!c->gridOverride && blocks == c->blocks) ? (uint32_t)c->numCUs * 28u : blocks;   // the full grid of the kernels built for 7 waves per SIMD
-        if (s->tlas4 && s->blasLayout == TBVH_LAYOUT_BVH4_GPU) {   // BVH4_GPU BLASes: the unified 4-wide kernel
-            q.spillStride = c->spillEntries;   // 32-bit stack entries
-            launch_tlas4(any, 0, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(timedEnd(c));
-            c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
-            return 0;
-        }
-        if (s->tlas8 && (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2)) {   // BVH8_CWBVH BLASes (or those and BVH_GPU ones): the unified 8-wide kernel
-            q.spillStride = c->spillEntries / 2;   // 8-byte stack entries
-            launch_tlas8(any, 0, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7, s->blasMixCw2);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(timedEnd(c));
-            c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
-            return 0;
-        }
-        if (s->blasLayout == TBVH_LAYOUT_BVH_GPU) {   // BVH_GPU BLASes: the TLAS already has their node format (kernels_tlas2.hip)
-            q.spillStride = c->spillEntries;   // 32-bit stack entries
-            launch_tlas2(any, 0, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(timedEnd(c));
-            c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
-            return 0;
-        }
-        q.spillStride = c->spillEntries / 2;
-        launch_tlas(any, s->blasLayout, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+        launchTlasKernels(s, q, any, blocks);
         HIP_TRY(hipGetLastError());
         HIP_TRY(timedEnd(c));
         c->poolCur ^= 1; c->poolClean = true;   // (the other counter area has been zeroed by what was just enqueued)
@@ -285,106 +413,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
         break;
     case TBVH_LAYOUT_CWBVH:
         q.spillStride = c->spillEntries / 2;  // 8-byte entries
-        {
-            const bool autoPad = s->variant == 0 && s->nodes128 != nullptr;   // nodes beyond the Infinity Cache: the padded copy (padCwbvhIfLarge)
-            const uint32_t blocks7 = c->gridOverride ? 0xFFFFFFFFu : (uint32_t)c->numCUs * 28u;
-            const float4* tris = s->tris;
-#ifdef TBVH_EXPERIMENTS
-            if ((c->expFlags & 2u) && s->tris64) { tris = s->tris64; q.flags |= 2u; }   // experiment: 64-byte triangle records in the ordinary kernels too
-#endif
-            // A probed launch on a scene with the incoherent-batch copies (prepareIncoherentCopies) is TWO kernels back to back, each for one
-            // verdict of the probe; the one the verdict is not for leaves at once (~10 us).  The coherent flavor keeps the packed arrays as
-            // uploaded (its working set lives in the L2s); the incoherent one walks the hybrid node copy and the 64-byte triangle records.
-            // Bistro stand-in, 16.7 M rays, interleaved medians (profiles/r03_ab_16m.txt): bounce rays +10 %, camera and shadow rays unchanged.
-            const bool twoFlavors = q.probe && s->variant == 0 && ((!autoPad && s->nodesHy && s->tris64) || probedSmall) && !(c->expFlags & 4u);
-            if (s->variant == 90 && s->nodesHy && s->tris64)   // diagnostic: the incoherent flavor whatever the batch (tests, tools/ab_configs.py)
-                launch_cwbvh(any, 0, s->nodesHy, s->tris64, q, c->status, blocksBase, c->stream, 13, small, blocks7);
-            else if (s->variant == 91) {   // diagnostic: the coherent flavor (deferred triangles, gated triangle phase) whatever the batch and whatever its probe says
-                QueryArgs qa = q;
-                qa.probe = poolArea + (size_t)kPoolParts * kPoolCounterStride; qa.baseBlocks = 0; qa.flags |= 16u;
-                launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, blocks, c->stream, 5, small, blocks7);
-            }
-            else if (s->variant == 92)   // diagnostic: one traversal per wave of 64 consecutive rays (kernels_cwbvh_packet.hip) whatever the batch, the scene's size and the tuner
-                launch_cwbvh_packet(any, s->nodes, s->tris, q, c->status, blocks, c->stream);
-            else if (twoFlavors) {
-                QueryArgs qa = q;
-                qa.baseBlocks = 0;   // every wave of the coherent flavor leaves unless the batch is coherent
-                if (c->expFlags & 16u) qa.flags |= 16u;   // (debug flag 16: the coherent flavor takes the batch whatever the probe finds: tests put incoherent rays through it)
-                // which schedule serves a coherent batch on this scene is measured, not assumed (CohTuner, capi_internal.h)
-                s->cohLastClass[any ? 1 : 0] = (uint8_t)sizeClass;
-                CohTuner& tu = s->cohTuner[any ? 1 : 0][sizeClass];
-                if (probedSmall && !tu.decided && tu.n[0] == 0) { tu.n[0] = CohTuner::kSamples; tu.best[0] = 1e30f; }   // (no deferred schedule on a small scene: strict or packet)
-                if (!tu.decided && !c->cohTunerMode) {
-                    for (size_t k = 0; k < tu.pending.size();) {   // harvest the launches that have finished since
-                        CohTuner::Pending pe = tu.pending[k];
-                        const hipError_t qe = hipEventQuery(pe.e1);
-                        if (qe == hipErrorNotReady) { (void)hipGetLastError(); k++; continue; }
-                        float t1 = 0.f;
-                        if (qe == hipSuccess && hipEventElapsedTime(&t1, pe.e0, pe.e1) == hipSuccess && t1 > (probedSmall ? 0.015f : 0.05f)) {   // (an incoherent batch: the first kernel left after a few us)
-                            // time per ray depends on the batch size (the tail of a launch): only batches of about one size are compared
-                            if (!tu.refRays) tu.refRays = pe.rays;
-                            if (pe.rays * 4 >= tu.refRays * 3 && pe.rays * 3 <= tu.refRays * 4) {
-                                const float perRay = t1 * 1e6f / (float)pe.rays;
-                                tu.n[pe.mode - 1]++;
-                                if (perRay < tu.best[pe.mode - 1]) tu.best[pe.mode - 1] = perRay;
-                            }
-                        } else (void)hipGetLastError();
-                        hipEventDestroy(pe.e0); hipEventDestroy(pe.e1);
-                        tu.pending.erase(tu.pending.begin() + k);
-                    }
-                    if (tu.n[0] >= CohTuner::kSamples && tu.n[1] >= CohTuner::kSamples && tu.n[2] >= CohTuner::kSamples) {
-                        int win = 0;   // the deferred + gated schedule unless another one beats it by 3 %
-                        for (int m = 1; m < CohTuner::kModes; m++) if (tu.best[m] < 0.97f * tu.best[0] && tu.best[m] < tu.best[win]) win = m;
-                        if (probedSmall) {   // strict (= from now on the unprobed single kernel) unless the packet kernel wins by 3 % AND by more than the second launch costs
-                            const float gainMs = (tu.best[1] - tu.best[2]) * (float)tu.refRays * 1e-6f;
-                            win = (tu.best[2] < (small ? 0.97f : 0.92f) * tu.best[1] && gainMs >= 0.015f) ? 2 : 1;   // (beyond 384 MB the per-lane flavor measured here walks the packed nodes; a scene with the padded node copy runs a few % faster unprobed)
-                        }
-                        tu.decided = win + 1; tu.drop_pending();
-                    } else if (tu.launches >= 96) { tu.decided = 1; tu.drop_pending(); }   // batches too varied to compare: the schedule that wins on most scenes
-                }
-                // a batch whose size only the device knows (the wavefront stages) cannot be priced per ray: the default schedule, no sample
-                const bool measure = !tu.decided && !c->cohTunerMode && !nDev && tu.pending.size() < 16;
-                // while undecided: the schedule with the fewest samples taken or in flight (round-robin by launch count aliased with callers whose coherent
-                // launches come every third time: one schedule got every sample, the others none, and the tuner idled into its fallback)
-                int least = 0;
-                if (!tu.decided && !c->cohTunerMode && !nDev) {
-                    uint32_t cnt[CohTuner::kModes];
-                    for (int m = 0; m < CohTuner::kModes; m++) cnt[m] = tu.n[m];
-                    for (const CohTuner::Pending& pe : tu.pending) cnt[pe.mode - 1]++;
-                    for (int m = 1; m < CohTuner::kModes; m++) if (cnt[m] < cnt[least]) least = m;
-                }
-                int mode = c->cohTunerMode ? c->cohTunerMode : tu.decided ? tu.decided : (nDev ? 1 : 1 + least);
-                if (probedSmall && mode == 1) mode = 2;
-                if (!nDev) tu.launches++;
-                if (mode == 2) qa.flags |= 32u;
-                CohTuner::Pending pe{nullptr, nullptr, mode, n};
-                if (measure) {
-                    if (hipEventCreate(&pe.e0) != hipSuccess || hipEventCreate(&pe.e1) != hipSuccess) { if (pe.e0) hipEventDestroy(pe.e0); pe.e0 = pe.e1 = nullptr; (void)hipGetLastError(); }
-                    else HIP_TRY(hipEventRecord(pe.e0, c->stream));
-                }
-                if (mode == 3) launch_cwbvh_packet(any, s->nodes, s->tris, qa, c->status, blocks, c->stream);   // one traversal per wave of 64 consecutive rays
-                else launch_cwbvh(any, 0, s->nodes, tris, qa, c->status, mode == 2 ? blocksBase : blocks, c->stream, 5, small, blocks7);
-                HIP_TRY(hipGetLastError());
-                if (pe.e0) {
-                    HIP_TRY(hipEventRecord(pe.e1, c->stream));
-                    tu.pending.push_back(pe);
-                }
-                if (probedSmall) {   // behind it: the scene's unprobed kernel, as launched without a probe
-                    QueryArgs qp = q;
-                    qp.probe = nullptr; qp.baseBlocks = 0;
-                    launch_cwbvh(any, s->variant, autoPad ? s->nodes128 : s->nodes, tris, qp, c->status, blocks, c->stream, autoPad ? 8 : 5, small, blocks7);
-                    break;
-                }
-                QueryArgs qb = q;
-                // the incoherent flavor on 28 one-wave workgroups per CU when the batch fills the grid (24 is the persistent grid's size: 20 / 26 / 28 / 30 /
-                // 32 per CU trace bounce rays at -4.4 / +0.6 / +0.9 / +0.5 / +0.5 %, interleaved medians of 13 rounds)
-                uint32_t wX = (c->expFlags >> 8) & 0xffu;   // experiment: another number of waves per CU
-                if (wX > 32u) wX = 32u;                     // (the spill area holds blocks + blocks / 3 = 32 workgroups per CU: LaneStack strides by gridDim)
-                const uint32_t wB = wX ? wX : (c->gridOverride ? 0u : 28u);
-                launch_cwbvh(any, 0, s->nodesHy, s->tris64, qb, c->status, (wB && blocksBase == c->blocks) ? (uint32_t)c->numCUs * wB : blocksBase, c->stream, 13, small, blocks7);
-            } else
-                launch_cwbvh(any, s->variant, autoPad ? s->nodes128 : s->nodes, tris, q, c->status, blocks, c->stream, autoPad ? 8 : 5, small, blocks7);
-        }
+        if (int r = launchCwbvhKernels(s, q, CwbvhLaunch{any, small, probedSmall, sizeClass, blocks, blocksBase, poolArea + (size_t)kPoolParts * kPoolCounterStride})) return r;
         break;
     default:
         return fail(TBVH_E_INVALID, "scene layout %d has no query kernel", s->layout);

@@ -38,7 +38,7 @@ constexpr int WG = 64;
 // [3] triangle-phase iterations, [4] sum of lanes in them, [5] node phases whose lanes all visit ONE node with ONE octant,
 // [6] sum of lanes in those, [7] node-phase iterations
 template <bool ANYHIT, int LDS_N, int REFILL_MIN, int TRI_MIN, bool SPEC, bool HAS_OMM, int STATS = 0, int NSTRIDE = 5, int PROBED = 0, int STEAL = 0, int MINW = 8, int TRI2 = 0>
-__global__ __launch_bounds__(WG, (STEAL || TRI2) ? MINW : 1) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+__global__ __launch_bounds__(WG, (STEAL || TRI2 || (SPEC && PROBED == 2)) ? MINW : 1) void k_cwbvh(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                               QueryArgs q, uint32_t* __restrict__ status) {
     __shared__ uint2 stk[LDS_N][WG];
     const uint32_t glane = blockIdx.x * WG + threadIdx.x;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(WG, (STEAL || TRI2) ? MINW : 1) void k_cwbvh(const 
     bool negX = false, negY = false, negZ = false;   // rD.x < 0 ...: per ray, kept in scalar lane masks (cw_test_node)
     uint32_t oct = 0, octinv4 = 0;
     uint2 ng = make_uint2(0u, 0u), tg = make_uint2(0u, 0u), tg2 = make_uint2(0u, 0u);
-    uint32_t tgn = 0;   // hybrid node copy: where tg's node lives (its line may hold one of its triangles: k_derive_hybrid)
+    uint32_t tgn = 0, tgn2 = 0;   // hybrid node copy: where tg's (tg2's) node lives (its line may hold one of its triangles: k_derive_hybrid)
     // STEAL > 0 (idle lanes needed): once the ray pool is dry, idle lanes take pending subtrees off the lanes that still traverse (ray_split.h)
     __shared__ SplitLds<STEAL ? WG : 1> split;
     int grp = -1;
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WG, (STEAL || TRI2) ? MINW : 1) void k_cwbvh(const 
             // +7 % on the Bistro and Sponza stand-ins, +7-10 % on 12 M triangles, camera and shadow rays +-1 % (profiles/r04_ab_triangle_loads_together.txt).
             // The deferred + gated schedule keeps the lazy load: -2 % with the loads together (its triangle phases are full of L2 hits, the saved
             // registers are worth more).
-            if (!SPEC && PROBED != 1) { tri_loads_together(v0); if (TRI2) tri_loads_together(w0); }
+            if ((!SPEC || PROBED == 2) && PROBED != 1) { tri_loads_together(v0); if (TRI2) tri_loads_together(w0); }
             TriHit h;
             if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w)) &&
                 (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), found, hit))) {   // (a split ray's group arbitrates: split_publish)
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(WG, (STEAL || TRI2) ? MINW : 1) void k_cwbvh(const 
                     if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
                 }
             }
-            if ((SPEC || PROBED == 1) && tg.y == 0) { tg = tg2; tg2 = make_uint2(0u, 0u); }
+            if ((SPEC || PROBED == 1) && tg.y == 0) { tg = tg2; tg2 = make_uint2(0u, 0u); if (NSTRIDE == kNodeHybrid) tgn = tgn2; }
         }
         // ---- node phase ---------------------------------------------------------------------------------------
         if (!done && (spec ? tg2.y == 0 : tg.y == 0)) {
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(WG, (STEAL || TRI2) ? MINW : 1) void k_cwbvh(const 
                 ng = make_uint2(r.childBase, (r.hitmask & 0xFF000000u) | r.imask);
                 const uint2 nt = make_uint2(r.triBase, r.hitmask & 0x00FFFFFFu);
                 if (tg.y == 0) { tg = nt; if (NSTRIDE == kNodeHybrid) tgn = cw_hybrid_offset(ci, hybridK); }
-                else tg2 = nt;
+                else { tg2 = nt; if (NSTRIDE == kNodeHybrid) tgn2 = cw_hybrid_offset(ci, hybridK); }
             }
         }
         if (done) {
@@ -391,6 +391,11 @@ const LaunchRow kLaunchTable[] = {
     {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x10000u) && x.tail; }, &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 16, 6, 1>, false},
     {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x10000u) != 0; },      &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 0, 6, 1>, false},
     // round 6: the ray-replacement threshold of the incoherent flavor (debug flags 0x20000: 8 idle lanes, 0x40000: 32; shipped: 16) — profiles/r06_diffuse.txt
+    // (round 6, late) deferred triangles in the incoherent flavor, triangle phase gated at 1 / 4 / 8 / 16 lanes
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x100000u) && !x.tail; }, &launch_both<8, 16, 1, true, 0, kNodeHybrid, 2, 0, 7>, false},
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x200000u) && !x.tail; }, &launch_both<8, 16, 4, true, 0, kNodeHybrid, 2, 0, 7>, false},
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x400000u) && !x.tail; }, &launch_both<8, 16, 8, true, 0, kNodeHybrid, 2, 0, 7>, false},
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x800000u) && !x.tail; }, &launch_both<8, 16, 16, true, 0, kNodeHybrid, 2, 0, 7>, false},
     {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x20000u) && !x.tail; }, &launch_both<8, 8, 1, false, 0, kNodeHybrid, 2>, false},
     {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x40000u) && !x.tail; }, &launch_both<8, 32, 1, false, 0, kNodeHybrid, 2>, false},
 #endif
