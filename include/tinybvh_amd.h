@@ -257,8 +257,12 @@ int tbvh_pinned_free(tbvh_context* ctx, void* ptr);
  * triangles a ray hits at exactly the same t the reference reports whichever it tested last (tiny_bvh.h:1656 accepts
  * t <= hit.t), so its answer depends on the traversal order and its own layouts disagree with each other there; this
  * library reports the one with the smaller primitive index (TLAS: then the smaller instance index), whatever the layout,
- * the schedule or the batch size — the same bytes from run to run.  (Residual, shared with every BVH traversal including
- * the reference's: a triangle lying exactly IN a face of its leaf box can be culled by a hit within a few ulps of it.)
+ * the schedule or the batch size, among the triangles a traversal tests.  (Residual, shared with every BVH traversal including
+ * the reference's: WHICH triangles are tested is decided by box tests, and where such a test decides at rounding level — a hit
+ * grazing a triangle's edge, a ray that starts in or skims the plane of an axis-aligned triangle, coplanar triangles within ulps
+ * of one t — two traversals of one scene can part: the 8-wide copy a BVH_GPU / BVH4_GPU scene is traced through and the
+ * wave-packet kernel test more candidates than the native / per-lane kernels and report more of these (real) hits.  DESIGN.md
+ * par. 4 has the classes and measured rates; tbvh_set_variant(scene, 1) and TBVH_COHERENT_TUNER=2 pin one traversal.)
  * Rays with a zero-length direction (rD = 1e30, tinybvh_safercp) or an infinite origin get the reference's answer; rays with NaN components
  * or an infinite direction component are traced without fault and without disturbing other rays, but what they report is unspecified
  * (the reference's own answer for them depends on the order of its comparisons).  Degenerate and duplicate triangles are fine

@@ -1,0 +1,183 @@
+"""Randomised parity on the paths only LARGER inputs reach (tests/test_random_configs.py stays under 20 k triangles and 34 k rays): scenes of
+30 k .. 400 k triangles in all three layouts — BVH_GPU and BVH4_GPU scenes then trace their 8-wide copy (capi_scene.hip: makeWideCopy) — and batches of
+0.8 .. 2.2 M camera, bounce, shadow and random rays, which a scene under 48 MB probes for the wave-packet kernel while its tuner measures (capi_query.hip:
+launchCoherentFlavor).  Eight launches in a row — the tuner moves through its schedules meanwhile.
+
+Two traversals of one scene can part where a box test decides at rounding level — the classes the reference's own layouts disagree on with each other
+(DESIGN.md par. 4) — whenever one of them TESTS MORE candidates than the other: the 8-wide copy's boxes are re-quantised outward from the uploaded tree's, and
+the wave-packet kernel walks the union of its 64 rays' paths (a lane tests the triangles of a leaf another lane's ray entered).  The classes:
+  * a hit that grazes an edge of its triangle (min(u, v, 1 - u - v) < 2e-3),
+  * a hit at t = +-0: the ray starts IN the plane of an axis-aligned triangle (bounce rays off axis-aligned geometry; MOLLER_TRUMBORE_TEST, tiny_bvh.h:1644-1656,
+    accepts t = -0; the flat box of such a triangle is entered or not by the sign of a rounding error),
+  * a ray that skims its triangle (|cos| of the angle between direction and normal below 1e-4): the slab distance through the triangle's flat box is the
+    quotient of two rounding errors,
+  * coplanar triangles hit at the same t, or within a few ulp of it: the closest — at equal t the smaller index (the tie rule) — wins among the candidates a
+    traversal TESTS; a flat box 1e-5 (relative to t) beyond the hit is culled by one tree and not by the other.
+Every differing record must be in one of these classes, must be a REAL hit (the oracle's triangle test on that one triangle reproduces its bytes), and there
+are at most n / 4000 of them for BVH_GPU / BVH4_GPU scenes against the native kernel on the nodes as uploaded (measured over 80 seeds: none in most batches,
+up to 1.2e-4 of a bounce batch in the street generator, whose walls carry coplanar window triangles) and at most 4 per launch for BVH8_CWBVH scenes
+against the forced strict per-lane kernel (measured: none).  A sample of every batch is compared with the oracle (BVH::Intersect restated,
+tiny_bvh.h:3222-3304) under the same rule.
+A longer hunt: TBVH_RANDOM_LARGE_SEEDS=200 python -m pytest tests/test_random_large.py -m gpu"""
+import os
+
+import numpy as np
+import pytest
+
+import tinybvh_amd as tb
+from tinybvh_amd import rays as R
+from tinybvh_amd import scenes
+from oracle_lib import compare_hits
+
+pytestmark = pytest.mark.gpu
+
+N_SEEDS = int(os.environ.get("TBVH_RANDOM_LARGE_SEEDS", "6"))
+LAYOUTS = [tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU, tb.LAYOUT_CWBVH]
+
+
+def make_scene(rng):
+    kind = int(rng.integers(0, 4))
+    seed = int(rng.integers(1, 1 << 20))
+    if kind == 0:
+        return "atrium", scenes.atrium(int(rng.integers(40_000, 300_000)), seed=seed)
+    if kind == 1:
+        return "street", scenes.street(int(rng.integers(50_000, 400_000)), seed=seed)
+    if kind == 2:
+        return "blob", scenes.blob(int(rng.integers(40_000, 200_000)), seed=seed)
+    return "soup", scenes.soup(int(rng.integers(33_000, 100_000)), seed=seed, extent=30.0, size=0.8)
+
+
+def camera_rays(rng, lo, hi, n_min):
+    """a pinhole camera somewhere around the scene looking at a point inside it, one sample per pixel, at least n_min rays"""
+    c = 0.5 * (lo + hi)
+    ext = hi - lo
+    d = rng.normal(size=3); d /= np.linalg.norm(d)
+    eye = c + d * ext * float(rng.uniform(0.2, 0.9))
+    tgt = c + rng.uniform(-0.2, 0.2, 3) * ext
+    view = tgt - eye; view /= np.linalg.norm(view)
+    if abs(view[1]) > 0.95:                                  # (the camera's up vector is y)
+        view = np.array([0.8, 0.5, 0.33]); view /= np.linalg.norm(view)
+    w = int(rng.choice([1024, 1280, 1536]))
+    h = -(-n_min // w)
+    return R.primary(R.camera(tuple(eye), tuple(view), w, h, 1, 1))
+
+
+def classes(a, b, rays, verts):
+    """how the differing rows of two record arrays split over the classes: for assertion messages"""
+    diff, ok = knife_edge(a, b, rays, verts)
+    x, y = a[diff], b[diff]
+    closer = np.where(x["t"] <= y["t"], x, y)
+    return {"differ": int(diff.size), "at_origin": int((np.abs(closer["t"]) < 1e-6).sum()), "same_or_near_t": int((np.abs(x["t"].astype(np.float64) - y["t"]) <= 4e-6 * np.abs(closer["t"])).sum()),
+            "a_closer": int((x["t"] < y["t"]).sum()), "b_closer": int((x["t"] > y["t"]).sum()), "outside": int((~ok).sum())}
+
+
+def knife_edge(a, b, rays, verts):
+    """rows of two hit-record arrays that differ, and whether each difference is one of the rounding-level classes of the module text (judged on the CLOSER record)"""
+    diff = np.nonzero((a.view(np.uint8).reshape(-1, 64)[:, 48:] != b.view(np.uint8).reshape(-1, 64)[:, 48:]).any(1))[0]
+    x, y = a[diff], b[diff]
+    closer = np.where(x["t"] <= y["t"], x, y)
+    w = 1.0 - closer["u"].astype(np.float64) - closer["v"]
+    edge = np.minimum(np.minimum(closer["u"], closer["v"]), w)
+    near = np.abs(x["t"].astype(np.float64) - y["t"]) <= 4e-6 * np.maximum(np.abs(closer["t"]), 1e-30)
+    tri = verts.reshape(-1, 3, 4)[np.minimum(closer["prim"], verts.shape[0] // 3 - 1), :, :3].astype(np.float64)
+    nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-300)
+    skim = np.abs((rays["D"][diff].astype(np.float64) * nrm).sum(1)) < 1e-4
+    ok = (edge < 2e-3) | (np.abs(closer["t"]) < 1e-6) | (near & (x["prim"] != y["prim"])) | skim
+    return diff, ok
+
+
+def assert_real_hits(oracle, verts, rays, recs, lo, hi):
+    """each record is what the oracle's triangle test gives for that ray on that ONE triangle (a root leaf over the whole scene's box)"""
+    box = np.zeros((1, 8), np.float32)
+    box[0, 0:3] = lo - 0.5 * (hi - lo) - 1.0; box[0, 4:7] = hi + 0.5 * (hi - lo) + 1.0
+    node = box.view(np.uint32).copy()
+    node[0, 3] = 0; node[0, 7] = 1
+    for r, g in zip(rays, recs):
+        if g["prim"] == r["prim"] and g["t"] == r["t"]:
+            continue                                        # (a miss: the record as uploaded)
+        one = oracle.bvh2_intersect(node, np.array([g["prim"]], np.uint32), verts, np.array([r]))[0]
+        assert one["t"] == g["t"] and one["u"] == g["u"] and one["v"] == g["v"] and one["prim"] == g["prim"], (r, g, one)
+
+
+class Case:
+    """one random configuration: scene, layout, library scene, batch kind, the camera the batch is made from"""
+    def __init__(self, ctx, seed):
+        self.ctx, self.seed = ctx, seed
+        self.rng = rng = np.random.default_rng(9000 + seed)
+        self.name, self.verts = make_scene(rng)
+        self.layout = LAYOUTS[int(rng.integers(0, 3))]
+        self.sc = tb.LAYOUT_CLASSES[self.layout](ctx).Build(self.verts)
+        self.lo, self.hi = self.verts[:, :3].min(0), self.verts[:, :3].max(0)
+        n_min = int(rng.choice([800_000, 1_100_000, 1_600_000, 2_200_000]))
+        self.kind = ["camera", "bounce", "shadow", "random"][int(rng.integers(0, 4))]
+        self.cam = camera_rays(rng, self.lo, self.hi, n_min)
+        self.n = self.cam.shape[0]
+        self.d = ctx.malloc(self.n * 64)
+        self.d_occ = ctx.malloc(self.n)
+        self.forced = 72 if self.layout == tb.LAYOUT_CWBVH else 1         # the strict per-lane kernel / the native kernel on the nodes as uploaded
+
+    def trace(self, rays, variant):
+        ctx, sc, d, d_occ, n = self.ctx, self.sc, self.d, self.d_occ, self.n
+        sc.set_variant(variant)
+        ctx.to_device(d, rays); sc.intersect_device_fresh(d, n, 1e30)
+        out = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(out, d)
+        ctx.to_device(d, rays); sc.occluded_device(d, n, d_occ)      # (the rays as generated: tmax = 1e30.  With tmax = the hit distance itself every flag would sit on the edge of the query interval)
+        occ = np.zeros(n, np.uint8); ctx.from_device(occ, d_occ)
+        sc.set_variant(0)
+        return out, occ
+
+    def rays(self):
+        rng, lo, hi, n = self.rng, self.lo, self.hi, self.n
+        if self.kind == "camera":
+            return self.cam
+        if self.kind == "random":
+            pad = 0.05 * (hi - lo)
+            return R.random_rays(n, lo - pad, hi + pad, seed=int(rng.integers(1, 1 << 20)))
+        first, _ = self.trace(self.cam, self.forced)
+        miss = first["t"] >= 1e30                            # camera rays that left the scene: continue from a random point inside it instead (R.bounce / R.shadow
+        if miss.any():                                       # would start 20 / 1000 units out, where a float's spacing is a visible fraction of a small triangle)
+            first["O"][miss] = (lo + rng.random((int(miss.sum()), 3)) * (hi - lo)).astype(np.float32)
+            first["t"][miss] = 0.0
+            first["prim"][miss] = 0
+        if self.kind == "bounce":
+            return R.bounce(first, self.verts, seed=int(rng.integers(1, 1 << 20)))
+        light = 0.5 * (lo + hi) + np.array([0.0, 0.45 * (hi[1] - lo[1]), 0.0])
+        rays = R.shadow(first, light, 1e-4 * float((hi - lo).max()))   # (the speedtest's 5e-7 of the extent, tiny_bvh_speedtest.cpp:851, is less than a float's spacing at these
+        rays["t"] = np.float32(1e30)                                  # coordinates: up to 3 % of a batch off an axis-aligned floor then starts ON it, and every traversal tosses its own coin)
+        return rays
+
+    def free(self):
+        self.ctx.free(self.d); self.ctx.free(self.d_occ); self.sc.free()
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
+def test_random_large_configuration(ctx, oracle, seed):
+    case = Case(ctx, seed)
+    name, verts, layout, kind, n, lo, hi, rng = case.name, case.verts, case.layout, case.kind, case.n, case.lo, case.hi, case.rng
+    host = case.sc.host
+    few = max(4, n // 4000)
+    trace, forced = case.trace, case.forced
+    rays = case.rays()
+    want, want_occ = trace(rays, forced)
+    for k in range(8):
+        got, occ = trace(rays, 0)
+        diff, ok = knife_edge(got, want, rays, verts)
+        c = classes(got, want, rays, verts)
+        assert ok.all() and c["differ"] - c["at_origin"] <= (4 if layout == tb.LAYOUT_CWBVH else few) and c["at_origin"] <= n // 1000, (seed, name, layout, kind, n, k, c)
+        assert int((occ != want_occ).sum()) <= few + n // 1000, (seed, name, layout, kind, n, k, int((occ != want_occ).sum()))
+        if diff.size and k in (0, 5):                      # (k = 5: the tuner is trying the packet kernel by then)
+            assert_real_hits(oracle, verts, rays[diff], got[diff], lo, hi)
+            assert_real_hits(oracle, verts, rays[diff], want[diff], lo, hi)
+    idx = np.arange(int(rng.integers(0, 32)), n, 32)
+    ref = oracle.bvh2_intersect(host.bvh2_nodes(), host.bvh2_prim_idx(), verts, rays[idx])
+    diff, ok = knife_edge(got[idx], ref, rays[idx], verts)
+    c = classes(got[idx], ref, rays[idx], verts)
+    # (hits at the ray's origin are the frequent class: a bounce ray leaves an axis-aligned surface by 1e-3 along a random direction and, when that
+    # direction is nearly tangent, lands within a float's spacing of the plane — up to 5e-4 of such a batch re-hit that surface at |t| < 1e-6 in one tree and not in another)
+    assert ok.all() and c["differ"] - c["at_origin"] <= max(2, idx.size // 4000) and c["at_origin"] <= max(2, idx.size // 500), (seed, name, layout, kind, n, c)
+    if diff.size:
+        assert_real_hits(oracle, verts, rays[idx][diff], got[idx][diff], lo, hi)
+    hit = (ref["prim"] != rays["prim"][idx]) | (ref["t"] != rays["t"][idx])
+    assert int((occ[idx].astype(bool) != hit).sum()) <= max(2, idx.size // 2000), (seed, name, layout, kind, n)
+    case.free()

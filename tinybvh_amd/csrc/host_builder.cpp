@@ -467,8 +467,9 @@ void clip_poly(const Poly& in, int a, float pos, Poly& lo, Poly& hi) {
     }
 }
 
-// box of a clipped piece: its vertices, widened by a few ulps of the coordinates involved off the cut axis (the cut points are rounded
-// results; a box must never be smaller than the exact piece), and never beyond the box of the piece it was cut from.  The polygon a piece is
+// box of a clipped piece: its vertices, widened by a few ulps of the coordinates involved (the cut points are rounded results; a box must never
+// be smaller than the exact piece — and along the cut axis the two halves overlap by that much: split_piece), and never beyond the box of the
+// piece it was cut from.  The polygon a piece is
 // clipped from was itself clipped `depth` times before — every level interpolates between rounded points, so the error of the off-axis
 // coordinates grows with the depth — and the pad grows with it (round 6; a fixed pad was only safe under BVH8_CWBVH's outward quantisation,
 // and the float-box layouts BVH_GPU / BVH4_GPU take split references too).
@@ -483,8 +484,9 @@ Box piece_box(const Poly& p, const Box& parent, const float* pad, uint32_t depth
     return b;
 }
 
+// cutFaces: which faces of `box` are cut planes (bit a: its low face on axis a, bit 3 + a: its high face).
 void split_piece(const SplitGrid& g, const Poly& poly, const Box& box, uint32_t splits, uint32_t tri, const float* pad,
-                 std::vector<Prim>& prims, std::vector<uint32_t>& refTri, uint32_t depth = 0) {
+                 std::vector<Prim>& prims, std::vector<uint32_t>& refTri, uint32_t depth = 0, uint32_t cutFaces = 0) {
     if (splits > 0 && poly.n >= 3) {
         int bestA = -1, bestLevel = SplitGrid::kBits + 1; float bestPos = 0, bestExt = -1;
         for (int a = 0; a < 3; a++) {
@@ -503,14 +505,23 @@ void split_piece(const SplitGrid& g, const Poly& poly, const Box& box, uint32_t 
                 const uint32_t rest = splits - 1;
                 uint32_t sl = wl + wh > 0 ? (uint32_t)((float)rest * wl / (wl + wh) + 0.5f) : rest / 2;
                 if (sl > rest) sl = rest;
-                split_piece(g, lo, bl, sl, tri, pad, prims, refTri, depth + 1u);
-                split_piece(g, hi, bh, rest - sl, tri, pad, prims, refTri, depth + 1u);
+                split_piece(g, lo, bl, sl, tri, pad, prims, refTri, depth + 1u, cutFaces | (8u << bestA));
+                split_piece(g, hi, bh, rest - sl, tri, pad, prims, refTri, depth + 1u, cutFaces | (1u << bestA));
                 return;
             }
         }
     }
+    // The pieces of a triangle tile it exactly: neighbours share the cut plane.  A hit within a rounding error of that plane can then fall between
+    // them — the piece that holds it in exact arithmetic rejects the ray by one ulp of its slab test, its neighbour rightly does not contain it: a
+    // hole in the INTERIOR of a triangle (found by tests/test_random_large.py, seed 222: one camera ray of 1.6 M went through a wall; the two box
+    // tests: tools/debug/cw_trace.py).  So the reference a piece becomes reaches a pad's width across each of its cut faces.
     Prim pr; pr.box = box;
-    for (int a = 0; a < 3; a++) pr.c[a] = 0.5f * (box.mn[a] + box.mx[a]);
+    for (int a = 0; a < 3; a++) {
+        pr.c[a] = 0.5f * (box.mn[a] + box.mx[a]);
+        const float over = (float)(depth + 1u) * pad[a];
+        if (cutFaces & (1u << a)) pr.box.mn[a] -= over;
+        if (cutFaces & (8u << a)) pr.box.mx[a] += over;
+    }
     prims.push_back(pr); refTri.push_back(tri);
 }
 
