@@ -261,3 +261,103 @@ def test_random_large_reference_blobs(ctx, oracle, reference, seed):
         same = np.setdiff1d(np.arange(idx.size), diff)
         assert np.array_equal(got[idx][same].view(np.uint8).reshape(-1, 64)[:, 48:], ref[same].view(np.uint8).reshape(-1, 64)[:, 48:])    # (t, u, v, prim: the reference's bits)
     ctx.free(d); sc.free()
+
+
+N_TLAS_SEEDS = int(os.environ.get("TBVH_RANDOM_LARGE_TLAS_SEEDS", "3"))
+
+
+@pytest.mark.parametrize("seed", range(N_TLAS_SEEDS))
+def test_random_large_tlas(ctx, oracle, seed):
+    """Two-level scenes at the sizes tests/test_random_configs.py does not reach: 64 .. 1728 instances of 1-3 BLASes of 5 k .. 80 k triangles (one layout, or the
+    reference's mix of layouts under one TLAS), host-built or rebuilt on the device, batches of 0.5 .. 2 M camera or random rays with masks on both sides;
+    a 1 / 16 sample against BVH::IntersectTLAS restated (tiny_bvh.h:3306-3380), every launch of four leaving the same bytes."""
+    from test_tlas import grid_instances, oracle_tlas
+    rng = np.random.default_rng(15000 + seed)
+    n_blas = int(rng.integers(1, 4))
+    meshes = []
+    for k in range(n_blas):
+        if rng.random() < 0.6:
+            m = scenes.blob(int(rng.integers(5_000, 80_000)), seed=int(rng.integers(1, 1 << 20)))
+        else:
+            m = scenes.soup(int(rng.integers(5_000, 40_000)), seed=int(rng.integers(1, 1 << 20)), extent=1.6, size=0.12)
+        m = m.copy()
+        c = 0.5 * (m[:, :3].min(0) + m[:, :3].max(0)); e = float((m[:, :3].max(0) - m[:, :3].min(0)).max())
+        m[:, :3] = (m[:, :3] - c) * np.float32(1.6 / e)        # every BLAS in [-0.8, 0.8]^3
+        meshes.append(np.ascontiguousarray(m))
+    if rng.random() < 0.5:
+        layouts = [[tb.LAYOUT_CWBVH, tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU][int(rng.integers(0, 3))] for _ in range(n_blas)]
+    else:
+        layouts = [[tb.LAYOUT_CWBVH, tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU][int(rng.integers(0, 3))]] * n_blas
+    blas = [tb.LAYOUT_CLASSES[l](ctx).Build(meshes[i]) for i, l in enumerate(layouts)]
+    side = int(rng.integers(4, 13))
+    inst = grid_instances(side, float(rng.uniform(0.3, 0.7)), int(rng.integers(1, 1 << 20)), n_blas=n_blas)
+    if rng.random() < 0.4:
+        inst["mask"][:: int(rng.integers(2, 6))] = 0x0001
+    tlas = tb.TLAS(ctx).Build(inst, blas)
+    if rng.random() < 0.5:
+        tlas.RebuildOnDevice()
+    lo, hi = np.full(3, -1.0), np.full(3, 2.0 * side - 1.0)
+    n_min = int(rng.choice([500_000, 1_000_000, 2_000_000]))
+    if rng.random() < 0.6:
+        rays = camera_rays(rng, lo, hi, n_min)
+    else:
+        rays = R.random_rays(n_min, lo - 1, hi + 1, seed=int(rng.integers(1, 1 << 20)))
+    if rng.random() < 0.4:
+        rays["mask"][::3] = 0x00F0
+    n = rays.shape[0]
+    first = tlas.Intersect(rays.copy())
+    for k in range(3):
+        again = tlas.Intersect(rays.copy())
+        assert np.array_equal(again.view(np.uint8), first.view(np.uint8)), (seed, layouts, side, n, k)
+    idx = np.arange(int(rng.integers(0, 16)), n, 16)
+    want = oracle_tlas(oracle, tlas, blas, rays[idx])
+    c = compare_hits(first[idx], want)
+    assert c["hitmiss"] <= 1 and c["prim_real"] <= 1 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] == 0 and c["onsurf"] <= 4, (seed, layouts, side, n, c)
+    assert c["bit_identical"] >= c["same_prim"] - 1, (seed, c)
+    same = (first[idx]["t"] < 1e30) & (first[idx]["prim"] == want["prim"]) & (first[idx]["t"] == want["t"])
+    assert np.array_equal(first[idx]["inst"][same], want["inst"][same])
+    occ = tlas.IsOccluded(rays.copy())
+    assert int((occ[idx].astype(bool) != (want["t"] < 1e30)).sum()) <= 2, (seed, layouts, side, n)
+    tlas.free()
+    for b in blas:
+        b.free()
+
+
+N_REFIT_SEEDS = int(os.environ.get("TBVH_RANDOM_LARGE_REFIT_SEEDS", "3"))
+
+
+@pytest.mark.parametrize("seed", range(N_REFIT_SEEDS))
+def test_random_large_refit(ctx, oracle, seed):
+    """Animated meshes at these sizes: after tbvh_refit to smoothly displaced vertices (three frames, the last back at rest) a batch of 0.8 .. 1.6 M rays
+    through the refitted tree — for BVH_GPU / BVH4_GPU scenes through their 8-wide copy, which the refit must carry along — gives the records of
+    BVH::Intersect on a tree BUILT over the moved vertices (hit records do not depend on the tree, up to the classes above)."""
+    from test_refit_device import deform
+    rng = np.random.default_rng(18000 + seed)
+    if rng.random() < 0.5:
+        name, verts = "blob", scenes.blob(int(rng.integers(40_000, 150_000)), seed=int(rng.integers(1, 1 << 20)))
+    else:
+        name, verts = "atrium", scenes.rotate(scenes.rotate(scenes.atrium(int(rng.integers(40_000, 150_000)), seed=int(rng.integers(1, 1 << 20))), 0, 0.618), 1, 0.755)
+    layout = LAYOUTS[int(rng.integers(0, 3))]
+    sc = tb.LAYOUT_CLASSES[layout](ctx).Build(verts)
+    lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+    n_min = int(rng.choice([800_000, 1_600_000]))
+    rays = camera_rays(rng, lo, hi, n_min) if rng.random() < 0.5 else R.random_rays(n_min, lo - 0.05 * (hi - lo), hi + 0.05 * (hi - lo), seed=int(rng.integers(1, 1 << 20)))
+    n = rays.shape[0]
+    d = ctx.malloc(n * 64)
+    ext = float((hi - lo).max())
+    for frame, amount in enumerate((0.0, 0.004 * ext, 0.015 * ext, 0.0)):
+        v2 = deform(verts, amount, seed=int(rng.integers(1, 1 << 20))) if amount else verts
+        if frame:
+            sc.Refit(v2)
+        ctx.to_device(d, rays); sc.intersect_device_fresh(d, n, 1e30)
+        got = np.zeros(n, tb.RAY_DTYPE); ctx.from_device(got, d)
+        idx = np.arange(int(rng.integers(0, 32)), n, 32)
+        h = tb.HostBVH(v2, tb.LAYOUT_BVH_GPU)
+        ref = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), v2, rays[idx])
+        diff, ok = knife_edge(got[idx], ref, rays[idx], v2)
+        c = classes(got[idx], ref, rays[idx], v2)
+        assert ok.all() and c["differ"] - c["at_origin"] <= max(2, idx.size // 4000) and c["at_origin"] <= max(2, idx.size // 500), (seed, name, layout, n, frame, c)
+        if diff.size:
+            assert_real_hits(oracle, v2, rays[idx][diff], got[idx][diff], v2[:, :3].min(0), v2[:, :3].max(0))
+        assert int((got["t"] < 1e30).sum()) > n // 50, (seed, name, layout, frame)
+    ctx.free(d); sc.free()
