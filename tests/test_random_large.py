@@ -32,6 +32,8 @@ from oracle_lib import compare_hits
 pytestmark = pytest.mark.gpu
 
 N_SEEDS = int(os.environ.get("TBVH_RANDOM_LARGE_SEEDS", "6"))
+SCALE = int(os.environ.get("TBVH_RANDOM_LARGE_SCALE", "1"))     # 8: scenes of 0.3 .. 3.2 M triangles and batches of 1.6 .. 4.4 M rays — the class of the bench scene (probed two-flavor launches on
+                                                                 # the incoherent-batch copies, three schedules to tune between); minutes per configuration on the host side
 LAYOUTS = [tb.LAYOUT_BVH_GPU, tb.LAYOUT_BVH4_GPU, tb.LAYOUT_CWBVH]
 
 
@@ -39,12 +41,12 @@ def make_scene(rng):
     kind = int(rng.integers(0, 4))
     seed = int(rng.integers(1, 1 << 20))
     if kind == 0:
-        return "atrium", scenes.atrium(int(rng.integers(40_000, 300_000)), seed=seed)
+        return "atrium", scenes.atrium(SCALE * int(rng.integers(40_000, 300_000)), seed=seed)
     if kind == 1:
-        return "street", scenes.street(int(rng.integers(50_000, 400_000)), seed=seed)
+        return "street", scenes.street(SCALE * int(rng.integers(50_000, 400_000)), seed=seed)
     if kind == 2:
-        return "blob", scenes.blob(int(rng.integers(40_000, 200_000)), seed=seed)
-    return "soup", scenes.soup(int(rng.integers(33_000, 100_000)), seed=seed, extent=30.0, size=0.8)
+        return "blob", scenes.blob(SCALE * int(rng.integers(40_000, 200_000)), seed=seed)
+    return "soup", scenes.soup(SCALE * int(rng.integers(33_000, 100_000)), seed=seed, extent=30.0 * SCALE ** (1 / 3), size=0.8)
 
 
 def camera_rays(rng, lo, hi, n_min):
@@ -110,7 +112,7 @@ class Case:
         self.layout = LAYOUTS[int(rng.integers(0, 3))]
         self.sc = tb.LAYOUT_CLASSES[self.layout](ctx).Build(self.verts)
         self.lo, self.hi = self.verts[:, :3].min(0), self.verts[:, :3].max(0)
-        n_min = int(rng.choice([800_000, 1_100_000, 1_600_000, 2_200_000]))
+        n_min = int(rng.choice([800_000, 1_100_000, 1_600_000, 2_200_000])) * (2 if SCALE > 1 else 1)
         self.kind = ["camera", "bounce", "shadow", "random"][int(rng.integers(0, 4))]
         self.cam = camera_rays(rng, self.lo, self.hi, n_min)
         self.n = self.cam.shape[0]
