@@ -870,7 +870,7 @@ def compact_line(full, detail_file=None):
         optional.append(("config2", {"layout": "BVH_GPU", "rays": c2.get("rays"), "mrays": _r(c2.get("bvh_gpu_mrays"), 1), "ref_opencl_mrays": _r(c2.get("ref_opencl_mrays"), 1) if isinstance(c2.get("ref_opencl_mrays"), float) else None}))
     t5 = d.get("tlas_1000_instances")
     if t5 and "error" not in t5:
-        optional.append(("config5", {"camera_mrays": _r(t5.get("camera_mrays"), 1), "tlas_rebuild_ms": _r(t5.get("device_tlas_rebuild_ms")), "blas_refit_ms": _r(t5.get("device_blas_refit_ms"))}))
+        optional.append(("config5", {"blas_layout": t5.get("blas_layout"), "camera_mrays": _r(t5.get("camera_mrays"), 1), "tlas_rebuild_ms": _r(t5.get("device_tlas_rebuild_ms")), "blas_refit_ms": _r(t5.get("device_blas_refit_ms"))}))
     if full.get("legs_s"):
         optional.append(("legs_s", {k: v for k, v in full["legs_s"]}))
     line["detail_file"] = detail_file
