@@ -115,8 +115,10 @@ int tbvh_wavefront_render(tbvh_wavefront* w, tbvh_scene* scene, const void* dVer
     c->skipTiming = true;
     for (uint32_t d = 0; d < maxDepth; d++) {
         const int nxt = cur ^ 1;
-        // Extend: nearest hit of every live path; the batch size lives on the device
-        if (int r = launchQuery(scene, w->rays[cur], w->n, nullptr, false, 1e30f, QP(d))) return r;
+        // Extend: nearest hit of every live path; the batch size lives on the device — except at depth 0, where it is the n camera rays k_wf_generate
+        // made: that launch goes out with a size the host knows, so it is probed, sampled by the scene's schedule tuner and traced by the kernel the
+        // tuner settles on (the packet kernel on most scenes: capi_query.hip) like any camera batch
+        if (int r = launchQuery(scene, w->rays[cur], w->n, nullptr, false, 1e30f, d == 0 ? nullptr : QP(d))) return r;
         ShadeArgs a;
         a.in = w->rays[cur]; a.auxIn = w->aux[cur]; a.nIn = QP(d);
         a.out = w->rays[nxt]; a.auxOut = w->aux[nxt]; a.nOut = QP(d + 1);

@@ -20,7 +20,7 @@ cams = scenes.STREET_CAMERAS if name == "bistro" else scenes.SPONZA_CAMERAS
 cam = R.camera(*cams[0], W, H, 1, 1)
 wf = tb.Wavefront(ctx, W, H)
 light = (0.0, 0.9 * float(verts[:, 1].max()), 0.0)
-for f in range(4):
+for f in range(int(os.environ.get("FRAMES", "4"))):
     st = wf.render(sc, d_verts, cam, light, (3000.0, 3000.0, 3000.0), max_depth=3, seed=f + 1)
     total = sum(st["extend_rays"]) + sum(st["shadow_rays"])
     print(f"frame {f}: {label}: extend {st['extend_rays']} shadow {st['shadow_rays']}  {st['frame_ms']:.2f} ms  -> {total / st['frame_ms'] / 1e3:.0f} MRays/s all stages", flush=True)
