@@ -340,7 +340,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     q.fresh = fresh ? 1u : 0u; q.freshTmax = freshTmax; q.nRaysDev = nDev; q.omm = Omm{s->opmap, s->opmapN};
     q.probe = nullptr; q.baseBlocks = 0; q.hybridK = s->hybridK; q.flags = 0u;
 #ifdef TBVH_EXPERIMENTS
-    q.flags = c->expFlags & 0xF70001u;
+    q.flags = c->expFlags & 0x3FF0001u;
 #endif
     c->lastProbed = false;
     q.splitBelow = c->splitBelow;

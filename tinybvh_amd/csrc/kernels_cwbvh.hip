@@ -171,6 +171,24 @@ __global__ __launch_bounds__(WG, (STEAL || TRI2 || (SPEC && PROBED == 2)) ? MINW
 
         bool done = false;
         if (tail && grp >= 0) split_poll<ANYHIT>(split, grp, hit, done);   // a split ray: bounded by its group's closest hit
+        // PREF (TRI2 == 2, experiment): the node a lane will visit in THIS pass is known before its triangle test — the next pending child, or the top of
+        // the stack; a triangle hit changes what the node's children are tested against, not which node is fetched — so its five loads go out ahead of
+        // the triangle phase and the two memory round trips of a pass overlap (strict schedule only: a lane takes its node step iff at most one triangle
+        // of its group is left).
+        constexpr bool PREF = TRI2 == 2 && !SPEC && PROBED != 1;
+        bool preHave = false;
+        CwNode preNode;
+        uint32_t preCi = 0;
+        if (PREF && !done && __popc(tg.y) <= 1) {
+            bool have = cw_has_child(ng);
+            if (!have && !st.empty()) { ng = st.pop(); have = true; }
+            if (have) {
+                preCi = cw_next_child(ng, oct);
+                if (cw_has_child(ng)) st.push(ng);
+                preNode = cw_load_node<NSTRIDE>(nodes, preCi, hybridK);
+                preHave = true;
+            }
+        }
         // ---- triangle phase: runs when enough lanes have a triangle pending, or when no lane could use a node
         // phase instead (so a waiting lane always makes progress) --------------------------------------------
         const bool spec = PROBED == 1 ? coh : SPEC;   // (PROBED == 3 is launched with SPEC = true)
@@ -197,7 +215,7 @@ __global__ __launch_bounds__(WG, (STEAL || TRI2 || (SPEC && PROBED == 2)) ? MINW
             // order immaterial for the record.
             // (gate, flags bits 20..23: only when at least that many lanes of the wave hold a second triangle — the second test is issued for the
             // whole wave whenever ONE lane wants it)
-            const bool two = TRI2 && tg.y != 0 && (((q.flags >> 20) & 15u) == 0u || wave_count(tg.y != 0) >= ((q.flags >> 20) & 15u));
+            const bool two = TRI2 == 1 && tg.y != 0 && (((q.flags >> 20) & 15u) == 0u || wave_count(tg.y != 0) >= ((q.flags >> 20) & 15u));
             float4 f2 = make_float4(0, 0, 0, 0), f1 = f2, w0 = f2;
             if (two) {
                 const uint32_t tj = 31u - (uint32_t)__clz(tg.y);
@@ -210,7 +228,7 @@ __global__ __launch_bounds__(WG, (STEAL || TRI2 || (SPEC && PROBED == 2)) ? MINW
             // +7 % on the Bistro and Sponza stand-ins, +7-10 % on 12 M triangles, camera and shadow rays +-1 % (profiles/r04_ab_triangle_loads_together.txt).
             // The deferred + gated schedule keeps the lazy load: -2 % with the loads together (its triangle phases are full of L2 hits, the saved
             // registers are worth more).
-            if ((!SPEC || PROBED == 2) && PROBED != 1) { tri_loads_together(v0); if (TRI2) tri_loads_together(w0); }
+            if ((!SPEC || PROBED == 2) && PROBED != 1) { tri_loads_together(v0); if (TRI2 == 1) tri_loads_together(w0); }
             TriHit h;
             if (tri_test(O, D, xyz(v0), xyz(e1), xyz(e2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(v0.w)) &&
                 (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(v0.w), found, hit))) {   // (a split ray's group arbitrates: split_publish)
@@ -219,7 +237,7 @@ __global__ __launch_bounds__(WG, (STEAL || TRI2 || (SPEC && PROBED == 2)) ? MINW
                 else hit = make_float4(h.t, h.u, h.v, v0.w);
                 if (tail && grp >= 0) split_publish<ANYHIT>(split, grp, hit);
             }
-            if (TRI2 && two && !(ANYHIT && done)) {
+            if (TRI2 == 1 && two && !(ANYHIT && done)) {
                 if (tri_test(O, D, xyz(w0), xyz(f1), xyz(f2), hit.x, h, HAS_OMM ? q.omm : Omm{nullptr, 0}, as_u32(w0.w)) &&
                     (ANYHIT || (tail && grp >= 0) || hit_wins(h.t, as_u32(w0.w), found, hit))) {
                     found = true;
@@ -231,6 +249,17 @@ __global__ __launch_bounds__(WG, (STEAL || TRI2 || (SPEC && PROBED == 2)) ? MINW
             if ((SPEC || PROBED == 1) && tg.y == 0) { tg = tg2; tg2 = make_uint2(0u, 0u); if (NSTRIDE == kNodeHybrid) tgn = tgn2; }
         }
         // ---- node phase ---------------------------------------------------------------------------------------
+        if (PREF) {
+            if (!done && tg.y == 0) {
+                if (!preHave) done = true;
+                else {
+                    const CwNodeHits r = cw_test_node(preNode, O, rD, cull_bound(hit.x), octinv4, negX, negY, negZ);
+                    ng = make_uint2(r.childBase, (r.hitmask & 0xFF000000u) | r.imask);
+                    tg = make_uint2(r.triBase, r.hitmask & 0x00FFFFFFu);
+                    if (NSTRIDE == kNodeHybrid) tgn = cw_hybrid_offset(preCi, hybridK);
+                }
+            }
+        } else
         if (!done && (spec ? tg2.y == 0 : tg.y == 0)) {
             bool have = cw_has_child(ng);
             if (!have) {
@@ -391,6 +420,10 @@ const LaunchRow kLaunchTable[] = {
     {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x10000u) && x.tail; }, &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 16, 6, 1>, false},
     {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x10000u) != 0; },      &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 0, 6, 1>, false},
     // round 6: the ray-replacement threshold of the incoherent flavor (debug flags 0x20000: 8 idle lanes, 0x40000: 32; shipped: 16) — profiles/r06_diffuse.txt
+    // (round 6, late) node loads ahead of the triangle phase (TRI2 == 2), at the register budgets of 8 / 7 / 6 waves per SIMD
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x80000u) && !x.tail; }, &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 0, 8, 2>, false},
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x1000000u) && !x.tail; }, &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 0, 7, 2>, false},
+    {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x2000000u) && !x.tail; }, &launch_both<8, 16, 1, false, 0, kNodeHybrid, 2, 0, 6, 2>, false},
     // (round 6, late) deferred triangles in the incoherent flavor, triangle phase gated at 1 / 4 / 8 / 16 lanes
     {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x100000u) && !x.tail; }, &launch_both<8, 16, 1, true, 0, kNodeHybrid, 2, 0, 7>, false},
     {[](const LaunchSel& x) { return x.nodeStride == kNodeHybrid && (x.expFlags & 0x200000u) && !x.tail; }, &launch_both<8, 16, 4, true, 0, kNodeHybrid, 2, 0, 7>, false},
