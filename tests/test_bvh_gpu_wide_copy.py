@@ -188,3 +188,42 @@ def test_a_blas_traced_only_through_a_tlas_never_pays_for_a_copy(ctx):
     blas.Intersect(R.random_rays(4096, (-20, 0, -10), (20, 15, 10), seed=3))
     assert blas.device_bytes > before                     # the first DIRECT query makes it
     tlas.free(); blas.free()
+
+
+def test_tlas_enters_bvh_gpu_blases_through_their_wide_copies(ctx, oracle):
+    """A TLAS over BVH_GPU BLASes (the reference's BLAS type for geometry that is refitted or rebuilt, traverse_tlas.cl:66-72) enters them through their
+    8-wide copies, made at the TLAS upload (capi_scene.hip: reclassifyTlas, blasView): the records are BVH::IntersectTLAS's either way; tbvh_set_variant(blas, 1)
+    puts the TLAS back on the uploaded nodes, a BLAS update is followed, a BLAS freed before its TLAS lives on with its copy."""
+    from test_tlas import grid_instances, oracle_tlas, check
+    meshes = [scenes.blob(40_000, seed=5), scenes.soup(3_000, seed=6, extent=1.6, size=0.2)]       # one with a copy, one below the threshold: the mixed kernel
+    for m in meshes:
+        m[:, :3] -= 0.5 * (m[:, :3].min(0) + m[:, :3].max(0))
+        m[:, :3] *= np.float32(1.6 / float((m[:, :3].max(0) - m[:, :3].min(0)).max()))
+    blas = [tb.BVH_GPU(ctx).Build(m) for m in meshes]
+    before = [b.device_bytes for b in blas]
+    inst = grid_instances(4, 0.5, 3, n_blas=2)
+    tlas = tb.TLAS(ctx).Build(inst, blas)
+    assert blas[0].device_bytes > before[0] and blas[1].device_bytes == before[1]
+    rays = np.concatenate([R.random_rays(60_000, (-2, -2, -2), (9, 9, 9), seed=4), R.primary(R.camera((-3.0, 4.0, -5.0), (0.5, -0.2, 0.84), 256, 256, 1, 1))])
+    want = oracle_tlas(oracle, tlas, blas, rays)
+    through_copies = tlas.Intersect(rays.copy())
+    check(through_copies, want)
+    occ = tlas.IsOccluded(rays.copy())
+    assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+    blas[0].set_variant(1)                                   # the uploaded nodes again (k_tlas2)
+    native = tlas.Intersect(rays.copy())
+    check(native, want)
+    assert np.array_equal(native.view(np.uint8), through_copies.view(np.uint8))
+    blas[0].set_variant(0)
+    assert np.array_equal(tlas.Intersect(rays.copy()).view(np.uint8), through_copies.view(np.uint8))
+    # the BLAS is rebuilt over other vertices and updated in place: the copy is made again, the TLAS follows
+    moved = np.ascontiguousarray(meshes[0][: 3 * 36_000]).copy(); moved[:, 1] *= np.float32(0.8)     # (fewer triangles: the blob fits the allocation; still enough for a copy)
+    h2 = tb.HostBVH(moved, tb.LAYOUT_BVH_GPU)
+    blas[0].Update(h2.blob(0, np.uint32, 16), h2.blob(1, np.uint32, 1), moved)
+    blas[0].host = h2
+    want2 = oracle_tlas(oracle, tlas, blas, rays)
+    check(tlas.Intersect(rays.copy()), want2)
+    # freed before its TLAS: the TLAS keeps what it traverses
+    blas[0].free()
+    check(tlas.Intersect(rays.copy()), want2)
+    tlas.free(); blas[1].free()

@@ -100,7 +100,7 @@ void freeWideCopy(tbvh_scene* s) {
 // tiny_bvh.h:4975-5048): triangle records are carried over bit for bit.  Blobs below TBVH_WIDE_COPY_MIN entries / triangles (default 32768; 0 = never)
 // keep their own kernel.  A failure here is never an error of the query: the scene then simply traces its own nodes.
 static int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris, tbvh_scene** out);
-int makeWideCopy(tbvh_scene* s) {
+static int makeWideCopyImpl(tbvh_scene* s) {
     tbvh_context* c = s->ctx;
     freeWideCopy(s);
     s->wideTried = true;
@@ -301,29 +301,69 @@ int tlasCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t
 }
 }  // namespace
 
+extern "C++" {
+namespace tbvh_capi {
+// What a TLAS traverses for BLAS b: a BVH_GPU BLAS with an 8-wide copy is entered through the copy (round 6: 1000 instances of a 100 k-triangle BLAS,
+// k_tlas8 on the copies against k_tlas2 on the uploaded nodes: camera rays +8 %, shadow rays +50 %, random rays +20 %); BVH4_GPU BLASes keep their own
+// stream under a TLAS (k_tlas4 is the fastest two-level kernel for closest hits), tbvh_set_variant(blas, 1) pins the uploaded nodes.
+static const tbvh_scene* blasView(const tbvh_scene* b) {
+    return (b->layout == TBVH_LAYOUT_BVH_GPU && b->wide && b->variant == 0) ? b->wide : b;
+}
+
+// The BLAS descriptors of TLAS t and the class of two-level kernel that serves it, from its BLASes as they are NOW (their 8-wide copies come and go:
+// tbvh_update_bvh_gpu makes a new one, tbvh_set_variant switches between copy and nodes); re-collapses the wide TLAS when the class changed.
+int reclassifyTlas(tbvh_scene* t) {
+    const size_t nBlas = t->blasList.size();
+    std::vector<BlasDesc> desc(nBlas);
+    int layout = 0;
+    bool anyBvh4 = false;
+    for (size_t i = 0; i < nBlas; i++) {
+        const tbvh_scene* b = t->blasList[i];
+        const tbvh_scene* v = blasView(b);
+        layout = i == 0 ? v->layout : (layout == v->layout ? layout : 0);   // 0: the BLASes mix layouts (traverse_tlas.cl:50-72)
+        anyBvh4 |= v->layout == TBVH_LAYOUT_BVH4_GPU;
+        desc[i].nodes = v->nodes; desc[i].tris = v->tris; desc[i].opmap = b->opmap; desc[i].opmapN = b->opmapN; desc[i].layout = (uint32_t)v->layout;
+    }
+    const bool mix = layout == 0 && !anyBvh4;
+    const bool changed = layout != t->blasLayout || mix != t->blasMixCw2;
+    t->blasLayout = layout; t->blasMixCw2 = mix;
+    if (!t->blasDesc) HIP_TRY(hipMalloc((void**)&t->blasDesc, nBlas * sizeof(BlasDesc)));
+    HIP_TRY(hipStreamSynchronize(t->ctx->stream));   // (launches in flight read the old descriptors)
+    HIP_TRY(hipMemcpy(t->blasDesc, desc.data(), nBlas * sizeof(BlasDesc), hipMemcpyHostToDevice));
+    if (changed && t->nodes) return buildTlas4(t);
+    return 0;
+}
+
+int makeWideCopy(tbvh_scene* s) {
+    const int r = makeWideCopyImpl(s);
+    for (size_t i = 0; i < s->usedBy.size(); i++) {
+        bool seen = false;
+        for (size_t k = 0; k < i; k++) seen |= s->usedBy[k] == s->usedBy[i];
+        if (!seen) (void)reclassifyTlas(s->usedBy[i]);   // (the copy's arrays are new ones — or gone)
+    }
+    return r;
+}
+}  // namespace tbvh_capi
+}  // extern "C++"
+
 int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, const uint32_t* idx, uint64_t nIdx, const void* inst,
                      uint64_t nInst, tbvh_scene* const* blas, uint64_t nBlas, tbvh_scene** out) {
     if (!c || !nodes64 || !idx || !inst || !blas || !out || !nNodes || !nIdx || !nInst || !nBlas) return fail(TBVH_E_INVALID, "tbvh_upload_tlas: null/empty argument");
-    int layout = 0;
-    std::vector<BlasDesc> desc(nBlas);
     for (uint64_t i = 0; i < nBlas; i++) {
         const tbvh_scene* b = blas[i];
         if (!b || b->ctx != c || b->isTlas || b->zombie) return fail(TBVH_E_INVALID, "BLAS %llu is null, freed, a TLAS, or from another context", (unsigned long long)i);
         if (b->layout != TBVH_LAYOUT_CWBVH && b->layout != TBVH_LAYOUT_BVH4_GPU && b->layout != TBVH_LAYOUT_BVH_GPU)
             return fail(TBVH_E_INVALID, "BLAS %llu: layout %d cannot be a BLAS", (unsigned long long)i, b->layout);
-        layout = i == 0 ? b->layout : (layout == b->layout ? layout : 0);   // 0: the BLASes mix layouts (traverse_tlas.cl:50-72)
-        desc[i].nodes = b->nodes; desc[i].tris = b->tris; desc[i].opmap = b->opmap; desc[i].opmapN = b->opmapN; desc[i].layout = (uint32_t)b->layout;
     }
     TBVH_ENTER(c);
+    for (uint64_t i = 0; i < nBlas; i++)   // BVH_GPU BLASes are entered through their 8-wide copies (blasView): made now unless a query of the BLAS has already tried
+        if (blas[i]->layout == TBVH_LAYOUT_BVH_GPU && !blas[i]->wideTried && blas[i]->variant == 0) makeWideCopy(blas[i]);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
-    s->isTlas = true; s->blasLayout = layout; s->nBlas = nBlas;
-    s->blasMixCw2 = layout == 0;
-    for (uint64_t i = 0; i < nBlas; i++) if (blas[i]->layout == TBVH_LAYOUT_BVH4_GPU) s->blasMixCw2 = false;
+    s->isTlas = true; s->nBlas = nBlas;
+    s->blasLayout = -1;   // (not classified yet)
     for (uint64_t i = 0; i < nBlas; i++) { s->blasList.push_back(blas[i]); blas[i]->usedBy.push_back(s); }
-    hipError_t e = hipMalloc((void**)&s->blasDesc, nBlas * sizeof(BlasDesc));
-    if (e == hipSuccess) e = hipMemcpy(s->blasDesc, desc.data(), nBlas * sizeof(BlasDesc), hipMemcpyHostToDevice);
-    if (e != hipSuccess) { tbvh_free_scene(s); return fail(TBVH_E_HIP, "TLAS upload failed: %s", hipGetErrorString(e)); }
+    if (int r = reclassifyTlas(s)) { tbvh_free_scene(s); return r; }
     if (int r = tlasCopy(s, nodes64, nNodes, idx, nIdx, inst, nInst)) { tbvh_free_scene(s); return r; }
     *out = s;
     return 0;
@@ -560,12 +600,11 @@ int tbvh_build_device_ploc(tbvh_context* c, const void* verts16, uint64_t nTris,
 namespace {
 // the TLASes over BLAS b hold a snapshot of its device pointers: rewrite their entries for b
 int refreshBlasDescs(tbvh_scene* b) {
-    for (tbvh_scene* t : b->usedBy)
-        for (size_t i = 0; i < t->blasList.size(); i++)
-            if (t->blasList[i] == b) {
-                BlasDesc d; d.nodes = b->nodes; d.tris = b->tris; d.opmap = b->opmap; d.opmapN = b->opmapN; d.layout = (uint32_t)b->layout;
-                HIP_TRY(hipMemcpy(t->blasDesc + i, &d, sizeof d, hipMemcpyHostToDevice));
-            }
+    for (size_t i = 0; i < b->usedBy.size(); i++) {
+        bool seen = false;
+        for (size_t k = 0; k < i; k++) seen |= b->usedBy[k] == b->usedBy[i];
+        if (!seen) if (int r = reclassifyTlas(b->usedBy[i])) return r;
+    }
     return 0;
 }
 }  // namespace
@@ -828,7 +867,9 @@ int tbvh_set_variant(tbvh_scene* s, int v) {
     // ... and BVH_GPU / BVH4_GPU scenes one: 1 = trace the nodes as uploaded (k_bvh2 / k_bvh4) even when the scene has an 8-wide copy (tests, A/B)
     const bool ok = v == 0 || (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH && cwbvh_variant_valid(v)) || (!s->isTlas && (s->layout == TBVH_LAYOUT_BVH_GPU || s->layout == TBVH_LAYOUT_BVH4_GPU) && v == 1);
     if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
+    const bool viewChanges = !s->isTlas && s->layout == TBVH_LAYOUT_BVH_GPU && s->wide && (s->variant == 0) != (v == 0);
     s->variant = v;
+    if (viewChanges) return refreshBlasDescs(s);   // (the TLASes over this BLAS enter it through the copy, or through its own nodes)
     return 0;
 }
 
