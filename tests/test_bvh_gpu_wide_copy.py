@@ -174,20 +174,40 @@ def test_library_built_bvh4_scene_refit_and_micromaps(ctx, oracle):
     sc.free()
 
 
-def test_a_blas_traced_only_through_a_tlas_never_pays_for_a_copy(ctx):
-    from test_tlas import grid_instances
-    verts = scenes.atrium(60_000, seed=3)
-    blas = tb.BVH4_GPU(ctx).Build(verts)
+def test_tlas_any_hit_queries_enter_bvh4_blases_through_their_copies(ctx, oracle):
+    """BVH4_GPU BLASes under a TLAS: Intersect walks their own streams (k_tlas4), IsOccluded their 8-wide copies (k_tlas8; capi_scene.hip: reclassifyTlas) —
+    made by the TLAS upload for BLASes of 32 k triangles and more; a small BLAS next to a large one keeps every query on the uploaded streams."""
+    from test_tlas import grid_instances, oracle_tlas, check
+    mesh = scenes.blob(40_000, seed=7)
+    mesh[:, :3] -= 0.5 * (mesh[:, :3].min(0) + mesh[:, :3].max(0))
+    mesh[:, :3] *= np.float32(1.6 / float((mesh[:, :3].max(0) - mesh[:, :3].min(0)).max()))
+    blas = tb.BVH4_GPU(ctx).Build(mesh)
     before = blas.device_bytes
-    tlas = tb.TLAS(ctx).Build(grid_instances(2, 0.05, 1), [blas])
-    got = tlas.Intersect(R.random_rays(20_000, (-1, -1, -1), (3, 3, 3), seed=2))
-    assert (got["t"] < 1e30).sum() > 100
-    assert blas.device_bytes == before                    # still only the uploaded stream
-    blas.Refit(verts)                                     # ... and a refit has no copy to follow
-    assert blas.device_bytes == before
-    blas.Intersect(R.random_rays(4096, (-20, 0, -10), (20, 15, 10), seed=3))
-    assert blas.device_bytes > before                     # the first DIRECT query makes it
-    tlas.free(); blas.free()
+    inst = grid_instances(4, 0.5, 3)
+    tlas = tb.TLAS(ctx).Build(inst, [blas])
+    assert blas.device_bytes > before                      # the copy IsOccluded walks
+    rays = np.concatenate([R.random_rays(60_000, (-2, -2, -2), (9, 9, 9), seed=4), R.primary(R.camera((-3.0, 4.0, -5.0), (0.5, -0.2, 0.84), 256, 256, 1, 1))])
+    want = oracle_tlas(oracle, tlas, [blas], rays)
+    check(tlas.Intersect(rays.copy()), want)
+    occ = tlas.IsOccluded(rays.copy())
+    assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+    blas.set_variant(1)                                     # the uploaded stream for every query
+    occ_native = tlas.IsOccluded(rays.copy())
+    assert int((occ != occ_native).sum()) <= 2
+    blas.set_variant(0)
+    assert np.array_equal(tlas.IsOccluded(rays.copy()), occ)
+    blas.Refit(mesh)                                        # both forms follow a refit
+    assert np.array_equal(tlas.IsOccluded(rays.copy()), occ)
+    check(tlas.Intersect(rays.copy()), want)
+    tlas.free()
+    small = tb.BVH4_GPU(ctx).Build(scenes.soup(2_000, seed=9, extent=1.6, size=0.2))
+    small_before = small.device_bytes
+    tlas2 = tb.TLAS(ctx).Build(grid_instances(3, 0.5, 5, n_blas=2), [blas, small])
+    assert small.device_bytes == small_before
+    want2 = oracle_tlas(oracle, tlas2, [blas, small], rays)
+    check(tlas2.Intersect(rays.copy()), want2)
+    assert int((tlas2.IsOccluded(rays.copy()).astype(bool) != (want2["t"] < 1e30)).sum()) <= 2
+    tlas2.free(); blas.free(); small.free()
 
 
 def test_tlas_enters_bvh_gpu_blases_through_their_wide_copies(ctx, oracle):

@@ -154,6 +154,11 @@ struct tbvh_scene {
     BlasDesc* blasDesc = nullptr;
     int blasLayout = 0;
     bool blasMixCw2 = false;          // blasLayout == 0 and every BLAS is BVH8_CWBVH or BVH_GPU: the reference's two BLAS types (traverse_tlas.cl:50-72)
+    // any-hit queries may enter the BLASes through other arrays than closest-hit ones (BVH4_GPU BLASes: their own stream for closest hits — k_tlas4 —, their
+    // 8-wide copies for IsOccluded — k_tlas8, + 28 % on 1000 instances —: capi_scene.hip: reclassifyTlas); blasDescAny == nullptr: the same as above
+    BlasDesc* blasDescAny = nullptr;
+    int blasLayoutAny = -1;
+    bool blasMixCw2Any = false;
     uint64_t capNodes = 0, capIdx = 0, capInst = 0;
     uint64_t nInst = 0, nBlas = 0, nTlasNodes = 0, nTlasIdx = 0;
     // the same TLAS collapsed 4-wide in the BVH4_GPU node format (kernels_tlas4.hip), kept current by every upload / update / device rebuild;

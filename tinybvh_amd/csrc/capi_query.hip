@@ -212,18 +212,23 @@ int hostQuery(tbvh_scene* s, const char* raysIn, char* raysOut, uint64_t n, uint
 static void launchTlasKernels(tbvh_scene* s, QueryArgs& q, bool any, uint32_t blocks) {
     tbvh_context* c = s->ctx;
     const uint32_t blocks7 = (!c->gridOverride && blocks == c->blocks) ? (uint32_t)c->numCUs * 28u : blocks;   // the full grid of the kernels built for 7 waves per SIMD
-    if (s->tlas4 && s->blasLayout == TBVH_LAYOUT_BVH4_GPU) {   // BVH4_GPU BLASes: the unified 4-wide kernel
+    // any-hit queries may have a class of their own (capi_scene.hip: reclassifyTlas)
+    const bool own = any && s->blasDescAny != nullptr;
+    const int layout = own ? s->blasLayoutAny : s->blasLayout;
+    const bool mix = own ? s->blasMixCw2Any : s->blasMixCw2;
+    const BlasDesc* desc = own ? s->blasDescAny : s->blasDesc;
+    if (s->tlas4 && layout == TBVH_LAYOUT_BVH4_GPU) {   // BVH4_GPU BLASes: the unified 4-wide kernel
         q.spillStride = c->spillEntries;   // 32-bit stack entries
-        launch_tlas4(any, 0, s->tlas4, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
-    } else if (s->tlas8 && (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2)) {   // BVH8_CWBVH BLASes (or those and BVH_GPU ones): the unified 8-wide kernel
+        launch_tlas4(any, 0, s->tlas4, s->instances, desc, q, c->status, blocks, c->stream, blocks7);
+    } else if (s->tlas8 && (layout == TBVH_LAYOUT_CWBVH || mix)) {   // BVH8_CWBVH BLASes (or those and BVH_GPU ones): the unified 8-wide kernel
         q.spillStride = c->spillEntries / 2;   // 8-byte stack entries
-        launch_tlas8(any, 0, s->tlas8, s->tlas8Refs, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7, s->blasMixCw2);
-    } else if (s->blasLayout == TBVH_LAYOUT_BVH_GPU) {   // BVH_GPU BLASes: the TLAS already has their node format (kernels_tlas2.hip)
+        launch_tlas8(any, 0, s->tlas8, s->tlas8Refs, s->instances, desc, q, c->status, blocks, c->stream, blocks7, mix);
+    } else if (layout == TBVH_LAYOUT_BVH_GPU) {   // BVH_GPU BLASes: the TLAS already has their node format (kernels_tlas2.hip)
         q.spillStride = c->spillEntries;
-        launch_tlas2(any, 0, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream, blocks7);
+        launch_tlas2(any, 0, s->nodes, s->tlasIdx, s->instances, desc, q, c->status, blocks, c->stream, blocks7);
     } else {
         q.spillStride = c->spillEntries / 2;
-        launch_tlas(any, s->blasLayout, s->nodes, s->tlasIdx, s->instances, s->blasDesc, q, c->status, blocks, c->stream);
+        launch_tlas(any, layout, s->nodes, s->tlasIdx, s->instances, desc, q, c->status, blocks, c->stream);
     }
 }
 

@@ -222,40 +222,42 @@ int tbvh_upload_cwbvh(tbvh_context* c, const void* nodes16, uint64_t nNodeBlocks
 }
 
 namespace {
-// (re)build the 4-wide TLAS from the BVH_GPU nodes on the device; asynchronous on the context's stream
-int buildTlas4(tbvh_scene* s) {
+// (re)build the wide TLAS(es) from the BVH_GPU nodes on the device — 8-wide in the BVH8_CWBVH node format, 4-wide in the BVH4_GPU one, whichever the
+// two-level kernels of this TLAS's closest-hit and any-hit queries walk; asynchronous on the context's stream
+int buildTlasWide8(tbvh_scene* s) {
     tbvh_context* c = s->ctx;
-    if (s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2) {
-        const uint64_t cap = tlas8_cap_nodes(s->nTlasNodes, s->nInst);
-        if (cap > 0x00ffffffull) {   // wide-node indices share a word with 8 flag bits in places: the flat loop serves larger TLASes — and a wide
-            // TLAS left from an earlier, smaller upload must not be traversed in its place (launchQuery keys on the pointer)
-            if (s->tlas8) hipFree(s->tlas8);
-            if (s->tlas8Refs) hipFree(s->tlas8Refs);
-            s->tlas8 = nullptr; s->tlas8Refs = nullptr; s->tlas8Cap = 0;
-            return 0;
-        }
-        if (cap > s->tlas8Cap) {
-            if (s->tlas8) hipFree(s->tlas8);
-            if (s->tlas8Refs) hipFree(s->tlas8Refs);
-            s->tlas8 = nullptr; s->tlas8Refs = nullptr; s->tlas8Cap = 0;
-            HIP_TRY(hipMalloc((void**)&s->tlas8, cap * 80));
-            HIP_TRY(hipMalloc((void**)&s->tlas8Refs, cap * 4));
-            s->tlas8Cap = cap;
-            s->bytes += cap * 84;
-        }
-        const size_t sb = tlas_wide_scratch_bytes(s->nTlasNodes, s->nInst);
-        if (sb > s->tlas4ScratchBytes) {
-            if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
-            s->tlas4Scratch = nullptr; s->tlas4ScratchBytes = 0;
-            HIP_TRY(hipMalloc(&s->tlas4Scratch, sb));
-            s->tlas4ScratchBytes = sb;
-        }
-        launch_tlas8_build(s->nodes, (uint32_t)s->nTlasNodes, s->tlasIdx, (uint32_t)s->nTlasIdx, s->instances, (uint32_t)s->nInst, s->tlas8, (uint32_t)s->tlas8Cap, s->tlas8Refs,
-                           (uint32_t)s->tlas8Cap, s->tlas4Scratch, c->status, c->stream);
-        HIP_TRY(hipGetLastError());
+    const uint64_t cap = tlas8_cap_nodes(s->nTlasNodes, s->nInst);
+    if (cap > 0x00ffffffull) {   // wide-node indices share a word with 8 flag bits in places: the flat loop serves larger TLASes — and a wide
+        // TLAS left from an earlier, smaller upload must not be traversed in its place (launchQuery keys on the pointer)
+        if (s->tlas8) hipFree(s->tlas8);
+        if (s->tlas8Refs) hipFree(s->tlas8Refs);
+        s->tlas8 = nullptr; s->tlas8Refs = nullptr; s->tlas8Cap = 0;
         return 0;
     }
-    if (s->blasLayout != TBVH_LAYOUT_BVH4_GPU) return 0;
+    if (cap > s->tlas8Cap) {
+        if (s->tlas8) hipFree(s->tlas8);
+        if (s->tlas8Refs) hipFree(s->tlas8Refs);
+        s->tlas8 = nullptr; s->tlas8Refs = nullptr; s->tlas8Cap = 0;
+        HIP_TRY(hipMalloc((void**)&s->tlas8, cap * 80));
+        HIP_TRY(hipMalloc((void**)&s->tlas8Refs, cap * 4));
+        s->tlas8Cap = cap;
+        s->bytes += cap * 84;
+    }
+    const size_t sb = tlas_wide_scratch_bytes(s->nTlasNodes, s->nInst);
+    if (sb > s->tlas4ScratchBytes) {
+        if (s->tlas4Scratch) hipFree(s->tlas4Scratch);
+        s->tlas4Scratch = nullptr; s->tlas4ScratchBytes = 0;
+        HIP_TRY(hipMalloc(&s->tlas4Scratch, sb));
+        s->tlas4ScratchBytes = sb;
+    }
+    launch_tlas8_build(s->nodes, (uint32_t)s->nTlasNodes, s->tlasIdx, (uint32_t)s->nTlasIdx, s->instances, (uint32_t)s->nInst, s->tlas8, (uint32_t)s->tlas8Cap, s->tlas8Refs,
+                       (uint32_t)s->tlas8Cap, s->tlas4Scratch, c->status, c->stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int buildTlasWide4(tbvh_scene* s) {
+    tbvh_context* c = s->ctx;
     const uint64_t cap = tlas4_cap_blocks(s->nTlasNodes, s->nInst);
     if (cap > 0x7fffffffull) {   // beyond 31-bit block offsets: the flat loop serves this TLAS; drop a 4-wide TLAS of an earlier, smaller upload
         if (s->tlas4) hipFree(s->tlas4);
@@ -278,6 +280,15 @@ int buildTlas4(tbvh_scene* s) {
     }
     launch_tlas4_build(s->nodes, (uint32_t)s->nTlasNodes, s->tlasIdx, (uint32_t)s->nTlasIdx, s->instances, (uint32_t)s->nInst, s->tlas4, (uint32_t)s->tlas4Cap, s->tlas4Scratch, c->status, c->stream);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int buildTlas4(tbvh_scene* s) {
+    const bool any2 = s->blasDescAny != nullptr;
+    const bool want8 = s->blasLayout == TBVH_LAYOUT_CWBVH || s->blasMixCw2 || (any2 && (s->blasLayoutAny == TBVH_LAYOUT_CWBVH || s->blasMixCw2Any));
+    const bool want4 = s->blasLayout == TBVH_LAYOUT_BVH4_GPU || (any2 && s->blasLayoutAny == TBVH_LAYOUT_BVH4_GPU);
+    if (want8) if (int r = buildTlasWide8(s)) return r;   // (the two builds share the scratch area: in order on one stream)
+    if (want4) if (int r = buildTlasWide4(s)) return r;
     return 0;
 }
 
@@ -304,33 +315,48 @@ int tlasCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t
 extern "C++" {
 namespace tbvh_capi {
 // What a TLAS traverses for BLAS b: a BVH_GPU BLAS with an 8-wide copy is entered through the copy (round 6: 1000 instances of a 100 k-triangle BLAS,
-// k_tlas8 on the copies against k_tlas2 on the uploaded nodes: camera rays +8 %, shadow rays +50 %, random rays +20 %); BVH4_GPU BLASes keep their own
-// stream under a TLAS (k_tlas4 is the fastest two-level kernel for closest hits), tbvh_set_variant(blas, 1) pins the uploaded nodes.
-static const tbvh_scene* blasView(const tbvh_scene* b) {
-    return (b->layout == TBVH_LAYOUT_BVH_GPU && b->wide && b->variant == 0) ? b->wide : b;
+// k_tlas8 on the copies against k_tlas2 on the uploaded nodes: camera rays +5 %, shadow rays +47 %, random rays +16 %); BVH4_GPU BLASes keep their own
+// stream for closest hits (k_tlas4 is the fastest two-level kernel there) and are entered through their copies by any-hit queries; tbvh_set_variant(blas, 1)
+// pins the uploaded nodes.
+static const tbvh_scene* blasView(const tbvh_scene* b, bool any) {
+    const bool viaCopy = b->wide && b->variant == 0 && (b->layout == TBVH_LAYOUT_BVH_GPU || (any && b->layout == TBVH_LAYOUT_BVH4_GPU));
+    return viaCopy ? b->wide : b;
 }
 
 // The BLAS descriptors of TLAS t and the class of two-level kernel that serves it, from its BLASes as they are NOW (their 8-wide copies come and go:
-// tbvh_update_bvh_gpu makes a new one, tbvh_set_variant switches between copy and nodes); re-collapses the wide TLAS when the class changed.
+// tbvh_update_bvh_gpu makes a new one, tbvh_set_variant switches between copy and nodes); builds the wide TLAS(es) those kernels walk.
+// Closest-hit and any-hit queries are classified separately: BVH4_GPU BLASes are entered through their own stream by Intersect (k_tlas4: the fastest
+// two-level kernel for closest hits) and through their 8-wide copies by IsOccluded (k_tlas8: 1000 instances, shadow rays 4460 -> 5700 MRays/s).
 int reclassifyTlas(tbvh_scene* t) {
     const size_t nBlas = t->blasList.size();
-    std::vector<BlasDesc> desc(nBlas);
-    int layout = 0;
-    bool anyBvh4 = false;
-    for (size_t i = 0; i < nBlas; i++) {
-        const tbvh_scene* b = t->blasList[i];
-        const tbvh_scene* v = blasView(b);
-        layout = i == 0 ? v->layout : (layout == v->layout ? layout : 0);   // 0: the BLASes mix layouts (traverse_tlas.cl:50-72)
-        anyBvh4 |= v->layout == TBVH_LAYOUT_BVH4_GPU;
-        desc[i].nodes = v->nodes; desc[i].tris = v->tris; desc[i].opmap = b->opmap; desc[i].opmapN = b->opmapN; desc[i].layout = (uint32_t)v->layout;
+    std::vector<BlasDesc> desc[2] = {std::vector<BlasDesc>(nBlas), std::vector<BlasDesc>(nBlas)};
+    int layout[2] = {0, 0};
+    bool mix[2], same = true;
+    for (int any = 0; any < 2; any++) {
+        bool anyBvh4 = false;
+        for (size_t i = 0; i < nBlas; i++) {
+            const tbvh_scene* b = t->blasList[i];
+            const tbvh_scene* v = blasView(b, any != 0);
+            layout[any] = i == 0 ? v->layout : (layout[any] == v->layout ? layout[any] : 0);   // 0: the BLASes mix layouts (traverse_tlas.cl:50-72)
+            anyBvh4 |= v->layout == TBVH_LAYOUT_BVH4_GPU;
+            desc[any][i].nodes = v->nodes; desc[any][i].tris = v->tris; desc[any][i].opmap = b->opmap; desc[any][i].opmapN = b->opmapN; desc[any][i].layout = (uint32_t)v->layout;
+            if (any) same &= desc[1][i].nodes == desc[0][i].nodes;
+        }
+        mix[any] = layout[any] == 0 && !anyBvh4;
     }
-    const bool mix = layout == 0 && !anyBvh4;
-    const bool changed = layout != t->blasLayout || mix != t->blasMixCw2;
-    t->blasLayout = layout; t->blasMixCw2 = mix;
+    // a class of its own for any-hit queries only where it is served by the 8-wide kernel (some BVH4_GPU BLASes with a copy and some without would
+    // take the flat loop: then IsOccluded stays with Intersect's arrays)
+    const bool any2 = !same && (layout[1] == TBVH_LAYOUT_CWBVH || mix[1]);
+    t->blasLayout = layout[0]; t->blasMixCw2 = mix[0];
+    t->blasLayoutAny = any2 ? layout[1] : -1; t->blasMixCw2Any = any2 && mix[1];
     if (!t->blasDesc) HIP_TRY(hipMalloc((void**)&t->blasDesc, nBlas * sizeof(BlasDesc)));
     HIP_TRY(hipStreamSynchronize(t->ctx->stream));   // (launches in flight read the old descriptors)
-    HIP_TRY(hipMemcpy(t->blasDesc, desc.data(), nBlas * sizeof(BlasDesc), hipMemcpyHostToDevice));
-    if (changed && t->nodes) return buildTlas4(t);
+    HIP_TRY(hipMemcpy(t->blasDesc, desc[0].data(), nBlas * sizeof(BlasDesc), hipMemcpyHostToDevice));
+    if (any2) {
+        if (!t->blasDescAny) HIP_TRY(hipMalloc((void**)&t->blasDescAny, nBlas * sizeof(BlasDesc)));
+        HIP_TRY(hipMemcpy(t->blasDescAny, desc[1].data(), nBlas * sizeof(BlasDesc), hipMemcpyHostToDevice));
+    } else if (t->blasDescAny) { hipFree(t->blasDescAny); t->blasDescAny = nullptr; }
+    if (t->nodes) return buildTlas4(t);
     return 0;
 }
 
@@ -356,8 +382,8 @@ int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, cons
             return fail(TBVH_E_INVALID, "BLAS %llu: layout %d cannot be a BLAS", (unsigned long long)i, b->layout);
     }
     TBVH_ENTER(c);
-    for (uint64_t i = 0; i < nBlas; i++)   // BVH_GPU BLASes are entered through their 8-wide copies (blasView): made now unless a query of the BLAS has already tried
-        if (blas[i]->layout == TBVH_LAYOUT_BVH_GPU && !blas[i]->wideTried && blas[i]->variant == 0) makeWideCopy(blas[i]);
+    for (uint64_t i = 0; i < nBlas; i++)   // BVH_GPU BLASes — and BVH4_GPU ones by any-hit queries — are entered through their 8-wide copies (blasView): made now unless a query of the BLAS has already tried
+        if ((blas[i]->layout == TBVH_LAYOUT_BVH_GPU || blas[i]->layout == TBVH_LAYOUT_BVH4_GPU) && !blas[i]->wideTried && blas[i]->variant == 0) makeWideCopy(blas[i]);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
     s->isTlas = true; s->nBlas = nBlas;
@@ -799,6 +825,7 @@ void tbvh_free_scene(tbvh_scene* s) {
     if (s->tlasIdx) hipFree(s->tlasIdx);
     if (s->instances) hipFree(s->instances);
     if (s->blasDesc) hipFree(s->blasDesc);
+    if (s->blasDescAny) hipFree(s->blasDescAny);
     if (s->blasBounds) hipFree(s->blasBounds);
     if (s->xformStage) hipFree(s->xformStage);
     if (s->buildScratch) hipFree(s->buildScratch);
@@ -867,7 +894,7 @@ int tbvh_set_variant(tbvh_scene* s, int v) {
     // ... and BVH_GPU / BVH4_GPU scenes one: 1 = trace the nodes as uploaded (k_bvh2 / k_bvh4) even when the scene has an 8-wide copy (tests, A/B)
     const bool ok = v == 0 || (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH && cwbvh_variant_valid(v)) || (!s->isTlas && (s->layout == TBVH_LAYOUT_BVH_GPU || s->layout == TBVH_LAYOUT_BVH4_GPU) && v == 1);
     if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
-    const bool viewChanges = !s->isTlas && s->layout == TBVH_LAYOUT_BVH_GPU && s->wide && (s->variant == 0) != (v == 0);
+    const bool viewChanges = !s->isTlas && (s->layout == TBVH_LAYOUT_BVH_GPU || s->layout == TBVH_LAYOUT_BVH4_GPU) && s->wide && (s->variant == 0) != (v == 0);
     s->variant = v;
     if (viewChanges) return refreshBlasDescs(s);   // (the TLASes over this BLAS enter it through the copy, or through its own nodes)
     return 0;
