@@ -157,6 +157,8 @@ struct tbvh_scene {
     // any-hit queries may enter the BLASes through other arrays than closest-hit ones (BVH4_GPU BLASes: their own stream for closest hits — k_tlas4 —, their
     // 8-wide copies for IsOccluded — k_tlas8, + 28 % on 1000 instances —: capi_scene.hip: reclassifyTlas); blasDescAny == nullptr: the same as above
     BlasDesc* blasDescAny = nullptr;
+    bool anyHitSeen = false;          // the TLAS has had an any-hit query: only then do its BVH4_GPU BLASes get their copies and the second wide tree is kept (a frame loop that only
+                                      // ever calls Intersect pays for neither: per frame the second tree's rebuild and the copies' refit cost 0.27 ms at 1000 instances)
     int blasLayoutAny = -1;
     bool blasMixCw2Any = false;
     uint64_t capNodes = 0, capIdx = 0, capInst = 0;
@@ -294,5 +296,6 @@ size_t hybridBytes(uint32_t nNodes, uint32_t K);
 bool wantsIncoherentCopies(const tbvh_scene* s);
 int prepareIncoherentCopies(tbvh_scene* s);
 void freeWideCopy(tbvh_scene* s);
+int reclassifyTlas(tbvh_scene* t);   // (capi_scene.hip) descriptors, kernel class and wide trees of a TLAS from its BLASes as they are now
 int makeWideCopy(tbvh_scene* s);   // (lazily, from launchQuery) the 8-wide copy of a BVH_GPU / BVH4_GPU scene   // (lazily, from launchQuery) hybrid node copy + 64-byte triangle records for incoherent batches
 }  // namespace tbvh_capi

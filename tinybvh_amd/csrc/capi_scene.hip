@@ -346,7 +346,7 @@ int reclassifyTlas(tbvh_scene* t) {
     }
     // a class of its own for any-hit queries only where it is served by the 8-wide kernel (some BVH4_GPU BLASes with a copy and some without would
     // take the flat loop: then IsOccluded stays with Intersect's arrays)
-    const bool any2 = !same && (layout[1] == TBVH_LAYOUT_CWBVH || mix[1]);
+    const bool any2 = t->anyHitSeen && !same && (layout[1] == TBVH_LAYOUT_CWBVH || mix[1]);
     t->blasLayout = layout[0]; t->blasMixCw2 = mix[0];
     t->blasLayoutAny = any2 ? layout[1] : -1; t->blasMixCw2Any = any2 && mix[1];
     if (!t->blasDesc) HIP_TRY(hipMalloc((void**)&t->blasDesc, nBlas * sizeof(BlasDesc)));
@@ -382,8 +382,9 @@ int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, cons
             return fail(TBVH_E_INVALID, "BLAS %llu: layout %d cannot be a BLAS", (unsigned long long)i, b->layout);
     }
     TBVH_ENTER(c);
-    for (uint64_t i = 0; i < nBlas; i++)   // BVH_GPU BLASes — and BVH4_GPU ones by any-hit queries — are entered through their 8-wide copies (blasView): made now unless a query of the BLAS has already tried
-        if ((blas[i]->layout == TBVH_LAYOUT_BVH_GPU || blas[i]->layout == TBVH_LAYOUT_BVH4_GPU) && !blas[i]->wideTried && blas[i]->variant == 0) makeWideCopy(blas[i]);
+    for (uint64_t i = 0; i < nBlas; i++)   // BVH_GPU BLASes are entered through their 8-wide copies (blasView): made now unless a query of the BLAS has already tried; BVH4_GPU BLASes get
+                                           // theirs when the TLAS has its first any-hit query (launchQuery)
+        if (blas[i]->layout == TBVH_LAYOUT_BVH_GPU && !blas[i]->wideTried && blas[i]->variant == 0) makeWideCopy(blas[i]);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
     s->isTlas = true; s->nBlas = nBlas;
