@@ -248,3 +248,37 @@ def test_tlas_enters_bvh_gpu_blases_through_their_wide_copies(ctx, oracle):
     blas[0].free()
     check(tlas.Intersect(rays.copy()), want2)
     tlas.free(); blas[1].free()
+
+
+def test_tlas_closest_hit_queries_enter_cwbvh_blases_through_4_wide_copies(ctx, oracle):
+    """BVH8_CWBVH BLASes under a TLAS (the configuration of tiny_bvh_gpu2.cpp): Intersect walks 4-wide copies (k_tlas4; host_builder.cpp: cwbvh_to_bvh2 + the device
+    converter in record mode), IsOccluded the uploaded nodes (k_tlas8).  Records are IntersectTLAS's; a forced variant on the BLAS pins the uploaded nodes for
+    every query; tbvh_update_cwbvh and tbvh_refit are followed."""
+    from test_tlas import grid_instances, oracle_tlas, check
+    from test_refit_device import deform
+    mesh = scenes.blob(40_000, seed=11)
+    mesh[:, :3] -= 0.5 * (mesh[:, :3].min(0) + mesh[:, :3].max(0))
+    mesh[:, :3] *= np.float32(1.6 / float((mesh[:, :3].max(0) - mesh[:, :3].min(0)).max()))
+    blas = tb.BVH8_CWBVH(ctx).Build(mesh)
+    before = blas.device_bytes
+    tlas = tb.TLAS(ctx).Build(grid_instances(4, 0.5, 3), [blas])
+    assert blas.device_bytes > before
+    rays = np.concatenate([R.random_rays(60_000, (-2, -2, -2), (9, 9, 9), seed=4), R.primary(R.camera((-3.0, 4.0, -5.0), (0.5, -0.2, 0.84), 256, 256, 1, 1))])
+    want = oracle_tlas(oracle, tlas, [blas], rays)
+    via4 = tlas.Intersect(rays.copy())
+    check(via4, want)
+    occ = tlas.IsOccluded(rays.copy())
+    assert int((occ.astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+    blas.set_variant(72)                                    # (any forced variant: the TLAS goes back to the uploaded nodes)
+    native = tlas.Intersect(rays.copy())
+    blas.set_variant(0)
+    assert np.array_equal(native.view(np.uint8), via4.view(np.uint8))
+    moved = deform(mesh, 0.05, seed=2)
+    blas.Refit(moved)
+    blas.host = tb.HostBVH(moved, tb.LAYOUT_CWBVH)
+    check(tlas.Intersect(rays.copy()), oracle_tlas(oracle, tlas, [blas], rays))
+    h2 = tb.HostBVH(mesh, tb.LAYOUT_CWBVH)
+    blas.Update(h2.blob(0, np.uint32, 4), h2.blob(1, np.uint32, 4))
+    blas.host = h2
+    check(tlas.Intersect(rays.copy()), want)
+    tlas.free(); blas.free()

@@ -118,6 +118,37 @@ def test_bvh4_stream_to_bvh2(oracle_ref, name):
         assert c["hitmiss"] <= 1 and c["prim_real"] == 0 and c["t_bad"] == 0, (name, k, c)
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_cwbvh_blob_to_bvh2(oracle_ref, name):
+    """... and of the 4-wide copy a TLAS enters a BVH8_CWBVH BLAS through (host_builder.cpp: cwbvh_to_bvh2): the reference's own BVH8_CWBVH::ConvertFrom blobs
+    (Build and BuildHQ) become a BVH2 the oracle can walk, every triangle record carried over once, bit for bit, as {v0|prim, e1, e2}."""
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    rays = g["rays"]
+    want = rays.copy()
+    want.view(np.uint32).reshape(-1, 16)[:, 12:16] = g["hits"]
+    for k in (0, 1):
+        cn = np.ascontiguousarray(g[f"cwbvh_nodes_{k}"]).view(np.float32).reshape(-1, 4)
+        ct = np.ascontiguousarray(g[f"cwbvh_tris_{k}"]).view(np.float32).reshape(-1, 4)
+        ct = ct[: ct.shape[0] // 3 * 3]
+        nodes, recs = decode(tb.LAYOUT_CWBVH, cn, None, ct)
+        assert max(leaf_sizes(nodes)) <= 3
+        # the records the blob's leaves reference, each exactly once (an SBVH's triangle array has slack behind them): {e2, e1, v0|prim} -> {v0|prim, e1, e2}
+        used = recs.reshape(-1, 3, 4)
+        theirs = ct.reshape(-1, 3, 4)[:, ::-1, :]
+        keys = set(map(bytes, theirs.reshape(theirs.shape[0], -1).view(np.uint8)))
+        assert all(bytes(r) in keys for r in used.reshape(used.shape[0], -1).view(np.uint8))
+        verts = np.zeros((used.shape[0] * 3, 4), np.float32)
+        verts[0::3, :3] = used[:, 0, :3]
+        verts[1::3, :3] = used[:, 0, :3] + used[:, 1, :3]
+        verts[2::3, :3] = used[:, 0, :3] + used[:, 2, :3]
+        idx = np.arange(used.shape[0], dtype=np.uint32)
+        got = oracle_ref.bvh2_intersect(nodes, idx, verts, rays.copy())
+        hit = got["t"] < 1e30
+        got["prim"][hit] = used[:, 0, 3].view(np.uint32)[got["prim"][hit]]
+        c = compare_hits(got, want, rtol=1e-5)
+        assert c["hitmiss"] <= 1 and c["prim_real"] == 0 and c["t_bad"] == 0, (name, k, c)
+
+
 def test_a_single_leaf_has_no_copy():
     verts = np.array([[0, 0, 0, 0], [1, 0, 0, 0], [0, 1, 0, 0]], np.float32)
     h = tb.HostBVH(verts, tb.LAYOUT_BVH_GPU)

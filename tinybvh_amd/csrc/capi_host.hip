@@ -212,7 +212,11 @@ int tbvh_debug_wide_copy_bvh2(int layout, const void* blob, uint64_t nBlob, cons
         } else if (layout == TBVH_LAYOUT_BVH4_GPU) {
             if (const char* why = validate_bvh4_gpu((const Vec4*)blob, nBlob)) return fail(TBVH_E_FORMAT, "%s", why);
             if (!bvh4_gpu_to_bvh2((const Vec4*)blob, nBlob, maxLeaf, n2, recs)) return fail(TBVH_E_FORMAT, "the root is a leaf or the stream is malformed");
-        } else return fail(TBVH_E_INVALID, "tbvh_debug_wide_copy_bvh2: layout %d (BVH_GPU 5 and BVH4_GPU 8 have wide copies)", layout);
+        } else if (layout == TBVH_LAYOUT_CWBVH) {   // (the 4-wide copy a TLAS enters a BVH8_CWBVH BLAS through: blob = node blocks, verts16 = the n_tris * 3 triangle blocks)
+            if (!verts16 || nBlob % 5) return fail(TBVH_E_INVALID, "tbvh_debug_wide_copy_bvh2: BVH8_CWBVH needs the node blocks (a multiple of 5) and the triangle blocks in verts16");
+            if (const char* why = validate_cwbvh((const Vec4*)blob, nBlob / 5, nTris * 3)) return fail(TBVH_E_FORMAT, "%s", why);
+            if (!cwbvh_to_bvh2((const Vec4*)blob, nBlob / 5, (const Vec4*)verts16, nTris * 3, n2, recs)) return fail(TBVH_E_FORMAT, "the root is a leaf or the blob is malformed");
+        } else return fail(TBVH_E_INVALID, "tbvh_debug_wide_copy_bvh2: layout %d (BVH_GPU 5, BVH4_GPU 8 and BVH8_CWBVH 10 have copies)", layout);
     } catch (const std::bad_alloc&) { return fail(TBVH_E_NOMEM, "out of host memory"); }
     if (nNodesOut) *nNodesOut = n2.size();
     if (nRecsOut) *nRecsOut = recs.size() / 3;

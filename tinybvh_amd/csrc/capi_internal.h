@@ -198,9 +198,13 @@ struct tbvh_scene {
     // BVH_GPU / BVH4_GPU: the same tree collapsed 8-wide into the BVH8_CWBVH format (capi_scene.hip: makeWideCopy; made by the first query), kept current by update / refit / micromap
     // calls and traced INSTEAD of `nodes` by the queries on this scene: hit records do not depend on the layout (device_common.h: hit_wins), and the
     // compressed wide kernels trace the same rays 1.6-2.9 x faster than the 2-wide one (profiles/r06_bvh2.txt).  Owned by this scene, not listed in
-    // the context's scene table; TLASes over this BLAS keep using `nodes`.
+    // the context's scene table; TLASes over this BLAS enter it through the copies as well (capi_scene.hip: blasView).
     tbvh_scene* wide = nullptr;
     bool wideTried = false;      // the copy was made, or found unwanted / impossible: launchQuery does not try again
+    // ... and a 4-wide one (BVH4_GPU format) of a BVH_GPU / BVH8_CWBVH BLAS, made when a TLAS is uploaded over it: under a TLAS k_tlas4 is the fastest kernel for
+    // closest hits (1000 instances, camera rays: 4650 MRays/s against 4190 through BVH8_CWBVH BLASes and 3840 through BVH_GPU ones), k_tlas8 for any-hit queries
+    tbvh_scene* wide4 = nullptr;
+    bool wide4Tried = false;
 };
 
 struct BLASInstanceCheck { float m[32]; float mn[3]; uint32_t blasIdx; float mx[3]; uint32_t mask; uint32_t pad[8]; };
@@ -296,6 +300,8 @@ size_t hybridBytes(uint32_t nNodes, uint32_t K);
 bool wantsIncoherentCopies(const tbvh_scene* s);
 int prepareIncoherentCopies(tbvh_scene* s);
 void freeWideCopy(tbvh_scene* s);
+void freeWide4Copy(tbvh_scene* s);
+int makeWide4Copy(tbvh_scene* s);   // the 4-wide copy of a BVH_GPU / BVH8_CWBVH BLAS (closest-hit queries of the TLASes over it)
 int reclassifyTlas(tbvh_scene* t);   // (capi_scene.hip) descriptors, kernel class and wide trees of a TLAS from its BLASes as they are now
 int makeWideCopy(tbvh_scene* s);   // (lazily, from launchQuery) the 8-wide copy of a BVH_GPU / BVH4_GPU scene   // (lazily, from launchQuery) hybrid node copy + 64-byte triangle records for incoherent batches
 }  // namespace tbvh_capi

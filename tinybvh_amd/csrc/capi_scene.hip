@@ -93,6 +93,15 @@ void freeWideCopy(tbvh_scene* s) {
     tbvh_free_scene(w);
 }
 
+void freeWide4Copy(tbvh_scene* s) {
+    if (!s || !s->wide4) return;
+    tbvh_scene* w = s->wide4;
+    s->wide4 = nullptr;
+    s->bytes -= w->bytes < s->bytes ? w->bytes : 0;
+    w->opmap = nullptr; w->opmapBytes = 0;   // (shared with the owner, never owned)
+    tbvh_free_scene(w);
+}
+
 // The 8-wide copy of a BVH_GPU / BVH4_GPU scene (tbvh_scene::wide), made LAZILY by the scene's first query of 1024 rays or more (launchQuery) — a BLAS
 // that is only ever traced through a TLAS never pays for it — from what the scene keeps on the device: the blob is read back, the host turns it into a
 // Wald-layout BVH2 with leaves of at most 3 entries (host_builder.cpp: bvh_gpu_to_bvh2 in record mode / bvh4_gpu_to_bvh2), the device converter every
@@ -100,11 +109,10 @@ void freeWideCopy(tbvh_scene* s) {
 // tiny_bvh.h:4975-5048): triangle records are carried over bit for bit.  Blobs below TBVH_WIDE_COPY_MIN entries / triangles (default 32768; 0 = never)
 // keep their own kernel.  A failure here is never an error of the query: the scene then simply traces its own nodes.
 static int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris, tbvh_scene** out);
-static int makeWideCopyImpl(tbvh_scene* s) {
+// One copy of scene s in the `target` layout (BVH8_CWBVH from a BVH_GPU / BVH4_GPU scene, BVH4_GPU from a BVH_GPU / BVH8_CWBVH one), or nullptr (too small,
+// too large, out of memory: never an error of the caller's operation).  Not listed in the context's scene table; shares the owner's opacity maps.
+static tbvh_scene* buildCopy(tbvh_scene* s, int target) {
     tbvh_context* c = s->ctx;
-    freeWideCopy(s);
-    s->wideTried = true;
-    if (s->isTlas || (s->layout != TBVH_LAYOUT_BVH_GPU && s->layout != TBVH_LAYOUT_BVH4_GPU)) return 0;
     uint64_t minIdx = 32768;
     if (const char* e = getenv("TBVH_WIDE_COPY_MIN")) { const long long v = atoll(e); minIdx = v <= 0 ? ~0ull : (uint64_t)v; }
     std::vector<Node2> n2;
@@ -115,39 +123,62 @@ static int makeWideCopyImpl(tbvh_scene* s) {
     try {
         if (s->layout == TBVH_LAYOUT_BVH_GPU) {
             const uint64_t nNodes = s->nNodeBlocks / 4, nIdx = s->nTriBlocks / 3;
-            if (nIdx < minIdx || nIdx > 0x7fffffffull || nNodes > 0x3fffffffull) return 0;
+            if (nIdx < minIdx || nIdx > 0x7fffffffull || nNodes > 0x3fffffffull) return nullptr;
             blob.resize(s->nNodeBlocks); recs.resize(s->nTriBlocks);
             if (hipMemcpyAsync(blob.data(), s->nodes, s->nNodeBlocks * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
                 hipMemcpyAsync(recs.data(), s->tris, s->nTriBlocks * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
-            if (!bvh_gpu_to_bvh2((const NodeAL*)blob.data(), nNodes, nullptr, nIdx, nullptr, 0, 3u, n2, recs.data())) return 0;
+                hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            if (!bvh_gpu_to_bvh2((const NodeAL*)blob.data(), nNodes, nullptr, nIdx, nullptr, 0, 3u, n2, recs.data())) return nullptr;
             dRecs = s->tris; nRecs = nIdx;       // (the gathered records are on the device already, in leaf order)
         } else {
-            if (s->nNodeBlocks / 4 < minIdx || s->nNodeBlocks > 0x7fffffffull) return 0;   // (a stream of n triangles has at least 3 n blocks: a cheap first cut)
-            blob.resize(s->nNodeBlocks);
-            if (hipMemcpyAsync(blob.data(), s->nodes, s->nNodeBlocks * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
-                hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
-            if (!bvh4_gpu_to_bvh2(blob.data(), s->nNodeBlocks, 3u, n2, recs)) return 0;
+            if (s->layout == TBVH_LAYOUT_BVH4_GPU) {
+                if (s->nNodeBlocks / 4 < minIdx || s->nNodeBlocks > 0x7fffffffull) return nullptr;   // (a stream of n triangles has at least 3 n blocks: a cheap first cut)
+                blob.resize(s->nNodeBlocks);
+                if (hipMemcpyAsync(blob.data(), s->nodes, s->nNodeBlocks * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                    hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+                if (!bvh4_gpu_to_bvh2(blob.data(), s->nNodeBlocks, 3u, n2, recs)) return nullptr;
+            } else {   // BVH8_CWBVH
+                if (s->nTriBlocks / 3 < minIdx || s->nTriBlocks > 0x7fffffffull) return nullptr;
+                std::vector<Vec4> tris(s->nTriBlocks);
+                blob.resize(s->nNodeBlocks);
+                if (hipMemcpyAsync(blob.data(), s->nodes, s->nNodeBlocks * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                    hipMemcpyAsync(tris.data(), s->tris, s->nTriBlocks * 16, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+                    hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+                if (!cwbvh_to_bvh2(blob.data(), s->nNodeBlocks / 5, tris.data(), s->nTriBlocks, n2, recs)) return nullptr;
+            }
             nRecs = recs.size() / 3;
-            if (nRecs < minIdx || nRecs > 0x7fffffffull) return 0;
+            if (nRecs < minIdx || nRecs > 0x7fffffffull) return nullptr;
             if (hipMalloc(&t.r, recs.size() * 16) != hipSuccess ||
-                hipMemcpyAsync(t.r, recs.data(), recs.size() * 16, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
+                hipMemcpyAsync(t.r, recs.data(), recs.size() * 16, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
             dRecs = (const float4*)t.r;
         }
-    } catch (const std::bad_alloc&) { return 0; }
-    if (n2.size() > 0x7fffffffull) return 0;
+    } catch (const std::bad_alloc&) { return nullptr; }
+    if (n2.size() > 0x7fffffffull) return nullptr;
     if (hipMalloc(&t.n2, n2.size() * 32) != hipSuccess ||
-        hipMemcpyAsync(t.n2, n2.data(), n2.size() * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        hipMemcpyAsync(t.n2, n2.data(), n2.size() * 32, hipMemcpyHostToDevice, c->stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     tbvh_scene* w = nullptr;
-    if (convertDeviceImpl(c, TBVH_LAYOUT_CWBVH, (const float4*)t.n2, n2.size(), nullptr, nRecs, dRecs, nRecs, &w) != 0 || !w) { (void)hipGetLastError(); return 0; }
+    if (convertDeviceImpl(c, target, (const float4*)t.n2, n2.size(), nullptr, nRecs, dRecs, nRecs, &w) != 0 || !w) { (void)hipGetLastError(); return nullptr; }
     for (size_t i = 0; i < c->scenes.size(); i++)
         if (c->scenes[i] == w) { c->scenes.erase(c->scenes.begin() + i); break; }   // owned by `s`, freed with it
     w->opmap = s->opmap; w->opmapN = s->opmapN;
-    s->wide = w;
-    s->bytes += w->bytes;
+    return w;
+}
+
+static int makeWideCopyImpl(tbvh_scene* s) {
+    freeWideCopy(s);
+    s->wideTried = true;
+    if (s->isTlas || (s->layout != TBVH_LAYOUT_BVH_GPU && s->layout != TBVH_LAYOUT_BVH4_GPU)) return 0;
+    if (tbvh_scene* w = buildCopy(s, TBVH_LAYOUT_CWBVH)) { s->wide = w; s->bytes += w->bytes; }
     return 0;
 }
 
+static int makeWide4CopyImpl(tbvh_scene* s) {
+    freeWide4Copy(s);
+    s->wide4Tried = true;
+    if (s->isTlas || (s->layout != TBVH_LAYOUT_BVH_GPU && s->layout != TBVH_LAYOUT_CWBVH)) return 0;
+    if (tbvh_scene* w = buildCopy(s, TBVH_LAYOUT_BVH4_GPU)) { s->wide4 = w; s->bytes += w->bytes; }
+    return 0;
+}
 }  // namespace tbvh_capi
 
 extern "C" {
@@ -318,8 +349,10 @@ namespace tbvh_capi {
 // k_tlas8 on the copies against k_tlas2 on the uploaded nodes: camera rays +5 %, shadow rays +47 %, random rays +16 %); BVH4_GPU BLASes keep their own
 // stream for closest hits (k_tlas4 is the fastest two-level kernel there) and are entered through their copies by any-hit queries; tbvh_set_variant(blas, 1)
 // pins the uploaded nodes.
-static const tbvh_scene* blasView(const tbvh_scene* b, bool any) {
-    const bool viaCopy = b->wide && b->variant == 0 && (b->layout == TBVH_LAYOUT_BVH_GPU || (any && b->layout == TBVH_LAYOUT_BVH4_GPU));
+static const tbvh_scene* blasView(const tbvh_scene* b, bool any, bool allow4 = true) {
+    if (b->variant != 0) return b;
+    if (!any && allow4 && b->wide4 && (b->layout == TBVH_LAYOUT_BVH_GPU || b->layout == TBVH_LAYOUT_CWBVH)) return b->wide4;   // closest hits: the 4-wide kernel
+    const bool viaCopy = b->wide && (b->layout == TBVH_LAYOUT_BVH_GPU || (any && b->layout == TBVH_LAYOUT_BVH4_GPU));
     return viaCopy ? b->wide : b;
 }
 
@@ -331,12 +364,16 @@ int reclassifyTlas(tbvh_scene* t) {
     const size_t nBlas = t->blasList.size();
     std::vector<BlasDesc> desc[2] = {std::vector<BlasDesc>(nBlas), std::vector<BlasDesc>(nBlas)};
     int layout[2] = {0, 0};
-    bool mix[2], same = true;
-    for (int any = 0; any < 2; any++) {
+    bool mix[2] = {false, false}, same = true;
+    for (int pass = 0; pass < 3; pass++) {
+        // pass 0: closest hits, BVH_GPU / BVH8_CWBVH BLASes through their 4-wide copies; pass 1 (only if pass 0 ended in the flat loop: a BLAS too small
+        // for a copy next to copied ones): closest hits without the 4-wide copies; pass 2: any-hit queries
+        const int any = pass == 2;
+        if (pass == 1 && (layout[0] != 0 || mix[0])) continue;
         bool anyBvh4 = false;
         for (size_t i = 0; i < nBlas; i++) {
             const tbvh_scene* b = t->blasList[i];
-            const tbvh_scene* v = blasView(b, any != 0);
+            const tbvh_scene* v = blasView(b, any != 0, pass == 0);
             layout[any] = i == 0 ? v->layout : (layout[any] == v->layout ? layout[any] : 0);   // 0: the BLASes mix layouts (traverse_tlas.cl:50-72)
             anyBvh4 |= v->layout == TBVH_LAYOUT_BVH4_GPU;
             desc[any][i].nodes = v->nodes; desc[any][i].tris = v->tris; desc[any][i].opmap = b->opmap; desc[any][i].opmapN = b->opmapN; desc[any][i].layout = (uint32_t)v->layout;
@@ -369,6 +406,16 @@ int makeWideCopy(tbvh_scene* s) {
     }
     return r;
 }
+
+int makeWide4Copy(tbvh_scene* s) {
+    const int r = makeWide4CopyImpl(s);
+    for (size_t i = 0; i < s->usedBy.size(); i++) {
+        bool seen = false;
+        for (size_t k = 0; k < i; k++) seen |= s->usedBy[k] == s->usedBy[i];
+        if (!seen) (void)reclassifyTlas(s->usedBy[i]);   // (the copy's arrays are new ones — or gone)
+    }
+    return r;
+}
 }  // namespace tbvh_capi
 }  // extern "C++"
 
@@ -382,9 +429,9 @@ int tbvh_upload_tlas(tbvh_context* c, const void* nodes64, uint64_t nNodes, cons
             return fail(TBVH_E_INVALID, "BLAS %llu: layout %d cannot be a BLAS", (unsigned long long)i, b->layout);
     }
     TBVH_ENTER(c);
-    for (uint64_t i = 0; i < nBlas; i++)   // BVH_GPU BLASes are entered through their 8-wide copies (blasView): made now unless a query of the BLAS has already tried; BVH4_GPU BLASes get
-                                           // theirs when the TLAS has its first any-hit query (launchQuery)
-        if (blas[i]->layout == TBVH_LAYOUT_BVH_GPU && !blas[i]->wideTried && blas[i]->variant == 0) makeWideCopy(blas[i]);
+    for (uint64_t i = 0; i < nBlas; i++)   // closest-hit queries enter BVH_GPU and BVH8_CWBVH BLASes through 4-wide copies (blasView), made now; the 8-wide copies any-hit queries
+                                           // enter BVH_GPU and BVH4_GPU BLASes through are made by the TLAS's first any-hit query (launchQuery)
+        if ((blas[i]->layout == TBVH_LAYOUT_BVH_GPU || blas[i]->layout == TBVH_LAYOUT_CWBVH) && !blas[i]->wide4Tried && blas[i]->variant == 0) makeWide4Copy(blas[i]);
     tbvh_scene* s = newScene(c, TBVH_LAYOUT_BVH_GPU);
     if (!s) return fail(TBVH_E_NOMEM, "out of host memory");
     s->isTlas = true; s->nBlas = nBlas;
@@ -424,6 +471,7 @@ int tbvh_update_bvh_gpu(tbvh_scene* s, const void* nodes64, uint64_t nNodes, con
     if (e != hipSuccess) return fail(TBVH_E_HIP, "tbvh_update_bvh_gpu: %s", hipGetErrorString(e));
     s->nNodeBlocks = nNodes * 4; s->nTriBlocks = nIdx * 3;
     if (s->wide) makeWideCopy(s);   // (the tree may have changed: collapsed again)
+    if (s->wide4) makeWide4Copy(s);
     return 0;
 }
 
@@ -442,7 +490,7 @@ int tbvh_update_bvh4_gpu(tbvh_scene* s, const void* blocks16, uint64_t nBlocks) 
     return 0;
 }
 
-int tbvh_update_cwbvh(tbvh_scene* s, const void* nodes16, uint64_t nNodeBlocks, const void* tris16, uint64_t nTriBlocks) {
+static int updateCwbvhImpl(tbvh_scene* s, const void* nodes16, uint64_t nNodeBlocks, const void* tris16, uint64_t nTriBlocks) {
     if (!s || s->isTlas || s->layout != TBVH_LAYOUT_CWBVH || !nodes16 || nNodeBlocks < 5 || (nTriBlocks && !tris16)) return fail(TBVH_E_INVALID, "tbvh_update_cwbvh: not a BVH8_CWBVH scene or null/empty argument");
     if (nNodeBlocks % 5) return fail(TBVH_E_FORMAT, "CWBVH node blocks (%llu) not a multiple of 5", (unsigned long long)nNodeBlocks);
     if (nNodeBlocks > s->capNodeBlocks || nTriBlocks > s->capTriBlocks) return fail(TBVH_E_INVALID, "tbvh_update_cwbvh: the blob (%llu + %llu blocks) is larger than the one uploaded (%llu + %llu): free the scene and upload",
@@ -475,6 +523,14 @@ int tbvh_update_cwbvh(tbvh_scene* s, const void* nodes16, uint64_t nNodeBlocks, 
     s->hybridK = 0; s->hyTried = false; s->hyLevelOrder = false;
     s->bytes = (nNodeBlocks + nTriBlocks) * 16 + s->opmapBytes;
     return padCwbvhIfLarge(s);
+}
+
+int tbvh_update_cwbvh(tbvh_scene* s, const void* nodes16, uint64_t nNodeBlocks, const void* tris16, uint64_t nTriBlocks) {
+    const bool had4 = s && !s->isTlas && s->wide4 != nullptr;
+    if (had4) { TBVH_LOCK(s->ctx); hipSetDevice(s->ctx->device); hipStreamSynchronize(s->ctx->stream); freeWide4Copy(s); }   // (the 4-wide copy TLASes enter this BLAS through: made again below)
+    const int r = updateCwbvhImpl(s, nodes16, nNodeBlocks, tris16, nTriBlocks);
+    if (had4) { TBVH_ENTER(s->ctx); makeWide4Copy(s); }   // (also after a refused update: the TLASes over the BLAS need their descriptors back)
+    return r;
 }
 
 namespace {
@@ -663,6 +719,7 @@ int tbvh_set_opacity_micromaps(tbvh_scene* s, const uint32_t* mapData, uint32_t 
     s->opmap = fresh; s->opmapN = clear ? 0u : N; s->opmapBytes = freshBytes;
     s->bytes += freshBytes; s->bytes -= oldBytes;
     if (s->wide) { s->wide->opmap = s->opmap; s->wide->opmapN = s->opmapN; }   // (shared, owned here)
+    if (s->wide4) { s->wide4->opmap = s->opmap; s->wide4->opmapN = s->opmapN; }
     const int r = refreshBlasDescs(s);   // the descriptors are rewritten before the old maps go
     if (old && r == 0) hipFree(old);   // (a failed refresh may have left a descriptor on the old maps: leak them rather than dangle)
     return r;
@@ -736,7 +793,8 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
     if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copy current
     if (s->nodesHy) launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, nNodes, s->hybridK, (c->embedTris && !(c->expFlags & 8u)) ? s->tris : nullptr, c->stream);
     if (s->tris64) launch_cwbvh_pad_tris(s->tris, s->tris64, s->nTriBlocks / 3, c->stream);
-    if (s->wide) return tbvh_refit(s->wide, dv, nTris, 1);   // the 8-wide copy follows (same vertices, already on the device)
+    if (s->wide) if (int r = tbvh_refit(s->wide, dv, nTris, 1)) return r;     // the 8-wide copy follows (same vertices, already on the device)
+    if (s->wide4) return tbvh_refit(s->wide4, dv, nTris, 1);                 // ... and the 4-wide one
     return 0;
 }
 
@@ -809,6 +867,7 @@ void tbvh_free_scene(tbvh_scene* s) {
     hipStreamSynchronize(c->stream);
     if (!s->isTlas && !s->usedBy.empty()) { s->zombie = true; return; }   // a TLAS still points at this BLAS's memory: freed with the last such TLAS
     freeWideCopy(s);
+    freeWide4Copy(s);
     if (s->isTlas) {
         std::vector<tbvh_scene*> mine;
         mine.swap(s->blasList);
@@ -895,7 +954,7 @@ int tbvh_set_variant(tbvh_scene* s, int v) {
     // ... and BVH_GPU / BVH4_GPU scenes one: 1 = trace the nodes as uploaded (k_bvh2 / k_bvh4) even when the scene has an 8-wide copy (tests, A/B)
     const bool ok = v == 0 || (!s->isTlas && s->layout == TBVH_LAYOUT_CWBVH && cwbvh_variant_valid(v)) || (!s->isTlas && (s->layout == TBVH_LAYOUT_BVH_GPU || s->layout == TBVH_LAYOUT_BVH4_GPU) && v == 1);
     if (!ok) return fail(TBVH_E_INVALID, "unknown variant %d for layout %d", v, s->layout);
-    const bool viewChanges = !s->isTlas && (s->layout == TBVH_LAYOUT_BVH_GPU || s->layout == TBVH_LAYOUT_BVH4_GPU) && s->wide && (s->variant == 0) != (v == 0);
+    const bool viewChanges = !s->isTlas && (s->wide || s->wide4) && (s->variant == 0) != (v == 0);
     s->variant = v;
     if (viewChanges) return refreshBlasDescs(s);   // (the TLASes over this BLAS enter it through the copy, or through its own nodes)
     return 0;

@@ -22,6 +22,7 @@
 #include <cassert>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <thread>
 
 namespace tbvh {
@@ -1243,6 +1244,133 @@ bool bvh4_gpu_to_bvh2(const Vec4* b, uint64_t nBlocks, uint32_t maxLeafTris, std
     }
     // every level of the source rounded its children on a grid of its own, so a child may reach an ulp beyond the box its parent stored for it: make the
     // boxes nest (children are allocated after their parent, so one sweep from the back sees every child before its parent)
+    for (size_t k = out.size(); k-- > 0;) {
+        Node2& n = out[k];
+        if (n.triCount || k == 1) continue;
+        const Node2 &l = out[n.leftFirst], &r = out[n.leftFirst + 1];
+        for (int a = 0; a < 3; a++) { n.mn[a] = std::min(n.mn[a], std::min(l.mn[a], r.mn[a])); n.mx[a] = std::max(n.mx[a], std::max(l.mx[a], r.mx[a])); }
+    }
+    return true;
+}
+
+// BVH8_CWBVH blob -> Wald-layout BVH2 + triangle records {v0|prim, e1, e2} in leaf order (the 4-wide copy a TLAS enters a BVH8_CWBVH BLAS through for
+// closest-hit queries: capi_scene.hip: makeWide4Copy).  Child boxes as the kernels evaluate them (origin + q * 2^e, padded by ulps of the larger operand);
+// the up to eight children of a node become a small binary tree: sorted along the node's widest axis, halved recursively.  Leaves keep their 1-3 triangles.
+bool cwbvh_to_bvh2(const Vec4* nodes, uint64_t nNodes, const Vec4* tris, uint64_t nTriBlocks, std::vector<Node2>& out, std::vector<Vec4>& recs) {
+    out.clear(); recs.clear();
+    if (nNodes == 0) return false;
+    auto u32 = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    auto down = [](float x) { return std::nextafter(std::nextafter(x, -INFINITY), -INFINITY); };
+    auto up = [](float x) { return std::nextafter(std::nextafter(x, INFINITY), INFINITY); };
+    struct Child { float mn[3], mx[3]; uint32_t inner; uint32_t a, n; };   // inner: node index a; else n triangles from record a
+    auto children = [&](uint64_t ni, Child* c) -> int {
+        const Vec4* nd = nodes + 5 * ni;
+        const uint32_t ew = u32(nd[0].w), imask = ew >> 24;
+        const float org[3] = {nd[0].x, nd[0].y, nd[0].z};
+        const float sc[3] = {std::ldexp(1.0f, (int)(int8_t)(ew & 255u)), std::ldexp(1.0f, (int)(int8_t)((ew >> 8) & 255u)), std::ldexp(1.0f, (int)(int8_t)((ew >> 16) & 255u))};
+        const uint32_t childBase = u32(nd[1].x), triBase = u32(nd[1].y);
+        const uint32_t meta[2] = {u32(nd[1].z), u32(nd[1].w)};
+        const uint32_t q[6][2] = {{u32(nd[2].x), u32(nd[2].y)}, {u32(nd[2].z), u32(nd[2].w)}, {u32(nd[3].x), u32(nd[3].y)},    // qlo x, y, z
+                                  {u32(nd[3].z), u32(nd[3].w)}, {u32(nd[4].x), u32(nd[4].y)}, {u32(nd[4].z), u32(nd[4].w)}};   // qhi x, y, z
+        int n = 0;
+        for (int s = 0; s < 8; s++) {
+            const uint32_t m = (meta[s >> 2] >> (8 * (s & 3))) & 255u;
+            if (!m) continue;
+            Child& k = c[n++];
+            if ((m & 0x18u) == 0x18u && (m >> 5) == 1u) {
+                const uint32_t slot = (m & 31u) - 24u;
+                k.inner = 1; k.a = childBase + (uint32_t)__builtin_popcount(imask & ((1u << slot) - 1u)); k.n = 0;
+            } else {
+                k.inner = 0; k.a = triBase / 3u + (m & 31u); k.n = (uint32_t)__builtin_popcount(m >> 5);
+            }
+            for (int a = 0; a < 3; a++) {
+                const float pl = (float)((q[a][s >> 2] >> (8 * (s & 3))) & 255u) * sc[a], ph = (float)((q[3 + a][s >> 2] >> (8 * (s & 3))) & 255u) * sc[a];
+                const float lo = org[a] + pl, hi = org[a] + ph;
+                const float ml = std::max(std::fabs(org[a]), std::max(std::fabs(pl), std::fabs(lo))), mh = std::max(std::fabs(org[a]), std::max(std::fabs(ph), std::fabs(hi)));
+                k.mn[a] = down(lo - ml * 2.4e-7f);
+                k.mx[a] = up(hi + mh * 2.4e-7f);
+            }
+        }
+        return n;
+    };
+    struct Item { uint32_t dst; uint32_t node; };
+    std::vector<Item> stack;
+    auto set_box = [&](uint32_t i, const float* mn, const float* mx) { for (int k = 0; k < 3; k++) { out[i].mn[k] = mn[k]; out[i].mx[k] = mx[k]; } };
+    auto pair = [&]() { const uint32_t c = (uint32_t)out.size(); out.resize(out.size() + 2); std::memset(&out[c], 0, 2 * sizeof(Node2)); return c; };
+    bool ok = true;
+    auto place = [&](uint32_t dst, const Child& k) {   // binary node dst IS child k
+        set_box(dst, k.mn, k.mx);
+        if (k.inner) { if (k.a >= nNodes) { ok = false; return; } stack.push_back(Item{dst, k.a}); return; }
+        if (k.n == 0 || 3ull * ((uint64_t)k.a + k.n) > nTriBlocks) { ok = false; return; }
+        out[dst].leftFirst = (uint32_t)(recs.size() / 3); out[dst].triCount = k.n;
+        for (uint32_t j = 0; j < k.n; j++) {   // {e2, e1, v0|prim} -> {v0|prim, e1, e2}
+            const Vec4* r = tris + 3ull * (k.a + j);
+            recs.push_back(r[2]); recs.push_back(r[1]); recs.push_back(r[0]);
+        }
+    };
+    // children c[0..n) under binary node dst (n >= 2): agglomerative — the two clusters whose union has the smallest surface area are merged until two are
+    // left (n <= 8: a few hundred box unions) —, so that the binary tree the 4-wide collapse starts from is as good as the wide node allows
+    struct Cluster { float mn[3], mx[3]; int left, right, child; };   // a leaf cluster names a child; an inner one two clusters
+    std::function<void(uint32_t, const Cluster*, int, const Child*)> emit = [&](uint32_t dst, const Cluster* cl, int ci, const Child* c) {
+        const Cluster& k = cl[ci];
+        if (k.child >= 0) { place(dst, c[k.child]); return; }
+        set_box(dst, k.mn, k.mx);
+        const uint32_t p = pair();
+        out[dst].leftFirst = p; out[dst].triCount = 0;
+        emit(p, cl, k.left, c); emit(p + 1, cl, k.right, c);
+    };
+    auto group = [&](uint32_t dst, Child* c, int n) {
+        Cluster cl[16];
+        int live[8], nLive = n, nCl = n;
+        for (int i = 0; i < n; i++) { for (int a = 0; a < 3; a++) { cl[i].mn[a] = c[i].mn[a]; cl[i].mx[a] = c[i].mx[a]; } cl[i].left = cl[i].right = -1; cl[i].child = i; live[i] = i; }
+        auto area = [](const float* mn, const float* mx) { const float x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2]; return x * y + y * z + z * x; };
+        while (nLive > 1) {
+            int bi = 0, bj = 1; float best = 1e38f;
+            for (int i = 0; i < nLive; i++) for (int j = i + 1; j < nLive; j++) {
+                float mn[3], mx[3];
+                for (int a = 0; a < 3; a++) { mn[a] = std::min(cl[live[i]].mn[a], cl[live[j]].mn[a]); mx[a] = std::max(cl[live[i]].mx[a], cl[live[j]].mx[a]); }
+                const float ar = area(mn, mx);
+                if (ar < best) { best = ar; bi = i; bj = j; }
+            }
+            Cluster& m = cl[nCl];
+            for (int a = 0; a < 3; a++) { m.mn[a] = std::min(cl[live[bi]].mn[a], cl[live[bj]].mn[a]); m.mx[a] = std::max(cl[live[bi]].mx[a], cl[live[bj]].mx[a]); }
+            m.left = live[bi]; m.right = live[bj]; m.child = -1;
+            live[bi] = nCl++; live[bj] = live[--nLive];
+        }
+        // the root cluster IS binary node dst (its box was set by the caller, and is at least as tight)
+        const Cluster& root = cl[live[0]];
+        const uint32_t p = pair();
+        out[dst].leftFirst = p; out[dst].triCount = 0;
+        emit(p, cl, root.left, c); emit(p + 1, cl, root.right, c);
+    };
+    out.resize(2);
+    std::memset(out.data(), 0, 2 * sizeof(Node2));
+    {
+        Child c[8];
+        const int n = children(0, c);
+        if (n == 0 || (n == 1 && !c[0].inner)) return false;   // a single leaf: nothing to collapse
+        float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+        for (int i = 0; i < n; i++) for (int a = 0; a < 3; a++) { mn[a] = std::min(mn[a], c[i].mn[a]); mx[a] = std::max(mx[a], c[i].mx[a]); }
+        set_box(0, mn, mx);
+    }
+    stack.push_back(Item{0u, 0u});
+    uint64_t guard = 0;
+    while (!stack.empty() && ok) {
+        const Item it = stack.back(); stack.pop_back();
+        if (++guard > nNodes + 16) return false;           // (validated blobs are trees; belt and braces)
+        Child c[8];
+        const int n = children(it.node, c);
+        if (n == 0) return false;
+        if (n == 1) {   // one child: this binary node IS that child (its box the tighter of the two)
+            Child k = c[0];
+            for (int a = 0; a < 3; a++) { k.mn[a] = std::max(k.mn[a], out[it.dst].mn[a]); k.mx[a] = std::min(k.mx[a], out[it.dst].mx[a]); if (!(k.mn[a] <= k.mx[a])) { k.mn[a] = c[0].mn[a]; k.mx[a] = c[0].mx[a]; } }
+            place(it.dst, k);
+            continue;
+        }
+        group(it.dst, c, n);
+    }
+    if (!ok) return false;
+    // every level of the source rounded its children on a grid of its own: make the boxes nest (children are allocated after their parent)
     for (size_t k = out.size(); k-- > 0;) {
         Node2& n = out[k];
         if (n.triCount || k == 1) continue;

@@ -76,6 +76,8 @@ bool bvh_gpu_to_bvh2(const NodeAL* al, uint64_t nNodes, const uint32_t* primIdx,
 // DEQUANTISED boxes (padded outward by two ulps: they only cull), leaves of at most maxLeafTris entries index `recs`, the blob's inline triangle
 // records {v0|prim, e1, e2} gathered in depth-first order (the converter copies them as they are: kernels_convert.hip, record mode).
 bool bvh4_gpu_to_bvh2(const Vec4* blocks, uint64_t nBlocks, uint32_t maxLeafTris, std::vector<Node2>& out, std::vector<Vec4>& recs);
+// ... and of a BVH8_CWBVH blob (nodes: 5 float4 each; tris: 3 float4 per record {e2, e1, v0|prim}); records come out as {v0|prim, e1, e2}
+bool cwbvh_to_bvh2(const Vec4* nodes, uint64_t nNodes, const Vec4* tris, uint64_t nTriBlocks, std::vector<Node2>& out, std::vector<Vec4>& recs);
 
 // CWBVH nodes (5 x Vec4 each) in surface-area priority order: newIdx[old] = new; see host_builder.cpp.
 bool cwbvh_priority_order(const Vec4* in, uint32_t nNodes, std::vector<uint32_t>& newIdx);   // false: not a strict tree, no numbering

@@ -195,8 +195,13 @@ __global__ void k_convert4_level(const float4* __restrict__ nodes2, uint32_t nNo
             info[i] = 0x80000000u | (c.triCount << 16) | rel;
             for (uint32_t j = 0; j < c.triCount; j++) {
                 const uint64_t pi = (uint64_t)c.leftFirst + j;
-                const uint32_t prim = pi < nIdx ? primIdx[pi] : 0xffffffffu;
                 float4* o = blocks + (size_t)base + rel + 3 * j;
+                if (!primIdx) {   // RECORD MODE (as in k_convert_level): `verts` holds finished records {v0|prim, e1, e2}, one per leaf entry, carried over bit for bit
+                    if (pi >= nTris) { atomicOr(status, 4u); o[0] = o[1] = o[2] = make_float4(0, 0, 0, 0); continue; }
+                    o[0] = verts[3 * pi]; o[1] = verts[3 * pi + 1]; o[2] = verts[3 * pi + 2];
+                    continue;
+                }
+                const uint32_t prim = pi < nIdx ? primIdx[pi] : 0xffffffffu;
                 if (prim >= nTris) { atomicOr(status, 4u); o[0] = o[1] = o[2] = make_float4(0, 0, 0, 0); continue; }
                 const float4 v0 = verts[3 * (uint64_t)prim], v1 = verts[3 * (uint64_t)prim + 1], v2 = verts[3 * (uint64_t)prim + 2];
                 o[0] = make_float4(v0.x, v0.y, v0.z, as_f32(prim));
