@@ -1194,7 +1194,19 @@ bool bvh4_gpu_to_bvh2(const Vec4* b, uint64_t nBlocks, uint32_t maxLeafTris, std
             out[it.dst].leftFirst = p; out[it.dst].triCount = 0;
             if (n == 2) { push_child(p, c[0], it.a); push_child(p + 1, c[1], it.a); }
             else {
-                // ((0, 1), 2) or ((0, 1), (2, 3)): slot order is the encoder's distance order along an axis, so neighbours in it are neighbours in space
+                // ((a, b), c) or ((a, b), (c, d)): the pairing whose unions have the smallest surface area (three candidates either way)
+                {
+                    auto area2 = [&](const Child& x, const Child& y) { Child u; unite(x, y, u); const float dx = u.mx[0] - u.mn[0], dy = u.mx[1] - u.mn[1], dz = u.mx[2] - u.mn[2]; return dx * dy + dy * dz + dz * dx; };
+                    if (n == 3) {
+                        const float a01 = area2(c[0], c[1]), a02 = area2(c[0], c[2]), a12 = area2(c[1], c[2]);
+                        if (a02 < a01 && a02 <= a12) std::swap(c[1], c[2]);        // (0, 2) pair, 1 alone
+                        else if (a12 < a01 && a12 < a02) std::swap(c[0], c[2]);    // (2, 1) pair, 0 alone
+                    } else {
+                        const float p0 = area2(c[0], c[1]) + area2(c[2], c[3]), p1 = area2(c[0], c[2]) + area2(c[1], c[3]), p2 = area2(c[0], c[3]) + area2(c[1], c[2]);
+                        if (p1 < p0 && p1 <= p2) std::swap(c[1], c[2]);            // (0, 2) (1, 3)
+                        else if (p2 < p0 && p2 < p1) std::swap(c[1], c[3]);        // (0, 3) (2, 1)
+                    }
+                }
                 Child l; unite(c[0], c[1], l);
                 set_box(p, l.mn, l.mx);
                 const uint32_t pl = pair();
