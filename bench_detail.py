@@ -291,7 +291,7 @@ def config5_setup(tb, R, scenes, ctx, blas_layout):
 
 def tlas_child(a, tb, R, scenes):
     """Config 5 in a process of its own: camera rays through the TLAS over BVH4_GPU BLASes (k_tlas4) — under rocprofv3 --pmc (--pmc-child) only
-    the launches; otherwise also the TLAS over BVH8_CWBVH BLASes (k_tlas8) next to the reference's traverse_tlas (traverse_tlas.cl:13-107, through
+    the launches; otherwise also the TLAS over BVH8_CWBVH BLASes (entered through their 4-wide copies: k_tlas4 as well) next to the reference's traverse_tlas (traverse_tlas.cl:13-107, through
     wavefront2.cl's Extend as tiny_bvh_gpu2.cpp:191 launches it) on the same TLAS nodes, instance records, BLAS blobs and rays."""
     ctx = tb.Context(0)
     dlabel, blas, tlas, cam, nt = config5_setup(tb, R, scenes, ctx, 8)
@@ -323,8 +323,9 @@ def tlas_child(a, tb, R, scenes):
         h = blas8.host
         ref, ref_ms = ocl.tlas_extend(nodes, idx, irec, h.blob(0, np.uint32, 4), h.blob(1, np.uint32, 4), rays, passes=3)
         mh, rh = mine["t"][: ref.shape[0]] < 1e30, ref[:, 0] < 1e30
-        out.update({"k_tlas8_ms": float(np.mean(ms8)), "k_tlas8_mrays": nt / float(np.mean(ms8)) / 1e3, "ref_opencl_traverse_tlas_ms": ref_ms,
-                    "ref_opencl_traverse_tlas_mrays": ref.shape[0] / ref_ms / 1e3, "ratio_k_tlas8_cwbvh_blas": ref_ms / float(np.mean(ms8)),
+        out.update({"cwbvh_blas_ms": float(np.mean(ms8)), "cwbvh_blas_mrays": nt / float(np.mean(ms8)) / 1e3, "ref_opencl_traverse_tlas_ms": ref_ms,
+                    "ref_opencl_traverse_tlas_mrays": ref.shape[0] / ref_ms / 1e3, "ratio_cwbvh_blas": ref_ms / float(np.mean(ms8)),
+                    "cwbvh_blas_note": "closest-hit queries enter BVH8_CWBVH BLASes through their 4-wide copies (k_tlas4; capi_scene.hip: blasView) since round 6",
                     "ratio_k_tlas4_bvh4_blas": ref_ms / float(np.mean(ms)), "hitmiss_diff": int((mh != rh).sum()), "opencl_device": ocl.device,
                     "ref_kernel": "traverse_tlas (traverse_tlas.cl:13-107) via wavefront2.cl Extend, BVH8_CWBVH BLAS (the configuration of tiny_bvh_gpu2.cpp), same TLAS / instances / rays"})
     except Exception as e:
