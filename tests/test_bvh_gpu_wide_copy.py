@@ -216,7 +216,7 @@ def test_tlas_enters_bvh_gpu_blases_through_their_wide_copies(ctx, oracle):
     8-wide copies, made at the TLAS upload (capi_scene.hip: reclassifyTlas, blasView): the records are BVH::IntersectTLAS's either way; tbvh_set_variant(blas, 1)
     puts the TLAS back on the uploaded nodes, a BLAS update is followed, a BLAS freed before its TLAS lives on with its copy."""
     from test_tlas import grid_instances, oracle_tlas, check
-    meshes = [scenes.blob(40_000, seed=5), scenes.soup(3_000, seed=6, extent=1.6, size=0.2)]       # one with a copy, one below the threshold: the mixed kernel
+    meshes = [scenes.blob(40_000, seed=5), scenes.soup(3_000, seed=6, extent=1.6, size=0.2)]       # a small BLAS gets its copies too when a TLAS wants them: one kernel class for the TLAS
     for m in meshes:
         m[:, :3] -= 0.5 * (m[:, :3].min(0) + m[:, :3].max(0))
         m[:, :3] *= np.float32(1.6 / float((m[:, :3].max(0) - m[:, :3].min(0)).max()))
@@ -224,7 +224,11 @@ def test_tlas_enters_bvh_gpu_blases_through_their_wide_copies(ctx, oracle):
     before = [b.device_bytes for b in blas]
     inst = grid_instances(4, 0.5, 3, n_blas=2)
     tlas = tb.TLAS(ctx).Build(inst, blas)
-    assert blas[0].device_bytes > before[0] and blas[1].device_bytes == before[1]
+    assert blas[0].device_bytes > before[0] and blas[1].device_bytes > before[1]
+    small_direct = blas[1].Intersect(R.random_rays(4096, (-1, -1, -1), (1, 1, 1), seed=2))         # ... while the small BLAS's OWN queries keep the uploaded nodes
+    blas[1].set_variant(1)
+    assert np.array_equal(small_direct.view(np.uint8), blas[1].Intersect(R.random_rays(4096, (-1, -1, -1), (1, 1, 1), seed=2)).view(np.uint8))
+    blas[1].set_variant(0)
     rays = np.concatenate([R.random_rays(60_000, (-2, -2, -2), (9, 9, 9), seed=4), R.primary(R.camera((-3.0, 4.0, -5.0), (0.5, -0.2, 0.84), 256, 256, 1, 1))])
     want = oracle_tlas(oracle, tlas, blas, rays)
     through_copies = tlas.Intersect(rays.copy())

@@ -201,6 +201,7 @@ struct tbvh_scene {
     // the context's scene table; TLASes over this BLAS enter it through the copies as well (capi_scene.hip: blasView).
     tbvh_scene* wide = nullptr;
     bool wideTried = false;      // the copy was made, or found unwanted / impossible: launchQuery does not try again
+    bool wideTlasOnly = false;   // the copy is a small one made for the TLASes over this scene: the scene's own queries keep the uploaded nodes
     // ... and a 4-wide one (BVH4_GPU format) of a BVH_GPU / BVH8_CWBVH BLAS, made when a TLAS is uploaded over it: under a TLAS k_tlas4 is the fastest kernel for
     // closest hits (1000 instances, camera rays: 4650 MRays/s against 4190 through BVH8_CWBVH BLASes and 3840 through BVH_GPU ones), k_tlas8 for any-hit queries
     tbvh_scene* wide4 = nullptr;

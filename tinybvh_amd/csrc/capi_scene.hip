@@ -84,6 +84,8 @@ tbvh_scene* newScene(tbvh_context* c, int layout) {
     return s;
 }
 
+constexpr uint64_t kWideCopyMin = 32768;   // blob entries from which a scene's own queries go through its 8-wide copy (TBVH_WIDE_COPY_MIN)
+
 void freeWideCopy(tbvh_scene* s) {
     if (!s || !s->wide) return;
     tbvh_scene* w = s->wide;
@@ -111,9 +113,11 @@ void freeWide4Copy(tbvh_scene* s) {
 static int convertDeviceImpl(tbvh_context* c, int layout, const float4* dN2, uint64_t nNodes2, const uint32_t* dIdx, uint64_t nIdx, const float4* dV, uint64_t nTris, tbvh_scene** out);
 // One copy of scene s in the `target` layout (BVH8_CWBVH from a BVH_GPU / BVH4_GPU scene, BVH4_GPU from a BVH_GPU / BVH8_CWBVH one), or nullptr (too small,
 // too large, out of memory: never an error of the caller's operation).  Not listed in the context's scene table; shares the owner's opacity maps.
-static tbvh_scene* buildCopy(tbvh_scene* s, int target) {
+// forTlas: the copy is wanted by a TLAS over s — there ONE kernel class for all BLASes is worth more than any single BLAS's speed (a BLAS without the copy
+// puts the whole TLAS on the flat loop), so small blobs get one too (from 64 entries; TBVH_WIDE_COPY_MIN still rules when set).
+static tbvh_scene* buildCopy(tbvh_scene* s, int target, bool forTlas) {
     tbvh_context* c = s->ctx;
-    uint64_t minIdx = 32768;
+    uint64_t minIdx = forTlas ? 64 : kWideCopyMin;
     if (const char* e = getenv("TBVH_WIDE_COPY_MIN")) { const long long v = atoll(e); minIdx = v <= 0 ? ~0ull : (uint64_t)v; }
     std::vector<Node2> n2;
     std::vector<Vec4> blob, recs;
@@ -168,7 +172,12 @@ static int makeWideCopyImpl(tbvh_scene* s) {
     freeWideCopy(s);
     s->wideTried = true;
     if (s->isTlas || (s->layout != TBVH_LAYOUT_BVH_GPU && s->layout != TBVH_LAYOUT_BVH4_GPU)) return 0;
-    if (tbvh_scene* w = buildCopy(s, TBVH_LAYOUT_CWBVH)) { s->wide = w; s->bytes += w->bytes; }
+    if (tbvh_scene* w = buildCopy(s, TBVH_LAYOUT_CWBVH, !s->usedBy.empty())) {
+        s->wide = w; s->bytes += w->bytes;
+        // a copy below the size at which the scene's OWN queries gain from it (made for the TLASes over the scene): those queries keep the uploaded nodes
+        const uint64_t entries = s->layout == TBVH_LAYOUT_BVH_GPU ? s->nTriBlocks / 3 : w->nTriBlocks / 3;
+        s->wideTlasOnly = entries < kWideCopyMin && !getenv("TBVH_WIDE_COPY_MIN");
+    }
     return 0;
 }
 
@@ -176,7 +185,7 @@ static int makeWide4CopyImpl(tbvh_scene* s) {
     freeWide4Copy(s);
     s->wide4Tried = true;
     if (s->isTlas || (s->layout != TBVH_LAYOUT_BVH_GPU && s->layout != TBVH_LAYOUT_CWBVH)) return 0;
-    if (tbvh_scene* w = buildCopy(s, TBVH_LAYOUT_BVH4_GPU)) { s->wide4 = w; s->bytes += w->bytes; }
+    if (tbvh_scene* w = buildCopy(s, TBVH_LAYOUT_BVH4_GPU, true)) { s->wide4 = w; s->bytes += w->bytes; }
     return 0;
 }
 }  // namespace tbvh_capi
