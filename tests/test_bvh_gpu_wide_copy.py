@@ -286,3 +286,38 @@ def test_tlas_closest_hit_queries_enter_cwbvh_blases_through_4_wide_copies(ctx, 
     blas.host = h2
     check(tlas.Intersect(rays.copy()), want)
     tlas.free(); blas.free()
+
+
+def test_an_update_drops_the_copies_until_the_blob_has_settled(ctx, oracle):
+    """tbvh_update_* is the reference's animation flow (BVH::Refit + ConvertFrom on the host, the blob re-uploaded every frame): making the copies again costs more
+    than a frame's queries gain, so an update drops them and they come back after four queries without another update — and an update that arrives soon
+    after they came back makes the scene wait four times as long (capi_internal.h: tbvh_scene::pendingCopies).  Results are right throughout."""
+    verts = scenes.blob(40_000, seed=21)
+    sc = tb.BVH_GPU(ctx).Build(verts)
+    h = sc.host
+    plain = h.blob(0, np.uint32, 16).shape[0] * 64 + h.blob(1, np.uint32, 1).shape[0] * 48
+    lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+    rays = R.random_rays(20_000, lo - 0.1, hi + 0.1, seed=3)
+    want = oracle.bvh2_intersect(h.bvh2_nodes(), h.bvh2_prim_idx(), verts, rays)
+
+    def ask():
+        c = compare_hits(sc.Intersect(rays.copy()), want)
+        assert c["hitmiss"] == 0 and c["prim_real"] == 0 and c["t_bad"] == 0, c
+
+    ask()
+    assert sc.device_bytes > plain                        # the 8-wide copy of the first query
+    nodes, idx = h.blob(0, np.uint32, 16), h.blob(1, np.uint32, 1).reshape(-1)
+    sc.Update(nodes, idx, verts)
+    assert sc.device_bytes == plain                       # dropped
+    for k in range(3):
+        ask()
+        assert sc.device_bytes == plain, k
+    ask()
+    assert sc.device_bytes > plain                        # back with the fourth query
+    sc.Update(nodes, idx, verts)                          # again, soon after: the scene now waits for 16 queries
+    for k in range(15):
+        ask()
+        assert sc.device_bytes == plain, k
+    ask()
+    assert sc.device_bytes > plain
+    sc.free()

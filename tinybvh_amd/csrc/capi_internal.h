@@ -202,6 +202,14 @@ struct tbvh_scene {
     tbvh_scene* wide = nullptr;
     bool wideTried = false;      // the copy was made, or found unwanted / impossible: launchQuery does not try again
     bool wideTlasOnly = false;   // the copy is a small one made for the TLASes over this scene: the scene's own queries keep the uploaded nodes
+    // tbvh_update_* (the reference's animation flow: BVH::Refit + ConvertFrom on the host, the blob re-uploaded) DROPS the copies — making them again costs
+    // milliseconds, more than a frame's queries gain — and they come back once the scene has answered `recopyAfter` queries without another update; an
+    // update that arrives soon after they came back quadruples that number (a blob that keeps changing ends up without copies, a blob updated once has
+    // them again after four queries).  tbvh_refit keeps the copies: it refits them in place.
+    uint8_t pendingCopies = 0;           // bit 0: the 8-wide copy, bit 1: the 4-wide one — dropped by an update, to be made again
+    uint32_t recopyAfter = 4, queriesSinceUpdate = 0;
+    bool remadeSinceUpdate = false;
+    bool blasRecopyPending = false;      // TLAS: some BLAS has pendingCopies
     // ... and a 4-wide one (BVH4_GPU format) of a BVH_GPU / BVH8_CWBVH BLAS, made when a TLAS is uploaded over it: under a TLAS k_tlas4 is the fastest kernel for
     // closest hits (1000 instances, camera rays: 4650 MRays/s against 4190 through BVH8_CWBVH BLASes and 3840 through BVH_GPU ones), k_tlas8 for any-hit queries
     tbvh_scene* wide4 = nullptr;
@@ -303,6 +311,8 @@ int prepareIncoherentCopies(tbvh_scene* s);
 void freeWideCopy(tbvh_scene* s);
 void freeWide4Copy(tbvh_scene* s);
 int makeWide4Copy(tbvh_scene* s);   // the 4-wide copy of a BVH_GPU / BVH8_CWBVH BLAS (closest-hit queries of the TLASes over it)
-int reclassifyTlas(tbvh_scene* t);   // (capi_scene.hip) descriptors, kernel class and wide trees of a TLAS from its BLASes as they are now
+int reclassifyTlas(tbvh_scene* t);
+void dropCopiesAfterUpdate(tbvh_scene* s);   // (capi_scene.hip) tbvh_update_*: see tbvh_scene::pendingCopies
+void countQueryForRecopy(tbvh_scene* s);     // ... and the query side of it (launchQuery)   // (capi_scene.hip) descriptors, kernel class and wide trees of a TLAS from its BLASes as they are now
 int makeWideCopy(tbvh_scene* s);   // (lazily, from launchQuery) the 8-wide copy of a BVH_GPU / BVH4_GPU scene   // (lazily, from launchQuery) hybrid node copy + 64-byte triangle records for incoherent batches
 }  // namespace tbvh_capi

@@ -425,6 +425,40 @@ int makeWide4Copy(tbvh_scene* s) {
     }
     return r;
 }
+
+void dropCopiesAfterUpdate(tbvh_scene* s) {
+    const uint8_t had = (uint8_t)((s->wide ? 1 : 0) | (s->wide4 ? 2 : 0) | s->pendingCopies);
+    if (!had) return;
+    if (s->remadeSinceUpdate && s->recopyAfter < (1u << 20)) s->recopyAfter *= 4u;   // updated again soon after the copies came back: a blob that keeps changing
+    s->remadeSinceUpdate = false;
+    hipStreamSynchronize(s->ctx->stream);
+    freeWideCopy(s); freeWide4Copy(s);
+    s->pendingCopies = had; s->queriesSinceUpdate = 0;
+    for (size_t i = 0; i < s->usedBy.size(); i++) {
+        bool seen = false;
+        for (size_t k = 0; k < i; k++) seen |= s->usedBy[k] == s->usedBy[i];
+        if (!seen) { (void)reclassifyTlas(s->usedBy[i]); s->usedBy[i]->blasRecopyPending = true; }   // (the TLASes enter this BLAS through its own nodes meanwhile)
+    }
+}
+
+static void remakePendingCopies(tbvh_scene* b) {
+    const uint8_t kinds = b->pendingCopies;
+    b->pendingCopies = 0; b->remadeSinceUpdate = true;
+    if (kinds & 1u) makeWideCopy(b);
+    if (kinds & 2u) makeWide4Copy(b);
+}
+
+void countQueryForRecopy(tbvh_scene* s) {
+    if (!s->isTlas) {
+        if (s->pendingCopies && ++s->queriesSinceUpdate >= s->recopyAfter) remakePendingCopies(s);
+        return;
+    }
+    if (!s->blasRecopyPending) return;
+    bool still = false;
+    for (tbvh_scene* b : s->blasList)
+        if (b->pendingCopies) { if (++b->queriesSinceUpdate >= b->recopyAfter) remakePendingCopies(b); else still = true; }
+    s->blasRecopyPending = still;
+}
 }  // namespace tbvh_capi
 }  // extern "C++"
 
@@ -479,8 +513,7 @@ int tbvh_update_bvh_gpu(tbvh_scene* s, const void* nodes64, uint64_t nNodes, con
     if (dVerts) hipFree(dVerts);
     if (e != hipSuccess) return fail(TBVH_E_HIP, "tbvh_update_bvh_gpu: %s", hipGetErrorString(e));
     s->nNodeBlocks = nNodes * 4; s->nTriBlocks = nIdx * 3;
-    if (s->wide) makeWideCopy(s);   // (the tree may have changed: collapsed again)
-    if (s->wide4) makeWide4Copy(s);
+    dropCopiesAfterUpdate(s);   // (the copies are of the old tree: they come back once the blob has settled — tbvh_scene::pendingCopies)
     return 0;
 }
 
@@ -495,7 +528,7 @@ int tbvh_update_bvh4_gpu(tbvh_scene* s, const void* blocks16, uint64_t nBlocks) 
     s->nNodeBlocks = nBlocks;
     s->b4Levels.clear();   // (the node list of a device refit is rebuilt by the next tbvh_refit)
     if (s->refitScratch) { hipFree(s->refitScratch); s->refitScratch = nullptr; }
-    if (s->wide) makeWideCopy(s);   // (the tree may have changed: decoded and collapsed again)
+    dropCopiesAfterUpdate(s);   // (the copy is of the old tree: it comes back once the blob has settled — tbvh_scene::pendingCopies)
     return 0;
 }
 
@@ -535,11 +568,11 @@ static int updateCwbvhImpl(tbvh_scene* s, const void* nodes16, uint64_t nNodeBlo
 }
 
 int tbvh_update_cwbvh(tbvh_scene* s, const void* nodes16, uint64_t nNodeBlocks, const void* tris16, uint64_t nTriBlocks) {
-    const bool had4 = s && !s->isTlas && s->wide4 != nullptr;
-    if (had4) { TBVH_LOCK(s->ctx); hipSetDevice(s->ctx->device); hipStreamSynchronize(s->ctx->stream); freeWide4Copy(s); }   // (the 4-wide copy TLASes enter this BLAS through: made again below)
-    const int r = updateCwbvhImpl(s, nodes16, nNodeBlocks, tris16, nTriBlocks);
-    if (had4) { TBVH_ENTER(s->ctx); makeWide4Copy(s); }   // (also after a refused update: the TLASes over the BLAS need their descriptors back)
-    return r;
+    if (s && !s->isTlas && (s->wide4 || s->pendingCopies)) {   // the 4-wide copy TLASes enter this BLAS through is of the old tree (also if the update is refused: harmless)
+        TBVH_ENTER(s->ctx);
+        dropCopiesAfterUpdate(s);
+    }
+    return updateCwbvhImpl(s, nodes16, nNodeBlocks, tris16, nTriBlocks);
 }
 
 namespace {
