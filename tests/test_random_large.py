@@ -320,6 +320,35 @@ def test_random_large_tlas(ctx, oracle, seed):
     assert np.array_equal(first[idx]["inst"][same], want["inst"][same])
     occ = tlas.IsOccluded(rays.copy())
     assert int((occ[idx].astype(bool) != (want["t"] < 1e30)).sum()) <= 2, (seed, layouts, side, n)
+    # one BLAS is animated: a device refit (the copies the TLAS enters it through are refitted in place), then the host flow — the blob rebuilt and
+    # re-uploaded (the copies are dropped and come back after four queries: every one of six queries must be right)
+    from test_refit_device import deform
+    k = int(rng.integers(0, n_blas))
+    moved = deform(meshes[k], 0.01, seed=int(rng.integers(1, 1 << 20)))
+    blas[k].Refit(moved)
+    blas[k].host = tb.HostBVH(moved, layouts[k])
+    want2 = oracle_tlas(oracle, tlas, blas, rays[idx])
+
+    def right(got, wanted, what):
+        c = compare_hits(got[idx], wanted)
+        assert c["hitmiss"] <= 1 and c["prim_real"] <= 1 and c["t_bad"] == 0 and c["uv_bad"] == 0 and c["tie"] == 0 and c["onsurf"] <= 4, (seed, layouts, side, n, what, c)
+
+    right(tlas.Intersect(rays.copy()), want2, "refit")
+    h0 = tb.HostBVH(meshes[k], layouts[k])
+    try:
+        if layouts[k] == tb.LAYOUT_BVH_GPU:
+            blas[k].Update(h0.blob(0, np.uint32, 16), h0.blob(1, np.uint32, 1), meshes[k])
+        elif layouts[k] == tb.LAYOUT_BVH4_GPU:
+            blas[k].Update(h0.blob(0, np.uint32, 4))
+        else:
+            blas[k].Update(h0.blob(0, np.uint32, 4), h0.blob(1, np.uint32, 4))
+        blas[k].host = h0
+        for q in range(6):
+            right(tlas.Intersect(rays.copy()), want, ("update", q))
+        assert int((tlas.IsOccluded(rays.copy())[idx].astype(bool) != (want["t"] < 1e30)).sum()) <= 2
+    except tb.TbvhError as e:
+        assert "larger than the one uploaded" in str(e)      # (cannot happen: the blob is the one first uploaded)
+        raise
     tlas.free()
     for b in blas:
         b.free()
