@@ -354,10 +354,10 @@ int tlasCopy(tbvh_scene* s, const void* nodes64, uint64_t nNodes, const uint32_t
 
 extern "C++" {
 namespace tbvh_capi {
-// What a TLAS traverses for BLAS b: a BVH_GPU BLAS with an 8-wide copy is entered through the copy (round 6: 1000 instances of a 100 k-triangle BLAS,
-// k_tlas8 on the copies against k_tlas2 on the uploaded nodes: camera rays +5 %, shadow rays +47 %, random rays +16 %); BVH4_GPU BLASes keep their own
-// stream for closest hits (k_tlas4 is the fastest two-level kernel there) and are entered through their copies by any-hit queries; tbvh_set_variant(blas, 1)
-// pins the uploaded nodes.
+// What a TLAS traverses for BLAS b, by the kind of query (round 6; 1000 instances of a 100 k-triangle BLAS, camera / shadow / random MRays/s in DESIGN.md par. 3.5):
+// closest hits through a 4-wide stream — a BVH4_GPU BLAS's own, the 4-wide copy of a BVH_GPU / BVH8_CWBVH one (k_tlas4 is the fastest two-level kernel for
+// closest hits) —, any-hit queries through 8-wide nodes — a BVH8_CWBVH BLAS's own, the 8-wide copy of the others (k_tlas8 is the fastest there).  A forced
+// variant on the BLAS (tbvh_set_variant) pins the uploaded nodes; allow4 = false: the closest-hit view without the 4-wide copies (reclassifyTlas's fallback).
 static const tbvh_scene* blasView(const tbvh_scene* b, bool any, bool allow4 = true) {
     if (b->variant != 0) return b;
     if (!any && allow4 && b->wide4 && (b->layout == TBVH_LAYOUT_BVH_GPU || b->layout == TBVH_LAYOUT_CWBVH)) return b->wide4;   // closest hits: the 4-wide kernel
@@ -365,10 +365,9 @@ static const tbvh_scene* blasView(const tbvh_scene* b, bool any, bool allow4 = t
     return viaCopy ? b->wide : b;
 }
 
-// The BLAS descriptors of TLAS t and the class of two-level kernel that serves it, from its BLASes as they are NOW (their 8-wide copies come and go:
-// tbvh_update_bvh_gpu makes a new one, tbvh_set_variant switches between copy and nodes); builds the wide TLAS(es) those kernels walk.
-// Closest-hit and any-hit queries are classified separately: BVH4_GPU BLASes are entered through their own stream by Intersect (k_tlas4: the fastest
-// two-level kernel for closest hits) and through their 8-wide copies by IsOccluded (k_tlas8: 1000 instances, shadow rays 4460 -> 5700 MRays/s).
+// The BLAS descriptors of TLAS t and the class of two-level kernel that serves each kind of query, from its BLASes as they are NOW (their copies come and
+// go: a tbvh_update_* drops them, queries bring them back, tbvh_set_variant switches between copy and nodes); builds the wide TLAS(es) those kernels walk.
+// With every BLAS copied, BLASes of different layouts under one TLAS share one kernel class per kind of query instead of the flat three-state loop.
 int reclassifyTlas(tbvh_scene* t) {
     const size_t nBlas = t->blasList.size();
     std::vector<BlasDesc> desc[2] = {std::vector<BlasDesc>(nBlas), std::vector<BlasDesc>(nBlas)};
