@@ -330,8 +330,75 @@ def tlas_child(a, tb, R, scenes):
                     "ref_kernel": "traverse_tlas (traverse_tlas.cl:13-107) via wavefront2.cl Extend, BVH8_CWBVH BLAS (the configuration of tiny_bvh_gpu2.cpp), same TLAS / instances / rays"})
     except Exception as e:
         out["ref_opencl_error"] = repr(e)[:300]
+    try:
+        out["mixed_layouts"] = tlas_mixed_layouts(tb, R, scenes, ctx)
+    except Exception as e:
+        out["mixed_layouts"] = {"error": repr(e)[:300]}
     print(json.dumps(out), flush=True)
     ctx.close()
+
+
+def tlas_mixed_layouts(tb, R, scenes, ctx):
+    """BLASes of three layouts and sizes under ONE TLAS (BVH_GPU 100 k, BVH8_CWBVH 20 k, BVH4_GPU 5 k triangles; 1000 instances, the reference's traverse_tlas.cl:50-72
+    allows two BLAS types): with the library's copies every BLAS is entered through a 4-wide form by closest-hit queries and an 8-wide one by any-hit queries —
+    one kernel class per kind of query —; with TBVH_WIDE_COPY_MIN=0 (no copies) the TLAS runs the flat three-state loop."""
+    def unit(m):
+        m = m.copy(); m[:, :3] -= 0.5 * (m[:, :3].min(0) + m[:, :3].max(0)); m[:, :3] *= np.float32(1.6 / float((m[:, :3].max(0) - m[:, :3].min(0)).max()))
+        return np.ascontiguousarray(m)
+    meshes = [unit(scenes.blob(100_000, seed=3)), unit(scenes.blob(20_000, seed=4)), unit(scenes.blob(5_000, seed=5))]
+    side = 10
+    rng = np.random.default_rng(3)
+    T = np.zeros((side ** 3, 4, 4), np.float32)
+    g = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    ang = rng.random(side ** 3).astype(np.float32) * 6.28
+    c_, s_ = np.cos(ang), np.sin(ang)
+    T[:, 0, 0] = c_ * 0.5; T[:, 0, 2] = s_ * 0.5; T[:, 1, 1] = 0.5; T[:, 2, 0] = -s_ * 0.5; T[:, 2, 2] = c_ * 0.5; T[:, 3, 3] = 1
+    T[:, :3, 3] = g * 2.0
+    inst = tb.make_instances(T, (np.arange(side ** 3) % 3).astype(np.uint32))
+    W_, H_ = 2560, 1600
+    nt = W_ * H_
+    cam = R.camera((-12.0, 16.0, -18.0), (0.62, -0.38, 0.68), W_, H_, 1, 1)
+    d = ctx.malloc(nt * 64); d_sh = ctx.malloc(nt * 64); d_occ = ctx.malloc(nt)
+    rr = R.random_rays(1 << 22, (-1.0, -1.0, -1.0), (20.0, 20.0, 20.0), seed=9)
+    d_r = ctx.malloc(rr.shape[0] * 64)
+    res = {"blas": "BVH_GPU 100 k + BVH8_CWBVH 20 k + BVH4_GPU 5 k triangles (procedural blobs), 1000 instances", "camera_rays": nt, "random_rays": int(rr.shape[0])}
+    old = os.environ.get("TBVH_WIDE_COPY_MIN")
+    try:
+        for label, env in (("with_copies", None), ("without_copies", "0")):
+            if env is None:
+                os.environ.pop("TBVH_WIDE_COPY_MIN", None)
+            else:
+                os.environ["TBVH_WIDE_COPY_MIN"] = env
+            blas = [tb.BVH_GPU(ctx).Build(meshes[0]), tb.BVH8_CWBVH(ctx).Build(meshes[1]), tb.BVH4_GPU(ctx).Build(meshes[2])]
+            tlas = tb.TLAS(ctx).Build(inst, blas)
+
+            def timed(fn, passes=6):
+                ms = []
+                for p in range(passes):
+                    fn(); ctx.synchronize()
+                    if p:
+                        ms.append(ctx.time_last_ms())
+                return float(np.median(ms))
+            ctx.generate_primary(cam, d, 0, nt)
+            ms_cam = timed(lambda: tlas.intersect_device_fresh(d, nt, 1e30))
+            rec = np.zeros(nt, tb.RAY_DTYPE); ctx.from_device(rec, d)
+            ctx.generate_shadow(d, d_sh, nt, (10.0, 40.0, 10.0), 1e-4)
+            ms_sh = timed(lambda: tlas.occluded_device(d_sh, nt, d_occ))
+            ctx.to_device(d_r, rr)
+            ms_r = timed(lambda: tlas.intersect_device_fresh(d_r, rr.shape[0], 1e30))
+            res[label] = {"camera_mrays": nt / ms_cam / 1e3, "shadow_mrays": nt / ms_sh / 1e3, "random_mrays": rr.shape[0] / ms_r / 1e3,
+                          "hits": int((rec["t"] < 1e30).sum()), "prim_checksum": int(rec["prim"][rec["t"] < 1e30].astype(np.uint64).sum())}
+            tlas.free()
+            for b in blas:
+                b.free()
+    finally:
+        if old is None:
+            os.environ.pop("TBVH_WIDE_COPY_MIN", None)
+        else:
+            os.environ["TBVH_WIDE_COPY_MIN"] = old
+        for p_ in (d, d_sh, d_occ, d_r):
+            ctx.free(p_)
+    return res
 
 
 def tlas_leg(a, log, valu_ceiling):
