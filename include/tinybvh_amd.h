@@ -136,7 +136,8 @@ int tbvh_update_tlas(tbvh_scene* tlas, const void* tlas_nodes64, uint64_t n_node
  * Validated like an upload (TBVH_E_FORMAT).  The library's derived copies follow: re-derived on the device when the tree kept its shape,
  * dropped and rebuilt as after an upload when it did not; the copies in ANOTHER layout (the 8-wide copy of a BVH_GPU / BVH4_GPU scene, the 4- and
  * 8-wide forms TLASes enter their BLASes through) are dropped and come back after four queries without another update (a blob re-uploaded every
- * frame is traced as uploaded: making them again would cost more than a frame's queries gain; tbvh_refit keeps them).  Synchronous (the caller's arrays may be reused on return).  A TLAS over the BLAS
+ * frame is traced as uploaded: making them again would cost more than a frame's queries gain; tbvh_refit refits them in place, unless fewer than 8 M rays were traced
+ * since the previous refit: then it drops them the same way).  Synchronous (the caller's arrays may be reused on return).  A TLAS over the BLAS
  * sees the new contents at once, but its instance boxes are its own: when the geometry left its old bounds, update or rebuild the TLAS as the
  * reference's frame loop does (tbvh_update_tlas, tbvh_rebuild_tlas_device with the new BLAS bounds). */
 int tbvh_update_bvh_gpu(tbvh_scene* scene, const void* nodes64, uint64_t n_nodes, const uint32_t* prim_idx, uint64_t n_idx, const void* verts16, uint64_t n_tris);

@@ -321,3 +321,32 @@ def test_an_update_drops_the_copies_until_the_blob_has_settled(ctx, oracle):
     ask()
     assert sc.device_bytes > plain
     sc.free()
+
+
+def test_a_refit_keeps_the_copies_only_if_enough_rays_were_traced_since_the_last_one(ctx):
+    """tbvh_refit refits a scene's copies in place (0.3-0.5 ms each per 100 k triangles): that pays from about 8 M rays per refit on.  A mesh refitted again
+    after fewer rays loses its copies (they come back like after an update); one that traces a frame's worth of rays in between keeps them."""
+    verts = scenes.blob(40_000, seed=23)
+    sc = tb.BVH_GPU(ctx).Build(verts)
+    h = sc.host
+    plain = h.blob(0, np.uint32, 16).shape[0] * 64 + h.blob(1, np.uint32, 1).shape[0] * 48
+    lo, hi = verts[:, :3].min(0), verts[:, :3].max(0)
+    few = R.random_rays(4096, lo - 0.1, hi + 0.1, seed=3)
+    n_many = 9 << 20
+    d = ctx.malloc(n_many * 64)
+    cam = R.camera(tuple(hi + (hi - lo)), tuple(-(hi - lo) / np.linalg.norm(hi - lo)), 3072, 3072, 1, 1)
+    ctx.generate_primary(cam, d, 0, n_many)
+    sc.Intersect(few.copy())
+    assert sc.device_bytes > plain
+    sc.Refit(verts)                                        # the first refit: nothing to compare with, the copy is refitted
+    assert sc.device_bytes > plain
+    sc.intersect_device_fresh(d, n_many, 1e30)             # 9.4 M rays
+    sc.Refit(verts)
+    assert sc.device_bytes > plain                         # kept
+    sc.Intersect(few.copy())
+    sc.Refit(verts)                                        # 4096 rays since the last refit
+    assert sc.device_bytes == plain                        # dropped
+    for k in range(4):
+        sc.Intersect(few.copy())
+    assert sc.device_bytes > plain                         # ... and back after four queries
+    ctx.free(d); sc.free()

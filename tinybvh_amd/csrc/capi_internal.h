@@ -210,6 +210,11 @@ struct tbvh_scene {
     uint32_t recopyAfter = 4, queriesSinceUpdate = 0;
     bool remadeSinceUpdate = false;
     bool blasRecopyPending = false;      // TLAS: some BLAS has pendingCopies
+    // tbvh_refit refits the copies in place (0.3-0.5 ms each for 100 k triangles) — unless fewer than kRefitKeepRays rays were traced through the scene (or the
+    // TLASes over it) since the previous refit: then the copies cost a frame more than they save and are dropped like after an update
+    uint64_t raysTraced = 0;             // rays of every query launched on this scene (a TLAS counts its own)
+    uint64_t raysAtRefit = 0;            // raysTraced of this scene + of the TLASes over it, at the previous tbvh_refit
+    bool refitSeen = false;
     // ... and a 4-wide one (BVH4_GPU format) of a BVH_GPU / BVH8_CWBVH BLAS, made when a TLAS is uploaded over it: under a TLAS k_tlas4 is the fastest kernel for
     // closest hits (1000 instances, camera rays: 4650 MRays/s against 4190 through BVH8_CWBVH BLASes and 3840 through BVH_GPU ones), k_tlas8 for any-hit queries
     tbvh_scene* wide4 = nullptr;

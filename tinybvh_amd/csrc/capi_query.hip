@@ -329,6 +329,7 @@ int launchQuery(tbvh_scene* s, RayRec* d_rays, uint64_t n, uint8_t* d_occ, bool 
     tbvh_context* c = s->ctx;
     TBVH_ENTER(c);
     if (n == 0) return 0;
+    s->raysTraced += n;   // (what tbvh_refit weighs the refit of a scene's copies against)
     if (s->pendingCopies || s->blasRecopyPending) countQueryForRecopy(s);   // copies dropped by a tbvh_update_* come back once the blob has settled
     if (!s->wideTried && !s->isTlas && s->variant == 0 && (nDev || n >= 1024u) && (s->layout == TBVH_LAYOUT_BVH_GPU || s->layout == TBVH_LAYOUT_BVH4_GPU)) makeWideCopy(s);   // first query of this scene (not part of its time)
     if (s->wide && s->variant == 0 && !s->wideTlasOnly) return launchQuery(s->wide, d_rays, n, d_occ, fresh, freshTmax, nDev);   // BVH_GPU with an 8-wide copy (capi_scene.hip: makeWideCopy)

@@ -781,6 +781,23 @@ int tbvh_scene_download(tbvh_scene* s, int which, void* dst, uint64_t capBytes, 
     return 0;
 }
 
+namespace {
+constexpr uint64_t kRefitKeepRays = 8ull << 20;   // a copy's refit (0.3-0.5 ms per 100 k triangles) pays from about this many rays per refit on (0.04-0.08 ns gained per ray)
+// a mesh refitted every frame with few rays traced in between: the copies are dropped (they come back like after an update: tbvh_scene::pendingCopies)
+bool refitDropsCopies(tbvh_scene* s) {
+    uint64_t total = s->raysTraced;
+    for (size_t i = 0; i < s->usedBy.size(); i++) {
+        bool seen = false;
+        for (size_t k = 0; k < i; k++) seen |= s->usedBy[k] == s->usedBy[i];
+        if (!seen) total += s->usedBy[i]->raysTraced;
+    }
+    const bool drop = (s->wide || s->wide4) && s->refitSeen && total - s->raysAtRefit < kRefitKeepRays;
+    s->refitSeen = true; s->raysAtRefit = total;
+    if (drop) dropCopiesAfterUpdate(s);
+    return drop;
+}
+}  // namespace
+
 int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice) {
     if (!s || !verts16 || !nTris) return fail(TBVH_E_INVALID, "tbvh_refit: null/empty argument");
     if (s->isTlas) return fail(TBVH_E_INVALID, "tbvh_refit: a TLAS is rebuilt with tbvh_rebuild_tlas_device / tbvh_update_tlas");
@@ -808,6 +825,7 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
         HIP_TRY(timedBegin(c));
         HIP_TRY(run_refit_bvh4(s->nodes, s->nNodeBlocks, dv4, nTris, items, capNodes, counter, childBox, s->b4Levels, c->status, c->stream));
         HIP_TRY(timedEnd(c));
+        if (refitDropsCopies(s)) return 0;
         if (s->wide) return tbvh_refit(s->wide, dv4, nTris, 1);   // the 8-wide copy follows
         return 0;
     }
@@ -834,6 +852,7 @@ int tbvh_refit(tbvh_scene* s, const void* verts16, uint64_t nTris, int onDevice)
     if (s->nodes128) launch_cwbvh_pad(s->nodes, s->nodes128, nNodes, c->stream);   // keep the padded copy current
     if (s->nodesHy) launch_cwbvh_derive_hybrid(s->nodes, s->hyPerm, s->nodesHy, nNodes, s->hybridK, (c->embedTris && !(c->expFlags & 8u)) ? s->tris : nullptr, c->stream);
     if (s->tris64) launch_cwbvh_pad_tris(s->tris, s->tris64, s->nTriBlocks / 3, c->stream);
+    if (refitDropsCopies(s)) return 0;
     if (s->wide) if (int r = tbvh_refit(s->wide, dv, nTris, 1)) return r;     // the 8-wide copy follows (same vertices, already on the device)
     if (s->wide4) return tbvh_refit(s->wide4, dv, nTris, 1);                 // ... and the 4-wide one
     return 0;
