@@ -392,3 +392,52 @@ def test_random_large_refit(ctx, oracle, seed):
             assert_real_hits(oracle, v2, rays[idx][diff], got[idx][diff], v2[:, :3].min(0), v2[:, :3].max(0))
         assert int((got["t"] < 1e30).sum()) > n // 50, (seed, name, layout, frame)
     ctx.free(d); sc.free()
+
+
+N_REF_TLAS_SEEDS = int(os.environ.get("TBVH_RANDOM_LARGE_REF_TLAS_SEEDS", "2"))
+
+
+@pytest.mark.parametrize("seed", range(N_REF_TLAS_SEEDS))
+def test_random_large_tlas_of_reference_blobs(ctx, reference, seed):
+    """Two-level scenes whose BLAS blobs the REAL reference built (Build or BuildHQ, any of the three layouts, also mixed under one TLAS) — so the 4-wide copies are
+    decoded from the reference's own BVH8_CWBVH / BVH_GPU encodings (host_builder.cpp: cwbvh_to_bvh2, bvh_gpu_to_bvh2) — against the REAL BVH::IntersectTLAS
+    (tiny_bvh.h:3306-3380) over the same instances: prim and instance exact, t / u / v the reference's bits up to its tie rule and the cull-bound class."""
+    from oracle_lib import RefTlas, compare_with_real_reference
+    from test_tlas import grid_instances
+    rng = np.random.default_rng(21000 + seed)
+    n_blas = int(rng.integers(1, 4))
+    meshes, refs, blas, layouts = [], [], [], []
+    for k in range(n_blas):
+        m = scenes.blob(int(rng.integers(5_000, 60_000)), seed=int(rng.integers(1, 1 << 20))).copy()
+        c = 0.5 * (m[:, :3].min(0) + m[:, :3].max(0)); e = float((m[:, :3].max(0) - m[:, :3].min(0)).max())
+        m[:, :3] = (m[:, :3] - c) * np.float32(1.6 / e)
+        m = np.ascontiguousarray(m)
+        rs = reference.build(m, hq=bool(rng.integers(0, 2)), threaded=True)
+        lay = LAYOUTS[int(rng.integers(0, 3))]
+        if lay == tb.LAYOUT_BVH_GPU:
+            b = tb.BVH_GPU(ctx).Upload(rs.blob(5, 0, np.uint32, 16), rs.blob(5, 1, np.uint32, 1), m)
+        elif lay == tb.LAYOUT_BVH4_GPU:
+            b = tb.BVH4_GPU(ctx).Upload(rs.blob(8, 0, np.uint32, 4))
+        else:
+            b = tb.BVH8_CWBVH(ctx).Upload(rs.blob(10, 0, np.uint32, 4), rs.blob(10, 1, np.uint32, 4))
+        b._bounds = np.concatenate([m[:, :3].min(0), m[:, :3].max(0)]).astype(np.float32)
+        meshes.append(m); refs.append(rs); blas.append(b); layouts.append(lay)
+    side = int(rng.integers(4, 11))
+    inst = grid_instances(side, float(rng.uniform(0.3, 0.7)), int(rng.integers(1, 1 << 20)), n_blas=n_blas)
+    tlas = tb.TLAS(ctx).Build(inst.copy(), blas)
+    rt = RefTlas(reference, inst, refs)
+    lo, hi = np.full(3, -1.0), np.full(3, 2.0 * side - 1.0)
+    n_min = int(rng.choice([500_000, 1_000_000]))
+    rays = camera_rays(rng, lo, hi, n_min) if rng.random() < 0.6 else R.random_rays(n_min, lo - 1, hi + 1, seed=int(rng.integers(1, 1 << 20)))
+    n = rays.shape[0]
+    got = tlas.Intersect(rays.copy())
+    idx = np.arange(int(rng.integers(0, 16)), n, 16)
+    c = compare_with_real_reference(got[idx], rt.intersect(rays[idx]), check_inst=True)
+    assert c["hitmiss"] <= 1 and c["prim_real"] <= 1 and c["t_bad"] == 0 and c["uv_differs"] == 0 and c["farther_by_ulps"] == 0, (seed, layouts, side, n, c)
+    assert c["identical"] >= c["hits"] - c["tie_equal_t"] - c["closer_by_ulps"] - c["onsurf"] - 2, (seed, layouts, c)
+    occ = tlas.IsOccluded(rays.copy())
+    want_hit = rt.intersect(rays[idx])["t"] < 1e30
+    assert int((occ[idx].astype(bool) != want_hit).sum()) <= 2, (seed, layouts, side, n)
+    tlas.free()
+    for b in blas:
+        b.free()
