@@ -274,6 +274,21 @@ void launch_tlas4(bool anyhit, int variant, const float4* tlas4, const float4* i
     // Register budget of 7 waves per SIMD (72 VGPRs, three spilled dwords) on 28 workgroups per CU: the BLASes of an instanced scene live in the L2s,
     // the loop is latency-bound — 8.3 M camera rays +4 %, 33 M +8 %, random rays +2…5 % over 6 waves; 8 waves (64 VGPRs, eight spilled) lose
     blocks = blocks7;
+#ifdef TBVH_EXPERIMENTS
+    // round 6, late: the phase thresholds once more, now that fused steps and 7 waves per SIMD are in (debug flags bits 16..19 pick a row; camera rays of config 5)
+    switch ((q.flags >> 16) & 15u) {
+    case 1: TBVH_T4(12, 16, 32, 8, 8, false, false, 16, 7, true); return;
+    case 2: TBVH_T4(12, 16, 16, 8, 8, false, false, 16, 7, true); return;
+    case 3: TBVH_T4(12, 16, 24, 4, 4, false, false, 16, 7, true); return;
+    case 4: TBVH_T4(12, 16, 24, 16, 16, false, false, 16, 7, true); return;
+    case 5: TBVH_T4(12, 16, 24, 8, 16, false, false, 16, 7, true); return;
+    case 6: TBVH_T4(12, 16, 24, 16, 8, false, false, 16, 7, true); return;
+    case 7: TBVH_T4(12, 8, 24, 8, 8, false, false, 16, 7, true); return;
+    case 8: TBVH_T4(12, 32, 24, 8, 8, false, false, 16, 7, true); return;
+    case 9: TBVH_T4(12, 16, 40, 8, 8, false, false, 16, 7, true); return;
+    default: break;
+    }
+#endif
     // fused steps (a lane done with its leaves, or entering an instance, takes its node step in the same pass): camera rays +4.5 %, random rays +2.5 %
     if (split_rays_wanted(q)) TBVH_T4(12, 16, 24, 8, 8, false, false, 16, 7, true);
     else TBVH_T4(12, 16, 24, 8, 8, false, false, 0, 7, true);
