@@ -238,3 +238,44 @@ def test_blas_freed_or_remapped_under_a_live_tlas(ctx, oracle):
     check(tlas.Intersect(rays.copy()), want)
     blas._h = C.c_void_p()                                                    # the handle is gone for the wrapper
     tlas.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", [tb.LAYOUT_BVH4_GPU, tb.LAYOUT_CWBVH])
+def test_wide_tlas_built_level_by_level_over_the_chip(ctx, oracle, layout):
+    """TLASes of tens of thousands of instances collapse their wide tree with one launch per level over the whole chip instead of one workgroup
+    (kernels_tlaswide.hip: k_tlas_wide_level; TBVH_TLAS_PAR_MIN = the instance count from which, 16384 by default).  Forced here on 1728 instances
+    (both wide formats), and run at its real size on 35 937: the hit records are the one-workgroup build's, and IntersectTLAS's."""
+    import os
+    from test_tlas import grid_instances, oracle_tlas, check
+    mesh = scenes.blob(3000, seed=4)
+    mesh[:, :3] -= 0.5 * (mesh[:, :3].min(0) + mesh[:, :3].max(0))
+    mesh[:, :3] *= np.float32(1.6 / float((mesh[:, :3].max(0) - mesh[:, :3].min(0)).max()))
+    blas = tb.LAYOUT_CLASSES[layout](ctx).Build(mesh)
+    old = os.environ.get("TBVH_TLAS_PAR_MIN")
+    try:
+        for side, force in ((12, True), (33, False)):
+            inst = grid_instances(side, 0.5, 7)
+            rays = R.random_rays(200_000, (-2, -2, -2), (2.0 * side, 2.0 * side, 2.0 * side), seed=5)
+            os.environ["TBVH_TLAS_PAR_MIN"] = "1000000000"
+            one = tb.TLAS(ctx).Build(inst.copy(), [blas])
+            one.RebuildOnDevice()
+            a = one.Intersect(rays.copy()); oa = one.IsOccluded(rays.copy())
+            if force:
+                os.environ["TBVH_TLAS_PAR_MIN"] = "1"
+            else:
+                os.environ.pop("TBVH_TLAS_PAR_MIN", None)
+            par = tb.TLAS(ctx).Build(inst.copy(), [blas])
+            par.RebuildOnDevice()
+            b = par.Intersect(rays.copy()); ob = par.IsOccluded(rays.copy())
+            assert (a["t"] < 1e30).sum() > 1000
+            assert np.array_equal(a.view(np.uint8), b.view(np.uint8)) and np.array_equal(oa, ob), (side, layout)
+            idx = np.arange(0, rays.shape[0], 8)
+            check(b[idx], oracle_tlas(oracle, par, [blas], rays[idx]))
+            one.free(); par.free()
+    finally:
+        if old is None:
+            os.environ.pop("TBVH_TLAS_PAR_MIN", None)
+        else:
+            os.environ["TBVH_TLAS_PAR_MIN"] = old
+    blas.free()
